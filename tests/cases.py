@@ -1,0 +1,269 @@
+"""Scenario builders and checks shared by the oracle tests (CPU) and the HIP parity tests (GPU).
+
+Every function takes `mk`, a zero-argument factory returning a fresh "world" object exposing
+the reference's process API (oracle.orc.World on the CPU side, subzero_jl_amd.World through the
+C-ABI on the GPU side).  The scenarios and expected values come from tests/golden/*.json, i.e.
+from the reference's own tests.
+"""
+import numpy as np
+
+KIND = {"open": 0, "periodic": 1, "collision": 2, "moving": 3}
+ACTIVE, REMOVE, FUSE = 1, 2, 3
+IDX, FX, FY, PX, PY, TRQ, OVER = range(7)
+
+
+def set_domain(w, kinds, g, topo=None):
+    w.set_domain([KIND[k] for k in kinds], g["x0"], g["xf"], g["y0"], g["yf"])
+    if topo:
+        w.set_topography([np.array(t, float) for t in topo])
+
+
+def set_vel(w, i, vel):
+    for k, v in vel.items():
+        a = w.get(k)
+        a[i] = v
+        w.set(k, a)
+
+
+def closed(c):
+    c = [list(p) for p in c]
+    if c[0] != c[-1]:
+        c.append(list(c[0]))
+    return np.array(c, float)
+
+
+# ------------------------------------------------------------------ floe-floe (test_collisions.jl:39-103)
+def run_floe_floe(mk, G, case):
+    w = mk()
+    set_domain(w, ["open"] * 4, G["grid"])
+    w.add_floe(closed(G["coords"][case["i"]]), G["hmean_floe_floe"])
+    w.add_floe(closed(G["coords"][case["j"]]), G["hmean_floe_floe"])
+    set_vel(w, 0, case["vel_i"]); set_vel(w, 1, case["vel_j"])
+    w.floe_floe_interaction(0, 1, G["dt"], G["max_overlap_floe_floe"])
+    w.calc_torque(0)
+    return w
+
+
+def check_floe_floe(w, case):
+    rows = w.inter(0)
+    _, _, status = w.ids()
+    assert len(rows) == len(case["rows"]), (case["name"], rows)
+    for r, e in zip(rows, case["rows"]):
+        atol = case["atol"]
+        assert r[IDX] == 2
+        assert abs(r[FX] - e["xforce"]) < atol, (case["name"], r[FX], e["xforce"])
+        assert abs(r[FY] - e["yforce"]) < atol, (case["name"], r[FY], e["yforce"])
+        assert abs(r[PX] - e["xpoint"]) < atol and abs(r[PY] - e["ypoint"]) < atol
+        assert abs(r[OVER] - e["overlap"]) < atol
+        assert abs(r[TRQ] - e["torque"]) < atol, (case["name"], r[TRQ], e["torque"])
+    if case["fuse"]:
+        assert status[0] == FUSE and w.fuse()[0] == [1]
+    else:
+        assert status[0] != FUSE and status[1] != FUSE and w.fuse()[0] == []
+
+
+# ------------------------------------------------------------------ floe-boundary (test_collisions.jl:105-188)
+def run_boundary(mk, G, case):
+    B = G["boundary"]
+    w = mk()
+    dom = B[case["domain"]]
+    set_domain(w, dom["kinds"], G["grid"], dom["topography"])
+    w.add_floe(closed(B["coords"][case["floe"]]), B["hmean"])
+    set_vel(w, 0, case["vel"])
+    w.floe_domain_interaction(0, G["dt"], case.get("max_overlap", B["max_overlap"]))
+    return w
+
+
+def check_boundary(w, case):
+    rows = w.inter(0)
+    _, _, status = w.ids()
+    if "rows" in case:
+        assert len(rows) == len(case["rows"]), (case["name"], rows)
+        for r, e in zip(rows, case["rows"]):
+            atol = case["atol"]
+            assert r[IDX] == e["floeidx"]
+            for col, key in ((FX, "xforce"), (FY, "yforce"), (PX, "xpoint"), (PY, "ypoint"), (OVER, "overlap")):
+                assert abs(r[col] - e[key]) < atol, (case["name"], key, r[col], e[key])
+    if case.get("status") == "remove":
+        assert status[0] == REMOVE
+    if "min_rows" in case:
+        assert len(rows) >= case["min_rows"]
+    if "first_row_floeidx" in case:
+        assert rows[0][IDX] == case["first_row_floeidx"]
+        assert rows[0][FX] < 0 and rows[0][FY] < 0
+    if case.get("all_forces_nonpositive"):
+        assert len(rows) >= 1
+        assert np.all(rows[:, FX] <= 0) and np.all(rows[:, FY] <= 0)
+
+
+# ------------------------------------------------------------------ add_ghosts (test_collisions.jl:190-259)
+def run_add_ghosts(mk, G, case):
+    A = G["add_ghosts"]
+    w = mk()
+    set_domain(w, case["kinds"], G["grid"])
+    for c in A["coords"]:
+        w.add_floe(closed(c), A["hmean"])
+    w.add_ghosts()
+    return w
+
+
+def check_add_ghosts(w, G, case):
+    A = G["add_ghosts"]
+    L = G["grid"]["xf"] - G["grid"]["x0"]
+    assert w.M == case["n"]
+    ids, gids, _ = w.ids()
+    assert list(ids) == case["id"] and list(gids) == case["ghost_id"]
+    # ghosts lists are 1-based in the fixture (reference), 0-based in the API
+    assert [[g + 1 for g in gl] for gl in w.ghosts()] == case["ghosts"]
+    cx, cy = w.get("cx"), w.get("cy")
+    for i, (src, sx, sy) in enumerate(case["shifts"]):
+        exp = closed(A["coords"][src]) + np.array([sx * L, sy * L])
+        got = w.ring(i)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (case["name"], i, got, exp)
+    for i in range(len(A["coords"])):   # parents keep their centroid inside the periodic box
+        if case["kinds"][2] == "periodic":
+            assert G["grid"]["x0"] < cx[i] < G["grid"]["xf"]
+        if case["kinds"][0] == "periodic":
+            assert G["grid"]["y0"] < cy[i] < G["grid"]["yf"]
+
+
+# ------------------------------------------------------------------ ghost collisions (test_collisions.jl:260-362)
+def oval_coords(o):
+    th = np.arange(o["nth"]) * (np.pi / 50)
+    return np.stack([o["r"] * np.cos(th) + o["cx"], o["r"] * np.sin(th) + o["cy"]], 1)
+
+
+def periodic_world(mk, G, coords_list, hmean):
+    w = mk()
+    set_domain(w, ["periodic"] * 4, G["grid"])
+    for c in coords_list:
+        w.add_floe(closed(c), hmean)
+    return w
+
+
+def ghost_collision_scenarios(mk, G):
+    """Returns dict name -> (world after timestep_collisions!, reference world or None)."""
+    C = G["ghost_collisions"]; h = C["hmean"]; dt = G["dt"]
+    L = G["grid"]["xf"] - G["grid"]["x0"]
+    tr = lambda c, dx, dy: (closed(c) + np.array([dx, dy]))
+    out = {}
+    # parent-parent (:288-303)
+    a = periodic_world(mk, G, [C["lshape"], oval_coords(C["oval"])], h)
+    a.timestep_collisions(2, dt)
+    b = periodic_world(mk, G, [C["lshape"], oval_coords(C["oval"])], h)
+    b.add_ghosts(); b.timestep_collisions(2, dt)
+    out["parent_parent"] = (b, a)
+    # ghost-ghost (:305-325)
+    t = periodic_world(mk, G, [tr(C["tall_rect"], 0.0, -L), tr(C["long_rect"], L, 0.0)], h)
+    t.timestep_collisions(2, dt)
+    f = periodic_world(mk, G, [C["tall_rect"], C["long_rect"]], h)
+    f.add_ghosts(); f.timestep_collisions(2, dt)
+    out["ghost_ghost"] = (f, t)
+    # parent-ghost (:327-343)
+    up = tr(C["long_rect"], 0.0, C["shifted_up_long_rect_dy"])
+    t = periodic_world(mk, G, [tr(C["tall_rect"], -L, 0.0), up], h)
+    t.timestep_collisions(2, dt)
+    f = periodic_world(mk, G, [C["tall_rect"], up], h)
+    f.add_ghosts(); f.timestep_collisions(2, dt)
+    out["parent_ghost"] = (f, t)
+    # parent and ghosts hitting the same floe (:345-362)
+    f = periodic_world(mk, G, [C["small_corner_rect"], C["large_tri"]], h)
+    f.add_ghosts(); n1 = f.M; f.timestep_collisions(2, dt)
+    out["same_floe_tri"] = (f, n1)
+    f = periodic_world(mk, G, [C["small_corner_rect"], C["south_bound_rect"]], h)
+    f.add_ghosts(); n2 = f.M; f.timestep_collisions(2, dt)
+    out["same_floe_south"] = (f, n2)
+    return out
+
+
+def check_ghost_collisions(sc, exact=True, rtol=0.0):
+    def eq(a, b):
+        if exact:
+            return a == b
+        return abs(a - b) <= rtol * max(abs(a), abs(b), 1e-300)
+
+    b, a = sc["parent_parent"]
+    assert b.M == 8
+    fx, fy, trq = b.get("coll_fx"), b.get("coll_fy"), b.get("coll_trq")
+    afx, afy, atrq = a.get("coll_fx"), a.get("coll_fy"), a.get("coll_trq")
+    assert abs(afx[0]) > 0
+    assert eq(abs(afx[0]), abs(fx[0])) and eq(abs(fx[0]), abs(fx[1]))
+    assert eq(abs(afy[0]), abs(fy[1]))
+    assert eq(atrq[0], trq[0]) and eq(atrq[1], trq[1])
+    assert np.all(fx[2:] == 0) and np.all(fy[2:] == 0) and np.all(trq[2:] == 0)
+
+    f, t = sc["ghost_ghost"]
+    fx, fy, trq = f.get("coll_fx"), f.get("coll_fy"), f.get("coll_trq")
+    tfx, tfy, ttrq = t.get("coll_fx"), t.get("coll_fy"), t.get("coll_trq")
+    assert abs(tfx[0]) > 0 or abs(tfy[0]) > 0
+    for k in (0, 1):
+        assert eq(abs(tfx[0]), abs(fx[k])) and eq(abs(tfy[0]), abs(fy[k]))
+        assert eq(ttrq[k], trq[k])
+    cols = [0, 1, 2, 3, 4, 6]
+    # floe 4 (index 3) is floe 1's ghost, floe 3 (index 2) is floe 2's ghost
+    assert np.array_equal(f.inter(0)[:, cols], f.inter(3)[:, cols])
+    assert np.array_equal(f.inter(1)[:, cols], f.inter(2)[:, cols])
+
+    f, t = sc["parent_ghost"]
+    fx, fy, trq = f.get("coll_fx"), f.get("coll_fy"), f.get("coll_trq")
+    tfx, tfy, ttrq = t.get("coll_fx"), t.get("coll_fy"), t.get("coll_trq")
+    assert abs(tfx[0]) > 0 or abs(tfy[0]) > 0
+    for k in (0, 1):
+        assert eq(abs(tfx[0]), abs(fx[k])) and eq(abs(tfy[0]), abs(fy[k]))
+        assert eq(ttrq[k], trq[k])
+    assert np.array_equal(f.inter(1)[:, cols], f.inter(2)[:, cols])
+    assert len(f.inter(3)) == 0
+
+    f, n = sc["same_floe_tri"]
+    assert n == 5
+    r0, r1 = f.inter(0), f.inter(1)
+    assert len(r0) == 3 and len(r1) == 3
+    assert r0[0, FX] != r0[1, FX] and r0[0, FX] != r0[2, FX]
+    assert r0[0, FY] != r0[1, FY] and r0[0, FY] != r0[2, FY]
+
+    f, n = sc["same_floe_south"]
+    assert n == 6
+    r0, r1 = f.inter(0), f.inter(1)
+    assert len(r0) == 2 and len(r1) == 2
+    assert r0[0, PX] != r0[1, PX] and r0[0, PY] == r0[1, PY]
+
+
+# ------------------------------------------------------------------ forcings (test_coupling.jl:464-639)
+def psi_fields(g):
+    x = np.arange(g["x0"], g["xf"] + g["dx"] / 2, g["dx"])
+    y = np.arange(g["y0"], g["yf"] + g["dy"] / 2, g["dy"])
+    xg, yg = np.meshgrid(x, y)            # [row = y, col = x] like grids_from_lines (output.jl:775-779)
+    psi = 0.5e4 * (np.sin(4 * (np.pi / 4e5) * xg) * np.sin(4 * (np.pi / 4e5) * yg))
+    u = np.zeros_like(xg); v = np.zeros_like(yg)
+    u[1:, :] = -1e-4 * (psi[1:, :] - psi[:-1, :])
+    v[:, 1:] = 1e-4 * (psi[:, 1:] - psi[:, :-1])
+    return u.T.copy(), v.T.copy()         # Ocean(u = u', v = v'): field[ix, iy]
+
+
+def run_forcing(mk, F, case):
+    g = F["grid"]
+    Nx = int(round((g["xf"] - g["x0"]) / g["dx"])); Ny = int(round((g["yf"] - g["y0"]) / g["dy"]))
+    w = mk()
+    set_domain(w, F["domain_kinds"], g)
+    w.set_settings(coupling_dd=case["dd"])
+    w.add_floe(np.array(F["floe"], float), F["height"])
+    w.set_subpoints(0, F["X"], F["Y"])
+    set_vel(w, 0, {"u": case["floe_uv"][0], "v": case["floe_uv"][1]})
+    pu, pv = psi_fields(g)
+
+    def fld(spec):
+        if spec == "psi":
+            return pu, pv
+        return np.full((Nx + 1, Ny + 1), spec[0]), np.full((Nx + 1, Ny + 1), spec[1])
+
+    uo, vo = fld(case["ocean"]); ua, va = fld(case["atmos"])
+    w.set_grid_fields(Nx, Ny, g["x0"], g["xf"], g["y0"], g["yf"], uo, vo, np.zeros((Nx + 1, Ny + 1)), ua, va)
+    w.timestep_coupling()
+    return w
+
+
+def check_forcing(w, case):
+    area = w.get("area")[0]
+    got = (w.get("fxOA")[0] / area, w.get("fyOA")[0] / area, w.get("trqOA")[0] / area)
+    for g, key, atol in zip(got, ("fx", "fy", "trq"), case["atol"]):
+        assert abs(g - case[key]) < atol, (case["name"], key, g, case[key])

@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Regenerates the golden fixtures under tests/golden/.
+
+Run in the authoring container only (it reads /root/reference, which does not exist on the GPU
+box).  The fixtures are DATA: literal inputs and expected outputs transcribed from the
+reference's own known-answer tests, plus the sub-floe points its forcing test loads from a
+data file.  No reference source text is copied.
+
+  collisions.json  <- test/test_physical_processes/test_collisions.jl:43-362 (literal inputs,
+                      MATLAB-derived expected values, tolerances as the reference states them)
+  floe_utils.json  <- test/test_floe_utils.jl:66-71
+  forcings.json    <- test/test_physical_processes/test_coupling.jl:464-639, with the sub-floe
+                      points X, Y decoded from test/inputs/test_mc_points.jld2 (two contiguous
+                      little-endian Float64 datasets of 241 values each inside the JLD2/HDF5
+                      container; located by scanning, since no HDF5 reader exists in the image)
+"""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+Lx = Ly = 1e5
+
+
+def translate(c, dx, dy):
+    return [[p[0] + dx, p[1] + dy] for p in c]
+
+
+def collisions():
+    corner_rect = [[0.0, 2.5e4], [0.0, 2.9e4], [2e4, 2.9e4], [2e4, 2.5e4], [0.0, 2.5e4]]
+    g = {
+        "_source": "test/test_physical_processes/test_collisions.jl",
+        "grid": {"x0": -Lx, "xf": Lx, "y0": -Ly, "yf": Ly},          # :10-12
+        "dt": 10, "hmean_floe_floe": 0.25, "max_overlap_floe_floe": 0.55,   # :3,40-41
+        "coords": {                                                  # :43-48
+            "tri": [[0.0, 0.0], [1e4, 3e4], [2e4, 0.0], [0.0, 0.0]],
+            "corner_rect": corner_rect,
+            "small_shift_corner_rect": translate(corner_rect, 0.5e4, 0.0),
+            "big_shift_corner_rect": translate(corner_rect, 1.9999999e4, 0.0),
+            "middle_rect": [[1.8e4, 2.7e4], [1.8e4, 2.8e4], [2.1e4, 2.8e4], [2.1e4, 2.7e4], [1.8e4, 2.7e4]],
+            "cshape": [[0.5e4, 2.7e4], [0.5e4, 3.5e4], [1.5e4, 3.5e4], [1.5e4, 2.7e4], [1.25e4, 2.7e4],
+                       [1.25e4, 3e4], [1e4, 3e4], [1e4, 2.7e4], [0.5e4, 2.7e4]],
+        },
+        "floe_floe": [
+            {   # :51-62
+                "name": "tri_tip_in_rect", "i": "tri", "j": "corner_rect",
+                "vel_i": {"u": 0.1}, "vel_j": {"v": -0.1},
+                "rows": [{"xforce": -64613382.47, "yforce": -521498991.51, "xpoint": 10000.00,
+                          "ypoint": 26555.55, "overlap": 8000000.0, "torque": 1069710443203.99}],
+                "atol": 1e-2, "fuse": False,
+            },
+            {   # :65-81
+                "name": "cshape_two_regions", "i": "cshape", "j": "corner_rect",
+                "vel_i": {"u": 0.3}, "vel_j": {"v": -0.1},
+                "rows": [
+                    {"xforce": -163013665.41, "yforce": 804819565.60, "xpoint": 7500.00, "ypoint": 28000.00,
+                     "overlap": 10000000.0, "torque": -2439177121266.03},
+                    {"xforce": -81506832.70, "yforce": 402409782.80, "xpoint": 13750.00, "ypoint": 28000.00,
+                     "overlap": 5000000.0, "torque": 1295472581868.05},
+                ],
+                "atol": 1e-2, "fuse": False,
+            },
+            {"name": "fuse_small_shift", "i": "corner_rect", "j": "small_shift_corner_rect",     # :84-89
+             "vel_i": {"v": -0.1}, "vel_j": {"v": -0.1}, "rows": [], "fuse": True},
+            {"name": "fuse_middle_rect", "i": "corner_rect", "j": "middle_rect",                 # :92-96
+             "vel_i": {"v": -0.1}, "vel_j": {}, "rows": [], "fuse": True},
+            {"name": "tiny_overlap_no_force", "i": "big_shift_corner_rect", "j": "corner_rect",  # :99-102
+             "vel_i": {"v": -0.1}, "vel_j": {"v": -0.1}, "rows": [], "fuse": False},
+        ],
+        "boundary": {   # :105-187
+            "hmean": 0.25, "max_overlap": 0.75,
+            # topo_domain: north/south periodic, east collision, west open, one topography element (:30-32)
+            "topo_domain": {"kinds": ["periodic", "periodic", "collision", "open"],
+                            "topography": [[[1e4, 0.0], [0.0, 1e4], [1e4, 2e4], [2e4, 1e4], [1e4, 0.0]]]},
+            "collision_domain": {"kinds": ["collision"] * 4, "topography": []},
+            "coords": {
+                "north": [[5e4, 9.75e4], [5e4, 10.05e4], [7e4, 10.05e4], [7e4, 9.75e4], [5e4, 9.75e4]],
+                "east_small": [[9.5e4, 0.0], [9e4, 0.5e4], [10e4, 2.5e4], [10.05e4, 2e4], [9.5e4, 0.0]],
+                "east_large": [[9e4, -7e4], [9e4, -5e4], [1.4e5, -5e4], [1.4e5, -7e4], [9e4, -7e4]],
+                "west": [[-9.75e4, 7e4], [-9.75e4, 5e4], [-10.05e4, 5e4], [-10.05e4, 7e4], [-9.75e4, 7e4]],
+                "cshape": [[9.5e4, 7e4], [9.5e4, 9e4], [1.05e5, 9e4], [1.05e5, 8.5e4], [9.9e4, 8.5e4],
+                           [9.9e4, 8e4], [1.05e5, 8e4], [1.05e5, 7e4], [9.5e4, 7e4]],
+                "topo_overlap": [[-0.5e4, 0.0], [-0.5e4, 0.75e4], [0.5e4, 0.75e4], [0.5e4, 0.0], [-0.5e4, 0.0]],
+                "corner": [[9.5e4, 7e4], [9e4, 7.5e4], [10e4, 1.05e5], [10.05e4, 9.5e4], [9.5e4, 7e4]],
+            },
+            "cases": [
+                {"name": "east_small", "floe": "east_small", "domain": "topo_domain", "vel": {"u": 0.5, "v": 0.25},   # :125-133
+                 "rows": [{"floeidx": -3, "xforce": -311304795.629, "yforce": -23618874.648,
+                           "overlap": 1704545.454, "xpoint": 100166.666, "ypoint": 21060.606}], "atol": 1e-3},
+                {"name": "cshape_two_regions", "floe": "cshape", "domain": "topo_domain", "vel": {"v": -0.1},        # :136-150
+                 "rows": [{"floeidx": -3, "xforce": -2876118708.17, "yforce": 575223741.63, "xpoint": 102500.0,
+                           "ypoint": 87500.0, "overlap": 25000000.0},
+                          {"floeidx": -3, "xforce": -5752237416.35, "yforce": 1150447483.27, "xpoint": 102500.0,
+                           "ypoint": 75000.0, "overlap": 50000000.0}], "atol": 1e-2},
+                {"name": "east_large_removed", "floe": "east_large", "domain": "topo_domain",                        # :153-157
+                 "vel": {"u": -0.4, "v": 0.2}, "rows": [], "status": "remove"},
+                {"name": "east_large_maxoverlap1", "floe": "east_large", "domain": "topo_domain",                    # :160-164
+                 "vel": {"u": -0.4, "v": 0.2}, "max_overlap": 1.0, "min_rows": 1},
+                {"name": "west_open_removed", "floe": "west", "domain": "topo_domain", "vel": {},                    # :167-169
+                 "rows": [], "status": "remove"},
+                {"name": "north_periodic_noop", "floe": "north", "domain": "topo_domain", "vel": {}, "rows": []},    # :172-174
+                {"name": "topography", "floe": "topo_overlap", "domain": "topo_domain", "vel": {},                   # :177-181
+                 "first_row_floeidx": -5, "first_row_force_negative": True},
+                {"name": "corner_two_walls", "floe": "corner", "domain": "collision_domain", "vel": {},              # :184-187
+                 "all_forces_nonpositive": True},
+            ],
+        },
+        "add_ghosts": {   # :190-258
+            "hmean": 0.5,
+            "coords": [
+                [[9.9e4, 9.9e4], [9.9e4, 1.02e5], [1.02e5, 1.02e5], [1.02e5, 9.9e4], [9.9e4, 9.9e4]],
+                [[-1.01e5, 7e4], [-1.01e5, 8e4], [-8e4, 8e4], [-8e4, 7e4], [-1.01e5, 7e4]],
+                [[-2e4, 9.5e4], [-2e4, 1.1e5], [-1e4, 1.1e5], [-1e4, 9.5e4], [-2e4, 9.5e4]],
+                [[0.0, 0.0], [0.0, 2e4], [2e4, 2e4], [2e4, 0.0], [0.0, 0.0]],
+            ],
+            "cases": [
+                {"name": "open", "kinds": ["open"] * 4, "n": 4, "shifts": [[0, 0, 0], [1, 0, 0], [2, 0, 0], [3, 0, 0]],
+                 "id": [1, 2, 3, 4], "ghost_id": [0, 0, 0, 0], "ghosts": [[], [], [], []]},
+                # shifts: [source coords index, dx/Lbox, dy/Lbox] per floe, Lbox = 2e5
+                {"name": "ew", "kinds": ["open", "open", "periodic", "periodic"], "n": 6,
+                 "shifts": [[0, -1, 0], [1, 0, 0], [2, 0, 0], [3, 0, 0], [0, 0, 0], [1, 1, 0]],
+                 "id": [1, 2, 3, 4, 1, 2], "ghost_id": [0, 0, 0, 0, 1, 1],
+                 "ghosts": [[5], [6], [], [], [], []]},
+                {"name": "ns", "kinds": ["periodic", "periodic", "open", "open"], "n": 6,
+                 "shifts": [[0, 0, -1], [1, 0, 0], [2, 0, -1], [3, 0, 0], [0, 0, 0], [2, 0, 0]],
+                 "id": [1, 2, 3, 4, 1, 3], "ghost_id": [0, 0, 0, 0, 1, 1],
+                 "ghosts": [[5], [], [6], [], [], []]},
+                {"name": "double", "kinds": ["periodic"] * 4, "n": 9,
+                 "shifts": [[0, -1, -1], [1, 0, 0], [2, 0, -1], [3, 0, 0], [0, 0, 0], [1, 1, 0], [0, 0, -1],
+                            [0, -1, 0], [2, 0, 0]],
+                 "id": [1, 2, 3, 4, 1, 2, 1, 1, 3], "ghost_id": [0, 0, 0, 0, 1, 1, 2, 3, 1],
+                 "ghosts": [[5, 7, 8], [6], [9], [], [], [], [], [], []]},
+            ],
+        },
+        "ghost_collisions": {   # :260-362 ; all on the doubly periodic domain, hmean 0.5
+            "hmean": 0.5,
+            "lshape": [[Lx / 2, Ly / 2], [Lx / 2, Ly + 10000], [3 * Lx / 4, Ly + 10000], [3 * Lx / 4, 3 * Ly / 4],
+                       [Lx + 10000, 3 * Ly / 4], [Lx + 10000, Ly / 2]],
+            "oval": {"r": Ly / 4 + 1000, "cx": Lx - 1, "cy": Ly - 1, "nth": 101},   # th = 0:pi/50:2pi
+            "tall_rect": [[5 * Lx / 8 + 1000, 3 * Ly / 4], [5 * Lx / 8 + 1000, 5 * Ly / 4],
+                          [3 * Lx / 4 + 1000, 5 * Ly / 4], [3 * Lx / 4 + 1000, 3 * Ly / 4]],
+            "long_rect": [[-5 * Lx / 4, -7 * Lx / 8], [-5 * Lx / 4, -(3 * Lx / 4 - 1000)],
+                          [-(3 * Lx / 4 - 1000), -(3 * Lx / 4 - 1000)], [-(3 * Lx / 4 - 1000), -7 * Lx / 8]],
+            "shifted_up_long_rect_dy": 1.615 * Ly,
+            "small_corner_rect": [[-1.1e5, -1.1e5], [-1.1e5, -9.5e4], [-9.5e4, -9.5e4], [-9.5e4, -1.1e5], [-1.1e5, -1.1e5]],
+            "large_tri": [[-1e5, -1e5], [-1e5, 1e5], [1e5, -1e5], [-1e5, -1e5]],
+            "south_bound_rect": [[-9.8e4, -1.1e5], [-9.8e4, -9.5e4], [9.8e4, -9.5e4], [9.8e4, -1.1e5], [-9.8e4, -1.1e5]],
+        },
+    }
+    return g
+
+
+def floe_utils():
+    return {
+        "_source": "test/test_floe_utils.jl:66-71",
+        "moment": [
+            {"coords": [[0.0, 1.0], [0.0, 0.0], [1.0, 0.0], [1.0, 1.0], [0.0, 1.0]], "height": 0.25,
+             "expected": 38.333, "atol": 1e-3},
+            {"coords": [[0.0, 6.67], [0.0, 0.0], [6.67, 0.0], [0.0, 6.67]], "height": 0.5,
+             "expected": 50581.145, "atol": 1e-3},
+        ],
+    }
+
+
+def decode_mc_points():
+    b = open(os.path.join(REF, "test/inputs/test_mc_points.jld2"), "rb").read()
+    runs = []
+    for off in range(8):
+        a = np.frombuffer(b[off:off + ((len(b) - off) // 8) * 8], dtype="<f8")
+        ok = np.isfinite(a) & (np.abs(a) > 1e-3) & (np.abs(a) < 1e6)
+        s = None
+        for i, v in enumerate(ok):
+            if v and s is None:
+                s = i
+            if not v and s is not None:
+                if i - s > 20:
+                    runs.append((off + 8 * s, i - s))
+                s = None
+        if s is not None and len(ok) - s > 20:
+            runs.append((off + 8 * s, len(ok) - s))
+    runs.sort()
+    assert len(runs) == 2 and runs[0][1] == runs[1][1] == 241, runs
+    arrs = [np.frombuffer(b[o:o + 8 * n], dtype="<f8") for o, n in runs]
+    # the floe is 5 km wide and 20 km tall, centred at the origin: X is the narrow one
+    X, Y = (arrs if np.abs(arrs[0]).max() < np.abs(arrs[1]).max() else arrs[::-1])
+    assert np.abs(X).max() <= 2500.0 and np.abs(Y).max() <= 10000.0
+    return X.tolist(), Y.tolist()
+
+
+def forcings():
+    X, Y = decode_mc_points()
+    return {
+        "_source": "test/test_physical_processes/test_coupling.jl:464-639; X,Y from test/inputs/test_mc_points.jld2",
+        "grid": {"x0": -1e5, "xf": 1e5, "y0": -1e5, "yf": 1e5, "dx": 1e4, "dy": 1e4},
+        "domain_kinds": ["collision"] * 4,
+        "floe": [[-1.75e4, 5e4], [-1.75e4, 7e4], [-1.25e4, 7e4], [-1.25e4, 5e4], [-1.75e4, 5e4]],
+        "height": 0.25, "X": X, "Y": Y,
+        "psi": "0.5e4*sin(4*(pi/4e5)*x)*sin(4*(pi/4e5)*y) on the grid-line lattice (:577-592)",
+        "cases": [
+            {"name": "zonal_ocean", "ocean": [1.0, 0.0], "atmos": [0.0, 0.0], "floe_uv": [0.0, 0.0], "dd": 2,
+             "fx": 2.9760, "fy": 0.8296, "trq": -523.9212, "atol": [1e-3, 1e-3, 1e-3]},
+            {"name": "meridional_ocean", "ocean": [0.0, 1.0], "atmos": [0.0, 0.0], "floe_uv": [0.0, 0.0], "dd": 2,
+             "fx": -0.8296, "fy": 2.9760, "trq": 239.3141, "atol": [1e-3, 1e-3, 1e-3]},
+            {"name": "moving_floe", "ocean": [0.0, 0.0], "atmos": [0.0, 0.0], "floe_uv": [0.25, 0.1], "dd": 2,
+             "fx": -0.1756, "fy": -0.1419, "trq": 29.0465, "atol": [1e-3, 1e-3, 1e-1]},
+            {"name": "diagonal_atmos", "ocean": [0.0, 0.0], "atmos": [-1.0, -0.5], "floe_uv": [0.0, 0.0], "dd": 2,
+             "fx": -0.0013, "fy": -6.7082e-4, "trq": 0.2276, "atol": [1e-3, 1e-3, 1e-3]},
+            {"name": "nonuniform_ocean", "ocean": "psi", "atmos": [0.0, 0.0], "floe_uv": [0.0, 0.0], "dd": 1,
+             "fx": -0.0182, "fy": 0.0392, "trq": 23.6399, "atol": [1e-3, 1e-3, 1e-3]},
+            {"name": "nonuniform_both_moving", "ocean": "psi", "atmos": "psi", "floe_uv": [0.5, -0.5], "dd": 1,
+             "fx": -1.6300, "fy": 1.1240, "trq": 523.2361, "atol": [1e-3, 1e-3, 2e-1]},
+        ],
+    }
+
+
+def main():
+    for name, fn in (("collisions.json", collisions), ("floe_utils.json", floe_utils), ("forcings.json", forcings)):
+        with open(os.path.join(HERE, name), "w") as f:
+            json.dump(fn(), f, indent=1)
+        print("wrote", name)
+
+
+if __name__ == "__main__":
+    main()
