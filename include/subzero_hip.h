@@ -1,0 +1,166 @@
+/*
+ * subzero_hip.h — C-ABI of libsubzero_hip.so, the MI355X (gfx950) engine for Subzero.jl's
+ * per-timestep collision / forcing / rigid-body-update path.
+ *
+ * This is the drop-in boundary: a Julia shim or any other host
+ * binds exactly these symbols with @ccall / ctypes / cgo.  Plain pointers and sizes only; no
+ * exceptions cross the boundary.  Every int-returning call returns 0 on success and a negative
+ * SZ_E_* code on failure (text via sz_last_error).  All calls are synchronous at return and
+ * must come from one host thread per context.  The caller owns every host buffer; the library
+ * keeps no host pointer after a call returns.
+ *
+ * Reference interfaces replaced (paths relative to the Subzero.jl repository):
+ *   sz_add_ghosts                 <- add_ghosts!(floes, domain)            src/physical_processes/collisions.jl:1060-1174
+ *   sz_timestep_collisions        <- timestep_collisions!(floes, n_init_floes, domain, consts, Δt,
+ *                                    collision_settings, spinlock)          collisions.jl:734-864
+ *   sz_collide_pairs              <- floe_floe_interaction!(ifloe, i, jfloe, j, consts, Δt,
+ *                                    max_overlap)                           collisions.jl:347-408
+ *   sz_collide_domain             <- floe_domain_interaction!(floe, domain, consts, Δt,
+ *                                    max_overlap)                           collisions.jl:594-662
+ *   sz_remove_ghosts              <- ghost-row deletion in timestep_sim!    src/simulation_components/simulation.jl:138-144
+ *   sz_timestep_coupling          <- timestep_coupling!(model, Δt, consts, coupling_settings,
+ *                                    floe_settings), one-way part           src/physical_processes/coupling.jl:1705-1738
+ *   sz_timestep_floe_properties   <- timestep_floe_properties!(floes, tstep, Δt, floe_settings)
+ *                                                                           src/physical_processes/update_floe.jl:469-551
+ *   sz_step                       <- timestep_sim!(sim, tstep), hot-path processes only,
+ *                                    state resident in HBM between steps   simulation.jl:94-170
+ *   sz_params                     <- Constants (simulation.jl:5-18), CollisionSettings
+ *                                    (process_settings.jl:183-187), FloeSettings (:25-32),
+ *                                    DecayAreaScaledCalculator.λ (stress_calculators.jl:82),
+ *                                    CouplingSettings.Δd (process_settings.jl:133-137)
+ *   sz_floe_columns               <- the hot columns of StructArray{Floe{Float64}} (src/simulation_components/floe.jl:24-77)
+ *
+ * Index conventions: all indices in this API are 0-based, EXCEPT the `floeidx` column (column 0)
+ * of interaction rows, which holds the partner exactly as the reference stores it
+ * (collisions.jl:297): 1-based floe index as a double, -1/-2/-3/-4 for the N/S/E/W boundary,
+ * -(4+k) for topography element k (1-based).
+ * Interaction rows are 7 doubles, row-major: floeidx, xforce, yforce, xpoint, ypoint, torque,
+ * overlap (floe.jl:102-110).
+ * 2x2 tensors are 4 doubles per floe in the order 11, 12, 21, 22.
+ */
+#ifndef SUBZERO_HIP_H
+#define SUBZERO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sz_ctx sz_ctx;
+
+enum { SZ_OK = 0, SZ_E_HIP = -1, SZ_E_ARG = -2, SZ_E_CAPACITY = -3, SZ_E_STATE = -4, SZ_E_NODEVICE = -5 };
+enum { SZ_OPEN = 0, SZ_PERIODIC = 1, SZ_COLLISION = 2, SZ_MOVING = 3 };       /* boundary kinds  */
+enum { SZ_NORTH = 0, SZ_SOUTH = 1, SZ_EAST = 2, SZ_WEST = 3 };                /* boundary order  */
+enum { SZ_ACTIVE = 1, SZ_REMOVE = 2, SZ_FUSE = 3 };                           /* floe.jl:8-12    */
+/* process switches for sz_step (CollisionSettings.collisions_on, CouplingSettings.coupling_on) */
+enum { SZ_COLLISIONS_ON = 1, SZ_COUPLING_ON = 2 };
+
+typedef struct {
+  double E, nu, mu, rho_o, rho_a, Cd_io, Cd_ia, f, turn_theta;
+  double floe_floe_max_overlap, floe_domain_max_overlap;
+  double rho_i, max_floe_height, maximum_xi, lambda;
+  int32_t coupling_dd;
+  int32_t _pad;
+} sz_params;
+
+/* Host-side view of the floe columns.  Scalar columns have one entry per floe (M entries);
+   ragged columns are CSR.  Rings are closed (last point == first).  NULL columns are read as
+   zeros on upload and skipped on download. */
+typedef struct {
+  double *cx, *cy, *rmax, *area, *height, *mass, *moment, *alpha, *u, *v, *xi;
+  double *p_dxdt, *p_dydt, *p_dalphadt, *p_dudt, *p_dvdt, *p_dxidt;
+  double *fxOA, *fyOA, *trqOA, *hflx_factor, *overarea;
+  double *coll_fx, *coll_fy, *coll_trq;
+  double *stress_accum, *stress_instant, *strain;        /* 4 per floe */
+  int64_t *id, *ghost_id;
+  int32_t *status;
+  int32_t *vert_off;  double *vx, *vy;                   /* M+1 offsets, closed rings   */
+  int32_t *sub_off;   double *sx, *sy;                   /* sub-floe points, centred    */
+  int32_t *ghost_off; int32_t *ghost_idx;                /* parent -> ghost rows        */
+} sz_floe_columns;
+
+typedef struct {
+  int64_t M, N;                 /* floes incl. ghosts / parents                              */
+  int64_t n_ring_points;        /* V_M                                                       */
+  int64_t n_sub_points;         /* S                                                         */
+  int64_t n_pairs;              /* P: pairs that reached the narrow phase in the last step   */
+  int64_t n_pair_ring_points;   /* sum over pairs of both rings' point counts                */
+  int64_t n_pair_rows;          /* C: floe-floe contact rows before mirroring                */
+  int64_t n_elem_items;         /* floe-boundary / floe-topography clips                     */
+  int64_t n_elem_rows;          /* C_b                                                       */
+  int64_t n_inter_rows;         /* total interaction rows after mirror + ghost fold          */
+  int64_t n_ghosts;             /* G                                                         */
+  int64_t warn_height, warn_force, warn_vel, warn_xi;   /* update_floe.jl guards             */
+} sz_stats;
+
+/* kernel classes for sz_kernel_time_ms */
+enum { SZ_K_GHOSTS = 0, SZ_K_BROAD = 1, SZ_K_NARROW = 2, SZ_K_REDUCE = 3, SZ_K_FORCING = 4,
+       SZ_K_INTEGRATE = 5, SZ_K_COUNT = 6 };
+
+/* ---- lifetime */
+sz_ctx     *sz_create(int device_id);            /* NULL if no HIP device / allocation failure */
+void        sz_destroy(sz_ctx *ctx);
+const char *sz_last_error(const sz_ctx *ctx);
+const char *sz_version(void);
+
+/* ---- static inputs */
+int sz_set_params(sz_ctx *ctx, const sz_params *p);
+/* boundaries in the order N, S, E, W: kind, wall coordinate `val`, rectangle
+   {xmin, xmax, ymin, ymax} (boundaries.jl:29-150) and velocity (MovingBoundary only) */
+int sz_set_domain(sz_ctx *ctx, const int32_t *kinds, const double *vals, const double *rects,
+                  const double *bu, const double *bv);
+/* topography elements: closed rings (CSR) with centroid and rmax (topography.jl:5-9) */
+int sz_set_topography(sz_ctx *ctx, int32_t ntopo, const int32_t *off, const double *x,
+                      const double *y, const double *cx, const double *cy, const double *rmax);
+/* grid (grids.jl:106) and the (Nx+1)x(Ny+1) ocean/atmosphere lattices, element [ix][iy] at
+   ix*(Ny+1)+iy (oceans.jl:74, atmos.jl:4) */
+int sz_set_fields(sz_ctx *ctx, int32_t Nx, int32_t Ny, double x0, double xf, double y0, double yf,
+                  const double *uocn, const double *vocn, const double *hflx_factor,
+                  const double *uatm, const double *vatm);
+
+/* ---- floe state */
+/* M rows, of which the first N are parents; M > N only when the caller ran add_ghosts!
+   itself, in which case ghost_off/ghost_idx must be given */
+int sz_upload_floes(sz_ctx *ctx, int64_t M, int64_t N, const sz_floe_columns *cols);
+int sz_get_stats(sz_ctx *ctx, sz_stats *out);
+/* copies every non-NULL column (sized from sz_get_stats) */
+int sz_download_floes(sz_ctx *ctx, sz_floe_columns *cols);
+/* interactions of all M floes: off has M+1 entries, rows has n_inter_rows*7 doubles */
+int sz_download_interactions(sz_ctx *ctx, int32_t *off, double *rows);
+/* the pairs that reached the narrow phase, in the reference's serial (i asc, j asc) order */
+int sz_download_pairs(sz_ctx *ctx, int32_t *pi, int32_t *pj);
+/* status.fuse_idx after the mirror pass (collisions.jl:801-806): off M+1, idx; call with
+   idx == NULL to get only the offsets (off[M] = total) */
+int sz_download_fuse(sz_ctx *ctx, int32_t *off, int32_t *idx);
+int sz_get_boundary_vals(sz_ctx *ctx, double *vals4);
+
+/* ---- processes (each mirrors one reference function, see the header comment) */
+int sz_add_ghosts(sz_ctx *ctx);
+int sz_remove_ghosts(sz_ctx *ctx);
+int sz_timestep_collisions(sz_ctx *ctx, int64_t n_init, int32_t dt);
+/* floe_floe_interaction! on explicit (i, j) pairs: only floe i of each pair is updated */
+int sz_collide_pairs(sz_ctx *ctx, int64_t npairs, const int32_t *pi, const int32_t *pj, int32_t dt,
+                     double max_overlap);
+/* floe_domain_interaction! for every floe */
+int sz_collide_domain(sz_ctx *ctx, int32_t dt, double max_overlap);
+int sz_timestep_coupling(sz_ctx *ctx);
+int sz_timestep_floe_properties(sz_ctx *ctx, int32_t dt);
+/* nsteps x timestep_sim! with the state resident in HBM; tstep counts from tstep0 */
+int sz_step(sz_ctx *ctx, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupling_dt,
+            int32_t flags);
+
+/* ---- measurement: HIP-event time per kernel class, accumulated since the last reset, on the
+   stream the kernels are launched on; launches = number of timed launches of that class */
+int sz_profile_enable(sz_ctx *ctx, int32_t on);
+int sz_profile_reset(sz_ctx *ctx);
+int sz_kernel_time_ms(sz_ctx *ctx, int32_t kclass, double *ms, int64_t *launches);
+
+/* ---- multi-GPU halo support: pack the records of the given floes into a
+   flat device buffer the host hands to RCCL, and append received records as extra floes */
+int sz_halo_record_doubles(sz_ctx *ctx, int32_t max_ring_points);
+int sz_device_ptr_note(void);   /* reserved */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

