@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""bench.py — floe-steps/s of the HIP collision / forcing / rigid-body engine on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one timestep_sim! of the hot path (add_ghosts! -> timestep_collisions! -> ghost
+removal -> timestep_coupling! -> timestep_floe_properties!) over the whole synthetic floe field,
+state resident in HBM.  At N=1 the workload is BASELINE.json configs[1]: 10 000 random-polygon
+floes (8-16 vertices), doubly periodic box, uniform_flow ocean forcing, fp64.  For N>1 (one
+process per GPU under torch.distributed / RCCL) the same field is sharded by spatial tile with a
+ghost-floe halo (subzero_jl_amd.tiles) and the N=1 field size is kept per job: strong scaling.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the narrow phase) with
+the algorithmic byte count of SURVEY.md §8(d) against HBM peak; `cpu_baseline` is the CPU oracle
+(a C/OpenMP port of the reference's algorithm) timed on the host cores of the same box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+W = 8                        # fp64 bytes
+
+
+def narrow_algorithmic_bytes(st):
+    """B_narrow of SURVEY.md §8(d): both rings of every pair (2 coordinates x w per point) plus
+    7 scalars of both floes, and every contact row written (floe-floe rows twice: i and mirrored
+    j; boundary rows once)."""
+    return (2 * W * st["n_pair_ring_points"] + 2 * 7 * W * st["n_pairs"]
+            + 7 * W * (2 * st["n_pair_rows"] + st["n_elem_rows"]))
+
+
+def step_algorithmic_bytes(st):
+    """B = B_broad + B_narrow + B_reduce + B_force + B_integ of SURVEY.md §8(d)."""
+    M, N = st["M"] + st["n_ghosts"], st["N"]
+    idx = 4
+    b_broad = M * (3 * W + 2 * idx)
+    b_reduce = N * (3 * W + idx)
+    b_force = 2 * W * st["n_sub_points"] + N * (8 * W + 4 * W)
+    b_integ = N * (22 * W + 14 * W + 24 * W) + 4 * W * st["n_ring_points"]
+    return b_broad + narrow_algorithmic_bytes(st) + b_reduce + b_force + b_integ
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """The oracle (kind: port) on a bounded sample of the same workload: the same 10k-floe field,
+    as many whole timesteps as fit the budget (at least 2), all host cores of this process."""
+    from oracle import orc
+    from subzero_jl_amd import fields
+    cores = len(os.sched_getaffinity(0))
+    w = fields.build_world(orc.World(), cfg)
+    w.set_threads(cores)
+    w.timestep_sim(0, cfg["dt"], coupling_dt=1)        # warm-up step (page-in, allocator)
+    t0 = time.perf_counter(); steps = 0
+    while steps < 2 or (time.perf_counter() - t0 < budget_s and steps < 50):
+        w.timestep_sim(1 + steps, cfg["dt"], coupling_dt=1); steps += 1
+    el = time.perf_counter() - t0
+    return {"value": cfg["n_floes"] * steps / el, "unit": "floe-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} timesteps of the same {cfg['n_floes']}-floe field ({el:.1f} s), OpenMP over floes "
+                      f"like the reference's Threads.@threads loops"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--floes", type=int, default=10000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import subzero_jl_amd
+    from subzero_jl_amd import fields
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    cfg = fields.make_config(n_floes=args.floes, seed=12345)
+    coupling_dt = 1
+    if world == 1:
+        hw = fields.build_world(subzero_jl_amd.World(local), cfg)
+        runner = lambda n, t0: hw.run(n, t0, cfg["dt"], coupling_dt=coupling_dt)
+    else:
+        from subzero_jl_amd import tiles
+        tw = tiles.TiledWorld(cfg, rank, world, local, dist)
+        hw = tw.world
+        runner = lambda n, t0: tw.run(n, t0, cfg["dt"], coupling_dt=coupling_dt)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    runner(args.warmup, 0)
+    hw.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    runner(args.steps, args.warmup)
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    kt = hw.kernel_times()
+    st = hw.stats()
+
+    if rank == 0:
+        n_ms, n_launch = kt["narrow"]
+        narrow_ms = n_ms / max(n_launch, 1)
+        b_narrow = narrow_algorithmic_bytes(st)
+        achieved = b_narrow / (narrow_ms * 1e-3) / 1e9 if narrow_ms > 0 else 0.0
+        out = {
+            "metric": "floe_steps_per_sec", "value": cfg["n_floes"] * args.steps / el, "unit": "floe-steps/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {cfg['n_floes']} random-polygon floes (8-16 verts), doubly periodic "
+                                   f"box {cfg['L'] / 1e3:.0f} km, uniform_flow ocean 0.1 m/s, collisions + one-way "
+                                   f"coupling every step + rigid-body update, dt={cfg['dt']} s",
+                       "n_floes": cfg["n_floes"], "seed": cfg["seed"], "coupling_dt": coupling_dt,
+                       "tiles": 1 if world == 1 else world},
+            "roofline": {"bound": "hbm", "kernel": "sz_k_narrow<16,32,16,80,128,0>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": narrow_ms, "algorithmic_bytes_per_launch": b_narrow,
+                         "step_algorithmic_bytes": step_algorithmic_bytes(st),
+                         "step_frac": step_algorithmic_bytes(st) / (el / args.steps) / 1e9 / HBM_PEAK_GBS},
+            "kernel_ms_per_step": {k: (v[0] / args.steps) for k, v in kt.items()},
+            "counts": {k: st[k] for k in ("M", "N", "n_ghosts", "n_pairs", "n_pair_rows", "n_elem_rows",
+                                           "n_inter_rows", "n_ring_points", "n_sub_points", "n_trace_fail")},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,6 +91,7 @@ typedef struct {
   int64_t n_inter_rows;         /* total interaction rows after mirror + ghost fold          */
   int64_t n_ghosts;             /* G                                                         */
   int64_t warn_height, warn_force, warn_vel, warn_xi;   /* update_floe.jl guards             */
+  int64_t n_trace_fail;         /* clip traces abandoned (self-intersecting input / round-off), cumulative */
 } sz_stats;
 
 /* kernel classes for sz_kernel_time_ms */

@@ -60,6 +60,8 @@ void   orc_intersection(const orc_ring *a, const orc_ring *b, orc_regions *out);
 /* GO.intersection_points: returns count, fills pts (malloc'd, caller frees) */
 int    orc_intersection_points(const orc_ring *a, const orc_ring *b, orc_pt **pts);
 
+long   orc_trace_failures(void);   /* diagnostics */
+
 /* ctypes-friendly wrappers on flat arrays (tests call these) */
 int    orc_clip_flat(int na, const double *ax, const double *ay,
                      int nb, const double *bx, const double *by,

@@ -319,6 +319,10 @@ static int ring_inside(const orc_ring *a, const orc_ring *b) {
   return 1;
 }
 
+/* diagnostics: traces abandoned by the guard (inconsistent crossing flags from round-off) */
+static long orc_trace_failures_ = 0;
+long orc_trace_failures(void) { return orc_trace_failures_; }
+
 void orc_intersection(const orc_ring *a, const orc_ring *b, orc_regions *out) {
   out->n = 0;
   if (a->n < 4 || b->n < 4) return;
@@ -370,6 +374,12 @@ void orc_intersection(const orc_ring *a, const orc_ring *b, orc_regions *out) {
       orc_ring *dst = regions_new(out);
       *dst = reg;
     } else {
+      if (!ok) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+        orc_trace_failures_++;
+      }
       orc_ring_free(&reg);
     }
   }

@@ -186,6 +186,7 @@ int upload_elements(sz_ctx* c) {
 void stage_ghosts(sz_ctx* c) {
   State& S = c->S;
   if (!S.any_periodic_ew && !S.any_periodic_ns) return;
+  (void)hipMemsetAsync(S.cnt + C_NGHOSTS, 0, sizeof(int), c->stream);
   Timed t(c, SZ_K_GHOSTS);
   int gN = grid_for(S.capM, 256);
   for (int axis = 0; axis < 2; axis++) {
@@ -279,6 +280,8 @@ void stage_forcing(sz_ctx* c) {
   t.end();
 }
 void stage_integrate(sz_ctx* c, int dt) {
+  // the guard counters describe the last timestep_floe_properties! call
+  (void)hipMemsetAsync(c->S.cnt + C_WARN_H, 0, 4 * sizeof(int), c->stream);
   Timed t(c, SZ_K_INTEGRATE);
   hipLaunchKernelGGL(sz_k_integrate, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt);
   hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S);
@@ -490,6 +493,7 @@ int sz_get_stats(sz_ctx* c, sz_stats* out) {
   out->n_pairs = h[C_NPAIRS]; out->n_pair_ring_points = st[0]; out->n_pair_rows = st[1];
   out->n_elem_items = h[C_NELEM]; out->n_elem_rows = st[2]; out->n_inter_rows = h[C_NINTER]; out->n_ghosts = h[C_NGHOSTS];
   out->warn_height = h[C_WARN_H]; out->warn_force = h[C_WARN_F]; out->warn_vel = h[C_WARN_V]; out->warn_xi = h[C_WARN_XI];
+  out->n_trace_fail = h[C_TRACE_FAIL];
   return SZ_OK;
 }
 

@@ -54,7 +54,7 @@ struct GroupMem {
   int16_t midx[KC];                        // matched region-vertex index per ipoint
   int16_t roff[2][RMAX + 2];
   uint8_t cfl[KC], rfl[KC], uniq[KC];
-  int nraw, nx, nreg[2], flag, err;
+  int nraw, nx, nreg[2], flag, err, ntracefail;
 };
 
 enum { ERR_CAP_RING = 1, ERR_CAP_XING = 2, ERR_CAP_REGION = 4, ERR_CAP_ROWS = 8, ERR_TRACE = 16,
@@ -264,8 +264,9 @@ SZ_DEV void clip(GroupMem<CAP, KC, RC>& m, int gl, const double* pax, const doub
   uint64_t visited = 0;      // KC <= 64
   int nreg = 0, off = 0;
   const int guard_max = 2 * (na + nb + 2 * K) + 8;
-  bool failed = false;
-  for (int s = 0; s < K && !failed; s++) {
+  int nfail = 0;
+  for (int s = 0; s < K; s++) {
+    bool failed = false;
     int c0 = m.ordA[s];
     if ((visited >> c0) & 1) continue;
     int start = off, cnt = 0, guard = 0;
@@ -306,7 +307,9 @@ SZ_DEV void clip(GroupMem<CAP, KC, RC>& m, int gl, const double* pax, const doub
       visited |= (1ull << cur);
       on_a = !on_a;
     } while (cur != c0);
-    if (failed) break;
+    // a trace abandoned by the guard (inconsistent crossing flags: self-intersecting input or
+    // round-off) yields no region; tracing goes on with the next unvisited crossing
+    if (failed) { nfail++; gsync(); continue; }
     if (off + cnt > RC) { if (gl == 0) m.err |= ERR_CAP_REGION; break; }
     gsync();
     double sa = (cnt >= 4) ? ring_signed_area(&m.rx[buf][start], &m.ry[buf][start], cnt) : 0.0;
@@ -318,7 +321,7 @@ SZ_DEV void clip(GroupMem<CAP, KC, RC>& m, int gl, const double* pax, const doub
     }
     gsync();
   }
-  if (failed && gl == 0) m.err |= ERR_TRACE;
+  if (nfail && gl == 0) m.ntracefail += nfail;
   if (gl == 0) m.nreg[buf] = nreg;
   gsync();
 }

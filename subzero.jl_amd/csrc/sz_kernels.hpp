@@ -210,7 +210,7 @@ __global__ void sz_k_remove_ghosts(State S) {
     S.ngh[i] = 0;
     for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = -1;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { S.cnt[C_M] = N; S.cnt[C_NV] = S.voff[N]; S.cnt[C_NGHOSTS] = 0; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { S.cnt[C_M] = N; S.cnt[C_NV] = S.voff[N]; }   // C_NGHOSTS keeps the last step's count
 }
 
 // ============================================================================ broad phase (A2, A3)
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, do
   GroupMem<CAP, KC, RC>& m = mem[gi];
   const int npairs = S.cnt[C_NPAIRS], nel = S.cnt[C_NELEM];
   const int nitems = npairs + nel;
-  if (gl == 0) m.err = 0;
+  if (gl == 0) { m.err = 0; m.ntracefail = 0; }
   for (int t = blockIdx.x * GPB + gi; t < nitems; t += gridDim.x * GPB) {
     const bool is_pair = t < npairs;
     int i, j = -1, e = -1, item;
@@ -458,6 +458,7 @@ __global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, do
   }
   gsync();
   if (gl == 0 && m.err) atomicOr(&S.cnt[C_ERR], m.err);
+  if (gl == 0 && m.ntracefail) atomicAdd(&S.cnt[C_TRACE_FAIL], m.ntracefail);
 }
 
 // items not touched by any narrow variant would keep stale row counts: clear them first

@@ -25,6 +25,7 @@ enum {
   C_NGHOSTS,
   C_NCELLS,
   C_SCRATCH0, C_SCRATCH1,
+  C_TRACE_FAIL,   // traces abandoned by the guard (diagnostic, cumulative)
   C_COUNT = 32
 };
 

@@ -77,7 +77,10 @@ def make_config(n_floes=10000, seed=12345, concentration=0.8, spacing=2.0e4, wal
     vx = np.zeros(off[-1]); vy = np.zeros(off[-1])
     for i in range(n_floes):
         n = nv[i]
-        th = np.sort(rng.uniform(0, 2 * np.pi, n))[::-1]          # clockwise
+        # jittered equally spaced angles: consecutive angles differ by < pi, so the ring is
+        # star-shaped about its centre (hence simple); descending = clockwise
+        th = (2 * np.pi / n) * (np.arange(n) + rng.uniform(-0.35, 0.35, n) + rng.uniform(0, 1))
+        th = th[::-1]
         rad = r0 * (0.6 + 0.4 * rng.uniform(0, 1, n))
         x = ccx[i] + rad * np.cos(th); y = ccy[i] + rad * np.sin(th)
         o = off[i]

@@ -50,7 +50,14 @@ def compare_worlds(hw, ow, rtol=1e-10, fields=SCALARS, check_pairs=True, check_i
     if check_inter:
         out.update(compare_interactions(hw, ow, rtol))
     for f in fields:
-        e = relerr(hw.get(f), ow.get(f))
+        a, b = hw.get(f), ow.get(f)
+        if f in ("e12", "e21"):
+            # the shear strain of a rigid rotation cancels analytically (update_floe.jl:436-446):
+            # what is stored is round-off, so compare it on the scale of the normal components
+            scale = max(np.abs(ow.get("e11")).max(), np.abs(ow.get("e22")).max(), 1e-300)
+            e = float(np.max(np.abs(a - b)) / scale)
+        else:
+            e = relerr(a, b)
         assert e <= rtol, (f, e)
         out[f] = e
     ho, hx, hy = hw.rings(); oo, ox, oy = ow.rings()
