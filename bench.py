@@ -52,6 +52,12 @@ def cpu_baseline(cfg, budget_s=20.0):
     from oracle import orc
     from subzero_jl_amd import fields
     cores = len(os.sched_getaffinity(0))
+    try:     # the box gives one GPU's share of the host: honour the cgroup CPU quota
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(quota) // int(period)))
+    except Exception:
+        pass
     w = fields.build_world(orc.World(), cfg)
     w.set_threads(cores)
     w.timestep_sim(0, cfg["dt"], coupling_dt=1)        # warm-up step (page-in, allocator)
