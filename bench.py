@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--floes", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-tiled", action="store_true", help="run the halo/RCCL path even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -91,18 +92,20 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_tiled:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29533"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     cfg = fields.make_config(n_floes=args.floes, seed=12345)
     coupling_dt = 1
-    if world == 1:
+    if world == 1 and not args.force_tiled:
         hw = fields.build_world(subzero_jl_amd.World(local), cfg)
         runner = lambda n, t0: hw.run(n, t0, cfg["dt"], coupling_dt=coupling_dt)
     else:
         from subzero_jl_amd import tiles
-        tw = tiles.TiledWorld(cfg, rank, world, local, dist)
+        tw = tiles.TiledWorld(cfg, rank, world, local, dist, always_exchange=args.force_tiled)
         hw = tw.world
         runner = lambda n, t0: tw.run(n, t0, cfg["dt"], coupling_dt=coupling_dt)
 

@@ -156,10 +156,26 @@ int sz_profile_enable(sz_ctx *ctx, int32_t on);
 int sz_profile_reset(sz_ctx *ctx);
 int sz_kernel_time_ms(sz_ctx *ctx, int32_t kclass, double *ms, int64_t *launches);
 
-/* ---- multi-GPU halo support: pack the records of the given floes into a
-   flat device buffer the host hands to RCCL, and append received records as extra floes */
-int sz_halo_record_doubles(sz_ctx *ctx, int32_t max_ring_points);
-int sz_device_ptr_note(void);   /* reserved */
+/* ---- multi-GPU halo support (no counterpart in the single-process reference:
+   its periodic ghost floes, collisions.jl:881-1047, are the same pattern inside one address
+   space).  One context per rank owns a fixed subset of the floes; every step the ranks trade
+   ghost-floe records (sz_halo_record_doubles() doubles each) through buffers in DEVICE memory
+   that the host hands to RCCL (torch.distributed all_to_all_single).
+     sz_tile_enable   after sz_upload_floes of the owned floes: gidx[i] = global index of owned
+                      floe i; all order-dependent rules then use global indices
+     sz_owned_box     bounding box of the owned centroids + largest rmax: xmin,xmax,ymin,ymax,rmax
+     sz_halo_pack     boxes: nranks x {xmin,xmax,ymin,ymax} (already expanded by the interaction
+                      range); writes the records for rank d at d_send + d*cap*REC, counts_out[d]
+     sz_halo_unpack   appends nrec received records as extra (halo) floes
+     sz_tile_step     one timestep_sim! on owned + halo floes; only owned floes are integrated,
+                      the halo is dropped at the end */
+int sz_tile_enable(sz_ctx *ctx, const int64_t *gidx, double reserved);
+int sz_owned_box(sz_ctx *ctx, double *out5);
+int sz_halo_record_doubles(void);
+int sz_halo_pack(sz_ctx *ctx, int32_t nranks, int32_t my_rank, const double *boxes, double Lx, double Ly,
+                 int32_t periodic_x, int32_t periodic_y, void *d_send, int32_t cap, int32_t *counts_out);
+int sz_halo_unpack(sz_ctx *ctx, const void *d_recv, int64_t nrec);
+int sz_tile_step(sz_ctx *ctx, int32_t tstep, int32_t dt, int32_t coupling_dt, int32_t flags);
 
 #ifdef __cplusplus
 }

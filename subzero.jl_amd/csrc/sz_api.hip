@@ -419,7 +419,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   S.capRows = S.capPairs * 3 + S.capElem * 2; S.capCells = 4 * S.capM + 64; S.capS = NS;
   int rc;
 #define DA(field, n) if ((rc = dalloc(c, &S.field, (size_t)(n), c->allocs))) return rc
-  DA(cnt, C_COUNT);
+  DA(cnt, C_COUNT + 64);
   double** dcols[] = { &S.cx, &S.cy, &S.rmax, &S.area, &S.height, &S.mass, &S.moment, &S.alpha, &S.u, &S.v, &S.xi,
                        &S.p_dxdt, &S.p_dydt, &S.p_dalphadt, &S.p_dudt, &S.p_dvdt, &S.p_dxidt, &S.fxOA, &S.fyOA, &S.trqOA,
                        &S.hflx, &S.overarea, &S.cfx, &S.cfy, &S.ctrq };
@@ -434,7 +434,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   if (f->stress_accum) H2D(S.sa, f->stress_accum, 4 * M, double);
   if (f->stress_instant) H2D(S.si, f->stress_instant, 4 * M, double);
   if (f->strain) H2D(S.strain, f->strain, 4 * M, double);
-  DA(id, S.capM); DA(ghost_id, S.capM); DA(status, S.capM); DA(parent, S.capM); DA(gh, MAX_GHOSTS * S.capM); DA(ngh, S.capM);
+  DA(id, S.capM); DA(ghost_id, S.capM); DA(okey, S.capM); DA(status, S.capM); DA(parent, S.capM); DA(gh, MAX_GHOSTS * S.capM); DA(ngh, S.capM);
   DA(osign, S.capM);
   {
     std::vector<long long> id(M), gid(M, 0);
@@ -448,6 +448,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
         for (int k = 0; k < n; k++) { int g = f->ghost_idx[f->ghost_off[i] + k]; if (g < N || g >= M) { c->err = "ghost index out of range"; return SZ_E_ARG; } gh[(size_t)i * MAX_GHOSTS + k] = g; parent[g] = i; }
       }
     }
+    { std::vector<long long> ok(S.capM); for (int i = 0; i < S.capM; i++) ok[i] = i; H2D(S.okey, ok.data(), S.capM, long long); HIPCHK(c, hipStreamSynchronize(c->stream)); }
     H2D(S.id, id.data(), M, long long); H2D(S.ghost_id, gid.data(), M, long long); H2D(S.status, st.data(), M, int);
     H2D(S.parent, parent.data(), M, int); H2D(S.gh, gh.data(), (size_t)MAX_GHOSTS * M, int); H2D(S.ngh, ngh.data(), M, int);
     HIPCHK(c, hipStreamSynchronize(c->stream));   // host vectors go out of scope
@@ -457,7 +458,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(soff, S.capM + 1); DA(sx, NS); DA(sy, NS);
   if (f->sub_off) { H2D(S.soff, f->sub_off, N + 1, int); H2D(S.sx, f->sx, NS, double); H2D(S.sy, f->sy, NS, double); }
   DA(gflag, S.capM + 1); DA(gcnt, S.capM + 1); DA(gscan, S.capM + 2); DA(gvcnt, S.capM + 1); DA(gvscan, S.capM + 2);
-  DA(bounds, 8); DA(cell_of, S.capM); DA(cell_cnt, S.capCells + 1); DA(cell_off, S.capCells + 2); DA(cell_cur, S.capCells + 1);
+  DA(bounds, 16 + 64 * 4); DA(cell_of, S.capM); DA(cell_cnt, S.capCells + 1); DA(cell_off, S.capCells + 2); DA(cell_cur, S.capCells + 1);
   DA(cell_items, S.capM);
   DA(nb_out, (size_t)S.capM * MAXNB); DA(nb_in, (size_t)S.capM * MAXNB); DA(n_out, S.capM + 1); DA(n_in, S.capM + 1);
   DA(out_off, S.capM + 2); DA(in_off, S.capM + 2); DA(in_i, S.capPairs); DA(pair_i, S.capPairs); DA(pair_j, S.capPairs);
@@ -468,7 +469,8 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(blk, std::max(S.capCells, std::max(S.capM, 1024)) / SCAN_B + 1024);
   DA(tagA, S.capM + 1);
   int h[C_COUNT] = { 0 };
-  h[C_M] = M; h[C_N] = N; h[C_NV] = V; h[C_NGHOSTS] = M - N;
+  h[C_M] = M; h[C_N] = N; h[C_NV] = V; h[C_NGHOSTS] = M - N; h[C_NOWN] = N;
+  S.tiled = 0;
   H2D(S.cnt, h, C_COUNT, int);
   hipLaunchKernelGGL(sz_k_osign, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0);
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -690,7 +692,73 @@ int sz_kernel_time_ms(sz_ctx* c, int32_t k, double* ms, int64_t* launches) {
   return SZ_OK;
 }
 
-int sz_halo_record_doubles(sz_ctx*, int32_t max_ring_points) { return 16 + 2 * max_ring_points; }
-int sz_device_ptr_note(void) { return 0; }
+
+// ---------------------------------------------------------------- multi-GPU halo API
+int sz_tile_enable(sz_ctx* c, const int64_t* gidx, double halo_capacity_factor) {
+  if (!c || !c->have_floes || !gidx) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  State& S = c->S;
+  if (c->hostM != c->hostN) { c->err = "sz_tile_enable needs a ghost-free upload"; return SZ_E_STATE; }
+  std::vector<long long> ok(c->hostN);
+  for (int i = 0; i < c->hostN; i++) ok[i] = gidx[i];
+  H2D(S.okey, ok.data(), c->hostN, long long);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  S.tiled = 1;
+  (void)halo_capacity_factor;
+  return SZ_OK;
+}
+
+int sz_owned_box(sz_ctx* c, double* out5) {
+  if (!c || !c->have_floes || !out5) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  hipLaunchKernelGGL(sz_k_owned_box, dim3(1), dim3(1024), 0, c->stream, c->S, c->S.bounds + 8);
+  HIPCHK(c, hipMemcpyAsync(out5, c->S.bounds + 8, 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SZ_OK;
+}
+
+int sz_halo_record_doubles(void) { return HALO_REC; }
+
+int sz_halo_pack(sz_ctx* c, int32_t nranks, int32_t me, const double* boxes, double Lx, double Ly, int32_t per_x,
+                 int32_t per_y, void* d_send, int32_t cap, int32_t* counts_out) {
+  if (!c || !c->have_floes || nranks < 1 || nranks > 64 || !boxes || !d_send || !counts_out) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  State& S = c->S;
+  double* dbox = S.bounds + 16;                 // 64*4 doubles reserved behind the grid bounds
+  int* dcnt = S.cnt + C_COUNT;                  // 64 ints reserved behind the counter block
+  HIPCHK(c, hipMemcpyAsync(dbox, boxes, (size_t)nranks * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dcnt, 0, 64 * sizeof(int), c->stream));
+  hipLaunchKernelGGL(sz_k_halo_pack, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, nranks, me, dbox, Lx, Ly,
+                     per_x, per_y, (double*)d_send, cap, dcnt);
+  HIPCHK(c, hipMemcpyAsync(counts_out, dcnt, (size_t)nranks * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  return sync_and_check(c);
+}
+
+int sz_halo_unpack(sz_ctx* c, const void* d_recv, int64_t nrec) {
+  if (!c || !c->have_floes || nrec < 0 || (nrec > 0 && !d_recv)) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  State& S = c->S;
+  if (nrec > S.capM) { c->err = "halo larger than the floe capacity"; return SZ_E_CAPACITY; }
+  hipLaunchKernelGGL(sz_k_halo_count, dim3(grid_for(nrec, 256)), dim3(256), 0, c->stream, S, (const double*)d_recv, (int)nrec);
+  scan(c, S.gvcnt, S.gvscan, S.capM, -1, (int)nrec, -1);
+  hipLaunchKernelGGL(sz_k_halo_unpack, dim3(grid_for(nrec, 128)), dim3(128), 0, c->stream, S, (const double*)d_recv, (int)nrec);
+  int rc = sync_and_check(c);
+  if (rc) return rc;
+  c->fuse_lists.resize(c->hostM);
+  return SZ_OK;
+}
+
+// one timestep_sim! on the local set (owned + halo parents); the halo is dropped afterwards
+int sz_tile_step(sz_ctx* c, int32_t tstep, int32_t dt, int32_t coupling_dt, int32_t flags) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  stage_ghosts(c);
+  if (flags & SZ_COLLISIONS_ON) collisions(c, c->hostN, dt);
+  hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
+  hipLaunchKernelGGL(sz_k_halo_drop, dim3(1), dim3(64), 0, c->stream, c->S);
+  if ((flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0) stage_forcing(c);
+  stage_integrate(c, dt);
+  return sync_and_check(c);
+}
 
 }  // extern "C"

@@ -174,6 +174,9 @@ __global__ void sz_k_ghost_fill(State S, int axis) {
       vb += n;
       S.ghost_id[g] = (long long)(k + 1 + ng);
       S.parent[g] = i;
+      // serial-order key: ghosts come after every parent, E/W-pass ghosts before N/S-pass ghosts,
+      // inside a pass by parent and copy number (collisions.jl:1024-1045)
+      S.okey[g] = S.tiled ? ((long long)(axis + 1) << 40) + S.okey[i] * 4 + k : (long long)g;
       for (int q = 0; q < MAX_GHOSTS; q++) S.gh[g * MAX_GHOSTS + q] = -1;
     }
     for (int k = 0; k <= ng; k++) S.gh[i * MAX_GHOSTS + ng + k] = base + k;
@@ -282,8 +285,12 @@ __device__ bool pair_allowed(const State& S, int i, int j) {   // i < j, ids dif
     int fx = x < 0 ? pi : S.gh[pi * MAX_GHOSTS + x];
     for (int y = -1; y < nj; y++) {
       int fy = y < 0 ? pj : S.gh[pj * MAX_GHOSTS + y];
-      int a = fx < fy ? fx : fy, b = fx < fy ? fy : fx;
-      if (a > ba || (a == ba && b >= bb)) continue;
+      bool lt = S.okey[fx] < S.okey[fy];
+      int a = lt ? fx : fy, b = lt ? fy : fx;
+      if (ba != 0x7fffffff) {
+        long long ka = S.okey[a], kb = S.okey[b], kba = S.okey[ba], kbb = S.okey[bb];
+        if (ka > kba || (ka == kba && kb >= kbb)) continue;
+      }
       if (circles_touch(S, a, b)) { ba = a; bb = b; }
     }
   }
@@ -303,7 +310,7 @@ __global__ void sz_k_neighbors(State S) {
     int ix = (int)floor((S.cx[k] - x0) / cs), iy = (int)floor((S.cy[k] - y0) / cs);
     int no = 0, ni = 0; bool ovf = false;
     int* lo = S.nb_out + (size_t)k * MAXNB; int* li = S.nb_in + (size_t)k * MAXNB;
-    long long idk = S.id[k];
+    long long idk = S.id[k], okk = S.okey[k];
     for (int dy = -1; dy <= 1; dy++) {
       int cy = iy + dy; if (cy < 0 || cy >= ncy) continue;
       for (int dx = -1; dx <= 1; dx++) {
@@ -313,13 +320,15 @@ __global__ void sz_k_neighbors(State S) {
         for (int t = b; t < e; t++) {
           int o = S.cell_items[t];
           if (o == k || S.id[o] == idk) continue;
-          int a = o < k ? o : k, bb = o < k ? k : o;
+          long long ko = S.okey[o];
+          bool after = ko > okk;                   // o comes after k in the serial order
+          int a = after ? k : o, bb = after ? o : k;
           if (!circles_touch(S, a, bb)) continue;
           if (!pair_allowed(S, a, bb)) continue;
-          int* l = o > k ? lo : li; int& n = o > k ? no : ni;
+          int* l = after ? lo : li; int& n = after ? no : ni;
           if (n >= MAXNB) { ovf = true; continue; }
           int u = n - 1;
-          while (u >= 0 && l[u] > o) { l[u + 1] = l[u]; u--; }
+          while (u >= 0 && S.okey[l[u]] > ko) { l[u + 1] = l[u]; u--; }
           l[u + 1] = o; n++;
         }
       }
@@ -473,7 +482,8 @@ __global__ void sz_k_items_clear(State S) {
 // ============================================================================ reduce (A9, A11)
 __device__ __forceinline__ int find_pair(const State& S, int i, int k) {   // index of pair (i, k), i < k; -1 if absent
   int lo = S.out_off[i], hi = S.out_off[i + 1];
-  while (lo < hi) { int mid = (lo + hi) >> 1; int v = S.pair_j[mid]; if (v < k) lo = mid + 1; else hi = mid; }
+  long long kk = S.okey[k];
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (S.okey[S.pair_j[mid]] < kk) lo = mid + 1; else hi = mid; }
   return (lo < S.out_off[i + 1] && S.pair_j[lo] == k) ? lo : -1;
 }
 
@@ -511,7 +521,7 @@ __device__ int emit_rows(const State& S, int f, double* dst, double sx, double s
     int n = S.it_nrows[p]; const double* src = S.it_rows + (size_t)p * ROWS_PER_ITEM * 5;
     for (int r = 0; r < n; r++) {
       double* d = dst + (size_t)(c++) * 7; const double* s = src + r * 5;
-      d[0] = (double)(S.pair_j[p] + 1); d[1] = s[0]; d[2] = s[1]; d[3] = s[2] - sx; d[4] = s[3] - sy; d[5] = 0.0; d[6] = s[4];
+      d[0] = (double)(S.okey[S.pair_j[p]] + 1); d[1] = s[0]; d[2] = s[1]; d[3] = s[2] - sx; d[4] = s[3] - sy; d[5] = 0.0; d[6] = s[4];
       *over_sum += s[4];
     }
   }
@@ -532,7 +542,7 @@ __device__ int emit_rows(const State& S, int f, double* dst, double sx, double s
       int n = S.it_nrows[p]; const double* src = S.it_rows + (size_t)p * ROWS_PER_ITEM * 5;
       for (int r = 0; r < n; r++) {
         double* d = dst + (size_t)(c++) * 7; const double* s = src + r * 5;
-        d[0] = (double)(i + 1); d[1] = s[0] * -1; d[2] = s[1] * -1; d[3] = s[2] - sx; d[4] = s[3] - sy; d[5] = 0.0; d[6] = s[4];
+        d[0] = (double)(S.okey[i] + 1); d[1] = s[0] * -1; d[2] = s[1] * -1; d[3] = s[2] - sx; d[4] = s[3] - sy; d[5] = 0.0; d[6] = s[4];
         *over_sum += s[4];
       }
     }
@@ -612,7 +622,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // one wavefront per floe, lanes over the sub-floe points
 __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
-  int N = S.cnt[C_N];
+  int N = S.cnt[C_NOWN];
   int lane = threadIdx.x & 63, wpb = blockDim.x >> 6, wid = threadIdx.x >> 6;
   int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
   double cturn = cos(P.turn), sturn = sin(P.turn);
@@ -668,7 +678,7 @@ __device__ __forceinline__ double sgn(double x) { return (double)((x > 0) - (x <
 
 // one thread per floe: stress, guards, thermodynamics, AB2 velocity update; stores the motion
 __global__ void sz_k_integrate(State S, Params P, int dt) {
-  int N = S.cnt[C_N];
+  int N = S.cnt[C_NOWN];
   int wh = 0, wf = 0, wv = 0, wx = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
     double cfx = S.cfx[i], cfy = S.cfy[i], ctrq = S.ctrq[i];
@@ -735,7 +745,7 @@ __global__ void sz_k_integrate(State S, Params P, int dt) {
 __global__ void __launch_bounds__(256) sz_k_move_strain(State S) {
   constexpr int G = 16;
   __shared__ double t11[256 / G][64], t12[256 / G][64], t22[256 / G][64];
-  int N = S.cnt[C_N];
+  int N = S.cnt[C_NOWN];
   int gl = threadIdx.x % G, gi = threadIdx.x / G, gpb = blockDim.x / G;
   for (int i = blockIdx.x * gpb + gi; i < N; i += gridDim.x * gpb) {
     double cx = S.cx[i], cy = S.cy[i];
@@ -779,6 +789,97 @@ __global__ void __launch_bounds__(256) sz_k_move_strain(State S) {
       S.strain[i * 4 + 0] = e11 / d; S.strain[i * 4 + 1] = e12 / d; S.strain[i * 4 + 2] = e12 / d; S.strain[i * 4 + 3] = e22 / d;
       S.cx[i] = ncx; S.cy[i] = ncy;
     }
+  }
+}
+
+// ============================================================================ halo exchange (multi-GPU)
+// One record per floe sent to another rank: the columns the collision path reads + the ring.
+constexpr int HALO_RING = 32;
+constexpr int HALO_REC = 12 + 2 * HALO_RING;   // doubles
+
+// Every owned floe whose centroid -- or one of its periodic images -- lies inside another rank's
+// (already expanded) box is written to that rank's region of the send buffer.
+__global__ void sz_k_halo_pack(State S, int nranks, int me, const double* boxes, double Lx, double Ly, int per_x,
+                               int per_y, double* send, int cap, int* counts) {
+  int n = S.cnt[C_NOWN];
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+    double cx = S.cx[q], cy = S.cy[q];
+    int o = S.voff[q], nv = S.voff[q + 1] - o;
+    for (int d = 0; d < nranks; d++) {
+      if (d == me) continue;
+      const double* b = boxes + 4 * d;
+      bool hit = false;
+      for (int kx = (per_x ? -1 : 0); kx <= (per_x ? 1 : 0) && !hit; kx++)
+        for (int ky = (per_y ? -1 : 0); ky <= (per_y ? 1 : 0) && !hit; ky++) {
+          double x = cx + kx * Lx, y = cy + ky * Ly;
+          hit = (b[0] <= x && x <= b[1] && b[2] <= y && y <= b[3]);
+        }
+      if (!hit) continue;
+      int slot = atomicAdd(&counts[d], 1);
+      if (slot >= cap || nv > HALO_RING) { atomicOr(&S.cnt[C_ERR], nv > HALO_RING ? ERR_CAP_RING : ERR_CAP_FLOES); continue; }
+      double* r = send + ((size_t)d * cap + slot) * HALO_REC;
+      r[0] = (double)S.okey[q]; r[1] = (double)S.status[q]; r[2] = (double)nv; r[3] = cx; r[4] = cy; r[5] = S.rmax[q];
+      r[6] = S.area[q]; r[7] = S.height[q]; r[8] = S.u[q]; r[9] = S.v[q]; r[10] = S.xi[q]; r[11] = (double)S.id[q];
+      for (int k = 0; k < nv; k++) { r[12 + k] = S.vx[o + k]; r[12 + HALO_RING + k] = S.vy[o + k]; }
+    }
+  }
+}
+__global__ void sz_k_halo_count(State S, const double* recv, int nrec) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nrec; t += gridDim.x * blockDim.x)
+    S.gvcnt[t] = (int)recv[(size_t)t * HALO_REC + 2];
+}
+// appends the received floes as extra parents [nown, nown + nrec)
+__global__ void sz_k_halo_unpack(State S, const double* recv, int nrec) {
+  int nown = S.cnt[C_NOWN];
+  int vbase = S.voff[nown];
+  int totv = nrec > 0 ? S.gvscan[nrec] : 0;
+  if (nown + nrec > S.capM || vbase + totv > S.capV) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], nown + nrec > S.capM ? ERR_CAP_FLOES : ERR_CAP_VERTS);
+    return;
+  }
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nrec; t += gridDim.x * blockDim.x) {
+    const double* r = recv + (size_t)t * HALO_REC;
+    int g = nown + t, nv = (int)r[2], vb = vbase + S.gvscan[t];
+    S.okey[g] = (long long)r[0]; S.status[g] = (int)r[1]; S.cx[g] = r[3]; S.cy[g] = r[4]; S.rmax[g] = r[5];
+    S.area[g] = r[6]; S.height[g] = r[7]; S.u[g] = r[8]; S.v[g] = r[9]; S.xi[g] = r[10]; S.id[g] = (long long)r[11];
+    S.ghost_id[g] = 0; S.parent[g] = g; S.ngh[g] = 0; S.overarea[g] = 0.0;
+    S.mass[g] = 0.0; S.moment[g] = 0.0; S.alpha[g] = 0.0;
+    for (int q = 0; q < MAX_GHOSTS; q++) S.gh[g * MAX_GHOSTS + q] = -1;
+    S.voff[g] = vb; S.voff[g + 1] = vb + nv;
+    for (int k = 0; k < nv; k++) { S.vx[vb + k] = r[12 + k]; S.vy[vb + k] = r[12 + HALO_RING + k]; }
+    S.osign[g] = ring_signed_area(S.vx + vb, S.vy + vb, nv) >= 0.0 ? 1 : -1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    S.cnt[C_M] = nown + nrec; S.cnt[C_N] = nown + nrec; S.cnt[C_NV] = vbase + totv; S.cnt[C_NHALO] = nrec;
+  }
+}
+// after the step: forget the halo floes (their owners integrate them)
+__global__ void sz_k_halo_drop(State S) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int nown = S.cnt[C_NOWN];
+    S.cnt[C_M] = nown; S.cnt[C_N] = nown; S.cnt[C_NV] = S.voff[nown];
+  }
+}
+// bounding box of the owned centroids and the largest rmax: out[0..4] = xmin, xmax, ymin, ymax, rmax
+__global__ void __launch_bounds__(1024) sz_k_owned_box(State S, double* out) {
+  __shared__ double sh[5][16];
+  int n = S.cnt[C_NOWN];
+  double x0 = __builtin_inf(), y0 = __builtin_inf(), x1 = -__builtin_inf(), y1 = -__builtin_inf(), rm = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    x0 = fmin(x0, S.cx[i]); x1 = fmax(x1, S.cx[i]); y0 = fmin(y0, S.cy[i]); y1 = fmax(y1, S.cy[i]); rm = fmax(rm, S.rmax[i]);
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    x0 = fmin(x0, __shfl_xor(x0, d)); y0 = fmin(y0, __shfl_xor(y0, d));
+    x1 = fmax(x1, __shfl_xor(x1, d)); y1 = fmax(y1, __shfl_xor(y1, d)); rm = fmax(rm, __shfl_xor(rm, d));
+  }
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { sh[0][wid] = x0; sh[1][wid] = y0; sh[2][wid] = x1; sh[3][wid] = y1; sh[4][wid] = rm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
+      x0 = fmin(x0, sh[0][w]); y0 = fmin(y0, sh[1][w]); x1 = fmax(x1, sh[2][w]); y1 = fmax(y1, sh[3][w]); rm = fmax(rm, sh[4][w]);
+    }
+    out[0] = x0; out[1] = x1; out[2] = y0; out[3] = y1; out[4] = rm;
   }
 }
 

@@ -25,7 +25,9 @@ enum {
   C_NGHOSTS,
   C_NCELLS,
   C_SCRATCH0, C_SCRATCH1,
-  C_TRACE_FAIL,   // traces abandoned by the guard (diagnostic, cumulative)
+  C_TRACE_FAIL,
+  C_NOWN,         // floes this context integrates (== C_N unless tiled: owned floes come first)
+  C_NHALO,   // traces abandoned by the guard (diagnostic, cumulative)
   C_COUNT = 32
 };
 
@@ -45,6 +47,7 @@ struct State {
   int capM, capV, capPairs, capElem, capRows, capCells, capS;
   int nelem;                 // 4 boundaries + topography elements
   int any_periodic_ew, any_periodic_ns, any_domain_work;
+  int tiled;                 // halo mode: order keys are global indices
   // ---- counters
   int* cnt;
   // ---- floe columns
@@ -52,7 +55,7 @@ struct State {
   double *p_dxdt, *p_dydt, *p_dalphadt, *p_dudt, *p_dvdt, *p_dxidt;
   double *fxOA, *fyOA, *trqOA, *hflx, *overarea, *cfx, *cfy, *ctrq;
   double *sa, *si, *strain;   // 4 per floe
-  long long *id, *ghost_id;
+  long long *id, *ghost_id, *okey;   // okey: position in the reference's serial order
   int *status, *parent, *gh, *ngh;   // gh: MAX_GHOSTS per floe
   signed char* osign;                // ring orientation sign
   int* voff; double *vx, *vy;

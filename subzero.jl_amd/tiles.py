@@ -1,0 +1,174 @@
+"""Multi-GPU sharding of the floe population by spatial tile with a ghost-floe halo.
+
+One process per GPU.  The domain box is cut into px x py tiles; a rank OWNS the floes whose
+centroid lies in its tile at partition time and keeps them for the whole run (floes move metres
+per step against tile sizes of hundreds of kilometres; `repartition` is a rare host-side
+operation).  Every step each rank
+
+  1. packs, on the device, the owned floes that any other rank may need: those whose centroid --
+     or a periodic image of it -- lies inside the other rank's owned bounding box expanded by the
+     interaction range 2*max(rmax) (+ a drift margin);
+  2. trades them with ONE all-to-all-v (`all_to_all_single` with split sizes: RCCL over xGMI; the
+     messages are KB-scale, the exchange is latency-bound);
+  3. appends the received records as extra floes and runs the ordinary single-GPU timestep on
+     owned + halo floes.  Order-dependent rules (which floe of a pair is p1, the Dict rule, row
+     order) use the floes' GLOBAL indices, so every pair is evaluated with the same roles on
+     every rank that sees it and the owned floes get bit-identical contact rows to a single-GPU
+     run; cross-tile pairs are evaluated on both sides instead of shipping rows back.
+  4. Only owned floes are integrated; the halo is dropped and rebuilt next step.
+
+The periodic ghost floes of the reference (collisions.jl:881-1047) are created locally from the
+local parents (owned or halo) by the same kernels as in the single-GPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .host import World
+
+
+def tile_grid(world):
+    """px x py with px >= py and px*py == world: 1x1, 2x1, 2x2, 4x2, ..."""
+    py = int(np.floor(np.sqrt(world)))
+    while world % py:
+        py -= 1
+    return world // py, py
+
+
+def assign_tiles(cx, cy, L, world):
+    px, py = tile_grid(world)
+    ix = np.clip((cx / L * px).astype(int), 0, px - 1)
+    iy = np.clip((cy / L * py).astype(int), 0, py - 1)
+    return iy * px + ix
+
+
+def select_halo(cx, cy, box, Lx, Ly, per_x, per_y):
+    """Host-side statement of the pack rule (used by the CPU tests): mask of floes whose centroid
+    or one of its periodic images lies inside `box` = (xmin, xmax, ymin, ymax)."""
+    hit = np.zeros(len(cx), bool)
+    for kx in ((-1, 0, 1) if per_x else (0,)):
+        for ky in ((-1, 0, 1) if per_y else (0,)):
+            x = cx + kx * Lx; y = cy + ky * Ly
+            hit |= (box[0] <= x) & (x <= box[1]) & (box[2] <= y) & (y <= box[3])
+    return hit
+
+
+def expanded_box(b5, margin):
+    """b5 = xmin, xmax, ymin, ymax, rmax of the owned floes -> box expanded by 2*rmax + margin."""
+    r = 2.0 * b5[4] + margin
+    return np.array([b5[0] - r, b5[1] + r, b5[2] - r, b5[3] + r])
+
+
+def subset_config(cfg, idx):
+    """The columns of a fields.make_config() scenario restricted to the floes `idx` (sorted)."""
+    off = cfg["vert_off"]; so = cfg["sub_off"]
+    nv = np.diff(off)[idx]; ns = np.diff(so)[idx]
+    voff = np.zeros(len(idx) + 1, np.int32); voff[1:] = np.cumsum(nv)
+    soff = np.zeros(len(idx) + 1, np.int32); soff[1:] = np.cumsum(ns)
+    vsel = np.concatenate([np.arange(off[i], off[i + 1]) for i in idx]) if len(idx) else np.zeros(0, int)
+    ssel = np.concatenate([np.arange(so[i], so[i + 1]) for i in idx]) if len(idx) else np.zeros(0, int)
+    d = cfg["derived"]
+    cols = dict(cx=d["cx"][idx], cy=d["cy"][idx], rmax=d["rmax"][idx], area=d["area"][idx], height=d["height"][idx],
+                mass=d["mass"][idx], moment=d["moment"][idx], u=cfg["u"][idx], v=cfg["v"][idx], xi=cfg["xi"][idx],
+                vert_off=voff, vx=cfg["vx"][vsel], vy=cfg["vy"][vsel],
+                id=(np.asarray(idx) + 1).astype(np.int64))
+    return cols, soff, cfg["sx"][ssel], cfg["sy"][ssel]
+
+
+class TiledWorld:
+    """One rank of a tiled run.  `dist` is torch.distributed (initialised) or None for world == 1."""
+
+    def __init__(self, cfg, rank, world, device, dist, drift_margin=2000.0, rebox_every=50, host_staging=False,
+                 always_exchange=False):
+        import torch
+        self.torch = torch
+        self.cfg, self.rank, self.nranks, self.dist = cfg, rank, world, dist
+        self.host_staging = host_staging          # gloo: exchange through CPU tensors
+        self.always_exchange = always_exchange    # run the collectives even with one rank (tests)
+        self.L = cfg["L"]
+        self.per_x = cfg["kinds"][2] == "periodic"; self.per_y = cfg["kinds"][0] == "periodic"
+        owner = assign_tiles(cfg["derived"]["cx"], cfg["derived"]["cy"], self.L, world)
+        self.gidx = np.nonzero(owner == rank)[0]
+        cols, soff, sx, sy = subset_config(cfg, self.gidx)
+        from . import fields
+        w = World(device)
+        w.set_consts(E=cfg["E"]); w.set_settings()
+        w.set_domain([fields.KIND[k] for k in cfg["kinds"]], 0.0, self.L, 0.0, self.L)
+        if cfg["topography"]:
+            w.set_topography(cfg["topography"])
+        w.set_grid_fields(cfg["Nx"], cfg["Ny"], 0.0, self.L, 0.0, self.L, cfg["uo"], cfg["vo"], cfg["hf"], cfg["ua"], cfg["va"])
+        w.load_columns(cols); w.set_subpoints_csr(soff, sx, sy)
+        w._push()
+        g = np.ascontiguousarray(self.gidx, np.int64)
+        w._chk(w.L.sz_tile_enable(w.h, capi.ptr(g, capi._lp), 0.0))
+        self.world = w
+        self.REC = w.L.sz_halo_record_doubles()
+        self.cap = max(256, len(self.gidx) // 2 + 64)
+        self.dev = torch.device("cuda", device)
+        self.send = torch.zeros(world * self.cap * self.REC, dtype=torch.float64, device=self.dev)
+        self.margin, self.rebox_every = drift_margin, rebox_every
+        self.boxes = None
+        self.steps_since_box = 0
+        self.n_halo_last = 0
+
+    # ---- collectives
+    def _allgather_boxes(self):
+        w = self.world
+        b5 = np.zeros(5)
+        w._chk(w.L.sz_owned_box(w.h, capi.ptr(b5)))
+        t = self.torch.tensor(b5, dtype=self.torch.float64, device="cpu" if self.host_staging else self.dev)
+        out = [self.torch.zeros_like(t) for _ in range(self.nranks)]
+        self.dist.all_gather(out, t)
+        allb = np.stack([o.cpu().numpy() for o in out])
+        rmax = allb[:, 4].max()
+        allb[:, 4] = rmax
+        self.boxes = np.ascontiguousarray(np.stack([expanded_box(b, self.margin) for b in allb]))
+        self.steps_since_box = 0
+
+    def exchange(self):
+        """steps 1-3 of the module docstring: returns the number of halo floes received."""
+        torch, dist, w = self.torch, self.dist, self.world
+        if self.boxes is None or self.steps_since_box >= self.rebox_every:
+            self._allgather_boxes()
+        self.steps_since_box += 1
+        counts = np.zeros(self.nranks, np.int32)
+        w._chk(w.L.sz_halo_pack(w.h, self.nranks, self.rank, capi.ptr(self.boxes), self.L, self.L, int(self.per_x),
+                                int(self.per_y), C.c_void_p(self.send.data_ptr()), self.cap, capi.ptr(counts, capi._ip)))
+        sview = self.send.view(self.nranks, self.cap * self.REC)
+        chunks = [sview[d, :int(counts[d]) * self.REC] for d in range(self.nranks)]
+        sbuf = torch.cat(chunks) if counts.sum() else torch.zeros(0, dtype=torch.float64, device=self.dev)
+        cdev = "cpu" if self.host_staging else self.dev
+        tc = torch.tensor(counts.astype(np.int64), device=cdev); rc = torch.zeros_like(tc)
+        dist.all_to_all_single(rc, tc)
+        rcounts = rc.cpu().numpy()
+        in_split = [int(c) * self.REC for c in counts]; out_split = [int(c) * self.REC for c in rcounts]
+        if self.host_staging:
+            sb = sbuf.cpu(); rb = torch.zeros(sum(out_split), dtype=torch.float64)
+            dist.all_to_all_single(rb, sb, out_split, in_split)
+            rbuf = rb.to(self.dev)
+        else:
+            rbuf = torch.zeros(sum(out_split), dtype=torch.float64, device=self.dev)
+            dist.all_to_all_single(rbuf, sbuf, out_split, in_split)
+        torch.cuda.synchronize()
+        nrec = int(rcounts.sum())
+        self._rbuf = rbuf                      # keep alive until unpack has consumed it
+        w._chk(w.L.sz_halo_unpack(w.h, C.c_void_p(rbuf.data_ptr()) if nrec else None, nrec))
+        self.n_halo_last = nrec
+        return nrec
+
+    def step(self, tstep, dt, coupling_dt=10, collisions_on=True, coupling_on=True):
+        w = self.world
+        if self.nranks > 1 or self.always_exchange:
+            self.exchange()
+        flags = (capi.COLLISIONS_ON if collisions_on else 0) | (capi.COUPLING_ON if coupling_on else 0)
+        w._chk(w.L.sz_tile_step(w.h, int(tstep), int(dt), int(coupling_dt), flags))
+        w._host_stale = True
+
+    def run(self, nsteps, tstep0, dt, coupling_dt=10, collisions_on=True, coupling_on=True):
+        for s in range(nsteps):
+            self.step(tstep0 + s, dt, coupling_dt, collisions_on, coupling_on)
+
+    def owned(self, name):
+        """column `name` of the owned floes (global indices in self.gidx)."""
+        return self.world.get(name)[:len(self.gidx)]
