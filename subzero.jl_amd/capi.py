@@ -55,7 +55,7 @@ EXPORTS = [
     "sz_add_ghosts", "sz_remove_ghosts", "sz_timestep_collisions", "sz_collide_pairs", "sz_collide_domain",
     "sz_timestep_coupling", "sz_timestep_floe_properties", "sz_step",
     "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms",
-    "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_pack", "sz_halo_unpack", "sz_tile_step",
+    "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_pack", "sz_halo_unpack", "sz_tile_step", "sz_debug_stamps",
 ]
 
 _LIB = None
@@ -112,6 +112,7 @@ def load(build_if_missing=True):
                                C.c_void_p, C.c_int32, _ip]
     L.sz_halo_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.sz_tile_step.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.sz_debug_stamps.argtypes = [C.c_void_p, _lp]
     for n in EXPORTS:
         if n not in ("sz_create", "sz_destroy", "sz_last_error", "sz_version"):
             getattr(L, n).restype = C.c_int

@@ -17,6 +17,9 @@ namespace {
 
 constexpr int NK = SZ_K_COUNT + 1;   // + large narrow variant
 constexpr int K_NARROW_LARGE = SZ_K_COUNT;
+#ifndef NARROW_G
+#define NARROW_G 8
+#endif
 
 struct EvPair { int k; hipEvent_t a, b; };
 
@@ -45,6 +48,7 @@ struct sz_ctx {
   std::vector<std::vector<int>> fuse_lists;
   long long* d_stats = nullptr;
   int last_dt = 0;
+  int dbg = 0;   // SZ_DEBUG bits: timing experiments only (1 skip contact rows, 2 skip direction check, 4 skip clip)
 };
 
 namespace {
@@ -207,13 +211,9 @@ void stage_broad(sz_ctx* c) {
   int gM = grid_for(S.capM, 256);
   hipLaunchKernelGGL(sz_k_bounds, dim3(1), dim3(1024), 0, c->stream, S);
   hipLaunchKernelGGL(sz_k_zero_int, dim3(grid_for(S.capCells, 256)), dim3(256), 0, c->stream, S.cell_cnt, S.cnt, C_NCELLS, 1);
-  hipLaunchKernelGGL(sz_k_zero_int, dim3(grid_for(S.capCells, 256)), dim3(256), 0, c->stream, S.cell_cur, S.cnt, C_NCELLS, 1);
-  hipLaunchKernelGGL(sz_k_cell_count, dim3(gM), dim3(256), 0, c->stream, S);
-  scan(c, S.cell_cnt, S.cell_off, S.capCells, C_NCELLS, 0, -1);
-  hipLaunchKernelGGL(sz_k_cell_fill, dim3(gM), dim3(256), 0, c->stream, S);
-  hipLaunchKernelGGL(sz_k_neighbors, dim3(grid_for(S.capM, 128)), dim3(128), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_cell_build, dim3(gM), dim3(256), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_neighbors, dim3(grid_for(S.capM, NB_TPB)), dim3(NB_TPB), 0, c->stream, S);
   scan(c, S.n_out, S.out_off, S.capM, C_M, 0, C_NPAIRS);
-  scan(c, S.n_in, S.in_off, S.capM, C_M, 0, -1);
   hipLaunchKernelGGL(sz_k_pairs_fill, dim3(gM), dim3(256), 0, c->stream, S);
   t.end();
 }
@@ -238,19 +238,21 @@ void stage_elems(sz_ctx* c, bool enabled) {
 void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo) {
   State& S = c->S;
   long long capItems = (long long)S.capPairs + S.capElem;
+  (void)hipMemsetAsync(S.cnt + C_ITEMCLASS, 0, sizeof(int), c->stream);
   hipLaunchKernelGGL(sz_k_items_clear, dim3(grid_for(capItems, 256)), dim3(256), 0, c->stream, S);
   {
     Timed t(c, SZ_K_NARROW);
-    constexpr int G = 16, TPB = 128;
-    hipLaunchKernelGGL((sz_k_narrow<G, 32, 16, 80, TPB, 0>), dim3(grid_for(capItems, TPB / G, 8192)), dim3(TPB), 0, c->stream,
-                       S, c->P, dt, ffmo, fdmo);
+    constexpr int G = NARROW_G, TPB = 64;
+    hipLaunchKernelGGL((sz_k_narrow<G, NARROW_CAP0, 12, 48, 4, TPB, 0, 0>), dim3(grid_for(capItems, TPB / G, 1536)), dim3(TPB), 0,
+                       c->stream, S, c->P, dt, ffmo, fdmo, c->dbg);
     t.end();
   }
   {
     Timed t(c, K_NARROW_LARGE);
-    constexpr int G = 64, TPB = 64;
-    hipLaunchKernelGGL((sz_k_narrow<G, 128, 64, 320, TPB, 32>), dim3(grid_for(capItems, 1, 2048)), dim3(TPB), 0, c->stream,
-                       S, c->P, dt, ffmo, fdmo);
+    hipLaunchKernelGGL((sz_k_narrow<16, NARROW_CAP1, 16, 80, 6, 64, NARROW_CAP0, 1>), dim3(grid_for(capItems, 4, 2048)), dim3(64), 0,
+                       c->stream, S, c->P, dt, ffmo, fdmo, c->dbg);
+    hipLaunchKernelGGL((sz_k_narrow<64, NARROW_CAP2, 64, 320, 6, 64, NARROW_CAP1, 2>), dim3(grid_for(capItems, 1, 2048)), dim3(64), 0,
+                       c->stream, S, c->P, dt, ffmo, fdmo, c->dbg);
     t.end();
   }
 }
@@ -329,6 +331,7 @@ sz_ctx* sz_create(int device_id) {
   if (hipSetDevice(device_id) != hipSuccess) return nullptr;
   sz_ctx* c = new sz_ctx();
   c->device = device_id;
+  if (const char* e = getenv("SZ_DEBUG")) c->dbg = atoi(e);
   if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; }
   // Constants() and default settings of the reference
   Params& P = c->P;
@@ -468,6 +471,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(cnt1, S.capM + 1); DA(tot, S.capM + 1); DA(inter_off, S.capM + 2); DA(inter_rows, (size_t)S.capRows * 7);
   DA(blk, std::max(S.capCells, std::max(S.capM, 1024)) / SCAN_B + 1024);
   DA(tagA, S.capM + 1);
+  DA(stamps, 16);
   int h[C_COUNT] = { 0 };
   h[C_M] = M; h[C_N] = N; h[C_NV] = V; h[C_NGHOSTS] = M - N; h[C_NOWN] = N;
   S.tiled = 0;
@@ -718,6 +722,15 @@ int sz_owned_box(sz_ctx* c, double* out5) {
 }
 
 int sz_halo_record_doubles(void) { return HALO_REC; }
+
+// diagnostic build only: cycles per narrow-phase stage, summed over groups (zeros otherwise)
+int sz_debug_stamps(sz_ctx* c, long long* out16) {
+  if (!c || !c->have_floes || !out16) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipMemcpy(out16, c->S.stamps, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemset(c->S.stamps, 0, 16 * sizeof(long long)));
+  return SZ_OK;
+}
 
 int sz_halo_pack(sz_ctx* c, int32_t nranks, int32_t me, const double* boxes, double Lx, double Ly, int32_t per_x,
                  int32_t per_y, void* d_send, int32_t cap, int32_t* counts_out) {

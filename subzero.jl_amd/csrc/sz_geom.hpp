@@ -29,31 +29,43 @@ namespace szg {
 
 #define SZ_DEV __device__ __forceinline__
 
+// In-kernel phase stamps for the diagnostic build only (-DSZ_STAMPS): cycles per phase summed
+// over all groups.  The production build compiles them out.
+#ifdef SZ_STAMPS
+struct Stamps { long long t, t0; long long acc[16]; };
+#define STAMP_INIT(st) do { for (int q_ = 0; q_ < 16; q_++) (st).acc[q_] = 0; (st).t = clock64(); (st).t0 = (st).t; } while (0)
+#define STAMP(st, k) do { long long n_ = clock64(); (st).acc[k] += n_ - (st).t; (st).t = n_; } while (0)
+#else
+struct Stamps {};
+#define STAMP_INIT(st) do {} while (0)
+#define STAMP(st, k) do {} while (0)
+#endif
+
 SZ_DEV void gsync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
 
-constexpr int RMAX = 6;   // regions kept per clip
-
-// LDS working set of one group.  CAP: ring points per polygon, KC: crossings, RC: region points.
-template <int CAP, int KC, int RC>
+// LDS working set of one group.  CAP: ring points per polygon, KC: crossings, RC: region points
+// per clip, RM: regions per clip.  The set is kept small on purpose: the number of pairs in
+// flight per CU is 160 KB / sizeof(GroupMem), and the narrow phase is latency-bound.
+template <int CAP, int KC, int RC, int RM>
 struct GroupMem {
+  static constexpr int RMAXV = RM;
   double ax[CAP], ay[CAP], bx[CAP], by[CAP];
-  double tx[CAP], ty[CAP];                 // p1 translated by the force direction
-  // crossings in canonical (ia, ib) order
-  double cta[KC], ctb[KC], cx[KC], cy[KC];
-  // raw detection slots
-  double rta[KC], rtb[KC], rcx[KC], rcy[KC];
-  double earr[RC], farr[RC], garr[RC];     // per-edge scratch (many-intersect)
-  double rx[2][RC], ry[2][RC];             // region rings of clip 0 (contact) and clip 1 (check)
-  double rarea[2][RMAX];
-  double red[64 * 4];                      // per-lane partials (bbox)
+  double cta[KC], ctb[KC], cx[KC], cy[KC];   // crossings in canonical (ia, ib) order
+  double reg[2][2][RC];                      // region rings [clip][x|y][point]; reg[1] doubles as the
+                                             // raw crossing slots during detection (4*KC <= 2*RC)
+  double rarea[2][RM];
+  double rcx[RM], rcy[RM];                   // centroids of the regions of clip 0
+  uint32_t cinfo[KC];                        // per crossing: ia | ib<<7 | rankA<<14 | rankB<<20 | flags<<26
   int16_t cia[KC], cib[KC], ria[KC], rib[KC];
-  int16_t ordA[KC], ordB[KC], rnkA[KC], rnkB[KC];
-  int16_t midx[KC];                        // matched region-vertex index per ipoint
-  int16_t roff[2][RMAX + 2];
+  int16_t rnkB[KC];                          // scratch of match_vertices
+  int16_t midx[KC];                          // matched region-vertex index per ipoint
+  uint8_t ordA[KC], ordB[KC];                // crossing id at rank r along a / b
+  int16_t roff[2][RM + 2];
   uint8_t cfl[KC], rfl[KC], uniq[KC];
+  int8_t ecode[RC];                          // many-intersect per-edge class
   int nraw, nx, nreg[2], flag, err, ntracefail;
 };
 
@@ -88,6 +100,7 @@ SZ_DEV bool on_segment(double ax, double ay, double bx, double by, double cx, do
 // 1 inside, 0 outside, -1 on the boundary (ring closed, n points)
 SZ_DEV int point_in_ring3(double x, double y, const double* rx, const double* ry, int n) {
   int inside = 0;
+#pragma unroll 4
   for (int i = 0; i + 1 < n; i++) {
     double ax = rx[i], ay = ry[i], bx = rx[i + 1], by = ry[i + 1];
     double o = orient(ax, ay, bx, by, x, y);
@@ -102,31 +115,57 @@ SZ_DEV int point_in_ring3(double x, double y, const double* rx, const double* ry
 SZ_DEV bool coveredby(double x, double y, const double* rx, const double* ry, int n) {
   return point_in_ring3(x, y, rx, ry, n) != 0;
 }
-SZ_DEV bool ring_inside(const double* ax, const double* ay, int na, const double* bx, const double* by, int nb) {
+// is ring a (+ offset) inside ring b, given that their boundaries do not cross
+SZ_DEV bool ring_inside(const double* ax, const double* ay, int na, double ox, double oy, const double* bx, const double* by, int nb) {
   for (int i = 0; i + 1 < na; i++) {
-    int c = point_in_ring3(ax[i], ay[i], bx, by, nb);
+    int c = point_in_ring3(ax[i] + ox, ay[i] + oy, bx, by, nb);
     if (c >= 0) return c != 0;
   }
   return true;
 }
-SZ_DEV double dist_pt_seg(double x0, double y0, double ax, double ay, double bx, double by) {
+// 1 inside, 0 outside, -1 on the boundary of ring (rx + ox, ry + oy)
+SZ_DEV int point_in_ring3_off(double x, double y, const double* rx, const double* ry, int n, double ox, double oy) {
+  int inside = 0;
+#pragma unroll 4
+  for (int i = 0; i + 1 < n; i++) {
+    double ax = rx[i] + ox, ay = ry[i] + oy, bx = rx[i + 1] + ox, by = ry[i + 1] + oy;
+    double o = orient(ax, ay, bx, by, x, y);
+    if (o == 0.0 && on_segment(ax, ay, bx, by, x, y)) return -1;
+    if ((ay > y) != (by > y)) {
+      if (by > ay) { if (o > 0.0) inside = !inside; }
+      else         { if (o < 0.0) inside = !inside; }
+    }
+  }
+  return inside;
+}
+SZ_DEV bool ring_inside_off(const double* bx, const double* by, int nb, const double* ax, const double* ay, int na, double ox, double oy) {
+  for (int i = 0; i + 1 < nb; i++) {
+    int c = point_in_ring3_off(bx[i], by[i], ax, ay, na, ox, oy);
+    if (c >= 0) return c != 0;
+  }
+  return true;
+}
+// squared GO._euclid_distance(point, segment); sqrt is monotone and correctly rounded, so
+// min over edges of sqrt(d2) == sqrt(min over edges of d2) bit for bit
+SZ_DEV double dist2_pt_seg(double x0, double y0, double ax, double ay, double bx, double by) {
   double vx = bx - ax, vy = by - ay;
   double wx = x0 - ax, wy = y0 - ay;
   double c1 = wx * vx + wy * vy;
-  if (c1 <= 0.0) return sqrt((x0 - ax) * (x0 - ax) + (y0 - ay) * (y0 - ay));
+  if (c1 <= 0.0) return (x0 - ax) * (x0 - ax) + (y0 - ay) * (y0 - ay);
   double c2 = vx * vx + vy * vy;
-  if (c2 <= c1) return sqrt((x0 - bx) * (x0 - bx) + (y0 - by) * (y0 - by));
+  if (c2 <= c1) return (x0 - bx) * (x0 - bx) + (y0 - by) * (y0 - by);
   double b2 = c1 / c2;
   double px = ax + b2 * vx, py = ay + b2 * vy;
-  return sqrt((x0 - px) * (x0 - px) + (y0 - py) * (y0 - py));
+  return (x0 - px) * (x0 - px) + (y0 - py) * (y0 - py);
 }
 SZ_DEV double dist_to_ring(double x, double y, const double* rx, const double* ry, int n) {
   double md = __builtin_inf();
+#pragma unroll 4
   for (int i = 0; i + 1 < n; i++) {
-    double d = dist_pt_seg(x, y, rx[i], ry[i], rx[i + 1], ry[i + 1]);
+    double d = dist2_pt_seg(x, y, rx[i], ry[i], rx[i + 1], ry[i + 1]);
     if (d < md) md = d;
   }
-  return md;
+  return sqrt(md);
 }
 SZ_DEV bool seg_seg_touch(double px, double py, double qx, double qy, double rx, double ry, double sx, double sy) {
   double o1 = orient(px, py, qx, qy, rx, ry), o2 = orient(px, py, qx, qy, sx, sy);
@@ -137,6 +176,23 @@ SZ_DEV bool seg_seg_touch(double px, double py, double qx, double qy, double rx,
   if (o3 == 0 && on_segment(rx, ry, sx, sy, px, py)) return true;
   if (o4 == 0 && on_segment(rx, ry, sx, sy, qx, qy)) return true;
   return false;
+}
+// one pass over a closed ring: GO._signed_area (sa) and the sums of GO.centroid (cx, cy); the
+// area terms of both formulas are the same products, so one accumulator serves both
+SZ_DEV void ring_area_centroid(const double* x, const double* y, int n, double& sa, double& cx, double& cy) {
+  double xc = 0.0, yc = 0.0, a2 = 0.0, p1x = x[0], p1y = y[0];
+#pragma unroll 4
+  for (int i = 1; i < n; i++) {
+    double p2x = x[i], p2y = y[i];
+    double ac = p1x * p2y - p2x * p1y;
+    a2 += ac;
+    xc += (p1x + p2x) * ac;
+    yc += (p1y + p2y) * ac;
+    p1x = p2x; p1y = p2y;
+  }
+  double ah = a2 / 2.0;
+  cx = xc / (6.0 * ah); cy = yc / (6.0 * ah);
+  sa = (a2 + (p1x * y[0] - p1y * x[0])) / 2.0;
 }
 // GO._signed_area on a closed ring
 SZ_DEV double ring_signed_area(const double* x, const double* y, int n) {
@@ -165,145 +221,180 @@ SZ_DEV void ring_centroid(const double* x, const double* y, int n, double& cx, d
   cy = yc / (6.0 * area);
 }
 
+template <int G>
+SZ_DEV double gmin(double v) { for (int d = G / 2; d >= 1; d >>= 1) v = fmin(v, __shfl_xor(v, d, G)); return v; }
+template <int G>
+SZ_DEV double gmax(double v) { for (int d = G / 2; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, G)); return v; }
+
 // ---------------------------------------------------------------------------------------------
-// clip(): regions of a ∩ b into buffer `buf` of the group memory.  a = (pax, pay, na) and
-// b = (m.bx, m.by, nb) are closed rings in LDS; oa/ob are their orientation signs.
-// Group-uniform: every lane must call it with the same arguments.
-template <int G, int CAP, int KC, int RC>
-SZ_DEV void clip(GroupMem<CAP, KC, RC>& m, int gl, const double* pax, const double* pay, int na,
-                 int oa, int nb, int ob, int buf) {
-  const double* pbx = m.bx; const double* pby = m.by;
+// clip(): regions of (a + (ox, oy)) ∩ b into buffer `buf`.  a = (m.ax, m.ay, na) and
+// b = (m.bx, m.by, nb) are closed rings in LDS; oa/ob their orientation signs.  The translation
+// is applied on the fly (x + 0.0 == x, so the untranslated clip is unchanged).
+// Group-uniform: every lane of the group calls it with the same arguments.
+template <int G, class MEM>
+SZ_DEV void clip(MEM& m, int gl, double ox, double oy, int na, int oa, int nb, int ob, int buf, bool skip_bbox, Stamps& st) {
+  constexpr int KC = sizeof(m.cta) / sizeof(double);
+  constexpr int RC = sizeof(m.ecode);
+  constexpr int RM = MEM::RMAXV;
+  const double* pax = m.ax; const double* pay = m.ay; const double* pbx = m.bx; const double* pby = m.by;
+  double* rgx = m.reg[buf][0]; double* rgy = m.reg[buf][1];
   if (gl == 0) { m.nraw = 0; m.nreg[buf] = 0; m.roff[buf][0] = 0; }
-  // ---- bounding boxes (lane partials, then every lane reduces the G partials)
-  {
+  if (na < 4 || nb < 4) { if (gl == 0) m.nx = 0; gsync(); return; }
+  if (!skip_bbox) {
     double x0 = __builtin_inf(), x1 = -__builtin_inf(), y0 = __builtin_inf(), y1 = -__builtin_inf();
     double u0 = x0, u1 = x1, v0 = y0, v1 = y1;
-    for (int i = gl; i < na; i += G) { x0 = fmin(x0, pax[i]); x1 = fmax(x1, pax[i]); y0 = fmin(y0, pay[i]); y1 = fmax(y1, pay[i]); }
+    for (int i = gl; i < na; i += G) { double x = pax[i] + ox, y = pay[i] + oy; x0 = fmin(x0, x); x1 = fmax(x1, x); y0 = fmin(y0, y); y1 = fmax(y1, y); }
     for (int i = gl; i < nb; i += G) { u0 = fmin(u0, pbx[i]); u1 = fmax(u1, pbx[i]); v0 = fmin(v0, pby[i]); v1 = fmax(v1, pby[i]); }
-    // overlap test needs min/max over the whole group: go through LDS
-    m.red[gl * 4 + 0] = x0; m.red[gl * 4 + 1] = x1; m.red[gl * 4 + 2] = y0; m.red[gl * 4 + 3] = y1;
-    gsync();
-    for (int l = 0; l < G; l++) { x0 = fmin(x0, m.red[l * 4]); x1 = fmax(x1, m.red[l * 4 + 1]); y0 = fmin(y0, m.red[l * 4 + 2]); y1 = fmax(y1, m.red[l * 4 + 3]); }
-    gsync();
-    m.red[gl * 4 + 0] = u0; m.red[gl * 4 + 1] = u1; m.red[gl * 4 + 2] = v0; m.red[gl * 4 + 3] = v1;
-    gsync();
-    for (int l = 0; l < G; l++) { u0 = fmin(u0, m.red[l * 4]); u1 = fmax(u1, m.red[l * 4 + 1]); v0 = fmin(v0, m.red[l * 4 + 2]); v1 = fmax(v1, m.red[l * 4 + 3]); }
-    gsync();
-    if (na < 4 || nb < 4 || x1 < u0 || u1 < x0 || y1 < v0 || v1 < y0) { m.nx = 0; gsync(); return; }
+    x0 = gmin<G>(x0); x1 = gmax<G>(x1); y0 = gmin<G>(y0); y1 = gmax<G>(y1);
+    u0 = gmin<G>(u0); u1 = gmax<G>(u1); v0 = gmin<G>(v0); v1 = gmax<G>(v1);
+    if (x1 < u0 || u1 < x0 || y1 < v0 || v1 < y0) { if (gl == 0) m.nx = 0; gsync(); return; }
   }
-  // ---- crossing detection: a-edges over lanes, all b-edges per lane
+  gsync();
+  STAMP(st, 1);
+  // ---- crossing detection, phase 1: which (a-edge, b-edge) pairs cross -- orientation signs only,
+  // a-edges over lanes.  Lanes of a wavefront diverge here, so the loop body is kept minimal; the
+  // divisions of the crossing parameters are done afterwards, once per crossing (phase 2).
+  double* raw = m.reg[1][0];
   for (int ia = gl; ia + 1 < na; ia += G) {
-    double px = pax[ia], py = pay[ia], qx = pax[ia + 1], qy = pay[ia + 1];
+    double px = pax[ia] + ox, py = pay[ia] + oy, qx = pax[ia + 1] + ox, qy = pay[ia + 1] + oy;
+    double rx = pbx[0], ry = pby[0];
+#pragma unroll 2
     for (int ib = 0; ib + 1 < nb; ib++) {
-      double rx = pbx[ib], ry = pby[ib], sx = pbx[ib + 1], sy = pby[ib + 1];
+      double sx = pbx[ib + 1], sy = pby[ib + 1];
       int sp = side_a_vs_b(rx, ry, sx, sy, px, py), sq = side_a_vs_b(rx, ry, sx, sy, qx, qy);
-      if (sp == sq) continue;
-      int sr = side_b_vs_a(px, py, qx, qy, rx, ry), ss = side_b_vs_a(px, py, qx, qy, sx, sy);
-      if (sr == ss) continue;
-      double ex = qx - px, ey = qy - py, fx = sx - rx, fy = sy - ry;
-      double denom = ex * fy - ey * fx;
-      if (denom == 0.0) continue;
-      double wx = rx - px, wy = ry - py;
-      double ta = (wx * fy - wy * fx) / denom;
-      double tb = (wx * ey - wy * ex) / denom;
-      ta = ta < 0.0 ? 0.0 : (ta > 1.0 ? 1.0 : ta);
-      tb = tb < 0.0 ? 0.0 : (tb > 1.0 ? 1.0 : tb);
-      int slot = atomicAdd(&m.nraw, 1);
-      if (slot < KC) {
-        m.ria[slot] = (int16_t)ia; m.rib[slot] = (int16_t)ib; m.rta[slot] = ta; m.rtb[slot] = tb;
-        m.rcx[slot] = px + ta * ex; m.rcy[slot] = py + ta * ey;
-        m.rfl[slot] = (uint8_t)((((sp * ob) < 0) ? 1 : 0) | (((sr * oa) < 0) ? 2 : 0));
+      if (sp != sq) {
+        int sr = side_b_vs_a(px, py, qx, qy, rx, ry), ss = side_b_vs_a(px, py, qx, qy, sx, sy);
+        if (sr != ss) {
+          int slot = atomicAdd(&m.nraw, 1);
+          if (slot < KC) {
+            m.ria[slot] = (int16_t)ia; m.rib[slot] = (int16_t)ib;
+            m.rfl[slot] = (uint8_t)((((sp * ob) < 0) ? 1 : 0) | (((sr * oa) < 0) ? 2 : 0));
+          }
+        }
       }
+      rx = sx; ry = sy;
     }
   }
   gsync();
   int K = m.nraw;
   if (K > KC) { if (gl == 0) { m.err |= ERR_CAP_XING; m.nx = 0; } gsync(); return; }
+  STAMP(st, 2);
+  // ---- phase 2: parameters and point of every crossing (one lane per crossing)
+  for (int s2 = gl; s2 < K; s2 += G) {
+    int ia = m.ria[s2], ib = m.rib[s2];
+    double px = pax[ia] + ox, py = pay[ia] + oy, qx = pax[ia + 1] + ox, qy = pay[ia + 1] + oy;
+    double rx = pbx[ib], ry = pby[ib], sx = pbx[ib + 1], sy = pby[ib + 1];
+    double ex = qx - px, ey = qy - py, fx = sx - rx, fy = sy - ry;
+    double denom = ex * fy - ey * fx;
+    double wx = rx - px, wy = ry - py;
+    double ta = (wx * fy - wy * fx) / denom;
+    double tb = (wx * ey - wy * ex) / denom;
+    ta = ta < 0.0 ? 0.0 : (ta > 1.0 ? 1.0 : ta);
+    tb = tb < 0.0 ? 0.0 : (tb > 1.0 ? 1.0 : tb);
+    raw[s2] = ta; raw[KC + s2] = tb; raw[2 * KC + s2] = px + ta * ex; raw[3 * KC + s2] = py + ta * ey;
+    if (denom == 0.0) m.rfl[s2] |= 128;     // cannot happen for straddling edges; kept as a marker
+  }
+  gsync();
+  STAMP(st, 3);
   // ---- canonical (ia, ib) order = the serial discovery order
   for (int s = gl; s < K; s += G) {
     int key = (int)m.ria[s] * 65536 + (int)m.rib[s], r = 0;
     for (int t = 0; t < K; t++) r += ((int)m.ria[t] * 65536 + (int)m.rib[t]) < key;
-    m.cia[r] = m.ria[s]; m.cib[r] = m.rib[s]; m.cta[r] = m.rta[s]; m.ctb[r] = m.rtb[s];
-    m.cx[r] = m.rcx[s]; m.cy[r] = m.rcy[s]; m.cfl[r] = m.rfl[s];
+    m.cia[r] = m.ria[s]; m.cib[r] = m.rib[s]; m.cta[r] = raw[s]; m.ctb[r] = raw[KC + s];
+    m.cx[r] = raw[2 * KC + s]; m.cy[r] = raw[3 * KC + s]; m.cfl[r] = m.rfl[s];
   }
   if (gl == 0) m.nx = K;
   gsync();
+  STAMP(st, 4);
   if (K == 0) {
-    // boundaries do not cross: containment (lane 0 stores)
-    bool a_in_b = ring_inside(pax, pay, na, pbx, pby, nb);
-    bool b_in_a = a_in_b ? false : ring_inside(pbx, pby, nb, pax, pay, na);
+    // boundaries do not cross: containment
+    bool a_in_b = ring_inside(pax, pay, na, ox, oy, pbx, pby, nb);
+    bool b_in_a = a_in_b ? false : ring_inside_off(pbx, pby, nb, pax, pay, na, ox, oy);
     if (a_in_b || b_in_a) {
-      const double* sx = a_in_b ? pax : pbx; const double* sy = a_in_b ? pay : pby;
       int n = a_in_b ? na : nb;
       if (n > RC) { if (gl == 0) m.err |= ERR_CAP_REGION; }
       else {
-        for (int i = gl; i < n; i += G) { m.rx[buf][i] = sx[i]; m.ry[buf][i] = sy[i]; }
+        for (int i = gl; i < n; i += G) {
+          rgx[i] = a_in_b ? pax[i] + ox : pbx[i]; rgy[i] = a_in_b ? pay[i] + oy : pby[i];
+        }
         gsync();
-        double sa = ring_signed_area(m.rx[buf], m.ry[buf], n);
-        if (gl == 0) { m.nreg[buf] = 1; m.roff[buf][1] = (int16_t)n; m.rarea[buf][0] = fabs(sa); }
+        double sa, ccx, ccy;
+        ring_area_centroid(rgx, rgy, n, sa, ccx, ccy);
+        if (gl == 0) {
+          m.nreg[buf] = 1; m.roff[buf][1] = (int16_t)n; m.rarea[buf][0] = fabs(sa);
+          if (buf == 0) { m.rcx[0] = ccx; m.rcy[0] = ccy; }
+        }
       }
     }
     gsync();
+    STAMP(st, 5);
     return;
   }
-  // ---- order along a: key (ia, ta, ib); along b: key (ib, tb, ia)
+  // ---- order along a: key (ia, ta, ib); along b: key (ib, tb, ia); everything the walk needs
+  // about a crossing is packed into one word so that a step costs two dependent LDS reads
   for (int k = gl; k < K; k += G) {
     int ra = 0, rb = 0;
     int ia = m.cia[k], ib = m.cib[k]; double ta = m.cta[k], tb = m.ctb[k];
+#pragma unroll 2
     for (int l = 0; l < K; l++) {
       int ja = m.cia[l], jb = m.cib[l]; double ua = m.cta[l], ub = m.ctb[l];
       ra += (ja < ia) || (ja == ia && (ua < ta || (ua == ta && jb < ib)));
       rb += (jb < ib) || (jb == ib && (ub < tb || (ub == tb && ja < ia)));
     }
-    m.rnkA[k] = (int16_t)ra; m.ordA[ra] = (int16_t)k;
-    m.rnkB[k] = (int16_t)rb; m.ordB[rb] = (int16_t)k;
+    m.ordA[ra] = (uint8_t)k; m.ordB[rb] = (uint8_t)k;
+    m.cinfo[k] = (uint32_t)ia | ((uint32_t)ib << 7) | ((uint32_t)ra << 14) | ((uint32_t)rb << 20) | ((uint32_t)m.cfl[k] << 26);
   }
   gsync();
+  STAMP(st, 6);
   // ---- trace (every lane walks, lane 0 stores)
   const int nea = na - 1, neb = nb - 1;
   uint64_t visited = 0;      // KC <= 64
-  int nreg = 0, off = 0;
+  int nreg = 0, off = 0, nfail = 0;
   const int guard_max = 2 * (na + nb + 2 * K) + 8;
-  int nfail = 0;
   for (int s = 0; s < K; s++) {
     bool failed = false;
     int c0 = m.ordA[s];
     if ((visited >> c0) & 1) continue;
     int start = off, cnt = 0, guard = 0;
     auto emit = [&](double x, double y) {
-      if (off + cnt < RC) { if (gl == 0) { m.rx[buf][off + cnt] = x; m.ry[buf][off + cnt] = y; } }
+      if (off + cnt < RC) { if (gl == 0) { rgx[off + cnt] = x; rgy[off + cnt] = y; } }
       cnt++;
     };
     emit(m.cx[c0], m.cy[c0]);
     visited |= (1ull << c0);
     int cur = c0; bool on_a = true;
+    uint32_t ci = m.cinfo[cur];
     do {
-      int fl = m.cfl[cur];
+      int fl = (int)(ci >> 26);
       bool fwd = on_a ? (fl & 1) : ((fl >> 1) & 1);
       int ne = on_a ? nea : neb;
       const double* vx = on_a ? pax : pbx; const double* vy = on_a ? pay : pby;
-      int r = on_a ? m.rnkA[cur] : m.rnkB[cur];
-      int e0 = on_a ? m.cia[cur] : m.cib[cur];
+      double sx = on_a ? ox : 0.0, sy = on_a ? oy : 0.0;
+      int r = on_a ? (int)((ci >> 14) & 63) : (int)((ci >> 20) & 63);
+      int e0 = on_a ? (int)(ci & 127) : (int)((ci >> 7) & 127);
       int rn, nxt, e1, nv, v;
+      uint32_t cn;
       if (fwd) {
         rn = r + 1; if (rn == K) rn = 0;
         nxt = on_a ? m.ordA[rn] : m.ordB[rn];
-        e1 = on_a ? m.cia[nxt] : m.cib[nxt];
+        cn = m.cinfo[nxt];
+        e1 = on_a ? (int)(cn & 127) : (int)((cn >> 7) & 127);
         nv = (rn > r) ? (e1 - e0) : (ne - e0 + e1);
         v = e0 + 1;
-        for (int t = 0; t < nv; t++) { if (v >= ne) v -= ne; emit(vx[v], vy[v]); v++; }
+        for (int t = 0; t < nv; t++) { if (v >= ne) v -= ne; emit(vx[v] + sx, vy[v] + sy); v++; }
       } else {
         rn = r - 1; if (rn < 0) rn = K - 1;
         nxt = on_a ? m.ordA[rn] : m.ordB[rn];
-        e1 = on_a ? m.cia[nxt] : m.cib[nxt];
+        cn = m.cinfo[nxt];
+        e1 = on_a ? (int)(cn & 127) : (int)((cn >> 7) & 127);
         nv = (rn < r) ? (e0 - e1) : (ne + e0 - e1);
         v = e0;
-        for (int t = 0; t < nv; t++) { if (v < 0) v += ne; emit(vx[v], vy[v]); v--; }
+        for (int t = 0; t < nv; t++) { if (v < 0) v += ne; emit(vx[v] + sx, vy[v] + sy); v--; }
       }
       emit(m.cx[nxt], m.cy[nxt]);
       guard += nv + 1;
       if (guard > guard_max) { failed = true; break; }
-      cur = nxt;
+      cur = nxt; ci = cn;
       visited |= (1ull << cur);
       on_a = !on_a;
     } while (cur != c0);
@@ -312,10 +403,14 @@ SZ_DEV void clip(GroupMem<CAP, KC, RC>& m, int gl, const double* pax, const doub
     if (failed) { nfail++; gsync(); continue; }
     if (off + cnt > RC) { if (gl == 0) m.err |= ERR_CAP_REGION; break; }
     gsync();
-    double sa = (cnt >= 4) ? ring_signed_area(&m.rx[buf][start], &m.ry[buf][start], cnt) : 0.0;
+    double sa = 0.0, ccx = 0.0, ccy = 0.0;
+    if (cnt >= 4) ring_area_centroid(&rgx[start], &rgy[start], cnt, sa, ccx, ccy);
     if (cnt >= 4 && sa != 0.0) {
-      if (nreg < RMAX) {
-        if (gl == 0) { m.rarea[buf][nreg] = fabs(sa); m.roff[buf][nreg + 1] = (int16_t)(off + cnt); }
+      if (nreg < RM) {
+        if (gl == 0) {
+          m.rarea[buf][nreg] = fabs(sa); m.roff[buf][nreg + 1] = (int16_t)(off + cnt);
+          if (buf == 0) { m.rcx[nreg] = ccx; m.rcy[nreg] = ccy; }
+        }
         nreg++; off += cnt;
       } else { if (gl == 0) m.err |= ERR_CAP_REGION; break; }
     }
@@ -324,35 +419,36 @@ SZ_DEV void clip(GroupMem<CAP, KC, RC>& m, int gl, const double* pax, const doub
   if (nfail && gl == 0) m.ntracefail += nfail;
   if (gl == 0) m.nreg[buf] = nreg;
   gsync();
+  STAMP(st, 7);
 }
 
 // ---------------------------------------------------------------------------------------------
 // which_vertices_match_points (floe_utils.jl:331-352) of the unique crossing points against one
-// region ring; fills m.midx[0..mcount) sorted ascending and returns mcount.
-template <int G, int CAP, int KC, int RC>
-SZ_DEV int match_vertices(GroupMem<CAP, KC, RC>& m, int gl, int nuniq, const double* rx, const double* ry, int nr) {
-  // unique crossing points are listed (in canonical order) in m.ordB reused as index list? no:
-  // m.uniq[k] flags them; the quirk `points[1] == points[end]` drops the last one.
+// region ring; fills m.midx[0..mcount) sorted ascending and returns mcount.  The nearest vertex
+// is found on squared distances (sqrt is monotone; a tie is only possible between coincident
+// vertices, where the first wins either way) and sqrt(sqrt(.)) is applied once, to the minimum.
+template <int G, class MEM>
+SZ_DEV int match_vertices(MEM& m, int gl, int nuniq, const double* rx, const double* ry, int nr) {
   int K = m.nx;
   int first = -1, last = -1;
   for (int k = 0; k < K; k++) if (m.uniq[k]) { if (first < 0) first = k; last = k; }
-  int np = nuniq;
-  bool drop_last = (np > 0 && m.cx[first] == m.cx[last] && m.cy[first] == m.cy[last]);
+  bool drop_last = (nuniq > 0 && m.cx[first] == m.cx[last] && m.cy[first] == m.cy[last]);
   for (int k = gl; k < K; k += G) {
     int res = -1;
     if (m.uniq[k] && !(drop_last && k == last)) {
       double md = __builtin_inf(); int mv = 0;
+      double px = m.cx[k], py = m.cy[k];
+#pragma unroll 4
       for (int j = 0; j < nr; j++) {
-        double dx = rx[j] - m.cx[k], dy = ry[j] - m.cy[k];
-        double d = sqrt(sqrt(dx * dx + dy * dy));
+        double dx = rx[j] - px, dy = ry[j] - py;
+        double d = dx * dx + dy * dy;
         if (d < md) { md = d; mv = j; }
       }
-      if (md < 1.0) res = mv;
+      if (sqrt(sqrt(md)) < 1.0) res = mv;
     }
     m.rnkB[k] = (int16_t)res;     // rnkB is free after the trace
   }
   gsync();
-  // gather + sort ascending (tiny; every lane computes, lane 0 stores)
   int cnt = 0;
   for (int k = 0; k < K; k++) if (m.rnkB[k] >= 0) cnt++;
   if (gl == 0) {
@@ -369,32 +465,36 @@ SZ_DEV int match_vertices(GroupMem<CAP, KC, RC>& m, int gl, int nuniq, const dou
   return cnt;
 }
 
-// _many_intersect_normal_force! (collisions.jl:78-119); returns Δl, updates dir
-template <int G, int CAP, int KC, int RC>
-SZ_DEV double many_intersect(GroupMem<CAP, KC, RC>& m, int gl, const double* rx, const double* ry, int nr,
-                             int na, double force_factor, double& dirx, double& diry) {
-  // per-edge classification in parallel: earr = mag (or -1 if the edge is not on p1), farr/garr = Fn
+// _many_intersect_normal_force! (collisions.jl:78-119); returns Δl, updates dir.  The per-edge
+// classification (is the edge midpoint on p1?  which side is inside the region?) runs over the
+// lanes; the sums run in ring order with the edge terms recomputed from the same expressions.
+template <int G, class MEM>
+SZ_DEV double many_intersect(MEM& m, int gl, const double* rx, const double* ry, int nr, int na, double force_factor,
+                             double& dirx, double& diry) {
   for (int i = 1 + gl; i < nr; i += G) {
     double x1 = rx[i - 1], y1 = ry[i - 1], x2 = rx[i], y2 = ry[i];
     double xmid = 0.5 * (x2 + x1), ymid = 0.5 * (y2 + y1);
     double dist = dist_to_ring(xmid, ymid, m.ax, m.ay, na);
-    double mag = -1.0, fnx = 0.0, fny = 0.0;
+    int code = 0;
     if (dist < 1e-8) {
       double dx = x2 - x1, dy = y2 - y1;
-      mag = sqrt(dx * dx + dy * dy);
+      double mag = sqrt(dx * dx + dy * dy);
       double xt = xmid + (-dy / (100 * mag));
       double yt = ymid + (dx / (100 * mag));
-      bool in_region = coveredby(xt, yt, rx, ry, nr);
-      double f_sign = in_region ? 1.0 : -1.0;
-      fnx = (f_sign * force_factor) * (-dy); fny = (f_sign * force_factor) * dx;
+      code = coveredby(xt, yt, rx, ry, nr) ? 1 : -1;
     }
-    m.earr[i] = mag; m.farr[i] = fnx; m.garr[i] = fny;
+    m.ecode[i] = (int8_t)code;
   }
   gsync();
   double dl = 0.0, fx = 0.0, fy = 0.0; int n_pts = 0;
   for (int i = 1; i < nr; i++) {
-    double mag = m.earr[i];
-    if (mag >= 0.0) { dl += mag; n_pts += 1; fx += m.farr[i]; fy += m.garr[i]; }
+    int code = m.ecode[i];
+    if (code != 0) {
+      double dx = rx[i] - rx[i - 1], dy = ry[i] - ry[i - 1];
+      double mag = sqrt(dx * dx + dy * dy);
+      double f_sign = code > 0 ? 1.0 : -1.0;
+      dl += mag; n_pts += 1; fx += (f_sign * force_factor) * (-dy); fy += (f_sign * force_factor) * dx;
+    }
   }
   gsync();
   if (0 < n_pts && n_pts < nr - 1) {
@@ -408,9 +508,9 @@ SZ_DEV double many_intersect(GroupMem<CAP, KC, RC>& m, int gl, const double* rx,
 }
 
 // GO.intersects(ring1, ring2) with both rings in LDS
-template <int G, int CAP, int KC, int RC>
-SZ_DEV bool rings_intersect(GroupMem<CAP, KC, RC>& m, int gl, const double* x1, const double* y1, int n1,
-                            const double* x2, const double* y2, int n2) {
+template <int G, class MEM>
+SZ_DEV bool rings_intersect(MEM& m, int gl, const double* x1, const double* y1, int n1, const double* x2,
+                            const double* y2, int n2) {
   if (n1 < 2 || n2 < 2) return false;
   if (gl == 0) m.flag = 0;
   gsync();
@@ -435,92 +535,131 @@ struct Body {          // kinematics of one side of a contact
   int rigid_uv;        // 1: boundary/topography: velocity is (u, v) everywhere
 };
 
-struct ContactParams {
-  double E, nu, mu; int dt;
-  double force_factor;
+enum { ITEM_PAIR = 0, ITEM_OPEN = 1, ITEM_SOLID = 2 };
+enum { IT_FUSE = 1, IT_REMOVE = 2 };
+
+struct ItemCtx {
+  int mode;            // ITEM_PAIR: floe-floe; ITEM_OPEN: open boundary; ITEM_SOLID: collision/moving boundary, topography
+  double E, nu, mu; int dt; int dbg;
+  double area_i, area_j, h_i, h_j;
+  double max_overlap;  // floe_floe_max_overlap (pairs) or floe_domain_max_overlap (elements)
   int elem_dir;        // -1 floe-floe / topography; else SZ_NORTH.. for _normal_direction_correct!
   double elem_val;
+  Body bi, bj;
 };
 
-// calc_elastic_forces + calc_friction_forces on the regions of clip buffer 0.
-// rows: out[k*5 + {fx, fy, px, py, overlap}], returns number of rows written (zero-force rows
-// are dropped exactly like add_interactions!, collisions.jl:288).
-template <int G, int CAP, int KC, int RC>
-SZ_DEV int contact_rows(GroupMem<CAP, KC, RC>& m, int gl, int na, int oa, int nb, int ob, const Body& bi,
-                        const Body& bj, const ContactParams& cp, double* out, int max_rows) {
-  int K = m.nx;
-  // unique crossing points (GO.intersection_points): first occurrences in canonical order
-  for (int k = gl; k < K; k += G) {
-    bool dup = false;
-    for (int l = 0; l < k; l++) if (m.cx[l] == m.cx[k] && m.cy[l] == m.cy[k]) { dup = true; break; }
-    m.uniq[k] = dup ? 0 : 1;
-  }
-  gsync();
-  int nip = 0;
-  for (int k = 0; k < K; k++) nip += m.uniq[k];
-  int nreg = m.nreg[0];
-  // region list after the min-area filter (collisions.jl:158-170): keep[] indexes into buffer 0
-  int keep[RMAX]; int nkeep = 0;
-  if (nip >= 2) {
-    int n1 = na - 1, n2 = nb - 1;
-    double min_area = (double)((n1 < n2 ? n1 : n2) * 100) / 1.75;
-    for (int r = 0; r < nreg; r++) if (!(m.rarea[0][r] < min_area)) keep[nkeep++] = r;
-  }
-  int nrows = 0;
-  // save crossings needed later? the direction-check clip overwrites the crossing arrays, so the
-  // matching for ALL kept regions is done first.
-  double dlv[RMAX], dxv[RMAX], dyv[RMAX];
-  for (int q = 0; q < nkeep; q++) {
-    int r = keep[q];
-    const double* rx = &m.rx[0][m.roff[0][r]]; const double* ry = &m.ry[0][m.roff[0][r]];
-    int nr = m.roff[0][r + 1] - m.roff[0][r];
-    double dirx = 0.0, diry = 0.0, dl = 0.0;
-    if (m.rarea[0][r] != 0) {
-      int mc = match_vertices<G>(m, gl, nip, rx, ry, nr);
-      if (mc == 2) {
-        int i1 = m.midx[0], i2 = m.midx[1];
-        double dx = rx[i2] - rx[i1], dy = ry[i2] - ry[i1];
-        dl = sqrt(dx * dx + dy * dy);
-        if (dl > 0.1) { dirx = -dy / dl; diry = dx / dl; }
-      } else if (mc != 0) {
-        dl = many_intersect<G>(m, gl, rx, ry, nr, na, cp.force_factor, dirx, diry);
+// One work item, start to finish: floe_floe_interaction! (collisions.jl:347-408) or
+// floe_domain_element_interaction! (:427-557) on the rings staged in m.ax/ay, m.bx/by.
+// rows: out[k*5 + {fx, fy, px, py, overlap}]; zero-force rows are dropped exactly like
+// add_interactions! (:288).  Returns the number of rows, sets IT_FUSE / IT_REMOVE in `flags`.
+//
+// The contact clip and the per-region direction-check clips (collisions.jl:58-68) are iterations
+// -1, 0, 1, .. of ONE loop, so that clip() -- by far the largest routine -- is instantiated once:
+// the kernel then fits the instruction cache, which matters more than anything else for a
+// divergent, latency-bound kernel like this one.
+template <int G, class MEM>
+SZ_DEV int collide_item(MEM& m, int gl, int na, int oa, int nb, int ob, const ItemCtx& cx_, double* out, int max_rows,
+                        int& flags, Stamps& st) {
+  constexpr int RM = MEM::RMAXV;
+  int keep[RM]; int nkeep = 0, nrows = 0;
+  double dlv[RM], dxv[RM], dyv[RM];
+  double force_factor = 0.0;
+  flags = 0;
+  for (int q = -1; q < nkeep; q++) {
+    const int r = q < 0 ? 0 : keep[q];
+    const double area = q < 0 ? 0.0 : m.rarea[0][r];
+    const double dl = q < 0 ? 0.0 : dlv[q];
+    double dirx = q < 0 ? 0.0 : dxv[q], diry = q < 0 ? 0.0 : dyv[q];
+    const bool check = q >= 0 && area != 0 && dl > 0.1 && !(cx_.dbg & 2);
+    if (q < 0 || check) clip<G>(m, gl, dirx, diry, na, oa, nb, ob, q < 0 ? 0 : 1, q >= 0, st);
+    if (q < 0) {
+      // ---------------- after the contact clip: overlap tests, force factor, per-region direction
+      const int nreg = m.nreg[0];
+      double total = 0.0, amax = 0.0;
+      for (int t = 0; t < nreg; t++) { double a = m.rarea[0][t]; total += a; if (a > amax) amax = a; }
+      if (cx_.mode == ITEM_PAIR) {
+        if (!(total > 0)) break;
+        double r1 = total / cx_.area_i, r2 = total / cx_.area_j;
+        if ((r1 > r2 ? r1 : r2) > cx_.max_overlap) { flags |= IT_FUSE; break; }
+        double ih = cx_.h_i, ir = sqrt(cx_.area_i), jh = cx_.h_j, jr = sqrt(cx_.area_j);
+        if (ir > 1e5 || jr > 1e5) force_factor = cx_.E * (ih < jh ? ih : jh) / (ir < jr ? ir : jr);
+        else force_factor = cx_.E * (ih * jh) / (ih * jr + jh * ir);
+      } else if (cx_.mode == ITEM_OPEN) {
+        if (total > 0) flags |= IT_REMOVE;
+        break;
+      } else {
+        if (!(amax > 0)) break;
+        if (amax / cx_.area_i > cx_.max_overlap) { flags |= IT_REMOVE; break; }
+        force_factor = cx_.E * cx_.h_i / sqrt(cx_.area_i);
+      }
+      if (cx_.dbg & 1) break;
+      // unique crossing points (GO.intersection_points): first occurrences in canonical order
+      const int K = m.nx;
+      for (int k = gl; k < K; k += G) {
+        bool dup = false;
+        for (int l = 0; l < k; l++) if (m.cx[l] == m.cx[k] && m.cy[l] == m.cy[k]) { dup = true; break; }
+        m.uniq[k] = dup ? 0 : 1;
       }
       gsync();
+      int nip = 0;
+      for (int k = 0; k < K; k++) nip += m.uniq[k];
+      // min-area filter (collisions.jl:158-170)
+      if (nip >= 2) {
+        int n1 = na - 1, n2 = nb - 1;
+        double min_area = (double)((n1 < n2 ? n1 : n2) * 100) / 1.75;
+        for (int t = 0; t < nreg; t++) if (!(m.rarea[0][t] < min_area)) keep[nkeep++] = t;
+      }
+      // calc_normal_force up to the direction check, for every kept region (the direction-check
+      // clips overwrite the crossing arrays, so all matching happens here)
+      for (int w = 0; w < nkeep; w++) {
+        int rr = keep[w];
+        const double* rx = &m.reg[0][0][m.roff[0][rr]]; const double* ry = &m.reg[0][1][m.roff[0][rr]];
+        int nr = m.roff[0][rr + 1] - m.roff[0][rr];
+        double ddx = 0.0, ddy = 0.0, ddl = 0.0;
+        if (m.rarea[0][rr] != 0) {
+          int mc = match_vertices<G>(m, gl, nip, rx, ry, nr);
+          if (mc == 2) {
+            int i1 = m.midx[0], i2 = m.midx[1];
+            double ex = rx[i2] - rx[i1], ey = ry[i2] - ry[i1];
+            ddl = sqrt(ex * ex + ey * ey);
+            if (ddl > 0.1) { ddx = -ey / ddl; ddy = ex / ddl; }
+          } else if (mc != 0) {
+            ddl = many_intersect<G>(m, gl, rx, ry, nr, na, force_factor, ddx, ddy);
+          }
+          gsync();
+        }
+        dlv[w] = ddl; dxv[w] = ddx; dyv[w] = ddy;
+      }
+      STAMP(st, 8);
+      continue;
     }
-    dlv[q] = dl; dxv[q] = dirx; dyv[q] = diry;
-  }
-  for (int q = 0; q < nkeep; q++) {
-    int r = keep[q];
-    const double* rx = &m.rx[0][m.roff[0][r]]; const double* ry = &m.ry[0][m.roff[0][r]];
-    int nr = m.roff[0][r + 1] - m.roff[0][r];
-    double area = m.rarea[0][r];
-    double fxn = 0.0, fyn = 0.0, px = 0.0, py = 0.0, dl = dlv[q];
+    // ---------------- region q: direction check, friction, row
+    const double* rx = &m.reg[0][0][m.roff[0][r]]; const double* ry = &m.reg[0][1][m.roff[0][r]];
+    const int nr = m.roff[0][r + 1] - m.roff[0][r];
+    double fxn = 0.0, fyn = 0.0, px = 0.0, py = 0.0;
     if (area != 0) {
-      ring_centroid(rx, ry, nr, px, py);
-      double dirx = dxv[q], diry = dyv[q];
-      if (dl > 0.1) {
-        // direction check (collisions.jl:58-68): move p1 by the unit direction and re-clip
-        for (int i = gl; i < na; i += G) { m.tx[i] = m.ax[i] + dirx; m.ty[i] = m.ay[i] + diry; }
-        gsync();
-        clip<G>(m, gl, m.tx, m.ty, na, oa, nb, ob, 1);
+      px = m.rcx[r]; py = m.rcy[r];
+      if (check) {
         int nn = m.nreg[1];
         for (int t = 0; t < nn; t++) {
-          const double* nx_ = &m.rx[1][m.roff[1][t]]; const double* ny_ = &m.ry[1][m.roff[1][t]];
+          const double* nx_ = &m.reg[1][0][m.roff[1][t]]; const double* ny_ = &m.reg[1][1][m.roff[1][t]];
           int nnr = m.roff[1][t + 1] - m.roff[1][t];
-          bool ints = rings_intersect<G>(m, gl, nx_, ny_, nnr, rx, ry, nr);
-          if (ints && m.rarea[1][t] / area > 1) { dirx *= -1; diry *= -1; }
+          // area ratio first: `intersects && ratio > 1` needs the (costlier) predicate only then
+          if (m.rarea[1][t] / area > 1 && rings_intersect<G>(m, gl, nx_, ny_, nnr, rx, ry, nr)) { dirx *= -1; diry *= -1; }
         }
+        STAMP(st, 10);
       }
-      fxn = dirx * area * cp.force_factor;
-      fyn = diry * area * cp.force_factor;
+      fxn = dirx * area * force_factor;
+      fyn = diry * area * force_factor;
     }
     // _normal_direction_correct! (boundaries.jl:37,73,110,147)
-    if (cp.elem_dir == 0 && py >= cp.elem_val) fxn = 0.0;
-    if (cp.elem_dir == 1 && py <= cp.elem_val) fxn = 0.0;
-    if (cp.elem_dir == 2 && px >= cp.elem_val) fyn = 0.0;
-    if (cp.elem_dir == 3 && px <= cp.elem_val) fyn = 0.0;
+    if (cx_.elem_dir == 0 && py >= cx_.elem_val) fxn = 0.0;
+    if (cx_.elem_dir == 1 && py <= cx_.elem_val) fxn = 0.0;
+    if (cx_.elem_dir == 2 && px >= cx_.elem_val) fyn = 0.0;
+    if (cx_.elem_dir == 3 && px <= cx_.elem_val) fyn = 0.0;
     // calc_friction_forces (collisions.jl:243-283)
-    double G_ = cp.E / (2 * (1 + cp.nu));
+    const Body& bi = cx_.bi; const Body& bj = cx_.bj;
+    double G_ = cx_.E / (2 * (1 + cx_.nu));
     double nnorm = sqrt(fxn * fxn + fyn * fyn);
     double iu = bi.u + bi.xi * (px - bi.cx), iv = bi.v + bi.xi * (py - bi.cy);
     double ju = bj.rigid_uv ? bj.u : bj.u + bj.xi * (px - bj.cx);
@@ -530,10 +669,10 @@ SZ_DEV int contact_rows(GroupMem<CAP, KC, RC>& m, int gl, int na, int oa, int nb
     double xdir = 0.0, ydir = 0.0;
     if (udiff != 0 || vdiff != 0) { xdir = udiff / vnorm; ydir = vdiff / vnorm; }
     double dot_dir = xdir * udiff + ydir * vdiff;
-    double xf = G_ * dl * cp.dt * nnorm * xdir * -dot_dir;
-    double yf = G_ * dl * cp.dt * nnorm * ydir * -dot_dir;
+    double xf = G_ * dl * cx_.dt * nnorm * xdir * -dot_dir;
+    double yf = G_ * dl * cx_.dt * nnorm * ydir * -dot_dir;
     double norm_fric = sqrt(xf * xf + yf * yf);
-    if (norm_fric > cp.mu * nnorm) { xf = -cp.mu * nnorm * xdir; yf = -cp.mu * nnorm * ydir; }
+    if (norm_fric > cx_.mu * nnorm) { xf = -cx_.mu * nnorm * xdir; yf = -cx_.mu * nnorm * ydir; }
     double fx = fxn + xf, fy = fyn + yf;
     if (fx != 0 || fy != 0) {
       if (nrows < max_rows) {

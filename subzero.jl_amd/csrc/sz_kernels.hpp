@@ -248,22 +248,15 @@ __global__ void __launch_bounds__(1024) sz_k_bounds(State S) {
     S.cnt[C_NCELLS] = (int)(ncx * ncy);
   }
 }
-__global__ void sz_k_cell_count(State S) {
+// uniform-grid binning as per-cell linked lists (atomic exchange on the cell heads): no counting
+// pass, no scan.  The order inside a cell is arbitrary; the consumers sort by order key.
+__global__ void sz_k_cell_build(State S) {
   int M = S.cnt[C_M];
   double x0 = S.bounds[0], y0 = S.bounds[1], cs = S.bounds[2]; int ncx = (int)S.bounds[3];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
     int ix = (int)floor((S.cx[i] - x0) / cs), iy = (int)floor((S.cy[i] - y0) / cs);
     int c = iy * ncx + ix;
-    S.cell_of[i] = c;
-    atomicAdd(&S.cell_cnt[c], 1);
-  }
-}
-__global__ void sz_k_cell_fill(State S) {
-  int M = S.cnt[C_M];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
-    int c = S.cell_of[i];
-    int pos = S.cell_off[c] + atomicAdd(&S.cell_cur[c], 1);
-    S.cell_items[pos] = i;
+    S.cell_items[i] = atomicExch(&S.cell_cnt[c], i + 1) - 1;   // cell_cnt holds head + 1 (0 = empty)
   }
 }
 
@@ -301,30 +294,33 @@ __device__ bool pair_allowed(const State& S, int i, int j) {   // i < j, ids dif
   return (A && B) || (A != B);
 }
 
-// one thread per floe: neighbours with larger index (outgoing, the pairs this floe owns) and
-// with smaller index (incoming, the pairs mirrored onto it), both sorted ascending
-__global__ void sz_k_neighbors(State S) {
+// one thread per floe: neighbours that come later in the serial order (outgoing: the pairs this
+// floe owns) and earlier ones (incoming: the pairs mirrored onto it), both sorted by order key.
+// The two candidate lists are built in LDS and written out once.
+constexpr int NB_TPB = 64;
+__global__ void __launch_bounds__(NB_TPB) sz_k_neighbors(State S) {
+  __shared__ int lists[NB_TPB][2 * MAXNB + 1];
   int M = S.cnt[C_M];
   double x0 = S.bounds[0], y0 = S.bounds[1], cs = S.bounds[2]; int ncx = (int)S.bounds[3], ncy = (int)S.bounds[4];
+  int* lo = lists[threadIdx.x]; int* li = lo + MAXNB;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
-    int ix = (int)floor((S.cx[k] - x0) / cs), iy = (int)floor((S.cy[k] - y0) / cs);
+    double ckx = S.cx[k], cky = S.cy[k], rk = S.rmax[k];
+    int ix = (int)floor((ckx - x0) / cs), iy = (int)floor((cky - y0) / cs);
     int no = 0, ni = 0; bool ovf = false;
-    int* lo = S.nb_out + (size_t)k * MAXNB; int* li = S.nb_in + (size_t)k * MAXNB;
     long long idk = S.id[k], okk = S.okey[k];
     for (int dy = -1; dy <= 1; dy++) {
       int cy = iy + dy; if (cy < 0 || cy >= ncy) continue;
       for (int dx = -1; dx <= 1; dx++) {
         int cxi = ix + dx; if (cxi < 0 || cxi >= ncx) continue;
-        int c = cy * ncx + cxi;
-        int b = S.cell_off[c], e = S.cell_off[c + 1];
-        for (int t = b; t < e; t++) {
-          int o = S.cell_items[t];
-          if (o == k || S.id[o] == idk) continue;
+        for (int o = S.cell_cnt[cy * ncx + cxi] - 1; o >= 0; o = S.cell_items[o]) {
+          if (o == k) continue;
+          // potential_interaction (collisions.jl:705-710), symmetric in its arguments
+          double ddx = ckx - S.cx[o], ddy = cky - S.cy[o], rr = rk + S.rmax[o];
+          if (!((ddx * ddx + ddy * ddy) < rr * rr)) continue;
+          if (S.id[o] == idk) continue;
           long long ko = S.okey[o];
           bool after = ko > okk;                   // o comes after k in the serial order
-          int a = after ? k : o, bb = after ? o : k;
-          if (!circles_touch(S, a, bb)) continue;
-          if (!pair_allowed(S, a, bb)) continue;
+          if (!pair_allowed(S, after ? k : o, after ? o : k)) continue;
           int* l = after ? lo : li; int& n = after ? no : ni;
           if (n >= MAXNB) { ovf = true; continue; }
           int u = n - 1;
@@ -335,6 +331,8 @@ __global__ void sz_k_neighbors(State S) {
     }
     if (ovf) atomicOr(&S.cnt[C_ERR], ERR_CAP_NEIGH);
     S.n_out[k] = no; S.n_in[k] = ni;
+    for (int t = 0; t < no; t++) S.nb_out[(size_t)k * MAXNB + t] = lo[t];
+    for (int t = 0; t < ni; t++) S.nb_in[(size_t)k * MAXNB + t] = li[t];
   }
 }
 __global__ void sz_k_pairs_fill(State S) {
@@ -344,8 +342,6 @@ __global__ void sz_k_pairs_fill(State S) {
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
     int o = S.out_off[k], n = S.n_out[k];
     for (int t = 0; t < n; t++) { S.pair_i[o + t] = k; S.pair_j[o + t] = S.nb_out[(size_t)k * MAXNB + t]; }
-    int oi = S.in_off[k], m = S.n_in[k];
-    for (int t = 0; t < m; t++) S.in_i[oi + t] = S.nb_in[(size_t)k * MAXNB + t];
   }
 }
 // explicit pair list (sz_collide_pairs): out lists from the given pairs, no incoming lists
@@ -355,7 +351,7 @@ __global__ void sz_k_pairs_explicit(State S, int np) {
     // pairs are sorted by i on the host; out_off[k] = first pair with i >= k
     int lo = 0, hi = np;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (S.pair_i[mid] < k) lo = mid + 1; else hi = mid; }
-    S.out_off[k] = lo; S.in_off[k] = 0;
+    S.out_off[k] = lo;
     if (k < M) S.n_in[k] = 0;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) S.cnt[C_NPAIRS] = np;
@@ -399,15 +395,18 @@ __global__ void sz_k_elem_fill(State S) {
 // ============================================================================ narrow phase (A4-A10)
 // items [0, P): floe-floe pairs; [P, P+Q): floe-element items.  SMALL kernels take the items
 // whose rings both fit LO..CAP points.
-template <int G, int CAP, int KC, int RC, int TPB, int LO>
-__global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, double ff_max_overlap, double fd_max_overlap) {
+template <int G, int CAP, int KC, int RC, int RM, int TPB, int LO, int CLS>
+__global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, double ff_max_overlap, double fd_max_overlap, int dbg) {
   constexpr int GPB = TPB / G;
-  __shared__ GroupMem<CAP, KC, RC> mem[GPB];
+  static_assert(4 * KC <= 2 * RC, "raw crossing slots alias reg[1]");
+  if (CLS > 0 && S.cnt[C_ITEMCLASS] < CLS) return;   // no item needs this (larger) variant this step
+  __shared__ GroupMem<CAP, KC, RC, RM> mem[GPB];
   const int gl = threadIdx.x % G, gi = threadIdx.x / G;
-  GroupMem<CAP, KC, RC>& m = mem[gi];
+  GroupMem<CAP, KC, RC, RM>& m = mem[gi];
   const int npairs = S.cnt[C_NPAIRS], nel = S.cnt[C_NELEM];
   const int nitems = npairs + nel;
   if (gl == 0) { m.err = 0; m.ntracefail = 0; }
+  Stamps st; STAMP_INIT(st);
   for (int t = blockIdx.x * GPB + gi; t < nitems; t += gridDim.x * GPB) {
     const bool is_pair = t < npairs;
     int i, j = -1, e = -1, item;
@@ -418,57 +417,44 @@ __global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, do
     const int nb = (is_pair ? S.voff[j + 1] : S.eoff[e + 1]) - bo;
     const int big = na > nb ? na : nb;
     if (big <= LO) continue;                          // handled by the smaller variant
-    if (big > CAP) { if (CAP >= 128 && gl == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); continue; }
+    if (big > CAP) { if (CLS == 2 && gl == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); continue; }
     const double* bxs = is_pair ? S.vx : S.ex; const double* bys = is_pair ? S.vy : S.ey;
     gsync();
     for (int q = gl; q < na; q += G) { m.ax[q] = S.vx[ao + q]; m.ay[q] = S.vy[ao + q]; }
     for (int q = gl; q < nb; q += G) { m.bx[q] = bxs[bo + q]; m.by[q] = bys[bo + q]; }
     gsync();
     const int oa = S.osign[i], ob = is_pair ? S.osign[j] : S.eosign[e];
-    clip<G>(m, gl, m.ax, m.ay, na, oa, nb, ob, 0);
-    const int nreg = m.nreg[0];
-    double total = 0.0, amax = 0.0;
-    for (int r = 0; r < nreg; r++) { double a = m.rarea[0][r]; total += a; if (a > amax) amax = a; }
-    int nrows = 0, flags = 0;
-    double* out = S.it_rows + (size_t)item * ROWS_PER_ITEM * 5;
+    STAMP(st, 0);
+    ItemCtx ic;
+    ic.E = P.E; ic.nu = P.nu; ic.mu = P.mu; ic.dt = dt; ic.dbg = dbg;
+    ic.area_i = S.area[i]; ic.h_i = S.height[i];
+    ic.bi = Body{ S.cx[i], S.cy[i], S.u[i], S.v[i], S.xi[i], 0 };
     if (is_pair) {
-      if (total > 0) {
-        double ai = S.area[i], aj = S.area[j];
-        double r1 = total / ai, r2 = total / aj;
-        if ((r1 > r2 ? r1 : r2) > ff_max_overlap) flags |= IT_FUSE;
-        else {
-          double ih = S.height[i], ir = sqrt(ai), jh = S.height[j], jr = sqrt(aj);
-          ContactParams cp; cp.E = P.E; cp.nu = P.nu; cp.mu = P.mu; cp.dt = dt; cp.elem_dir = -1; cp.elem_val = 0.0;
-          if (ir > 1e5 || jr > 1e5) cp.force_factor = P.E * (ih < jh ? ih : jh) / (ir < jr ? ir : jr);
-          else cp.force_factor = P.E * (ih * jh) / (ih * jr + jh * ir);
-          Body bi{ S.cx[i], S.cy[i], S.u[i], S.v[i], S.xi[i], 0 };
-          Body bj{ S.cx[j], S.cy[j], S.u[j], S.v[j], S.xi[j], 0 };
-          nrows = contact_rows<G>(m, gl, na, oa, nb, ob, bi, bj, cp, out, ROWS_PER_ITEM);
-        }
-      }
+      ic.mode = ITEM_PAIR; ic.area_j = S.area[j]; ic.h_j = S.height[j]; ic.max_overlap = ff_max_overlap;
+      ic.elem_dir = -1; ic.elem_val = 0.0;
+      ic.bj = Body{ S.cx[j], S.cy[j], S.u[j], S.v[j], S.xi[j], 0 };
     } else {
       int kind = S.ekind[e];
-      if (kind == 0) {                       // OpenBoundary, collisions.jl:427-441
-        if (total > 0) flags |= IT_REMOVE;
-      } else if (amax > 0) {                 // Collision/Moving boundary or topography, :499-557
-        double ai = S.area[i];
-        if (amax / ai > fd_max_overlap) flags |= IT_REMOVE;
-        else {
-          ContactParams cp; cp.E = P.E; cp.nu = P.nu; cp.mu = P.mu; cp.dt = dt;
-          cp.force_factor = P.E * S.height[i] / sqrt(ai);
-          cp.elem_dir = e < 4 ? e : -1; cp.elem_val = S.eval[e];
-          Body bi{ S.cx[i], S.cy[i], S.u[i], S.v[i], S.xi[i], 0 };
-          Body bj{ 0.0, 0.0, kind == 3 ? S.eu[e] : 0.0, kind == 3 ? S.ev[e] : 0.0, 0.0, 1 };
-          nrows = contact_rows<G>(m, gl, na, oa, nb, ob, bi, bj, cp, out, ROWS_PER_ITEM);
-        }
-      }
+      ic.mode = kind == 0 ? ITEM_OPEN : ITEM_SOLID; ic.area_j = 0.0; ic.h_j = 0.0; ic.max_overlap = fd_max_overlap;
+      ic.elem_dir = e < 4 ? e : -1; ic.elem_val = S.eval[e];
+      ic.bj = Body{ 0.0, 0.0, kind == 3 ? S.eu[e] : 0.0, kind == 3 ? S.ev[e] : 0.0, 0.0, 1 };
     }
+    int nrows = 0, flags = 0;
+    double* out = S.it_rows + (size_t)item * ROWS_PER_ITEM * 5;
+    if (!(dbg & 4)) nrows = collide_item<G>(m, gl, na, oa, nb, ob, ic, out, ROWS_PER_ITEM, flags, st);
     if (gl == 0) { S.it_nrows[item] = nrows; S.it_flags[item] = flags; }
+    STAMP(st, 11);
   }
   gsync();
   if (gl == 0 && m.err) atomicOr(&S.cnt[C_ERR], m.err);
   if (gl == 0 && m.ntracefail) atomicAdd(&S.cnt[C_TRACE_FAIL], m.ntracefail);
+#ifdef SZ_STAMPS
+  st.acc[12] = clock64() - st.t0; st.acc[13] = 1; st.acc[14] = (st.acc[1] + st.acc[2]) > 0 ? 1 : 0;
+  if (gl == 0 && CLS == 0) for (int q = 0; q < 15; q++) atomicAdd((unsigned long long*)&S.stamps[q], (unsigned long long)st.acc[q]);
+#endif
 }
+
+constexpr int NARROW_CAP0 = 20, NARROW_CAP1 = 32, NARROW_CAP2 = 128;   // ring points per variant
 
 // items not touched by any narrow variant would keep stale row counts: clear them first
 __global__ void sz_k_items_clear(State S) {
@@ -476,6 +462,14 @@ __global__ void sz_k_items_clear(State S) {
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < npairs + nel; t += gridDim.x * blockDim.x) {
     int item = t < npairs ? t : S.capPairs + (t - npairs);
     S.it_nrows[item] = 0; S.it_flags[item] = 0;
+    // size class of the item: which narrow-phase variant takes it
+    int i, nb;
+    if (t < npairs) { i = S.pair_i[t]; int j = S.pair_j[t]; nb = S.voff[j + 1] - S.voff[j]; }
+    else { int q = t - npairs; i = S.el_floe[q]; int e = S.el_elem[q]; nb = S.eoff[e + 1] - S.eoff[e]; }
+    int na = S.voff[i + 1] - S.voff[i];
+    int big = na > nb ? na : nb;
+    int cls = big <= NARROW_CAP0 ? 0 : (big <= NARROW_CAP1 ? 1 : 2);
+    if (cls > 0) atomicMax(&S.cnt[C_ITEMCLASS], cls);
   }
 }
 
@@ -497,9 +491,9 @@ __global__ void sz_k_cnt1(State S, int mirror) {
     for (int q = S.el_off[k]; q < S.el_off[k + 1]; q++) { c += S.it_nrows[S.capPairs + q]; if (S.it_flags[S.capPairs + q] & IT_REMOVE) st = SZ_REMOVE; }
     S.tagA[k] = st;     // tag after the pair/domain phase, before the mirror pass (host fuse replay)
     if (mirror) {
-      int o = S.in_off[k], n = S.n_in[k];
+      int n = S.n_in[k];
       for (int t = 0; t < n; t++) {
-        int p = find_pair(S, S.in_i[o + t], k);
+        int p = find_pair(S, S.nb_in[(size_t)k * MAXNB + t], k);
         if (p >= 0) { c += S.it_nrows[p]; if (S.it_flags[p] & IT_FUSE) st = SZ_FUSE; }
       }
     }
@@ -535,9 +529,9 @@ __device__ int emit_rows(const State& S, int f, double* dst, double sx, double s
     }
   }
   if (mirror) {
-    int o = S.in_off[f], m = S.n_in[f];
+    int m = S.n_in[f];
     for (int t = 0; t < m; t++) {
-      int i = S.in_i[o + t]; int p = find_pair(S, i, f);
+      int i = S.nb_in[(size_t)f * MAXNB + t]; int p = find_pair(S, i, f);
       if (p < 0) continue;
       int n = S.it_nrows[p]; const double* src = S.it_rows + (size_t)p * ROWS_PER_ITEM * 5;
       for (int r = 0; r < n; r++) {
@@ -598,21 +592,29 @@ __global__ void sz_k_update_boundaries(State S, int dt) {
 }
 
 // ============================================================================ forcings (A13)
-__device__ __forceinline__ double sample_field(const State& S, const double* A, double x, double y, int per_x, int per_y) {
+// bilinear sample on the grid-line lattice (Interpolations.linear_interpolation over the knot window
+// of mc_interpolation, coupling.jl:845-902, incl. the periodic wrap of find_interp_knots :702-744).
+// Cell and weights depend only on the point, so they are computed once for all five fields.
+struct LatticeCell { int o00, o01, o10, o11; double tx, ty; };
+__device__ __forceinline__ LatticeCell lattice_cell(const State& S, double x, double y, int per_x, int per_y) {
   int Nx = S.Nx, Ny = S.Ny;
   long long ix = (long long)floor((x - S.gx0) / S.gdx), iy = (long long)floor((y - S.gy0) / S.gdy);
   if (!per_x) { if (ix < 0) ix = 0; if (ix > Nx - 1) ix = Nx - 1; }
   if (!per_y) { if (iy < 0) iy = 0; if (iy > Ny - 1) iy = Ny - 1; }
   double xk = S.gx0 + (double)ix * S.gdx, yk = S.gy0 + (double)iy * S.gdy;
-  double tx = (x - xk) / S.gdx, ty = (y - yk) / S.gdy;
-  long long i0, i1, j0, j1;
-  if (per_x) { i0 = ((ix % Nx) + Nx) % Nx; i1 = (((ix + 1) % Nx) + Nx) % Nx; } else { i0 = ix; i1 = ix + 1; }
-  if (per_y) { j0 = ((iy % Ny) + Ny) % Ny; j1 = (((iy + 1) % Ny) + Ny) % Ny; } else { j0 = iy; j1 = iy + 1; }
-  size_t s = (size_t)(Ny + 1);
-  double a00 = A[(size_t)i0 * s + j0], a01 = A[(size_t)i0 * s + j1], a10 = A[(size_t)i1 * s + j0], a11 = A[(size_t)i1 * s + j1];
-  double c0 = (1.0 - ty) * a00 + ty * a01;
-  double c1 = (1.0 - ty) * a10 + ty * a11;
-  return (1.0 - tx) * c0 + tx * c1;
+  LatticeCell c;
+  c.tx = (x - xk) / S.gdx; c.ty = (y - yk) / S.gdy;
+  int i0, i1, j0, j1;
+  if (per_x) { i0 = (int)(((ix % Nx) + Nx) % Nx); i1 = (int)((((ix + 1) % Nx) + Nx) % Nx); } else { i0 = (int)ix; i1 = (int)ix + 1; }
+  if (per_y) { j0 = (int)(((iy % Ny) + Ny) % Ny); j1 = (int)((((iy + 1) % Ny) + Ny) % Ny); } else { j0 = (int)iy; j1 = (int)iy + 1; }
+  int s = Ny + 1;
+  c.o00 = i0 * s + j0; c.o01 = i0 * s + j1; c.o10 = i1 * s + j0; c.o11 = i1 * s + j1;
+  return c;
+}
+__device__ __forceinline__ double sample_field(const double* A, const LatticeCell& c) {
+  double c0 = (1.0 - c.ty) * A[c.o00] + c.ty * A[c.o01];
+  double c1 = (1.0 - c.ty) * A[c.o10] + c.ty * A[c.o11];
+  return (1.0 - c.tx) * c0 + c.tx * c1;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -640,15 +642,18 @@ __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
       if (!inb) continue;
       np++;
       double xc = x - cxf, yc = y - cyf;
-      double theta = atan2(yc, xc), rad = sqrt(xc * xc + yc * yc);
-      double st = sin(theta), ct = cos(theta);
+      // sin(atan(y, x)) and cos(atan(y, x)) of coupling.jl:1530-1537 as y/r and x/r (equal to
+      // within an ulp; atan(0, 0) = 0 gives sin = 0, cos = 1)
+      double rad = sqrt(xc * xc + yc * yc);
+      double st = rad > 0.0 ? yc / rad : 0.0, ct = rad > 0.0 ? xc / rad : 1.0;
       double up = u - xi * rad * st, vp = v + xi * rad * ct;
-      double uatm = sample_field(S, S.ua, x, y, per_x, per_y), vatm = sample_field(S, S.va, x, y, per_x, per_y);
+      LatticeCell lc = lattice_cell(S, x, y, per_x, per_y);
+      double uatm = sample_field(S.ua, lc), vatm = sample_field(S.va, lc);
       double du = uatm - up, dv = vatm - vp;
       double nrm = sqrt(du * du + dv * dv);
       double tax = P.rho_a * P.Cd_ia * nrm * du, tay = P.rho_a * P.Cd_ia * nrm * dv;
-      double uocn = sample_field(S, S.uo, x, y, per_x, per_y), vocn = sample_field(S, S.vo, x, y, per_x, per_y);
-      double hfl = sample_field(S, S.hf, x, y, per_x, per_y);
+      double uocn = sample_field(S.uo, lc), vocn = sample_field(S.vo, lc);
+      double hfl = sample_field(S.hf, lc);
       double duo = uocn - up, dvo = vocn - vp;
       double nrmo = sqrt(duo * duo + dvo * dvo);
       double tox = P.rho_o * P.Cd_io * nrmo * (cturn * duo - sturn * dvo);

@@ -27,7 +27,8 @@ enum {
   C_SCRATCH0, C_SCRATCH1,
   C_TRACE_FAIL,
   C_NOWN,         // floes this context integrates (== C_N unless tiled: owned floes come first)
-  C_NHALO,   // traces abandoned by the guard (diagnostic, cumulative)
+  C_NHALO,
+  C_ITEMCLASS,    // largest narrow-phase size class among this step's items   // traces abandoned by the guard (diagnostic, cumulative)
   C_COUNT = 32
 };
 
@@ -84,8 +85,9 @@ struct State {
   int* blk;
   // ---- motion scratch (integrator)
   double* mot;               // 4 per floe: dx, dy, cos, sin
+  long long* stamps;         // diagnostic build (-DSZ_STAMPS) only
 };
 
-enum { IT_FUSE = 1, IT_REMOVE = 2 };
+using szg_flags_note = int;   // IT_FUSE / IT_REMOVE are defined in sz_geom.hpp
 
 }  // namespace sz
