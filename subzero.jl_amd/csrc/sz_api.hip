@@ -48,6 +48,7 @@ struct sz_ctx {
   std::vector<std::vector<int>> fuse_lists;
   long long* d_stats = nullptr;
   int last_dt = 0;
+  bool any_moving = false;
   int dbg = 0;   // SZ_DEBUG bits: timing experiments only (1 skip contact rows, 2 skip direction check, 4 skip clip)
 };
 
@@ -181,7 +182,8 @@ int upload_elements(sz_ctx* c) {
   S.any_periodic_ew = c->h_kinds[SZ_EAST] == SZ_PERIODIC && c->h_kinds[SZ_WEST] == SZ_PERIODIC;
   S.any_periodic_ns = c->h_kinds[SZ_NORTH] == SZ_PERIODIC && c->h_kinds[SZ_SOUTH] == SZ_PERIODIC;
   S.any_domain_work = ntopo > 0;
-  for (int k = 0; k < 4; k++) if (c->h_kinds[k] != SZ_PERIODIC) S.any_domain_work = 1;
+  c->any_moving = false;
+  for (int k = 0; k < 4; k++) { if (c->h_kinds[k] != SZ_PERIODIC) S.any_domain_work = 1; if (c->h_kinds[k] == SZ_MOVING) c->any_moving = true; }
   c->have_domain = true;
   return SZ_OK;
 }
@@ -192,16 +194,13 @@ void stage_ghosts(sz_ctx* c) {
   if (!S.any_periodic_ew && !S.any_periodic_ns) return;
   (void)hipMemsetAsync(S.cnt + C_NGHOSTS, 0, sizeof(int), c->stream);
   Timed t(c, SZ_K_GHOSTS);
-  int gN = grid_for(S.capM, 256);
-  for (int axis = 0; axis < 2; axis++) {
-    if (axis == 0 && !S.any_periodic_ew) continue;
-    if (axis == 1 && !S.any_periodic_ns) continue;
-    hipLaunchKernelGGL(sz_k_ghost_flag, dim3(gN), dim3(256), 0, c->stream, S, axis);
-    scan(c, S.gcnt, S.gscan, S.capM, C_N, 0, C_NG_NEW);
-    scan(c, S.gvcnt, S.gvscan, S.capM, C_N, 0, C_SCRATCH0);
-    hipLaunchKernelGGL(sz_k_ghost_fill, dim3(gN), dim3(256), 0, c->stream, S, axis);
-    hipLaunchKernelGGL(sz_k_ghost_commit, dim3(1), dim3(64), 0, c->stream, S);
-  }
+  int gN = grid_for(S.capM, 256), nb = grid_for(S.capM, SCAN_B, 1 << 20);
+  hipLaunchKernelGGL(sz_k_ghost_flag, dim3(gN), dim3(256), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_scan4_1, dim3(nb), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.gblk4, S.cnt, C_N);
+  hipLaunchKernelGGL(sz_k_scan4_2, dim3(1), dim3(SCAN_B), 0, c->stream, S.gblk4, S.cnt, C_N);
+  hipLaunchKernelGGL(sz_k_scan4_3, dim3(nb), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.gblk4, S.cnt, C_N, S.gtot4);
+  hipLaunchKernelGGL(sz_k_ghost_fill, dim3(gN), dim3(256), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_ghost_commit, dim3(1), dim3(64), 0, c->stream, S);
   t.end();
 }
 
@@ -261,11 +260,10 @@ void stage_reduce(sz_ctx* c, int mirror, int n_init, int dt) {
   State& S = c->S;
   Timed t(c, SZ_K_REDUCE);
   int gM = grid_for(S.capM, 256);
-  hipLaunchKernelGGL(sz_k_cnt1, dim3(gM), dim3(256), 0, c->stream, S, mirror);
-  hipLaunchKernelGGL(sz_k_tot, dim3(gM), dim3(256), 0, c->stream, S, mirror);
+  hipLaunchKernelGGL(sz_k_cnt_tot, dim3(gM), dim3(256), 0, c->stream, S, mirror);
   scan(c, S.tot, S.inter_off, S.capM, C_M, 0, C_NINTER);
   hipLaunchKernelGGL(sz_k_inter_fill, dim3(grid_for(S.capM, 128)), dim3(128), 0, c->stream, S, mirror, n_init);
-  if (mirror) hipLaunchKernelGGL(sz_k_update_boundaries, dim3(1), dim3(64), 0, c->stream, S, dt);
+  if (mirror && c->any_moving) hipLaunchKernelGGL(sz_k_update_boundaries, dim3(1), dim3(64), 0, c->stream, S, dt);
   t.end();
 }
 
@@ -460,6 +458,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   H2D(S.voff, f->vert_off, M + 1, int); H2D(S.vx, f->vx, V, double); H2D(S.vy, f->vy, V, double);
   DA(soff, S.capM + 1); DA(sx, NS); DA(sy, NS);
   if (f->sub_off) { H2D(S.soff, f->sub_off, N + 1, int); H2D(S.sx, f->sx, NS, double); H2D(S.sy, f->sy, NS, double); }
+  DA(gplan, S.capM + 1); DA(gscan4, S.capM + 1); DA(gblk4, S.capM / SCAN_B + 1024); DA(gtot4, 4);
   DA(gflag, S.capM + 1); DA(gcnt, S.capM + 1); DA(gscan, S.capM + 2); DA(gvcnt, S.capM + 1); DA(gvscan, S.capM + 2);
   DA(bounds, 16 + 64 * 4); DA(cell_of, S.capM); DA(cell_cnt, S.capCells + 1); DA(cell_off, S.capCells + 2); DA(cell_cur, S.capCells + 1);
   DA(cell_items, S.capM);

@@ -105,32 +105,104 @@ __global__ void sz_k_elem_osign(State S) {
 }
 
 // ============================================================================ ghosts (A1)
-// axis 0: east/west pass, axis 1: north/south pass (collisions.jl:1171-1172: E/W first)
-__global__ void sz_k_ghost_flag(State S, int axis) {
-  int N = S.cnt[C_N];
+// add_ghosts! (collisions.jl:1060-1174) runs an east/west pass and then a north/south pass over
+// the parents.  Whether a parent gets a ghost in a pass depends on that parent alone (the x-swap of
+// the first pass does not touch y), so both passes are planned by ONE flag kernel, ordered by ONE
+// scan of int4 {E/W ghosts, E/W ring points, N/S ghosts, N/S ring points} and carried out by ONE
+// fill kernel in which each thread does its parent's E/W step and then its N/S step (which copies
+// the E/W ghost the same thread has just made).  Rows come out in the reference's order: all E/W
+// ghosts by parent, then all N/S ghosts by parent with the ghost-of-ghost before the parent's copy.
+
+// int4 exclusive scan (same three-kernel scheme as the int scan)
+__device__ __forceinline__ int4 add4(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ int4 shfl_up4(int4 v, int d) { return make_int4(__shfl_up(v.x, d), __shfl_up(v.y, d), __shfl_up(v.z, d), __shfl_up(v.w, d)); }
+__device__ __forceinline__ int4 block_exclusive_scan4(int4 v, int4* total) {
+  __shared__ int4 wsum4[SCAN_B / 64];
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int4 inc = v;
+  for (int d = 1; d < 64; d <<= 1) { int4 t = shfl_up4(inc, d); if (lane >= d) inc = add4(inc, t); }
+  if (lane == 63) wsum4[wid] = inc;
+  __syncthreads();
+  if (wid == 0) {
+    int4 w = lane < (int)(blockDim.x >> 6) ? wsum4[lane] : make_int4(0, 0, 0, 0), wi = w;
+    for (int d = 1; d < 64; d <<= 1) { int4 t = shfl_up4(wi, d); if (lane >= d) wi = add4(wi, t); }
+    if (lane < (int)(blockDim.x >> 6)) wsum4[lane] = make_int4(wi.x - w.x, wi.y - w.y, wi.z - w.z, wi.w - w.w);
+    if (lane == 63) *total = wi;
+  }
+  __syncthreads();
+  int4 o = wsum4[wid];
+  int4 res = make_int4(inc.x - v.x + o.x, inc.y - v.y + o.y, inc.z - v.z + o.z, inc.w - v.w + o.w);
+  __syncthreads();
+  return res;
+}
+__global__ void __launch_bounds__(SCAN_B) sz_k_scan4_1(const int4* in, int4* out, int4* blk, const int* cnt, int ci) {
+  __shared__ int4 tot;
+  int n = cnt[ci];
+  int base = blockIdx.x * SCAN_B;
+  if (base >= n && !(n == 0 && blockIdx.x == 0)) return;
+  int i = base + threadIdx.x;
+  int4 v = i < n ? in[i] : make_int4(0, 0, 0, 0);
+  int4 ex = block_exclusive_scan4(v, &tot);
+  if (i < n) out[i] = ex;
+  if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(SCAN_B) sz_k_scan4_2(int4* blk, const int* cnt, int ci) {
+  __shared__ int4 tot;
+  int n = cnt[ci];
+  int nb = (n + SCAN_B - 1) / SCAN_B;
+  if (nb < 1) nb = 1;
+  int4 carry = make_int4(0, 0, 0, 0);
+  for (int base = 0; base < nb; base += SCAN_B) {
+    int i = base + threadIdx.x;
+    int4 v = i < nb ? blk[i] : make_int4(0, 0, 0, 0);
+    int4 ex = block_exclusive_scan4(v, &tot);
+    if (i < nb) blk[i] = add4(ex, carry);
+    carry = add4(carry, tot);
+    __syncthreads();
+  }
+}
+// adds the block offsets; the grand totals go to tot4[0]
+__global__ void __launch_bounds__(SCAN_B) sz_k_scan4_3(const int4* in, int4* out, const int4* blk, const int* cnt, int ci, int4* tot4) {
+  int n = cnt[ci];
+  int i = blockIdx.x * SCAN_B + threadIdx.x;
+  if (n == 0) { if (i == 0) tot4[0] = make_int4(0, 0, 0, 0); return; }
+  if (i >= n) return;
+  int4 o = add4(out[i], blk[blockIdx.x]);
+  out[i] = o;
+  if (i == n - 1) tot4[0] = add4(o, in[i]);
+}
+
+// does ring i reach strictly beyond the wall in the direction that needs a ghost?  This is
+// !isempty(intersect_polys(poly, boundary.poly)) of collisions.jl:889: the wall rectangle extends
+// half a domain outward, so a positive-area overlap exists iff a vertex lies strictly beyond the wall
+__device__ __forceinline__ int ghost_dir(const State& S, int i, int axis) {
   const int maxb = axis == 0 ? 2 : 0, minb = axis == 0 ? 3 : 1;
   double maxv = S.eval[maxb], minv = S.eval[minb];
+  double c = axis == 0 ? S.cx[i] : S.cy[i], r = S.rmax[i];
+  int dir = 0;
+  if (c - r < minv) dir = 1; else if (c + r > maxv) dir = -1;
+  if (dir != 0) {
+    const double* v = axis == 0 ? S.vx : S.vy;
+    int o = S.voff[i], n = S.voff[i + 1] - o; bool beyond = false;
+    for (int k = 0; k < n; k++) { double x = v[o + k]; if (dir > 0 ? (x < minv) : (x > maxv)) { beyond = true; break; } }
+    if (!beyond) dir = 0;
+  }
+  return dir;
+}
+
+// plan of both passes for every parent: gplan[i] = {E/W ghosts, E/W points, N/S ghosts, N/S points}
+__global__ void sz_k_ghost_flag(State S) {
+  int N = S.cnt[C_N];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-    int dir = 0, cntg = 0, cntv = 0;
+    int dx = 0, dy = 0;
     if (S.status[i] == SZ_ACTIVE && S.ghost_id[i] == 0) {
-      double c = axis == 0 ? S.cx[i] : S.cy[i], r = S.rmax[i];
-      if (c - r < minv) dir = 1; else if (c + r > maxv) dir = -1;
-      if (dir != 0) {
-        // !isempty(intersect_polys(poly, boundary.poly)) (collisions.jl:889): the wall rectangle
-        // reaches half a domain outward, so a positive-area overlap exists iff a vertex lies
-        // strictly beyond the wall line
-        const double* v = axis == 0 ? S.vx : S.vy;
-        int o = S.voff[i], n = S.voff[i + 1] - o; bool beyond = false;
-        for (int k = 0; k < n; k++) { double x = v[o + k]; if (dir > 0 ? (x < minv) : (x > maxv)) { beyond = true; break; } }
-        if (!beyond) dir = 0;
-      }
-      if (dir != 0) {
-        int ng = S.ngh[i];
-        cntg = 1 + ng; cntv = S.voff[i + 1] - S.voff[i];
-        for (int k = 0; k < ng; k++) { int g = S.gh[i * MAX_GHOSTS + k]; cntv += S.voff[g + 1] - S.voff[g]; }
-      }
+      if (S.any_periodic_ew) dx = ghost_dir(S, i, 0);
+      if (S.any_periodic_ns) dy = ghost_dir(S, i, 1);
     }
-    S.gflag[i] = dir; S.gcnt[i] = cntg; S.gvcnt[i] = cntv;
+    int nv = S.voff[i + 1] - S.voff[i];
+    int gew = dx != 0 ? 1 : 0, gns = dy != 0 ? 1 + gew : 0;
+    S.gflag[i] = (dx + 1) | ((dy + 1) << 2);
+    S.gplan[i] = make_int4(gew, gew * nv, gns, gns * nv);
   }
 }
 
@@ -144,65 +216,75 @@ __device__ __forceinline__ void copy_floe_row(State& S, int dst, int src) {
   S.ngh[dst] = 0;
 }
 
-// gscan/gvscan hold the exclusive scans; cnt[C_NG_NEW]/cnt[C_SCRATCH0] the totals
-__global__ void sz_k_ghost_fill(State S, int axis) {
+// one ghost row: copy of `src` translated by (tx, ty) with its ring at vb (ghosts_on_bounds!, :881-901)
+__device__ __forceinline__ void make_ghost(State& S, int g, int src, int parent, int vb, double tx, double ty, int ghost_id,
+                                           long long okey) {
+  copy_floe_row(S, g, src);
+  S.cx[g] += tx; S.cy[g] += ty;
+  int so = S.voff[src], n = S.voff[src + 1] - so;
+  S.voff[g] = vb; S.voff[g + 1] = vb + n;      // neighbours write the same values: rings are packed back to back
+  for (int q = 0; q < n; q++) { S.vx[vb + q] = S.vx[so + q] + tx; S.vy[vb + q] = S.vy[so + q] + ty; }
+  S.ghost_id[g] = (long long)ghost_id; S.parent[g] = parent; S.okey[g] = okey;
+  for (int q = 0; q < MAX_GHOSTS; q++) S.gh[g * MAX_GHOSTS + q] = -1;
+}
+__device__ __forceinline__ void translate_row(State& S, int f, double px, double py) {
+  S.cx[f] += px; S.cy[f] += py;
+  int o = S.voff[f], n = S.voff[f + 1] - o;
+  for (int q = 0; q < n; q++) { S.vx[o + q] += px; S.vy[o + q] += py; }
+}
+
+// gscan4 holds the exclusive int4 scan of gplan, gtot4[0] the totals
+__global__ void sz_k_ghost_fill(State S) {
   int N = S.cnt[C_N], M0 = S.cnt[C_M], NV0 = S.cnt[C_NV];
-  int newg = S.cnt[C_NG_NEW], newv = S.cnt[C_SCRATCH0];
-  if (M0 + newg > S.capM) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
-  if (NV0 + newv > S.capV) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); return; }
-  const int maxb = axis == 0 ? 2 : 0, minb = axis == 0 ? 3 : 1;
-  double maxv = S.eval[maxb], minv = S.eval[minb];
-  double L = maxv - minv;
+  int4 T = S.gtot4[0];
+  if (M0 + T.x + T.z > S.capM) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
+  if (NV0 + T.y + T.w > S.capV) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); return; }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-    int dir = S.gflag[i];
-    if (dir == 0) continue;
-    double t = dir > 0 ? L : -L;
-    double tx = axis == 0 ? t : 0.0, ty = axis == 0 ? 0.0 : t;
-    int ng = S.ngh[i];
-    if (ng + 1 + ng > MAX_GHOSTS) { atomicOr(&S.cnt[C_ERR], ERR_GHOSTS_PER_PARENT); continue; }
-    int base = M0 + S.gscan[i], vb = NV0 + S.gvscan[i];
-    int last = base + ng;
-    for (int k = 0; k <= ng; k++) {                 // ghosts of existing ghosts first, then the parent's
-      int src = k < ng ? S.gh[i * MAX_GHOSTS + k] : i;
-      int g = base + k;
-      copy_floe_row(S, g, src);
-      S.cx[g] += tx; S.cy[g] += ty;
-      int so = S.voff[src], n = S.voff[src + 1] - so;
-      if (g == M0 + newg - 1) S.voff[g + 1] = vb + n;   // closing offset of the very last ghost
-      S.voff[g] = vb;
-      for (int q = 0; q < n; q++) { S.vx[vb + q] = S.vx[so + q] + tx; S.vy[vb + q] = S.vy[so + q] + ty; }
-      vb += n;
-      S.ghost_id[g] = (long long)(k + 1 + ng);
-      S.parent[g] = i;
-      // serial-order key: ghosts come after every parent, E/W-pass ghosts before N/S-pass ghosts,
-      // inside a pass by parent and copy number (collisions.jl:1024-1045)
-      S.okey[g] = S.tiled ? ((long long)(axis + 1) << 40) + S.okey[i] * 4 + k : (long long)g;
-      for (int q = 0; q < MAX_GHOSTS; q++) S.gh[g * MAX_GHOSTS + q] = -1;
+    int fl = S.gflag[i];
+    int dirs[2] = { (fl & 3) - 1, ((fl >> 2) & 3) - 1 };
+    if (dirs[0] == 0 && dirs[1] == 0) continue;
+    int4 sc = S.gscan4[i];
+    if (S.ngh[i] != 0) { atomicOr(&S.cnt[C_ERR], ERR_GHOSTS_PER_PARENT); continue; }
+    int ng = 0;
+    for (int axis = 0; axis < 2; axis++) {
+      int dir = dirs[axis];
+      if (dir == 0) continue;
+      const int maxb = axis == 0 ? 2 : 0, minb = axis == 0 ? 3 : 1;
+      double maxv = S.eval[maxb], minv = S.eval[minb], L = maxv - minv;
+      double t = dir > 0 ? L : -L;
+      double tx = axis == 0 ? t : 0.0, ty = axis == 0 ? 0.0 : t;
+      int base = axis == 0 ? M0 + sc.x : M0 + T.x + sc.z;
+      int vb = axis == 0 ? NV0 + sc.y : NV0 + T.y + sc.w;
+      int last = base + ng;
+      for (int k = 0; k <= ng; k++) {            // ghosts of the existing ghosts first, then the parent's
+        int src = k < ng ? S.gh[i * MAX_GHOSTS + k] : i;
+        long long key = S.tiled ? ((long long)(axis + 1) << 40) + S.okey[i] * 4 + k : (long long)(base + k);
+        make_ghost(S, base + k, src, i, vb, tx, ty, k + 1 + ng, key);
+        vb += S.voff[src + 1] - S.voff[src];
+      }
+      for (int k = 0; k <= ng; k++) S.gh[i * MAX_GHOSTS + ng + k] = base + k;
+      // parent centroid outside the domain: swap roles with its own new ghost (collisions.jl:942-950)
+      double c = axis == 0 ? S.cx[i] : S.cy[i];
+      double sp = 0.0;
+      if (c < minv) sp = L; else if (maxv < c) sp = -L;
+      if (sp != 0.0) {
+        double px = axis == 0 ? sp : 0.0, py = axis == 0 ? 0.0 : sp;
+        translate_row(S, i, px, py);
+        translate_row(S, last, -px, -py);
+      }
+      ng = ng + ng + 1;
     }
-    for (int k = 0; k <= ng; k++) S.gh[i * MAX_GHOSTS + ng + k] = base + k;
-    S.ngh[i] = ng + ng + 1;
-    // parent centroid outside the domain: swap roles with its own new ghost (collisions.jl:942-950)
-    double c = axis == 0 ? S.cx[i] : S.cy[i];
-    double sp = 0.0;
-    if (c < minv) sp = L; else if (maxv < c) sp = -L;
-    if (sp != 0.0) {
-      double px = axis == 0 ? sp : 0.0, py = axis == 0 ? 0.0 : sp;
-      S.cx[i] += px; S.cy[i] += py;
-      int o = S.voff[i], n = S.voff[i + 1] - o;
-      for (int q = 0; q < n; q++) { S.vx[o + q] += px; S.vy[o + q] += py; }
-      S.cx[last] += -px; S.cy[last] += -py;
-      int lo = S.voff[last], ln = n;
-      for (int q = 0; q < ln; q++) { S.vx[lo + q] += -px; S.vy[lo + q] += -py; }
-    }
+    S.ngh[i] = ng;
   }
 }
 __global__ void sz_k_ghost_commit(State S) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    int newg = S.cnt[C_NG_NEW], newv = S.cnt[C_SCRATCH0];
+    int4 T = S.gtot4[0];
+    int newg = T.x + T.z, newv = T.y + T.w;
     if (S.cnt[C_M] + newg <= S.capM && S.cnt[C_NV] + newv <= S.capV) {
       int M = S.cnt[C_M] + newg;
       S.cnt[C_M] = M; S.cnt[C_NV] += newv; S.cnt[C_NGHOSTS] += newg;
-      if (newg == 0) S.voff[M] = S.cnt[C_NV];
+      S.voff[M] = S.cnt[C_NV];
     }
   }
 }
@@ -481,30 +563,34 @@ __device__ __forceinline__ int find_pair(const State& S, int i, int k) {   // in
   return (lo < S.out_off[i + 1] && S.pair_j[lo] == k) ? lo : -1;
 }
 
-// rows of floe k before the ghost fold: own pairs (j asc), domain elements (N,S,E,W,topography),
-// rows mirrored from smaller-index partners (i asc).  Also resolves the status tags.
-__global__ void sz_k_cnt1(State S, int mirror) {
-  int M = S.cnt[C_M];
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
-    int c = 0, st = S.status[k];
-    for (int p = S.out_off[k]; p < S.out_off[k + 1]; p++) { c += S.it_nrows[p]; if (S.it_flags[p] & IT_FUSE) st = SZ_FUSE; }
-    for (int q = S.el_off[k]; q < S.el_off[k + 1]; q++) { c += S.it_nrows[S.capPairs + q]; if (S.it_flags[S.capPairs + q] & IT_REMOVE) st = SZ_REMOVE; }
-    S.tagA[k] = st;     // tag after the pair/domain phase, before the mirror pass (host fuse replay)
-    if (mirror) {
-      int n = S.n_in[k];
-      for (int t = 0; t < n; t++) {
-        int p = find_pair(S, S.nb_in[(size_t)k * MAXNB + t], k);
-        if (p >= 0) { c += S.it_nrows[p]; if (S.it_flags[p] & IT_FUSE) st = SZ_FUSE; }
-      }
+// number of rows of floe f before the ghost fold: own pairs (j asc), domain elements (N,S,E,W,
+// topography), rows mirrored from partners that come earlier in the serial order (i asc).
+// Also resolves the status tag of f (tagA = after the pair/domain phase, st = after the mirror pass).
+__device__ int count_rows(const State& S, int f, int mirror, int& st, int& tagA) {
+  int c = 0;
+  for (int p = S.out_off[f]; p < S.out_off[f + 1]; p++) { c += S.it_nrows[p]; if (S.it_flags[p] & IT_FUSE) st = SZ_FUSE; }
+  for (int q = S.el_off[f]; q < S.el_off[f + 1]; q++) { c += S.it_nrows[S.capPairs + q]; if (S.it_flags[S.capPairs + q] & IT_REMOVE) st = SZ_REMOVE; }
+  tagA = st;
+  if (mirror) {
+    int n = S.n_in[f];
+    for (int t = 0; t < n; t++) {
+      int p = find_pair(S, S.nb_in[(size_t)f * MAXNB + t], f);
+      if (p >= 0) { c += S.it_nrows[p]; if (S.it_flags[p] & IT_FUSE) st = SZ_FUSE; }
     }
-    S.cnt1[k] = c; S.status[k] = st;
   }
+  return c;
 }
-__global__ void sz_k_tot(State S, int mirror) {
+// rows per floe incl. the ghost fold for parents (collisions.jl:830-850)
+__global__ void sz_k_cnt_tot(State S, int mirror) {
   int M = S.cnt[C_M], N = S.cnt[C_N];
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
-    int c = S.cnt1[k];
-    if (mirror && k < N) { int ng = S.ngh[k]; for (int g = 0; g < ng; g++) c += S.cnt1[S.gh[k * MAX_GHOSTS + g]]; }
+    int st = S.status[k], tagA;
+    int c = count_rows(S, k, mirror, st, tagA);
+    S.tagA[k] = tagA; S.status[k] = st;
+    if (mirror && k < N) {
+      int ng = S.ngh[k];
+      for (int g = 0; g < ng; g++) { int gf = S.gh[k * MAX_GHOSTS + g]; int s2 = 0, t2; c += count_rows(S, gf, mirror, s2, t2); }
+    }
     S.tot[k] = c;
   }
 }

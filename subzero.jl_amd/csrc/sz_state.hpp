@@ -4,6 +4,7 @@
 // pointers and host-known capacities; all per-step counts live in the device counter block
 // `cnt` so that a whole timestep is enqueued without a host round trip.
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace sz {
@@ -70,6 +71,7 @@ struct State {
   double *uo, *vo, *hf, *ua, *va;
   // ---- ghosts workspace
   int *gflag, *gcnt, *gscan, *gvcnt, *gvscan;
+  int4 *gplan, *gscan4, *gblk4, *gtot4;
   // ---- broad phase
   double* bounds;            // xmin, ymin, cell size, (ncx, ncy as doubles)
   int *cell_of, *cell_cnt, *cell_off, *cell_cur, *cell_items;
