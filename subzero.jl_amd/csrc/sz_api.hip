@@ -192,14 +192,13 @@ int upload_elements(sz_ctx* c) {
 void stage_ghosts(sz_ctx* c) {
   State& S = c->S;
   if (!S.any_periodic_ew && !S.any_periodic_ns) return;
-  (void)hipMemsetAsync(S.cnt + C_NGHOSTS, 0, sizeof(int), c->stream);
   Timed t(c, SZ_K_GHOSTS);
   int gN = grid_for(S.capM, 256), nb = grid_for(S.capM, SCAN_B, 1 << 20);
   hipLaunchKernelGGL(sz_k_ghost_flag, dim3(gN), dim3(256), 0, c->stream, S);
   hipLaunchKernelGGL(sz_k_scan4_1, dim3(nb), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.gblk4, S.cnt, C_N);
   hipLaunchKernelGGL(sz_k_scan4_2, dim3(1), dim3(SCAN_B), 0, c->stream, S.gblk4, S.cnt, C_N);
   hipLaunchKernelGGL(sz_k_scan4_3, dim3(nb), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.gblk4, S.cnt, C_N, S.gtot4);
-  hipLaunchKernelGGL(sz_k_ghost_fill, dim3(gN), dim3(256), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_ghost_fill, dim3(grid_for(S.capM, 256, 1024)), dim3(256), 0, c->stream, S);
   hipLaunchKernelGGL(sz_k_ghost_commit, dim3(1), dim3(64), 0, c->stream, S);
   t.end();
 }
@@ -211,7 +210,7 @@ void stage_broad(sz_ctx* c) {
   hipLaunchKernelGGL(sz_k_bounds, dim3(1), dim3(1024), 0, c->stream, S);
   hipLaunchKernelGGL(sz_k_zero_int, dim3(grid_for(S.capCells, 256)), dim3(256), 0, c->stream, S.cell_cnt, S.cnt, C_NCELLS, 1);
   hipLaunchKernelGGL(sz_k_cell_build, dim3(gM), dim3(256), 0, c->stream, S);
-  hipLaunchKernelGGL(sz_k_neighbors, dim3(grid_for(S.capM, NB_TPB)), dim3(NB_TPB), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_neighbors, dim3(grid_for(S.capM, NB_TPB / NB_G, 8192)), dim3(NB_TPB), 0, c->stream, S);
   scan(c, S.n_out, S.out_off, S.capM, C_M, 0, C_NPAIRS);
   hipLaunchKernelGGL(sz_k_pairs_fill, dim3(gM), dim3(256), 0, c->stream, S);
   t.end();
@@ -237,7 +236,6 @@ void stage_elems(sz_ctx* c, bool enabled) {
 void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo) {
   State& S = c->S;
   long long capItems = (long long)S.capPairs + S.capElem;
-  (void)hipMemsetAsync(S.cnt + C_ITEMCLASS, 0, sizeof(int), c->stream);
   hipLaunchKernelGGL(sz_k_items_clear, dim3(grid_for(capItems, 256)), dim3(256), 0, c->stream, S);
   {
     Timed t(c, SZ_K_NARROW);
@@ -279,9 +277,10 @@ void stage_forcing(sz_ctx* c) {
   hipLaunchKernelGGL(sz_k_forcing, dim3(grid_for(c->S.capM, 4, 8192)), dim3(256), 0, c->stream, c->S, c->P);
   t.end();
 }
-void stage_integrate(sz_ctx* c, int dt) {
-  // the guard counters describe the last timestep_floe_properties! call
-  (void)hipMemsetAsync(c->S.cnt + C_WARN_H, 0, 4 * sizeof(int), c->stream);
+void stage_integrate(sz_ctx* c, int dt, bool reset_guards) {
+  // the guard counters describe the last timestep_floe_properties! call (inside a step the
+  // ghost-removal kernel has already cleared them)
+  if (reset_guards) (void)hipMemsetAsync(c->S.cnt + C_WARN_H, 0, 4 * sizeof(int), c->stream);
   Timed t(c, SZ_K_INTEGRATE);
   hipLaunchKernelGGL(sz_k_integrate, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt);
   hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S);
@@ -662,7 +661,7 @@ int sz_timestep_coupling(sz_ctx* c) {
 int sz_timestep_floe_properties(sz_ctx* c, int32_t dt) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
-  stage_integrate(c, dt);
+  stage_integrate(c, dt, true);
   return sync_and_check(c);
 }
 
@@ -676,7 +675,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     if (flags & SZ_COLLISIONS_ON) collisions(c, c->hostN, dt);
     hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
     if ((flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0) stage_forcing(c);
-    stage_integrate(c, dt);
+    stage_integrate(c, dt, false);
   }
   return sync_and_check(c);
 }
@@ -769,7 +768,7 @@ int sz_tile_step(sz_ctx* c, int32_t tstep, int32_t dt, int32_t coupling_dt, int3
   hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
   hipLaunchKernelGGL(sz_k_halo_drop, dim3(1), dim3(64), 0, c->stream, c->S);
   if ((flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0) stage_forcing(c);
-  stage_integrate(c, dt);
+  stage_integrate(c, dt, false);
   return sync_and_check(c);
 }
 

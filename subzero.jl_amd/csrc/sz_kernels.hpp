@@ -201,6 +201,7 @@ __global__ void sz_k_ghost_flag(State S) {
     }
     int nv = S.voff[i + 1] - S.voff[i];
     int gew = dx != 0 ? 1 : 0, gns = dy != 0 ? 1 + gew : 0;
+    if (i == 0) S.cnt[C_NGHOSTS] = 0;               // last step's count is kept until here for the stats
     S.gflag[i] = (dx + 1) | ((dy + 1) << 2);
     S.gplan[i] = make_int4(gew, gew * nv, gns, gns * nv);
   }
@@ -216,65 +217,88 @@ __device__ __forceinline__ void copy_floe_row(State& S, int dst, int src) {
   S.ngh[dst] = 0;
 }
 
+// Ghost rows are made by a whole wavefront: every lane executes the scalar column copies with the
+// same values (same-address stores coalesce), the ring loops are spread over the lanes.
+__device__ __forceinline__ void wave_mem_sync() {   // make the wave's global stores visible to its own later loads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 // one ghost row: copy of `src` translated by (tx, ty) with its ring at vb (ghosts_on_bounds!, :881-901)
-__device__ __forceinline__ void make_ghost(State& S, int g, int src, int parent, int vb, double tx, double ty, int ghost_id,
-                                           long long okey) {
+__device__ __forceinline__ void make_ghost(State& S, int lane, int g, int src, int parent, int vb, double tx, double ty,
+                                           int ghost_id, long long okey) {
   copy_floe_row(S, g, src);
-  S.cx[g] += tx; S.cy[g] += ty;
+  S.cx[g] = S.cx[src] + tx; S.cy[g] = S.cy[src] + ty;
   int so = S.voff[src], n = S.voff[src + 1] - so;
   S.voff[g] = vb; S.voff[g + 1] = vb + n;      // neighbours write the same values: rings are packed back to back
-  for (int q = 0; q < n; q++) { S.vx[vb + q] = S.vx[so + q] + tx; S.vy[vb + q] = S.vy[so + q] + ty; }
+  for (int q = lane; q < n; q += 64) { S.vx[vb + q] = S.vx[so + q] + tx; S.vy[vb + q] = S.vy[so + q] + ty; }
   S.ghost_id[g] = (long long)ghost_id; S.parent[g] = parent; S.okey[g] = okey;
-  for (int q = 0; q < MAX_GHOSTS; q++) S.gh[g * MAX_GHOSTS + q] = -1;
+  if (lane < MAX_GHOSTS) S.gh[g * MAX_GHOSTS + lane] = -1;
 }
-__device__ __forceinline__ void translate_row(State& S, int f, double px, double py) {
-  S.cx[f] += px; S.cy[f] += py;
+__device__ __forceinline__ void translate_row(State& S, int lane, int f, double px, double py) {
+  double ncx = S.cx[f] + px, ncy = S.cy[f] + py;
+  wave_mem_sync();                                 // every lane has read the old centroid
+  S.cx[f] = ncx; S.cy[f] = ncy;
   int o = S.voff[f], n = S.voff[f + 1] - o;
-  for (int q = 0; q < n; q++) { S.vx[o + q] += px; S.vy[o + q] += py; }
+  for (int q = lane; q < n; q += 64) { S.vx[o + q] += px; S.vy[o + q] += py; }
 }
 
 // gscan4 holds the exclusive int4 scan of gplan, gtot4[0] the totals
-__global__ void sz_k_ghost_fill(State S) {
+__global__ void __launch_bounds__(256) sz_k_ghost_fill(State S) {
   int N = S.cnt[C_N], M0 = S.cnt[C_M], NV0 = S.cnt[C_NV];
   int4 T = S.gtot4[0];
   if (M0 + T.x + T.z > S.capM) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
   if (NV0 + T.y + T.w > S.capV) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); return; }
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-    int fl = S.gflag[i];
-    int dirs[2] = { (fl & 3) - 1, ((fl >> 2) & 3) - 1 };
-    if (dirs[0] == 0 && dirs[1] == 0) continue;
-    int4 sc = S.gscan4[i];
-    if (S.ngh[i] != 0) { atomicOr(&S.cnt[C_ERR], ERR_GHOSTS_PER_PARENT); continue; }
-    int ng = 0;
-    for (int axis = 0; axis < 2; axis++) {
-      int dir = dirs[axis];
-      if (dir == 0) continue;
-      const int maxb = axis == 0 ? 2 : 0, minb = axis == 0 ? 3 : 1;
-      double maxv = S.eval[maxb], minv = S.eval[minb], L = maxv - minv;
-      double t = dir > 0 ? L : -L;
-      double tx = axis == 0 ? t : 0.0, ty = axis == 0 ? 0.0 : t;
-      int base = axis == 0 ? M0 + sc.x : M0 + T.x + sc.z;
-      int vb = axis == 0 ? NV0 + sc.y : NV0 + T.y + sc.w;
-      int last = base + ng;
-      for (int k = 0; k <= ng; k++) {            // ghosts of the existing ghosts first, then the parent's
-        int src = k < ng ? S.gh[i * MAX_GHOSTS + k] : i;
-        long long key = S.tiled ? ((long long)(axis + 1) << 40) + S.okey[i] * 4 + k : (long long)(base + k);
-        make_ghost(S, base + k, src, i, vb, tx, ty, k + 1 + ng, key);
-        vb += S.voff[src + 1] - S.voff[src];
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  // chunk c looks at parents c, c + nchunks, c + 2 nchunks, ..: floes near one wall have consecutive
+  // indices, striding spreads them over the wavefronts
+  const int nchunks = (N + 63) / 64;
+  for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
+    int mine = chunk + lane * nchunks;
+    int flm = mine < N ? S.gflag[mine] : 5;          // 5 = (0+1) | (0+1)<<2: no ghost
+    unsigned long long todo = __ballot(flm != 5);
+    while (todo) {
+      int src_lane = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int i = chunk + src_lane * nchunks;
+      const int fl = __shfl(flm, src_lane);
+      int dirs[2] = { (fl & 3) - 1, ((fl >> 2) & 3) - 1 };
+      int4 sc = S.gscan4[i];
+      if (S.ngh[i] != 0) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_GHOSTS_PER_PARENT); continue; }
+      int ng = 0;
+      for (int axis = 0; axis < 2; axis++) {
+        int dir = dirs[axis];
+        if (dir == 0) continue;
+        const int maxb = axis == 0 ? 2 : 0, minb = axis == 0 ? 3 : 1;
+        double maxv = S.eval[maxb], minv = S.eval[minb], L = maxv - minv;
+        double t = dir > 0 ? L : -L;
+        double tx = axis == 0 ? t : 0.0, ty = axis == 0 ? 0.0 : t;
+        int gbase = axis == 0 ? M0 + sc.x : M0 + T.x + sc.z;
+        int vb = axis == 0 ? NV0 + sc.y : NV0 + T.y + sc.w;
+        int last = gbase + ng;
+        for (int k = 0; k <= ng; k++) {            // ghosts of the existing ghosts first, then the parent's
+          int src = k < ng ? S.gh[i * MAX_GHOSTS + k] : i;
+          long long key = S.tiled ? ((long long)(axis + 1) << 40) + S.okey[i] * 4 + k : (long long)(gbase + k);
+          make_ghost(S, lane, gbase + k, src, i, vb, tx, ty, k + 1 + ng, key);
+          vb += S.voff[src + 1] - S.voff[src];
+        }
+        wave_mem_sync();
+        if (lane <= ng) S.gh[i * MAX_GHOSTS + ng + lane] = gbase + lane;
+        // parent centroid outside the domain: swap roles with its own new ghost (collisions.jl:942-950)
+        double c = axis == 0 ? S.cx[i] : S.cy[i];
+        double sp = 0.0;
+        if (c < minv) sp = L; else if (maxv < c) sp = -L;
+        if (sp != 0.0) {
+          double px = axis == 0 ? sp : 0.0, py = axis == 0 ? 0.0 : sp;
+          translate_row(S, lane, i, px, py);
+          translate_row(S, lane, last, -px, -py);
+        }
+        wave_mem_sync();
+        ng = ng + ng + 1;
       }
-      for (int k = 0; k <= ng; k++) S.gh[i * MAX_GHOSTS + ng + k] = base + k;
-      // parent centroid outside the domain: swap roles with its own new ghost (collisions.jl:942-950)
-      double c = axis == 0 ? S.cx[i] : S.cy[i];
-      double sp = 0.0;
-      if (c < minv) sp = L; else if (maxv < c) sp = -L;
-      if (sp != 0.0) {
-        double px = axis == 0 ? sp : 0.0, py = axis == 0 ? 0.0 : sp;
-        translate_row(S, i, px, py);
-        translate_row(S, last, -px, -py);
-      }
-      ng = ng + ng + 1;
+      if (lane == 0) S.ngh[i] = ng;
+      wave_mem_sync();
     }
-    S.ngh[i] = ng;
   }
 }
 __global__ void sz_k_ghost_commit(State S) {
@@ -295,7 +319,10 @@ __global__ void sz_k_remove_ghosts(State S) {
     S.ngh[i] = 0;
     for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = -1;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { S.cnt[C_M] = N; S.cnt[C_NV] = S.voff[N]; }   // C_NGHOSTS keeps the last step's count
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    S.cnt[C_M] = N; S.cnt[C_NV] = S.voff[N];        // C_NGHOSTS keeps the last step's count
+    S.cnt[C_WARN_H] = 0; S.cnt[C_WARN_F] = 0; S.cnt[C_WARN_V] = 0; S.cnt[C_WARN_XI] = 0;   // guards of the coming update
+  }
 }
 
 // ============================================================================ broad phase (A2, A3)
@@ -326,6 +353,7 @@ __global__ void __launch_bounds__(1024) sz_k_bounds(State S) {
       if (ncx * ncy <= (long long)S.capCells) break;
       cs *= 2.0;
     }
+    S.cnt[C_ITEMCLASS] = 0;                              // narrow-phase size classes of this step
     S.bounds[0] = x0; S.bounds[1] = y0; S.bounds[2] = cs; S.bounds[3] = (double)ncx; S.bounds[4] = (double)ncy;
     S.cnt[C_NCELLS] = (int)(ncx * ncy);
   }
@@ -376,24 +404,29 @@ __device__ bool pair_allowed(const State& S, int i, int j) {   // i < j, ids dif
   return (A && B) || (A != B);
 }
 
-// one thread per floe: neighbours that come later in the serial order (outgoing: the pairs this
-// floe owns) and earlier ones (incoming: the pairs mirrored onto it), both sorted by order key.
-// The two candidate lists are built in LDS and written out once.
-constexpr int NB_TPB = 64;
+// 16 lanes per floe, 9 of them walk one cell of the 3x3 neighbourhood each: neighbours that come
+// later in the serial order (outgoing: the pairs this floe owns) and earlier ones (incoming: the
+// pairs mirrored onto it).  Candidates are collected unsorted in LDS, then rank-sorted by order key.
+constexpr int NB_G = 16, NB_TPB = 128;
 __global__ void __launch_bounds__(NB_TPB) sz_k_neighbors(State S) {
-  __shared__ int lists[NB_TPB][2 * MAXNB + 1];
+  constexpr int GPB = NB_TPB / NB_G;
+  __shared__ int cand[GPB][2][MAXNB];
+  __shared__ long long ckey[GPB][2][MAXNB];
+  __shared__ int cnts[GPB][2];
+  const int gl = threadIdx.x % NB_G, gi = threadIdx.x / NB_G;
   int M = S.cnt[C_M];
   double x0 = S.bounds[0], y0 = S.bounds[1], cs = S.bounds[2]; int ncx = (int)S.bounds[3], ncy = (int)S.bounds[4];
-  int* lo = lists[threadIdx.x]; int* li = lo + MAXNB;
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
+  for (int k = blockIdx.x * GPB + gi; k < M; k += gridDim.x * GPB) {
+    gsync();
+    if (gl == 0) { cnts[gi][0] = 0; cnts[gi][1] = 0; }
+    gsync();
     double ckx = S.cx[k], cky = S.cy[k], rk = S.rmax[k];
     int ix = (int)floor((ckx - x0) / cs), iy = (int)floor((cky - y0) / cs);
-    int no = 0, ni = 0; bool ovf = false;
     long long idk = S.id[k], okk = S.okey[k];
-    for (int dy = -1; dy <= 1; dy++) {
-      int cy = iy + dy; if (cy < 0 || cy >= ncy) continue;
-      for (int dx = -1; dx <= 1; dx++) {
-        int cxi = ix + dx; if (cxi < 0 || cxi >= ncx) continue;
+    bool ovf = false;
+    if (gl < 9) {
+      int cy = iy + gl / 3 - 1, cxi = ix + gl % 3 - 1;
+      if (cy >= 0 && cy < ncy && cxi >= 0 && cxi < ncx) {
         for (int o = S.cell_cnt[cy * ncx + cxi] - 1; o >= 0; o = S.cell_items[o]) {
           if (o == k) continue;
           // potential_interaction (collisions.jl:705-710), symmetric in its arguments
@@ -403,18 +436,24 @@ __global__ void __launch_bounds__(NB_TPB) sz_k_neighbors(State S) {
           long long ko = S.okey[o];
           bool after = ko > okk;                   // o comes after k in the serial order
           if (!pair_allowed(S, after ? k : o, after ? o : k)) continue;
-          int* l = after ? lo : li; int& n = after ? no : ni;
-          if (n >= MAXNB) { ovf = true; continue; }
-          int u = n - 1;
-          while (u >= 0 && S.okey[l[u]] > ko) { l[u + 1] = l[u]; u--; }
-          l[u + 1] = o; n++;
+          int w = after ? 0 : 1;
+          int slot = atomicAdd(&cnts[gi][w], 1);
+          if (slot < MAXNB) { cand[gi][w][slot] = o; ckey[gi][w][slot] = ko; } else ovf = true;
         }
       }
     }
     if (ovf) atomicOr(&S.cnt[C_ERR], ERR_CAP_NEIGH);
-    S.n_out[k] = no; S.n_in[k] = ni;
-    for (int t = 0; t < no; t++) S.nb_out[(size_t)k * MAXNB + t] = lo[t];
-    for (int t = 0; t < ni; t++) S.nb_in[(size_t)k * MAXNB + t] = li[t];
+    gsync();
+    for (int w = 0; w < 2; w++) {
+      int n = cnts[gi][w] < MAXNB ? cnts[gi][w] : MAXNB;
+      int* dst = (w == 0 ? S.nb_out : S.nb_in) + (size_t)k * MAXNB;
+      for (int e = gl; e < n; e += NB_G) {
+        long long ke = ckey[gi][w][e]; int r = 0;
+        for (int f = 0; f < n; f++) r += ckey[gi][w][f] < ke;
+        dst[r] = cand[gi][w][e];
+      }
+      if (gl == 0) { if (w == 0) S.n_out[k] = n; else S.n_in[k] = n; }
+    }
   }
 }
 __global__ void sz_k_pairs_fill(State S) {
