@@ -49,6 +49,7 @@ struct sz_ctx {
   long long* d_stats = nullptr;
   int last_dt = 0;
   bool any_moving = false;
+  int max_ring = 0, max_elem_ring = 5;   // largest ring sizes (host knowledge: which narrow variants can be needed)
   int dbg = 0;   // SZ_DEBUG bits: timing experiments only (1 skip contact rows, 2 skip direction check, 4 skip clip)
 };
 
@@ -158,6 +159,8 @@ int upload_elements(sz_ctx* c) {
     ecx[e] = c->h_tcx[t]; ecy[e] = c->h_tcy[t]; erm[e] = c->h_trmax[t];
   }
   S.nelem = ne;
+  c->max_elem_ring = 5;
+  for (int e = 0; e < ne; e++) c->max_elem_ring = std::max(c->max_elem_ring, eoff[e + 1] - eoff[e]);
   int rc;
   if ((rc = dalloc(c, &S.eoff, ne + 1, c->static_allocs))) return rc;
   if ((rc = dalloc(c, &S.ex, ex.size(), c->static_allocs))) return rc;
@@ -236,7 +239,10 @@ void stage_elems(sz_ctx* c, bool enabled) {
 void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo) {
   State& S = c->S;
   long long capItems = (long long)S.capPairs + S.capElem;
-  hipLaunchKernelGGL(sz_k_items_clear, dim3(grid_for(capItems, 256)), dim3(256), 0, c->stream, S);
+  // Rings never change size inside the hot path, so the host knows whether any item can need a
+  // larger variant (halo floes of a tiled run arrive unseen: then always check on the device).
+  const bool larger = S.tiled || std::max(c->max_ring, c->max_elem_ring) > NARROW_CAP0;
+  if (larger) hipLaunchKernelGGL(sz_k_items_clear, dim3(grid_for(capItems, 256)), dim3(256), 0, c->stream, S);
   {
     Timed t(c, SZ_K_NARROW);
     constexpr int G = NARROW_G, TPB = 64;
@@ -244,7 +250,7 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo) {
                        c->stream, S, c->P, dt, ffmo, fdmo, c->dbg);
     t.end();
   }
-  {
+  if (larger) {
     Timed t(c, K_NARROW_LARGE);
     hipLaunchKernelGGL((sz_k_narrow<16, NARROW_CAP1, 16, 80, 6, 64, NARROW_CAP0, 1>), dim3(grid_for(capItems, 4, 2048)), dim3(64), 0,
                        c->stream, S, c->P, dt, ffmo, fdmo, c->dbg);
@@ -258,8 +264,6 @@ void stage_reduce(sz_ctx* c, int mirror, int n_init, int dt) {
   State& S = c->S;
   Timed t(c, SZ_K_REDUCE);
   int gM = grid_for(S.capM, 256);
-  hipLaunchKernelGGL(sz_k_cnt_tot, dim3(gM), dim3(256), 0, c->stream, S, mirror);
-  scan(c, S.tot, S.inter_off, S.capM, C_M, 0, C_NINTER);
   hipLaunchKernelGGL(sz_k_inter_fill, dim3(grid_for(S.capM, 128)), dim3(128), 0, c->stream, S, mirror, n_init);
   if (mirror && c->any_moving) hipLaunchKernelGGL(sz_k_update_boundaries, dim3(1), dim3(64), 0, c->stream, S, dt);
   t.end();
@@ -414,6 +418,8 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   State& S = c->S;
   const int M = (int)M64, N = (int)N64;
   const int V = f->vert_off[M];
+  c->max_ring = 0;
+  for (int i = 0; i < M; i++) c->max_ring = std::max(c->max_ring, f->vert_off[i + 1] - f->vert_off[i]);
   const int NS = f->sub_off ? f->sub_off[N] : 0;
   S.capM = 2 * M + 64; S.capV = 2 * V + 4096; S.capPairs = S.capM * 8; S.capElem = S.capM * 4;
   S.capRows = S.capPairs * 3 + S.capElem * 2; S.capCells = 4 * S.capM + 64; S.capS = NS;
@@ -466,7 +472,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(el_cnt, S.capM + 1); DA(el_off, S.capM + 2); DA(el_floe, S.capElem); DA(el_elem, S.capElem);
   size_t items = (size_t)S.capPairs + S.capElem;
   DA(it_rows, items * ROWS_PER_ITEM * 5); DA(it_nrows, items); DA(it_flags, items);
-  DA(cnt1, S.capM + 1); DA(tot, S.capM + 1); DA(inter_off, S.capM + 2); DA(inter_rows, (size_t)S.capRows * 7);
+  DA(inter_cnt, S.capM + 1); DA(inter_off, S.capM + 2); DA(inter_rows, (size_t)S.capM * ROWCAP * 7);
   DA(blk, std::max(S.capCells, std::max(S.capM, 1024)) / SCAN_B + 1024);
   DA(tagA, S.capM + 1);
   DA(stamps, 16);
@@ -495,7 +501,7 @@ int sz_get_stats(sz_ctx* c, sz_stats* out) {
   HIPCHK(c, hipMemcpy(&soffN, S.soff + h[C_N], sizeof(int), hipMemcpyDeviceToHost));
   out->M = h[C_M]; out->N = h[C_N]; out->n_ring_points = h[C_NV]; out->n_sub_points = soffN;
   out->n_pairs = h[C_NPAIRS]; out->n_pair_ring_points = st[0]; out->n_pair_rows = st[1];
-  out->n_elem_items = h[C_NELEM]; out->n_elem_rows = st[2]; out->n_inter_rows = h[C_NINTER]; out->n_ghosts = h[C_NGHOSTS];
+  out->n_elem_items = h[C_NELEM]; out->n_elem_rows = st[2]; out->n_inter_rows = st[3]; out->n_ghosts = h[C_NGHOSTS];
   out->warn_height = h[C_WARN_H]; out->warn_force = h[C_WARN_F]; out->warn_vel = h[C_WARN_V]; out->warn_xi = h[C_WARN_XI];
   out->n_trace_fail = h[C_TRACE_FAIL];
   return SZ_OK;
@@ -538,10 +544,22 @@ int sz_download_interactions(sz_ctx* c, int32_t* off, double* rows) {
   if (!c || !off || !c->have_floes) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
   State& S = c->S;
+  // rows are kept at a fixed stride on the device: compact to CSR here
+  scan(c, S.inter_cnt, S.inter_off, S.capM, C_M, 0, C_NINTER);
   int h[C_COUNT];
-  HIPCHK(c, hipMemcpy(h, S.cnt, sizeof(h), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpyAsync(h, S.cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(off, S.inter_off, (size_t)(h[C_M] + 1) * sizeof(int), hipMemcpyDeviceToHost));
-  if (rows && off[h[C_M]] > 0) HIPCHK(c, hipMemcpy(rows, S.inter_rows, (size_t)off[h[C_M]] * 7 * sizeof(double), hipMemcpyDeviceToHost));
+  int total = h[C_NINTER];
+  if (rows && total > 0) {
+    double* tmp = nullptr;
+    HIPCHK(c, hipMalloc((void**)&tmp, (size_t)total * 7 * sizeof(double)));
+    hipLaunchKernelGGL(sz_k_inter_compact, dim3(grid_for(S.capM, 128)), dim3(128), 0, c->stream, S, tmp);
+    hipError_t e = hipMemcpyAsync(rows, tmp, (size_t)total * 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) { c->err = hipGetErrorString(e); return SZ_E_HIP; }
+  }
   return SZ_OK;
 }
 

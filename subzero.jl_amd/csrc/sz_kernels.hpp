@@ -602,83 +602,66 @@ __device__ __forceinline__ int find_pair(const State& S, int i, int k) {   // in
   return (lo < S.out_off[i + 1] && S.pair_j[lo] == k) ? lo : -1;
 }
 
-// number of rows of floe f before the ghost fold: own pairs (j asc), domain elements (N,S,E,W,
-// topography), rows mirrored from partners that come earlier in the serial order (i asc).
-// Also resolves the status tag of f (tagA = after the pair/domain phase, st = after the mirror pass).
-__device__ int count_rows(const State& S, int f, int mirror, int& st, int& tagA) {
-  int c = 0;
-  for (int p = S.out_off[f]; p < S.out_off[f + 1]; p++) { c += S.it_nrows[p]; if (S.it_flags[p] & IT_FUSE) st = SZ_FUSE; }
-  for (int q = S.el_off[f]; q < S.el_off[f + 1]; q++) { c += S.it_nrows[S.capPairs + q]; if (S.it_flags[S.capPairs + q] & IT_REMOVE) st = SZ_REMOVE; }
-  tagA = st;
-  if (mirror) {
-    int n = S.n_in[f];
-    for (int t = 0; t < n; t++) {
-      int p = find_pair(S, S.nb_in[(size_t)f * MAXNB + t], f);
-      if (p >= 0) { c += S.it_nrows[p]; if (S.it_flags[p] & IT_FUSE) st = SZ_FUSE; }
-    }
-  }
-  return c;
-}
-// rows per floe incl. the ghost fold for parents (collisions.jl:830-850)
-__global__ void sz_k_cnt_tot(State S, int mirror) {
-  int M = S.cnt[C_M], N = S.cnt[C_N];
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
-    int st = S.status[k], tagA;
-    int c = count_rows(S, k, mirror, st, tagA);
-    S.tagA[k] = tagA; S.status[k] = st;
-    if (mirror && k < N) {
-      int ng = S.ngh[k];
-      for (int g = 0; g < ng; g++) { int gf = S.gh[k * MAX_GHOSTS + g]; int s2 = 0, t2; c += count_rows(S, gf, mirror, s2, t2); }
-    }
-    S.tot[k] = c;
-  }
-}
-// writes the rows of floe f (own, element, mirrored) at dst, shifted by (-sx, -sy); returns count
-__device__ int emit_rows(const State& S, int f, double* dst, double sx, double sy, int mirror, double* over_sum) {
-  int c = 0;
+// Interaction rows live at a fixed stride (ROWCAP rows per floe): no offsets, no scan in the step;
+// sz_download_interactions compacts them to CSR on demand.  A floe with more rows than ROWCAP
+// raises ERR_CAP_INTER.
+constexpr int ROWCAP = 32;
+
+// writes the rows of floe f -- own pairs (j asc), domain elements (N,S,E,W, topography), rows
+// mirrored from partners that come earlier in the serial order (i asc, force negated) -- at dst,
+// points shifted by (-sx, -sy).  Returns the count (clamped to cap, overflow flagged).  When
+// `st` is given it also resolves the status tag of f: tagA after the pair/domain phase
+// (collisions.jl:367,438,525), st after the mirror pass (:801-806).
+__device__ int emit_rows(const State& S, int f, double* dst, int cap, double sx, double sy, int mirror, double* over_sum,
+                         int* st, int* tagA) {
+  int c = 0; bool ovf = false;
+  auto put = [&](double idx, const double* s, double sign) {
+    if (c < cap) {
+      double* d = dst + (size_t)c * 7;
+      d[0] = idx; d[1] = s[0] * sign; d[2] = s[1] * sign; d[3] = s[2] - sx; d[4] = s[3] - sy; d[5] = 0.0; d[6] = s[4];
+      *over_sum += s[4];
+      c++;
+    } else ovf = true;
+  };
   for (int p = S.out_off[f]; p < S.out_off[f + 1]; p++) {
     int n = S.it_nrows[p]; const double* src = S.it_rows + (size_t)p * ROWS_PER_ITEM * 5;
-    for (int r = 0; r < n; r++) {
-      double* d = dst + (size_t)(c++) * 7; const double* s = src + r * 5;
-      d[0] = (double)(S.okey[S.pair_j[p]] + 1); d[1] = s[0]; d[2] = s[1]; d[3] = s[2] - sx; d[4] = s[3] - sy; d[5] = 0.0; d[6] = s[4];
-      *over_sum += s[4];
-    }
+    if (st && (S.it_flags[p] & IT_FUSE)) *st = SZ_FUSE;
+    double idx = (double)(S.okey[S.pair_j[p]] + 1);
+    for (int r = 0; r < n; r++) put(idx, src + r * 5, 1.0);
   }
   for (int q = S.el_off[f]; q < S.el_off[f + 1]; q++) {
     int item = S.capPairs + q; int n = S.it_nrows[item]; const double* src = S.it_rows + (size_t)item * ROWS_PER_ITEM * 5;
-    int e = S.el_elem[q];
-    for (int r = 0; r < n; r++) {
-      double* d = dst + (size_t)(c++) * 7; const double* s = src + r * 5;
-      d[0] = -(double)(e + 1); d[1] = s[0]; d[2] = s[1]; d[3] = s[2] - sx; d[4] = s[3] - sy; d[5] = 0.0; d[6] = s[4];
-      *over_sum += s[4];
-    }
+    if (st && (S.it_flags[item] & IT_REMOVE)) *st = SZ_REMOVE;
+    double idx = -(double)(S.el_elem[q] + 1);
+    for (int r = 0; r < n; r++) put(idx, src + r * 5, 1.0);
   }
+  if (tagA) *tagA = *st;
   if (mirror) {
     int m = S.n_in[f];
     for (int t = 0; t < m; t++) {
       int i = S.nb_in[(size_t)f * MAXNB + t]; int p = find_pair(S, i, f);
       if (p < 0) continue;
       int n = S.it_nrows[p]; const double* src = S.it_rows + (size_t)p * ROWS_PER_ITEM * 5;
-      for (int r = 0; r < n; r++) {
-        double* d = dst + (size_t)(c++) * 7; const double* s = src + r * 5;
-        d[0] = (double)(S.okey[i] + 1); d[1] = s[0] * -1; d[2] = s[1] * -1; d[3] = s[2] - sx; d[4] = s[3] - sy; d[5] = 0.0; d[6] = s[4];
-        *over_sum += s[4];
-      }
+      if (st && (S.it_flags[p] & IT_FUSE)) *st = SZ_FUSE;
+      double idx = (double)(S.okey[i] + 1);
+      for (int r = 0; r < n; r++) put(idx, src + r * 5, -1.0);
     }
   }
+  if (ovf) atomicOr(&S.cnt[C_ERR], ERR_CAP_INTER);
   return c;
 }
+// mirror pass, ghost fold, torque and totals (collisions.jl:799-862), one thread per floe
 __global__ void sz_k_inter_fill(State S, int mirror, int n_init) {
   int M = S.cnt[C_M];
-  int T = S.cnt[C_NINTER];
-  if (T > S.capRows) { if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&S.cnt[C_ERR], ERR_CAP_INTER); S.cnt[C_NINTER] = 0; } return; }
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
-    double* dst = S.inter_rows + (size_t)S.inter_off[k] * 7;
+    double* dst = S.inter_rows + (size_t)k * ROWCAP * 7;
     bool is_ghost = S.ghost_id[k] != 0;
     double sx = 0.0, sy = 0.0;
     if (mirror && is_ghost && S.parent[k] < n_init) { int p = S.parent[k]; sx = S.cx[k] - S.cx[p]; sy = S.cy[k] - S.cy[p]; }
     double over = 0.0;
-    int c = emit_rows(S, k, dst, sx, sy, mirror, &over);
+    int st = S.status[k], tagA = st;
+    int c = emit_rows(S, k, dst, ROWCAP, sx, sy, mirror, &over, &st, &tagA);
+    S.status[k] = st; S.tagA[k] = tagA;
     // reset + totals (collisions.jl:747-749, 852-861); ghosts keep zero totals
     double fx = 0.0, fy = 0.0, tq = 0.0;
     if (mirror && k < n_init) {
@@ -686,7 +669,7 @@ __global__ void sz_k_inter_fill(State S, int mirror, int n_init) {
       for (int g = 0; g < ng; g++) {
         int gf = S.gh[k * MAX_GHOSTS + g];
         double gx = S.cx[gf] - S.cx[k], gy = S.cy[gf] - S.cy[k];
-        c += emit_rows(S, gf, dst + (size_t)c * 7, gx, gy, mirror, &over);
+        c += emit_rows(S, gf, dst + (size_t)c * 7, ROWCAP - c, gx, gy, mirror, &over, nullptr, nullptr);
       }
       double cx = S.cx[k], cy = S.cy[k];
       for (int r = 0; r < c; r++) {
@@ -700,8 +683,18 @@ __global__ void sz_k_inter_fill(State S, int mirror, int n_init) {
       double cx = S.cx[k], cy = S.cy[k];
       for (int r = 0; r < c; r++) { double* d = dst + (size_t)r * 7; double xp = d[3] - cx, yp = d[4] - cy; d[5] = xp * d[2] - yp * d[1]; }
     }
+    S.inter_cnt[k] = c;
     S.cfx[k] = fx; S.cfy[k] = fy; S.ctrq[k] = tq;
     S.overarea[k] += over;
+  }
+}
+// CSR compaction of the fixed-stride rows (sz_download_interactions only)
+__global__ void sz_k_inter_compact(State S, double* dst) {
+  int M = S.cnt[C_M];
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
+    int n = S.inter_cnt[k]; const double* src = S.inter_rows + (size_t)k * ROWCAP * 7;
+    double* d = dst + (size_t)S.inter_off[k] * 7;
+    for (int q = 0; q < n * 7; q++) d[q] = src[q];
   }
 }
 // update_boundaries!, collisions.jl:565-571, boundaries.jl:526-568 (MovingBoundary only)
@@ -815,10 +808,10 @@ __global__ void sz_k_integrate(State S, Params P, int dt) {
     double cx = S.cx[i], cy = S.cy[i];
     // calc_stress!, update_floe.jl:392-414
     double s11 = 0, s12 = 0, s21 = 0, s22 = 0;
-    int ro = S.inter_off[i], rn = S.inter_off[i + 1] - ro;
+    int rn = S.inter_cnt[i];
     if (rn > 0) {
       for (int k = 0; k < rn; k++) {
-        const double* r = S.inter_rows + (size_t)(ro + k) * 7;
+        const double* r = S.inter_rows + ((size_t)i * ROWCAP + k) * 7;
         s11 += (r[3] - cx) * r[1];
         s12 += (r[4] - cy) * r[1] + (r[3] - cx) * r[2];
         s22 += (r[4] - cy) * r[2];
@@ -1015,7 +1008,7 @@ __global__ void __launch_bounds__(1024) sz_k_owned_box(State S, double* out) {
 
 // ============================================================================ stats
 __global__ void sz_k_stats(State S, long long* out) {
-  // out[0] = sum ring points over pairs, out[1] = pair rows, out[2] = elem rows
+  // out[0] = sum ring points over pairs, out[1] = pair rows, out[2] = elem rows, out[3] = interaction rows
   int npairs = S.cnt[C_NPAIRS], nel = S.cnt[C_NELEM];
   long long a = 0, b = 0, c = 0;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < npairs + nel; t += gridDim.x * blockDim.x) {
@@ -1028,6 +1021,9 @@ __global__ void sz_k_stats(State S, long long* out) {
   atomicAdd((unsigned long long*)&out[0], (unsigned long long)a);
   atomicAdd((unsigned long long*)&out[1], (unsigned long long)b);
   atomicAdd((unsigned long long*)&out[2], (unsigned long long)c);
+  long long d = 0;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < S.cnt[C_M]; k += gridDim.x * blockDim.x) d += S.inter_cnt[k];
+  atomicAdd((unsigned long long*)&out[3], (unsigned long long)d);
 }
 
 }  // namespace sz

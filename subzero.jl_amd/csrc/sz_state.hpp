@@ -82,7 +82,7 @@ struct State {
   // ---- contact rows per item (pairs first, then element items at capPairs + e)
   double* it_rows; int* it_nrows; int* it_flags;
   // ---- per-floe interaction lists
-  int *cnt1, *tot, *inter_off, *tagA; double* inter_rows;
+  int *inter_cnt, *inter_off, *tagA; double* inter_rows;   // ROWCAP rows per floe; inter_off: download scratch
   // ---- scan scratch
   int* blk;
   // ---- motion scratch (integrator)
