@@ -177,8 +177,9 @@ int sz_halo_pack(sz_ctx *ctx, int32_t nranks, int32_t my_rank, const double *box
 int sz_halo_unpack(sz_ctx *ctx, const void *d_recv, int64_t nrec);
 int sz_tile_step(sz_ctx *ctx, int32_t tstep, int32_t dt, int32_t coupling_dt, int32_t flags);
 
-/* diagnostic build (-DSZ_STAMPS) only: cycles per narrow-phase stage summed over lane groups */
-int sz_debug_stamps(sz_ctx *ctx, long long *out16);
+/* diagnostic build (-DSZ_STAMPS) only: stamp log of one lane group of the narrow phase
+   (out512[0] = entries, then (stage << 48) | cycles since the wave started) */
+int sz_debug_stamps(sz_ctx *ctx, long long *out512);
 
 #ifdef __cplusplus
 }

@@ -175,6 +175,7 @@ int upload_elements(sz_ctx* c) {
   if ((rc = dalloc(c, &S.ermax, ne, c->static_allocs))) return rc;
   if ((rc = dalloc(c, &S.erect, 16, c->static_allocs))) return rc;
   if ((rc = dalloc(c, &S.eosign, ne, c->static_allocs))) return rc;
+  if ((rc = dalloc(c, &S.ebb, 4 * ne, c->static_allocs))) return rc;
 #define H2D(dst, src, n, T) HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(T), hipMemcpyHostToDevice, c->stream))
   H2D(S.eoff, eoff.data(), ne + 1, int); H2D(S.ex, ex.data(), ex.size(), double); H2D(S.ey, ey.data(), ey.size(), double);
   H2D(S.ekind, ekind.data(), ne, int); H2D(S.edir, edir.data(), ne, int); H2D(S.eval, eval.data(), ne, double);
@@ -441,7 +442,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   if (f->stress_instant) H2D(S.si, f->stress_instant, 4 * M, double);
   if (f->strain) H2D(S.strain, f->strain, 4 * M, double);
   DA(id, S.capM); DA(ghost_id, S.capM); DA(okey, S.capM); DA(status, S.capM); DA(parent, S.capM); DA(gh, MAX_GHOSTS * S.capM); DA(ngh, S.capM);
-  DA(osign, S.capM);
+  DA(osign, S.capM); DA(bbx0, S.capM); DA(bbx1, S.capM); DA(bby0, S.capM); DA(bby1, S.capM);
   {
     std::vector<long long> id(M), gid(M, 0);
     std::vector<int> st(M, SZ_ACTIVE), parent(M), gh((size_t)MAX_GHOSTS * M, -1), ngh(M, 0);
@@ -475,7 +476,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(inter_cnt, S.capM + 1); DA(inter_off, S.capM + 2); DA(inter_rows, (size_t)S.capM * ROWCAP * 7);
   DA(blk, std::max(S.capCells, std::max(S.capM, 1024)) / SCAN_B + 1024);
   DA(tagA, S.capM + 1);
-  DA(stamps, 16);
+  DA(stamps, 512);
   int h[C_COUNT] = { 0 };
   h[C_M] = M; h[C_N] = N; h[C_NV] = V; h[C_NGHOSTS] = M - N; h[C_NOWN] = N;
   S.tiled = 0;
@@ -743,8 +744,8 @@ int sz_halo_record_doubles(void) { return HALO_REC; }
 int sz_debug_stamps(sz_ctx* c, long long* out16) {
   if (!c || !c->have_floes || !out16) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
-  HIPCHK(c, hipMemcpy(out16, c->S.stamps, 16 * sizeof(long long), hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemset(c->S.stamps, 0, 16 * sizeof(long long)));
+  HIPCHK(c, hipMemcpy(out16, c->S.stamps, 512 * sizeof(long long), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemset(c->S.stamps, 0, 512 * sizeof(long long)));
   return SZ_OK;
 }
 

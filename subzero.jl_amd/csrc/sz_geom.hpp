@@ -32,9 +32,9 @@ namespace szg {
 // In-kernel phase stamps for the diagnostic build only (-DSZ_STAMPS): cycles per phase summed
 // over all groups.  The production build compiles them out.
 #ifdef SZ_STAMPS
-struct Stamps { long long t, t0; long long acc[16]; };
-#define STAMP_INIT(st) do { for (int q_ = 0; q_ < 16; q_++) (st).acc[q_] = 0; (st).t = clock64(); (st).t0 = (st).t; } while (0)
-#define STAMP(st, k) do { long long n_ = clock64(); (st).acc[k] += n_ - (st).t; (st).t = n_; } while (0)
+struct Stamps { long long t0; long long* log; int n; bool on; };
+#define STAMP_INIT(st) do { (st).t0 = clock64(); (st).n = 0; (st).on = false; (st).log = nullptr; } while (0)
+#define STAMP(st, k) do { if ((st).on && (st).n < 500) { (st).log[(st).n++] = ((long long)(k) << 48) | (clock64() - (st).t0); } } while (0)
 #else
 struct Stamps {};
 #define STAMP_INIT(st) do {} while (0)
@@ -66,7 +66,8 @@ struct GroupMem {
   int16_t roff[2][RM + 2];
   uint8_t cfl[KC], rfl[KC], uniq[KC];
   int8_t ecode[RC];                          // many-intersect per-edge class
-  int nraw, nx, nreg[2], flag, err, ntracefail;
+  uint8_t ea[CAP], eb[CAP];                  // edges of a / b that reach into the overlap box
+  int nraw, nx, nreg[2], flag, err, ntracefail, nea, neb;
 };
 
 enum { ERR_CAP_RING = 1, ERR_CAP_XING = 2, ERR_CAP_REGION = 4, ERR_CAP_ROWS = 8, ERR_TRACE = 16,
@@ -221,6 +222,8 @@ SZ_DEV void ring_centroid(const double* x, const double* y, int n, double& cx, d
   cy = yc / (6.0 * area);
 }
 
+struct Box { double x0, x1, y0, y1; };   // closed bounding box of a ring
+
 template <int G>
 SZ_DEV double gmin(double v) { for (int d = G / 2; d >= 1; d >>= 1) v = fmin(v, __shfl_xor(v, d, G)); return v; }
 template <int G>
@@ -232,35 +235,43 @@ SZ_DEV double gmax(double v) { for (int d = G / 2; d >= 1; d >>= 1) v = fmax(v, 
 // is applied on the fly (x + 0.0 == x, so the untranslated clip is unchanged).
 // Group-uniform: every lane of the group calls it with the same arguments.
 template <int G, class MEM>
-SZ_DEV void clip(MEM& m, int gl, double ox, double oy, int na, int oa, int nb, int ob, int buf, bool skip_bbox, Stamps& st) {
+SZ_DEV void clip(MEM& m, int gl, double ox, double oy, int na, int oa, int nb, int ob, int buf, const Box& ba, const Box& bb,
+                 Stamps& st) {
   constexpr int KC = sizeof(m.cta) / sizeof(double);
   constexpr int RC = sizeof(m.ecode);
   constexpr int RM = MEM::RMAXV;
   const double* pax = m.ax; const double* pay = m.ay; const double* pbx = m.bx; const double* pby = m.by;
   double* rgx = m.reg[buf][0]; double* rgy = m.reg[buf][1];
-  if (gl == 0) { m.nraw = 0; m.nreg[buf] = 0; m.roff[buf][0] = 0; }
+  if (gl == 0) { m.nraw = 0; m.nreg[buf] = 0; m.roff[buf][0] = 0; m.nea = 0; m.neb = 0; }
   if (na < 4 || nb < 4) { if (gl == 0) m.nx = 0; gsync(); return; }
-  if (!skip_bbox) {
-    double x0 = __builtin_inf(), x1 = -__builtin_inf(), y0 = __builtin_inf(), y1 = -__builtin_inf();
-    double u0 = x0, u1 = x1, v0 = y0, v1 = y1;
-    for (int i = gl; i < na; i += G) { double x = pax[i] + ox, y = pay[i] + oy; x0 = fmin(x0, x); x1 = fmax(x1, x); y0 = fmin(y0, y); y1 = fmax(y1, y); }
-    for (int i = gl; i < nb; i += G) { u0 = fmin(u0, pbx[i]); u1 = fmax(u1, pbx[i]); v0 = fmin(v0, pby[i]); v1 = fmax(v1, pby[i]); }
-    x0 = gmin<G>(x0); x1 = gmax<G>(x1); y0 = gmin<G>(y0); y1 = gmax<G>(y1);
-    u0 = gmin<G>(u0); u1 = gmax<G>(u1); v0 = gmin<G>(v0); v1 = gmax<G>(v1);
-    if (x1 < u0 || u1 < x0 || y1 < v0 || v1 < y0) { if (gl == 0) m.nx = 0; gsync(); return; }
+  // bounding boxes are kept per floe (min/max commute with the rounding of `+ ox`, so the box of
+  // the translated ring is the translated box, bit for bit)
+  const double ax0 = ba.x0 + ox, ax1 = ba.x1 + ox, ay0 = ba.y0 + oy, ay1 = ba.y1 + oy;
+  if (ax1 < bb.x0 || bb.x1 < ax0 || ay1 < bb.y0 || bb.y1 < ay0) { if (gl == 0) m.nx = 0; gsync(); return; }
+  // overlap box: a crossing point lies in both rings' boxes, so only edges that reach into it can cross
+  const double qx0 = fmax(ax0, bb.x0), qx1 = fmin(ax1, bb.x1), qy0 = fmax(ay0, bb.y0), qy1 = fmin(ay1, bb.y1);
+  gsync();
+  for (int ia = gl; ia + 1 < na; ia += G) {
+    double px = pax[ia] + ox, py = pay[ia] + oy, rx = pax[ia + 1] + ox, ry = pay[ia + 1] + oy;
+    if (fmax(px, rx) >= qx0 && fmin(px, rx) <= qx1 && fmax(py, ry) >= qy0 && fmin(py, ry) <= qy1) m.ea[atomicAdd(&m.nea, 1)] = (uint8_t)ia;
+  }
+  for (int ib = gl; ib + 1 < nb; ib += G) {
+    double px = pbx[ib], py = pby[ib], rx = pbx[ib + 1], ry = pby[ib + 1];
+    if (fmax(px, rx) >= qx0 && fmin(px, rx) <= qx1 && fmax(py, ry) >= qy0 && fmin(py, ry) <= qy1) m.eb[atomicAdd(&m.neb, 1)] = (uint8_t)ib;
   }
   gsync();
   STAMP(st, 1);
-  // ---- crossing detection, phase 1: which (a-edge, b-edge) pairs cross -- orientation signs only,
-  // a-edges over lanes.  Lanes of a wavefront diverge here, so the loop body is kept minimal; the
-  // divisions of the crossing parameters are done afterwards, once per crossing (phase 2).
+  // ---- crossing detection, phase 1: which candidate (a-edge, b-edge) pairs cross -- orientation
+  // signs only, candidate pairs over lanes.  The divisions of the crossing parameters are done
+  // afterwards, once per crossing (phase 2).
   double* raw = m.reg[1][0];
-  for (int ia = gl; ia + 1 < na; ia += G) {
-    double px = pax[ia] + ox, py = pay[ia] + oy, qx = pax[ia + 1] + ox, qy = pay[ia + 1] + oy;
-    double rx = pbx[0], ry = pby[0];
-#pragma unroll 2
-    for (int ib = 0; ib + 1 < nb; ib++) {
-      double sx = pbx[ib + 1], sy = pby[ib + 1];
+  {
+    const int ca = m.nea, cb = m.neb, tot = ca * cb;
+    for (int t = gl; t < tot; t += G) {
+      int ua = t / cb, ub = t - ua * cb;
+      int ia = m.ea[ua], ib = m.eb[ub];
+      double px = pax[ia] + ox, py = pay[ia] + oy, qx = pax[ia + 1] + ox, qy = pay[ia + 1] + oy;
+      double rx = pbx[ib], ry = pby[ib], sx = pbx[ib + 1], sy = pby[ib + 1];
       int sp = side_a_vs_b(rx, ry, sx, sy, px, py), sq = side_a_vs_b(rx, ry, sx, sy, qx, qy);
       if (sp != sq) {
         int sr = side_b_vs_a(px, py, qx, qy, rx, ry), ss = side_b_vs_a(px, py, qx, qy, sx, sy);
@@ -272,13 +283,11 @@ SZ_DEV void clip(MEM& m, int gl, double ox, double oy, int na, int oa, int nb, i
           }
         }
       }
-      rx = sx; ry = sy;
     }
   }
   gsync();
   int K = m.nraw;
   if (K > KC) { if (gl == 0) { m.err |= ERR_CAP_XING; m.nx = 0; } gsync(); return; }
-  STAMP(st, 2);
   // ---- phase 2: parameters and point of every crossing (one lane per crossing)
   for (int s2 = gl; s2 < K; s2 += G) {
     int ia = m.ria[s2], ib = m.rib[s2];
@@ -308,8 +317,10 @@ SZ_DEV void clip(MEM& m, int gl, double ox, double oy, int na, int oa, int nb, i
   STAMP(st, 4);
   if (K == 0) {
     // boundaries do not cross: containment
-    bool a_in_b = ring_inside(pax, pay, na, ox, oy, pbx, pby, nb);
-    bool b_in_a = a_in_b ? false : ring_inside_off(pbx, pby, nb, pax, pay, na, ox, oy);
+    // a ring inside another has its box inside the other's box (closed): skip the walk otherwise
+    bool a_in_b = (bb.x0 <= ax0 && ax1 <= bb.x1 && bb.y0 <= ay0 && ay1 <= bb.y1) && ring_inside(pax, pay, na, ox, oy, pbx, pby, nb);
+    bool b_in_a = a_in_b ? false
+                         : (ax0 <= bb.x0 && bb.x1 <= ax1 && ay0 <= bb.y0 && bb.y1 <= ay1) && ring_inside_off(pbx, pby, nb, pax, pay, na, ox, oy);
     if (a_in_b || b_in_a) {
       int n = a_in_b ? na : nb;
       if (n > RC) { if (gl == 0) m.err |= ERR_CAP_REGION; }
@@ -356,11 +367,12 @@ SZ_DEV void clip(MEM& m, int gl, double ox, double oy, int na, int oa, int nb, i
     int c0 = m.ordA[s];
     if ((visited >> c0) & 1) continue;
     int start = off, cnt = 0, guard = 0;
-    auto emit = [&](double x, double y) {
+    // points are appended at off + cnt; every lane tracks cnt, the stores are spread over the lanes
+    auto emit1 = [&](double x, double y) {          // one point (a crossing): lane 0 stores
       if (off + cnt < RC) { if (gl == 0) { rgx[off + cnt] = x; rgy[off + cnt] = y; } }
       cnt++;
     };
-    emit(m.cx[c0], m.cy[c0]);
+    emit1(m.cx[c0], m.cy[c0]);
     visited |= (1ull << c0);
     int cur = c0; bool on_a = true;
     uint32_t ci = m.cinfo[cur];
@@ -372,26 +384,24 @@ SZ_DEV void clip(MEM& m, int gl, double ox, double oy, int na, int oa, int nb, i
       double sx = on_a ? ox : 0.0, sy = on_a ? oy : 0.0;
       int r = on_a ? (int)((ci >> 14) & 63) : (int)((ci >> 20) & 63);
       int e0 = on_a ? (int)(ci & 127) : (int)((ci >> 7) & 127);
-      int rn, nxt, e1, nv, v;
+      int rn, nxt, e1, nv;
       uint32_t cn;
-      if (fwd) {
-        rn = r + 1; if (rn == K) rn = 0;
-        nxt = on_a ? m.ordA[rn] : m.ordB[rn];
-        cn = m.cinfo[nxt];
-        e1 = on_a ? (int)(cn & 127) : (int)((cn >> 7) & 127);
-        nv = (rn > r) ? (e1 - e0) : (ne - e0 + e1);
-        v = e0 + 1;
-        for (int t = 0; t < nv; t++) { if (v >= ne) v -= ne; emit(vx[v] + sx, vy[v] + sy); v++; }
-      } else {
-        rn = r - 1; if (rn < 0) rn = K - 1;
-        nxt = on_a ? m.ordA[rn] : m.ordB[rn];
-        cn = m.cinfo[nxt];
-        e1 = on_a ? (int)(cn & 127) : (int)((cn >> 7) & 127);
-        nv = (rn < r) ? (e0 - e1) : (ne + e0 - e1);
-        v = e0;
-        for (int t = 0; t < nv; t++) { if (v < 0) v += ne; emit(vx[v] + sx, vy[v] + sy); v--; }
+      if (fwd) { rn = r + 1; if (rn == K) rn = 0; } else { rn = r - 1; if (rn < 0) rn = K - 1; }
+      nxt = on_a ? m.ordA[rn] : m.ordB[rn];
+      cn = m.cinfo[nxt];
+      e1 = on_a ? (int)(cn & 127) : (int)((cn >> 7) & 127);
+      if (fwd) nv = (rn > r) ? (e1 - e0) : (ne - e0 + e1);
+      else     nv = (rn < r) ? (e0 - e1) : (ne + e0 - e1);
+      // the run of ring vertices between the two crossings: vertex t of the run is
+      // e0 + 1 + t (forward) or e0 - t (backward), modulo the ring; lanes copy it in parallel
+      for (int t = gl; t < nv; t += G) {
+        int v = fwd ? e0 + 1 + t : e0 - t;
+        if (v >= ne) v -= ne;
+        if (v < 0) v += ne;
+        if (off + cnt + t < RC) { rgx[off + cnt + t] = vx[v] + sx; rgy[off + cnt + t] = vy[v] + sy; }
       }
-      emit(m.cx[nxt], m.cy[nxt]);
+      cnt += nv;
+      emit1(m.cx[nxt], m.cy[nxt]);
       guard += nv + 1;
       if (guard > guard_max) { failed = true; break; }
       cur = nxt; ci = cn;
@@ -558,8 +568,8 @@ struct ItemCtx {
 // the kernel then fits the instruction cache, which matters more than anything else for a
 // divergent, latency-bound kernel like this one.
 template <int G, class MEM>
-SZ_DEV int collide_item(MEM& m, int gl, int na, int oa, int nb, int ob, const ItemCtx& cx_, double* out, int max_rows,
-                        int& flags, Stamps& st) {
+SZ_DEV int collide_item(MEM& m, int gl, int na, int oa, int nb, int ob, const Box& ba, const Box& bb, const ItemCtx& cx_,
+                        double* out, int max_rows, int& flags, Stamps& st) {
   constexpr int RM = MEM::RMAXV;
   int keep[RM]; int nkeep = 0, nrows = 0;
   double dlv[RM], dxv[RM], dyv[RM];
@@ -571,7 +581,7 @@ SZ_DEV int collide_item(MEM& m, int gl, int na, int oa, int nb, int ob, const It
     const double dl = q < 0 ? 0.0 : dlv[q];
     double dirx = q < 0 ? 0.0 : dxv[q], diry = q < 0 ? 0.0 : dyv[q];
     const bool check = q >= 0 && area != 0 && dl > 0.1 && !(cx_.dbg & 2);
-    if (q < 0 || check) clip<G>(m, gl, dirx, diry, na, oa, nb, ob, q < 0 ? 0 : 1, q >= 0, st);
+    if (q < 0 || check) clip<G>(m, gl, dirx, diry, na, oa, nb, ob, q < 0 ? 0 : 1, ba, bb, st);
     if (q < 0) {
       // ---------------- after the contact clip: overlap tests, force factor, per-region direction
       const int nreg = m.nreg[0];

@@ -94,6 +94,9 @@ __global__ void sz_k_osign(State S, int first) {
     int o = S.voff[i], n = S.voff[i + 1] - o;
     double a = ring_signed_area(S.vx + o, S.vy + o, n);
     S.osign[i] = a >= 0.0 ? 1 : -1;
+    double x0 = __builtin_inf(), x1 = -__builtin_inf(), y0 = __builtin_inf(), y1 = -__builtin_inf();
+    for (int q = 0; q < n; q++) { x0 = fmin(x0, S.vx[o + q]); x1 = fmax(x1, S.vx[o + q]); y0 = fmin(y0, S.vy[o + q]); y1 = fmax(y1, S.vy[o + q]); }
+    S.bbx0[i] = x0; S.bbx1[i] = x1; S.bby0[i] = y0; S.bby1[i] = y1;
   }
 }
 __global__ void sz_k_elem_osign(State S) {
@@ -101,6 +104,9 @@ __global__ void sz_k_elem_osign(State S) {
     int o = S.eoff[e], n = S.eoff[e + 1] - o;
     double a = ring_signed_area(S.ex + o, S.ey + o, n);
     S.eosign[e] = a >= 0.0 ? 1 : -1;
+    double x0 = __builtin_inf(), x1 = -__builtin_inf(), y0 = __builtin_inf(), y1 = -__builtin_inf();
+    for (int q = 0; q < n; q++) { x0 = fmin(x0, S.ex[o + q]); x1 = fmax(x1, S.ex[o + q]); y0 = fmin(y0, S.ey[o + q]); y1 = fmax(y1, S.ey[o + q]); }
+    S.ebb[4 * e] = x0; S.ebb[4 * e + 1] = x1; S.ebb[4 * e + 2] = y0; S.ebb[4 * e + 3] = y1;
   }
 }
 
@@ -213,6 +219,7 @@ __device__ __forceinline__ void copy_floe_row(State& S, int dst, int src) {
   S.alpha[dst] = S.alpha[src]; S.u[dst] = S.u[src]; S.v[dst] = S.v[src]; S.xi[dst] = S.xi[src];
   S.overarea[dst] = S.overarea[src]; S.id[dst] = S.id[src]; S.status[dst] = S.status[src];
   S.osign[dst] = S.osign[src];
+  S.bbx0[dst] = S.bbx0[src]; S.bbx1[dst] = S.bbx1[src]; S.bby0[dst] = S.bby0[src]; S.bby1[dst] = S.bby1[src];
   S.cfx[dst] = 0.0; S.cfy[dst] = 0.0; S.ctrq[dst] = 0.0;
   S.ngh[dst] = 0;
 }
@@ -228,6 +235,7 @@ __device__ __forceinline__ void make_ghost(State& S, int lane, int g, int src, i
                                            int ghost_id, long long okey) {
   copy_floe_row(S, g, src);
   S.cx[g] = S.cx[src] + tx; S.cy[g] = S.cy[src] + ty;
+  S.bbx0[g] = S.bbx0[src] + tx; S.bbx1[g] = S.bbx1[src] + tx; S.bby0[g] = S.bby0[src] + ty; S.bby1[g] = S.bby1[src] + ty;
   int so = S.voff[src], n = S.voff[src + 1] - so;
   S.voff[g] = vb; S.voff[g + 1] = vb + n;      // neighbours write the same values: rings are packed back to back
   for (int q = lane; q < n; q += 64) { S.vx[vb + q] = S.vx[so + q] + tx; S.vy[vb + q] = S.vy[so + q] + ty; }
@@ -236,8 +244,9 @@ __device__ __forceinline__ void make_ghost(State& S, int lane, int g, int src, i
 }
 __device__ __forceinline__ void translate_row(State& S, int lane, int f, double px, double py) {
   double ncx = S.cx[f] + px, ncy = S.cy[f] + py;
-  wave_mem_sync();                                 // every lane has read the old centroid
-  S.cx[f] = ncx; S.cy[f] = ncy;
+  double b0 = S.bbx0[f] + px, b1 = S.bbx1[f] + px, b2 = S.bby0[f] + py, b3 = S.bby1[f] + py;
+  wave_mem_sync();                                 // every lane has read the old values
+  S.cx[f] = ncx; S.cy[f] = ncy; S.bbx0[f] = b0; S.bbx1[f] = b1; S.bby0[f] = b2; S.bby1[f] = b3;
   int o = S.voff[f], n = S.voff[f + 1] - o;
   for (int q = lane; q < n; q += 64) { S.vx[o + q] += px; S.vy[o + q] += py; }
 }
@@ -528,6 +537,9 @@ __global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, do
   const int nitems = npairs + nel;
   if (gl == 0) { m.err = 0; m.ntracefail = 0; }
   Stamps st; STAMP_INIT(st);
+#ifdef SZ_STAMPS
+  st.on = (CLS == 0 && blockIdx.x == (unsigned)S.cnt[C_SCRATCH1] && threadIdx.x == 0); st.log = S.stamps + 1;
+#endif
   for (int t = blockIdx.x * GPB + gi; t < nitems; t += gridDim.x * GPB) {
     const bool is_pair = t < npairs;
     int i, j = -1, e = -1, item;
@@ -562,7 +574,9 @@ __global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, do
     }
     int nrows = 0, flags = 0;
     double* out = S.it_rows + (size_t)item * ROWS_PER_ITEM * 5;
-    if (!(dbg & 4)) nrows = collide_item<G>(m, gl, na, oa, nb, ob, ic, out, ROWS_PER_ITEM, flags, st);
+    Box ba{ S.bbx0[i], S.bbx1[i], S.bby0[i], S.bby1[i] };
+    Box bb = is_pair ? Box{ S.bbx0[j], S.bbx1[j], S.bby0[j], S.bby1[j] } : Box{ S.ebb[4 * e], S.ebb[4 * e + 1], S.ebb[4 * e + 2], S.ebb[4 * e + 3] };
+    if (!(dbg & 4)) nrows = collide_item<G>(m, gl, na, oa, nb, ob, ba, bb, ic, out, ROWS_PER_ITEM, flags, st);
     if (gl == 0) { S.it_nrows[item] = nrows; S.it_flags[item] = flags; }
     STAMP(st, 11);
   }
@@ -570,8 +584,7 @@ __global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, do
   if (gl == 0 && m.err) atomicOr(&S.cnt[C_ERR], m.err);
   if (gl == 0 && m.ntracefail) atomicAdd(&S.cnt[C_TRACE_FAIL], m.ntracefail);
 #ifdef SZ_STAMPS
-  st.acc[12] = clock64() - st.t0; st.acc[13] = 1; st.acc[14] = (st.acc[1] + st.acc[2]) > 0 ? 1 : 0;
-  if (gl == 0 && CLS == 0) for (int q = 0; q < 15; q++) atomicAdd((unsigned long long*)&S.stamps[q], (unsigned long long)st.acc[q]);
+  if (st.on) { STAMP(st, 15); S.stamps[0] = st.n; }
 #endif
 }
 
@@ -707,6 +720,7 @@ __global__ void sz_k_update_boundaries(State S, int dt) {
   int o = S.eoff[e];
   S.ex[o] = rc[0]; S.ey[o] = rc[2]; S.ex[o + 1] = rc[0]; S.ey[o + 1] = rc[3]; S.ex[o + 2] = rc[1]; S.ey[o + 2] = rc[3];
   S.ex[o + 3] = rc[1]; S.ey[o + 3] = rc[2]; S.ex[o + 4] = rc[0]; S.ey[o + 4] = rc[2];
+  S.ebb[4 * e] = rc[0]; S.ebb[4 * e + 1] = rc[1]; S.ebb[4 * e + 2] = rc[2]; S.ebb[4 * e + 3] = rc[3];
 }
 
 // ============================================================================ forcings (A13)
@@ -902,10 +916,14 @@ __global__ void __launch_bounds__(256) sz_k_move_strain(State S) {
     }
     // all reads of the old ring are done (each lane's loads complete before its dependent LDS
     // stores, and the sums above consumed every LDS store of the group)
+    double bx0 = __builtin_inf(), bx1 = -__builtin_inf(), by0 = __builtin_inf(), by1 = -__builtin_inf();
     for (int k = gl; k < n; k += G) {
       double mx, my; moved(k, mx, my);
       S.vx[o + k] = mx; S.vy[o + k] = my;
+      bx0 = fmin(bx0, mx); bx1 = fmax(bx1, mx); by0 = fmin(by0, my); by1 = fmax(by1, my);
     }
+    bx0 = gmin<G>(bx0); bx1 = gmax<G>(bx1); by0 = gmin<G>(by0); by1 = gmax<G>(by1);
+    if (gl == 0) { S.bbx0[i] = bx0; S.bbx1[i] = bx1; S.bby0[i] = by0; S.bby1[i] = by1; }
     if (gl == 0) {
       e12 *= 0.5;
       double d = 2 * S.area[i];
@@ -971,6 +989,9 @@ __global__ void sz_k_halo_unpack(State S, const double* recv, int nrec) {
     S.voff[g] = vb; S.voff[g + 1] = vb + nv;
     for (int k = 0; k < nv; k++) { S.vx[vb + k] = r[12 + k]; S.vy[vb + k] = r[12 + HALO_RING + k]; }
     S.osign[g] = ring_signed_area(S.vx + vb, S.vy + vb, nv) >= 0.0 ? 1 : -1;
+    double x0 = __builtin_inf(), x1 = -__builtin_inf(), y0 = __builtin_inf(), y1 = -__builtin_inf();
+    for (int k = 0; k < nv; k++) { x0 = fmin(x0, r[12 + k]); x1 = fmax(x1, r[12 + k]); y0 = fmin(y0, r[12 + HALO_RING + k]); y1 = fmax(y1, r[12 + HALO_RING + k]); }
+    S.bbx0[g] = x0; S.bbx1[g] = x1; S.bby0[g] = y0; S.bby1[g] = y1;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     S.cnt[C_M] = nown + nrec; S.cnt[C_N] = nown + nrec; S.cnt[C_NV] = vbase + totv; S.cnt[C_NHALO] = nrec;

@@ -60,12 +60,13 @@ struct State {
   long long *id, *ghost_id, *okey;   // okey: position in the reference's serial order
   int *status, *parent, *gh, *ngh;   // gh: MAX_GHOSTS per floe
   signed char* osign;                // ring orientation sign
+  double *bbx0, *bbx1, *bby0, *bby1; // ring bounding boxes (kept current by every kernel that moves a ring)
   int* voff; double *vx, *vy;
   int* soff; double *sx, *sy;
   // ---- domain elements: 0..3 = N,S,E,W boundaries, 4.. = topography
   int* eoff; double *ex, *ey;
   int *ekind, *edir; double *eval, *eu, *ev, *ecx, *ecy, *ermax, *erect;  // erect: 4 per boundary
-  signed char* eosign;
+  signed char* eosign; double* ebb;   // element orientation signs and boxes (4 per element)
   // ---- grid fields
   int Nx, Ny; double gx0, gxf, gy0, gyf, gdx, gdy;
   double *uo, *vo, *hf, *ua, *va;

@@ -1,4 +1,5 @@
-"""Diagnostic: builds a -DSZ_STAMPS copy of the library and prints cycles per narrow-phase stage."""
+"""Diagnostic: builds a -DSZ_STAMPS copy of the library and prints the stamp timeline of one lane
+group (block 0, group 0) of the narrow-phase kernel: stage id and cycles since the wave started."""
 import ctypes, os, subprocess, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from subzero_jl_amd import build as b
@@ -12,19 +13,17 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 cfg = fields.make_config(n_floes=n, seed=12345)
 w = fields.build_world(subzero_jl_amd.World(0), cfg)
 w.run(3, 0, cfg["dt"], coupling_dt=1)
-out = np.zeros(16, np.int64)
+out = np.zeros(512, np.int64)
 w._chk(w.L.sz_debug_stamps(w.h, capi.ptr(out, capi._lp)))
 w.profile(True)
-w.run(10, 3, cfg["dt"], coupling_dt=1)
+w.run(1, 3, cfg["dt"], coupling_dt=1)
 w._chk(w.L.sz_debug_stamps(w.h, capi.ptr(out, capi._lp)))
-P = w.stats()["n_pairs"]
-names = ["load rings", "bbox", "detect signs", "detect params", "canonical", "(K==0 pre)", "containment", "rank", "trace+area",
-         "match/many", "rows pre-check", "dir check", "rows tail+store"]
-names = ["0 load", "1 bbox", "2 detect-signs", "3 detect-params", "4 canonical", "5 containment", "6 rank", "7 trace+area",
-         "8 match/many", "9 rows-pre", "10 dircheck-intersects", "11 tail"]
-print("pairs", P, "steps 10; cycles per pair per stage (100 MHz ticks? see clock64):")
-for k, nm in enumerate(names):
-    print(f"  {nm:24s} {out[k] / (10 * P):10.1f}")
-print("  total", out[:12].sum() / (10 * P))
-print("  groups", out[13] / 10, "groups with items", out[14] / 10, "mean wave lifetime ticks", out[12] / max(out[13], 1))
-kt = w.kernel_times(); print("  narrow kernel ms", kt["narrow"][0] / max(kt["narrow"][1], 1))
+kt = w.kernel_times(); print("narrow kernel ms", kt["narrow"][0] / max(kt["narrow"][1], 1))
+names = {0: "rings staged", 1: "bbox done", 2: "detect signs done", 3: "detect params done", 4: "canonical done",
+         5: "containment done", 6: "rank done", 7: "trace+area done", 8: "match/many done", 10: "intersects done",
+         11: "item done", 15: "wave end"}
+prev = 0
+for e in out[1:1 + int(out[0])]:
+    k, t = int(e) >> 48, int(e) & ((1 << 48) - 1)
+    print(f"  {names.get(k, k):22s} t={t:8d}  +{t - prev:7d}")
+    prev = t
