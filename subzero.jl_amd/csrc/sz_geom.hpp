@@ -603,6 +603,7 @@ SZ_DEV int collide_item(MEM& m, int gl, int na, int oa, int nb, int ob, const Bo
         force_factor = cx_.E * cx_.h_i / sqrt(cx_.area_i);
       }
       if (cx_.dbg & 1) break;
+      STAMP(st, 12);
       // unique crossing points (GO.intersection_points): first occurrences in canonical order
       const int K = m.nx;
       for (int k = gl; k < K; k += G) {
@@ -662,6 +663,7 @@ SZ_DEV int collide_item(MEM& m, int gl, int na, int oa, int nb, int ob, const Bo
       fxn = dirx * area * force_factor;
       fyn = diry * area * force_factor;
     }
+    STAMP(st, 13);
     // _normal_direction_correct! (boundaries.jl:37,73,110,147)
     if (cx_.elem_dir == 0 && py >= cx_.elem_val) fxn = 0.0;
     if (cx_.elem_dir == 1 && py <= cx_.elem_val) fxn = 0.0;

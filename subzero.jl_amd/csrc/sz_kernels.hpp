@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, do
   if (gl == 0) { m.err = 0; m.ntracefail = 0; }
   Stamps st; STAMP_INIT(st);
 #ifdef SZ_STAMPS
-  st.on = (CLS == 0 && blockIdx.x == (unsigned)S.cnt[C_SCRATCH1] && threadIdx.x == 0); st.log = S.stamps + 1;
+  st.on = (CLS == 0 && blockIdx.x == (unsigned)(dbg >> 8) && threadIdx.x == 0); st.log = S.stamps + 1;
 #endif
   for (int t = blockIdx.x * GPB + gi; t < nitems; t += gridDim.x * GPB) {
     const bool is_pair = t < npairs;
@@ -579,12 +579,15 @@ __global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, do
     if (!(dbg & 4)) nrows = collide_item<G>(m, gl, na, oa, nb, ob, ba, bb, ic, out, ROWS_PER_ITEM, flags, st);
     if (gl == 0) { S.it_nrows[item] = nrows; S.it_flags[item] = flags; }
     STAMP(st, 11);
+#ifdef SZ_STAMPS
+    if (st.on) { if (nrows > 0) { S.stamps[0] = st.n; st.on = false; } else { st.n = 0; st.t0 = clock64(); } }
+#endif
   }
   gsync();
   if (gl == 0 && m.err) atomicOr(&S.cnt[C_ERR], m.err);
   if (gl == 0 && m.ntracefail) atomicAdd(&S.cnt[C_TRACE_FAIL], m.ntracefail);
 #ifdef SZ_STAMPS
-  if (st.on) { STAMP(st, 15); S.stamps[0] = st.n; }
+  (void)0;
 #endif
 }
 

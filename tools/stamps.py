@@ -11,19 +11,22 @@ from subzero_jl_amd import fields, capi
 capi._LIB = None
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 cfg = fields.make_config(n_floes=n, seed=12345)
-w = fields.build_world(subzero_jl_amd.World(0), cfg)
-w.run(3, 0, cfg["dt"], coupling_dt=1)
-out = np.zeros(512, np.int64)
-w._chk(w.L.sz_debug_stamps(w.h, capi.ptr(out, capi._lp)))
-w.profile(True)
-w.run(1, 3, cfg["dt"], coupling_dt=1)
-w._chk(w.L.sz_debug_stamps(w.h, capi.ptr(out, capi._lp)))
-kt = w.kernel_times(); print("narrow kernel ms", kt["narrow"][0] / max(kt["narrow"][1], 1))
-names = {0: "rings staged", 1: "bbox done", 2: "detect signs done", 3: "detect params done", 4: "canonical done",
+names = {0: "rings staged", 1: "candidate edges done", 2: "detect signs done", 3: "detect params done", 4: "canonical done",
          5: "containment done", 6: "rank done", 7: "trace+area done", 8: "match/many done", 10: "intersects done",
-         11: "item done", 15: "wave end"}
-prev = 0
-for e in out[1:1 + int(out[0])]:
-    k, t = int(e) >> 48, int(e) & ((1 << 48) - 1)
-    print(f"  {names.get(k, k):22s} t={t:8d}  +{t - prev:7d}")
-    prev = t
+         11: "item done", 12: "overlap tests done", 13: "direction settled"}
+for blk in range(0, 40):
+    os.environ["SZ_DEBUG"] = str(blk << 8)
+    w = fields.build_world(subzero_jl_amd.World(0), cfg)
+    w.run(3, 0, cfg["dt"], coupling_dt=1)
+    out = np.zeros(512, np.int64)
+    w._chk(w.L.sz_debug_stamps(w.h, capi.ptr(out, capi._lp)))
+    w.run(1, 3, cfg["dt"], coupling_dt=1)
+    w._chk(w.L.sz_debug_stamps(w.h, capi.ptr(out, capi._lp)))
+    if out[0] > 0:
+        print("block", blk, "group 0: timeline of a pair with contact rows (cycles)")
+        prev = 0
+        for e in out[1:1 + int(out[0])]:
+            k, t = int(e) >> 48, int(e) & ((1 << 48) - 1)
+            print(f"  {names.get(k, k):24s} t={t:8d}  +{t - prev:7d}")
+            prev = t
+        break
