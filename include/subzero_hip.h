@@ -92,6 +92,7 @@ typedef struct {
   int64_t n_ghosts;             /* G                                                         */
   int64_t warn_height, warn_force, warn_vel, warn_xi;   /* update_floe.jl guards             */
   int64_t n_trace_fail;         /* clip traces abandoned (self-intersecting input / round-off), cumulative */
+  int64_t n_halo;               /* halo floes received in the last tiled step */
 } sz_stats;
 
 /* kernel classes for sz_kernel_time_ms */
@@ -164,18 +165,26 @@ int sz_kernel_time_ms(sz_ctx *ctx, int32_t kclass, double *ms, int64_t *launches
      sz_tile_enable   after sz_upload_floes of the owned floes: gidx[i] = global index of owned
                       floe i; all order-dependent rules then use global indices
      sz_owned_box     bounding box of the owned centroids + largest rmax: xmin,xmax,ymin,ymax,rmax
-     sz_halo_pack     boxes: nranks x {xmin,xmax,ymin,ymax} (already expanded by the interaction
-                      range); writes the records for rank d at d_send + d*cap*REC, counts_out[d]
-     sz_halo_unpack   appends nrec received records as extra (halo) floes
-     sz_tile_step     one timestep_sim! on owned + halo floes; only owned floes are integrated,
-                      the halo is dropped at the end */
+     sz_halo_set_boxes  nranks x {xmin,xmax,ymin,ymax}, already expanded by the interaction range
+     sz_halo_pack     ASYNC. Exchange buffers have one region per peer: 1 header record (count in
+                      double [0]) + cap record slots.  Fills d_send with the owned floes whose
+                      centroid, or a periodic image of it, lies in the peer's box
+     sz_tile_step     ASYNC. Appends the records of d_recv (same layout, region r = from rank r) as
+                      halo floes, runs one timestep_sim! on owned + halo floes; only owned floes are
+                      integrated, the halo is dropped at the end.  d_recv may be NULL (no peers)
+     sz_sync          waits for everything enqueued, reports sticky device errors
+     sz_set_stream    enqueue on the caller's HIP stream (torch.cuda.current_stream().cuda_stream) so
+                      that the framework's collectives order with the kernels without host syncs */
 int sz_tile_enable(sz_ctx *ctx, const int64_t *gidx, double reserved);
 int sz_owned_box(sz_ctx *ctx, double *out5);
 int sz_halo_record_doubles(void);
-int sz_halo_pack(sz_ctx *ctx, int32_t nranks, int32_t my_rank, const double *boxes, double Lx, double Ly,
-                 int32_t periodic_x, int32_t periodic_y, void *d_send, int32_t cap, int32_t *counts_out);
-int sz_halo_unpack(sz_ctx *ctx, const void *d_recv, int64_t nrec);
-int sz_tile_step(sz_ctx *ctx, int32_t tstep, int32_t dt, int32_t coupling_dt, int32_t flags);
+int sz_halo_set_boxes(sz_ctx *ctx, int32_t nranks, const double *boxes);
+int sz_halo_pack(sz_ctx *ctx, int32_t nranks, int32_t my_rank, double Lx, double Ly, int32_t periodic_x,
+                 int32_t periodic_y, void *d_send, int32_t cap);
+int sz_tile_step(sz_ctx *ctx, const void *d_recv, int32_t nranks, int32_t cap, int32_t tstep, int32_t dt,
+                 int32_t coupling_dt, int32_t flags);
+int sz_sync(sz_ctx *ctx);
+int sz_set_stream(sz_ctx *ctx, void *hip_stream);
 
 /* diagnostic build (-DSZ_STAMPS) only: stamp log of one lane group of the narrow phase
    (out512[0] = entries, then (stage << 48) | cycles since the wave started) */

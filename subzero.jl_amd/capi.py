@@ -45,7 +45,7 @@ class SzStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in
                 ("M", "N", "n_ring_points", "n_sub_points", "n_pairs", "n_pair_ring_points", "n_pair_rows",
                  "n_elem_items", "n_elem_rows", "n_inter_rows", "n_ghosts",
-                 "warn_height", "warn_force", "warn_vel", "warn_xi", "n_trace_fail")]
+                 "warn_height", "warn_force", "warn_vel", "warn_xi", "n_trace_fail", "n_halo")]
 
 
 EXPORTS = [
@@ -55,7 +55,7 @@ EXPORTS = [
     "sz_add_ghosts", "sz_remove_ghosts", "sz_timestep_collisions", "sz_collide_pairs", "sz_collide_domain",
     "sz_timestep_coupling", "sz_timestep_floe_properties", "sz_step",
     "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms",
-    "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_pack", "sz_halo_unpack", "sz_tile_step", "sz_debug_stamps",
+    "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps",
 ]
 
 _LIB = None
@@ -108,10 +108,12 @@ def load(build_if_missing=True):
     L.sz_tile_enable.argtypes = [C.c_void_p, _lp, C.c_double]
     L.sz_owned_box.argtypes = [C.c_void_p, _dp]
     L.sz_halo_record_doubles.argtypes = []
-    L.sz_halo_pack.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, C.c_double, C.c_double, C.c_int32, C.c_int32,
-                               C.c_void_p, C.c_int32, _ip]
-    L.sz_halo_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
-    L.sz_tile_step.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.sz_halo_set_boxes.argtypes = [C.c_void_p, C.c_int32, _dp]
+    L.sz_halo_pack.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32,
+                               C.c_void_p, C.c_int32]
+    L.sz_tile_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.sz_sync.argtypes = [C.c_void_p]
+    L.sz_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.sz_debug_stamps.argtypes = [C.c_void_p, _lp]
     for n in EXPORTS:
         if n not in ("sz_create", "sz_destroy", "sz_last_error", "sz_version"):

@@ -28,6 +28,7 @@ struct EvPair { int k; hipEvent_t a, b; };
 struct sz_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool own_stream = true;
   State S{};
   Params P{};
   std::string err;
@@ -351,7 +352,7 @@ void sz_destroy(sz_ctx* c) {
   free_pool(c->allocs); free_pool(c->static_allocs); free_pool(c->field_allocs);
   for (auto& e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   (void)hipFree(c->d_stats);
-  (void)hipStreamDestroy(c->stream);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -505,6 +506,7 @@ int sz_get_stats(sz_ctx* c, sz_stats* out) {
   out->n_elem_items = h[C_NELEM]; out->n_elem_rows = st[2]; out->n_inter_rows = st[3]; out->n_ghosts = h[C_NGHOSTS];
   out->warn_height = h[C_WARN_H]; out->warn_force = h[C_WARN_F]; out->warn_vel = h[C_WARN_V]; out->warn_xi = h[C_WARN_XI];
   out->n_trace_fail = h[C_TRACE_FAIL];
+  out->n_halo = h[C_NHALO];
   return SZ_OK;
 }
 
@@ -749,46 +751,73 @@ int sz_debug_stamps(sz_ctx* c, long long* out16) {
   return SZ_OK;
 }
 
-int sz_halo_pack(sz_ctx* c, int32_t nranks, int32_t me, const double* boxes, double Lx, double Ly, int32_t per_x,
-                 int32_t per_y, void* d_send, int32_t cap, int32_t* counts_out) {
-  if (!c || !c->have_floes || nranks < 1 || nranks > 64 || !boxes || !d_send || !counts_out) return SZ_E_ARG;
+// boxes: nranks x {xmin, xmax, ymin, ymax}, already expanded by the interaction range (rarely changes)
+int sz_halo_set_boxes(sz_ctx* c, int32_t nranks, const double* boxes) {
+  if (!c || !c->have_floes || nranks < 1 || nranks > 64 || !boxes) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
-  State& S = c->S;
-  double* dbox = S.bounds + 16;                 // 64*4 doubles reserved behind the grid bounds
-  int* dcnt = S.cnt + C_COUNT;                  // 64 ints reserved behind the counter block
-  HIPCHK(c, hipMemcpyAsync(dbox, boxes, (size_t)nranks * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(dcnt, 0, 64 * sizeof(int), c->stream));
-  hipLaunchKernelGGL(sz_k_halo_pack, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, nranks, me, dbox, Lx, Ly,
-                     per_x, per_y, (double*)d_send, cap, dcnt);
-  HIPCHK(c, hipMemcpyAsync(counts_out, dcnt, (size_t)nranks * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  return sync_and_check(c);
+  HIPCHK(c, hipMemcpyAsync(c->S.bounds + 16, boxes, (size_t)nranks * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SZ_OK;
 }
 
-int sz_halo_unpack(sz_ctx* c, const void* d_recv, int64_t nrec) {
-  if (!c || !c->have_floes || nrec < 0 || (nrec > 0 && !d_recv)) return SZ_E_ARG;
+// asynchronous: fills d_send (nranks regions of (cap + 1) records, record 0 = header with the count)
+int sz_halo_pack(sz_ctx* c, int32_t nranks, int32_t me, double Lx, double Ly, int32_t per_x, int32_t per_y, void* d_send,
+                 int32_t cap) {
+  if (!c || !c->have_floes || nranks < 1 || nranks > 64 || !d_send || cap < 1) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
   State& S = c->S;
-  if (nrec > S.capM) { c->err = "halo larger than the floe capacity"; return SZ_E_CAPACITY; }
-  hipLaunchKernelGGL(sz_k_halo_count, dim3(grid_for(nrec, 256)), dim3(256), 0, c->stream, S, (const double*)d_recv, (int)nrec);
-  scan(c, S.gvcnt, S.gvscan, S.capM, -1, (int)nrec, -1);
-  hipLaunchKernelGGL(sz_k_halo_unpack, dim3(grid_for(nrec, 128)), dim3(128), 0, c->stream, S, (const double*)d_recv, (int)nrec);
-  int rc = sync_and_check(c);
+  int* dcnt = S.cnt + C_COUNT;                  // 64 ints reserved behind the counter block
+  (void)hipMemsetAsync(dcnt, 0, 64 * sizeof(int), c->stream);
+  hipLaunchKernelGGL(sz_k_halo_pack, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, nranks, me, S.bounds + 16, Lx, Ly,
+                     per_x, per_y, (double*)d_send, cap, dcnt);
+  hipLaunchKernelGGL(sz_k_halo_header, dim3(1), dim3(64), 0, c->stream, (double*)d_send, nranks, cap, dcnt);
+  return SZ_OK;
+}
+
+// asynchronous: unpack d_recv (same layout, region r = records from rank r) and run one timestep_sim!
+// on owned + halo floes; only owned floes are integrated, the halo is dropped afterwards
+int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int32_t tstep, int32_t dt, int32_t coupling_dt,
+                 int32_t flags) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  State& S = c->S;
+  if (d_recv && nranks > 0) {
+    hipLaunchKernelGGL(sz_k_halo_count, dim3(grid_for((long long)nranks * cap, 256)), dim3(256), 0, c->stream, S,
+                       (const double*)d_recv, nranks, cap);
+    scan(c, S.gvcnt, S.gvscan, S.capM, C_NHALO, 0, -1);
+    hipLaunchKernelGGL(sz_k_halo_unpack, dim3(grid_for((long long)nranks * cap, 128)), dim3(128), 0, c->stream, S,
+                       (const double*)d_recv, nranks, cap);
+  }
+  stage_ghosts(c);
+  // n_init = every local parent (owned + halo): totals of halo floes are computed and then ignored
+  if (flags & SZ_COLLISIONS_ON) collisions(c, -1, dt);
+  hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_halo_drop, dim3(1), dim3(64), 0, c->stream, S);
+  if ((flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0) stage_forcing(c);
+  stage_integrate(c, dt, false);
+  return SZ_OK;
+}
+
+// waits for everything enqueued so far and reports sticky device errors
+int sz_sync(sz_ctx* c) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  int h[C_COUNT];
+  int rc = sync_and_check(c, h);
   if (rc) return rc;
   c->fuse_lists.resize(c->hostM);
   return SZ_OK;
 }
 
-// one timestep_sim! on the local set (owned + halo parents); the halo is dropped afterwards
-int sz_tile_step(sz_ctx* c, int32_t tstep, int32_t dt, int32_t coupling_dt, int32_t flags) {
-  if (!c || !c->have_floes) return SZ_E_STATE;
+// run on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream) instead of the
+// library's own, so that collectives enqueued by the host framework order with the kernels
+int sz_set_stream(sz_ctx* c, void* hip_stream) {
+  if (!c) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
-  stage_ghosts(c);
-  if (flags & SZ_COLLISIONS_ON) collisions(c, c->hostN, dt);
-  hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
-  hipLaunchKernelGGL(sz_k_halo_drop, dim3(1), dim3(64), 0, c->stream, c->S);
-  if ((flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0) stage_forcing(c);
-  stage_integrate(c, dt, false);
-  return sync_and_check(c);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
+  c->stream = (hipStream_t)hip_stream;
+  return SZ_OK;
 }
 
 }  // extern "C"

@@ -667,8 +667,9 @@ __device__ int emit_rows(const State& S, int f, double* dst, int cap, double sx,
   return c;
 }
 // mirror pass, ghost fold, torque and totals (collisions.jl:799-862), one thread per floe
-__global__ void sz_k_inter_fill(State S, int mirror, int n_init) {
+__global__ void sz_k_inter_fill(State S, int mirror, int n_init_arg) {
   int M = S.cnt[C_M];
+  const int n_init = n_init_arg >= 0 ? n_init_arg : S.cnt[C_N];   // < 0: every parent on the device
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
     double* dst = S.inter_rows + (size_t)k * ROWCAP * 7;
     bool is_ghost = S.ghost_id[k] != 0;
@@ -961,34 +962,60 @@ __global__ void sz_k_halo_pack(State S, int nranks, int me, const double* boxes,
       if (!hit) continue;
       int slot = atomicAdd(&counts[d], 1);
       if (slot >= cap || nv > HALO_RING) { atomicOr(&S.cnt[C_ERR], nv > HALO_RING ? ERR_CAP_RING : ERR_CAP_FLOES); continue; }
-      double* r = send + ((size_t)d * cap + slot) * HALO_REC;
+      double* r = send + ((size_t)d * (cap + 1) + 1 + slot) * HALO_REC;
       r[0] = (double)S.okey[q]; r[1] = (double)S.status[q]; r[2] = (double)nv; r[3] = cx; r[4] = cy; r[5] = S.rmax[q];
       r[6] = S.area[q]; r[7] = S.height[q]; r[8] = S.u[q]; r[9] = S.v[q]; r[10] = S.xi[q]; r[11] = (double)S.id[q];
       for (int k = 0; k < nv; k++) { r[12 + k] = S.vx[o + k]; r[12 + HALO_RING + k] = S.vy[o + k]; }
     }
   }
 }
-__global__ void sz_k_halo_count(State S, const double* recv, int nrec) {
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nrec; t += gridDim.x * blockDim.x)
-    S.gvcnt[t] = (int)recv[(size_t)t * HALO_REC + 2];
+// ---- fixed-layout exchange buffers: region of peer r = 1 header record (count in [0]) followed by
+// `cap` record slots.  The host never needs the counts, so a whole step is enqueued without a sync.
+__global__ void sz_k_halo_header(double* send, int nranks, int cap, const int* counts) {
+  int d = threadIdx.x;
+  if (blockIdx.x == 0 && d < nranks) send[(size_t)d * (cap + 1) * HALO_REC] = (double)counts[d];
 }
-// appends the received floes as extra parents [nown, nown + nrec)
-__global__ void sz_k_halo_unpack(State S, const double* recv, int nrec) {
-  int nown = S.cnt[C_NOWN];
+__device__ __forceinline__ bool halo_locate(const double* recv, int nranks, int cap, int t, int& src, int& slot, int& before) {
+  // t = src * cap + slot; `before` = records of lower sources
+  src = t / cap; slot = t - src * cap;
+  int cnt = (int)recv[(size_t)src * (cap + 1) * HALO_REC];
+  if (slot >= cnt) return false;
+  before = 0;
+  for (int r = 0; r < src; r++) before += (int)recv[(size_t)r * (cap + 1) * HALO_REC];
+  return true;
+}
+__global__ void sz_k_halo_count(State S, const double* recv, int nranks, int cap) {
+  int tot = 0;
+  for (int r = 0; r < nranks; r++) tot += (int)recv[(size_t)r * (cap + 1) * HALO_REC];
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nranks * cap; t += gridDim.x * blockDim.x) {
+    int src, slot, before;
+    if (!halo_locate(recv, nranks, cap, t, src, slot, before)) continue;
+    S.gvcnt[before + slot] = (int)recv[((size_t)src * (cap + 1) + 1 + slot) * HALO_REC + 2];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) S.cnt[C_NHALO] = tot;
+}
+// appends the received floes as extra parents [nown, nown + nrec); gvscan = exclusive scan of their ring sizes
+__global__ void sz_k_halo_unpack(State S, const double* recv, int nranks, int cap) {
+  int nown = S.cnt[C_NOWN], nrec = S.cnt[C_NHALO];
   int vbase = S.voff[nown];
   int totv = nrec > 0 ? S.gvscan[nrec] : 0;
-  if (nown + nrec > S.capM || vbase + totv > S.capV) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], nown + nrec > S.capM ? ERR_CAP_FLOES : ERR_CAP_VERTS);
+  bool bad = false;
+  for (int r = 0; r < nranks; r++) bad |= (int)recv[(size_t)r * (cap + 1) * HALO_REC] > cap;
+  if (bad || nown + nrec > S.capM || vbase + totv > S.capV) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], (bad || nown + nrec > S.capM) ? ERR_CAP_FLOES : ERR_CAP_VERTS);
     return;
   }
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nrec; t += gridDim.x * blockDim.x) {
-    const double* r = recv + (size_t)t * HALO_REC;
-    int g = nown + t, nv = (int)r[2], vb = vbase + S.gvscan[t];
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nranks * cap; t += gridDim.x * blockDim.x) {
+    int src, slot, before;
+    if (!halo_locate(recv, nranks, cap, t, src, slot, before)) continue;
+    const double* r = recv + ((size_t)src * (cap + 1) + 1 + slot) * HALO_REC;
+    int q = before + slot;
+    int g = nown + q, nv = (int)r[2], vb = vbase + S.gvscan[q];
     S.okey[g] = (long long)r[0]; S.status[g] = (int)r[1]; S.cx[g] = r[3]; S.cy[g] = r[4]; S.rmax[g] = r[5];
     S.area[g] = r[6]; S.height[g] = r[7]; S.u[g] = r[8]; S.v[g] = r[9]; S.xi[g] = r[10]; S.id[g] = (long long)r[11];
     S.ghost_id[g] = 0; S.parent[g] = g; S.ngh[g] = 0; S.overarea[g] = 0.0;
     S.mass[g] = 0.0; S.moment[g] = 0.0; S.alpha[g] = 0.0;
-    for (int q = 0; q < MAX_GHOSTS; q++) S.gh[g * MAX_GHOSTS + q] = -1;
+    for (int k = 0; k < MAX_GHOSTS; k++) S.gh[g * MAX_GHOSTS + k] = -1;
     S.voff[g] = vb; S.voff[g + 1] = vb + nv;
     for (int k = 0; k < nv; k++) { S.vx[vb + k] = r[12 + k]; S.vy[vb + k] = r[12 + HALO_RING + k]; }
     S.osign[g] = ring_signed_area(S.vx + vb, S.vy + vb, nv) >= 0.0 ? 1 : -1;
@@ -997,7 +1024,7 @@ __global__ void sz_k_halo_unpack(State S, const double* recv, int nrec) {
     S.bbx0[g] = x0; S.bbx1[g] = x1; S.bby0[g] = y0; S.bby1[g] = y1;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    S.cnt[C_M] = nown + nrec; S.cnt[C_N] = nown + nrec; S.cnt[C_NV] = vbase + totv; S.cnt[C_NHALO] = nrec;
+    S.cnt[C_M] = nown + nrec; S.cnt[C_N] = nown + nrec; S.cnt[C_NV] = vbase + totv;
   }
 }
 // after the step: forget the halo floes (their owners integrate them)

@@ -104,70 +104,72 @@ class TiledWorld:
         w._chk(w.L.sz_tile_enable(w.h, capi.ptr(g, capi._lp), 0.0))
         self.world = w
         self.REC = w.L.sz_halo_record_doubles()
-        self.cap = max(256, len(self.gidx) // 2 + 64)
+        self.cap = max(256, len(self.gidx) // 2 + 64)         # record slots per peer
         self.dev = torch.device("cuda", device)
-        self.send = torch.zeros(world * self.cap * self.REC, dtype=torch.float64, device=self.dev)
+        n = world * (self.cap + 1) * self.REC
+        self.send = torch.zeros(n, dtype=torch.float64, device=self.dev)
+        self.recv = torch.zeros(n, dtype=torch.float64, device=self.dev)
+        if not host_staging:
+            # kernels and RCCL collectives are ordered by ONE stream: no host sync inside a step
+            w._chk(w.L.sz_set_stream(w.h, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
         self.margin, self.rebox_every = drift_margin, rebox_every
         self.boxes = None
         self.steps_since_box = 0
-        self.n_halo_last = 0
 
     # ---- collectives
     def _allgather_boxes(self):
         w = self.world
         b5 = np.zeros(5)
+        w._chk(w.L.sz_sync(w.h))
         w._chk(w.L.sz_owned_box(w.h, capi.ptr(b5)))
         t = self.torch.tensor(b5, dtype=self.torch.float64, device="cpu" if self.host_staging else self.dev)
         out = [self.torch.zeros_like(t) for _ in range(self.nranks)]
         self.dist.all_gather(out, t)
         allb = np.stack([o.cpu().numpy() for o in out])
-        rmax = allb[:, 4].max()
-        allb[:, 4] = rmax
+        allb[:, 4] = allb[:, 4].max()
         self.boxes = np.ascontiguousarray(np.stack([expanded_box(b, self.margin) for b in allb]))
+        w._chk(w.L.sz_halo_set_boxes(w.h, self.nranks, capi.ptr(self.boxes)))
         self.steps_since_box = 0
 
     def exchange(self):
-        """steps 1-3 of the module docstring: returns the number of halo floes received."""
+        """steps 1-2 of the module docstring, asynchronous on the device: fills self.recv."""
         torch, dist, w = self.torch, self.dist, self.world
         if self.boxes is None or self.steps_since_box >= self.rebox_every:
             self._allgather_boxes()
         self.steps_since_box += 1
-        counts = np.zeros(self.nranks, np.int32)
-        w._chk(w.L.sz_halo_pack(w.h, self.nranks, self.rank, capi.ptr(self.boxes), self.L, self.L, int(self.per_x),
-                                int(self.per_y), C.c_void_p(self.send.data_ptr()), self.cap, capi.ptr(counts, capi._ip)))
-        sview = self.send.view(self.nranks, self.cap * self.REC)
-        chunks = [sview[d, :int(counts[d]) * self.REC] for d in range(self.nranks)]
-        sbuf = torch.cat(chunks) if counts.sum() else torch.zeros(0, dtype=torch.float64, device=self.dev)
-        cdev = "cpu" if self.host_staging else self.dev
-        tc = torch.tensor(counts.astype(np.int64), device=cdev); rc = torch.zeros_like(tc)
-        dist.all_to_all_single(rc, tc)
-        rcounts = rc.cpu().numpy()
-        in_split = [int(c) * self.REC for c in counts]; out_split = [int(c) * self.REC for c in rcounts]
-        if self.host_staging:
-            sb = sbuf.cpu(); rb = torch.zeros(sum(out_split), dtype=torch.float64)
-            dist.all_to_all_single(rb, sb, out_split, in_split)
-            rbuf = rb.to(self.dev)
-        else:
-            rbuf = torch.zeros(sum(out_split), dtype=torch.float64, device=self.dev)
-            dist.all_to_all_single(rbuf, sbuf, out_split, in_split)
-        torch.cuda.synchronize()
-        nrec = int(rcounts.sum())
-        self._rbuf = rbuf                      # keep alive until unpack has consumed it
-        w._chk(w.L.sz_halo_unpack(w.h, C.c_void_p(rbuf.data_ptr()) if nrec else None, nrec))
-        self.n_halo_last = nrec
-        return nrec
+        w._chk(w.L.sz_halo_pack(w.h, self.nranks, self.rank, self.L, self.L, int(self.per_x), int(self.per_y),
+                                C.c_void_p(self.send.data_ptr()), self.cap))
+        if self.host_staging:                       # gloo: through the host
+            w._chk(w.L.sz_sync(w.h))
+            sb = self.send.cpu(); rb = torch.zeros_like(sb)
+            dist.all_to_all_single(rb, sb)
+            self.recv.copy_(rb)
+            torch.cuda.synchronize()
+        else:                                       # RCCL: equal splits, device to device
+            dist.all_to_all_single(self.recv, self.send)
 
     def step(self, tstep, dt, coupling_dt=10, collisions_on=True, coupling_on=True):
         w = self.world
-        if self.nranks > 1 or self.always_exchange:
-            self.exchange()
         flags = (capi.COLLISIONS_ON if collisions_on else 0) | (capi.COUPLING_ON if coupling_on else 0)
-        w._chk(w.L.sz_tile_step(w.h, int(tstep), int(dt), int(coupling_dt), flags))
+        peers = self.nranks > 1 or self.always_exchange
+        if peers:
+            self.exchange()
+        w._chk(w.L.sz_tile_step(w.h, C.c_void_p(self.recv.data_ptr()) if peers else None, self.nranks if peers else 0,
+                                self.cap, int(tstep), int(dt), int(coupling_dt), flags))
         w._host_stale = True
 
     def run(self, nsteps, tstep0, dt, coupling_dt=10, collisions_on=True, coupling_on=True):
         for s in range(nsteps):
             self.step(tstep0 + s, dt, coupling_dt, collisions_on, coupling_on)
+        self.sync()
+
+    def sync(self):
+        self.world._chk(self.world.L.sz_sync(self.world.h))
+
+    @property
+    def n_halo_last(self):
+        self.sync()
+        return self.world.stats().get("n_halo", 0)
 
     def owned(self, name):
         """column `name` of the owned floes (global indices in self.gidx)."""
