@@ -83,6 +83,12 @@ def main():
     ap.add_argument("--force-tiled", action="store_true", help="run the halo/RCCL path even with one rank")
     args = ap.parse_args()
 
+    # RCCL prints a version banner on stdout; the contract is ONE JSON line there.  Everything the
+    # libraries write to fd 1 goes to stderr, the JSON line is written to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import subzero_jl_amd
     from subzero_jl_amd import fields
@@ -159,7 +165,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
