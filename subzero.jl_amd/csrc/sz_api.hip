@@ -29,6 +29,8 @@ struct sz_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = true;
+  hipStream_t stream2 = nullptr;        // forcings beside the collision kernels
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   State S{};
   Params P{};
   std::string err;
@@ -50,6 +52,8 @@ struct sz_ctx {
   long long* d_stats = nullptr;
   int last_dt = 0;
   bool any_moving = false;
+  bool overlap_forcing = false;   // SZ_OVERLAP=1: forcings on a second stream (measured: no gain at 10k-100k floes, the
+                                  // forcing workgroups delay the latency-bound collision kernels; kept for tuning)
   int max_ring = 0, max_elem_ring = 5;   // largest ring sizes (host knowledge: which narrow variants can be needed)
   int dbg = 0;   // SZ_DEBUG bits: timing experiments only (1 skip contact rows, 2 skip direction check, 4 skip clip)
 };
@@ -85,17 +89,17 @@ inline int grid_for(long long n, int tpb, int maxb = 4096) {
 }
 
 struct Timed {   // RAII-free helper: begin/end a timed kernel class
-  sz_ctx* c; int k; size_t idx = (size_t)-1;
-  Timed(sz_ctx* c_, int k_) : c(c_), k(k_) {
+  sz_ctx* c; int k; size_t idx = (size_t)-1; hipStream_t st;
+  Timed(sz_ctx* c_, int k_, hipStream_t st_ = nullptr) : c(c_), k(k_), st(st_ ? st_ : c_->stream) {
     if (!c->profile) return;
     if (c->ev_used == c->evs.size()) {
       EvPair e; e.k = k; (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); c->evs.push_back(e);
     }
     idx = c->ev_used++;
     c->evs[idx].k = k;
-    (void)hipEventRecord(c->evs[idx].a, c->stream);
+    (void)hipEventRecord(c->evs[idx].a, st);
   }
-  void end() { if (idx != (size_t)-1) (void)hipEventRecord(c->evs[idx].b, c->stream); }
+  void end() { if (idx != (size_t)-1) (void)hipEventRecord(c->evs[idx].b, st); }
 };
 void resolve_events(sz_ctx* c) {
   for (size_t i = 0; i < c->ev_used; i++) {
@@ -117,6 +121,7 @@ int sync_and_check(sz_ctx* c, int* cnt_out = nullptr) {
   int h[C_COUNT];
   HIPCHK(c, hipMemcpyAsync(h, c->S.cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
   if (c->profile) resolve_events(c);
   c->hostM = h[C_M]; c->hostN = h[C_N];
   if (cnt_out) memcpy(cnt_out, h, sizeof(h));
@@ -278,17 +283,30 @@ void collisions(sz_ctx* c, int n_init, int dt) {
   stage_reduce(c, 1, n_init, dt);
 }
 
-void stage_forcing(sz_ctx* c) {
+// The forcings only read the floes' state at the start of the step and write fxOA/fyOA/trqOA/
+// hflx_factor, which nothing but the integrator reads: inside a step they run on a second stream
+// BESIDE the ghost / broad / narrow / reduce kernels (all of them latency-bound, the chip is far
+// from full) and join before the integrator.
+void stage_forcing_fork(sz_ctx* c) {
+  (void)hipEventRecord(c->ev_fork, c->stream);
+  (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+  Timed t(c, SZ_K_FORCING, c->stream2);
+  hipLaunchKernelGGL(sz_k_forcing, dim3(grid_for(c->S.capM, 4, 8192)), dim3(256), 0, c->stream2, c->S, c->P);
+  t.end();
+  (void)hipEventRecord(c->ev_join, c->stream2);
+}
+void stage_forcing_join(sz_ctx* c) { (void)hipStreamWaitEvent(c->stream, c->ev_join, 0); }
+void stage_forcing(sz_ctx* c) {      // in-order variant (process mode, profiling)
   Timed t(c, SZ_K_FORCING);
   hipLaunchKernelGGL(sz_k_forcing, dim3(grid_for(c->S.capM, 4, 8192)), dim3(256), 0, c->stream, c->S, c->P);
   t.end();
 }
-void stage_integrate(sz_ctx* c, int dt, bool reset_guards) {
+void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc) {
   // the guard counters describe the last timestep_floe_properties! call (inside a step the
   // ghost-removal kernel has already cleared them)
   if (reset_guards) (void)hipMemsetAsync(c->S.cnt + C_WARN_H, 0, 4 * sizeof(int), c->stream);
   Timed t(c, SZ_K_INTEGRATE);
-  hipLaunchKernelGGL(sz_k_integrate, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt);
+  hipLaunchKernelGGL(sz_k_integrate, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0);
   hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S);
   t.end();
 }
@@ -335,7 +353,10 @@ sz_ctx* sz_create(int device_id) {
   sz_ctx* c = new sz_ctx();
   c->device = device_id;
   if (const char* e = getenv("SZ_DEBUG")) c->dbg = atoi(e);
+  if (const char* e = getenv("SZ_OVERLAP")) c->overlap_forcing = atoi(e) != 0;
   if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; }
+  if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+  (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
   // Constants() and default settings of the reference
   Params& P = c->P;
   P.E = 6e6; P.nu = 0.3; P.mu = 0.2; P.rho_o = 1027.0; P.rho_a = 1.2; P.Cd_io = 3e-3; P.Cd_ia = 1e-3;
@@ -353,6 +374,8 @@ void sz_destroy(sz_ctx* c) {
   for (auto& e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   (void)hipFree(c->d_stats);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2);
+  (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
   delete c;
 }
 
@@ -443,7 +466,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   if (f->stress_instant) H2D(S.si, f->stress_instant, 4 * M, double);
   if (f->strain) H2D(S.strain, f->strain, 4 * M, double);
   DA(id, S.capM); DA(ghost_id, S.capM); DA(okey, S.capM); DA(status, S.capM); DA(parent, S.capM); DA(gh, MAX_GHOSTS * S.capM); DA(ngh, S.capM);
-  DA(osign, S.capM); DA(bbx0, S.capM); DA(bbx1, S.capM); DA(bby0, S.capM); DA(bby1, S.capM);
+  DA(frc_remove, S.capM); DA(osign, S.capM); DA(bbx0, S.capM); DA(bbx1, S.capM); DA(bby0, S.capM); DA(bby1, S.capM);
   {
     std::vector<long long> id(M), gid(M, 0);
     std::vector<int> st(M, SZ_ACTIVE), parent(M), gh((size_t)MAX_GHOSTS * M, -1), ngh(M, 0);
@@ -676,13 +699,14 @@ int sz_timestep_coupling(sz_ctx* c) {
   if (!c->have_fields) { c->err = "sz_set_fields must be called before sz_timestep_coupling"; return SZ_E_STATE; }
   (void)hipSetDevice(c->device);
   stage_forcing(c);
+  hipLaunchKernelGGL(sz_k_apply_frc, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
   return sync_and_check(c);
 }
 
 int sz_timestep_floe_properties(sz_ctx* c, int32_t dt) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
-  stage_integrate(c, dt, true);
+  stage_integrate(c, dt, true, false);
   return sync_and_check(c);
 }
 
@@ -692,11 +716,15 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   (void)hipSetDevice(c->device);
   for (int s = 0; s < nsteps; s++) {
     int tstep = tstep0 + s;
+    const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
+    const bool overlap = coupling && c->overlap_forcing;
+    if (overlap) stage_forcing_fork(c);
     stage_ghosts(c);
     if (flags & SZ_COLLISIONS_ON) collisions(c, c->hostN, dt);
     hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
-    if ((flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0) stage_forcing(c);
-    stage_integrate(c, dt, false);
+    if (coupling && !overlap) stage_forcing(c);
+    if (overlap) stage_forcing_join(c);
+    stage_integrate(c, dt, false, coupling);
   }
   return sync_and_check(c);
 }
@@ -788,13 +816,17 @@ int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int
     hipLaunchKernelGGL(sz_k_halo_unpack, dim3(grid_for((long long)nranks * cap, 128)), dim3(128), 0, c->stream, S,
                        (const double*)d_recv, nranks, cap);
   }
+  const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
+  const bool overlap = coupling && c->overlap_forcing;
+  if (overlap) stage_forcing_fork(c);               // owned floes only (C_NOWN): independent of the halo
   stage_ghosts(c);
   // n_init = every local parent (owned + halo): totals of halo floes are computed and then ignored
   if (flags & SZ_COLLISIONS_ON) collisions(c, -1, dt);
   hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S);
   hipLaunchKernelGGL(sz_k_halo_drop, dim3(1), dim3(64), 0, c->stream, S);
-  if ((flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0) stage_forcing(c);
-  stage_integrate(c, dt, false);
+  if (coupling && !overlap) stage_forcing(c);
+  if (overlap) stage_forcing_join(c);
+  stage_integrate(c, dt, false, coupling);
   return SZ_OK;
 }
 

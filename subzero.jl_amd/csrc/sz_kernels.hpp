@@ -759,6 +759,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // one wavefront per floe, lanes over the sub-floe points
+// apply the removal flags of the forcing kernel (standalone timestep_coupling! call)
+__global__ void sz_k_apply_frc(State S) {
+  int N = S.cnt[C_NOWN];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
+    if (S.frc_remove[i]) S.status[i] = SZ_REMOVE;
+}
 __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
   int N = S.cnt[C_NOWN];
   int lane = threadIdx.x & 63, wpb = blockDim.x >> 6, wid = threadIdx.x >> 6;
@@ -802,7 +808,11 @@ __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
     int npt = np;
     for (int d = 32; d >= 1; d >>= 1) npt += __shfl_xor(npt, d);
     if (lane == 0) {
-      if (npt == 0) S.status[i] = SZ_REMOVE;
+      // no in-bounds point: the floe is marked for removal (coupling.jl:1507-1508).  The tag itself is
+      // written by the integrate kernel: this kernel may run beside the collision kernels, which also
+      // write status, and the reference applies the coupling result after them
+      S.frc_remove[i] = npt == 0 ? 1 : 0;
+      if (npt == 0) { }
       else {
         double xcor = ma_ratio * P.fcor * v, ycor = ma_ratio * P.fcor * u;
         double totx = npt * xcor + tx, toty = -npt * ycor + ty;
@@ -818,10 +828,11 @@ __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
 __device__ __forceinline__ double sgn(double x) { return (double)((x > 0) - (x < 0)); }
 
 // one thread per floe: stress, guards, thermodynamics, AB2 velocity update; stores the motion
-__global__ void sz_k_integrate(State S, Params P, int dt) {
+__global__ void sz_k_integrate(State S, Params P, int dt, int apply_frc) {
   int N = S.cnt[C_NOWN];
   int wh = 0, wf = 0, wv = 0, wx = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    if (apply_frc && S.frc_remove[i]) S.status[i] = SZ_REMOVE;
     double cfx = S.cfx[i], cfy = S.cfy[i], ctrq = S.ctrq[i];
     double cx = S.cx[i], cy = S.cy[i];
     // calc_stress!, update_floe.jl:392-414

@@ -58,7 +58,7 @@ struct State {
   double *fxOA, *fyOA, *trqOA, *hflx, *overarea, *cfx, *cfy, *ctrq;
   double *sa, *si, *strain;   // 4 per floe
   long long *id, *ghost_id, *okey;   // okey: position in the reference's serial order
-  int *status, *parent, *gh, *ngh;   // gh: MAX_GHOSTS per floe
+  int *status, *parent, *gh, *ngh, *frc_remove;   // gh: MAX_GHOSTS per floe
   signed char* osign;                // ring orientation sign
   double *bbx0, *bbx1, *bby0, *bby1; // ring bounding boxes (kept current by every kernel that moves a ring)
   int* voff; double *vx, *vy;
