@@ -81,6 +81,39 @@ def test_collisions_walls_topography():
     assert np.any(rows[:, 0] < 0)      # boundary / topography contacts exist
 
 
+def test_moving_boundary_compression():
+    """MovingBoundary walls (examples/moving_bounds.jl style): the north and south walls close in,
+    contribute their velocity to the friction and are moved after the contacts (collisions.jl:797)."""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=400, seed=8, walls=True, ocean="strait")
+    L = cfg["L"]
+    worlds = []
+    for w in (mk(), omk()):
+        w.set_consts(E=cfg["E"]); w.set_settings()
+        w.set_domain([3, 3, 2, 2], 0.0, L, 0.0, L, bu=[0.05, -0.05, 0, 0], bv=[-0.4, 0.4, 0, 0])   # N,S moving; E,W collision
+        w.set_grid_fields(cfg["Nx"], cfg["Ny"], 0.0, L, 0.0, L, cfg["uo"], cfg["vo"], cfg["hf"], cfg["ua"], cfg["va"])
+        off, vx, vy = cfg["vert_off"], cfg["vx"], cfg["vy"]
+        if hasattr(w, "load_columns"):
+            d = cfg["derived"]
+            w.load_columns(dict(cx=d["cx"], cy=d["cy"], rmax=d["rmax"], area=d["area"], height=d["height"], mass=d["mass"],
+                                moment=d["moment"], u=cfg["u"], v=cfg["v"], xi=cfg["xi"], vert_off=off, vx=vx, vy=vy))
+            w.set_subpoints_csr(cfg["sub_off"], cfg["sx"], cfg["sy"])
+        else:
+            so = cfg["sub_off"]
+            for i in range(cfg["n_floes"]):
+                w.add_floe(np.stack([vx[off[i]:off[i + 1]], vy[off[i]:off[i + 1]]], 1), cfg["height"][i])
+                w.set_subpoints(i, cfg["sx"][so[i]:so[i + 1]], cfg["sy"][so[i]:so[i + 1]])
+            w.set("u", cfg["u"]); w.set("v", cfg["v"]); w.set("xi", cfg["xi"])
+        worlds.append(w)
+    hw, ow = worlds
+    for t in range(6):
+        hw.timestep_sim(t, cfg["dt"], coupling_dt=1); ow.timestep_sim(t, cfg["dt"], coupling_dt=1)
+    assert np.array_equal(hw.boundary_vals(), ow.boundary_vals())
+    assert hw.boundary_vals()[0] == L - 0.4 * cfg["dt"] * 6
+    parity.compare_worlds(hw, ow, rtol=1e-9, check_pairs=True)
+    assert np.any(ow.interactions()[1][:, 0] < 0)
+
+
 def test_forcing_and_integrator_random():
     from subzero_jl_amd import fields
     cfg = fields.make_config(n_floes=500, seed=4, ocean="converge_diverge")
