@@ -188,9 +188,8 @@ __device__ __forceinline__ int ghost_dir(const State& S, int i, int axis) {
   int dir = 0;
   if (c - r < minv) dir = 1; else if (c + r > maxv) dir = -1;
   if (dir != 0) {
-    const double* v = axis == 0 ? S.vx : S.vy;
-    int o = S.voff[i], n = S.voff[i + 1] - o; bool beyond = false;
-    for (int k = 0; k < n; k++) { double x = v[o + k]; if (dir > 0 ? (x < minv) : (x > maxv)) { beyond = true; break; } }
+    // "a vertex strictly beyond the wall" == the ring's box reaches strictly beyond it
+    bool beyond = dir > 0 ? ((axis == 0 ? S.bbx0[i] : S.bby0[i]) < minv) : ((axis == 0 ? S.bbx1[i] : S.bby1[i]) > maxv);
     if (!beyond) dir = 0;
   }
   return dir;
