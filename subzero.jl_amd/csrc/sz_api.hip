@@ -199,26 +199,27 @@ int upload_elements(sz_ctx* c) {
 }
 
 // ---------------------------------------------------------------- pipeline stages
-void stage_ghosts(sz_ctx* c) {
+// in_step: the previous step's ghosts are dropped by the flag kernel and the commit is done by
+// the bounds kernel of the broad phase (which always follows inside a step)
+void stage_ghosts(sz_ctx* c, bool in_step = false) {
   State& S = c->S;
   if (!S.any_periodic_ew && !S.any_periodic_ns) return;
   Timed t(c, SZ_K_GHOSTS);
   int gN = grid_for(S.capM, 256), nb = grid_for(S.capM, SCAN_B, 1 << 20);
-  hipLaunchKernelGGL(sz_k_ghost_flag, dim3(gN), dim3(256), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_ghost_flag, dim3(gN), dim3(256), 0, c->stream, S, in_step ? 1 : 0);
   hipLaunchKernelGGL(sz_k_scan4_1, dim3(nb), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.gblk4, S.cnt, C_N);
   hipLaunchKernelGGL(sz_k_scan4_2, dim3(1), dim3(SCAN_B), 0, c->stream, S.gblk4, S.cnt, C_N);
   hipLaunchKernelGGL(sz_k_scan4_3, dim3(nb), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.gblk4, S.cnt, C_N, S.gtot4);
   hipLaunchKernelGGL(sz_k_ghost_fill, dim3(grid_for(S.capM, 256, 1024)), dim3(256), 0, c->stream, S);
-  hipLaunchKernelGGL(sz_k_ghost_commit, dim3(1), dim3(64), 0, c->stream, S);
+  if (!in_step) hipLaunchKernelGGL(sz_k_ghost_commit, dim3(1), dim3(64), 0, c->stream, S);
   t.end();
 }
 
-void stage_broad(sz_ctx* c) {
+void stage_broad(sz_ctx* c, bool commit_ghosts = false) {
   State& S = c->S;
   Timed t(c, SZ_K_BROAD);
   int gM = grid_for(S.capM, 256);
-  hipLaunchKernelGGL(sz_k_bounds, dim3(1), dim3(1024), 0, c->stream, S);
-  hipLaunchKernelGGL(sz_k_zero_int, dim3(grid_for(S.capCells, 256)), dim3(256), 0, c->stream, S.cell_cnt, S.cnt, C_NCELLS, 1);
+  hipLaunchKernelGGL(sz_k_bounds, dim3(1), dim3(1024), 0, c->stream, S, commit_ghosts ? 1 : 0);
   hipLaunchKernelGGL(sz_k_cell_build, dim3(gM), dim3(256), 0, c->stream, S);
   hipLaunchKernelGGL(sz_k_neighbors, dim3(grid_for(S.capM, NB_TPB / NB_G, 8192)), dim3(NB_TPB), 0, c->stream, S);
   scan(c, S.n_out, S.out_off, S.capM, C_M, 0, C_NPAIRS);
@@ -230,6 +231,7 @@ void stage_elems(sz_ctx* c, bool enabled) {
   State& S = c->S;
   if (!enabled || !S.any_domain_work) {
     // el_off stays all-zero (allocated zeroed and never written in this mode)
+    if (!S.any_domain_work) return;              // C_NELEM is 0 since the upload and nothing ever changes it
     hipLaunchKernelGGL(sz_k_zero_int, dim3(1), dim3(64), 0, c->stream, S.cnt + C_NELEM, S.cnt, -1, 1);
     if (S.any_domain_work)
       hipLaunchKernelGGL(sz_k_zero_int, dim3(grid_for(S.capM + 1, 256)), dim3(256), 0, c->stream, S.el_off, S.cnt, C_M, 1);
@@ -276,8 +278,8 @@ void stage_reduce(sz_ctx* c, int mirror, int n_init, int dt) {
   t.end();
 }
 
-void collisions(sz_ctx* c, int n_init, int dt) {
-  stage_broad(c);
+void collisions(sz_ctx* c, int n_init, int dt, bool commit_ghosts = false) {
+  stage_broad(c, commit_ghosts);
   stage_elems(c, true);
   stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap);
   stage_reduce(c, 1, n_init, dt);
@@ -714,18 +716,21 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   if (!c || !c->have_floes) return SZ_E_STATE;
   if ((flags & SZ_COUPLING_ON) && !c->have_fields) { c->err = "sz_set_fields must be called before coupling"; return SZ_E_STATE; }
   (void)hipSetDevice(c->device);
+  const bool periodic = c->S.any_periodic_ew || c->S.any_periodic_ns;
+  const bool coll = (flags & SZ_COLLISIONS_ON) != 0;
   for (int s = 0; s < nsteps; s++) {
     int tstep = tstep0 + s;
     const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
     const bool overlap = coupling && c->overlap_forcing;
     if (overlap) stage_forcing_fork(c);
-    stage_ghosts(c);
-    if (flags & SZ_COLLISIONS_ON) collisions(c, c->hostN, dt);
-    hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
+    // with collisions on, the ghosts of step s are detached by the ghost kernels of step s+1 (nothing
+    // in between looks past the parents) and committed by the bounds kernel: two launches less
+    if (coll) { stage_ghosts(c, true); collisions(c, c->hostN, dt, periodic); }
     if (coupling && !overlap) stage_forcing(c);
     if (overlap) stage_forcing_join(c);
-    stage_integrate(c, dt, false, coupling);
+    stage_integrate(c, dt, !coll, coupling);
   }
+  if (coll && periodic) hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
   return sync_and_check(c);
 }
 

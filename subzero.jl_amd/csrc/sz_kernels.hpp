@@ -196,9 +196,16 @@ __device__ __forceinline__ int ghost_dir(const State& S, int i, int axis) {
 }
 
 // plan of both passes for every parent: gplan[i] = {E/W ghosts, E/W points, N/S ghosts, N/S points}
-__global__ void sz_k_ghost_flag(State S) {
+// `drop_old`: ghosts of the previous step are still attached (their removal, simulation.jl:138-144,
+// was deferred because nothing after the collision kernels looks at them): detach them here.
+__global__ void sz_k_ghost_flag(State S, int drop_old) {
   int N = S.cnt[C_N];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    if (drop_old) {
+      S.ngh[i] = 0;
+      for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = -1;
+      if (i == 0) { S.cnt[C_M] = N; S.cnt[C_NV] = S.voff[N]; }
+    }
     int dx = 0, dy = 0;
     if (S.status[i] == SZ_ACTIVE && S.ghost_id[i] == 0) {
       if (S.any_periodic_ew) dx = ghost_dir(S, i, 0);
@@ -309,16 +316,18 @@ __global__ void __launch_bounds__(256) sz_k_ghost_fill(State S) {
     }
   }
 }
-__global__ void sz_k_ghost_commit(State S) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    int4 T = S.gtot4[0];
-    int newg = T.x + T.z, newv = T.y + T.w;
-    if (S.cnt[C_M] + newg <= S.capM && S.cnt[C_NV] + newv <= S.capV) {
-      int M = S.cnt[C_M] + newg;
-      S.cnt[C_M] = M; S.cnt[C_NV] += newv; S.cnt[C_NGHOSTS] += newg;
-      S.voff[M] = S.cnt[C_NV];
-    }
+__device__ __forceinline__ void ghost_commit(State& S) {
+  int4 T = S.gtot4[0];
+  int newg = T.x + T.z, newv = T.y + T.w;
+  if (S.cnt[C_M] + newg <= S.capM && S.cnt[C_NV] + newv <= S.capV) {
+    int M = S.cnt[C_M] + newg;
+    S.cnt[C_M] = M; S.cnt[C_NV] += newv; S.cnt[C_NGHOSTS] += newg;
+    S.voff[M] = S.cnt[C_NV];
   }
+  S.gtot4[0] = make_int4(0, 0, 0, 0);      // committed
+}
+__global__ void sz_k_ghost_commit(State S) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) ghost_commit(S);
 }
 // simulation.jl:138-144
 __global__ void sz_k_remove_ghosts(State S) {
@@ -329,13 +338,20 @@ __global__ void sz_k_remove_ghosts(State S) {
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     S.cnt[C_M] = N; S.cnt[C_NV] = S.voff[N];        // C_NGHOSTS keeps the last step's count
-    S.cnt[C_WARN_H] = 0; S.cnt[C_WARN_F] = 0; S.cnt[C_WARN_V] = 0; S.cnt[C_WARN_XI] = 0;   // guards of the coming update
   }
 }
 
 // ============================================================================ broad phase (A2, A3)
-__global__ void __launch_bounds__(1024) sz_k_bounds(State S) {
+// Single block.  Prologue: commit the ghosts planned by the ghost kernels (C_M, C_NV).  Then the
+// bounding box of all centroids and the largest rmax -> uniform grid geometry; finally the cell
+// heads are cleared and the per-step counters reset, so the step needs no separate launches for that.
+__global__ void __launch_bounds__(1024) sz_k_bounds(State S, int commit_ghosts) {
   __shared__ double sh[5][16];
+  __shared__ int s_ncells;
+  if (commit_ghosts) {
+    if (threadIdx.x == 0) ghost_commit(S);
+    __syncthreads();
+  }
   int M = S.cnt[C_M];
   double x0 = __builtin_inf(), y0 = __builtin_inf(), x1 = -__builtin_inf(), y1 = -__builtin_inf(), rm = 0.0;
   for (int i = threadIdx.x; i < M; i += blockDim.x) {
@@ -362,9 +378,13 @@ __global__ void __launch_bounds__(1024) sz_k_bounds(State S) {
       cs *= 2.0;
     }
     S.cnt[C_ITEMCLASS] = 0;                              // narrow-phase size classes of this step
+    S.cnt[C_WARN_H] = 0; S.cnt[C_WARN_F] = 0; S.cnt[C_WARN_V] = 0; S.cnt[C_WARN_XI] = 0;   // guards of the coming update
     S.bounds[0] = x0; S.bounds[1] = y0; S.bounds[2] = cs; S.bounds[3] = (double)ncx; S.bounds[4] = (double)ncy;
     S.cnt[C_NCELLS] = (int)(ncx * ncy);
+    s_ncells = (int)(ncx * ncy);
   }
+  __syncthreads();
+  for (int q = threadIdx.x; q <= s_ncells; q += blockDim.x) S.cell_cnt[q] = 0;
 }
 // uniform-grid binning as per-cell linked lists (atomic exchange on the cell heads): no counting
 // pass, no scan.  The order inside a cell is arbitrary; the consumers sort by order key.
