@@ -138,6 +138,35 @@ def test_trajectories(n, seed, steps):
     assert np.array_equal(hw.warn_counts(), ow.warn_counts())
 
 
+def test_sparse_field_config5_geometry():
+    """config-5 geometry (25 % concentration: most broad-phase candidates are rejected) in fp64:
+    pair list bit-exact, forces within 1e-10."""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=3000, seed=14, concentration=0.25)
+    hw, ow = _pair(cfg)
+    hw.add_ghosts(); ow.add_ghosts()
+    hw.timestep_collisions(3000, cfg["dt"]); ow.timestep_collisions(3000, cfg["dt"])
+    res = parity.compare_worlds(hw, ow, rtol=1e-10, fields=["coll_fx", "coll_fy", "coll_trq", "overarea"])
+    assert res["n_pairs"] < 3000          # sparse: fewer pairs than floes
+
+
+def test_converge_diverge_100k_properties():
+    """config-3 size on one GPU (100 000 floes, converge/diverge ocean): capacities hold, internal contact
+    forces cancel over the parents, no guard fires for the forcings, state stays finite over 5 steps."""
+    from subzero_jl_amd import fields
+    n = 100000
+    cfg = fields.make_config(n_floes=n, seed=12346, ocean="converge_diverge")
+    hw = fields.build_world(mk(), cfg)
+    hw.run(5, 0, cfg["dt"], coupling_dt=1)
+    st = hw.stats()
+    assert st["M"] == n and st["n_pairs"] > n and st["n_trace_fail"] == 0
+    for f in ("cx", "cy", "u", "v", "xi", "coll_fx", "fxOA"):
+        assert np.all(np.isfinite(hw.get(f))), f
+    fx = hw.get("coll_fx")
+    assert abs(fx.sum()) <= 1e-9 * np.abs(fx).max() * st["n_inter_rows"]
+    assert np.all(hw.get("fxOA") != 0)
+
+
 def test_full_size_properties():
     """BASELINE config 2 size (10k floes): size-independent checks (no oracle run at this size in
     the GPU suite): Newton's third law on the mirrored rows, parents only keep totals, momentum
