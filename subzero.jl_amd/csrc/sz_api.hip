@@ -259,11 +259,14 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo) {
                        c->stream, S, c->P, dt, ffmo, fdmo, c->dbg);
     t.end();
   }
-  if (larger) {
+  {
+    // larger working sets: items with larger rings (only if such rings can exist) and items the
+    // smaller variant handed on; both kernels return at once when the step has no such item
     Timed t(c, K_NARROW_LARGE);
-    hipLaunchKernelGGL((sz_k_narrow<16, NARROW_CAP1, 16, 80, 6, 64, NARROW_CAP0, 1>), dim3(grid_for(capItems, 4, 2048)), dim3(64), 0,
-                       c->stream, S, c->P, dt, ffmo, fdmo, c->dbg);
-    hipLaunchKernelGGL((sz_k_narrow<64, NARROW_CAP2, 64, 320, 6, 64, NARROW_CAP1, 2>), dim3(grid_for(capItems, 1, 2048)), dim3(64), 0,
+    if (larger)
+      hipLaunchKernelGGL((sz_k_narrow<16, NARROW_CAP1, 16, 80, 6, 64, NARROW_CAP0, 1>), dim3(grid_for(capItems, 4, 2048)), dim3(64), 0,
+                         c->stream, S, c->P, dt, ffmo, fdmo, c->dbg);
+    hipLaunchKernelGGL((sz_k_narrow<64, NARROW_CAP2, 64, 320, 6, 64, NARROW_CAP1, 2>), dim3(grid_for(capItems, 1, larger ? 2048 : 256)), dim3(64), 0,
                        c->stream, S, c->P, dt, ffmo, fdmo, c->dbg);
     t.end();
   }

@@ -546,7 +546,7 @@ struct Body {          // kinematics of one side of a contact
 };
 
 enum { ITEM_PAIR = 0, ITEM_OPEN = 1, ITEM_SOLID = 2 };
-enum { IT_FUSE = 1, IT_REMOVE = 2 };
+enum { IT_FUSE = 1, IT_REMOVE = 2, IT_RETRY = 4 };
 
 struct ItemCtx {
   int mode;            // ITEM_PAIR: floe-floe; ITEM_OPEN: open boundary; ITEM_SOLID: collision/moving boundary, topography

@@ -568,7 +568,11 @@ __global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, do
     const int bo = is_pair ? S.voff[j] : S.eoff[e];
     const int nb = (is_pair ? S.voff[j + 1] : S.eoff[e + 1]) - bo;
     const int big = na > nb ? na : nb;
-    if (big <= LO) continue;                          // handled by the smaller variant
+    // an item belongs to the first variant whose ring capacity fits it; an item a smaller variant
+    // gave up on (more crossings / region points / regions than its working set holds) is handed to
+    // the largest one through IT_RETRY
+    const bool retry = CLS == 2 && (S.it_flags[item] & IT_RETRY);
+    if (big <= LO && !retry) continue;
     if (big > CAP) { if (CLS == 2 && gl == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); continue; }
     const double* bxs = is_pair ? S.vx : S.ex; const double* bys = is_pair ? S.vy : S.ey;
     gsync();
@@ -596,6 +600,13 @@ __global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, do
     Box ba{ S.bbx0[i], S.bbx1[i], S.bby0[i], S.bby1[i] };
     Box bb = is_pair ? Box{ S.bbx0[j], S.bbx1[j], S.bby0[j], S.bby1[j] } : Box{ S.ebb[4 * e], S.ebb[4 * e + 1], S.ebb[4 * e + 2], S.ebb[4 * e + 3] };
     if (!(dbg & 4)) nrows = collide_item<G>(m, gl, na, oa, nb, ob, ba, bb, ic, out, ROWS_PER_ITEM, flags, st);
+    gsync();
+    constexpr int CAPBITS = ERR_CAP_XING | ERR_CAP_REGION | ERR_CAP_ROWS;
+    if (CLS < 2 && (m.err & CAPBITS)) {                // working set too small: let the next variant redo the item
+      nrows = 0; flags = IT_RETRY;
+      gsync();
+      if (gl == 0) { m.err &= ~CAPBITS; atomicMax(&S.cnt[C_ITEMCLASS], 2); }   // the largest variant retries
+    }
     if (gl == 0) { S.it_nrows[item] = nrows; S.it_flags[item] = flags; }
     STAMP(st, 11);
 #ifdef SZ_STAMPS

@@ -138,6 +138,29 @@ def test_trajectories(n, seed, steps):
     assert np.array_equal(hw.warn_counts(), ow.warn_counts())
 
 
+def test_narrow_variant_retry_many_crossings():
+    """two 8-spike stars crossing 16 times: more crossings than the small narrow-phase working set
+    holds, so the item is redone by the largest variant; rows must still match the oracle."""
+    th = np.arange(16) * (2 * np.pi / 16)
+    rad = np.where(np.arange(16) % 2 == 0, 1.0e4, 0.55e4)
+    star = lambda rot, cx: np.stack([cx + rad * np.cos(-th + rot), 3e4 + rad * np.sin(-th + rot)], 1)
+    res = []
+    for w in (mk(), omk()):
+        w.set_domain([0, 0, 0, 0], -1e5, 1e5, -1e5, 1e5)
+        w.add_floe(cases.closed(star(0.0, 1.0e4)), 0.25)
+        w.add_floe(cases.closed(star(np.pi / 8, 1.05e4)), 0.25)
+        cases.set_vel(w, 0, {"u": 0.1}); cases.set_vel(w, 1, {"v": -0.1})
+        w.floe_floe_interaction(0, 1, 10, 1.0)
+        res.append(w.inter(0))
+    h, o = res
+    assert len(o) >= 1 and h.shape == o.shape
+    assert np.array_equal(h[:, 0], o[:, 0])
+    for c in (1, 2, 3, 4, 6):
+        assert parity.relerr(h[:, c], o[:, c]) <= 1e-10, c
+    from oracle import orc
+    assert len(orc.intersection_points(cases.closed(star(0.0, 1.0e4)), cases.closed(star(np.pi / 8, 1.05e4)))) > 12
+
+
 def test_sparse_field_config5_geometry():
     """config-5 geometry (25 % concentration: most broad-phase candidates are rejected) in fp64:
     pair list bit-exact, forces within 1e-10."""
