@@ -163,7 +163,8 @@ int sz_kernel_time_ms(sz_ctx *ctx, int32_t kclass, double *ms, int64_t *launches
    ghost-floe records (sz_halo_record_doubles() doubles each) through buffers in DEVICE memory
    that the host hands to RCCL (torch.distributed all_to_all_single).
      sz_tile_enable   after sz_upload_floes of the owned floes: gidx[i] = global index of owned
-                      floe i; all order-dependent rules then use global indices
+                      floe i; all order-dependent rules then use global indices.  max_ring = largest
+                      ring (points) over the floes of ALL ranks, 0 if unknown
      sz_owned_box     bounding box of the owned centroids + largest rmax: xmin,xmax,ymin,ymax,rmax
      sz_halo_set_boxes  nranks x {xmin,xmax,ymin,ymax}, already expanded by the interaction range
      sz_halo_pack     ASYNC. Exchange buffers have one region per peer: 1 header record (count in
@@ -175,12 +176,13 @@ int sz_kernel_time_ms(sz_ctx *ctx, int32_t kclass, double *ms, int64_t *launches
      sz_sync          waits for everything enqueued, reports sticky device errors
      sz_set_stream    enqueue on the caller's HIP stream (torch.cuda.current_stream().cuda_stream) so
                       that the framework's collectives order with the kernels without host syncs */
-int sz_tile_enable(sz_ctx *ctx, const int64_t *gidx, double reserved);
+int sz_tile_enable(sz_ctx *ctx, const int64_t *gidx, double max_ring);
 int sz_owned_box(sz_ctx *ctx, double *out5);
 int sz_halo_record_doubles(void);
 int sz_halo_set_boxes(sz_ctx *ctx, int32_t nranks, const double *boxes);
 int sz_halo_pack(sz_ctx *ctx, int32_t nranks, int32_t my_rank, double Lx, double Ly, int32_t periodic_x,
                  int32_t periodic_y, void *d_send, int32_t cap);
+int sz_halo_counts(sz_ctx *ctx, int32_t nranks, int32_t *counts_out);   /* of the last pack; d_send NULL = count only */
 int sz_tile_step(sz_ctx *ctx, const void *d_recv, int32_t nranks, int32_t cap, int32_t tstep, int32_t dt,
                  int32_t coupling_dt, int32_t flags);
 int sz_sync(sz_ctx *ctx);

@@ -55,7 +55,7 @@ EXPORTS = [
     "sz_add_ghosts", "sz_remove_ghosts", "sz_timestep_collisions", "sz_collide_pairs", "sz_collide_domain",
     "sz_timestep_coupling", "sz_timestep_floe_properties", "sz_step",
     "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms",
-    "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps",
+    "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps",
 ]
 
 _LIB = None
@@ -111,6 +111,7 @@ def load(build_if_missing=True):
     L.sz_halo_set_boxes.argtypes = [C.c_void_p, C.c_int32, _dp]
     L.sz_halo_pack.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32,
                                C.c_void_p, C.c_int32]
+    L.sz_halo_counts.argtypes = [C.c_void_p, C.c_int32, _ip]
     L.sz_tile_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.sz_sync.argtypes = [C.c_void_p]
     L.sz_set_stream.argtypes = [C.c_void_p, C.c_void_p]

@@ -54,7 +54,7 @@ struct sz_ctx {
   bool any_moving = false;
   bool overlap_forcing = false;   // SZ_OVERLAP=1: forcings on a second stream (measured: no gain at 10k-100k floes, the
                                   // forcing workgroups delay the latency-bound collision kernels; kept for tuning)
-  int max_ring = 0, max_elem_ring = 5;   // largest ring sizes (host knowledge: which narrow variants can be needed)
+  int max_ring = 0, max_elem_ring = 5, max_ring_tiled = 0;   // largest ring sizes (host knowledge: which narrow variants can be needed)
   int dbg = 0;   // SZ_DEBUG bits: timing experiments only (1 skip contact rows, 2 skip direction check, 4 skip clip)
 };
 
@@ -250,7 +250,7 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo) {
   long long capItems = (long long)S.capPairs + S.capElem;
   // Rings never change size inside the hot path, so the host knows whether any item can need a
   // larger variant (halo floes of a tiled run arrive unseen: then always check on the device).
-  const bool larger = S.tiled || std::max(c->max_ring, c->max_elem_ring) > NARROW_CAP0;
+  const bool larger = std::max(std::max(c->max_ring, c->max_elem_ring), S.tiled ? c->max_ring_tiled : 0) > NARROW_CAP0;
   if (larger) hipLaunchKernelGGL(sz_k_items_clear, dim3(grid_for(capItems, 256)), dim3(256), 0, c->stream, S);
   {
     Timed t(c, SZ_K_NARROW);
@@ -646,7 +646,7 @@ int sz_add_ghosts(sz_ctx* c) {
 int sz_remove_ghosts(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
-  hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
+  hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
   int rc = sync_and_check(c);
   if (rc) return rc;
   c->fuse_lists.resize(c->hostM);
@@ -733,7 +733,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     if (overlap) stage_forcing_join(c);
     stage_integrate(c, dt, !coll, coupling);
   }
-  if (coll && periodic) hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
+  if (coll && periodic) hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
   return sync_and_check(c);
 }
 
@@ -763,7 +763,8 @@ int sz_tile_enable(sz_ctx* c, const int64_t* gidx, double halo_capacity_factor) 
   H2D(S.okey, ok.data(), c->hostN, long long);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   S.tiled = 1;
-  (void)halo_capacity_factor;
+  // largest ring among ALL ranks' floes (halo floes arrive unseen): decides which narrow variants can be needed
+  c->max_ring_tiled = halo_capacity_factor > 0 ? (int)halo_capacity_factor : HALO_RING;
   return SZ_OK;
 }
 
@@ -799,14 +800,12 @@ int sz_halo_set_boxes(sz_ctx* c, int32_t nranks, const double* boxes) {
 // asynchronous: fills d_send (nranks regions of (cap + 1) records, record 0 = header with the count)
 int sz_halo_pack(sz_ctx* c, int32_t nranks, int32_t me, double Lx, double Ly, int32_t per_x, int32_t per_y, void* d_send,
                  int32_t cap) {
-  if (!c || !c->have_floes || nranks < 1 || nranks > 64 || !d_send || cap < 1) return SZ_E_ARG;
+  if (!c || !c->have_floes || nranks < 1 || nranks > 64 || cap < 1) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
   State& S = c->S;
   int* dcnt = S.cnt + C_COUNT;                  // 64 ints reserved behind the counter block
-  (void)hipMemsetAsync(dcnt, 0, 64 * sizeof(int), c->stream);
-  hipLaunchKernelGGL(sz_k_halo_pack, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, nranks, me, S.bounds + 16, Lx, Ly,
+  hipLaunchKernelGGL(sz_k_halo_pack, dim3(1), dim3(1024), 0, c->stream, S, nranks, me, S.bounds + 16, Lx, Ly,
                      per_x, per_y, (double*)d_send, cap, dcnt);
-  hipLaunchKernelGGL(sz_k_halo_header, dim3(1), dim3(64), 0, c->stream, (double*)d_send, nranks, cap, dcnt);
   return SZ_OK;
 }
 
@@ -818,11 +817,7 @@ int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int
   (void)hipSetDevice(c->device);
   State& S = c->S;
   if (d_recv && nranks > 0) {
-    hipLaunchKernelGGL(sz_k_halo_count, dim3(grid_for((long long)nranks * cap, 256)), dim3(256), 0, c->stream, S,
-                       (const double*)d_recv, nranks, cap);
-    scan(c, S.gvcnt, S.gvscan, S.capM, C_NHALO, 0, -1);
-    hipLaunchKernelGGL(sz_k_halo_unpack, dim3(grid_for((long long)nranks * cap, 128)), dim3(128), 0, c->stream, S,
-                       (const double*)d_recv, nranks, cap);
+    hipLaunchKernelGGL(sz_k_halo_unpack, dim3(1), dim3(1024), 0, c->stream, S, (const double*)d_recv, nranks, cap);
   }
   const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
   const bool overlap = coupling && c->overlap_forcing;
@@ -830,11 +825,19 @@ int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int
   stage_ghosts(c);
   // n_init = every local parent (owned + halo): totals of halo floes are computed and then ignored
   if (flags & SZ_COLLISIONS_ON) collisions(c, -1, dt);
-  hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S);
-  hipLaunchKernelGGL(sz_k_halo_drop, dim3(1), dim3(64), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 1);
   if (coupling && !overlap) stage_forcing(c);
   if (overlap) stage_forcing_join(c);
   stage_integrate(c, dt, false, coupling);
+  return SZ_OK;
+}
+
+// counts of the last sz_halo_pack per destination rank (synchronises); used to size the exchange buffers
+int sz_halo_counts(sz_ctx* c, int32_t nranks, int32_t* counts_out) {
+  if (!c || !c->have_floes || nranks < 1 || nranks > 64 || !counts_out) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipMemcpyAsync(counts_out, c->S.cnt + C_COUNT, (size_t)nranks * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return SZ_OK;
 }
 

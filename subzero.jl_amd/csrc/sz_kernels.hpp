@@ -330,14 +330,15 @@ __global__ void sz_k_ghost_commit(State S) {
   if (blockIdx.x == 0 && threadIdx.x == 0) ghost_commit(S);
 }
 // simulation.jl:138-144
-__global__ void sz_k_remove_ghosts(State S) {
-  int N = S.cnt[C_N];
+// drop_halo: tiled runs also forget the halo parents (N := owned)
+__global__ void sz_k_remove_ghosts(State S, int drop_halo) {
+  int N = drop_halo ? S.cnt[C_NOWN] : S.cnt[C_N];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
     S.ngh[i] = 0;
     for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = -1;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    S.cnt[C_M] = N; S.cnt[C_NV] = S.voff[N];        // C_NGHOSTS keeps the last step's count
+    S.cnt[C_M] = N; S.cnt[C_N] = N; S.cnt[C_NV] = S.voff[N];        // C_NGHOSTS keeps the last step's count
   }
 }
 
@@ -984,11 +985,16 @@ constexpr int HALO_RING = 32;
 constexpr int HALO_REC = 12 + 2 * HALO_RING;   // doubles
 
 // Every owned floe whose centroid -- or one of its periodic images -- lies inside another rank's
-// (already expanded) box is written to that rank's region of the send buffer.
-__global__ void sz_k_halo_pack(State S, int nranks, int me, const double* boxes, double Lx, double Ly, int per_x,
-                               int per_y, double* send, int cap, int* counts) {
+// (already expanded) box is written to that rank's region of the send buffer.  One block: the
+// per-destination counters live in LDS and the header records are written by the same launch.
+// With send == nullptr only the counts are produced (sizing pass).
+__global__ void __launch_bounds__(1024) sz_k_halo_pack(State S, int nranks, int me, const double* boxes, double Lx, double Ly,
+                                                       int per_x, int per_y, double* send, int cap, int* counts) {
+  __shared__ int lc[64];
+  if (threadIdx.x < 64) lc[threadIdx.x] = 0;
+  __syncthreads();
   int n = S.cnt[C_NOWN];
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+  for (int q = threadIdx.x; q < n; q += blockDim.x) {
     double cx = S.cx[q], cy = S.cy[q];
     int o = S.voff[q], nv = S.voff[q + 1] - o;
     for (int d = 0; d < nranks; d++) {
@@ -1001,7 +1007,8 @@ __global__ void sz_k_halo_pack(State S, int nranks, int me, const double* boxes,
           hit = (b[0] <= x && x <= b[1] && b[2] <= y && y <= b[3]);
         }
       if (!hit) continue;
-      int slot = atomicAdd(&counts[d], 1);
+      int slot = atomicAdd(&lc[d], 1);
+      if (send == nullptr) continue;                 // counting pass (sizing of the exchange buffers)
       if (slot >= cap || nv > HALO_RING) { atomicOr(&S.cnt[C_ERR], nv > HALO_RING ? ERR_CAP_RING : ERR_CAP_FLOES); continue; }
       double* r = send + ((size_t)d * (cap + 1) + 1 + slot) * HALO_REC;
       r[0] = (double)S.okey[q]; r[1] = (double)S.status[q]; r[2] = (double)nv; r[3] = cx; r[4] = cy; r[5] = S.rmax[q];
@@ -1009,48 +1016,51 @@ __global__ void sz_k_halo_pack(State S, int nranks, int me, const double* boxes,
       for (int k = 0; k < nv; k++) { r[12 + k] = S.vx[o + k]; r[12 + HALO_RING + k] = S.vy[o + k]; }
     }
   }
+  __syncthreads();
+  if ((int)threadIdx.x < nranks) {
+    int d = threadIdx.x;
+    counts[d] = lc[d];
+    if (send) send[(size_t)d * (cap + 1) * HALO_REC] = (double)(lc[d] < cap ? lc[d] : cap);
+  }
 }
 // ---- fixed-layout exchange buffers: region of peer r = 1 header record (count in [0]) followed by
 // `cap` record slots.  The host never needs the counts, so a whole step is enqueued without a sync.
-__global__ void sz_k_halo_header(double* send, int nranks, int cap, const int* counts) {
-  int d = threadIdx.x;
-  if (blockIdx.x == 0 && d < nranks) send[(size_t)d * (cap + 1) * HALO_REC] = (double)counts[d];
-}
-__device__ __forceinline__ bool halo_locate(const double* recv, int nranks, int cap, int t, int& src, int& slot, int& before) {
-  // t = src * cap + slot; `before` = records of lower sources
-  src = t / cap; slot = t - src * cap;
-  int cnt = (int)recv[(size_t)src * (cap + 1) * HALO_REC];
-  if (slot >= cnt) return false;
-  before = 0;
-  for (int r = 0; r < src; r++) before += (int)recv[(size_t)r * (cap + 1) * HALO_REC];
-  return true;
-}
-__global__ void sz_k_halo_count(State S, const double* recv, int nranks, int cap) {
-  int tot = 0;
-  for (int r = 0; r < nranks; r++) tot += (int)recv[(size_t)r * (cap + 1) * HALO_REC];
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nranks * cap; t += gridDim.x * blockDim.x) {
-    int src, slot, before;
-    if (!halo_locate(recv, nranks, cap, t, src, slot, before)) continue;
-    S.gvcnt[before + slot] = (int)recv[((size_t)src * (cap + 1) + 1 + slot) * HALO_REC + 2];
+// One block appends the received floes as extra parents [nown, nown + nrec): ring offsets by an
+// in-kernel scan of the ring sizes, then the copy.
+__global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* recv, int nranks, int cap) {
+  __shared__ int before[65];
+  __shared__ int tot, carry_s;
+  if (threadIdx.x == 0) {
+    int acc = 0; bool bad = false;
+    for (int r = 0; r < nranks; r++) { int cnt = (int)recv[(size_t)r * (cap + 1) * HALO_REC]; if (cnt > cap) { bad = true; cnt = cap; } before[r] = acc; acc += cnt; }
+    before[nranks] = acc;
+    if (bad) atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES);
+    carry_s = 0;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) S.cnt[C_NHALO] = tot;
-}
-// appends the received floes as extra parents [nown, nown + nrec); gvscan = exclusive scan of their ring sizes
-__global__ void sz_k_halo_unpack(State S, const double* recv, int nranks, int cap) {
-  int nown = S.cnt[C_NOWN], nrec = S.cnt[C_NHALO];
-  int vbase = S.voff[nown];
-  int totv = nrec > 0 ? S.gvscan[nrec] : 0;
-  bool bad = false;
-  for (int r = 0; r < nranks; r++) bad |= (int)recv[(size_t)r * (cap + 1) * HALO_REC] > cap;
-  if (bad || nown + nrec > S.capM || vbase + totv > S.capV) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], (bad || nown + nrec > S.capM) ? ERR_CAP_FLOES : ERR_CAP_VERTS);
-    return;
+  __syncthreads();
+  const int nrec = before[nranks];
+  const int nown = S.cnt[C_NOWN];
+  const int vbase = S.voff[nown];
+  if (nown + nrec > S.capM) { if (threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
+  // pass 1: ring offsets (gvscan[q] = exclusive scan of the ring sizes in record order)
+  for (int base = 0; base < nrec; base += blockDim.x) {
+    int q = base + threadIdx.x, nv = 0;
+    if (q < nrec) {
+      int src = 0; while (q >= before[src + 1]) src++;
+      nv = (int)recv[((size_t)src * (cap + 1) + 1 + (q - before[src])) * HALO_REC + 2];
+    }
+    int ex = block_exclusive_scan(nv, &tot);
+    if (q < nrec) S.gvscan[q] = carry_s + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += tot;
+    __syncthreads();
   }
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nranks * cap; t += gridDim.x * blockDim.x) {
-    int src, slot, before;
-    if (!halo_locate(recv, nranks, cap, t, src, slot, before)) continue;
-    const double* r = recv + ((size_t)src * (cap + 1) + 1 + slot) * HALO_REC;
-    int q = before + slot;
+  const int totv = carry_s;
+  if (vbase + totv > S.capV) { if (threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); return; }
+  // pass 2: copy
+  for (int q = threadIdx.x; q < nrec; q += blockDim.x) {
+    int src = 0; while (q >= before[src + 1]) src++;
+    const double* r = recv + ((size_t)src * (cap + 1) + 1 + (q - before[src])) * HALO_REC;
     int g = nown + q, nv = (int)r[2], vb = vbase + S.gvscan[q];
     S.okey[g] = (long long)r[0]; S.status[g] = (int)r[1]; S.cx[g] = r[3]; S.cy[g] = r[4]; S.rmax[g] = r[5];
     S.area[g] = r[6]; S.height[g] = r[7]; S.u[g] = r[8]; S.v[g] = r[9]; S.xi[g] = r[10]; S.id[g] = (long long)r[11];
@@ -1058,14 +1068,18 @@ __global__ void sz_k_halo_unpack(State S, const double* recv, int nranks, int ca
     S.mass[g] = 0.0; S.moment[g] = 0.0; S.alpha[g] = 0.0;
     for (int k = 0; k < MAX_GHOSTS; k++) S.gh[g * MAX_GHOSTS + k] = -1;
     S.voff[g] = vb; S.voff[g + 1] = vb + nv;
-    for (int k = 0; k < nv; k++) { S.vx[vb + k] = r[12 + k]; S.vy[vb + k] = r[12 + HALO_RING + k]; }
-    S.osign[g] = ring_signed_area(S.vx + vb, S.vy + vb, nv) >= 0.0 ? 1 : -1;
     double x0 = __builtin_inf(), x1 = -__builtin_inf(), y0 = __builtin_inf(), y1 = -__builtin_inf();
-    for (int k = 0; k < nv; k++) { x0 = fmin(x0, r[12 + k]); x1 = fmax(x1, r[12 + k]); y0 = fmin(y0, r[12 + HALO_RING + k]); y1 = fmax(y1, r[12 + HALO_RING + k]); }
+    for (int k = 0; k < nv; k++) {
+      double x = r[12 + k], y = r[12 + HALO_RING + k];
+      S.vx[vb + k] = x; S.vy[vb + k] = y;
+      x0 = fmin(x0, x); x1 = fmax(x1, x); y0 = fmin(y0, y); y1 = fmax(y1, y);
+    }
+    S.osign[g] = ring_signed_area(r + 12, r + 12 + HALO_RING, nv) >= 0.0 ? 1 : -1;
     S.bbx0[g] = x0; S.bbx1[g] = x1; S.bby0[g] = y0; S.bby1[g] = y1;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    S.cnt[C_M] = nown + nrec; S.cnt[C_N] = nown + nrec; S.cnt[C_NV] = vbase + totv;
+  if (threadIdx.x == 0) {
+    S.cnt[C_M] = nown + nrec; S.cnt[C_N] = nown + nrec; S.cnt[C_NV] = vbase + totv; S.cnt[C_NHALO] = nrec;
+    if (nrec == 0) S.voff[nown] = vbase;
   }
 }
 // after the step: forget the halo floes (their owners integrate them)

@@ -101,14 +101,13 @@ class TiledWorld:
         w.load_columns(cols); w.set_subpoints_csr(soff, sx, sy)
         w._push()
         g = np.ascontiguousarray(self.gidx, np.int64)
-        w._chk(w.L.sz_tile_enable(w.h, capi.ptr(g, capi._lp), 0.0))
+        max_ring = float(np.diff(cfg["vert_off"]).max())        # over ALL floes: halo floes arrive unseen
+        w._chk(w.L.sz_tile_enable(w.h, capi.ptr(g, capi._lp), max_ring))
         self.world = w
         self.REC = w.L.sz_halo_record_doubles()
-        self.cap = max(256, len(self.gidx) // 2 + 64)         # record slots per peer
         self.dev = torch.device("cuda", device)
-        n = world * (self.cap + 1) * self.REC
-        self.send = torch.zeros(n, dtype=torch.float64, device=self.dev)
-        self.recv = torch.zeros(n, dtype=torch.float64, device=self.dev)
+        self.cap = 0                                          # record slots per peer, sized from a counting pass
+        self.send = self.recv = None
         if not host_staging:
             # kernels and RCCL collectives are ordered by ONE stream: no host sync inside a step
             w._chk(w.L.sz_set_stream(w.h, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
@@ -130,6 +129,19 @@ class TiledWorld:
         self.boxes = np.ascontiguousarray(np.stack([expanded_box(b, self.margin) for b in allb]))
         w._chk(w.L.sz_halo_set_boxes(w.h, self.nranks, capi.ptr(self.boxes)))
         self.steps_since_box = 0
+        # size the exchange buffers: counting pass, largest count over all ranks and peers, 50 % head room
+        # (the all-to-all uses equal splits, so every rank must use the same number of slots)
+        w._chk(w.L.sz_halo_pack(w.h, self.nranks, self.rank, self.L, self.L, int(self.per_x), int(self.per_y), None, 1))
+        counts = np.zeros(self.nranks, np.int32)
+        w._chk(w.L.sz_halo_counts(w.h, self.nranks, capi.ptr(counts, capi._ip)))
+        t = self.torch.tensor([int(counts.max())], dtype=self.torch.int64, device="cpu" if self.host_staging else self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        cap = int(t.item()) * 3 // 2 + 32
+        if cap > self.cap:
+            self.cap = cap
+            n = self.nranks * (self.cap + 1) * self.REC
+            self.send = self.torch.zeros(n, dtype=self.torch.float64, device=self.dev)
+            self.recv = self.torch.zeros(n, dtype=self.torch.float64, device=self.dev)
 
     def exchange(self):
         """steps 1-2 of the module docstring, asynchronous on the device: fills self.recv."""
