@@ -359,8 +359,10 @@ sz_ctx* sz_create(int device_id) {
   c->device = device_id;
   if (const char* e = getenv("SZ_DEBUG")) c->dbg = atoi(e);
   if (const char* e = getenv("SZ_OVERLAP")) c->overlap_forcing = atoi(e) != 0;
-  if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; }
-  if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     // lo = least urgent, hi = most urgent
+  if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_hi) != hipSuccess) { delete c; return nullptr; }
+  if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess) { delete c; return nullptr; }
   (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
   // Constants() and default settings of the reference
   Params& P = c->P;
@@ -433,7 +435,7 @@ int sz_set_fields(sz_ctx* c, int32_t Nx, int32_t Ny, double x0, double xf, doubl
     c->field_allocs.push_back(q);
     *dst[k] = (double*)q;
   }
-  S.Nx = Nx; S.Ny = Ny; S.gx0 = x0; S.gxf = xf; S.gy0 = y0; S.gyf = yf; S.gdx = (xf - x0) / Nx; S.gdy = (yf - y0) / Ny;
+  S.Nx = Nx; S.Ny = Ny; S.gx0 = x0; S.gxf = xf; S.gy0 = y0; S.gyf = yf; S.gdx = (xf - x0) / Nx; S.gdy = (yf - y0) / Ny; S.rdx = 1.0 / S.gdx; S.rdy = 1.0 / S.gdy;
   c->have_fields = true;
   return SZ_OK;
 }

@@ -763,17 +763,24 @@ __global__ void sz_k_update_boundaries(State S, int dt) {
 // of mc_interpolation, coupling.jl:845-902, incl. the periodic wrap of find_interp_knots :702-744).
 // Cell and weights depend only on the point, so they are computed once for all five fields.
 struct LatticeCell { int o00, o01, o10, o11; double tx, ty; };
+__device__ __forceinline__ int wrap_index(int i, int n) {       // i mod n for i within a few periods of [0, n)
+  if (i < 0) { i += n; if (i < 0) i = ((i % n) + n) % n; }
+  else if (i >= n) { i -= n; if (i >= n) i %= n; }
+  return i;
+}
 __device__ __forceinline__ LatticeCell lattice_cell(const State& S, double x, double y, int per_x, int per_y) {
   int Nx = S.Nx, Ny = S.Ny;
-  long long ix = (long long)floor((x - S.gx0) / S.gdx), iy = (long long)floor((y - S.gy0) / S.gdy);
+  // cell index and weights with the reciprocal spacing: a point on a grid line may land in the
+  // neighbouring cell, where bilinear interpolation gives the same value
+  int ix = (int)floor((x - S.gx0) * S.rdx), iy = (int)floor((y - S.gy0) * S.rdy);
   if (!per_x) { if (ix < 0) ix = 0; if (ix > Nx - 1) ix = Nx - 1; }
   if (!per_y) { if (iy < 0) iy = 0; if (iy > Ny - 1) iy = Ny - 1; }
   double xk = S.gx0 + (double)ix * S.gdx, yk = S.gy0 + (double)iy * S.gdy;
   LatticeCell c;
-  c.tx = (x - xk) / S.gdx; c.ty = (y - yk) / S.gdy;
+  c.tx = (x - xk) * S.rdx; c.ty = (y - yk) * S.rdy;
   int i0, i1, j0, j1;
-  if (per_x) { i0 = (int)(((ix % Nx) + Nx) % Nx); i1 = (int)((((ix + 1) % Nx) + Nx) % Nx); } else { i0 = (int)ix; i1 = (int)ix + 1; }
-  if (per_y) { j0 = (int)(((iy % Ny) + Ny) % Ny); j1 = (int)((((iy + 1) % Ny) + Ny) % Ny); } else { j0 = (int)iy; j1 = (int)iy + 1; }
+  if (per_x) { i0 = wrap_index(ix, Nx); i1 = i0 + 1 == Nx ? 0 : i0 + 1; } else { i0 = ix; i1 = ix + 1; }
+  if (per_y) { j0 = wrap_index(iy, Ny); j1 = j0 + 1 == Ny ? 0 : j0 + 1; } else { j0 = iy; j1 = iy + 1; }
   int s = Ny + 1;
   c.o00 = i0 * s + j0; c.o01 = i0 * s + j1; c.o10 = i1 * s + j0; c.o11 = i1 * s + j1;
   return c;
@@ -818,7 +825,8 @@ __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
       // sin(atan(y, x)) and cos(atan(y, x)) of coupling.jl:1530-1537 as y/r and x/r (equal to
       // within an ulp; atan(0, 0) = 0 gives sin = 0, cos = 1)
       double rad = sqrt(xc * xc + yc * yc);
-      double st = rad > 0.0 ? yc / rad : 0.0, ct = rad > 0.0 ? xc / rad : 1.0;
+      double irad = rad > 0.0 ? 1.0 / rad : 0.0;
+      double st = yc * irad, ct = rad > 0.0 ? xc * irad : 1.0;
       double up = u - xi * rad * st, vp = v + xi * rad * ct;
       LatticeCell lc = lattice_cell(S, x, y, per_x, per_y);
       double uatm = sample_field(S.ua, lc), vatm = sample_field(S.va, lc);
@@ -948,10 +956,10 @@ __global__ void __launch_bounds__(256) sz_k_move_strain(State S) {
         moved(k - 1, ax, ay); moved(k, bx, by);
         double x1 = ax + (-ncx), y1 = ay + (-ncy), x2 = bx + (-ncx), y2 = by + (-ncy);
         double xd = x2 - x1, yd = y2 - y1;
-        double rad1 = sqrt(x1 * x1 + y1 * y1), rad2 = sqrt(x2 * x2 + y2 * y2);
-        double th1 = atan2(y1, x1), th2 = atan2(y2, x2);
-        double u1 = u - xi * rad1 * sin(th1), u2 = u - xi * rad2 * sin(th2);
-        double v1 = u + xi * rad1 * cos(th1), v2 = u + xi * rad2 * cos(th2);
+        // rad*sin(atan(y, x)) == y and rad*cos(atan(y, x)) == x up to the last bit (update_floe.jl:437-442
+        // evaluates them through atan/sin/cos); the vertex velocities use floe.u for v1, v2: literal
+        double u1 = u - xi * y1, u2 = u - xi * y2;
+        double v1 = u + xi * x1, v2 = u + xi * x2;
         double ud = u2 - u1, vd = v2 - v1;
         t11[gi][k - base] = ud * yd; t12[gi][k - base] = ud * xd + vd * yd; t22[gi][k - base] = vd * xd;
       }

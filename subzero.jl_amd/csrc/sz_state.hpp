@@ -68,7 +68,7 @@ struct State {
   int *ekind, *edir; double *eval, *eu, *ev, *ecx, *ecy, *ermax, *erect;  // erect: 4 per boundary
   signed char* eosign; double* ebb;   // element orientation signs and boxes (4 per element)
   // ---- grid fields
-  int Nx, Ny; double gx0, gxf, gy0, gyf, gdx, gdy;
+  int Nx, Ny; double gx0, gxf, gy0, gyf, gdx, gdy, rdx, rdy;   // rdx = 1/gdx
   double *uo, *vo, *hf, *ua, *va;
   // ---- ghosts workspace
   int *gflag, *gcnt, *gscan, *gvcnt, *gvscan;
