@@ -296,14 +296,14 @@ void stage_forcing_fork(sz_ctx* c) {
   (void)hipEventRecord(c->ev_fork, c->stream);
   (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
   Timed t(c, SZ_K_FORCING, c->stream2);
-  hipLaunchKernelGGL(sz_k_forcing, dim3(grid_for(c->S.capM, 4, 8192)), dim3(256), 0, c->stream2, c->S, c->P);
+  hipLaunchKernelGGL(sz_k_forcing, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream2, c->S, c->P);
   t.end();
   (void)hipEventRecord(c->ev_join, c->stream2);
 }
 void stage_forcing_join(sz_ctx* c) { (void)hipStreamWaitEvent(c->stream, c->ev_join, 0); }
 void stage_forcing(sz_ctx* c) {      // in-order variant (process mode, profiling)
   Timed t(c, SZ_K_FORCING);
-  hipLaunchKernelGGL(sz_k_forcing, dim3(grid_for(c->S.capM, 4, 8192)), dim3(256), 0, c->stream, c->S, c->P);
+  hipLaunchKernelGGL(sz_k_forcing, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream, c->S, c->P);
   t.end();
 }
 void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc) {

@@ -803,9 +803,10 @@ __global__ void sz_k_apply_frc(State S) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
     if (S.frc_remove[i]) S.status[i] = SZ_REMOVE;
 }
+constexpr int FRC_G = 32;      // lanes per floe (sub-floe points per floe ~ 100: 32 lanes keep every wavefront resident at 10k floes)
 __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
   int N = S.cnt[C_NOWN];
-  int lane = threadIdx.x & 63, wpb = blockDim.x >> 6, wid = threadIdx.x >> 6;
+  int lane = threadIdx.x % FRC_G, wpb = blockDim.x / FRC_G, wid = threadIdx.x / FRC_G;
   int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
   double cturn = cos(P.turn), sturn = sin(P.turn);
   for (int i = blockIdx.x * wpb + wid; i < N; i += gridDim.x * wpb) {
@@ -814,7 +815,7 @@ __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
     double ma_ratio = S.mass[i] / S.area[i];
     int o = S.soff[i], ns = S.soff[i + 1] - o;
     double tx = 0, ty = 0, ttrq = 0, th = 0; int np = 0;
-    for (int k = lane; k < ns; k += 64) {
+    for (int k = lane; k < ns; k += FRC_G) {
       double sxk = S.sx[o + k], syk = S.sy[o + k];
       double x = (ca * sxk - sa * syk) + cxf;
       double y = (sa * sxk + ca * syk) + cyf;
@@ -843,9 +844,11 @@ __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
       double fx = tax + tpx + tox, fy = tay + tpy + toy;
       tx += fx; ty += fy; ttrq += (-fx * st + fy * ct) * rad; th += hfl;
     }
-    tx = wave_sum(tx); ty = wave_sum(ty); ttrq = wave_sum(ttrq); th = wave_sum(th);
+    for (int d = FRC_G / 2; d >= 1; d >>= 1) {
+      tx += __shfl_xor(tx, d, FRC_G); ty += __shfl_xor(ty, d, FRC_G); ttrq += __shfl_xor(ttrq, d, FRC_G); th += __shfl_xor(th, d, FRC_G);
+    }
     int npt = np;
-    for (int d = 32; d >= 1; d >>= 1) npt += __shfl_xor(npt, d);
+    for (int d = FRC_G / 2; d >= 1; d >>= 1) npt += __shfl_xor(npt, d, FRC_G);
     if (lane == 0) {
       // no in-bounds point: the floe is marked for removal (coupling.jl:1507-1508).  The tag itself is
       // written by the integrate kernel: this kernel may run beside the collision kernels, which also
