@@ -435,7 +435,15 @@ int sz_set_fields(sz_ctx* c, int32_t Nx, int32_t Ny, double x0, double xf, doubl
     c->field_allocs.push_back(q);
     *dst[k] = (double*)q;
   }
+  {
+    void* q = nullptr;
+    HIPCHK(c, hipMalloc(&q, n * 8 * sizeof(double)));
+    c->field_allocs.push_back(q);
+    S.nodes = (double*)q;
+  }
   S.Nx = Nx; S.Ny = Ny; S.gx0 = x0; S.gxf = xf; S.gy0 = y0; S.gyf = yf; S.gdx = (xf - x0) / Nx; S.gdy = (yf - y0) / Ny; S.rdx = 1.0 / S.gdx; S.rdy = 1.0 / S.gdy;
+  hipLaunchKernelGGL(sz_k_interleave_fields, dim3(grid_for((long long)n, 256)), dim3(256), 0, c->stream, S);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_fields = true;
   return SZ_OK;
 }

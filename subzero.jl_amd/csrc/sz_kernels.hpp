@@ -785,10 +785,19 @@ __device__ __forceinline__ LatticeCell lattice_cell(const State& S, double x, do
   c.o00 = i0 * s + j0; c.o01 = i0 * s + j1; c.o10 = i1 * s + j0; c.o11 = i1 * s + j1;
   return c;
 }
-__device__ __forceinline__ double sample_field(const double* A, const LatticeCell& c) {
-  double c0 = (1.0 - c.ty) * A[c.o00] + c.ty * A[c.o01];
-  double c1 = (1.0 - c.ty) * A[c.o10] + c.ty * A[c.o11];
+// The five lattices are interleaved per node (8 doubles = one 64-byte line: uo, vo, hf, ua, va, pad):
+// a point touches 4 lines instead of 10.  Field f of the four corner nodes -> bilinear value.
+__device__ __forceinline__ double sample_field(const double* nodes, int f, const LatticeCell& c) {
+  double c0 = (1.0 - c.ty) * nodes[(size_t)c.o00 * 8 + f] + c.ty * nodes[(size_t)c.o01 * 8 + f];
+  double c1 = (1.0 - c.ty) * nodes[(size_t)c.o10 * 8 + f] + c.ty * nodes[(size_t)c.o11 * 8 + f];
   return (1.0 - c.tx) * c0 + c.tx * c1;
+}
+__global__ void sz_k_interleave_fields(State S) {
+  int n = (S.Nx + 1) * (S.Ny + 1);
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+    double* d = S.nodes + (size_t)q * 8;
+    d[0] = S.uo[q]; d[1] = S.vo[q]; d[2] = S.hf[q]; d[3] = S.ua[q]; d[4] = S.va[q]; d[5] = 0.0; d[6] = 0.0; d[7] = 0.0;
+  }
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -830,12 +839,12 @@ __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
       double st = yc * irad, ct = rad > 0.0 ? xc * irad : 1.0;
       double up = u - xi * rad * st, vp = v + xi * rad * ct;
       LatticeCell lc = lattice_cell(S, x, y, per_x, per_y);
-      double uatm = sample_field(S.ua, lc), vatm = sample_field(S.va, lc);
+      double uatm = sample_field(S.nodes, 3, lc), vatm = sample_field(S.nodes, 4, lc);
       double du = uatm - up, dv = vatm - vp;
       double nrm = sqrt(du * du + dv * dv);
       double tax = P.rho_a * P.Cd_ia * nrm * du, tay = P.rho_a * P.Cd_ia * nrm * dv;
-      double uocn = sample_field(S.uo, lc), vocn = sample_field(S.vo, lc);
-      double hfl = sample_field(S.hf, lc);
+      double uocn = sample_field(S.nodes, 0, lc), vocn = sample_field(S.nodes, 1, lc);
+      double hfl = sample_field(S.nodes, 2, lc);
       double duo = uocn - up, dvo = vocn - vp;
       double nrmo = sqrt(duo * duo + dvo * dvo);
       double tox = P.rho_o * P.Cd_io * nrmo * (cturn * duo - sturn * dvo);

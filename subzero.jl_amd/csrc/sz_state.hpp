@@ -70,6 +70,7 @@ struct State {
   // ---- grid fields
   int Nx, Ny; double gx0, gxf, gy0, gyf, gdx, gdy, rdx, rdy;   // rdx = 1/gdx
   double *uo, *vo, *hf, *ua, *va;
+  double* nodes;             // the five lattices interleaved per node (8 doubles each)
   // ---- ghosts workspace
   int *gflag, *gcnt, *gscan, *gvcnt, *gvscan;
   int4 *gplan, *gscan4, *gblk4, *gtot4;
