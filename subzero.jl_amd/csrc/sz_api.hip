@@ -210,7 +210,7 @@ void stage_ghosts(sz_ctx* c, bool in_step = false) {
   hipLaunchKernelGGL(sz_k_scan4_1, dim3(nb), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.gblk4, S.cnt, C_N);
   hipLaunchKernelGGL(sz_k_scan4_2, dim3(1), dim3(SCAN_B), 0, c->stream, S.gblk4, S.cnt, C_N);
   hipLaunchKernelGGL(sz_k_scan4_3, dim3(nb), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.gblk4, S.cnt, C_N, S.gtot4);
-  hipLaunchKernelGGL(sz_k_ghost_fill, dim3(grid_for(S.capM, 256, 1024)), dim3(256), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_ghost_fill, dim3(grid_for(S.capM, 32, 2048)), dim3(256), 0, c->stream, S);
   if (!in_step) hipLaunchKernelGGL(sz_k_ghost_commit, dim3(1), dim3(64), 0, c->stream, S);
   t.end();
 }

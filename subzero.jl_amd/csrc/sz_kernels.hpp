@@ -230,31 +230,22 @@ __device__ __forceinline__ void copy_floe_row(State& S, int dst, int src) {
   S.ngh[dst] = 0;
 }
 
-// Ghost rows are made by a whole wavefront: every lane executes the scalar column copies with the
-// same values (same-address stores coalesce), the ring loops are spread over the lanes.
-__device__ __forceinline__ void wave_mem_sync() {   // make the wave's global stores visible to its own later loads
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+// Ghost rows are made by a whole wavefront per flagged parent.  The geometry that the two passes
+// change (centroid, box, this lane's ring points) of the parent and of its up to three ghosts is kept
+// in REGISTERS through both passes and stored once at the end, so the chain of one parent is two
+// memory round trips instead of one per ghost and per swap.  The arithmetic is the reference's:
+// a ghost is a copy translated by (+-L, 0) / (0, +-L) (ghosts_on_bounds!, collisions.jl:881-901), the
+// swap translates parent and its own new ghost in opposite directions (:942-950, :994-1000).
+struct Rig { double cx, cy, b0, b1, b2, b3, x0, y0, x1, y1; };    // x1, y1: the lane's second point (rings of 65..128 points)
+__device__ __forceinline__ Rig rig_shift(Rig r, double dx, double dy) {
+  r.cx += dx; r.cy += dy; r.b0 += dx; r.b1 += dx; r.b2 += dy; r.b3 += dy;
+  r.x0 += dx; r.y0 += dy; r.x1 += dx; r.y1 += dy;
+  return r;
 }
-// one ghost row: copy of `src` translated by (tx, ty) with its ring at vb (ghosts_on_bounds!, :881-901)
-__device__ __forceinline__ void make_ghost(State& S, int lane, int g, int src, int parent, int vb, double tx, double ty,
-                                           int ghost_id, long long okey) {
-  copy_floe_row(S, g, src);
-  S.cx[g] = S.cx[src] + tx; S.cy[g] = S.cy[src] + ty;
-  S.bbx0[g] = S.bbx0[src] + tx; S.bbx1[g] = S.bbx1[src] + tx; S.bby0[g] = S.bby0[src] + ty; S.bby1[g] = S.bby1[src] + ty;
-  int so = S.voff[src], n = S.voff[src + 1] - so;
-  S.voff[g] = vb; S.voff[g + 1] = vb + n;      // neighbours write the same values: rings are packed back to back
-  for (int q = lane; q < n; q += 64) { S.vx[vb + q] = S.vx[so + q] + tx; S.vy[vb + q] = S.vy[so + q] + ty; }
-  S.ghost_id[g] = (long long)ghost_id; S.parent[g] = parent; S.okey[g] = okey;
-  if (lane < MAX_GHOSTS) S.gh[g * MAX_GHOSTS + lane] = -1;
-}
-__device__ __forceinline__ void translate_row(State& S, int lane, int f, double px, double py) {
-  double ncx = S.cx[f] + px, ncy = S.cy[f] + py;
-  double b0 = S.bbx0[f] + px, b1 = S.bbx1[f] + px, b2 = S.bby0[f] + py, b3 = S.bby1[f] + py;
-  wave_mem_sync();                                 // every lane has read the old values
-  S.cx[f] = ncx; S.cy[f] = ncy; S.bbx0[f] = b0; S.bbx1[f] = b1; S.bby0[f] = b2; S.bby1[f] = b3;
-  int o = S.voff[f], n = S.voff[f + 1] - o;
-  for (int q = lane; q < n; q += 64) { S.vx[o + q] += px; S.vy[o + q] += py; }
+__device__ __forceinline__ void rig_store(State& S, int lane, int f, int vo, int n, const Rig& r) {
+  S.cx[f] = r.cx; S.cy[f] = r.cy; S.bbx0[f] = r.b0; S.bbx1[f] = r.b1; S.bby0[f] = r.b2; S.bby1[f] = r.b3;
+  if (lane < n) { S.vx[vo + lane] = r.x0; S.vy[vo + lane] = r.y0; }
+  if (lane + 64 < n) { S.vx[vo + lane + 64] = r.x1; S.vy[vo + lane + 64] = r.y1; }
 }
 
 // gscan4 holds the exclusive int4 scan of gplan, gtot4[0] the totals
@@ -267,20 +258,33 @@ __global__ void __launch_bounds__(256) sz_k_ghost_fill(State S) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   // chunk c looks at parents c, c + nchunks, c + 2 nchunks, ..: floes near one wall have consecutive
   // indices, striding spreads them over the wavefronts
-  const int nchunks = (N + 63) / 64;
+  // Only GH_CH parents per wavefront visit, taken in a scattered order (multiplicative permutation of
+  // [0, 2^k)): flagged parents are a few per cent but sit in rows/columns of the index space, and a
+  // wavefront works its flagged parents off one after the other.
+  constexpr int GH_CH = 8;
+  unsigned np2 = 1; while ((int)np2 < N) np2 <<= 1;
+  const int nchunks = (int)(np2 / GH_CH) > 0 ? (int)(np2 / GH_CH) : 1;
   for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
-    int mine = chunk + lane * nchunks;
-    int flm = mine < N ? S.gflag[mine] : 5;          // 5 = (0+1) | (0+1)<<2: no ghost
+    unsigned qv = (unsigned)(chunk * GH_CH + lane);
+    int mine = (int)((qv * 0x9E3779B1u) & (np2 - 1));
+    int flm = (lane < GH_CH && qv < np2 && mine < N) ? S.gflag[mine] : 5;          // 5 = (0+1) | (0+1)<<2: no ghost
     unsigned long long todo = __ballot(flm != 5);
     while (todo) {
       int src_lane = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
-      const int i = chunk + src_lane * nchunks;
+      const int i = __shfl(mine, src_lane);
       const int fl = __shfl(flm, src_lane);
-      int dirs[2] = { (fl & 3) - 1, ((fl >> 2) & 3) - 1 };
-      int4 sc = S.gscan4[i];
+      const int dirs[2] = { (fl & 3) - 1, ((fl >> 2) & 3) - 1 };
+      const int4 sc = S.gscan4[i];
+      const int vo = S.voff[i], n = S.voff[i + 1] - vo;
       if (S.ngh[i] != 0) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_GHOSTS_PER_PARENT); continue; }
-      int ng = 0;
+      if (n > 128) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); continue; }
+      Rig P;
+      P.cx = S.cx[i]; P.cy = S.cy[i]; P.b0 = S.bbx0[i]; P.b1 = S.bbx1[i]; P.b2 = S.bby0[i]; P.b3 = S.bby1[i];
+      P.x0 = lane < n ? S.vx[vo + lane] : 0.0; P.y0 = lane < n ? S.vy[vo + lane] : 0.0;
+      P.x1 = lane + 64 < n ? S.vx[vo + lane + 64] : 0.0; P.y1 = lane + 64 < n ? S.vy[vo + lane + 64] : 0.0;
+      Rig Gs[MAX_GHOSTS]; int slot[MAX_GHOSTS], vbs[MAX_GHOSTS], gid[MAX_GHOSTS]; long long key[MAX_GHOSTS];
+      int ng = 0; bool moved = false;
       for (int axis = 0; axis < 2; axis++) {
         int dir = dirs[axis];
         if (dir == 0) continue;
@@ -290,29 +294,35 @@ __global__ void __launch_bounds__(256) sz_k_ghost_fill(State S) {
         double tx = axis == 0 ? t : 0.0, ty = axis == 0 ? 0.0 : t;
         int gbase = axis == 0 ? M0 + sc.x : M0 + T.x + sc.z;
         int vb = axis == 0 ? NV0 + sc.y : NV0 + T.y + sc.w;
-        int last = gbase + ng;
-        for (int k = 0; k <= ng; k++) {            // ghosts of the existing ghosts first, then the parent's
-          int src = k < ng ? S.gh[i * MAX_GHOSTS + k] : i;
-          long long key = S.tiled ? ((long long)(axis + 1) << 40) + S.okey[i] * 4 + k : (long long)(gbase + k);
-          make_ghost(S, lane, gbase + k, src, i, vb, tx, ty, k + 1 + ng, key);
-          vb += S.voff[src + 1] - S.voff[src];
+        // ghosts of the existing ghosts first, then the parent's (every copy has the parent's ring size)
+        for (int k = 0; k <= ng; k++) {
+          int w = ng + k;
+          Gs[w] = rig_shift(k < ng ? Gs[k] : P, tx, ty);
+          slot[w] = gbase + k; vbs[w] = vb + k * n; gid[w] = k + 1 + ng;
+          key[w] = S.tiled ? ((long long)(axis + 1) << 40) + S.okey[i] * 4 + k : (long long)(gbase + k);
         }
-        wave_mem_sync();
-        if (lane <= ng) S.gh[i * MAX_GHOSTS + ng + lane] = gbase + lane;
-        // parent centroid outside the domain: swap roles with its own new ghost (collisions.jl:942-950)
-        double c = axis == 0 ? S.cx[i] : S.cy[i];
+        // parent centroid outside the domain: swap roles with its own new ghost
+        double c = axis == 0 ? P.cx : P.cy;
         double sp = 0.0;
         if (c < minv) sp = L; else if (maxv < c) sp = -L;
         if (sp != 0.0) {
           double px = axis == 0 ? sp : 0.0, py = axis == 0 ? 0.0 : sp;
-          translate_row(S, lane, i, px, py);
-          translate_row(S, lane, last, -px, -py);
+          P = rig_shift(P, px, py); moved = true;
+          Gs[ng + ng] = rig_shift(Gs[ng + ng], -px, -py);
         }
-        wave_mem_sync();
         ng = ng + ng + 1;
       }
+      for (int w = 0; w < ng; w++) {
+        int g = slot[w];
+        copy_floe_row(S, g, i);
+        rig_store(S, lane, g, vbs[w], n, Gs[w]);
+        S.voff[g] = vbs[w]; S.voff[g + 1] = vbs[w] + n;   // neighbours write the same values: rings are packed back to back
+        S.ghost_id[g] = (long long)gid[w]; S.parent[g] = i; S.okey[g] = key[w];
+        if (lane < MAX_GHOSTS) S.gh[g * MAX_GHOSTS + lane] = -1;
+      }
+      if (moved) rig_store(S, lane, i, vo, n, P);
+      if (lane < ng) S.gh[i * MAX_GHOSTS + lane] = slot[lane < MAX_GHOSTS ? lane : 0];
       if (lane == 0) S.ngh[i] = ng;
-      wave_mem_sync();
     }
   }
 }
