@@ -152,7 +152,9 @@ int sz_step(sz_ctx *ctx, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t cou
             int32_t flags);
 
 /* ---- measurement: HIP-event time per kernel class, accumulated since the last reset, on the
-   stream the kernels are launched on; launches = number of timed launches of that class */
+   stream the kernels are launched on; launches = number of timed launches of that class.
+   on = 0: off; 1: every class; otherwise a mask, bit (k+1) = class k (e.g. 2 << SZ_K_NARROW: only
+   the dominant kernel -- every event pair costs a few microseconds of a ~250 us step) */
 int sz_profile_enable(sz_ctx *ctx, int32_t on);
 int sz_profile_reset(sz_ctx *ctx);
 int sz_kernel_time_ms(sz_ctx *ctx, int32_t kclass, double *ms, int64_t *launches);

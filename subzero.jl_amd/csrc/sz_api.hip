@@ -44,7 +44,7 @@ struct sz_ctx {
   double h_vals[4] = { 0, 0, 0, 0 }, h_rects[16] = { 0 }, h_bu[4] = { 0 }, h_bv[4] = { 0 };
   std::vector<int> h_toff; std::vector<double> h_tx, h_ty, h_tcx, h_tcy, h_trmax;
   // profiling
-  bool profile = false;
+  unsigned pmask = 0;               // bit k: kernel class k is event-timed
   std::vector<EvPair> evs; size_t ev_used = 0;
   double kms[NK] = { 0 }; long long kl[NK] = { 0 };
   // fuse bookkeeping (status.fuse_idx lives on the host: it only changes on rare fuse events)
@@ -91,7 +91,7 @@ inline int grid_for(long long n, int tpb, int maxb = 4096) {
 struct Timed {   // RAII-free helper: begin/end a timed kernel class
   sz_ctx* c; int k; size_t idx = (size_t)-1; hipStream_t st;
   Timed(sz_ctx* c_, int k_, hipStream_t st_ = nullptr) : c(c_), k(k_), st(st_ ? st_ : c_->stream) {
-    if (!c->profile) return;
+    if (!(c->pmask >> k & 1u)) return;
     if (c->ev_used == c->evs.size()) {
       EvPair e; e.k = k; (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); c->evs.push_back(e);
     }
@@ -122,7 +122,7 @@ int sync_and_check(sz_ctx* c, int* cnt_out = nullptr) {
   HIPCHK(c, hipMemcpyAsync(h, c->S.cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream2));
-  if (c->profile) resolve_events(c);
+  if (c->pmask) resolve_events(c);
   c->hostM = h[C_M]; c->hostN = h[C_N];
   if (cnt_out) memcpy(cnt_out, h, sizeof(h));
   if (h[C_ERR]) {
@@ -747,7 +747,11 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   return sync_and_check(c);
 }
 
-int sz_profile_enable(sz_ctx* c, int32_t on) { if (!c) return SZ_E_ARG; c->profile = on != 0; return SZ_OK; }
+int sz_profile_enable(sz_ctx* c, int32_t on) {
+  if (!c) return SZ_E_ARG;
+  c->pmask = on == 1 ? ~0u : on > 1 ? (unsigned)on >> 1 : 0u;
+  return SZ_OK;
+}
 int sz_profile_reset(sz_ctx* c) {
   if (!c) return SZ_E_ARG;
   for (int k = 0; k < NK; k++) { c->kms[k] = 0; c->kl[k] = 0; }

@@ -365,8 +365,10 @@ class World:
         self.run(1, tstep, dt, coupling_dt, collisions_on, coupling_on)
 
     # ------------------------------------------------------------------ measurement
-    def profile(self, on=True):
-        self._chk(self.L.sz_profile_enable(self.h, int(on))); self._chk(self.L.sz_profile_reset(self.h))
+    def profile(self, on=True, only=None):
+        """event-time the kernel classes (all, or the one named `only`, e.g. "narrow") from now on."""
+        mode = (2 << capi.KERNEL_CLASS_NAMES.index(only)) if (on and only) else int(bool(on))
+        self._chk(self.L.sz_profile_enable(self.h, mode)); self._chk(self.L.sz_profile_reset(self.h))
 
     def kernel_times(self):
         out = {}
