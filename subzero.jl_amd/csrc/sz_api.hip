@@ -20,6 +20,10 @@ constexpr int K_NARROW_LARGE = SZ_K_COUNT;
 #ifndef NARROW_G
 #define NARROW_G 8
 #endif
+#ifndef NARROW_KC0          // working set of the first narrow variant: crossings, region points
+#define NARROW_KC0 8
+#define NARROW_RC0 16
+#endif
 
 struct EvPair { int k; hipEvent_t a, b; };
 
@@ -55,6 +59,7 @@ struct sz_ctx {
   bool overlap_forcing = false;   // SZ_OVERLAP=1: forcings on a second stream (measured: no gain at 10k-100k floes, the
                                   // forcing workgroups delay the latency-bound collision kernels; kept for tuning)
   int max_ring = 0, max_elem_ring = 5, max_ring_tiled = 0;   // largest ring sizes (host knowledge: which narrow variants can be needed)
+  int narrow_grid0 = 0;
   int dbg = 0;   // SZ_DEBUG bits: timing experiments only (1 skip contact rows, 2 skip direction check, 4 skip clip)
 };
 
@@ -255,7 +260,18 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo) {
   {
     Timed t(c, SZ_K_NARROW);
     constexpr int G = NARROW_G, TPB = 64;
-    hipLaunchKernelGGL((sz_k_narrow<G, NARROW_CAP0, 12, 48, 4, TPB, 0, 0>), dim3(grid_for(capItems, TPB / G, 1536)), dim3(TPB), 0,
+    // 160 VGPRs (3 wavefronts per SIMD) and 16 KB of LDS per workgroup: 10 workgroups = 80 items in flight per CU
+    auto kern = sz_k_narrow<G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3>;
+    int& grid = c->narrow_grid0;
+    if (grid == 0) {       // as many workgroups as the chip holds at once, so that every one of them runs the same number of rounds
+      int per_cu = 0, cus = 0;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, TPB, 0);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+      grid = per_cu > 0 && cus > 0 ? per_cu * cus : 2048;
+      if (const char* e = getenv("SZ_NARROW_GRID")) { int v = atoi(e); if (v > 0) grid = v; }
+      if (getenv("SZ_VERBOSE")) fprintf(stderr, "[subzero-hip] narrow: %d workgroups per CU x %d CUs\n", per_cu, cus);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid_for(capItems, TPB / G, grid)), dim3(TPB), 0,
                        c->stream, S, c->P, dt, ffmo, fdmo, c->dbg);
     t.end();
   }

@@ -67,6 +67,11 @@ struct GroupMem {
   uint8_t cfl[KC], rfl[KC], uniq[KC];
   int8_t ecode[RC];                          // many-intersect per-edge class
   uint8_t ea[CAP], eb[CAP];                  // edges of a / b that reach into the overlap box
+  // per-item scalars live here rather than in registers across the clips (the kernel's register
+  // budget decides how many items the chip holds in flight):
+  double kin[14];                            // i: cx cy u v xi, j: cx cy u v xi, area_i h_i area_j h_j
+  double dlv[RM], dxv[RM], dyv[RM];          // per kept region: contact length and force direction
+  int8_t keep[RM];
   int nraw, nx, nreg[2], flag, err, ntracefail, nea, neb;
 };
 
@@ -548,14 +553,15 @@ struct Body {          // kinematics of one side of a contact
 enum { ITEM_PAIR = 0, ITEM_OPEN = 1, ITEM_SOLID = 2 };
 enum { IT_FUSE = 1, IT_REMOVE = 2, IT_RETRY = 4 };
 
+enum { KIN_I = 0, KIN_J = 5, KIN_AREA_I = 10, KIN_H_I = 11, KIN_AREA_J = 12, KIN_H_J = 13 };   // GroupMem::kin
+
 struct ItemCtx {
   int mode;            // ITEM_PAIR: floe-floe; ITEM_OPEN: open boundary; ITEM_SOLID: collision/moving boundary, topography
   double E, nu, mu; int dt; int dbg;
-  double area_i, area_j, h_i, h_j;
   double max_overlap;  // floe_floe_max_overlap (pairs) or floe_domain_max_overlap (elements)
   int elem_dir;        // -1 floe-floe / topography; else SZ_NORTH.. for _normal_direction_correct!
   double elem_val;
-  Body bi, bj;
+  int rigid_j;         // 1: boundary/topography: the velocity of side j is (u, v) everywhere
 };
 
 // One work item, start to finish: floe_floe_interaction! (collisions.jl:347-408) or
@@ -571,15 +577,14 @@ template <int G, class MEM>
 SZ_DEV int collide_item(MEM& m, int gl, int na, int oa, int nb, int ob, const Box& ba, const Box& bb, const ItemCtx& cx_,
                         double* out, int max_rows, int& flags, Stamps& st) {
   constexpr int RM = MEM::RMAXV;
-  int keep[RM]; int nkeep = 0, nrows = 0;
-  double dlv[RM], dxv[RM], dyv[RM];
+  int nkeep = 0, nrows = 0;
   double force_factor = 0.0;
   flags = 0;
   for (int q = -1; q < nkeep; q++) {
-    const int r = q < 0 ? 0 : keep[q];
+    const int r = q < 0 ? 0 : m.keep[q];
     const double area = q < 0 ? 0.0 : m.rarea[0][r];
-    const double dl = q < 0 ? 0.0 : dlv[q];
-    double dirx = q < 0 ? 0.0 : dxv[q], diry = q < 0 ? 0.0 : dyv[q];
+    const double dl = q < 0 ? 0.0 : m.dlv[q];
+    double dirx = q < 0 ? 0.0 : m.dxv[q], diry = q < 0 ? 0.0 : m.dyv[q];
     const bool check = q >= 0 && area != 0 && dl > 0.1 && !(cx_.dbg & 2);
     if (q < 0 || check) clip<G>(m, gl, dirx, diry, na, oa, nb, ob, q < 0 ? 0 : 1, ba, bb, st);
     if (q < 0) {
@@ -587,11 +592,13 @@ SZ_DEV int collide_item(MEM& m, int gl, int na, int oa, int nb, int ob, const Bo
       const int nreg = m.nreg[0];
       double total = 0.0, amax = 0.0;
       for (int t = 0; t < nreg; t++) { double a = m.rarea[0][t]; total += a; if (a > amax) amax = a; }
+      const double area_i = m.kin[KIN_AREA_I], h_i = m.kin[KIN_H_I];
       if (cx_.mode == ITEM_PAIR) {
         if (!(total > 0)) break;
-        double r1 = total / cx_.area_i, r2 = total / cx_.area_j;
+        const double area_j = m.kin[KIN_AREA_J], h_j = m.kin[KIN_H_J];
+        double r1 = total / area_i, r2 = total / area_j;
         if ((r1 > r2 ? r1 : r2) > cx_.max_overlap) { flags |= IT_FUSE; break; }
-        double ih = cx_.h_i, ir = sqrt(cx_.area_i), jh = cx_.h_j, jr = sqrt(cx_.area_j);
+        double ih = h_i, ir = sqrt(area_i), jh = h_j, jr = sqrt(area_j);
         if (ir > 1e5 || jr > 1e5) force_factor = cx_.E * (ih < jh ? ih : jh) / (ir < jr ? ir : jr);
         else force_factor = cx_.E * (ih * jh) / (ih * jr + jh * ir);
       } else if (cx_.mode == ITEM_OPEN) {
@@ -599,8 +606,8 @@ SZ_DEV int collide_item(MEM& m, int gl, int na, int oa, int nb, int ob, const Bo
         break;
       } else {
         if (!(amax > 0)) break;
-        if (amax / cx_.area_i > cx_.max_overlap) { flags |= IT_REMOVE; break; }
-        force_factor = cx_.E * cx_.h_i / sqrt(cx_.area_i);
+        if (amax / area_i > cx_.max_overlap) { flags |= IT_REMOVE; break; }
+        force_factor = cx_.E * h_i / sqrt(area_i);
       }
       if (cx_.dbg & 1) break;
       STAMP(st, 12);
@@ -618,12 +625,13 @@ SZ_DEV int collide_item(MEM& m, int gl, int na, int oa, int nb, int ob, const Bo
       if (nip >= 2) {
         int n1 = na - 1, n2 = nb - 1;
         double min_area = (double)((n1 < n2 ? n1 : n2) * 100) / 1.75;
-        for (int t = 0; t < nreg; t++) if (!(m.rarea[0][t] < min_area)) keep[nkeep++] = t;
+        for (int t = 0; t < nreg; t++) if (!(m.rarea[0][t] < min_area)) { if (gl == 0) m.keep[nkeep] = (int8_t)t; nkeep++; }
       }
+      gsync();
       // calc_normal_force up to the direction check, for every kept region (the direction-check
       // clips overwrite the crossing arrays, so all matching happens here)
       for (int w = 0; w < nkeep; w++) {
-        int rr = keep[w];
+        int rr = m.keep[w];
         const double* rx = &m.reg[0][0][m.roff[0][rr]]; const double* ry = &m.reg[0][1][m.roff[0][rr]];
         int nr = m.roff[0][rr + 1] - m.roff[0][rr];
         double ddx = 0.0, ddy = 0.0, ddl = 0.0;
@@ -639,8 +647,9 @@ SZ_DEV int collide_item(MEM& m, int gl, int na, int oa, int nb, int ob, const Bo
           }
           gsync();
         }
-        dlv[w] = ddl; dxv[w] = ddx; dyv[w] = ddy;
+        if (gl == 0) { m.dlv[w] = ddl; m.dxv[w] = ddx; m.dyv[w] = ddy; }
       }
+      gsync();
       STAMP(st, 8);
       continue;
     }
@@ -670,7 +679,8 @@ SZ_DEV int collide_item(MEM& m, int gl, int na, int oa, int nb, int ob, const Bo
     if (cx_.elem_dir == 2 && px >= cx_.elem_val) fyn = 0.0;
     if (cx_.elem_dir == 3 && px <= cx_.elem_val) fyn = 0.0;
     // calc_friction_forces (collisions.jl:243-283)
-    const Body& bi = cx_.bi; const Body& bj = cx_.bj;
+    const Body bi{ m.kin[KIN_I], m.kin[KIN_I + 1], m.kin[KIN_I + 2], m.kin[KIN_I + 3], m.kin[KIN_I + 4], 0 };
+    const Body bj{ m.kin[KIN_J], m.kin[KIN_J + 1], m.kin[KIN_J + 2], m.kin[KIN_J + 3], m.kin[KIN_J + 4], cx_.rigid_j };
     double G_ = cx_.E / (2 * (1 + cx_.nu));
     double nnorm = sqrt(fxn * fxn + fyn * fyn);
     double iu = bi.u + bi.xi * (px - bi.cx), iv = bi.v + bi.xi * (py - bi.cy);

@@ -555,8 +555,9 @@ __global__ void sz_k_elem_fill(State S) {
 // ============================================================================ narrow phase (A4-A10)
 // items [0, P): floe-floe pairs; [P, P+Q): floe-element items.  SMALL kernels take the items
 // whose rings both fit LO..CAP points.
-template <int G, int CAP, int KC, int RC, int RM, int TPB, int LO, int CLS>
-__global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, double ff_max_overlap, double fd_max_overlap, int dbg) {
+// WPE: wavefronts per SIMD the kernel is compiled for (register budget 512 / WPE)
+template <int G, int CAP, int KC, int RC, int RM, int TPB, int LO, int CLS, int WPE = 1>
+__global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int dt, double ff_max_overlap, double fd_max_overlap, int dbg) {
   constexpr int GPB = TPB / G;
   static_assert(4 * KC <= 2 * RC, "raw crossing slots alias reg[1]");
   if (CLS > 0 && S.cnt[C_ITEMCLASS] < CLS) return;   // no item needs this (larger) variant this step
@@ -589,22 +590,27 @@ __global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, do
     gsync();
     for (int q = gl; q < na; q += G) { m.ax[q] = S.vx[ao + q]; m.ay[q] = S.vy[ao + q]; }
     for (int q = gl; q < nb; q += G) { m.bx[q] = bxs[bo + q]; m.by[q] = bys[bo + q]; }
+    const int ekind = is_pair ? 0 : S.ekind[e];
+    for (int q = gl; q < 14; q += G) {          // the item's scalars, one lane each
+      const int c = q < 10 ? q % 5 : 5 + (q & 1);                  // cx cy u v xi | area height
+      const bool side_j = q < 10 ? q >= 5 : q >= 12;
+      const double* col = c == 0 ? S.cx : c == 1 ? S.cy : c == 2 ? S.u : c == 3 ? S.v : c == 4 ? S.xi : c == 5 ? S.area : S.height;
+      double val;
+      if (!side_j) val = col[i];
+      else if (is_pair) val = col[j];
+      else val = (ekind == 3 && c == 2) ? S.eu[e] : (ekind == 3 && c == 3) ? S.ev[e] : 0.0;   // a wall / topography: rigid (u, v)
+      m.kin[q] = val;
+    }
     gsync();
     const int oa = S.osign[i], ob = is_pair ? S.osign[j] : S.eosign[e];
     STAMP(st, 0);
     ItemCtx ic;
     ic.E = P.E; ic.nu = P.nu; ic.mu = P.mu; ic.dt = dt; ic.dbg = dbg;
-    ic.area_i = S.area[i]; ic.h_i = S.height[i];
-    ic.bi = Body{ S.cx[i], S.cy[i], S.u[i], S.v[i], S.xi[i], 0 };
     if (is_pair) {
-      ic.mode = ITEM_PAIR; ic.area_j = S.area[j]; ic.h_j = S.height[j]; ic.max_overlap = ff_max_overlap;
-      ic.elem_dir = -1; ic.elem_val = 0.0;
-      ic.bj = Body{ S.cx[j], S.cy[j], S.u[j], S.v[j], S.xi[j], 0 };
+      ic.mode = ITEM_PAIR; ic.max_overlap = ff_max_overlap; ic.elem_dir = -1; ic.elem_val = 0.0; ic.rigid_j = 0;
     } else {
-      int kind = S.ekind[e];
-      ic.mode = kind == 0 ? ITEM_OPEN : ITEM_SOLID; ic.area_j = 0.0; ic.h_j = 0.0; ic.max_overlap = fd_max_overlap;
-      ic.elem_dir = e < 4 ? e : -1; ic.elem_val = S.eval[e];
-      ic.bj = Body{ 0.0, 0.0, kind == 3 ? S.eu[e] : 0.0, kind == 3 ? S.ev[e] : 0.0, 0.0, 1 };
+      ic.mode = ekind == 0 ? ITEM_OPEN : ITEM_SOLID; ic.max_overlap = fd_max_overlap;
+      ic.elem_dir = e < 4 ? e : -1; ic.elem_val = S.eval[e]; ic.rigid_j = 1;
     }
     int nrows = 0, flags = 0;
     double* out = S.it_rows + (size_t)item * ROWS_PER_ITEM * 5;
@@ -627,9 +633,6 @@ __global__ void __launch_bounds__(TPB) sz_k_narrow(State S, Params P, int dt, do
   gsync();
   if (gl == 0 && m.err) atomicOr(&S.cnt[C_ERR], m.err);
   if (gl == 0 && m.ntracefail) atomicAdd(&S.cnt[C_TRACE_FAIL], m.ntracefail);
-#ifdef SZ_STAMPS
-  (void)0;
-#endif
 }
 
 constexpr int NARROW_CAP0 = 20, NARROW_CAP1 = 32, NARROW_CAP2 = 128;   // ring points per variant

@@ -29,7 +29,7 @@ enum {
   C_TRACE_FAIL,
   C_NOWN,         // floes this context integrates (== C_N unless tiled: owned floes come first)
   C_NHALO,
-  C_ITEMCLASS,    // largest narrow-phase size class among this step's items   // traces abandoned by the guard (diagnostic, cumulative)
+  C_ITEMCLASS,    // largest narrow-phase size class among this step's items
   C_COUNT = 32
 };
 
