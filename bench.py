@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--floes", type=int, default=10000, help="floes per GPU")
     ap.add_argument("--total-floes", type=int, default=0, help="fix the job size instead (strong scaling)")
+    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs3", "configs4"],
+                    help="BASELINE.json configs[k]: 1 = periodic box + uniform flow (the metric's config, default); 2 = "
+                         "converge/diverge flow; 3 = four collision walls + topography, strait flow; 4 = 25 %% concentration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-tiled", action="store_true", help="run the halo/RCCL path even with one rank")
     args = ap.parse_args()
@@ -108,7 +111,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     n_total = args.total_floes if args.total_floes > 0 else args.floes * world
-    cfg = fields.make_config(n_floes=n_total, seed=12345)
+    wl = {"configs1": dict(seed=12345), "configs2": dict(seed=12346, ocean="converge_diverge"),
+          "configs3": dict(seed=12345, walls=True, topography=True, ocean="strait"),
+          "configs4": dict(seed=12347, concentration=0.25)}[args.workload]
+    cfg = fields.make_config(n_floes=n_total, **wl)
     coupling_dt = 1
     if world == 1 and not args.force_tiled:
         hw = fields.build_world(subzero_jl_amd.World(local), cfg)
@@ -156,7 +162,7 @@ def main():
         # HBM bytes per launch of the narrow kernel from the PMC passes committed under profiles/
         # (r01_pmc_fetch_size.csv, r01_pmc_write_size.csv: FETCH_SIZE 5255 KB, WRITE_SIZE 802 KB per launch on the
         # default workload; gfx950 correction: 2 x FETCH_SIZE + WRITE_SIZE).  Only valid for that workload.
-        traffic = (2 * 5255.0 + 802.3) * 1024 if (world == 1 and cfg["n_floes"] == 10000) else None
+        traffic = (2 * 5255.0 + 802.3) * 1024 if (world == 1 and cfg["n_floes"] == 10000 and args.workload == "configs1") else None
         out = {
             "metric": "floe_steps_per_sec", "value": cfg["n_floes"] * args.steps / el, "unit": "floe-steps/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
@@ -164,7 +170,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{'configs[1]' if world == 1 else 'configs[1] field x ' + str(world) + ' GPUs (tiled, ghost-floe halo)'}: {cfg['n_floes']} random-polygon floes (8-16 verts), doubly periodic "
                                    f"box {cfg['L'] / 1e3:.0f} km, uniform_flow ocean 0.1 m/s, collisions + one-way "
-                                   f"coupling every step + rigid-body update, dt={cfg['dt']} s",
+                                   f"coupling every step + rigid-body update, dt={cfg['dt']} s" if args.workload == "configs1" else
+                                   f"configs[{args.workload[-1]}]-style field ({wl}): {cfg['n_floes']} floes, box {cfg['L'] / 1e3:.0f} km, "
+                                   f"boundaries {cfg['kinds'][0]}, {len(cfg['topography'])} topography elements, dt={cfg['dt']} s",
                        "n_floes": cfg["n_floes"], "seed": cfg["seed"], "coupling_dt": coupling_dt,
                        "tiles": 1 if world == 1 else world},
             "roofline": {"bound": "hbm", "kernel": "sz_k_narrow<8,20,12,48,4,64,0,0>", "achieved": achieved,
@@ -175,7 +183,7 @@ def main():
             "kernel_ms_per_step": {k: (v[0] / nb) for k, v in kt_all.items()},
             "kernel_ms_per_step_note": f"separate untimed pass of {nb} steps with all kernel classes event-timed",
             "counts": {k: st[k] for k in ("M", "N", "n_ghosts", "n_pairs", "n_pair_rows", "n_elem_rows",
-                                           "n_inter_rows", "n_ring_points", "n_sub_points", "n_trace_fail")},
+                                           "n_inter_rows", "n_ring_points", "n_sub_points", "n_trace_fail", "n_retry")},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg)

@@ -93,6 +93,7 @@ typedef struct {
   int64_t warn_height, warn_force, warn_vel, warn_xi;   /* update_floe.jl guards             */
   int64_t n_trace_fail;         /* clip traces abandoned (self-intersecting input / round-off), cumulative */
   int64_t n_halo;               /* halo floes received in the last tiled step */
+  int64_t n_retry;              /* narrow-phase items redone by the largest kernel variant (working set overflow), cumulative */
 } sz_stats;
 
 /* kernel classes for sz_kernel_time_ms */

@@ -492,7 +492,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
     if ((rc = dalloc(c, dcols[k], S.capM, c->allocs))) return rc;
     if (hcols[k]) H2D(*dcols[k], hcols[k], M, double);
   }
-  DA(sa, 4 * S.capM); DA(si, 4 * S.capM); DA(strain, 4 * S.capM); DA(mot, 4 * S.capM);
+  DA(sa, 4 * S.capM); DA(si, 4 * S.capM); DA(strain, 4 * S.capM); DA(mot, 4 * S.capM); DA(trig, 2 * S.capM);
   if (f->stress_accum) H2D(S.sa, f->stress_accum, 4 * M, double);
   if (f->stress_instant) H2D(S.si, f->stress_instant, 4 * M, double);
   if (f->strain) H2D(S.strain, f->strain, 4 * M, double);
@@ -561,6 +561,7 @@ int sz_get_stats(sz_ctx* c, sz_stats* out) {
   out->warn_height = h[C_WARN_H]; out->warn_force = h[C_WARN_F]; out->warn_vel = h[C_WARN_V]; out->warn_xi = h[C_WARN_XI];
   out->n_trace_fail = h[C_TRACE_FAIL];
   out->n_halo = h[C_NHALO];
+  out->n_retry = h[C_NRETRY];
   return SZ_OK;
 }
 

@@ -328,18 +328,21 @@ SZ_DEV void clip(MEM& m, int gl, double ox, double oy, int na, int oa, int nb, i
                          : (ax0 <= bb.x0 && bb.x1 <= ax1 && ay0 <= bb.y0 && bb.y1 <= ay1) && ring_inside_off(pbx, pby, nb, pax, pay, na, ox, oy);
     if (a_in_b || b_in_a) {
       int n = a_in_b ? na : nb;
-      if (n > RC) { if (gl == 0) m.err |= ERR_CAP_REGION; }
+      double sa, ccx, ccy;
+      if (buf == 0) {
+        // contact clip (ox = oy = 0): the region IS the contained ring.  Without crossing points it
+        // can only contribute its area (fuse / remove tests), never a force row (collisions.jl:156-170),
+        // so it is measured where it lies instead of being copied into the region buffer.
+        ring_area_centroid(a_in_b ? pax : pbx, a_in_b ? pay : pby, n, sa, ccx, ccy);
+        if (gl == 0) { m.nreg[0] = 1; m.roff[0][1] = 0; m.rarea[0][0] = fabs(sa); m.rcx[0] = ccx; m.rcy[0] = ccy; }
+      } else if (n > RC) { if (gl == 0) m.err |= ERR_CAP_REGION; }
       else {
         for (int i = gl; i < n; i += G) {
           rgx[i] = a_in_b ? pax[i] + ox : pbx[i]; rgy[i] = a_in_b ? pay[i] + oy : pby[i];
         }
         gsync();
-        double sa, ccx, ccy;
         ring_area_centroid(rgx, rgy, n, sa, ccx, ccy);
-        if (gl == 0) {
-          m.nreg[buf] = 1; m.roff[buf][1] = (int16_t)n; m.rarea[buf][0] = fabs(sa);
-          if (buf == 0) { m.rcx[0] = ccx; m.rcy[0] = ccy; }
-        }
+        if (gl == 0) { m.nreg[buf] = 1; m.roff[buf][1] = (int16_t)n; m.rarea[buf][0] = fabs(sa); }
       }
     }
     gsync();

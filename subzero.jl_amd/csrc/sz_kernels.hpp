@@ -97,6 +97,8 @@ __global__ void sz_k_osign(State S, int first) {
     double x0 = __builtin_inf(), x1 = -__builtin_inf(), y0 = __builtin_inf(), y1 = -__builtin_inf();
     for (int q = 0; q < n; q++) { x0 = fmin(x0, S.vx[o + q]); x1 = fmax(x1, S.vx[o + q]); y0 = fmin(y0, S.vy[o + q]); y1 = fmax(y1, S.vy[o + q]); }
     S.bbx0[i] = x0; S.bbx1[i] = x1; S.bby0[i] = y0; S.bby1[i] = y1;
+    double al = S.alpha[i];
+    S.trig[2 * i] = cos(al); S.trig[2 * i + 1] = sin(al);
   }
 }
 __global__ void sz_k_elem_osign(State S) {
@@ -571,7 +573,28 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
 #ifdef SZ_STAMPS
   st.on = (CLS == 0 && blockIdx.x == (unsigned)(dbg >> 8) && threadIdx.x == 0); st.log = S.stamps + 1;
 #endif
-  for (int t = blockIdx.x * GPB + gi; t < nitems; t += gridDim.x * GPB) {
+  // The one-item-per-wavefront variant mostly looks for the few items meant for it: its lanes test 64
+  // items at a time and the wavefront then works the flagged ones off one by one.
+  constexpr bool SCAN = (G == 64 && TPB == 64);
+  constexpr int STRIDE = SCAN ? 64 : GPB;
+  for (int t0 = blockIdx.x * STRIDE; t0 < nitems; t0 += gridDim.x * STRIDE) {
+   unsigned long long todo = 1;
+   if (SCAN) {
+     const int tt = t0 + (int)threadIdx.x;
+     bool want = false;
+     if (tt < nitems) {
+       int i_, nb_, item_;
+       if (tt < npairs) { i_ = S.pair_i[tt]; int j_ = S.pair_j[tt]; nb_ = S.voff[j_ + 1] - S.voff[j_]; item_ = tt; }
+       else { int q = tt - npairs; i_ = S.el_floe[q]; int e_ = S.el_elem[q]; nb_ = S.eoff[e_ + 1] - S.eoff[e_]; item_ = S.capPairs + q; }
+       int na_ = S.voff[i_ + 1] - S.voff[i_];
+       want = (na_ > nb_ ? na_ : nb_) > LO || (S.it_flags[item_] & IT_RETRY);
+     }
+     todo = __ballot(want);
+   }
+   while (todo) {
+    int t;
+    if (SCAN) { t = t0 + __ffsll((long long)todo) - 1; todo &= todo - 1; }
+    else { todo = 0; t = t0 + gi; if (t >= nitems) break; }
     const bool is_pair = t < npairs;
     int i, j = -1, e = -1, item;
     if (is_pair) { i = S.pair_i[t]; j = S.pair_j[t]; item = t; }
@@ -622,13 +645,14 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     if (CLS < 2 && (m.err & CAPBITS)) {                // working set too small: let the next variant redo the item
       nrows = 0; flags = IT_RETRY;
       gsync();
-      if (gl == 0) { m.err &= ~CAPBITS; atomicMax(&S.cnt[C_ITEMCLASS], 2); }   // the largest variant retries
+      if (gl == 0) { m.err &= ~CAPBITS; atomicMax(&S.cnt[C_ITEMCLASS], 2); atomicAdd(&S.cnt[C_NRETRY], 1); }   // the largest variant retries
     }
     if (gl == 0) { S.it_nrows[item] = nrows; S.it_flags[item] = flags; }
     STAMP(st, 11);
 #ifdef SZ_STAMPS
     if (st.on) { if (nrows > 0) { S.stamps[0] = st.n; st.on = false; } else { st.n = 0; st.t0 = clock64(); } }
 #endif
+   }
   }
   gsync();
   if (gl == 0 && m.err) atomicOr(&S.cnt[C_ERR], m.err);
@@ -832,8 +856,8 @@ __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
   int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
   double cturn = cos(P.turn), sturn = sin(P.turn);
   for (int i = blockIdx.x * wpb + wid; i < N; i += gridDim.x * wpb) {
-    double alpha = S.alpha[i], cxf = S.cx[i], cyf = S.cy[i], u = S.u[i], v = S.v[i], xi = S.xi[i];
-    double ca = cos(alpha), sa = sin(alpha);
+    double cxf = S.cx[i], cyf = S.cy[i], u = S.u[i], v = S.v[i], xi = S.xi[i];
+    double ca = S.trig[2 * i], sa = S.trig[2 * i + 1];   // cos(alpha), sin(alpha)
     double ma_ratio = S.mass[i] / S.area[i];
     int o = S.soff[i], ns = S.soff[i + 1] - o;
     double tx = 0, ty = 0, ttrq = 0, th = 0; int np = 0;
@@ -928,7 +952,9 @@ __global__ void sz_k_integrate(State S, Params P, int dt, int apply_frc) {
     double dx = 1.5 * dt * u - 0.5 * dt * S.p_dxdt[i];
     double dy = 1.5 * dt * v - 0.5 * dt * S.p_dydt[i];
     double da = 1.5 * dt * xi - 0.5 * dt * S.p_dalphadt[i];
-    S.alpha[i] += da;
+    const double al = S.alpha[i] + da;
+    S.alpha[i] = al;
+    S.trig[2 * i] = cos(al); S.trig[2 * i + 1] = sin(al);   // for the forcing kernel (32 lanes per floe: not the place for it)
     S.mot[i * 4 + 0] = dx; S.mot[i * 4 + 1] = dy; S.mot[i * 4 + 2] = cos(da); S.mot[i * 4 + 3] = sin(da);
     S.p_dxdt[i] = u; S.p_dydt[i] = v; S.p_dalphadt[i] = xi;
     double dudt = (S.fxOA[i] + cfx) / mass, dvdt = (S.fyOA[i] + cfy) / mass;

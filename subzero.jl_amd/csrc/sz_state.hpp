@@ -30,6 +30,7 @@ enum {
   C_NOWN,         // floes this context integrates (== C_N unless tiled: owned floes come first)
   C_NHALO,
   C_ITEMCLASS,    // largest narrow-phase size class among this step's items
+  C_NRETRY,       // items handed on to the largest narrow variant (diagnostic, cumulative)
   C_COUNT = 32
 };
 
@@ -89,6 +90,7 @@ struct State {
   int* blk;
   // ---- motion scratch (integrator)
   double* mot;               // 4 per floe: dx, dy, cos, sin
+  double* trig;              // 2 per floe: cos(alpha), sin(alpha), kept current by the upload and the integrator
   long long* stamps;         // diagnostic build (-DSZ_STAMPS) only
 };
 
