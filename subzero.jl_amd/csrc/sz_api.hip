@@ -115,7 +115,9 @@ void resolve_events(sz_ctx* c) {
 }
 
 // exclusive scan of in[0..n) into out[0..n], n = cnt[ci] + add; total also to cnt[co]
+constexpr int SCAN_ONE_MAX = 1 << 13;     // up to here a scan is one single-workgroup launch instead of three (measured: wins below ~5k floes)
 void scan(sz_ctx* c, const int* in, int* out, int cap, int ci, int add, int co) {
+  if (cap <= SCAN_ONE_MAX) { hipLaunchKernelGGL(sz_k_scan_one, dim3(1), dim3(SCAN_B), 0, c->stream, in, out, c->S.cnt, ci, add, co); return; }
   int nb = grid_for(cap, SCAN_B, 1 << 20);
   hipLaunchKernelGGL(sz_k_scan1, dim3(nb), dim3(SCAN_B), 0, c->stream, in, out, c->S.blk, c->S.cnt, ci, add);
   hipLaunchKernelGGL(sz_k_scan2, dim3(1), dim3(SCAN_B), 0, c->stream, c->S.blk, c->S.cnt, ci, add);
@@ -212,9 +214,12 @@ void stage_ghosts(sz_ctx* c, bool in_step = false) {
   Timed t(c, SZ_K_GHOSTS);
   int gN = grid_for(S.capM, 256), nb = grid_for(S.capM, SCAN_B, 1 << 20);
   hipLaunchKernelGGL(sz_k_ghost_flag, dim3(gN), dim3(256), 0, c->stream, S, in_step ? 1 : 0);
-  hipLaunchKernelGGL(sz_k_scan4_1, dim3(nb), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.gblk4, S.cnt, C_N);
-  hipLaunchKernelGGL(sz_k_scan4_2, dim3(1), dim3(SCAN_B), 0, c->stream, S.gblk4, S.cnt, C_N);
-  hipLaunchKernelGGL(sz_k_scan4_3, dim3(nb), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.gblk4, S.cnt, C_N, S.gtot4);
+  if (S.capM <= SCAN_ONE_MAX) hipLaunchKernelGGL(sz_k_scan4_one, dim3(1), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.cnt, C_N, S.gtot4);
+  else {
+    hipLaunchKernelGGL(sz_k_scan4_1, dim3(nb), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.gblk4, S.cnt, C_N);
+    hipLaunchKernelGGL(sz_k_scan4_2, dim3(1), dim3(SCAN_B), 0, c->stream, S.gblk4, S.cnt, C_N);
+    hipLaunchKernelGGL(sz_k_scan4_3, dim3(nb), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.gblk4, S.cnt, C_N, S.gtot4);
+  }
   hipLaunchKernelGGL(sz_k_ghost_fill, dim3(grid_for(S.capM, 32, 2048)), dim3(256), 0, c->stream, S);
   if (!in_step) hipLaunchKernelGGL(sz_k_ghost_commit, dim3(1), dim3(64), 0, c->stream, S);
   t.end();

@@ -81,6 +81,23 @@ __global__ void __launch_bounds__(SCAN_B) sz_k_scan3(const int* in, int* out, co
   if (i == n - 1) { int t = o + in[i]; out[n] = t; if (co >= 0) cnt[co] = t; }
 }
 
+// The whole scan in ONE workgroup (4 elements per thread and tile): below a few thousand elements three
+// launches cost more than the work.  Same contract as scan1..3.
+__global__ void __launch_bounds__(SCAN_B) sz_k_scan_one(const int* in, int* out, int* cnt, int ci, int add, int co) {
+  __shared__ int tot;
+  const int n = (ci >= 0 ? cnt[ci] : 0) + add;
+  int carry = 0;
+  for (int base = 0; base < n; base += 4 * SCAN_B) {
+    const int i0 = base + 4 * (int)threadIdx.x;
+    int v[4], sum = 0;
+    for (int k = 0; k < 4; k++) { v[k] = i0 + k < n ? in[i0 + k] : 0; sum += v[k]; }
+    int ex = block_exclusive_scan(sum, &tot) + carry;
+    for (int k = 0; k < 4; k++) { if (i0 + k < n) out[i0 + k] = ex; ex += v[k]; }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) { out[n] = carry; if (co >= 0) cnt[co] = carry; }
+}
+
 // ============================================================================ small utilities
 __global__ void sz_k_zero_int(int* p, const int* cnt, int ci, int add) {
   int n = (ci >= 0 ? cnt[ci] : 0) + add;
@@ -178,6 +195,21 @@ __global__ void __launch_bounds__(SCAN_B) sz_k_scan4_3(const int4* in, int4* out
   int4 o = add4(out[i], blk[blockIdx.x]);
   out[i] = o;
   if (i == n - 1) tot4[0] = add4(o, in[i]);
+}
+// one-workgroup variant of scan4_1..3 (see sz_k_scan_one)
+__global__ void __launch_bounds__(SCAN_B) sz_k_scan4_one(const int4* in, int4* out, const int* cnt, int ci, int4* tot4) {
+  __shared__ int4 tot;
+  const int n = cnt[ci];
+  int4 carry = make_int4(0, 0, 0, 0);
+  for (int base = 0; base < n; base += 2 * SCAN_B) {
+    const int i0 = base + 2 * (int)threadIdx.x;
+    int4 v0 = i0 < n ? in[i0] : make_int4(0, 0, 0, 0), v1 = i0 + 1 < n ? in[i0 + 1] : make_int4(0, 0, 0, 0);
+    int4 ex = add4(block_exclusive_scan4(add4(v0, v1), &tot), carry);
+    if (i0 < n) out[i0] = ex;
+    if (i0 + 1 < n) out[i0 + 1] = add4(ex, v0);
+    carry = add4(carry, tot);
+  }
+  if (threadIdx.x == 0) tot4[0] = carry;
 }
 
 // does ring i reach strictly beyond the wall in the direction that needs a ghost?  This is
