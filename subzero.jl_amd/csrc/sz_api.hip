@@ -297,7 +297,7 @@ void stage_reduce(sz_ctx* c, int mirror, int n_init, int dt) {
   State& S = c->S;
   Timed t(c, SZ_K_REDUCE);
   int gM = grid_for(S.capM, 256);
-  hipLaunchKernelGGL(sz_k_inter_fill, dim3(grid_for(S.capM, 128)), dim3(128), 0, c->stream, S, mirror, n_init);
+  hipLaunchKernelGGL(sz_k_inter_fill, dim3(grid_for(S.capM, 128 / IF_G, 16384)), dim3(128), 0, c->stream, S, mirror, n_init);
   if (mirror && c->any_moving) hipLaunchKernelGGL(sz_k_update_boundaries, dim3(1), dim3(64), 0, c->stream, S, dt);
   t.end();
 }

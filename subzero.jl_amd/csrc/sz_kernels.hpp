@@ -711,98 +711,111 @@ __global__ void sz_k_items_clear(State S) {
 }
 
 // ============================================================================ reduce (A9, A11)
-__device__ __forceinline__ int find_pair(const State& S, int i, int k) {   // index of pair (i, k), i < k; -1 if absent
-  int lo = S.out_off[i], hi = S.out_off[i + 1];
-  long long kk = S.okey[k];
-  while (lo < hi) { int mid = (lo + hi) >> 1; if (S.okey[S.pair_j[mid]] < kk) lo = mid + 1; else hi = mid; }
-  return (lo < S.out_off[i + 1] && S.pair_j[lo] == k) ? lo : -1;
-}
-
 // Interaction rows live at a fixed stride (ROWCAP rows per floe): no offsets, no scan in the step;
 // sz_download_interactions compacts them to CSR on demand.  A floe with more rows than ROWCAP
 // raises ERR_CAP_INTER.
 constexpr int ROWCAP = 32;
 
-// writes the rows of floe f -- own pairs (j asc), domain elements (N,S,E,W, topography), rows
-// mirrored from partners that come earlier in the serial order (i asc, force negated) -- at dst,
-// points shifted by (-sx, -sy).  Returns the count (clamped to cap, overflow flagged).  When
-// `st` is given it also resolves the status tag of f: tagA after the pair/domain phase
-// (collisions.jl:367,438,525), st after the mirror pass (:801-806).
-__device__ int emit_rows(const State& S, int f, double* dst, int cap, double sx, double sy, int mirror, double* over_sum,
-                         int* st, int* tagA) {
-  int c = 0; bool ovf = false;
-  auto put = [&](double idx, const double* s, double sign) {
-    if (c < cap) {
-      double* d = dst + (size_t)c * 7;
-      d[0] = idx; d[1] = s[0] * sign; d[2] = s[1] * sign; d[3] = s[2] - sx; d[4] = s[3] - sy; d[5] = 0.0; d[6] = s[4];
-      *over_sum += s[4];
-      c++;
-    } else ovf = true;
-  };
-  for (int p = S.out_off[f]; p < S.out_off[f + 1]; p++) {
-    int n = S.it_nrows[p]; const double* src = S.it_rows + (size_t)p * ROWS_PER_ITEM * 5;
-    if (st && (S.it_flags[p] & IT_FUSE)) *st = SZ_FUSE;
-    double idx = (double)(S.okey[S.pair_j[p]] + 1);
-    for (int r = 0; r < n; r++) put(idx, src + r * 5, 1.0);
-  }
-  for (int q = S.el_off[f]; q < S.el_off[f + 1]; q++) {
-    int item = S.capPairs + q; int n = S.it_nrows[item]; const double* src = S.it_rows + (size_t)item * ROWS_PER_ITEM * 5;
-    if (st && (S.it_flags[item] & IT_REMOVE)) *st = SZ_REMOVE;
-    double idx = -(double)(S.el_elem[q] + 1);
-    for (int r = 0; r < n; r++) put(idx, src + r * 5, 1.0);
-  }
-  if (tagA) *tagA = *st;
-  if (mirror) {
-    int m = S.n_in[f];
-    for (int t = 0; t < m; t++) {
-      int i = S.nb_in[(size_t)f * MAXNB + t]; int p = find_pair(S, i, f);
-      if (p < 0) continue;
-      int n = S.it_nrows[p]; const double* src = S.it_rows + (size_t)p * ROWS_PER_ITEM * 5;
-      if (st && (S.it_flags[p] & IT_FUSE)) *st = SZ_FUSE;
-      double idx = (double)(S.okey[i] + 1);
-      for (int r = 0; r < n; r++) put(idx, src + r * 5, -1.0);
+// A group of IF_G lanes per floe.  Appends the rows of floe f -- own pairs (j asc), domain elements
+// (N,S,E,W, topography), rows mirrored from partners that come earlier in the serial order (i asc,
+// force negated) -- to dst at row c, points shifted by (-sx, -sy); every lane takes one source (an
+// item), the row positions come from a prefix sum over the lanes, so the rows land in exactly the
+// serial order.  Returns the new count (clamped to cap, overflow flagged).  When `st` is given it
+// also resolves the status tag of f: tagA after the pair/domain phase (collisions.jl:367,438,525),
+// st after the mirror pass (:801-806).
+constexpr int IF_G = 8;
+__device__ __forceinline__ int emit_rows(const State& S, int lane, int f, double* dst, int c, int cap, double sx, double sy,
+                                         int mirror, bool& ovf, int* st, int* tagA) {
+  const int o0 = S.out_off[f], nown = S.out_off[f + 1] - o0;
+  const int e0 = S.el_off[f], nel = S.el_off[f + 1] - e0;
+  const int nin = mirror ? S.n_in[f] : 0;
+  const int T = nown + nel + nin;
+  const int gshift = (int)(threadIdx.x & 63) / IF_G * IF_G;
+  unsigned fuse_own = 0, rem_el = 0, fuse_in = 0;
+  for (int base = 0; base < T; base += IF_G) {
+    const int s = base + lane;
+    int item = -1, n = 0, kind = -1; double idx = 0.0, sign = 1.0;
+    if (s < nown) { item = o0 + s; idx = (double)(S.okey[S.pair_j[item]] + 1); kind = 0; }
+    else if (s < nown + nel) { int q = e0 + (s - nown); item = S.capPairs + q; idx = -(double)(S.el_elem[q] + 1); kind = 1; }
+    else if (s < T) {
+      const int i = S.nb_in[(size_t)f * MAXNB + (s - nown - nel)];
+      const int lo = S.out_off[i], hi = S.out_off[i + 1];
+      for (int q = lo; q < hi; q++) if (S.pair_j[q] == f) item = q;     // pair (i, f); absent if the Dict rule dropped it
+      idx = (double)(S.okey[i] + 1); sign = -1.0; kind = 2;
     }
+    int fl = 0;
+    if (item >= 0) { n = S.it_nrows[item]; fl = S.it_flags[item]; }
+    fuse_own |= (unsigned)(__ballot(kind == 0 && (fl & IT_FUSE)) >> gshift) & 0xffu;
+    rem_el |= (unsigned)(__ballot(kind == 1 && (fl & IT_REMOVE)) >> gshift) & 0xffu;
+    fuse_in |= (unsigned)(__ballot(kind == 2 && (fl & IT_FUSE)) >> gshift) & 0xffu;
+    int inc = n;
+    for (int d = 1; d < IF_G; d <<= 1) { int t = __shfl_up(inc, d, IF_G); if (lane >= d) inc += t; }
+    const int tot = __shfl(inc, IF_G - 1, IF_G), off = inc - n;
+    const double* src = S.it_rows + (size_t)(item < 0 ? 0 : item) * ROWS_PER_ITEM * 5;
+    for (int r = 0; r < n; r++) {
+      const int pos = c + off + r;
+      if (pos < cap) {
+        double* d = dst + (size_t)pos * 7; const double* q = src + r * 5;
+        d[0] = idx; d[1] = q[0] * sign; d[2] = q[1] * sign; d[3] = q[2] - sx; d[4] = q[3] - sy; d[5] = 0.0; d[6] = q[4];
+      } else ovf = true;
+    }
+    c = c + tot < cap ? c + tot : cap;
   }
-  if (ovf) atomicOr(&S.cnt[C_ERR], ERR_CAP_INTER);
+  if (st) {
+    if (fuse_own) *st = SZ_FUSE;
+    if (rem_el) *st = SZ_REMOVE;
+    *tagA = *st;
+    if (fuse_in) *st = SZ_FUSE;
+  }
   return c;
 }
-// mirror pass, ghost fold, torque and totals (collisions.jl:799-862), one thread per floe
-__global__ void sz_k_inter_fill(State S, int mirror, int n_init_arg) {
-  int M = S.cnt[C_M];
+// mirror pass, ghost fold, torque and totals (collisions.jl:799-862)
+__global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int n_init_arg) {
+  const int M = S.cnt[C_M];
   const int n_init = n_init_arg >= 0 ? n_init_arg : S.cnt[C_N];   // < 0: every parent on the device
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x % IF_G, gpb = blockDim.x / IF_G;
+  for (int k = blockIdx.x * gpb + threadIdx.x / IF_G; k < M; k += gridDim.x * gpb) {
     double* dst = S.inter_rows + (size_t)k * ROWCAP * 7;
-    bool is_ghost = S.ghost_id[k] != 0;
+    const bool is_ghost = S.ghost_id[k] != 0;
+    const double cx = S.cx[k], cy = S.cy[k];
     double sx = 0.0, sy = 0.0;
-    if (mirror && is_ghost && S.parent[k] < n_init) { int p = S.parent[k]; sx = S.cx[k] - S.cx[p]; sy = S.cy[k] - S.cy[p]; }
-    double over = 0.0;
+    if (mirror && is_ghost && S.parent[k] < n_init) { int p = S.parent[k]; sx = cx - S.cx[p]; sy = cy - S.cy[p]; }
+    bool ovf = false;
     int st = S.status[k], tagA = st;
-    int c = emit_rows(S, k, dst, ROWCAP, sx, sy, mirror, &over, &st, &tagA);
-    S.status[k] = st; S.tagA[k] = tagA;
-    // reset + totals (collisions.jl:747-749, 852-861); ghosts keep zero totals
-    double fx = 0.0, fy = 0.0, tq = 0.0;
-    if (mirror && k < n_init) {
-      int ng = S.ngh[k];
+    int c = emit_rows(S, lane, k, dst, 0, ROWCAP, sx, sy, mirror, ovf, &st, &tagA);
+    const bool totals = mirror && k < n_init;
+    if (totals) {                      // ghost fold (collisions.jl:830-850)
+      const int ng = S.ngh[k];
       for (int g = 0; g < ng; g++) {
-        int gf = S.gh[k * MAX_GHOSTS + g];
-        double gx = S.cx[gf] - S.cx[k], gy = S.cy[gf] - S.cy[k];
-        c += emit_rows(S, gf, dst + (size_t)c * 7, ROWCAP - c, gx, gy, mirror, &over, nullptr, nullptr);
+        const int gf = S.gh[k * MAX_GHOSTS + g];
+        c = emit_rows(S, lane, gf, dst, c, ROWCAP, S.cx[gf] - cx, S.cy[gf] - cy, mirror, ovf, nullptr, nullptr);
       }
-      double cx = S.cx[k], cy = S.cy[k];
-      for (int r = 0; r < c; r++) {
-        double* d = dst + (size_t)r * 7;
-        double xp = d[3] - cx, yp = d[4] - cy;
-        d[5] = xp * d[2] - yp * d[1];
-        fx += d[1]; fy += d[2]; tq += d[5];
-      }
-    } else if (!mirror) {
-      // floe_floe_interaction!/floe_domain_interaction! entry points: torque filled for convenience
-      double cx = S.cx[k], cy = S.cy[k];
-      for (int r = 0; r < c; r++) { double* d = dst + (size_t)r * 7; double xp = d[3] - cx, yp = d[4] - cy; d[5] = xp * d[2] - yp * d[1]; }
     }
-    S.inter_cnt[k] = c;
-    S.cfx[k] = fx; S.cfy[k] = fy; S.ctrq[k] = tq;
-    S.overarea[k] += over;
+    if (ovf) atomicOr(&S.cnt[C_ERR], ERR_CAP_INTER);
+    __threadfence_block();             // the rows were written by other lanes of this wavefront
+    // torque per row over the lanes; totals (collisions.jl:747-749, 852-861) and the overlap sum in row
+    // order; ghosts keep zero totals.  Without the mirror pass (floe_floe_interaction! /
+    // floe_domain_interaction! entry points) the torque is filled for convenience.
+    double fx = 0.0, fy = 0.0, tq = 0.0, over = 0.0;
+    for (int base = 0; base < c; base += IF_G) {
+      const int r = base + lane;
+      double f1 = 0.0, f2 = 0.0, t = 0.0, ov = 0.0;
+      if (r < c) {
+        double* d = dst + (size_t)r * 7;
+        f1 = d[1]; f2 = d[2]; ov = d[6];
+        if (totals || !mirror) { double xp = d[3] - cx, yp = d[4] - cy; t = xp * f2 - yp * f1; d[5] = t; }
+      }
+      const int cnt = c - base < IF_G ? c - base : IF_G;
+      for (int l = 0; l < cnt; l++) {
+        fx += __shfl(f1, l, IF_G); fy += __shfl(f2, l, IF_G); tq += __shfl(t, l, IF_G); over += __shfl(ov, l, IF_G);
+      }
+    }
+    if (lane == 0) {
+      S.status[k] = st; S.tagA[k] = tagA;
+      S.inter_cnt[k] = c;
+      S.cfx[k] = totals ? fx : 0.0; S.cfy[k] = totals ? fy : 0.0; S.ctrq[k] = totals ? tq : 0.0;
+      S.overarea[k] += over;
+    }
   }
 }
 // CSR compaction of the fixed-stride rows (sz_download_interactions only)
