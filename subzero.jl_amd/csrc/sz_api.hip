@@ -60,6 +60,7 @@ struct sz_ctx {
                                   // forcing workgroups delay the latency-bound collision kernels; kept for tuning)
   int max_ring = 0, max_elem_ring = 5, max_ring_tiled = 0;   // largest ring sizes (host knowledge: which narrow variants can be needed)
   int narrow_grid0 = 0;
+  bool tile_dirty = false;      // ghosts / halo floes of the last sz_tile_step still appended
   int dbg = 0;   // SZ_DEBUG bits: timing experiments only (1 skip contact rows, 2 skip direction check, 4 skip clip)
 };
 
@@ -124,7 +125,14 @@ void scan(sz_ctx* c, const int* in, int* out, int cap, int ci, int add, int co) 
   hipLaunchKernelGGL(sz_k_scan3, dim3(nb), dim3(SCAN_B), 0, c->stream, in, out, c->S.blk, c->S.cnt, ci, add, co);
 }
 
+// after tiled steps: forget the ghosts and halo floes of the last one (simulation.jl:138-144; N := owned)
+void tile_cleanup(sz_ctx* c) {
+  if (!c->tile_dirty) return;
+  hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 1);
+  c->tile_dirty = false;
+}
 int sync_and_check(sz_ctx* c, int* cnt_out = nullptr) {
+  tile_cleanup(c);
   int h[C_COUNT];
   HIPCHK(c, hipMemcpyAsync(h, c->S.cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -213,10 +221,11 @@ void stage_ghosts(sz_ctx* c, bool in_step = false) {
   if (!S.any_periodic_ew && !S.any_periodic_ns) return;
   Timed t(c, SZ_K_GHOSTS);
   int gN = grid_for(S.capM, 256), nb = grid_for(S.capM, SCAN_B, 1 << 20);
-  hipLaunchKernelGGL(sz_k_ghost_flag, dim3(gN), dim3(256), 0, c->stream, S, in_step ? 1 : 0);
-  if (S.capM <= SCAN_ONE_MAX) hipLaunchKernelGGL(sz_k_scan4_one, dim3(1), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.cnt, C_N, S.gtot4);
-  else {
-    hipLaunchKernelGGL(sz_k_scan4_1, dim3(nb), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.gblk4, S.cnt, C_N);
+  if (S.capM <= SCAN_ONE_MAX) {
+    hipLaunchKernelGGL(sz_k_ghost_flag, dim3(gN), dim3(256), 0, c->stream, S, in_step ? 1 : 0);
+    hipLaunchKernelGGL(sz_k_scan4_one, dim3(1), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.cnt, C_N, S.gtot4);
+  } else {
+    hipLaunchKernelGGL(sz_k_ghost_flag_scan1, dim3(nb), dim3(SCAN_B), 0, c->stream, S, in_step ? 1 : 0);
     hipLaunchKernelGGL(sz_k_scan4_2, dim3(1), dim3(SCAN_B), 0, c->stream, S.gblk4, S.cnt, C_N);
     hipLaunchKernelGGL(sz_k_scan4_3, dim3(nb), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.gblk4, S.cnt, C_N, S.gtot4);
   }
@@ -232,8 +241,15 @@ void stage_broad(sz_ctx* c, bool commit_ghosts = false) {
   hipLaunchKernelGGL(sz_k_bounds, dim3(1), dim3(1024), 0, c->stream, S, commit_ghosts ? 1 : 0);
   hipLaunchKernelGGL(sz_k_cell_build, dim3(gM), dim3(256), 0, c->stream, S);
   hipLaunchKernelGGL(sz_k_neighbors, dim3(grid_for(S.capM, NB_TPB / NB_G, 8192)), dim3(NB_TPB), 0, c->stream, S);
-  scan(c, S.n_out, S.out_off, S.capM, C_M, 0, C_NPAIRS);
-  hipLaunchKernelGGL(sz_k_pairs_fill, dim3(gM), dim3(256), 0, c->stream, S);
+  if (S.capM <= SCAN_ONE_MAX) {
+    scan(c, S.n_out, S.out_off, S.capM, C_M, 0, C_NPAIRS);
+    hipLaunchKernelGGL(sz_k_pairs_fill, dim3(gM), dim3(256), 0, c->stream, S);
+  } else {
+    int nb = grid_for(S.capM, SCAN_B, 1 << 20);
+    hipLaunchKernelGGL(sz_k_scan1, dim3(nb), dim3(SCAN_B), 0, c->stream, S.n_out, S.out_off, S.blk, S.cnt, C_M, 0);
+    hipLaunchKernelGGL(sz_k_scan2, dim3(1), dim3(SCAN_B), 0, c->stream, S.blk, S.cnt, C_M, 0);
+    hipLaunchKernelGGL(sz_k_scan3_pairs, dim3(nb), dim3(SCAN_B), 0, c->stream, S);
+  }
   t.end();
 }
 
@@ -543,7 +559,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   H2D(S.cnt, h, C_COUNT, int);
   hipLaunchKernelGGL(sz_k_osign, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0);
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->hostM = M; c->hostN = N; c->have_floes = true;
+  c->hostM = M; c->hostN = N; c->have_floes = true; c->tile_dirty = false;
   c->fuse_lists.assign(M, {});
   return SZ_OK;
 }
@@ -551,6 +567,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
 int sz_get_stats(sz_ctx* c, sz_stats* out) {
   if (!c || !out || !c->have_floes) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
+  tile_cleanup(c);
   State& S = c->S;
   HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 4 * sizeof(long long), c->stream));
   hipLaunchKernelGGL(sz_k_stats, dim3(grid_for((long long)S.capPairs + S.capElem, 256, 1024)), dim3(256), 0, c->stream, S, c->d_stats);
@@ -573,6 +590,7 @@ int sz_get_stats(sz_ctx* c, sz_stats* out) {
 int sz_download_floes(sz_ctx* c, sz_floe_columns* f) {
   if (!c || !f || !c->have_floes) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
+  tile_cleanup(c);
   State& S = c->S;
   int h[C_COUNT];
   HIPCHK(c, hipMemcpy(h, S.cnt, sizeof(h), hipMemcpyDeviceToHost));
@@ -606,6 +624,7 @@ int sz_download_floes(sz_ctx* c, sz_floe_columns* f) {
 int sz_download_interactions(sz_ctx* c, int32_t* off, double* rows) {
   if (!c || !off || !c->have_floes) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
+  tile_cleanup(c);
   State& S = c->S;
   // rows are kept at a fixed stride on the device: compact to CSR here
   scan(c, S.inter_cnt, S.inter_off, S.capM, C_M, 0, C_NINTER);
@@ -629,6 +648,7 @@ int sz_download_interactions(sz_ctx* c, int32_t* off, double* rows) {
 int sz_download_pairs(sz_ctx* c, int32_t* pi, int32_t* pj) {
   if (!c || !pi || !pj || !c->have_floes) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
+  tile_cleanup(c);
   int h[C_COUNT];
   HIPCHK(c, hipMemcpy(h, c->S.cnt, sizeof(h), hipMemcpyDeviceToHost));
   if (h[C_NPAIRS] > 0) {
@@ -653,6 +673,7 @@ int sz_download_fuse(sz_ctx* c, int32_t* off, int32_t* idx) {
 int sz_get_boundary_vals(sz_ctx* c, double* vals4) {
   if (!c || !vals4 || !c->have_domain) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
+  tile_cleanup(c);
   HIPCHK(c, hipMemcpy(vals4, c->S.eval, 4 * sizeof(double), hipMemcpyDeviceToHost));
   return SZ_OK;
 }
@@ -857,14 +878,18 @@ int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int
   }
   const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
   const bool overlap = coupling && c->overlap_forcing;
+  const bool periodic = S.any_periodic_ew || S.any_periodic_ns;
   if (overlap) stage_forcing_fork(c);               // owned floes only (C_NOWN): independent of the halo
-  stage_ghosts(c);
+  // As in sz_step, the ghosts of the previous step are detached by this step's flag kernel and the new ones
+  // committed by the bounds kernel; the halo of the previous step was overwritten by the unpack kernel.  Nothing
+  // between two steps looks past the owned floes, so no clean-up launch is needed per step: the ghosts and halo
+  // floes of the LAST step are dropped when the host next looks at the state (tile_cleanup).
   // n_init = every local parent (owned + halo): totals of halo floes are computed and then ignored
-  if (flags & SZ_COLLISIONS_ON) collisions(c, -1, dt);
-  hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 1);
+  if (flags & SZ_COLLISIONS_ON) { stage_ghosts(c, true); collisions(c, -1, dt, periodic); }
   if (coupling && !overlap) stage_forcing(c);
   if (overlap) stage_forcing_join(c);
   stage_integrate(c, dt, false, coupling);
+  c->tile_dirty = true;
   return SZ_OK;
 }
 

@@ -232,25 +232,40 @@ __device__ __forceinline__ int ghost_dir(const State& S, int i, int axis) {
 // plan of both passes for every parent: gplan[i] = {E/W ghosts, E/W points, N/S ghosts, N/S points}
 // `drop_old`: ghosts of the previous step are still attached (their removal, simulation.jl:138-144,
 // was deferred because nothing after the collision kernels looks at them): detach them here.
+__device__ __forceinline__ int4 ghost_plan(State& S, int i, int N, int drop_old) {
+  if (drop_old) {
+    S.ngh[i] = 0;
+    for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = -1;
+    if (i == 0) { S.cnt[C_M] = N; S.cnt[C_NV] = S.voff[N]; }
+  }
+  int dx = 0, dy = 0;
+  if (S.status[i] == SZ_ACTIVE && S.ghost_id[i] == 0) {
+    if (S.any_periodic_ew) dx = ghost_dir(S, i, 0);
+    if (S.any_periodic_ns) dy = ghost_dir(S, i, 1);
+  }
+  int nv = S.voff[i + 1] - S.voff[i];
+  int gew = dx != 0 ? 1 : 0, gns = dy != 0 ? 1 + gew : 0;
+  if (i == 0) S.cnt[C_NGHOSTS] = 0;               // last step's count is kept until here for the stats
+  S.gflag[i] = (dx + 1) | ((dy + 1) << 2);
+  int4 plan = make_int4(gew, gew * nv, gns, gns * nv);
+  S.gplan[i] = plan;
+  return plan;
+}
 __global__ void sz_k_ghost_flag(State S, int drop_old) {
   int N = S.cnt[C_N];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-    if (drop_old) {
-      S.ngh[i] = 0;
-      for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = -1;
-      if (i == 0) { S.cnt[C_M] = N; S.cnt[C_NV] = S.voff[N]; }
-    }
-    int dx = 0, dy = 0;
-    if (S.status[i] == SZ_ACTIVE && S.ghost_id[i] == 0) {
-      if (S.any_periodic_ew) dx = ghost_dir(S, i, 0);
-      if (S.any_periodic_ns) dy = ghost_dir(S, i, 1);
-    }
-    int nv = S.voff[i + 1] - S.voff[i];
-    int gew = dx != 0 ? 1 : 0, gns = dy != 0 ? 1 + gew : 0;
-    if (i == 0) S.cnt[C_NGHOSTS] = 0;               // last step's count is kept until here for the stats
-    S.gflag[i] = (dx + 1) | ((dy + 1) << 2);
-    S.gplan[i] = make_int4(gew, gew * nv, gns, gns * nv);
-  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) (void)ghost_plan(S, i, N, drop_old);
+}
+// the flag kernel and the first scan pass in one launch (fields above the single-workgroup scan size)
+__global__ void __launch_bounds__(SCAN_B) sz_k_ghost_flag_scan1(State S, int drop_old) {
+  __shared__ int4 tot;
+  int n = S.cnt[C_N];
+  int base = blockIdx.x * SCAN_B;
+  if (base >= n && !(n == 0 && blockIdx.x == 0)) return;
+  int i = base + threadIdx.x;
+  int4 v = i < n ? ghost_plan(S, i, n, drop_old) : make_int4(0, 0, 0, 0);
+  int4 ex = block_exclusive_scan4(v, &tot);
+  if (i < n) S.gscan4[i] = ex;
+  if (threadIdx.x == 0) S.gblk4[blockIdx.x] = tot;
 }
 
 __device__ __forceinline__ void copy_floe_row(State& S, int dst, int src) {
@@ -537,6 +552,23 @@ __global__ void sz_k_pairs_fill(State S) {
     int o = S.out_off[k], n = S.n_out[k];
     for (int t = 0; t < n; t++) { S.pair_i[o + t] = k; S.pair_j[o + t] = S.nb_out[(size_t)k * MAXNB + t]; }
   }
+}
+// the last scan pass over n_out and the pair fill in one launch: thread i finishes out_off[i] and
+// writes the pairs floe i owns
+__global__ void __launch_bounds__(SCAN_B) sz_k_scan3_pairs(State S) {
+  int n = S.cnt[C_M];
+  int i = blockIdx.x * SCAN_B + threadIdx.x;
+  if (n == 0) { if (i == 0) { S.out_off[0] = 0; S.cnt[C_NPAIRS] = 0; } return; }
+  if (i >= n) return;
+  int o = S.out_off[i] + S.blk[blockIdx.x], nk = S.n_out[i];
+  S.out_off[i] = o;
+  if (i == n - 1) {
+    int t = o + nk; S.out_off[n] = t;
+    if (t > S.capPairs) { atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS); t = 0; }
+    S.cnt[C_NPAIRS] = t;
+  }
+  if (o + nk > S.capPairs) return;
+  for (int t = 0; t < nk; t++) { S.pair_i[o + t] = i; S.pair_j[o + t] = S.nb_out[(size_t)i * MAXNB + t]; }
 }
 // explicit pair list (sz_collide_pairs): out lists from the given pairs, no incoming lists
 __global__ void sz_k_pairs_explicit(State S, int np) {
