@@ -56,8 +56,9 @@ struct sz_ctx {
   long long* d_stats = nullptr;
   int last_dt = 0;
   bool any_moving = false;
-  bool overlap_forcing = false;   // SZ_OVERLAP=1: forcings on a second stream (measured: no gain at 10k-100k floes, the
-                                  // forcing workgroups delay the latency-bound collision kernels; kept for tuning)
+  int overlap_forcing = -1;       // forcings on a second stream beside the broad / narrow / reduce kernels.  -1 = by field size:
+                                  // the fork/join costs ~10 us, measured -5 % at 10k floes, +3 % at 40k, +6 % at 100k.
+                                  // SZ_OVERLAP=0/1 forces it off / on.
   int max_ring = 0, max_elem_ring = 5, max_ring_tiled = 0;   // largest ring sizes (host knowledge: which narrow variants can be needed)
   int narrow_grid0 = 0;
   bool tile_dirty = false;      // ghosts / halo floes of the last sz_tile_step still appended
@@ -395,7 +396,7 @@ sz_ctx* sz_create(int device_id) {
   sz_ctx* c = new sz_ctx();
   c->device = device_id;
   if (const char* e = getenv("SZ_DEBUG")) c->dbg = atoi(e);
-  if (const char* e = getenv("SZ_OVERLAP")) c->overlap_forcing = atoi(e) != 0;
+  if (const char* e = getenv("SZ_OVERLAP")) c->overlap_forcing = atoi(e) != 0 ? 1 : 0;
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     // lo = least urgent, hi = most urgent
   if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_hi) != hipSuccess) { delete c; return nullptr; }
@@ -777,11 +778,12 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   for (int s = 0; s < nsteps; s++) {
     int tstep = tstep0 + s;
     const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
-    const bool overlap = coupling && c->overlap_forcing;
-    if (overlap) stage_forcing_fork(c);
+    const bool overlap = coupling && (c->overlap_forcing < 0 ? c->hostN >= 32768 : c->overlap_forcing != 0);
     // with collisions on, the ghosts of step s are detached by the ghost kernels of step s+1 (nothing
     // in between looks past the parents) and committed by the bounds kernel: two launches less
-    if (coll) { stage_ghosts(c, true); collisions(c, c->hostN, dt, periodic); }
+    if (coll) stage_ghosts(c, true);
+    if (overlap) stage_forcing_fork(c);      // after the ghost pass: it may wrap a parent around the domain
+    if (coll) collisions(c, c->hostN, dt, periodic);
     if (coupling && !overlap) stage_forcing(c);
     if (overlap) stage_forcing_join(c);
     stage_integrate(c, dt, !coll, coupling);
@@ -877,15 +879,17 @@ int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int
     hipLaunchKernelGGL(sz_k_halo_unpack, dim3(1), dim3(1024), 0, c->stream, S, (const double*)d_recv, nranks, cap);
   }
   const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
-  const bool overlap = coupling && c->overlap_forcing;
+  const bool overlap = coupling && (c->overlap_forcing < 0 ? c->hostN >= 32768 : c->overlap_forcing != 0);
   const bool periodic = S.any_periodic_ew || S.any_periodic_ns;
-  if (overlap) stage_forcing_fork(c);               // owned floes only (C_NOWN): independent of the halo
   // As in sz_step, the ghosts of the previous step are detached by this step's flag kernel and the new ones
   // committed by the bounds kernel; the halo of the previous step was overwritten by the unpack kernel.  Nothing
   // between two steps looks past the owned floes, so no clean-up launch is needed per step: the ghosts and halo
   // floes of the LAST step are dropped when the host next looks at the state (tile_cleanup).
   // n_init = every local parent (owned + halo): totals of halo floes are computed and then ignored
-  if (flags & SZ_COLLISIONS_ON) { stage_ghosts(c, true); collisions(c, -1, dt, periodic); }
+  const bool coll = (flags & SZ_COLLISIONS_ON) != 0;
+  if (coll) stage_ghosts(c, true);
+  if (overlap) stage_forcing_fork(c);               // owned floes only (C_NOWN); after the ghost pass, which may wrap a parent
+  if (coll) collisions(c, -1, dt, periodic);
   if (coupling && !overlap) stage_forcing(c);
   if (overlap) stage_forcing_join(c);
   stage_integrate(c, dt, false, coupling);
