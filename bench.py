@@ -160,9 +160,10 @@ def main():
         b_narrow = narrow_algorithmic_bytes(st)
         achieved = b_narrow / (narrow_ms * 1e-3) / 1e9 if narrow_ms > 0 else 0.0
         # HBM bytes per launch of the narrow kernel from the PMC passes committed under profiles/
-        # (r01_pmc_fetch_size.csv, r01_pmc_write_size.csv: FETCH_SIZE 5255 KB, WRITE_SIZE 802 KB per launch on the
-        # default workload; gfx950 correction: 2 x FETCH_SIZE + WRITE_SIZE).  Only valid for that workload.
-        traffic = (2 * 5255.0 + 802.3) * 1024 if (world == 1 and cfg["n_floes"] == 10000 and args.workload == "configs1") else None
+        # (r01_pmc_fetch_size.csv, r01_pmc_write_size.csv, made by tools/profile_round.sh: FETCH_SIZE 5358.5 KB,
+        # WRITE_SIZE 845.2 KB per launch on the default workload; gfx950 correction: 2 x FETCH_SIZE + WRITE_SIZE).
+        # Only valid for that workload.
+        traffic = (2 * 5358.5 + 845.2) * 1024 if (world == 1 and cfg["n_floes"] == 10000 and args.workload == "configs1") else None
         out = {
             "metric": "floe_steps_per_sec", "value": cfg["n_floes"] * args.steps / el, "unit": "floe-steps/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
@@ -175,7 +176,7 @@ def main():
                                    f"boundaries {cfg['kinds'][0]}, {len(cfg['topography'])} topography elements, dt={cfg['dt']} s",
                        "n_floes": cfg["n_floes"], "seed": cfg["seed"], "coupling_dt": coupling_dt,
                        "tiles": 1 if world == 1 else world},
-            "roofline": {"bound": "hbm", "kernel": "sz_k_narrow<8,20,12,48,4,64,0,0>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "sz_k_narrow<8,20,8,16,4,64,0,0,3>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": narrow_ms, "algorithmic_bytes_per_launch": b_narrow,
                          "step_algorithmic_bytes": step_algorithmic_bytes(st),
