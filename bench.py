@@ -30,10 +30,12 @@ W = 8                        # fp64 bytes
 
 
 def narrow_algorithmic_bytes(st):
-    """B_narrow of SURVEY.md §8(d): both rings of every pair (2 coordinates x w per point) plus
-    7 scalars of both floes, and every contact row written (floe-floe rows twice: i and mirrored
-    j; boundary rows once)."""
-    return (2 * W * st["n_pair_ring_points"] + 2 * 7 * W * st["n_pairs"]
+    """B_narrow of SURVEY.md §8(d): both rings of every pair executed (2 coordinates x w per point)
+    plus 7 scalars of both floes, and every contact row written (floe-floe rows twice: i and mirrored
+    j; boundary rows once).  "Executed" = the pairs the narrow kernel is launched on: the broad phase
+    culls the bounding-circle pairs whose ring boxes are disjoint (about a third), and those cost the
+    narrow phase no byte."""
+    return (2 * W * st["n_pair_ring_points"] + 2 * 7 * W * st["n_pairs_clipped"]
             + 7 * W * (2 * st["n_pair_rows"] + st["n_elem_rows"]))
 
 
@@ -183,7 +185,7 @@ def main():
                          "step_frac": step_algorithmic_bytes(st) / (el / args.steps) / 1e9 / HBM_PEAK_GBS},
             "kernel_ms_per_step": {k: (v[0] / nb) for k, v in kt_all.items()},
             "kernel_ms_per_step_note": f"separate untimed pass of {nb} steps with all kernel classes event-timed",
-            "counts": {k: st[k] for k in ("M", "N", "n_ghosts", "n_pairs", "n_pair_rows", "n_elem_rows",
+            "counts": {k: st[k] for k in ("M", "N", "n_ghosts", "n_pairs", "n_pairs_clipped", "n_pair_rows", "n_elem_rows",
                                            "n_inter_rows", "n_ring_points", "n_sub_points", "n_trace_fail", "n_retry")},
         }
         if not args.no_cpu_baseline and world == 1:

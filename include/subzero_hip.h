@@ -84,7 +84,7 @@ typedef struct {
   int64_t n_ring_points;        /* V_M                                                       */
   int64_t n_sub_points;         /* S                                                         */
   int64_t n_pairs;              /* P: pairs that reached the narrow phase in the last step   */
-  int64_t n_pair_ring_points;   /* sum over pairs of both rings' point counts                */
+  int64_t n_pair_ring_points;   /* sum over the pairs the narrow phase ran of both rings' point counts */
   int64_t n_pair_rows;          /* C: floe-floe contact rows before mirroring                */
   int64_t n_elem_items;         /* floe-boundary / floe-topography clips                     */
   int64_t n_elem_rows;          /* C_b                                                       */
@@ -93,6 +93,7 @@ typedef struct {
   int64_t warn_height, warn_force, warn_vel, warn_xi;   /* update_floe.jl guards             */
   int64_t n_trace_fail;         /* clip traces abandoned (self-intersecting input / round-off), cumulative */
   int64_t n_halo;               /* halo floes received in the last tiled step */
+  int64_t n_pairs_clipped;      /* pairs with overlapping ring boxes: the pair items the narrow phase ran */
   int64_t n_retry;              /* narrow-phase items redone by the largest kernel variant (working set overflow), cumulative */
 } sz_stats;
 

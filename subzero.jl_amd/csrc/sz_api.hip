@@ -242,15 +242,10 @@ void stage_broad(sz_ctx* c, bool commit_ghosts = false) {
   hipLaunchKernelGGL(sz_k_bounds, dim3(1), dim3(1024), 0, c->stream, S, commit_ghosts ? 1 : 0);
   hipLaunchKernelGGL(sz_k_cell_build, dim3(gM), dim3(256), 0, c->stream, S);
   hipLaunchKernelGGL(sz_k_neighbors, dim3(grid_for(S.capM, NB_TPB / NB_G, 8192)), dim3(NB_TPB), 0, c->stream, S);
-  if (S.capM <= SCAN_ONE_MAX) {
-    scan(c, S.n_out, S.out_off, S.capM, C_M, 0, C_NPAIRS);
-    hipLaunchKernelGGL(sz_k_pairs_fill, dim3(gM), dim3(256), 0, c->stream, S);
-  } else {
-    int nb = grid_for(S.capM, SCAN_B, 1 << 20);
-    hipLaunchKernelGGL(sz_k_scan1, dim3(nb), dim3(SCAN_B), 0, c->stream, S.n_out, S.out_off, S.blk, S.cnt, C_M, 0);
-    hipLaunchKernelGGL(sz_k_scan2, dim3(1), dim3(SCAN_B), 0, c->stream, S.blk, S.cnt, C_M, 0);
-    hipLaunchKernelGGL(sz_k_scan3_pairs, dim3(nb), dim3(SCAN_B), 0, c->stream, S);
-  }
+  int nb = grid_for(S.capM, SCAN_B, 1 << 20);
+  hipLaunchKernelGGL(sz_k_pscan1, dim3(nb), dim3(SCAN_B), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_scan4_2, dim3(1), dim3(SCAN_B), 0, c->stream, S.gblk4, S.cnt, C_M);
+  hipLaunchKernelGGL(sz_k_pscan3_fill, dim3(nb), dim3(SCAN_B), 0, c->stream, S);
   t.end();
 }
 
@@ -546,7 +541,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(bounds, 16 + 64 * 4); DA(cell_of, S.capM); DA(cell_cnt, S.capCells + 1); DA(cell_off, S.capCells + 2); DA(cell_cur, S.capCells + 1);
   DA(cell_items, S.capM);
   DA(nb_out, (size_t)S.capM * MAXNB); DA(nb_in, (size_t)S.capM * MAXNB); DA(n_out, S.capM + 1); DA(n_in, S.capM + 1);
-  DA(out_off, S.capM + 2); DA(in_off, S.capM + 2); DA(in_i, S.capPairs); DA(pair_i, S.capPairs); DA(pair_j, S.capPairs);
+  DA(out_off, S.capM + 2); DA(out_mask, S.capM + 1); DA(n_work, S.capM + 1); DA(work_off, S.capM + 2); DA(work, S.capPairs + 1); DA(in_off, S.capM + 2); DA(in_i, S.capPairs); DA(pair_i, S.capPairs); DA(pair_j, S.capPairs);
   DA(el_cnt, S.capM + 1); DA(el_off, S.capM + 2); DA(el_floe, S.capElem); DA(el_elem, S.capElem);
   size_t items = (size_t)S.capPairs + S.capElem;
   DA(it_rows, items * ROWS_PER_ITEM * 5); DA(it_nrows, items); DA(it_flags, items);
@@ -584,6 +579,7 @@ int sz_get_stats(sz_ctx* c, sz_stats* out) {
   out->warn_height = h[C_WARN_H]; out->warn_force = h[C_WARN_F]; out->warn_vel = h[C_WARN_V]; out->warn_xi = h[C_WARN_XI];
   out->n_trace_fail = h[C_TRACE_FAIL];
   out->n_halo = h[C_NHALO];
+  out->n_pairs_clipped = h[C_NWORK];
   out->n_retry = h[C_NRETRY];
   return SZ_OK;
 }

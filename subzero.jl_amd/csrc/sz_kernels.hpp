@@ -3,7 +3,7 @@
 // Pipeline (every launch reads its sizes from the device counter block, no host round trip):
 //   ghosts    sz_k_ghost_flag / sz_k_ghost_fill (x2: E/W then N/S)     add_ghosts!          collisions.jl:1060-1174
 //   broad     sz_k_bounds, sz_k_cell_count, sz_k_cell_fill,
-//             sz_k_neighbors, sz_k_pairs_fill                          pair loop + Dict     collisions.jl:745-775
+//             sz_k_neighbors, sz_k_pscan*                              pair loop + Dict     collisions.jl:745-775
 //   domain    sz_k_elem_count / sz_k_elem_fill                         wall prefilters      collisions.jl:608-660
 //   narrow    sz_k_narrow<G,CAP,...>                                    floe_floe_interaction! / floe_domain_element_interaction!
 //   reduce    sz_k_cnt1, sz_k_inter_fill                               mirror, ghost fold, torque, totals  collisions.jl:799-862
@@ -501,14 +501,16 @@ __global__ void __launch_bounds__(NB_TPB) sz_k_neighbors(State S) {
   __shared__ int cand[GPB][2][MAXNB];
   __shared__ long long ckey[GPB][2][MAXNB];
   __shared__ int cnts[GPB][2];
+  __shared__ int wmask[GPB];
   const int gl = threadIdx.x % NB_G, gi = threadIdx.x / NB_G;
   int M = S.cnt[C_M];
   double x0 = S.bounds[0], y0 = S.bounds[1], cs = S.bounds[2]; int ncx = (int)S.bounds[3], ncy = (int)S.bounds[4];
   for (int k = blockIdx.x * GPB + gi; k < M; k += gridDim.x * GPB) {
     gsync();
-    if (gl == 0) { cnts[gi][0] = 0; cnts[gi][1] = 0; }
+    if (gl == 0) { cnts[gi][0] = 0; cnts[gi][1] = 0; wmask[gi] = 0; }
     gsync();
     double ckx = S.cx[k], cky = S.cy[k], rk = S.rmax[k];
+    const double kx0 = S.bbx0[k], kx1 = S.bbx1[k], ky0 = S.bby0[k], ky1 = S.bby1[k];
     int ix = (int)floor((ckx - x0) / cs), iy = (int)floor((cky - y0) / cs);
     long long idk = S.id[k], okk = S.okey[k];
     bool ovf = false;
@@ -517,16 +519,23 @@ __global__ void __launch_bounds__(NB_TPB) sz_k_neighbors(State S) {
       if (cy >= 0 && cy < ncy && cxi >= 0 && cxi < ncx) {
         for (int o = S.cell_cnt[cy * ncx + cxi] - 1; o >= 0; o = S.cell_items[o]) {
           if (o == k) continue;
+          // everything the tests below may need about o is requested at once (one round trip)
+          const double ocx = S.cx[o], ocy = S.cy[o], orm = S.rmax[o];
+          const double ox0 = S.bbx0[o], ox1 = S.bbx1[o], oy0 = S.bby0[o], oy1 = S.bby1[o];
+          const long long oid = S.id[o], ko = S.okey[o];
           // potential_interaction (collisions.jl:705-710), symmetric in its arguments
-          double ddx = ckx - S.cx[o], ddy = cky - S.cy[o], rr = rk + S.rmax[o];
+          double ddx = ckx - ocx, ddy = cky - ocy, rr = rk + orm;
           if (!((ddx * ddx + ddy * ddy) < rr * rr)) continue;
-          if (S.id[o] == idk) continue;
-          long long ko = S.okey[o];
+          if (oid == idk) continue;
           bool after = ko > okk;                   // o comes after k in the serial order
           if (!pair_allowed(S, after ? k : o, after ? o : k)) continue;
           int w = after ? 0 : 1;
           int slot = atomicAdd(&cnts[gi][w], 1);
-          if (slot < MAXNB) { cand[gi][w][slot] = o; ckey[gi][w][slot] = ko; } else ovf = true;
+          // AABB cull of the pairs this floe owns: rings whose boxes are disjoint cannot overlap, the item would
+          // end at the first test of the clip (sz_geom.hpp clip()) with no row and no flag -- it is not run at all
+          int boxes = 1;
+          if (after) boxes = !(kx1 < ox0 || ox1 < kx0 || ky1 < oy0 || oy1 < ky0);
+          if (slot < MAXNB) { cand[gi][w][slot] = o | (boxes << 30); ckey[gi][w][slot] = ko; } else ovf = true;
         }
       }
     }
@@ -538,37 +547,53 @@ __global__ void __launch_bounds__(NB_TPB) sz_k_neighbors(State S) {
       for (int e = gl; e < n; e += NB_G) {
         long long ke = ckey[gi][w][e]; int r = 0;
         for (int f = 0; f < n; f++) r += ckey[gi][w][f] < ke;
-        dst[r] = cand[gi][w][e];
+        const int cv = cand[gi][w][e];
+        dst[r] = cv & 0x3fffffff;
+        if (w == 0 && (cv >> 30)) atomicOr(&wmask[gi], 1 << r);
       }
-      if (gl == 0) { if (w == 0) S.n_out[k] = n; else S.n_in[k] = n; }
+      gsync();
+      if (gl == 0) {
+        if (w == 0) { S.n_out[k] = n; S.out_mask[k] = wmask[gi]; S.n_work[k] = __popc(wmask[gi]); }
+        else S.n_in[k] = n;
+      }
     }
   }
 }
-__global__ void sz_k_pairs_fill(State S) {
-  int M = S.cnt[C_M];
-  int P = S.cnt[C_NPAIRS];
-  if (P > S.capPairs) { if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS); S.cnt[C_NPAIRS] = 0; } return; }
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
-    int o = S.out_off[k], n = S.n_out[k];
-    for (int t = 0; t < n; t++) { S.pair_i[o + t] = k; S.pair_j[o + t] = S.nb_out[(size_t)k * MAXNB + t]; }
-  }
+// Scan of {outgoing pairs, pairs to run} per floe and the pair fill in three launches.  Pass 3: thread i
+// finishes out_off[i] / work_off[i], writes the pairs floe i owns and appends those with overlapping ring
+// boxes to the work list of the narrow phase; the others get their (empty) result here.
+__global__ void __launch_bounds__(SCAN_B) sz_k_pscan1(State S) {
+  __shared__ int4 tot;
+  int n = S.cnt[C_M];
+  int base = blockIdx.x * SCAN_B;
+  if (base >= n && !(n == 0 && blockIdx.x == 0)) return;
+  int i = base + threadIdx.x;
+  int4 v = i < n ? make_int4(S.n_out[i], S.n_work[i], 0, 0) : make_int4(0, 0, 0, 0);
+  int4 ex = block_exclusive_scan4(v, &tot);
+  if (i < n) { S.out_off[i] = ex.x; S.work_off[i] = ex.y; }
+  if (threadIdx.x == 0) S.gblk4[blockIdx.x] = tot;
 }
-// the last scan pass over n_out and the pair fill in one launch: thread i finishes out_off[i] and
-// writes the pairs floe i owns
-__global__ void __launch_bounds__(SCAN_B) sz_k_scan3_pairs(State S) {
+__global__ void __launch_bounds__(SCAN_B) sz_k_pscan3_fill(State S) {
   int n = S.cnt[C_M];
   int i = blockIdx.x * SCAN_B + threadIdx.x;
-  if (n == 0) { if (i == 0) { S.out_off[0] = 0; S.cnt[C_NPAIRS] = 0; } return; }
+  if (n == 0) { if (i == 0) { S.out_off[0] = 0; S.cnt[C_NPAIRS] = 0; S.cnt[C_NWORK] = 0; } return; }
   if (i >= n) return;
-  int o = S.out_off[i] + S.blk[blockIdx.x], nk = S.n_out[i];
-  S.out_off[i] = o;
+  const int4 b = S.gblk4[blockIdx.x];
+  int o = S.out_off[i] + b.x, wo = S.work_off[i] + b.y, nk = S.n_out[i];
+  const int mask = S.out_mask[i];
+  S.out_off[i] = o; S.work_off[i] = wo;
   if (i == n - 1) {
-    int t = o + nk; S.out_off[n] = t;
-    if (t > S.capPairs) { atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS); t = 0; }
-    S.cnt[C_NPAIRS] = t;
+    int t = o + nk, tw = wo + __popc(mask); S.out_off[n] = t;
+    if (t > S.capPairs) { atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS); t = 0; tw = 0; }
+    S.cnt[C_NPAIRS] = t; S.cnt[C_NWORK] = tw;
   }
   if (o + nk > S.capPairs) return;
-  for (int t = 0; t < nk; t++) { S.pair_i[o + t] = i; S.pair_j[o + t] = S.nb_out[(size_t)i * MAXNB + t]; }
+  for (int t = 0; t < nk; t++) {
+    const int j = S.nb_out[(size_t)i * MAXNB + t], p = o + t;
+    S.pair_i[p] = i; S.pair_j[p] = j;
+    if (mask >> t & 1) S.work[wo++] = make_int4(p, i, j, 0);
+    else { S.it_nrows[p] = 0; S.it_flags[p] = 0; }
+  }
 }
 // explicit pair list (sz_collide_pairs): out lists from the given pairs, no incoming lists
 __global__ void sz_k_pairs_explicit(State S, int np) {
@@ -580,7 +605,9 @@ __global__ void sz_k_pairs_explicit(State S, int np) {
     S.out_off[k] = lo;
     if (k < M) S.n_in[k] = 0;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) S.cnt[C_NPAIRS] = np;
+  // an explicit list is run as given (floe_floe_interaction! has no broad phase)
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < np; p += gridDim.x * blockDim.x) S.work[p] = make_int4(p, S.pair_i[p], S.pair_j[p], 0);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { S.cnt[C_NPAIRS] = np; S.cnt[C_NWORK] = np; }
 }
 __global__ void sz_k_nout_from_off(State S) {
   int M = S.cnt[C_M];
@@ -630,7 +657,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
   __shared__ GroupMem<CAP, KC, RC, RM> mem[GPB];
   const int gl = threadIdx.x % G, gi = threadIdx.x / G;
   GroupMem<CAP, KC, RC, RM>& m = mem[gi];
-  const int npairs = S.cnt[C_NPAIRS], nel = S.cnt[C_NELEM];
+  const int npairs = S.cnt[C_NWORK], nel = S.cnt[C_NELEM];     // pair items = the work list (ring boxes overlap)
   const int nitems = npairs + nel;
   if (gl == 0) { m.err = 0; m.ntracefail = 0; }
   Stamps st; STAMP_INIT(st);
@@ -648,7 +675,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
      bool want = false;
      if (tt < nitems) {
        int i_, nb_, item_;
-       if (tt < npairs) { i_ = S.pair_i[tt]; int j_ = S.pair_j[tt]; nb_ = S.voff[j_ + 1] - S.voff[j_]; item_ = tt; }
+       if (tt < npairs) { int4 w_ = S.work[tt]; i_ = w_.y; int j_ = w_.z; nb_ = S.voff[j_ + 1] - S.voff[j_]; item_ = w_.x; }
        else { int q = tt - npairs; i_ = S.el_floe[q]; int e_ = S.el_elem[q]; nb_ = S.eoff[e_ + 1] - S.eoff[e_]; item_ = S.capPairs + q; }
        int na_ = S.voff[i_ + 1] - S.voff[i_];
        want = (na_ > nb_ ? na_ : nb_) > LO || (S.it_flags[item_] & IT_RETRY);
@@ -661,7 +688,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     else { todo = 0; t = t0 + gi; if (t >= nitems) break; }
     const bool is_pair = t < npairs;
     int i, j = -1, e = -1, item;
-    if (is_pair) { i = S.pair_i[t]; j = S.pair_j[t]; item = t; }
+    if (is_pair) { int4 w = S.work[t]; item = w.x; i = w.y; j = w.z; }
     else { int q = t - npairs; i = S.el_floe[q]; e = S.el_elem[q]; item = S.capPairs + q; }
     const int ao = S.voff[i], na = S.voff[i + 1] - ao;
     const int bo = is_pair ? S.voff[j] : S.eoff[e];
@@ -727,14 +754,13 @@ constexpr int NARROW_CAP0 = 20, NARROW_CAP1 = 32, NARROW_CAP2 = 128;   // ring p
 
 // items not touched by any narrow variant would keep stale row counts: clear them first
 __global__ void sz_k_items_clear(State S) {
-  int npairs = S.cnt[C_NPAIRS], nel = S.cnt[C_NELEM];
+  int npairs = S.cnt[C_NWORK], nel = S.cnt[C_NELEM];
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < npairs + nel; t += gridDim.x * blockDim.x) {
-    int item = t < npairs ? t : S.capPairs + (t - npairs);
-    S.it_nrows[item] = 0; S.it_flags[item] = 0;
     // size class of the item: which narrow-phase variant takes it
-    int i, nb;
-    if (t < npairs) { i = S.pair_i[t]; int j = S.pair_j[t]; nb = S.voff[j + 1] - S.voff[j]; }
-    else { int q = t - npairs; i = S.el_floe[q]; int e = S.el_elem[q]; nb = S.eoff[e + 1] - S.eoff[e]; }
+    int item, i, nb;
+    if (t < npairs) { int4 w = S.work[t]; item = w.x; i = w.y; nb = S.voff[w.z + 1] - S.voff[w.z]; }
+    else { int q = t - npairs; item = S.capPairs + q; i = S.el_floe[q]; int e = S.el_elem[q]; nb = S.eoff[e + 1] - S.eoff[e]; }
+    S.it_nrows[item] = 0; S.it_flags[item] = 0;
     int na = S.voff[i + 1] - S.voff[i];
     int big = na > nb ? na : nb;
     int cls = big <= NARROW_CAP0 ? 0 : (big <= NARROW_CAP1 ? 1 : 2);
@@ -1250,14 +1276,15 @@ __global__ void __launch_bounds__(1024) sz_k_owned_box(State S, double* out) {
 
 // ============================================================================ stats
 __global__ void sz_k_stats(State S, long long* out) {
-  // out[0] = sum ring points over pairs, out[1] = pair rows, out[2] = elem rows, out[3] = interaction rows
-  int npairs = S.cnt[C_NPAIRS], nel = S.cnt[C_NELEM];
+  // out[0] = sum ring points over the pairs the narrow phase ran, out[1] = pair rows, out[2] = elem rows,
+  // out[3] = interaction rows
+  int npairs = S.cnt[C_NWORK], nel = S.cnt[C_NELEM];
   long long a = 0, b = 0, c = 0;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < npairs + nel; t += gridDim.x * blockDim.x) {
     if (t < npairs) {
-      int i = S.pair_i[t], j = S.pair_j[t];
-      a += (S.voff[i + 1] - S.voff[i]) + (S.voff[j + 1] - S.voff[j]);
-      b += S.it_nrows[t];
+      int4 w = S.work[t];
+      a += (S.voff[w.y + 1] - S.voff[w.y]) + (S.voff[w.z + 1] - S.voff[w.z]);
+      b += S.it_nrows[w.x];
     } else c += S.it_nrows[S.capPairs + (t - npairs)];
   }
   atomicAdd((unsigned long long*)&out[0], (unsigned long long)a);

@@ -31,6 +31,7 @@ enum {
   C_NHALO,
   C_ITEMCLASS,    // largest narrow-phase size class among this step's items
   C_NRETRY,       // items handed on to the largest narrow variant (diagnostic, cumulative)
+  C_NWORK,        // pairs whose ring boxes overlap: the pair items the narrow phase runs
   C_COUNT = 32
 };
 
@@ -80,6 +81,8 @@ struct State {
   int *cell_of, *cell_cnt, *cell_off, *cell_cur, *cell_items;
   int *nb_out, *nb_in, *n_out, *n_in, *out_off, *in_off, *in_i;
   int *pair_i, *pair_j;
+  int *out_mask, *n_work, *work_off;   // per floe: which of its outgoing pairs have overlapping ring boxes (bit r = rank r)
+  int4* work;                // compacted pair items: {pair slot, i, j, -}
   // ---- element items
   int *el_cnt, *el_off, *el_floe, *el_elem;
   // ---- contact rows per item (pairs first, then element items at capPairs + e)
