@@ -414,8 +414,19 @@ __global__ void __launch_bounds__(1024) sz_k_bounds(State S, int commit_ghosts) 
   }
   int M = S.cnt[C_M];
   double x0 = __builtin_inf(), y0 = __builtin_inf(), x1 = -__builtin_inf(), y1 = -__builtin_inf(), rm = 0.0;
-  for (int i = threadIdx.x; i < M; i += blockDim.x) {
-    x0 = fmin(x0, S.cx[i]); x1 = fmax(x1, S.cx[i]); y0 = fmin(y0, S.cy[i]); y1 = fmax(y1, S.cy[i]); rm = fmax(rm, S.rmax[i]);
+  // one workgroup reads three columns: eight floes per thread and trip, so that the loads of a trip are all
+  // in flight together (a plain loop would pay one memory round trip per floe)
+  for (int i0 = threadIdx.x; i0 < M; i0 += 8 * blockDim.x) {
+    double ax[8], ay[8], ar[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int i = i0 + k * (int)blockDim.x; const bool in = i < M;
+      ax[k] = in ? S.cx[i] : __builtin_nan(""); ay[k] = in ? S.cy[i] : __builtin_nan(""); ar[k] = in ? S.rmax[i] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {      // fmin / fmax ignore a NaN operand
+      x0 = fmin(x0, ax[k]); x1 = fmax(x1, ax[k]); y0 = fmin(y0, ay[k]); y1 = fmax(y1, ay[k]); rm = fmax(rm, ar[k]);
+    }
   }
   for (int d = 32; d >= 1; d >>= 1) {
     x0 = fmin(x0, __shfl_xor(x0, d)); y0 = fmin(y0, __shfl_xor(y0, d));
@@ -513,22 +524,26 @@ __global__ void __launch_bounds__(NB_TPB) sz_k_neighbors(State S) {
     const double kx0 = S.bbx0[k], kx1 = S.bbx1[k], ky0 = S.bby0[k], ky1 = S.bby1[k];
     int ix = (int)floor((ckx - x0) / cs), iy = (int)floor((cky - y0) / cs);
     long long idk = S.id[k], okk = S.okey[k];
+    const bool kplain = S.parent[k] == k && S.ngh[k] == 0;
     bool ovf = false;
     if (gl < 9) {
       int cy = iy + gl / 3 - 1, cxi = ix + gl % 3 - 1;
       if (cy >= 0 && cy < ncy && cxi >= 0 && cxi < ncx) {
-        for (int o = S.cell_cnt[cy * ncx + cxi] - 1; o >= 0; o = S.cell_items[o]) {
-          if (o == k) continue;
-          // everything the tests below may need about o is requested at once (one round trip)
+        for (int o = S.cell_cnt[cy * ncx + cxi] - 1, nxt; o >= 0; o = nxt) {
+          // everything the tests below may need about o is requested at once (one round trip per list node)
+          nxt = S.cell_items[o];
           const double ocx = S.cx[o], ocy = S.cy[o], orm = S.rmax[o];
           const double ox0 = S.bbx0[o], ox1 = S.bbx1[o], oy0 = S.bby0[o], oy1 = S.bby1[o];
           const long long oid = S.id[o], ko = S.okey[o];
+          const bool oplain = S.parent[o] == o && S.ngh[o] == 0;     // a parent without ghosts
+          if (o == k) continue;
           // potential_interaction (collisions.jl:705-710), symmetric in its arguments
           double ddx = ckx - ocx, ddy = cky - ocy, rr = rk + orm;
           if (!((ddx * ddx + ddy * ddy) < rr * rr)) continue;
           if (oid == idk) continue;
           bool after = ko > okk;                   // o comes after k in the serial order
-          if (!pair_allowed(S, after ? k : o, after ? o : k)) continue;
+          // the Dict rule only bites when one of the two floes has periodic images
+          if (!(kplain && oplain) && !pair_allowed(S, after ? k : o, after ? o : k)) continue;
           int w = after ? 0 : 1;
           int slot = atomicAdd(&cnts[gi][w], 1);
           // AABB cull of the pairs this floe owns: rings whose boxes are disjoint cannot overlap, the item would
