@@ -50,6 +50,21 @@ def step_algorithmic_bytes(st):
     return b_broad + narrow_algorithmic_bytes(st) + b_reduce + b_force + b_integ
 
 
+def measured_hbm_ceiling(torch, device):
+    """On-device copy ceiling (SURVEY.md §8d asks for the fraction against a measured ceiling as well as the
+    nominal 8 TB/s): a 1 GiB device-to-device copy timed with events, read + write bytes over the best of 5."""
+    n = 1 << 27
+    a = torch.empty(n, dtype=torch.float64, device=device); b = torch.empty_like(a)
+    a.fill_(1.0); b.copy_(a); torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(5):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); b.copy_(a); e1.record(); torch.cuda.synchronize()
+        best = max(best, 2 * 8 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return best
+
+
 def cpu_baseline(cfg, budget_s=20.0):
     """The oracle (kind: port) on a bounded sample of the same workload: the same 10k-floe field,
     as many whole timesteps as fit the budget (at least 2), all host cores of this process."""
@@ -66,12 +81,19 @@ def cpu_baseline(cfg, budget_s=20.0):
     w.set_threads(cores)
     w.timestep_sim(0, cfg["dt"], coupling_dt=1)        # warm-up step (page-in, allocator)
     t0 = time.perf_counter(); steps = 0
-    while steps < 2 or (time.perf_counter() - t0 < budget_s and steps < 300):
+    while steps < 2 or (time.perf_counter() - t0 < 0.75 * budget_s and steps < 300):
         w.timestep_sim(1 + steps, cfg["dt"], coupling_dt=1); steps += 1
     el = time.perf_counter() - t0
+    # the same on one core (the reference's default when Julia is started without -t)
+    w.set_threads(1)
+    t1 = time.perf_counter(); s1 = 0
+    while s1 < 2 or (time.perf_counter() - t1 < 0.25 * budget_s and s1 < 100):
+        w.timestep_sim(1 + steps + s1, cfg["dt"], coupling_dt=1); s1 += 1
+    el1 = time.perf_counter() - t1
     return {"value": cfg["n_floes"] * steps / el, "unit": "floe-steps/s", "cores": cores, "kind": "port",
             "sample": f"{steps} timesteps of the same {cfg['n_floes']}-floe field ({el:.1f} s), OpenMP over floes "
-                      f"like the reference's Threads.@threads loops"}
+                      f"like the reference's Threads.@threads loops; then {s1} steps on one core ({el1:.1f} s)",
+            "value_1core": cfg["n_floes"] * s1 / el1}
 
 
 def main():
@@ -147,6 +169,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     kt = hw.kernel_times()
+    ceiling = measured_hbm_ceiling(torch, torch.device("cuda", local)) if rank == 0 else 0.0
     # per-class breakdown from a second, untimed pass with every class event-timed
     nb = max(1, min(args.steps, 50))
     hw.profile(True)
@@ -180,6 +203,7 @@ def main():
                        "tiles": 1 if world == 1 else world},
             "roofline": {"bound": "hbm", "kernel": "sz_k_narrow<8,20,8,16,4,64,0,0,3>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_copy_ceiling": ceiling, "frac_of_measured_ceiling": achieved / ceiling if ceiling > 0 else None,
                          "kernel_ms": narrow_ms, "algorithmic_bytes_per_launch": b_narrow,
                          "step_algorithmic_bytes": step_algorithmic_bytes(st),
                          "step_frac": step_algorithmic_bytes(st) / (el / args.steps) / 1e9 / HBM_PEAK_GBS},
