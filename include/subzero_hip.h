@@ -149,6 +149,13 @@ int sz_collide_pairs(sz_ctx *ctx, int64_t npairs, const int32_t *pi, const int32
 int sz_collide_domain(sz_ctx *ctx, int32_t dt, double max_overlap);
 int sz_timestep_coupling(sz_ctx *ctx);
 int sz_timestep_floe_properties(sz_ctx *ctx, int32_t dt);
+/* calc_stress! (update_floe.jl:392-414, with _update_stress_accum!, stress_calculators.jl:118-122) and
+   calc_strain! (update_floe.jl:425-453) on their own, for every floe, as the reference's tests call them
+   (test_update_floe.jl:10-39).  sz_upload_interactions replaces floe.interactions of every floe by hand-made
+   matrices first (CSR offsets, rows of 7: floeidx, xforce, yforce, xpoint, ypoint, torque, overlap). */
+int sz_upload_interactions(sz_ctx *ctx, const int32_t *inter_off, const double *rows);
+int sz_calc_stress(sz_ctx *ctx);
+int sz_calc_strain(sz_ctx *ctx);
 /* nsteps x timestep_sim! with the state resident in HBM; tstep counts from tstep0 */
 int sz_step(sz_ctx *ctx, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupling_dt,
             int32_t flags);

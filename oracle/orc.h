@@ -139,6 +139,9 @@ void orc_floe_domain_interaction(orc_world *w, int i, int dt, double max_overlap
 void orc_calc_torque(orc_world *w, int i);                           /* collisions.jl:673-686 */
 void orc_timestep_coupling(orc_world *w);                            /* coupling.jl:1705 (one-way) */
 void orc_timestep_floe_properties(orc_world *w, int dt);             /* update_floe.jl:469-551 */
+void orc_set_interactions(orc_world *w, int i, int k, const double *rows);   /* floe.interactions = k x 7 matrix, row-major */
+void orc_calc_stress(orc_world *w, int i);                            /* calc_stress!, update_floe.jl:392-414 */
+void orc_calc_strain(orc_world *w, int i);                            /* calc_strain!, update_floe.jl:425-453 */
 /* timestep_sim! (simulation.jl:94-170) restricted to the hot path */
 void orc_timestep_sim(orc_world *w, int tstep, int dt, int coupling_dt, int collisions_on, int coupling_on);
 

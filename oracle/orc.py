@@ -181,6 +181,19 @@ class World:
         off, rows = self.interactions()
         return rows[off[i]:off[i + 1]]
 
+    def set_interactions(self, i, rows):
+        """floe.interactions = rows (k x 7: floeidx, xforce, yforce, xpoint, ypoint, torque, overlap)"""
+        r = np.ascontiguousarray(rows, np.float64).reshape(-1, 7)
+        self.L.orc_set_interactions(self.h, int(i), int(len(r)), _p(r))
+
+    def calc_stress(self, i=None):
+        for k in (range(self.M) if i is None else [i]):
+            self.L.orc_calc_stress(self.h, int(k))
+
+    def calc_strain(self, i=None):
+        for k in (range(self.M) if i is None else [i]):
+            self.L.orc_calc_strain(self.h, int(k))
+
     def ghosts(self):
         M = self.M; T = self.L.orc_total_ghost_links(self.h)
         off = np.zeros(M + 1, np.int32); idx = np.zeros(max(T, 1), np.int32)

@@ -896,6 +896,17 @@ static void calc_strain(floe_t *f) {
 }
 static double sgn(double x) { return (x > 0) - (x < 0); }
 
+/* the reference's own tests call calc_stress! / calc_strain! on floes whose interaction matrix was set by hand
+   (test_update_floe.jl:10-39): the three entry points below are what those tests need */
+void orc_set_interactions(orc_world *w, int i, int k, const double *rows) {
+  floe_t *f = &w->f[i];
+  if (k > f->capinter) { f->capinter = k; f->inter = (double *)realloc(f->inter, (size_t)k * I_NCOL * sizeof(double)); }
+  memcpy(f->inter, rows, (size_t)k * I_NCOL * sizeof(double));
+  f->ninter = k;
+}
+void orc_calc_stress(orc_world *w, int i) { calc_stress(w, &w->f[i]); }
+void orc_calc_strain(orc_world *w, int i) { calc_strain(&w->f[i]); }
+
 /* timestep_floe_properties!, update_floe.jl:469-551 */
 void orc_timestep_floe_properties(orc_world *w, int dt) {
   int64_t wh = 0, wf = 0, wv = 0, wx = 0;

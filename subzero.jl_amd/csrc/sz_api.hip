@@ -345,7 +345,7 @@ void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc) {
   if (reset_guards) (void)hipMemsetAsync(c->S.cnt + C_WARN_H, 0, 4 * sizeof(int), c->stream);
   Timed t(c, SZ_K_INTEGRATE);
   hipLaunchKernelGGL(sz_k_integrate, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0);
-  hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S);
+  hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 0);
   t.end();
 }
 
@@ -762,6 +762,40 @@ int sz_timestep_floe_properties(sz_ctx* c, int32_t dt) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
   stage_integrate(c, dt, true, false);
+  return sync_and_check(c);
+}
+
+// floe.interactions of every floe replaced by hand (CSR, rows k x 7: floeidx, xforce, yforce, xpoint, ypoint,
+// torque, overlap): what the reference's calc_stress! test does before calling it (test_update_floe.jl:27-30)
+int sz_upload_interactions(sz_ctx* c, const int32_t* off, const double* rows) {
+  if (!c || !c->have_floes || !off) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  tile_cleanup(c);
+  State& S = c->S;
+  const int M = c->hostM;
+  std::vector<int> cnt(M); std::vector<double> buf((size_t)M * ROWCAP * 7, 0.0);
+  for (int i = 0; i < M; i++) {
+    int k = off[i + 1] - off[i];
+    if (k < 0 || k > ROWCAP) { c->err = "more interaction rows per floe than the fixed stride holds"; return SZ_E_CAPACITY; }
+    cnt[i] = k;
+    if (k) memcpy(&buf[(size_t)i * ROWCAP * 7], rows + (size_t)off[i] * 7, (size_t)k * 7 * sizeof(double));
+  }
+  H2D(S.inter_cnt, cnt.data(), M, int);
+  H2D(S.inter_rows, buf.data(), (size_t)M * ROWCAP * 7, double);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SZ_OK;
+}
+// calc_stress! (update_floe.jl:392-414) and calc_strain! (:425-453) on their own, for every floe
+int sz_calc_stress(sz_ctx* c) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  hipLaunchKernelGGL(sz_k_calc_stress, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P);
+  return sync_and_check(c);
+}
+int sz_calc_strain(sz_ctx* c) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 1);
   return sync_and_check(c);
 }
 

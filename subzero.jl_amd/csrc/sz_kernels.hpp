@@ -1033,6 +1033,30 @@ __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
 // ============================================================================ rigid-body update (A12)
 __device__ __forceinline__ double sgn(double x) { return (double)((x > 0) - (x < 0)); }
 
+// calc_stress!, update_floe.jl:392-414, and _update_stress_accum!, stress_calculators.jl:118-122
+__device__ __forceinline__ void floe_stress(State& S, const Params& P, int i, double cx, double cy) {
+  double s11 = 0, s12 = 0, s21 = 0, s22 = 0;
+  int rn = S.inter_cnt[i];
+  if (rn > 0) {
+    for (int k = 0; k < rn; k++) {
+      const double* r = S.inter_rows + ((size_t)i * ROWCAP + k) * 7;
+      s11 += (r[3] - cx) * r[1];
+      s12 += (r[4] - cy) * r[1] + (r[3] - cx) * r[2];
+      s22 += (r[4] - cy) * r[2];
+    }
+    s12 *= 0.5; s21 = s12;
+    double sc = 1 / (S.area[i] * S.height[i]);
+    s11 *= sc; s12 *= sc; s21 *= sc; s22 *= sc;
+  }
+  double l = P.lambda, s[4] = { s11, s12, s21, s22 };
+  for (int k = 0; k < 4; k++) { S.sa[i * 4 + k] = (1 - l) * S.sa[i * 4 + k] + l * s[k]; S.si[i * 4 + k] = s[k]; }
+}
+// calc_stress! on its own (the reference's tests call it on hand-made interaction matrices)
+__global__ void sz_k_calc_stress(State S, Params P) {
+  int N = S.cnt[C_NOWN];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) floe_stress(S, P, i, S.cx[i], S.cy[i]);
+}
+
 // one thread per floe: stress, guards, thermodynamics, AB2 velocity update; stores the motion
 __global__ void sz_k_integrate(State S, Params P, int dt, int apply_frc) {
   int N = S.cnt[C_NOWN];
@@ -1041,22 +1065,7 @@ __global__ void sz_k_integrate(State S, Params P, int dt, int apply_frc) {
     if (apply_frc && S.frc_remove[i]) S.status[i] = SZ_REMOVE;
     double cfx = S.cfx[i], cfy = S.cfy[i], ctrq = S.ctrq[i];
     double cx = S.cx[i], cy = S.cy[i];
-    // calc_stress!, update_floe.jl:392-414
-    double s11 = 0, s12 = 0, s21 = 0, s22 = 0;
-    int rn = S.inter_cnt[i];
-    if (rn > 0) {
-      for (int k = 0; k < rn; k++) {
-        const double* r = S.inter_rows + ((size_t)i * ROWCAP + k) * 7;
-        s11 += (r[3] - cx) * r[1];
-        s12 += (r[4] - cy) * r[1] + (r[3] - cx) * r[2];
-        s22 += (r[4] - cy) * r[2];
-      }
-      s12 *= 0.5; s21 = s12;
-      double sc = 1 / (S.area[i] * S.height[i]);
-      s11 *= sc; s12 *= sc; s21 *= sc; s22 *= sc;
-    }
-    double l = P.lambda, s[4] = { s11, s12, s21, s22 };
-    for (int k = 0; k < 4; k++) { S.sa[i * 4 + k] = (1 - l) * S.sa[i * 4 + k] + l * s[k]; S.si[i * 4 + k] = s[k]; }
+    floe_stress(S, P, i, cx, cy);
     double hh = S.height[i];
     if (hh > P.max_h) { hh = P.max_h; wh++; }
     double mass = S.mass[i];
@@ -1102,18 +1111,21 @@ __global__ void sz_k_integrate(State S, Params P, int dt, int apply_frc) {
 // (update_floe.jl:425-453) with the new velocities.  Strain terms are evaluated from the moved
 // coordinates recomputed in registers (same expression as the store, hence the same bits), the
 // ring is overwritten afterwards, and the per-edge terms are summed in ring order.
-__global__ void __launch_bounds__(256) sz_k_move_strain(State S) {
+// strain_only: calc_strain! on its own -- the ring stays where it is and nothing but the strain is written
+__global__ void __launch_bounds__(256) sz_k_move_strain(State S, int strain_only) {
   constexpr int G = 16;
   __shared__ double t11[256 / G][64], t12[256 / G][64], t22[256 / G][64];
   int N = S.cnt[C_NOWN];
   int gl = threadIdx.x % G, gi = threadIdx.x / G, gpb = blockDim.x / G;
   for (int i = blockIdx.x * gpb + gi; i < N; i += gridDim.x * gpb) {
     double cx = S.cx[i], cy = S.cy[i];
-    double dx = S.mot[i * 4], dy = S.mot[i * 4 + 1], c = S.mot[i * 4 + 2], s = S.mot[i * 4 + 3];
+    double dx = 0.0, dy = 0.0, c = 1.0, s = 0.0;
+    if (!strain_only) { dx = S.mot[i * 4]; dy = S.mot[i * 4 + 1]; c = S.mot[i * 4 + 2]; s = S.mot[i * 4 + 3]; }
     int o = S.voff[i], n = S.voff[i + 1] - o;
     double ncx = cx + dx, ncy = cy + dy;
     double u = S.u[i], xi = S.xi[i];
     auto moved = [&](int k, double& mx, double& my) {
+      if (strain_only) { mx = S.vx[o + k]; my = S.vy[o + k]; return; }
       double x = S.vx[o + k] + (-cx), y = S.vy[o + k] + (-cy);
       double xr = c * x - s * y, yr = s * x + c * y;
       mx = xr + (cx + dx); my = yr + (cy + dy);
@@ -1140,18 +1152,18 @@ __global__ void __launch_bounds__(256) sz_k_move_strain(State S) {
     // all reads of the old ring are done (each lane's loads complete before its dependent LDS
     // stores, and the sums above consumed every LDS store of the group)
     double bx0 = __builtin_inf(), bx1 = -__builtin_inf(), by0 = __builtin_inf(), by1 = -__builtin_inf();
-    for (int k = gl; k < n; k += G) {
+    for (int k = gl; k < n && !strain_only; k += G) {
       double mx, my; moved(k, mx, my);
       S.vx[o + k] = mx; S.vy[o + k] = my;
       bx0 = fmin(bx0, mx); bx1 = fmax(bx1, mx); by0 = fmin(by0, my); by1 = fmax(by1, my);
     }
     bx0 = gmin<G>(bx0); bx1 = gmax<G>(bx1); by0 = gmin<G>(by0); by1 = gmax<G>(by1);
-    if (gl == 0) { S.bbx0[i] = bx0; S.bbx1[i] = bx1; S.bby0[i] = by0; S.bby1[i] = by1; }
+    if (gl == 0 && !strain_only) { S.bbx0[i] = bx0; S.bbx1[i] = bx1; S.bby0[i] = by0; S.bby1[i] = by1; }
     if (gl == 0) {
       e12 *= 0.5;
       double d = 2 * S.area[i];
       S.strain[i * 4 + 0] = e11 / d; S.strain[i * 4 + 1] = e12 / d; S.strain[i * 4 + 2] = e12 / d; S.strain[i * 4 + 3] = e22 / d;
-      S.cx[i] = ncx; S.cy[i] = ncy;
+      if (!strain_only) { S.cx[i] = ncx; S.cy[i] = ncy; }
     }
   }
 }

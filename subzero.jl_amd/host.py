@@ -43,6 +43,7 @@ class World:
         self._M = 0
         self._dirty = True        # host columns changed since the last upload
         self._host_stale = False  # device columns changed since the last download
+        self._inter = {}          # hand-set interaction matrices waiting for upload
         self._have_domain = False
         self._domain = None
         self._topo = []
@@ -253,7 +254,13 @@ class World:
 
     def set(self, name, vals):
         self._pull()
-        self.col[name] = np.ascontiguousarray(np.broadcast_to(vals, (self._M,)), np.float64).copy()
+        v = np.ascontiguousarray(np.broadcast_to(vals, (self._M,)), np.float64).copy()
+        for pre, full in {"sa": "stress_accum", "si": "stress_instant", "e": "strain"}.items():
+            if name.startswith(pre) and name[len(pre):] in ("11", "12", "21", "22"):
+                self.col[full][:, ("11", "12", "21", "22").index(name[len(pre):])] = v
+                break
+        else:
+            self.col[name] = v
         self._dirty = True
 
     def ids(self):
@@ -342,6 +349,30 @@ class World:
     def floe_domain_interaction(self, i, dt, max_overlap):
         self._push()
         self._chk(self.L.sz_collide_domain(self.h, int(dt), float(max_overlap))); self._host_stale = True
+
+    def set_interactions(self, i, rows):
+        """floe.interactions of floe i = rows (k x 7), set by hand as the reference's calc_stress! test does"""
+        self._inter[int(i)] = np.ascontiguousarray(rows, np.float64).reshape(-1, 7)
+
+    def _push_interactions(self):
+        self._push()
+        if not self._inter:
+            return
+        M = self._M
+        off = np.zeros(M + 1, _I32)
+        for i in range(M):
+            off[i + 1] = off[i] + len(self._inter.get(i, ()))
+        rows = np.concatenate([self._inter[i] for i in range(M) if i in self._inter]) if off[M] else np.zeros((1, 7))
+        self._chk(self.L.sz_upload_interactions(self.h, capi.ptr(off, capi._ip), capi.ptr(rows)))
+        self._inter = {}
+
+    def calc_stress(self):
+        self._push_interactions()
+        self._chk(self.L.sz_calc_stress(self.h)); self._host_stale = True
+
+    def calc_strain(self):
+        self._push_interactions()
+        self._chk(self.L.sz_calc_strain(self.h)); self._host_stale = True
 
     def calc_torque(self, i):
         """calc_torque! is fused into the interaction-list kernel; nothing to do."""

@@ -267,3 +267,33 @@ def check_forcing(w, case):
     got = (w.get("fxOA")[0] / area, w.get("fyOA")[0] / area, w.get("trqOA")[0] / area)
     for g, key, atol in zip(got, ("fx", "fy", "trq"), case["atol"]):
         assert abs(g - case[key]) < atol, (case["name"], key, g, case[key])
+
+
+# ------------------------------------------------------------------ stress / strain (test_update_floe.jl:2-43)
+def run_stress_strain(mk, U):
+    """Both floes of the reference's fixture in one world: interactions and last stress set by hand,
+    then calc_stress! and calc_strain! exactly as the reference's test calls them."""
+    w = mk()
+    w.set_settings()
+    w.set_domain([KIND["open"]] * 4, -1e6, 1e6, -1e6, 1e6)
+    for f in U["floes"]:
+        w.add_floe(np.array(f["coords"], float), f["height"])
+    for i, f in enumerate(U["floes"]):
+        set_vel(w, i, {"u": f["u"], "v": f["v"], "xi": f["xi"]})
+        set_vel(w, i, dict(zip(("si11", "si12", "si21", "si22"), f["last_stress"])))
+    for i, f in enumerate(U["floes"]):
+        w.set_interactions(i, np.array(f["interactions"], float))
+    w.calc_stress()
+    w.calc_strain()
+    return w
+
+
+def check_stress_strain(w, U):
+    for i, f in enumerate(U["floes"]):
+        assert abs(w.get("area")[i] - f["area"]) < 1e-6 * f["area"]
+        si = [w.get(k)[i] for k in ("si11", "si12", "si21", "si22")]
+        assert np.allclose(si, U["stress_instant"][i], rtol=0, atol=U["atol"]), (i, si)
+        e = [w.get(k)[i] * 1e6 for k in ("e11", "e12", "e21", "e22")]
+        assert np.allclose(e, U["strain_times_1e6"][i], rtol=0, atol=U["atol"]), (i, e)
+        # the reference's test also asserts that calc_strain! leaves the coordinates alone
+        assert np.array_equal(w.ring(i), np.array(f["coords"], float))

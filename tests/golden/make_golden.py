@@ -13,7 +13,14 @@ data file.  No reference source text is copied.
                       points X, Y decoded from test/inputs/test_mc_points.jld2 (two contiguous
                       little-endian Float64 datasets of 241 values each inside the JLD2/HDF5
                       container; located by scanning, since no HDF5 reader exists in the image)
+  update_floe.json <- test/test_physical_processes/test_update_floe.jl:2-43 (expected stress / strain),
+                      with the two floes of test/inputs/stress_strain.jld2 decoded from the container:
+                      the root group's link messages give the object-header address of every named
+                      dataset, the small Float64 datasets sit 61 bytes behind their header, and the
+                      ring points are consecutive 2-value datasets (81 bytes apart) in ring order
 """
+import re
+import struct
 import json
 import os
 
@@ -216,8 +223,77 @@ def forcings():
     }
 
 
+def decode_stress_strain():
+    b = open(os.path.join(REF, "test/inputs/stress_strain.jld2"), "rb").read()
+    base = 512                                           # JLD2 superblock offset: addresses are relative to it
+
+    def dbl(o, n):
+        return list(struct.unpack_from("<%dd" % n, b, o))
+
+    # root group link messages: version 1, flags 0x10, charset 1, name length, name, address
+    links = {}
+    for m in re.finditer(rb"\x01\x10\x01(.)", b[8800:], re.S):
+        ln = m.group(1)[0]; st = 8800 + m.end()
+        links[b[st:st + ln].decode("utf8")] = base + struct.unpack_from("<Q", b, st + ln)[0]
+    assert {"u", "v", "ξ", "height", "area", "interactions", "coords", "last_stress"} <= set(links), links
+    small = {k: dbl(links[k] + 61, 2) for k in ("u", "v", "ξ", "height", "area")}      # Vector{Float64}(2) each
+    assert small["height"] == [0.25, 0.25] and small["area"] == [8e7, 7.25e7], small
+
+    def runs(lo, hi, n, pred):
+        out = []
+        o = lo
+        while o + 8 * n <= hi:
+            v = dbl(o, n)
+            if pred(v):
+                out.append((o, v)); o += 8 * n
+            else:
+                o += 1
+        return out
+
+    def plausible(v):
+        return all(np.isfinite(x) and (x == 0.0 or 1e-3 < abs(x) < 1e13) for x in v)
+    # interactions: two 2x7 matrices (column-major, 14 doubles) whose first column is the partner index
+    inter = [v for _, v in runs(links["interactions"], links["coords"], 14,
+                                lambda v: plausible(v) and v[0] == v[1] and v[0] in (1.0, 2.0) and abs(v[2]) > 1e6)]
+    assert len(inter) == 2, inter
+    inter = [np.array(v).reshape(7, 2).T.tolist() for v in inter]
+    # ring points: 2-value datasets 81 bytes apart, in ring order; a ring ends when its first point recurs
+    pts = runs(links["coords"], links["centroid"], 2,
+               lambda v: plausible(v) and all(x == 0.0 or 1e3 <= abs(x) <= 1e5 for x in v) and any(x != 0.0 for x in v))
+    pts = [(o, v) for o, v in pts if not (abs(v[0] - 1.2353074274786685e-4) < 1e-12)]
+    rings, cur = [], []
+    for k, (o, v) in enumerate(pts):
+        if cur and o - pts[k - 1][0] != 81 and len(cur) < 4:
+            cur = []
+        cur.append(v)
+        if len(cur) >= 4 and cur[-1] == cur[0]:
+            rings.append(cur); cur = []
+    assert len(rings) == 2 and len(rings[0]) == 5 and len(rings[1]) == 9, rings
+    last = [v for _, v in runs(links["last_stress"], links["last_stress"] + 400, 4,
+                               lambda v: plausible(v) and v[1] == v[2] and abs(v[0]) > 1e3)]
+    assert len(last) == 2, last
+    return small, inter, rings, last
+
+
+def update_floe():
+    small, inter, rings, last = decode_stress_strain()
+    return {
+        "_source": "test/test_physical_processes/test_update_floe.jl:2-43; floes from test/inputs/stress_strain.jld2",
+        "dt": 10,
+        "floes": [{"coords": rings[i], "height": small["height"][i], "u": small["u"][i], "v": small["v"][i],
+                   "xi": small["ξ"][i], "area": small["area"][i], "interactions": inter[i],
+                   "last_stress": last[i]} for i in range(2)],
+        # calc_stress!: floe.stress_instant (the reference's variable name for it is stress_histories); the
+        # stress_accum check is @test_broken in the reference and is not transcribed
+        "stress_instant": [[-4971.252, 17483.052, 17483.052, -57097.458], [4028.520, 9502.886, 9502.886, -205199.791]],
+        "strain_times_1e6": [[-0.0372, 0, 0, 0.9310], [7.419, 0, 0, -6.987]],
+        "atol": 1e-3,
+    }
+
+
 def main():
-    for name, fn in (("collisions.json", collisions), ("floe_utils.json", floe_utils), ("forcings.json", forcings)):
+    for name, fn in (("collisions.json", collisions), ("floe_utils.json", floe_utils), ("forcings.json", forcings),
+                     ("update_floe.json", update_floe)):
         with open(os.path.join(HERE, name), "w") as f:
             json.dump(fn(), f, indent=1)
         print("wrote", name)

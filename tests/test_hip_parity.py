@@ -19,6 +19,16 @@ def omk():
     return orc.World()
 
 
+def test_stress_strain(golden):
+    """calc_stress! / calc_strain! on the two floes of the reference's stress_strain.jld2 fixture"""
+    U = golden["update_floe"]
+    w = cases.run_stress_strain(mk, U)
+    cases.check_stress_strain(w, U)
+    o = cases.run_stress_strain(omk, U)
+    for k in ("si11", "si12", "si22", "sa11", "sa22", "e11", "e22"):
+        assert parity.relerr(w.get(k), o.get(k)) < 1e-12, k
+
+
 # ---------------------------------------------------------------- the reference's known answers, through the C-ABI
 @pytest.mark.parametrize("k", range(5))
 def test_floe_floe(golden, k):

@@ -2,7 +2,7 @@
 
 This pins the oracle: every literal-input test of the reference's
 test_collisions.jl, the moment-of-inertia values of test_floe_utils.jl and the OA-forcing
-values of test_coupling.jl must be reproduced before the oracle is trusted as the checker
+values of test_coupling.jl and the stress / strain values of test_update_floe.jl must be reproduced before the oracle is trusted as the checker
 for the HIP path.
 """
 import numpy as np
@@ -75,3 +75,8 @@ def test_forcings(golden, k):
     F = golden["forcings"]
     case = F["cases"][k]
     cases.check_forcing(cases.run_forcing(mk, F, case), case)
+
+
+def test_stress_strain(golden):
+    U = golden["update_floe"]
+    cases.check_stress_strain(cases.run_stress_strain(mk, U), U)
