@@ -94,6 +94,8 @@ typedef struct {
   int64_t n_trace_fail;         /* clip traces abandoned (self-intersecting input / round-off), cumulative */
   int64_t n_halo;               /* halo floes received in the last tiled step */
   int64_t n_pairs_clipped;      /* pairs with overlapping ring boxes: the pair items the narrow phase ran */
+  int64_t n_status_remove;      /* floes tagged remove / fuse: when both are zero the host-side simplify_floes!  */
+  int64_t n_status_fuse;        /* (simulation.jl:206) has no removal or fusion to do and needs no download       */
   int64_t n_retry;              /* narrow-phase items redone by the largest kernel variant (working set overflow), cumulative */
 } sz_stats;
 

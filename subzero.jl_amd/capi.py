@@ -45,7 +45,7 @@ class SzStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in
                 ("M", "N", "n_ring_points", "n_sub_points", "n_pairs", "n_pair_ring_points", "n_pair_rows",
                  "n_elem_items", "n_elem_rows", "n_inter_rows", "n_ghosts",
-                 "warn_height", "warn_force", "warn_vel", "warn_xi", "n_trace_fail", "n_halo", "n_pairs_clipped", "n_retry")]
+                 "warn_height", "warn_force", "warn_vel", "warn_xi", "n_trace_fail", "n_halo", "n_pairs_clipped", "n_status_remove", "n_status_fuse", "n_retry")]
 
 
 EXPORTS = [

@@ -402,7 +402,7 @@ sz_ctx* sz_create(int device_id) {
   P.E = 6e6; P.nu = 0.3; P.mu = 0.2; P.rho_o = 1027.0; P.rho_a = 1.2; P.Cd_io = 3e-3; P.Cd_ia = 1e-3;
   P.fcor = 1.4e-4; P.turn = 15.0 * 3.14159265358979323846 / 180.0; P.ff_max_overlap = 0.55; P.fd_max_overlap = 0.75;
   P.rho_i = 920.0; P.max_h = 10.0; P.max_xi = 1e-5; P.lambda = 0.2; P.dd = 1;
-  if (hipMalloc((void**)&c->d_stats, 4 * sizeof(long long)) != hipSuccess) { delete c; return nullptr; }
+  if (hipMalloc((void**)&c->d_stats, 8 * sizeof(long long)) != hipSuccess) { delete c; return nullptr; }
   return c;
 }
 
@@ -565,9 +565,9 @@ int sz_get_stats(sz_ctx* c, sz_stats* out) {
   (void)hipSetDevice(c->device);
   tile_cleanup(c);
   State& S = c->S;
-  HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 4 * sizeof(long long), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(long long), c->stream));
   hipLaunchKernelGGL(sz_k_stats, dim3(grid_for((long long)S.capPairs + S.capElem, 256, 1024)), dim3(256), 0, c->stream, S, c->d_stats);
-  int h[C_COUNT]; long long st[4];
+  int h[C_COUNT]; long long st[8];
   HIPCHK(c, hipMemcpyAsync(st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(h, S.cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -580,6 +580,7 @@ int sz_get_stats(sz_ctx* c, sz_stats* out) {
   out->n_trace_fail = h[C_TRACE_FAIL];
   out->n_halo = h[C_NHALO];
   out->n_pairs_clipped = h[C_NWORK];
+  out->n_status_remove = st[4]; out->n_status_fuse = st[5];
   out->n_retry = h[C_NRETRY];
   return SZ_OK;
 }

@@ -1317,9 +1317,16 @@ __global__ void sz_k_stats(State S, long long* out) {
   atomicAdd((unsigned long long*)&out[0], (unsigned long long)a);
   atomicAdd((unsigned long long*)&out[1], (unsigned long long)b);
   atomicAdd((unsigned long long*)&out[2], (unsigned long long)c);
-  long long d = 0;
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < S.cnt[C_M]; k += gridDim.x * blockDim.x) d += S.inter_cnt[k];
+  // out[4], out[5]: floes tagged remove / fuse (what simplify_floes!, simulation.jl:206, has to act on)
+  long long d = 0, nr = 0, nf = 0;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < S.cnt[C_M]; k += gridDim.x * blockDim.x) {
+    d += S.inter_cnt[k];
+    int st = S.status[k];
+    nr += st == SZ_REMOVE; nf += st == SZ_FUSE;
+  }
   atomicAdd((unsigned long long*)&out[3], (unsigned long long)d);
+  if (nr) atomicAdd((unsigned long long*)&out[4], (unsigned long long)nr);
+  if (nf) atomicAdd((unsigned long long*)&out[5], (unsigned long long)nf);
 }
 
 }  // namespace sz

@@ -89,6 +89,10 @@ def test_collisions_walls_topography():
     parity.compare_worlds(hw, ow, rtol=1e-10, fields=["coll_fx", "coll_fy", "coll_trq", "overarea"])
     rows = ow.interactions()[1]
     assert np.any(rows[:, 0] < 0)      # boundary / topography contacts exist
+    # the tag counts a host uses to skip simplify_floes! when nothing was removed or fused
+    st = hw.stats(); tags = hw.ids()[2]
+    assert st["n_status_remove"] == int((tags == cases.REMOVE).sum()) and st["n_status_fuse"] == int((tags == cases.FUSE).sum())
+    assert st["n_status_remove"] == int((ow.ids()[2] == cases.REMOVE).sum()) > 0
 
 
 def test_moving_boundary_compression():
