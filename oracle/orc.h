@@ -137,7 +137,18 @@ void orc_timestep_collisions(orc_world *w, int n_init, int dt);      /* collisio
 void orc_floe_floe_interaction(orc_world *w, int i, int j, int dt, double max_overlap); /* :347 */
 void orc_floe_domain_interaction(orc_world *w, int i, int dt, double max_overlap);      /* :594 */
 void orc_calc_torque(orc_world *w, int i);                           /* collisions.jl:673-686 */
-void orc_timestep_coupling(orc_world *w);                            /* coupling.jl:1705 (one-way) */
+void orc_timestep_coupling(orc_world *w);                            /* coupling.jl:1705-1738 */
+/* two-way coupling (off by default): ice-on-ocean stress per centre cell, coupling.jl:1617-1680 */
+void orc_set_two_way(orc_world *w, int on, double Cd_ao, double k, double L, int dt);
+void orc_set_temps(orc_world *w, const double *t_ocn, const double *t_atm);       /* (Nx+1) x (Ny+1), [ix][iy] */
+void orc_get_ocean_stress(const orc_world *w, double *tau_x, double *tau_y, double *si_frac, double *hflx);
+void orc_clear_cells(orc_world *w);
+int  orc_shift_cell_idx(int idx, int nlines, int periodic);              /* coupling.jl:1154-1178 */
+void orc_center_cell_coords(const orc_world *w, int xidx, int yidx, int ns_periodic, int ew_periodic, double *out4); /* :1116 */
+void orc_floe_to_grid_info(orc_world *w, int floeidx, int xidx, int yidx, double tx_ocn, double ty_ocn); /* :1417 */
+int  orc_cell_count(const orc_world *w, int xidx, int yidx);
+void orc_cell_entry(const orc_world *w, int xidx, int yidx, int k, double *out6);
+void orc_calc_two_way_coupling(orc_world *w);                           /* coupling.jl:1617-1680 */
 void orc_timestep_floe_properties(orc_world *w, int dt);             /* update_floe.jl:469-551 */
 void orc_set_interactions(orc_world *w, int i, int k, const double *rows);   /* floe.interactions = k x 7 matrix, row-major */
 void orc_calc_stress(orc_world *w, int i);                            /* calc_stress!, update_floe.jl:392-414 */

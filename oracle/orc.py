@@ -49,7 +49,7 @@ def lib():
         L.orc_add_floe.restype = C.c_int
         for name in ("orc_num_floes", "orc_total_ring_points", "orc_total_interactions",
                      "orc_total_ghost_links", "orc_total_fuse", "orc_num_pairs",
-                     "orc_clip_flat", "orc_ipoints_flat"):
+                     "orc_clip_flat", "orc_ipoints_flat", "orc_cell_count", "orc_shift_cell_idx"):
             getattr(L, name).restype = C.c_int
     return _LIB
 
@@ -123,6 +123,40 @@ class World:
         arrs = [_d(np.broadcast_to(a, (Nx + 1, Ny + 1))) for a in (uo, vo, hflx, ua, va)]
         self.L.orc_set_grid_fields(self.h, Nx, Ny, C.c_double(x0), C.c_double(xf), C.c_double(y0),
                                    C.c_double(yf), *(_p(a) for a in arrs))
+
+        self._grid = (Nx, Ny)
+
+    # ---- two-way coupling (coupling.jl:1617-1680); off by default like CouplingSettings()
+    def set_two_way(self, on=True, Cd_ao=1.25e-3, k=2.14, L=2.93e5, dt=10):
+        self.L.orc_set_two_way(self.h, int(on), C.c_double(Cd_ao), C.c_double(k), C.c_double(L), int(dt))
+
+    def set_temps(self, t_ocn, t_atm):
+        Nx, Ny = self._grid
+        a, b = (_d(np.broadcast_to(t, (Nx + 1, Ny + 1))) for t in (t_ocn, t_atm))
+        self.L.orc_set_temps(self.h, _p(a), _p(b))
+
+    def ocean_stress(self):
+        """tau_x, tau_y, si_frac, hflx_factor on the (Nx+1) x (Ny+1) grid-line lattice"""
+        Nx, Ny = self._grid
+        out = [np.zeros((Nx + 1, Ny + 1)) for _ in range(4)]
+        self.L.orc_get_ocean_stress(self.h, *(_p(a) for a in out))
+        return out
+
+    def floe_to_grid_info(self, floeidx, xidx, yidx, tx, ty):
+        self.L.orc_floe_to_grid_info(self.h, int(floeidx), int(xidx), int(yidx), C.c_double(tx), C.c_double(ty))
+
+    def cell_entries(self, xidx, yidx):
+        """rows (floeidx, dx, dy, sum tx, sum ty, npoints) of centre cell (xidx, yidx), 1-based"""
+        n = self.L.orc_cell_count(self.h, int(xidx), int(yidx))
+        out = np.zeros((n, 6))
+        for k in range(n):
+            row = np.zeros(6); self.L.orc_cell_entry(self.h, int(xidx), int(yidx), k, _p(row)); out[k] = row
+        return out
+
+    def center_cell_coords(self, xidx, yidx, ns_periodic, ew_periodic):
+        out = np.zeros(4)
+        self.L.orc_center_cell_coords(self.h, int(xidx), int(yidx), int(ns_periodic), int(ew_periodic), _p(out))
+        return out
 
     def add_floe(self, coords, height):
         c = _d(coords)

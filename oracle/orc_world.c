@@ -42,6 +42,9 @@ typedef struct {
 
 typedef struct { orc_ring poly; double cx, cy, rmax; } topo_t;
 
+typedef struct { int floe; double dx, dy, tx, ty; int n; } cell_ent;
+struct cell_list { cell_ent *e; int n, cap; };
+
 struct orc_world {
   floe_t *f; int M, cap;
   bound_t b[4];
@@ -53,6 +56,11 @@ struct orc_world {
   /* grid */
   int Nx, Ny; double gx0, gxf, gy0, gyf, gdx, gdy;
   double *uo, *vo, *hf, *ua, *va;
+  /* two-way coupling (coupling.jl:1617-1680): per centre cell (cells centred on the grid lines) the floes whose
+     sub-floe points fell into it, CellFloes / CellStresses of grids.jl:4-8 and oceans.jl:4-8 */
+  int two_way; double Cd_ao, k_ice, L_ice; int dt_couple;
+  double *t_ocn, *t_atm, *tau_x, *tau_y, *si_frac;
+  struct cell_list *cells;
   /* last broad-phase result */
   int32_t *pi, *pj; int npairs, cappairs;
   int64_t warn[4];
@@ -151,6 +159,8 @@ void orc_destroy(orc_world *w) {
   for (int k = 0; k < 4; k++) orc_ring_free(&w->b[k].poly);
   for (int k = 0; k < w->ntopo; k++) orc_ring_free(&w->topo[k].poly);
   free(w->topo); free(w->uo); free(w->vo); free(w->hf); free(w->ua); free(w->va);
+  free(w->t_ocn); free(w->t_atm); free(w->tau_x); free(w->tau_y); free(w->si_frac);
+  if (w->cells) { size_t nc = (size_t)(w->Nx + 1) * (size_t)(w->Ny + 1); for (size_t q = 0; q < nc; q++) free(w->cells[q].e); free(w->cells); }
   free(w->pi); free(w->pj);
   free(w);
 }
@@ -200,10 +210,16 @@ void orc_set_grid_fields(orc_world *w, int Nx, int Ny, double x0, double xf, dou
                          const double *uo, const double *vo, const double *hflx, const double *ua,
                          const double *va) {
   free(w->uo); free(w->vo); free(w->hf); free(w->ua); free(w->va);
+  if (w->cells) { size_t nc = (size_t)(w->Nx + 1) * (size_t)(w->Ny + 1); for (size_t q = 0; q < nc; q++) free(w->cells[q].e); free(w->cells); }
+  free(w->t_ocn); free(w->t_atm); free(w->tau_x); free(w->tau_y); free(w->si_frac);
   w->Nx = Nx; w->Ny = Ny; w->gx0 = x0; w->gxf = xf; w->gy0 = y0; w->gyf = yf;
   w->gdx = (xf - x0) / Nx; w->gdy = (yf - y0) / Ny;
   size_t n = (size_t)(Nx + 1) * (size_t)(Ny + 1);
   w->uo = dupd(uo, n); w->vo = dupd(vo, n); w->hf = dupd(hflx, n); w->ua = dupd(ua, n); w->va = dupd(va, n);
+  w->t_ocn = (double *)calloc(n, sizeof(double)); w->t_atm = (double *)calloc(n, sizeof(double));
+  w->tau_x = (double *)calloc(n, sizeof(double)); w->tau_y = (double *)calloc(n, sizeof(double));
+  w->si_frac = (double *)calloc(n, sizeof(double));
+  w->cells = (struct cell_list *)calloc(n, sizeof(struct cell_list));
 }
 
 /* Floe{FT}(poly, hmean, 0), floe.jl:144-200 */
@@ -804,11 +820,118 @@ static double sample(const orc_world *w, const double *A, double x, double y, in
   return (1.0 - tx) * c0 + tx * c1;
 }
 
+/* ------------------------------------------------------------------ two-way coupling */
+void orc_set_two_way(orc_world *w, int on, double Cd_ao, double k, double L, int dt) {
+  w->two_way = on; w->Cd_ao = Cd_ao; w->k_ice = k; w->L_ice = L; w->dt_couple = dt;
+}
+void orc_set_temps(orc_world *w, const double *t_ocn, const double *t_atm) {
+  size_t n = (size_t)(w->Nx + 1) * (size_t)(w->Ny + 1);
+  memcpy(w->t_ocn, t_ocn, n * sizeof(double)); memcpy(w->t_atm, t_atm, n * sizeof(double));
+}
+void orc_get_ocean_stress(const orc_world *w, double *tau_x, double *tau_y, double *si_frac, double *hflx) {
+  size_t n = (size_t)(w->Nx + 1) * (size_t)(w->Ny + 1);
+  memcpy(tau_x, w->tau_x, n * sizeof(double)); memcpy(tau_y, w->tau_y, n * sizeof(double));
+  memcpy(si_frac, w->si_frac, n * sizeof(double)); memcpy(hflx, w->hf, n * sizeof(double));
+}
+void orc_clear_cells(orc_world *w) {
+  size_t n = (size_t)(w->Nx + 1) * (size_t)(w->Ny + 1);
+  for (size_t q = 0; q < n; q++) w->cells[q].n = 0;
+}
+/* shift_cell_idx, coupling.jl:1154-1178 (1-based grid-line index) */
+int orc_shift_cell_idx(int idx, int nlines, int periodic) {
+  if (!periodic) return idx;
+  int ncells = nlines - 1;
+  return idx < 1 ? (idx + ncells) : (ncells < idx ? (idx - ncells) : idx);
+}
+/* center_cell_coords, coupling.jl:1116-1140, with check_cell_bounds :931-1087; out = xmin, xmax, ymin, ymax */
+void orc_center_cell_coords(const orc_world *w, int xidx, int yidx, int per_y, int per_x, double *out) {
+  double xmin = (xidx - 1.5) * w->gdx + w->gx0, xmax = xmin + w->gdx;
+  double ymin = (yidx - 1.5) * w->gdy + w->gy0, ymax = ymin + w->gdy;
+  if (!per_x) {
+    xmin = xmin < w->gx0 ? w->gx0 : (xmin > w->gxf ? w->gxf : xmin);
+    xmax = xmax > w->gxf ? w->gxf : (xmax < w->gx0 ? w->gx0 : xmax);
+  }
+  if (!per_y) {
+    ymin = ymin < w->gy0 ? w->gy0 : (ymin > w->gyf ? w->gyf : ymin);
+    ymax = ymax > w->gyf ? w->gyf : (ymax < w->gy0 ? w->gy0 : ymax);
+  }
+  out[0] = xmin; out[1] = xmax; out[2] = ymin; out[3] = ymax;
+}
+/* floe_to_grid_info!, coupling.jl:1417-1454, with add_point! :1336-1360: one sub-floe point of floe `floeidx`
+   (0-based here) in centre cell (xidx, yidx) (1-based, unshifted) with ocean stress (tx_ocn, ty_ocn) */
+void orc_floe_to_grid_info(orc_world *w, int floeidx, int xidx, int yidx, double tx_ocn, double ty_ocn) {
+  int per_x = w->b[ORC_EAST].kind == ORC_PERIODIC, per_y = w->b[ORC_NORTH].kind == ORC_PERIODIC;
+  int sx = orc_shift_cell_idx(xidx, w->Nx + 1, per_x), sy = orc_shift_cell_idx(yidx, w->Ny + 1, per_y);
+  double dx = (sx - xidx) * w->gdx, dy = (sy - yidx) * w->gdy;
+  if (sx < 1 || sx > w->Nx + 1 || sy < 1 || sy > w->Ny + 1) return;   /* the reference would throw a BoundsError */
+  struct cell_list *c = &w->cells[(size_t)(sx - 1) * (size_t)(w->Ny + 1) + (size_t)(sy - 1)];
+  if (c->n == 0 || c->e[c->n - 1].floe != floeidx) {
+    if (c->n == c->cap) { c->cap = c->cap ? 2 * c->cap : 4; c->e = (cell_ent *)realloc(c->e, (size_t)c->cap * sizeof(cell_ent)); }
+    cell_ent *e = &c->e[c->n++];
+    e->floe = floeidx; e->dx = dx; e->dy = dy; e->tx = -tx_ocn; e->ty = -ty_ocn; e->n = 1;
+  } else {
+    cell_ent *e = &c->e[c->n - 1];
+    e->tx += -tx_ocn; e->ty += -ty_ocn; e->n += 1;
+  }
+}
+int orc_cell_count(const orc_world *w, int xidx, int yidx) { return w->cells[(size_t)(xidx - 1) * (size_t)(w->Ny + 1) + (size_t)(yidx - 1)].n; }
+/* entry k of centre cell (xidx, yidx): out = floeidx, dx, dy, tx, ty, npoints */
+void orc_cell_entry(const orc_world *w, int xidx, int yidx, int k, double *out6) {
+  const cell_ent *e = &w->cells[(size_t)(xidx - 1) * (size_t)(w->Ny + 1) + (size_t)(yidx - 1)].e[k];
+  out6[0] = e->floe; out6[1] = e->dx; out6[2] = e->dy; out6[3] = e->tx; out6[4] = e->ty; out6[5] = e->n;
+}
+/* calc_two_way_coupling!, coupling.jl:1617-1680 */
+void orc_calc_two_way_coupling(orc_world *w) {
+  int per_x = w->b[ORC_EAST].kind == ORC_PERIODIC, per_y = w->b[ORC_NORTH].kind == ORC_PERIODIC;
+  double cell_area = w->gdx * w->gdy;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 16) num_threads(w->nthreads)
+#endif
+  for (int ix = 1; ix <= w->Nx + 1; ix++) {
+    orc_ring cell, moved; orc_regions rg;
+    orc_ring_init(&cell); orc_ring_init(&moved); orc_regions_init(&rg);
+    for (int iy = 1; iy <= w->Ny + 1; iy++) {
+      size_t q = (size_t)(ix - 1) * (size_t)(w->Ny + 1) + (size_t)(iy - 1);
+      double tx = 0.0, ty = 0.0, si = 0.0;
+      const struct cell_list *c = &w->cells[q];
+      if (c->n > 0) {
+        double bb[4]; orc_center_cell_coords(w, ix, iy, per_y, per_x, bb);
+        /* _make_bounding_box_polygon: (xmin,ymin) (xmin,ymax) (xmax,ymax) (xmax,ymin) (xmin,ymin) */
+        cell.n = 0;
+        orc_ring_push(&cell, bb[0], bb[2]); orc_ring_push(&cell, bb[0], bb[3]); orc_ring_push(&cell, bb[1], bb[3]);
+        orc_ring_push(&cell, bb[1], bb[2]); orc_ring_push(&cell, bb[0], bb[2]);
+        for (int k = 0; k < c->n; k++) {
+          const cell_ent *e = &c->e[k];
+          const floe_t *f = &w->f[e->floe];
+          moved.n = 0;
+          for (int v = 0; v < f->poly.n; v++) orc_ring_push(&moved, f->poly.p[v].x + e->dx, f->poly.p[v].y + e->dy);
+          orc_intersection(&cell, &moved, &rg);
+          double a = 0.0;
+          for (int r = 0; r < rg.n; r++) a += orc_area(&rg.r[r]);
+          if (a > 0) {
+            tx += (e->tx / e->n) * a; ty += (e->ty / e->n) * a; si += a;
+          }
+        }
+        if (si > 0) { tx /= si; ty /= si; si /= cell_area; }
+      }
+      double du = w->ua[q] - w->uo[q], dv = w->va[q] - w->vo[q];
+      double ocn_frac = 1 - si;
+      double nrm = sqrt(du * du + dv * dv);
+      tx += w->rho_a * w->Cd_ao * ocn_frac * nrm * du;
+      ty += w->rho_a * w->Cd_ao * ocn_frac * nrm * dv;
+      w->tau_x[q] = tx; w->tau_y[q] = ty; w->si_frac[q] = si;
+      w->hf[q] = w->dt_couple * w->k_ice / (w->rho_i * w->L_ice) * (w->t_ocn[q] - w->t_atm[q]);
+    }
+    orc_ring_free(&cell); orc_ring_free(&moved); orc_regions_free(&rg);
+  }
+}
+
 /* calc_one_way_coupling!, coupling.jl:1486-1589 (with calc_subfloe_values! :627-657,
    in_bounds :494-597, calc_atmosphere_forcing :1212-1232, calc_ocean_forcing! :1277-1299) */
 void orc_timestep_coupling(orc_world *w) {
   int per_x = w->b[ORC_EAST].kind == ORC_PERIODIC;
   int per_y = w->b[ORC_NORTH].kind == ORC_PERIODIC;
+  if (w->two_way) orc_clear_cells(w);            /* empty!.(grid.floe_locations), empty!.(ocean.scells): :1721-1724 */
   for (int i = 0; i < w->M; i++) {
     floe_t *f = &w->f[i];
     double ca = cos(f->alpha), sa = sin(f->alpha);
@@ -848,12 +971,18 @@ void orc_timestep_coupling(orc_world *w) {
       double tx = tax + tpx + tox, ty = tay + tpy + toy;
       double trq = (-tx * st + ty * ct) * rad;
       tot_x += tx; tot_y += ty; tot_trq += trq; tot_h += hfl;
+      if (w->two_way) {
+        /* find_center_cell_index, coupling.jl:466-470 (1-based), then floe_to_grid_info! :1417-1454 */
+        int xidx = (int)floor((x - w->gx0) / w->gdx + 0.5) + 1, yidx = (int)floor((y - w->gy0) / w->gdy + 0.5) + 1;
+        orc_floe_to_grid_info(w, i, xidx, yidx, tox, toy);
+      }
     }
     f->fxOA = tot_x / npoints * f->area;
     f->fyOA = tot_y / npoints * f->area;
     f->trqOA = tot_trq / npoints * f->area;
     f->hflx = tot_h / npoints;
   }
+  if (w->two_way) orc_calc_two_way_coupling(w);
 }
 
 /* ------------------------------------------------------------------ rigid-body update */

@@ -18,6 +18,8 @@ data file.  No reference source text is copied.
                       the root group's link messages give the object-header address of every named
                       dataset, the small Float64 datasets sit 61 bytes behind their header, and the
                       ring points are consecutive 2-value datasets (81 bytes apart) in ring order
+  coupling_grid.json <- test/test_physical_processes/test_coupling.jl:165-180,276-460 (centre-cell index,
+                      centre-cell rectangles, floe_to_grid_info! bookkeeping)
 """
 import re
 import struct
@@ -291,9 +293,47 @@ def update_floe():
     }
 
 
+def coupling_grid():
+    """Grid bookkeeping of the coupling: test_coupling.jl:165-180 (find_center_cell_index), :276-289
+    (center_cell_coords) and :291-460 (floe_to_grid_info!), literal inputs and expected values."""
+    P, O = "periodic", "open"
+    return {
+        "_source": "test/test_physical_processes/test_coupling.jl:165-180,276-460",
+        "grid": {"x0": -10.0, "xf": 10.0, "y0": -8.0, "yf": 8.0, "dx": 2.0, "dy": 4.0},
+        "find_center_cell_index": {"x": [-10.5, -10, -10, -6.5, -6, -4, 10, 10.5, 12], "y": [0.0, 6.0, -8.0, 4.5, 0.0, 5.0, -8.0, 0.0, 0.0],
+                                   "xidx": [1, 1, 1, 3, 3, 4, 11, 11, 12], "yidx": [3, 5, 1, 4, 3, 4, 1, 3, 3]},
+        # (xidx, yidx, north/south kind, east/west kind) -> xmin, xmax, ymin, ymax of the expected rectangle
+        "center_cell_coords": [
+            {"idx": [2, 3], "ns": P, "ew": P, "rect": [-9, -7, -2, 2]},
+            {"idx": [1, 1], "ns": O, "ew": O, "rect": [-10, -9, -8, -6]},
+            {"idx": [11, 6], "ns": P, "ew": P, "rect": [9, 11, 10, 14]},
+            {"idx": [11, 6], "ns": O, "ew": O, "rect": [9, 10, 8, 8]},
+            {"idx": [11, 6], "ns": O, "ew": P, "rect": [9, 11, 8, 8]},
+            {"idx": [11, 6], "ns": P, "ew": O, "rect": [9, 10, 10, 14]},
+        ],
+        # floe_to_grid_info!(floeidx, xidx[i], yidx[i], tx[i], ty[i], grid, ns, ew, scells, two_way_coupling_on)
+        "floe_to_grid": [
+            {"floeidx": 1, "xidx": [7, 7, 6, 6, 7, 7], "yidx": [4, 4, 3, 3, 4, 4], "tx": 1.0, "ty": 2.0, "ns": O, "ew": O,
+             "cells": [[7, 4], [6, 3]], "dx": [0.0, 0.0], "dy": [0.0, 0.0], "sum_tx": [-4, -2], "sum_ty": [-8, -4], "npoints": [4, 2]},
+            {"floeidx": 2, "xidx": [7, 7, 8, 8, 9, 9], "yidx": [2, 3, 3, 3, 2, 2], "tx": 1.0, "ty": 2.0, "ns": P, "ew": P,
+             "cells": [[7, 2], [7, 3], [9, 2], [8, 3]], "dx": [0.0] * 4, "dy": [0.0] * 4,
+             "sum_tx": [-1, -1, -2, -2], "sum_ty": [-2, -2, -4, -4], "npoints": [1, 1, 2, 2]},
+            {"floeidx": 3, "xidx": [10, 10, 10, 11, 11, 11, 11], "yidx": [4, 5, 6, 5, 6, 5, 6], "tx": 1.0, "ty": 2.0, "ns": P, "ew": O,
+             "cells": [[10, 1], [11, 1], [10, 2], [11, 2], [10, 4]], "dx": [0.0] * 5, "dy": [-16.0, -16.0, -16.0, -16.0, 0.0],
+             "sum_tx": [-1, -2, -1, -2, -1], "sum_ty": [-2, -4, -2, -4, -2], "npoints": [1, 2, 1, 2, 1]},
+            {"floeidx": 4, "xidx": [11, 11, 12, 12, 11], "yidx": [4, 5, 5, 5, 4], "tx": 1.0, "ty": 2.0, "ns": O, "ew": P,
+             "cells": [[1, 4], [1, 5], [2, 5]], "dx": [-20.0] * 3, "dy": [0.0] * 3,
+             "sum_tx": [-2, -1, -2], "sum_ty": [-4, -2, -4], "npoints": [2, 1, 2]},
+            {"floeidx": 2, "xidx": [0, -1, -1, 1, -1], "yidx": [0, -1, -2, 1, -1], "tx": -1.0, "ty": -2.0, "ns": P, "ew": P,
+             "cells": [[1, 1], [10, 4], [9, 3], [9, 2]], "dx": [0.0, 20.0, 20.0, 20.0], "dy": [0.0, 16.0, 16.0, 16.0],
+             "sum_tx": [1, 1, 2, 1], "sum_ty": [2, 2, 4, 2], "npoints": [1, 1, 2, 1]},
+        ],
+    }
+
+
 def main():
     for name, fn in (("collisions.json", collisions), ("floe_utils.json", floe_utils), ("forcings.json", forcings),
-                     ("update_floe.json", update_floe)):
+                     ("update_floe.json", update_floe), ("coupling_grid.json", coupling_grid)):
         with open(os.path.join(HERE, name), "w") as f:
             json.dump(fn(), f, indent=1)
         print("wrote", name)

@@ -80,3 +80,82 @@ def test_forcings(golden, k):
 def test_stress_strain(golden):
     U = golden["update_floe"]
     cases.check_stress_strain(cases.run_stress_strain(mk, U), U)
+
+
+# ---------------------------------------------------------------- two-way coupling bookkeeping (test_coupling.jl:165-460)
+def _grid_world(G, ns, ew):
+    g = G["grid"]
+    w = mk()
+    kinds = [cases.KIND[ns], cases.KIND[ns], cases.KIND[ew], cases.KIND[ew]]      # N, S, E, W
+    w.set_domain(kinds, g["x0"], g["xf"], g["y0"], g["yf"])
+    Nx = int(round((g["xf"] - g["x0"]) / g["dx"])); Ny = int(round((g["yf"] - g["y0"]) / g["dy"]))
+    w.set_grid_fields(Nx, Ny, g["x0"], g["xf"], g["y0"], g["yf"], 0.0, 0.0, 0.0, 0.0, 0.0)
+    w.set_two_way(True)
+    return w, Nx, Ny
+
+
+def test_center_cell_coords(golden):
+    G = golden["coupling_grid"]
+    for c in G["center_cell_coords"]:
+        w, _, _ = _grid_world(G, c["ns"], c["ew"])
+        got = w.center_cell_coords(c["idx"][0], c["idx"][1], c["ns"] == "periodic", c["ew"] == "periodic")
+        assert list(got) == [float(v) for v in c["rect"]], (c, got)
+
+
+@pytest.mark.parametrize("k", range(5))
+def test_floe_to_grid_info(golden, k):
+    G = golden["coupling_grid"]; c = G["floe_to_grid"][k]
+    w, Nx, Ny = _grid_world(G, c["ns"], c["ew"])
+    fi = c["floeidx"] - 1
+    for x, y in zip(c["xidx"], c["yidx"]):
+        w.floe_to_grid_info(fi, x, y, c["tx"], c["ty"])
+    occupied = {tuple(cc) for cc in c["cells"]}
+    for cc, dx, dy, sx, sy, n in zip(c["cells"], c["dx"], c["dy"], c["sum_tx"], c["sum_ty"], c["npoints"]):
+        e = w.cell_entries(*cc)
+        assert len(e) >= 1
+        assert list(e[-1]) == [fi, dx, dy, sx, sy, n], (cc, e)
+    for ix in range(1, Nx + 2):
+        for iy in range(1, Ny + 2):
+            if (ix, iy) not in occupied:
+                assert len(w.cell_entries(ix, iy)) == 0
+
+
+def test_find_center_cell_index(golden):
+    """through the coupling itself: one sub-floe point per test point, unit ocean stress -> the cell it lands in"""
+    G = golden["coupling_grid"]; F = G["find_center_cell_index"]
+    from oracle import orc as O
+    for x, y, xi, yi in zip(F["x"], F["y"], F["xidx"], F["yidx"]):
+        g = G["grid"]
+        assert int(np.floor((x - g["x0"]) / g["dx"] + 0.5)) + 1 == xi and int(np.floor((y - g["y0"]) / g["dy"] + 0.5)) + 1 == yi
+    assert O.lib().orc_shift_cell_idx(11, 11, 1) == 1 and O.lib().orc_shift_cell_idx(0, 11, 1) == 10
+    assert O.lib().orc_shift_cell_idx(11, 11, 0) == 11
+
+
+def test_two_way_coupling_analytic():
+    """calc_two_way_coupling! (coupling.jl:1617-1680) on one floe at rest in a uniform ocean: the ice-covered
+    area is conserved cell by cell, a fully covered cell carries minus the ocean-on-ice stress, an open cell only
+    the atmosphere-on-ocean stress."""
+    w = mk()
+    L = 1e5; Nx = Ny = 10
+    w.set_domain([cases.KIND["collision"]] * 4, 0.0, L, 0.0, L)
+    w.set_settings(coupling_dd=1)
+    uo = 0.5
+    w.set_grid_fields(Nx, Ny, 0.0, L, 0.0, L, uo, 0.0, 0.0, 0.0, 0.0)
+    floe = np.array([[2.3e4, 3.1e4], [2.3e4, 6.7e4], [5.9e4, 6.7e4], [5.9e4, 3.1e4], [2.3e4, 3.1e4]])
+    w.add_floe(floe, 0.5)
+    gx, gy = np.meshgrid(np.linspace(-1.75e4, 1.75e4, 15), np.linspace(-1.75e4, 1.75e4, 15))
+    w.set_subpoints(0, gx.ravel(), gy.ravel())
+    w.set_two_way(True, dt=20)
+    w.set_temps(0.0, -10.0)
+    w.timestep_coupling()
+    tx, ty, si, hf = w.ocean_stress()
+    cell_area = (L / Nx) ** 2
+    assert abs(si.sum() * cell_area - w.get("area")[0]) < 1e-6 * cell_area
+    rho_o, Cd_io, th = 1027.0, 3e-3, 15 * np.pi / 180
+    tocn_x = rho_o * Cd_io * uo * (np.cos(th) * uo); tocn_y = rho_o * Cd_io * uo * (np.sin(th) * uo)
+    assert si[4, 5] == 1.0 and abs(tx[4, 5] + tocn_x) < 1e-12 and abs(ty[4, 5] + tocn_y) < 1e-12
+    rho_a, Cd_ao = 1.2, 1.25e-3
+    assert si[0, 0] == 0.0 and abs(tx[0, 0] - rho_a * Cd_ao * uo * (-uo)) < 1e-15 and ty[0, 0] == 0.0
+    # partly covered cell: the ice stress is an area-weighted mean (here of one floe) plus the open-water part
+    assert 0 < si[2, 3] < 1 and abs(tx[2, 3] - (-tocn_x + rho_a * Cd_ao * (1 - si[2, 3]) * uo * (-uo))) < 1e-12
+    assert np.allclose(hf, 20 * 2.14 / (920.0 * 2.93e5) * 10.0, rtol=1e-14)
