@@ -151,6 +151,17 @@ int sz_collide_pairs(sz_ctx *ctx, int64_t npairs, const int32_t *pi, const int32
 int sz_collide_domain(sz_ctx *ctx, int32_t dt, double max_overlap);
 int sz_timestep_coupling(sz_ctx *ctx);
 int sz_timestep_floe_properties(sz_ctx *ctx, int32_t dt);
+/* ---- two-way coupling: calc_two_way_coupling! (coupling.jl:1617-1680) with floe_to_grid_info! (:1417-1454),
+   center_cell_coords (:1116-1140) and shift_cell_idx (:1154-1178).  Off by default like CouplingSettings().
+   With it on, every coupling step (sz_timestep_coupling, sz_step) also produces the ice+atmosphere stress on the
+   ocean, the sea-ice fraction and the heat-flux factor per centre cell ((Nx+1) x (Ny+1) values, element
+   [ix][iy] at ix*(Ny+1)+iy); the heat-flux factor replaces the hflx lattice given to sz_set_fields, as
+   ocean.hflx_factor is overwritten in the reference.  Cd_ao, k, L: Constants() (simulation.jl:10-14); dt is the
+   timestep used for the heat-flux factor by sz_timestep_coupling (sz_step uses its own).  Not available in
+   tiled (multi-GPU) runs. */
+int sz_set_two_way(sz_ctx *ctx, int32_t on, double Cd_ao, double k, double L, int32_t dt);
+int sz_set_temps(sz_ctx *ctx, const double *t_ocn, const double *t_atm);
+int sz_download_ocean_stress(sz_ctx *ctx, double *tau_x, double *tau_y, double *si_frac, double *hflx);
 /* calc_stress! (update_floe.jl:392-414, with _update_stress_accum!, stress_calculators.jl:118-122) and
    calc_strain! (update_floe.jl:425-453) on their own, for every floe, as the reference's tests call them
    (test_update_floe.jl:10-39).  sz_upload_interactions replaces floe.interactions of every floe by hand-made

@@ -10,6 +10,7 @@
 
 #include "../../include/subzero_hip.h"
 #include "sz_kernels.hpp"
+#include "sz_twoway.hpp"
 
 using namespace sz;
 
@@ -61,6 +62,9 @@ struct sz_ctx {
                                   // SZ_OVERLAP=0/1 forces it off / on.
   int max_ring = 0, max_elem_ring = 5, max_ring_tiled = 0;   // largest ring sizes (host knowledge: which narrow variants can be needed)
   int narrow_grid0 = 0;
+  // two-way coupling (off by default, like CouplingSettings())
+  bool two_way = false; int tw_dt = 10; int tw_capM = 0; size_t tw_ncell = 0;
+  std::vector<void*> tw_allocs, tw_field_allocs;
   bool tile_dirty = false;      // ghosts / halo floes of the last sz_tile_step still appended
   int dbg = 0;   // SZ_DEBUG bits: timing experiments only (1 skip contact rows, 2 skip direction check, 4 skip clip)
 };
@@ -329,14 +333,55 @@ void stage_forcing_fork(sz_ctx* c) {
   (void)hipEventRecord(c->ev_fork, c->stream);
   (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
   Timed t(c, SZ_K_FORCING, c->stream2);
-  hipLaunchKernelGGL(sz_k_forcing, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream2, c->S, c->P);
+  hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream2, c->S, c->P);
   t.end();
   (void)hipEventRecord(c->ev_join, c->stream2);
 }
 void stage_forcing_join(sz_ctx* c) { (void)hipStreamWaitEvent(c->stream, c->ev_join, 0); }
-void stage_forcing(sz_ctx* c) {      // in-order variant (process mode, profiling)
+// buffers of the two-way coupling: per-floe cell slots follow the floe capacity, per-cell arrays the lattice
+int ensure_two_way(sz_ctx* c) {
+  State& S = c->S;
+  const size_t ncell = (size_t)(S.Nx + 1) * (S.Ny + 1);
+  int rc;
+  if (c->tw_field_allocs.empty() || c->tw_ncell != ncell) {
+    free_pool(c->tw_field_allocs);
+    if ((rc = dalloc(c, &S.t_ocn, ncell, c->tw_field_allocs)) || (rc = dalloc(c, &S.t_atm, ncell, c->tw_field_allocs)) ||
+        (rc = dalloc(c, &S.tau_x, ncell, c->tw_field_allocs)) || (rc = dalloc(c, &S.tau_y, ncell, c->tw_field_allocs)) ||
+        (rc = dalloc(c, &S.si_frac, ncell, c->tw_field_allocs)) || (rc = dalloc(c, &S.cl_cnt, ncell + 1, c->tw_field_allocs)) ||
+        (rc = dalloc(c, &S.cl_off, ncell + 2, c->tw_field_allocs)) || (rc = dalloc(c, &S.cl_cur, ncell + 1, c->tw_field_allocs)))
+      return rc;
+    c->tw_ncell = ncell;
+  }
+  if (c->have_floes && (c->tw_allocs.empty() || c->tw_capM != S.capM)) {
+    free_pool(c->tw_allocs);
+    const size_t ne = (size_t)S.capM * FC_CAP;
+    if ((rc = dalloc(c, &S.fc_key, ne, c->tw_allocs)) || (rc = dalloc(c, &S.fc_n, ne, c->tw_allocs)) ||
+        (rc = dalloc(c, &S.fc_cnt, (size_t)S.capM, c->tw_allocs)) || (rc = dalloc(c, &S.fc_code, ne, c->tw_allocs)) ||
+        (rc = dalloc(c, &S.fc_tx, ne, c->tw_allocs)) || (rc = dalloc(c, &S.fc_ty, ne, c->tw_allocs)) ||
+        (rc = dalloc(c, &S.fc_area, ne, c->tw_allocs)) || (rc = dalloc(c, &S.cl_ent, ne, c->tw_allocs)))
+      return rc;
+    c->tw_capM = S.capM;
+  }
+  return SZ_OK;
+}
+void stage_forcing(sz_ctx* c, int dt = -1) {      // in-order variant (process mode, profiling)
   Timed t(c, SZ_K_FORCING);
-  hipLaunchKernelGGL(sz_k_forcing, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream, c->S, c->P);
+  if (!c->two_way) {
+    hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream, c->S, c->P);
+  } else {
+    // timestep_coupling! with two_way_coupling_on (coupling.jl:1705-1738): one-way forcings + per-floe cell slots,
+    // then calc_two_way_coupling! (:1617-1680) as a counting sort by cell, one clip per (floe, cell) entry, a reduction
+    State& S = c->S;
+    const int ncell = (int)c->tw_ncell;
+    hipLaunchKernelGGL(sz_k_forcing<true>, dim3(grid_for(S.capM, TW_FPB, 16384)), dim3(TW_FPB * FRC_G), 0, c->stream, S, c->P);
+    const int ge = grid_for((long long)S.capM * FC_CAP, 256, 8192);
+    hipLaunchKernelGGL(sz_k_tw_count, dim3(ge), dim3(256), 0, c->stream, S);
+    scan(c, S.cl_cnt, S.cl_off, ncell, -1, ncell, C_NENT);
+    hipLaunchKernelGGL(sz_k_tw_fill, dim3(ge), dim3(256), 0, c->stream, S);
+    hipLaunchKernelGGL(sz_k_tw_sort, dim3(grid_for(ncell, 256)), dim3(256), 0, c->stream, S, ncell);
+    hipLaunchKernelGGL(sz_k_tw_area, dim3(grid_for((long long)S.capM * FC_CAP, 64 / TW_G, 4096)), dim3(64), 0, c->stream, S);
+    hipLaunchKernelGGL(sz_k_tw_reduce, dim3(grid_for(ncell, 256)), dim3(256), 0, c->stream, S, c->P, ncell, dt >= 0 ? dt : c->tw_dt);
+  }
   t.end();
 }
 void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc) {
@@ -402,6 +447,7 @@ sz_ctx* sz_create(int device_id) {
   P.E = 6e6; P.nu = 0.3; P.mu = 0.2; P.rho_o = 1027.0; P.rho_a = 1.2; P.Cd_io = 3e-3; P.Cd_ia = 1e-3;
   P.fcor = 1.4e-4; P.turn = 15.0 * 3.14159265358979323846 / 180.0; P.ff_max_overlap = 0.55; P.fd_max_overlap = 0.75;
   P.rho_i = 920.0; P.max_h = 10.0; P.max_xi = 1e-5; P.lambda = 0.2; P.dd = 1;
+  P.Cd_ao = 1.25e-3; P.k_ice = 2.14; P.L_ice = 2.93e5;
   if (hipMalloc((void**)&c->d_stats, 8 * sizeof(long long)) != hipSuccess) { delete c; return nullptr; }
   return c;
 }
@@ -410,7 +456,7 @@ void sz_destroy(sz_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  free_pool(c->allocs); free_pool(c->static_allocs); free_pool(c->field_allocs);
+  free_pool(c->allocs); free_pool(c->static_allocs); free_pool(c->field_allocs); free_pool(c->tw_allocs); free_pool(c->tw_field_allocs);
   for (auto& e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   (void)hipFree(c->d_stats);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -458,7 +504,7 @@ int sz_set_fields(sz_ctx* c, int32_t Nx, int32_t Ny, double x0, double xf, doubl
   (void)hipSetDevice(c->device);
   State& S = c->S;
   size_t n = (size_t)(Nx + 1) * (Ny + 1);
-  free_pool(c->field_allocs);
+  free_pool(c->field_allocs); free_pool(c->tw_field_allocs); c->tw_ncell = 0;
   double** dst[5] = { &S.uo, &S.vo, &S.hf, &S.ua, &S.va };
   const double* src[5] = { uocn, vocn, hflx, uatm, vatm };
   for (int k = 0; k < 5; k++) {
@@ -754,9 +800,38 @@ int sz_timestep_coupling(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   if (!c->have_fields) { c->err = "sz_set_fields must be called before sz_timestep_coupling"; return SZ_E_STATE; }
   (void)hipSetDevice(c->device);
+  if (c->two_way) { if (c->S.tiled) { c->err = "two-way coupling is not available in tiled runs"; return SZ_E_STATE; } int rc = ensure_two_way(c); if (rc) return rc; }
   stage_forcing(c);
   hipLaunchKernelGGL(sz_k_apply_frc, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
   return sync_and_check(c);
+}
+
+// ---- two-way coupling (coupling.jl:1617-1680; CouplingSettings(two_way_coupling_on = true))
+int sz_set_two_way(sz_ctx* c, int32_t on, double Cd_ao, double k, double L, int32_t dt) {
+  if (!c) return SZ_E_ARG;
+  c->two_way = on != 0; c->P.Cd_ao = Cd_ao; c->P.k_ice = k; c->P.L_ice = L; c->tw_dt = dt;
+  return SZ_OK;
+}
+int sz_set_temps(sz_ctx* c, const double* t_ocn, const double* t_atm) {
+  if (!c || !t_ocn || !t_atm) return SZ_E_ARG;
+  if (!c->have_fields) { c->err = "sz_set_fields must be called before sz_set_temps"; return SZ_E_STATE; }
+  (void)hipSetDevice(c->device);
+  int rc = ensure_two_way(c); if (rc) return rc;
+  H2D(c->S.t_ocn, t_ocn, c->tw_ncell, double); H2D(c->S.t_atm, t_atm, c->tw_ncell, double);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SZ_OK;
+}
+int sz_download_ocean_stress(sz_ctx* c, double* tau_x, double* tau_y, double* si_frac, double* hflx) {
+  if (!c || !c->have_fields) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  int rc = ensure_two_way(c); if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t nb = c->tw_ncell * sizeof(double);
+  if (tau_x) HIPCHK(c, hipMemcpy(tau_x, c->S.tau_x, nb, hipMemcpyDeviceToHost));
+  if (tau_y) HIPCHK(c, hipMemcpy(tau_y, c->S.tau_y, nb, hipMemcpyDeviceToHost));
+  if (si_frac) HIPCHK(c, hipMemcpy(si_frac, c->S.si_frac, nb, hipMemcpyDeviceToHost));
+  if (hflx) HIPCHK(c, hipMemcpy(hflx, c->S.hf, nb, hipMemcpyDeviceToHost));
+  return SZ_OK;
 }
 
 int sz_timestep_floe_properties(sz_ctx* c, int32_t dt) {
@@ -806,16 +881,20 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   (void)hipSetDevice(c->device);
   const bool periodic = c->S.any_periodic_ew || c->S.any_periodic_ns;
   const bool coll = (flags & SZ_COLLISIONS_ON) != 0;
+  if (c->two_way && (flags & SZ_COUPLING_ON)) {
+    if (c->S.tiled) { c->err = "two-way coupling is not available in tiled runs"; return SZ_E_STATE; }
+    int rc = ensure_two_way(c); if (rc) return rc;
+  }
   for (int s = 0; s < nsteps; s++) {
     int tstep = tstep0 + s;
     const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
-    const bool overlap = coupling && (c->overlap_forcing < 0 ? c->hostN >= 32768 : c->overlap_forcing != 0);
+    const bool overlap = coupling && !c->two_way && (c->overlap_forcing < 0 ? c->hostN >= 32768 : c->overlap_forcing != 0);
     // with collisions on, the ghosts of step s are detached by the ghost kernels of step s+1 (nothing
     // in between looks past the parents) and committed by the bounds kernel: two launches less
     if (coll) stage_ghosts(c, true);
     if (overlap) stage_forcing_fork(c);      // after the ghost pass: it may wrap a parent around the domain
     if (coll) collisions(c, c->hostN, dt, periodic);
-    if (coupling && !overlap) stage_forcing(c);
+    if (coupling && !overlap) stage_forcing(c, dt);
     if (overlap) stage_forcing_join(c);
     stage_integrate(c, dt, !coll, coupling);
   }

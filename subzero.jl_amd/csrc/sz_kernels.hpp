@@ -968,7 +968,21 @@ __global__ void sz_k_apply_frc(State S) {
     if (S.frc_remove[i]) S.status[i] = SZ_REMOVE;
 }
 constexpr int FRC_G = 32;      // lanes per floe (sub-floe points per floe ~ 100: 32 lanes keep every wavefront resident at 10k floes)
+// Two-way coupling (TW): the kernel also fills the floe's part of grid.floe_locations / ocean.scells
+// (floe_to_grid_info!, coupling.jl:1417-1454): per distinct centre cell its sub-floe points fall into, the
+// periodic shift of the first such point, the sum of minus the ocean stress over the points IN POINT ORDER, and
+// their number.  Points (cell, stress) are parked in LDS; slots are opened in order of first appearance; every
+// lane then owns two slots and walks the points in order.
+constexpr int FC_CAP = 64;      // distinct centre cells per floe
+constexpr int TW_PMAX = 512;    // sub-floe points per floe with two-way coupling on
+constexpr int TW_FPB = 4;       // floes per workgroup of the two-way variant (128 threads)
+template <bool TW>
 __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
+  __shared__ int pkey[TW ? TW_FPB : 1][TW ? TW_PMAX : 1];
+  __shared__ double ptx[TW ? TW_FPB : 1][TW ? TW_PMAX : 1], pty[TW ? TW_FPB : 1][TW ? TW_PMAX : 1];
+  __shared__ signed char pcode[TW ? TW_FPB : 1][TW ? TW_PMAX : 1];
+  __shared__ int skey[TW ? TW_FPB : 1][TW ? FC_CAP : 1];
+  __shared__ signed char scode[TW ? TW_FPB : 1][TW ? FC_CAP : 1];
   int N = S.cnt[C_NOWN];
   int lane = threadIdx.x % FRC_G, wpb = blockDim.x / FRC_G, wid = threadIdx.x / FRC_G;
   int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
@@ -978,6 +992,12 @@ __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
     double ca = S.trig[2 * i], sa = S.trig[2 * i + 1];   // cos(alpha), sin(alpha)
     double ma_ratio = S.mass[i] / S.area[i];
     int o = S.soff[i], ns = S.soff[i + 1] - o;
+    if (TW) {
+      if (ns > TW_PMAX) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_CELLS); ns = TW_PMAX; }
+      gsync();
+      for (int k = lane; k < ns; k += FRC_G) pkey[wid][k] = -1;
+      gsync();
+    }
     double tx = 0, ty = 0, ttrq = 0, th = 0; int np = 0;
     for (int k = lane; k < ns; k += FRC_G) {
       double sxk = S.sx[o + k], syk = S.sy[o + k];
@@ -1007,6 +1027,19 @@ __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
       double tpx = -ma_ratio * P.fcor * vocn, tpy = ma_ratio * P.fcor * uocn;
       double fx = tax + tpx + tox, fy = tay + tpy + toy;
       tx += fx; ty += fy; ttrq += (-fx * st + fy * ct) * rad; th += hfl;
+      if (TW) {
+        // find_center_cell_index (coupling.jl:466-470, 1-based) and shift_cell_idx (:1154-1178)
+        int xidx = (int)floor((x - S.gx0) / S.gdx + 0.5) + 1, yidx = (int)floor((y - S.gy0) / S.gdy + 0.5) + 1;
+        int sxi = xidx, syi = yidx;
+        if (per_x) sxi = xidx < 1 ? xidx + S.Nx : (S.Nx < xidx ? xidx - S.Nx : xidx);
+        if (per_y) syi = yidx < 1 ? yidx + S.Ny : (S.Ny < yidx ? yidx - S.Ny : yidx);
+        if (sxi >= 1 && sxi <= S.Nx + 1 && syi >= 1 && syi <= S.Ny + 1) {
+          pkey[wid][k] = (sxi - 1) * (S.Ny + 1) + (syi - 1);
+          ptx[wid][k] = -tox; pty[wid][k] = -toy;
+          int cx3 = sxi == xidx ? 1 : (sxi > xidx ? 2 : 0), cy3 = syi == yidx ? 1 : (syi > yidx ? 2 : 0);
+          pcode[wid][k] = (signed char)(cx3 + 3 * cy3);
+        }
+      }
     }
     for (int d = FRC_G / 2; d >= 1; d >>= 1) {
       tx += __shfl_xor(tx, d, FRC_G); ty += __shfl_xor(ty, d, FRC_G); ttrq += __shfl_xor(ttrq, d, FRC_G); th += __shfl_xor(th, d, FRC_G);
@@ -1026,6 +1059,44 @@ __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
         S.fxOA[i] = totx / npt * area; S.fyOA[i] = toty / npt * area;
         S.trqOA[i] = ttrq / npt * area; S.hflx[i] = th / npt;
       }
+    }
+    if (TW) {
+      gsync();
+      // slots in order of first appearance (add_point!, coupling.jl:1336-1360, keeps one entry per floe and cell)
+      int nslots = 0;
+      const unsigned long long half = 0xffffffffull << (32 * ((threadIdx.x >> 5) & 1));
+      for (int base = 0; base < ns; base += FRC_G) {
+        const int k = base + lane;
+        bool first = false;
+        if (k < ns && pkey[wid][k] >= 0) {
+          const int key = pkey[wid][k];
+          first = true;
+          for (int s = 0; s < nslots && s < FC_CAP; s++) if (skey[wid][s] == key) { first = false; break; }
+          for (int j = base; first && j < k; j++) if (pkey[wid][j] == key) first = false;
+        }
+        const unsigned long long mask = __ballot(first) & half;
+        if (first) {
+          const int slot = nslots + __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1));
+          if (slot < FC_CAP) { skey[wid][slot] = pkey[wid][k]; scode[wid][slot] = pcode[wid][k]; }
+        }
+        nslots += __popcll(mask);
+        gsync();
+      }
+      if (nslots > FC_CAP) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_CELLS); nslots = FC_CAP; }
+      // ordered sums: lane owns slots lane and lane + 32
+      const int k0 = lane < nslots ? skey[wid][lane] : -2, k1 = lane + 32 < nslots ? skey[wid][lane + 32] : -2;
+      double ax0 = 0, ay0 = 0, ax1 = 0, ay1 = 0; int n0 = 0, n1 = 0;
+      bool f0 = true, f1 = true;
+      for (int j = 0; j < ns; j++) {
+        const int key = pkey[wid][j];
+        if (key == k0) { if (f0) { ax0 = ptx[wid][j]; ay0 = pty[wid][j]; f0 = false; } else { ax0 += ptx[wid][j]; ay0 += pty[wid][j]; } n0++; }
+        if (key == k1) { if (f1) { ax1 = ptx[wid][j]; ay1 = pty[wid][j]; f1 = false; } else { ax1 += ptx[wid][j]; ay1 += pty[wid][j]; } n1++; }
+      }
+      const size_t fb = (size_t)i * FC_CAP;
+      if (lane < nslots) { S.fc_key[fb + lane] = k0; S.fc_code[fb + lane] = scode[wid][lane]; S.fc_tx[fb + lane] = ax0; S.fc_ty[fb + lane] = ay0; S.fc_n[fb + lane] = n0; }
+      if (lane + 32 < nslots) { S.fc_key[fb + lane + 32] = k1; S.fc_code[fb + lane + 32] = scode[wid][lane + 32]; S.fc_tx[fb + lane + 32] = ax1; S.fc_ty[fb + lane + 32] = ay1; S.fc_n[fb + lane + 32] = n1; }
+      if (lane == 0) S.fc_cnt[i] = npt == 0 ? 0 : nslots;
+      gsync();
     }
   }
 }

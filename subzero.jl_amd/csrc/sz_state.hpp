@@ -32,6 +32,7 @@ enum {
   C_ITEMCLASS,    // largest narrow-phase size class among this step's items
   C_NRETRY,       // items handed on to the largest narrow variant (diagnostic, cumulative)
   C_NWORK,        // pairs whose ring boxes overlap: the pair items the narrow phase runs
+  C_NENT,         // two-way coupling: (floe, centre cell) entries of the current coupling step
   C_COUNT = 32
 };
 
@@ -44,6 +45,7 @@ struct Params {
   double ff_max_overlap, fd_max_overlap;
   double rho_i, max_h, max_xi, lambda;
   int dd;
+  double Cd_ao, k_ice, L_ice;   // two-way coupling: atmosphere-ocean drag, conductivity and latent heat of ice (Constants())
 };
 
 struct State {
@@ -73,6 +75,11 @@ struct State {
   int Nx, Ny; double gx0, gxf, gy0, gyf, gdx, gdy, rdx, rdy;   // rdx = 1/gdx
   double *uo, *vo, *hf, *ua, *va;
   double* nodes;             // the five lattices interleaved per node (8 doubles each)
+  // ---- two-way coupling (allocated by sz_set_two_way): per floe the centre cells its sub-floe points fall into
+  // (FC_CAP slots per floe: cell id, shift code, sum of -tau_ocn, points), per cell the entries sorted by floe
+  int *fc_key, *fc_n, *fc_cnt; signed char* fc_code; double *fc_tx, *fc_ty, *fc_area;
+  int *cl_cnt, *cl_off, *cl_cur, *cl_ent;
+  double *t_ocn, *t_atm, *tau_x, *tau_y, *si_frac;
   // ---- ghosts workspace
   int *gflag, *gcnt, *gscan, *gvcnt, *gvscan;
   int4 *gplan, *gscan4, *gblk4, *gtot4;

@@ -112,6 +112,23 @@ class World:
         arrs = [np.ascontiguousarray(np.broadcast_to(a, (Nx + 1, Ny + 1)), np.float64) for a in (uo, vo, hflx, ua, va)]
         self._chk(self.L.sz_set_fields(self.h, int(Nx), int(Ny), float(x0), float(xf), float(y0), float(yf),
                                        *(capi.ptr(a) for a in arrs)))
+        self._grid = (int(Nx), int(Ny))
+
+    # ---- two-way coupling (coupling.jl:1617-1680); off by default like CouplingSettings()
+    def set_two_way(self, on=True, Cd_ao=1.25e-3, k=2.14, L=2.93e5, dt=10):
+        self._chk(self.L.sz_set_two_way(self.h, int(on), float(Cd_ao), float(k), float(L), int(dt)))
+
+    def set_temps(self, t_ocn, t_atm):
+        Nx, Ny = self._grid
+        a, b = (np.ascontiguousarray(np.broadcast_to(t, (Nx + 1, Ny + 1)), np.float64) for t in (t_ocn, t_atm))
+        self._chk(self.L.sz_set_temps(self.h, capi.ptr(a), capi.ptr(b)))
+
+    def ocean_stress(self):
+        """tau_x, tau_y, si_frac, hflx_factor on the (Nx+1) x (Ny+1) grid-line lattice"""
+        Nx, Ny = self._grid
+        out = [np.zeros((Nx + 1, Ny + 1)) for _ in range(4)]
+        self._chk(self.L.sz_download_ocean_stress(self.h, *(capi.ptr(a) for a in out)))
+        return out
 
     # ------------------------------------------------------------------ floe setup (host side)
     def add_floe(self, coords, height):

@@ -297,3 +297,37 @@ def check_stress_strain(w, U):
         assert np.allclose(e, U["strain_times_1e6"][i], rtol=0, atol=U["atol"]), (i, e)
         # the reference's test also asserts that calc_strain! leaves the coordinates alone
         assert np.array_equal(w.ring(i), np.array(f["coords"], float))
+
+
+# ------------------------------------------------------------------ two-way coupling (coupling.jl:1617-1680)
+def run_two_way_analytic(mk):
+    """One floe at rest in a uniform ocean, grid-aligned domain with collision walls."""
+    w = mk()
+    L = 1e5; Nx = Ny = 10; uo = 0.5
+    w.set_domain([KIND["collision"]] * 4, 0.0, L, 0.0, L)
+    w.set_settings(coupling_dd=1)
+    w.set_grid_fields(Nx, Ny, 0.0, L, 0.0, L, uo, 0.0, 0.0, 0.0, 0.0)
+    floe = np.array([[2.3e4, 3.1e4], [2.3e4, 6.7e4], [5.9e4, 6.7e4], [5.9e4, 3.1e4], [2.3e4, 3.1e4]])
+    w.add_floe(floe, 0.5)
+    gx, gy = np.meshgrid(np.linspace(-1.75e4, 1.75e4, 15), np.linspace(-1.75e4, 1.75e4, 15))
+    w.set_subpoints(0, gx.ravel(), gy.ravel())
+    w.set_two_way(True, dt=20)
+    w.set_temps(0.0, -10.0)
+    w.timestep_coupling()
+    return w, L, Nx, uo
+
+
+def check_two_way_analytic(w, L, Nx, uo):
+    """The ice-covered area is conserved cell by cell, a fully covered cell carries minus the ocean-on-ice
+    stress, an open cell only the atmosphere-on-ocean stress."""
+    tx, ty, si, hf = w.ocean_stress()
+    cell_area = (L / Nx) ** 2
+    assert abs(si.sum() * cell_area - w.get("area")[0]) < 1e-6 * cell_area
+    rho_o, Cd_io, th = 1027.0, 3e-3, 15 * np.pi / 180
+    tocn_x = rho_o * Cd_io * uo * (np.cos(th) * uo); tocn_y = rho_o * Cd_io * uo * (np.sin(th) * uo)
+    assert si[4, 5] == 1.0 and abs(tx[4, 5] + tocn_x) < 1e-12 and abs(ty[4, 5] + tocn_y) < 1e-12
+    rho_a, Cd_ao = 1.2, 1.25e-3
+    assert si[0, 0] == 0.0 and abs(tx[0, 0] - rho_a * Cd_ao * uo * (-uo)) < 1e-15 and ty[0, 0] == 0.0
+    # partly covered cell: the ice stress is an area-weighted mean (here of one floe) plus the open-water part
+    assert 0 < si[2, 3] < 1 and abs(tx[2, 3] - (-tocn_x + rho_a * Cd_ao * (1 - si[2, 3]) * uo * (-uo))) < 1e-12
+    assert np.allclose(hf, 20 * 2.14 / (920.0 * 2.93e5) * 10.0, rtol=1e-14)

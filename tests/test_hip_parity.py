@@ -29,6 +29,33 @@ def test_stress_strain(golden):
         assert parity.relerr(w.get(k), o.get(k)) < 1e-12, k
 
 
+def test_two_way_coupling_analytic():
+    cases.check_two_way_analytic(*cases.run_two_way_analytic(mk))
+
+
+@pytest.mark.parametrize("walls", [False, True])
+def test_two_way_coupling_random(walls):
+    """calc_two_way_coupling! on a random field against the oracle: stress on the ocean, sea-ice fraction and
+    heat-flux factor per centre cell; periodic (floes shifted across the domain) and walled (trimmed cells)."""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=400, seed=11, walls=walls, ocean="converge_diverge")
+    hw, ow = _pair(cfg)
+    Nx, Ny = cfg["Nx"], cfg["Ny"]
+    rng = np.random.default_rng(5)
+    tocn = rng.uniform(-2, 2, (Nx + 1, Ny + 1)); tatm = rng.uniform(-20, 0, (Nx + 1, Ny + 1))
+    for w in (hw, ow):
+        w.set_two_way(True, dt=cfg["dt"]); w.set_temps(tocn, tatm)
+    # a few steps first so that rotated floes, wrapped parents and contacts are in play
+    hw.run(3, 0, cfg["dt"], coupling_dt=1)
+    for t in range(3):
+        ow.timestep_sim(t, cfg["dt"], coupling_dt=1)
+    got = hw.ocean_stress(); ref = ow.ocean_stress()
+    assert np.count_nonzero(ref[2]) > 1000
+    for name, g, r in zip(("tau_x", "tau_y", "si_frac", "hflx"), got, ref):
+        assert parity.relerr(g, r) < 1e-9, name
+    parity.compare_worlds(hw, ow, rtol=1e-9, fields=["fxOA", "fyOA", "trqOA", "hflx_factor"])
+
+
 # ---------------------------------------------------------------- the reference's known answers, through the C-ABI
 @pytest.mark.parametrize("k", range(5))
 def test_floe_floe(golden, k):
