@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs3", "configs4"],
                     help="BASELINE.json configs[k]: 1 = periodic box + uniform flow (the metric's config, default); 2 = "
                          "converge/diverge flow; 3 = four collision walls + topography, strait flow; 4 = 25 %% concentration")
+    ap.add_argument("--two-way", action="store_true", help="two-way coupling on (ice-on-ocean stress per centre cell; "
+                                                           "off in the metric's config, as in CouplingSettings())")
+    ap.add_argument("--coupling-dt", type=int, default=1, help="couple every k-th step (reference default: 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-tiled", action="store_true", help="run the halo/RCCL path even with one rank")
     args = ap.parse_args()
@@ -139,9 +142,11 @@ def main():
           "configs3": dict(seed=12345, walls=True, topography=True, ocean="strait"),
           "configs4": dict(seed=12347, concentration=0.25)}[args.workload]
     cfg = fields.make_config(n_floes=n_total, **wl)
-    coupling_dt = 1
+    coupling_dt = args.coupling_dt
     if world == 1 and not args.force_tiled:
         hw = fields.build_world(subzero_jl_amd.World(local), cfg)
+        if args.two_way:
+            hw.set_two_way(True, dt=cfg["dt"]); hw.set_temps(0.0, -10.0)
         runner = lambda n, t0: hw.run(n, t0, cfg["dt"], coupling_dt=coupling_dt)
     else:
         from subzero_jl_amd import tiles
@@ -199,7 +204,7 @@ def main():
                                    f"coupling every step + rigid-body update, dt={cfg['dt']} s" if args.workload == "configs1" else
                                    f"configs[{args.workload[-1]}]-style field ({wl}): {cfg['n_floes']} floes, box {cfg['L'] / 1e3:.0f} km, "
                                    f"boundaries {cfg['kinds'][0]}, {len(cfg['topography'])} topography elements, dt={cfg['dt']} s",
-                       "n_floes": cfg["n_floes"], "seed": cfg["seed"], "coupling_dt": coupling_dt,
+                       "n_floes": cfg["n_floes"], "seed": cfg["seed"], "coupling_dt": coupling_dt, "two_way_coupling": bool(args.two_way),
                        "tiles": 1 if world == 1 else world},
             "roofline": {"bound": "hbm", "kernel": "sz_k_narrow<8,20,8,16,4,64,0,0,3>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
