@@ -92,6 +92,9 @@ def make_config(n_floes=10000, seed=12345, concentration=0.8, spacing=2.0e4, wal
     xl = np.linspace(0.0, L, Nx + 1)
     if ocean == "uniform":                   # examples/uniform_flow.jl:14-15
         uo = np.full((Nx + 1, Ny + 1), 0.1); vo = np.zeros((Nx + 1, Ny + 1))
+    elif ocean == "shear":                   # examples/shear_flow.jl:16-25: u 0 -> 0.5 -> 0 across y, v = 0
+        prof = 0.5 * (1.0 - np.abs(2.0 * xl / L - 1.0))
+        uo = np.repeat(prof[None, :], Nx + 1, 0); vo = np.zeros((Nx + 1, Ny + 1))
     elif ocean == "strait":                  # examples/simple_strait.jl:14
         uo = np.zeros((Nx + 1, Ny + 1)); vo = np.full((Nx + 1, Ny + 1), -0.3)
     elif ocean == "converge_diverge":        # examples/converge_diverge_flow.jl:16-23: 0.1 -> 0.6 -> 0.1 across x

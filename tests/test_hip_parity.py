@@ -56,6 +56,23 @@ def test_two_way_coupling_random(walls):
     parity.compare_worlds(hw, ow, rtol=1e-9, fields=["fxOA", "fyOA", "trqOA", "hflx_factor"])
 
 
+def test_config0_shear_flow_two_way():
+    """BASELINE configs[0] (examples/shear_flow.jl): ~100 floes in a 100 km doubly periodic box, shear ocean,
+    collisions on, two-way coupling on; 20 timesteps against the oracle."""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=100, seed=21, spacing=1.0e4, ocean="shear")
+    hw, ow = _pair(cfg)
+    for w in (hw, ow):
+        w.set_two_way(True, dt=cfg["dt"]); w.set_temps(0.0, 0.0)
+    hw.run(20, 0, cfg["dt"], coupling_dt=10)
+    for t in range(20):
+        ow.timestep_sim(t, cfg["dt"], coupling_dt=10)
+    parity.compare_worlds(hw, ow, rtol=1e-9)
+    for name, g, r in zip(("tau_x", "tau_y", "si_frac"), hw.ocean_stress(), ow.ocean_stress()):
+        assert parity.relerr(g, r) < 1e-9, name
+    assert 0.6 < ow.ocean_stress()[2].mean() < 0.9       # sea-ice fraction of the 0.8-concentration field
+
+
 # ---------------------------------------------------------------- the reference's known answers, through the C-ABI
 @pytest.mark.parametrize("k", range(5))
 def test_floe_floe(golden, k):
