@@ -583,11 +583,11 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(soff, S.capM + 1); DA(sx, NS); DA(sy, NS);
   if (f->sub_off) { H2D(S.soff, f->sub_off, N + 1, int); H2D(S.sx, f->sx, NS, double); H2D(S.sy, f->sy, NS, double); }
   DA(gplan, S.capM + 1); DA(gscan4, S.capM + 1); DA(gblk4, S.capM / SCAN_B + 1024); DA(gtot4, 4);
-  DA(gflag, S.capM + 1); DA(gcnt, S.capM + 1); DA(gscan, S.capM + 2); DA(gvcnt, S.capM + 1); DA(gvscan, S.capM + 2);
-  DA(bounds, 16 + 64 * 4); DA(cell_of, S.capM); DA(cell_cnt, S.capCells + 1); DA(cell_off, S.capCells + 2); DA(cell_cur, S.capCells + 1);
+  DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2);
+  DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1);
   DA(cell_items, S.capM);
   DA(nb_out, (size_t)S.capM * MAXNB); DA(nb_in, (size_t)S.capM * MAXNB); DA(n_out, S.capM + 1); DA(n_in, S.capM + 1);
-  DA(out_off, S.capM + 2); DA(out_mask, S.capM + 1); DA(n_work, S.capM + 1); DA(work_off, S.capM + 2); DA(work, S.capPairs + 1); DA(in_off, S.capM + 2); DA(in_i, S.capPairs); DA(pair_i, S.capPairs); DA(pair_j, S.capPairs);
+  DA(out_off, S.capM + 2); DA(out_mask, S.capM + 1); DA(n_work, S.capM + 1); DA(work_off, S.capM + 2); DA(work, S.capPairs + 1); DA(pair_i, S.capPairs); DA(pair_j, S.capPairs);
   DA(el_cnt, S.capM + 1); DA(el_off, S.capM + 2); DA(el_floe, S.capElem); DA(el_elem, S.capElem);
   size_t items = (size_t)S.capPairs + S.capElem;
   DA(it_rows, items * ROWS_PER_ITEM * 5); DA(it_nrows, items); DA(it_flags, items);

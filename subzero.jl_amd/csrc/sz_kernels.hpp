@@ -1,14 +1,15 @@
 // sz_kernels.hpp — the HIP kernels of one Subzero timestep on gfx950 (MI355X).
 //
 // Pipeline (every launch reads its sizes from the device counter block, no host round trip):
-//   ghosts    sz_k_ghost_flag / sz_k_ghost_fill (x2: E/W then N/S)     add_ghosts!          collisions.jl:1060-1174
-//   broad     sz_k_bounds, sz_k_cell_count, sz_k_cell_fill,
-//             sz_k_neighbors, sz_k_pscan*                              pair loop + Dict     collisions.jl:745-775
-//   domain    sz_k_elem_count / sz_k_elem_fill                         wall prefilters      collisions.jl:608-660
-//   narrow    sz_k_narrow<G,CAP,...>                                    floe_floe_interaction! / floe_domain_element_interaction!
-//   reduce    sz_k_cnt1, sz_k_inter_fill                               mirror, ghost fold, torque, totals  collisions.jl:799-862
-//   forcing   sz_k_forcing                                             calc_one_way_coupling! coupling.jl:1486-1589
-//   integrate sz_k_integrate                                           timestep_floe_properties! update_floe.jl:469-551
+//   ghosts    sz_k_ghost_flag(_scan1), sz_k_scan4_*, sz_k_ghost_fill      add_ghosts!          collisions.jl:1060-1174
+//   broad     sz_k_bounds, sz_k_cell_build, sz_k_neighbors,
+//             sz_k_pscan1, sz_k_scan4_2, sz_k_pscan3_fill                 pair loop + Dict     collisions.jl:745-775
+//   domain    sz_k_elem_count / sz_k_elem_fill                            wall prefilters      collisions.jl:608-660
+//   narrow    sz_k_narrow<G,CAP,...>                                       floe_floe_interaction! / floe_domain_element_interaction!
+//   reduce    sz_k_inter_fill                                             mirror, ghost fold, torque, totals  collisions.jl:799-862
+//   forcing   sz_k_forcing<TW>  (+ sz_twoway.hpp with two-way coupling)   timestep_coupling!   coupling.jl:1486-1738
+//   integrate sz_k_integrate, sz_k_move_strain                            timestep_floe_properties! update_floe.jl:469-551
+//   tiles     sz_k_halo_pack / sz_k_halo_unpack                           ghost-floe halo of a tiled (multi-GPU) run
 // All of it is HBM/latency-bound integer + fp64 vector work: no MFMA anywhere.
 #pragma once
 #include "sz_geom.hpp"
@@ -159,17 +160,6 @@ __device__ __forceinline__ int4 block_exclusive_scan4(int4 v, int4* total) {
   int4 res = make_int4(inc.x - v.x + o.x, inc.y - v.y + o.y, inc.z - v.z + o.z, inc.w - v.w + o.w);
   __syncthreads();
   return res;
-}
-__global__ void __launch_bounds__(SCAN_B) sz_k_scan4_1(const int4* in, int4* out, int4* blk, const int* cnt, int ci) {
-  __shared__ int4 tot;
-  int n = cnt[ci];
-  int base = blockIdx.x * SCAN_B;
-  if (base >= n && !(n == 0 && blockIdx.x == 0)) return;
-  int i = base + threadIdx.x;
-  int4 v = i < n ? in[i] : make_int4(0, 0, 0, 0);
-  int4 ex = block_exclusive_scan4(v, &tot);
-  if (i < n) out[i] = ex;
-  if (threadIdx.x == 0) blk[blockIdx.x] = tot;
 }
 __global__ void __launch_bounds__(SCAN_B) sz_k_scan4_2(int4* blk, const int* cnt, int ci) {
   __shared__ int4 tot;
@@ -624,11 +614,6 @@ __global__ void sz_k_pairs_explicit(State S, int np) {
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < np; p += gridDim.x * blockDim.x) S.work[p] = make_int4(p, S.pair_i[p], S.pair_j[p], 0);
   if (blockIdx.x == 0 && threadIdx.x == 0) { S.cnt[C_NPAIRS] = np; S.cnt[C_NWORK] = np; }
 }
-__global__ void sz_k_nout_from_off(State S) {
-  int M = S.cnt[C_M];
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) S.n_out[k] = S.out_off[k + 1] - S.out_off[k];
-}
-
 // ============================================================================ domain element items (A10 prefilter)
 template <typename F>
 __device__ __forceinline__ void elem_candidates(const State& S, int k, F&& emit) {
@@ -955,12 +940,6 @@ __global__ void sz_k_interleave_fields(State S) {
   }
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-  return v;
-}
-
-// one wavefront per floe, lanes over the sub-floe points
 // apply the removal flags of the forcing kernel (standalone timestep_coupling! call)
 __global__ void sz_k_apply_frc(State S) {
   int N = S.cnt[C_NOWN];
@@ -1340,13 +1319,6 @@ __global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* 
   if (threadIdx.x == 0) {
     S.cnt[C_M] = nown + nrec; S.cnt[C_N] = nown + nrec; S.cnt[C_NV] = vbase + totv; S.cnt[C_NHALO] = nrec;
     if (nrec == 0) S.voff[nown] = vbase;
-  }
-}
-// after the step: forget the halo floes (their owners integrate them)
-__global__ void sz_k_halo_drop(State S) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    int nown = S.cnt[C_NOWN];
-    S.cnt[C_M] = nown; S.cnt[C_N] = nown; S.cnt[C_NV] = S.voff[nown];
   }
 }
 // bounding box of the owned centroids and the largest rmax: out[0..4] = xmin, xmax, ymin, ymax, rmax

@@ -81,12 +81,12 @@ struct State {
   int *cl_cnt, *cl_off, *cl_cur, *cl_ent;
   double *t_ocn, *t_atm, *tau_x, *tau_y, *si_frac;
   // ---- ghosts workspace
-  int *gflag, *gcnt, *gscan, *gvcnt, *gvscan;
+  int *gflag, *gvscan;        // gvscan: ring offsets of the halo records being unpacked
   int4 *gplan, *gscan4, *gblk4, *gtot4;
   // ---- broad phase
   double* bounds;            // xmin, ymin, cell size, (ncx, ncy as doubles)
-  int *cell_of, *cell_cnt, *cell_off, *cell_cur, *cell_items;
-  int *nb_out, *nb_in, *n_out, *n_in, *out_off, *in_off, *in_i;
+  int *cell_cnt, *cell_items;   // per-cell list head (+1) and next links
+  int *nb_out, *nb_in, *n_out, *n_in, *out_off;
   int *pair_i, *pair_j;
   int *out_mask, *n_work, *work_off;   // per floe: which of its outgoing pairs have overlapping ring boxes (bit r = rank r)
   int4* work;                // compacted pair items: {pair slot, i, j, -}
