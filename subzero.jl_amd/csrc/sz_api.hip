@@ -65,6 +65,7 @@ struct sz_ctx {
   // two-way coupling (off by default, like CouplingSettings())
   bool two_way = false; int tw_dt = 10; int tw_capM = 0; size_t tw_ncell = 0;
   std::vector<void*> tw_allocs, tw_field_allocs;
+  unsigned scan_epoch = 0;      // launch counter of the look-back scans (their flags carry it: no reset pass)
   bool tile_dirty = false;      // ghosts / halo floes of the last sz_tile_step still appended
   int dbg = 0;   // SZ_DEBUG bits: timing experiments only (1 skip contact rows, 2 skip direction check, 4 skip clip)
 };
@@ -146,10 +147,10 @@ int sync_and_check(sz_ctx* c, int* cnt_out = nullptr) {
   c->hostM = h[C_M]; c->hostN = h[C_N];
   if (cnt_out) memcpy(cnt_out, h, sizeof(h));
   if (h[C_ERR]) {
-    char buf[256];
+    char buf[320];
     snprintf(buf, sizeof(buf),
              "device capacity/consistency error bits 0x%x (ring=1 crossings=2 regions=4 rows=8 trace=16 neighbours=32 "
-             "pairs=64 elems=128 inter=256 floes=512 verts=1024 cells=2048 ghosts/parent=4096)", h[C_ERR]);
+             "pairs=64 elems=128 inter=256 floes=512 verts=1024 cells=2048 ghosts/parent=4096 scan=8192)", h[C_ERR]);
     c->err = buf;
     int z = 0;
     (void)hipMemcpy(c->S.cnt + C_ERR, &z, sizeof(int), hipMemcpyHostToDevice);
@@ -218,6 +219,16 @@ int upload_elements(sz_ctx* c) {
   return SZ_OK;
 }
 
+// launch number of the look-back scans; when the counter would no longer fit beside the status bits the flags
+// are cleared once and it starts over
+unsigned next_epoch(sz_ctx* c) {
+  if (++c->scan_epoch >= (1u << 30)) {
+    (void)hipMemsetAsync(c->S.lb_flag, 0, ((size_t)c->S.capM / SCAN_B + 8) * sizeof(unsigned), c->stream);
+    c->scan_epoch = 1;
+  }
+  return c->scan_epoch;
+}
+
 // ---------------------------------------------------------------- pipeline stages
 // in_step: the previous step's ghosts are dropped by the flag kernel and the commit is done by
 // the bounds kernel of the broad phase (which always follows inside a step)
@@ -225,15 +236,8 @@ void stage_ghosts(sz_ctx* c, bool in_step = false) {
   State& S = c->S;
   if (!S.any_periodic_ew && !S.any_periodic_ns) return;
   Timed t(c, SZ_K_GHOSTS);
-  int gN = grid_for(S.capM, 256), nb = grid_for(S.capM, SCAN_B, 1 << 20);
-  if (S.capM <= SCAN_ONE_MAX) {
-    hipLaunchKernelGGL(sz_k_ghost_flag, dim3(gN), dim3(256), 0, c->stream, S, in_step ? 1 : 0);
-    hipLaunchKernelGGL(sz_k_scan4_one, dim3(1), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.cnt, C_N, S.gtot4);
-  } else {
-    hipLaunchKernelGGL(sz_k_ghost_flag_scan1, dim3(nb), dim3(SCAN_B), 0, c->stream, S, in_step ? 1 : 0);
-    hipLaunchKernelGGL(sz_k_scan4_2, dim3(1), dim3(SCAN_B), 0, c->stream, S.gblk4, S.cnt, C_N);
-    hipLaunchKernelGGL(sz_k_scan4_3, dim3(nb), dim3(SCAN_B), 0, c->stream, S.gplan, S.gscan4, S.gblk4, S.cnt, C_N, S.gtot4);
-  }
+  const int nb = grid_for(S.capM, SCAN_B, 1 << 20);
+  hipLaunchKernelGGL(sz_k_ghost_flag_scan, dim3(nb), dim3(SCAN_B), 0, c->stream, S, in_step ? 1 : 0, next_epoch(c));
   hipLaunchKernelGGL(sz_k_ghost_fill, dim3(grid_for(S.capM, 32, 2048)), dim3(256), 0, c->stream, S);
   if (!in_step) hipLaunchKernelGGL(sz_k_ghost_commit, dim3(1), dim3(64), 0, c->stream, S);
   t.end();
@@ -247,9 +251,7 @@ void stage_broad(sz_ctx* c, bool commit_ghosts = false) {
   hipLaunchKernelGGL(sz_k_cell_build, dim3(gM), dim3(256), 0, c->stream, S);
   hipLaunchKernelGGL(sz_k_neighbors, dim3(grid_for(S.capM, NB_TPB / NB_G, 8192)), dim3(NB_TPB), 0, c->stream, S);
   int nb = grid_for(S.capM, SCAN_B, 1 << 20);
-  hipLaunchKernelGGL(sz_k_pscan1, dim3(nb), dim3(SCAN_B), 0, c->stream, S);
-  hipLaunchKernelGGL(sz_k_scan4_2, dim3(1), dim3(SCAN_B), 0, c->stream, S.gblk4, S.cnt, C_M);
-  hipLaunchKernelGGL(sz_k_pscan3_fill, dim3(nb), dim3(SCAN_B), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_pscan_fill, dim3(nb), dim3(SCAN_B), 0, c->stream, S, next_epoch(c));
   t.end();
 }
 
@@ -582,7 +584,8 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   H2D(S.voff, f->vert_off, M + 1, int); H2D(S.vx, f->vx, V, double); H2D(S.vy, f->vy, V, double);
   DA(soff, S.capM + 1); DA(sx, NS); DA(sy, NS);
   if (f->sub_off) { H2D(S.soff, f->sub_off, N + 1, int); H2D(S.sx, f->sx, NS, double); H2D(S.sy, f->sy, NS, double); }
-  DA(gplan, S.capM + 1); DA(gscan4, S.capM + 1); DA(gblk4, S.capM / SCAN_B + 1024); DA(gtot4, 4);
+  DA(gplan, S.capM + 1); DA(gscan4, S.capM + 1); DA(gtot4, 4);
+  DA(lb_agg, S.capM / SCAN_B + 8); DA(lb_inc, S.capM / SCAN_B + 8); DA(lb_flag, S.capM / SCAN_B + 8); c->scan_epoch = 0;
   DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2);
   DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1);
   DA(cell_items, S.capM);

@@ -1,9 +1,9 @@
 // sz_kernels.hpp — the HIP kernels of one Subzero timestep on gfx950 (MI355X).
 //
 // Pipeline (every launch reads its sizes from the device counter block, no host round trip):
-//   ghosts    sz_k_ghost_flag(_scan1), sz_k_scan4_*, sz_k_ghost_fill      add_ghosts!          collisions.jl:1060-1174
+//   ghosts    sz_k_ghost_flag_scan (look-back scan), sz_k_ghost_fill   add_ghosts!          collisions.jl:1060-1174
 //   broad     sz_k_bounds, sz_k_cell_build, sz_k_neighbors,
-//             sz_k_pscan1, sz_k_scan4_2, sz_k_pscan3_fill                 pair loop + Dict     collisions.jl:745-775
+//             sz_k_pscan_fill (look-back scan + pair fill)            pair loop + Dict     collisions.jl:745-775
 //   domain    sz_k_elem_count / sz_k_elem_fill                            wall prefilters      collisions.jl:608-660
 //   narrow    sz_k_narrow<G,CAP,...>                                       floe_floe_interaction! / floe_domain_element_interaction!
 //   reduce    sz_k_inter_fill                                             mirror, ghost fold, torque, totals  collisions.jl:799-862
@@ -161,48 +161,76 @@ __device__ __forceinline__ int4 block_exclusive_scan4(int4 v, int4* total) {
   __syncthreads();
   return res;
 }
-__global__ void __launch_bounds__(SCAN_B) sz_k_scan4_2(int4* blk, const int* cnt, int ci) {
-  __shared__ int4 tot;
-  int n = cnt[ci];
-  int nb = (n + SCAN_B - 1) / SCAN_B;
-  if (nb < 1) nb = 1;
-  int4 carry = make_int4(0, 0, 0, 0);
-  for (int base = 0; base < nb; base += SCAN_B) {
-    int i = base + threadIdx.x;
-    int4 v = i < nb ? blk[i] : make_int4(0, 0, 0, 0);
-    int4 ex = block_exclusive_scan4(v, &tot);
-    if (i < nb) blk[i] = add4(ex, carry);
-    carry = add4(carry, tot);
-    __syncthreads();
-  }
+// ---------------------------------------------------------------- single-pass scan (decoupled look-back)
+// A scan over M elements in ONE launch: every workgroup scans its tile, publishes the tile total (AGG), adds up
+// its predecessors' totals until it meets one that already knows its inclusive prefix (INC), then publishes
+// its own.  The status words carry the launch number (`epoch`), so nothing has to be cleared between
+// launches.  Workgroups are dispatched in index order and a workgroup only waits for lower indices; the wait
+// is bounded (ERR_SCAN instead of a hang should the protocol ever be broken).
+constexpr int ERR_SCAN = 8192;
+__device__ __forceinline__ int4 ld4_agent(const int4* p) {
+  int* q = (int*)p;
+  return make_int4(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                   __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
-// adds the block offsets; the grand totals go to tot4[0]
-__global__ void __launch_bounds__(SCAN_B) sz_k_scan4_3(const int4* in, int4* out, const int4* blk, const int* cnt, int ci, int4* tot4) {
-  int n = cnt[ci];
-  int i = blockIdx.x * SCAN_B + threadIdx.x;
-  if (n == 0) { if (i == 0) tot4[0] = make_int4(0, 0, 0, 0); return; }
-  if (i >= n) return;
-  int4 o = add4(out[i], blk[blockIdx.x]);
-  out[i] = o;
-  if (i == n - 1) tot4[0] = add4(o, in[i]);
+__device__ __forceinline__ void st4_agent(int4* p, int4 v) {
+  int* q = (int*)p;
+  __hip_atomic_store(q, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(q + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(q + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// one-workgroup variant of scan4_1..3 (see sz_k_scan_one)
-__global__ void __launch_bounds__(SCAN_B) sz_k_scan4_one(const int4* in, int4* out, const int* cnt, int ci, int4* tot4) {
-  __shared__ int4 tot;
-  const int n = cnt[ci];
-  int4 carry = make_int4(0, 0, 0, 0);
-  for (int base = 0; base < n; base += 2 * SCAN_B) {
-    const int i0 = base + 2 * (int)threadIdx.x;
-    int4 v0 = i0 < n ? in[i0] : make_int4(0, 0, 0, 0), v1 = i0 + 1 < n ? in[i0 + 1] : make_int4(0, 0, 0, 0);
-    int4 ex = add4(block_exclusive_scan4(add4(v0, v1), &tot), carry);
-    if (i0 < n) out[i0] = ex;
-    if (i0 + 1 < n) out[i0 + 1] = add4(ex, v0);
-    carry = add4(carry, tot);
+// called by every thread of the workgroup with the tile total; returns the sum of all earlier tiles
+__device__ __forceinline__ int4 lookback_prefix4(State& S, int4 tot, unsigned epoch) {
+  __shared__ int4 s_prefix;
+  const int b = blockIdx.x;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    if (b == 0) {
+      if (lane == 0) {
+        st4_agent(&S.lb_inc[0], tot);
+        __hip_atomic_store(&S.lb_flag[0], (epoch << 2) | 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        s_prefix = make_int4(0, 0, 0, 0);
+      }
+    } else {
+      if (lane == 0) {
+        st4_agent(&S.lb_agg[b], tot);
+        __hip_atomic_store(&S.lb_flag[b], (epoch << 2) | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      int4 running = make_int4(0, 0, 0, 0);
+      int p = b - 1, spins = 0;
+      for (;;) {
+        const int q = p - lane;                       // lane 0 looks at the nearest predecessor
+        unsigned f = 0;
+        if (q >= 0) f = __hip_atomic_load(&S.lb_flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ready = q < 0 || (f >> 2) == epoch;
+        const unsigned long long isinc = __ballot(q >= 0 && ready && (f & 3u) == 2u);
+        const int firstinc = isinc ? __ffsll((long long)isinc) - 1 : 64;
+        const unsigned long long need = firstinc >= 63 ? ~0ull : ((2ull << firstinc) - 1ull);
+        if (__ballot(!ready) & need) {
+          if (++spins > (1 << 22)) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_SCAN); break; }
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        int4 v = make_int4(0, 0, 0, 0);
+        if (q >= 0 && lane <= firstinc) v = lane == firstinc ? ld4_agent(&S.lb_inc[q]) : ld4_agent(&S.lb_agg[q]);
+        for (int d = 32; d >= 1; d >>= 1) v = add4(v, make_int4(__shfl_xor(v.x, d), __shfl_xor(v.y, d), __shfl_xor(v.z, d), __shfl_xor(v.w, d)));
+        running = add4(running, v);
+        if (firstinc < 64) break;
+        p -= 64;
+        if (p < 0) break;
+      }
+      if (lane == 0) {
+        st4_agent(&S.lb_inc[b], add4(running, tot));
+        __hip_atomic_store(&S.lb_flag[b], (epoch << 2) | 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        s_prefix = running;
+      }
+    }
   }
-  if (threadIdx.x == 0) tot4[0] = carry;
+  __syncthreads();
+  const int4 r = s_prefix;
+  __syncthreads();
+  return r;
 }
 
-// does ring i reach strictly beyond the wall in the direction that needs a ghost?  This is
 // !isempty(intersect_polys(poly, boundary.poly)) of collisions.jl:889: the wall rectangle extends
 // half a domain outward, so a positive-area overlap exists iff a vertex lies strictly beyond the wall
 __device__ __forceinline__ int ghost_dir(const State& S, int i, int axis) {
@@ -241,21 +269,19 @@ __device__ __forceinline__ int4 ghost_plan(State& S, int i, int N, int drop_old)
   S.gplan[i] = plan;
   return plan;
 }
-__global__ void sz_k_ghost_flag(State S, int drop_old) {
-  int N = S.cnt[C_N];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) (void)ghost_plan(S, i, N, drop_old);
-}
-// the flag kernel and the first scan pass in one launch (fields above the single-workgroup scan size)
-__global__ void __launch_bounds__(SCAN_B) sz_k_ghost_flag_scan1(State S, int drop_old) {
+// flag kernel + the whole int4 scan of the plan in one launch (look-back scan)
+__global__ void __launch_bounds__(SCAN_B) sz_k_ghost_flag_scan(State S, int drop_old, unsigned epoch) {
   __shared__ int4 tot;
-  int n = S.cnt[C_N];
-  int base = blockIdx.x * SCAN_B;
-  if (base >= n && !(n == 0 && blockIdx.x == 0)) return;
-  int i = base + threadIdx.x;
-  int4 v = i < n ? ghost_plan(S, i, n, drop_old) : make_int4(0, 0, 0, 0);
-  int4 ex = block_exclusive_scan4(v, &tot);
-  if (i < n) S.gscan4[i] = ex;
-  if (threadIdx.x == 0) S.gblk4[blockIdx.x] = tot;
+  const int n = S.cnt[C_N];
+  const int base = blockIdx.x * SCAN_B;
+  if (base >= n && blockIdx.x != 0) return;          // tiles past the end: nobody waits for them
+  const int i = base + threadIdx.x;
+  const int4 v = i < n ? ghost_plan(S, i, n, drop_old) : make_int4(0, 0, 0, 0);
+  const int4 ex = block_exclusive_scan4(v, &tot);
+  const int4 before = lookback_prefix4(S, tot, epoch);
+  if (i < n) S.gscan4[i] = add4(ex, before);
+  if (n == 0) { if (i == 0) S.gtot4[0] = make_int4(0, 0, 0, 0); }
+  else if (i == n - 1) S.gtot4[0] = add4(add4(ex, before), v);
 }
 
 __device__ __forceinline__ void copy_floe_row(State& S, int dst, int src) {
@@ -564,29 +590,22 @@ __global__ void __launch_bounds__(NB_TPB) sz_k_neighbors(State S) {
     }
   }
 }
-// Scan of {outgoing pairs, pairs to run} per floe and the pair fill in three launches.  Pass 3: thread i
-// finishes out_off[i] / work_off[i], writes the pairs floe i owns and appends those with overlapping ring
+// Scan of {outgoing pairs, pairs to run} per floe (look-back scan) and the pair fill in one launch: thread i
+// gets out_off[i] and its work-list offset, writes the pairs floe i owns and appends those with overlapping ring
 // boxes to the work list of the narrow phase; the others get their (empty) result here.
-__global__ void __launch_bounds__(SCAN_B) sz_k_pscan1(State S) {
+__global__ void __launch_bounds__(SCAN_B) sz_k_pscan_fill(State S, unsigned epoch) {
   __shared__ int4 tot;
-  int n = S.cnt[C_M];
-  int base = blockIdx.x * SCAN_B;
-  if (base >= n && !(n == 0 && blockIdx.x == 0)) return;
-  int i = base + threadIdx.x;
-  int4 v = i < n ? make_int4(S.n_out[i], S.n_work[i], 0, 0) : make_int4(0, 0, 0, 0);
-  int4 ex = block_exclusive_scan4(v, &tot);
-  if (i < n) { S.out_off[i] = ex.x; S.work_off[i] = ex.y; }
-  if (threadIdx.x == 0) S.gblk4[blockIdx.x] = tot;
-}
-__global__ void __launch_bounds__(SCAN_B) sz_k_pscan3_fill(State S) {
-  int n = S.cnt[C_M];
-  int i = blockIdx.x * SCAN_B + threadIdx.x;
+  const int n = S.cnt[C_M];
+  const int base = blockIdx.x * SCAN_B;
+  if (base >= n && blockIdx.x != 0) return;
+  const int i = base + threadIdx.x;
+  const int nk = i < n ? S.n_out[i] : 0, mask = i < n ? S.out_mask[i] : 0;
+  const int4 ex = block_exclusive_scan4(make_int4(nk, __popc(mask), 0, 0), &tot);
+  const int4 before = lookback_prefix4(S, tot, epoch);
   if (n == 0) { if (i == 0) { S.out_off[0] = 0; S.cnt[C_NPAIRS] = 0; S.cnt[C_NWORK] = 0; } return; }
   if (i >= n) return;
-  const int4 b = S.gblk4[blockIdx.x];
-  int o = S.out_off[i] + b.x, wo = S.work_off[i] + b.y, nk = S.n_out[i];
-  const int mask = S.out_mask[i];
-  S.out_off[i] = o; S.work_off[i] = wo;
+  const int o = ex.x + before.x; int wo = ex.y + before.y;
+  S.out_off[i] = o;
   if (i == n - 1) {
     int t = o + nk, tw = wo + __popc(mask); S.out_off[n] = t;
     if (t > S.capPairs) { atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS); t = 0; tw = 0; }

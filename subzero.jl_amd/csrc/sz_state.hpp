@@ -82,7 +82,8 @@ struct State {
   double *t_ocn, *t_atm, *tau_x, *tau_y, *si_frac;
   // ---- ghosts workspace
   int *gflag, *gvscan;        // gvscan: ring offsets of the halo records being unpacked
-  int4 *gplan, *gscan4, *gblk4, *gtot4;
+  int4 *gplan, *gscan4, *gtot4;
+  int4 *lb_agg, *lb_inc; unsigned* lb_flag;   // decoupled look-back scan: per workgroup aggregate, inclusive prefix, (epoch << 2 | status)
   // ---- broad phase
   double* bounds;            // xmin, ymin, cell size, (ncx, ncy as doubles)
   int *cell_cnt, *cell_items;   // per-cell list head (+1) and next links
