@@ -266,10 +266,7 @@ void stage_elems(sz_ctx* c, bool enabled) {
     return;
   }
   Timed t(c, SZ_K_BROAD);
-  int gM = grid_for(S.capM, 256);
-  hipLaunchKernelGGL(sz_k_elem_count, dim3(gM), dim3(256), 0, c->stream, S);
-  scan(c, S.el_cnt, S.el_off, S.capM, C_M, 0, C_NELEM);
-  hipLaunchKernelGGL(sz_k_elem_fill, dim3(gM), dim3(256), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_elem_scan_fill, dim3(grid_for(S.capM, SCAN_B, 1 << 20)), dim3(SCAN_B), 0, c->stream, S, next_epoch(c));
   t.end();
 }
 
@@ -591,7 +588,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(cell_items, S.capM);
   DA(nb_out, (size_t)S.capM * MAXNB); DA(nb_in, (size_t)S.capM * MAXNB); DA(n_out, S.capM + 1); DA(n_in, S.capM + 1);
   DA(out_off, S.capM + 2); DA(out_mask, S.capM + 1); DA(n_work, S.capM + 1); DA(work_off, S.capM + 2); DA(work, S.capPairs + 1); DA(pair_i, S.capPairs); DA(pair_j, S.capPairs);
-  DA(el_cnt, S.capM + 1); DA(el_off, S.capM + 2); DA(el_floe, S.capElem); DA(el_elem, S.capElem);
+  DA(el_off, S.capM + 2); DA(el_floe, S.capElem); DA(el_elem, S.capElem);
   size_t items = (size_t)S.capPairs + S.capElem;
   DA(it_rows, items * ROWS_PER_ITEM * 5); DA(it_nrows, items); DA(it_flags, items);
   DA(inter_cnt, S.capM + 1); DA(inter_off, S.capM + 2); DA(inter_rows, (size_t)S.capM * ROWCAP * 7);

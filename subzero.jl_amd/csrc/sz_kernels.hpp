@@ -4,7 +4,7 @@
 //   ghosts    sz_k_ghost_flag_scan (look-back scan), sz_k_ghost_fill   add_ghosts!          collisions.jl:1060-1174
 //   broad     sz_k_bounds, sz_k_cell_build, sz_k_neighbors,
 //             sz_k_pscan_fill (look-back scan + pair fill)            pair loop + Dict     collisions.jl:745-775
-//   domain    sz_k_elem_count / sz_k_elem_fill                            wall prefilters      collisions.jl:608-660
+//   domain    sz_k_elem_scan_fill (count, scan, fill)                       wall prefilters      collisions.jl:608-660
 //   narrow    sz_k_narrow<G,CAP,...>                                       floe_floe_interaction! / floe_domain_element_interaction!
 //   reduce    sz_k_inter_fill                                             mirror, ghost fold, torque, totals  collisions.jl:799-862
 //   forcing   sz_k_forcing<TW>  (+ sz_twoway.hpp with two-way coupling)   timestep_coupling!   coupling.jl:1486-1738
@@ -646,22 +646,28 @@ __device__ __forceinline__ void elem_candidates(const State& S, int k, F&& emit)
     if (dx * dx + dy * dy < rr * rr) emit(e);
   }
 }
-__global__ void sz_k_elem_count(State S) {
-  int M = S.cnt[C_M];
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
-    int c = 0;
-    elem_candidates(S, k, [&](int) { c++; });
-    S.el_cnt[k] = c;
+// count, scan (look-back) and fill of the floe-element items in one launch
+__global__ void __launch_bounds__(SCAN_B) sz_k_elem_scan_fill(State S, unsigned epoch) {
+  __shared__ int4 tot;
+  const int M = S.cnt[C_M];
+  const int base = blockIdx.x * SCAN_B;
+  if (base >= M && blockIdx.x != 0) return;
+  const int k = base + threadIdx.x;
+  int c = 0;
+  if (k < M) elem_candidates(S, k, [&](int) { c++; });
+  const int4 ex = block_exclusive_scan4(make_int4(c, 0, 0, 0), &tot);
+  const int4 before = lookback_prefix4(S, tot, epoch);
+  if (M == 0) { if (k == 0) { S.el_off[0] = 0; S.cnt[C_NELEM] = 0; } return; }
+  if (k >= M) return;
+  int o = ex.x + before.x;
+  S.el_off[k] = o;
+  if (k == M - 1) {
+    int t = o + c; S.el_off[M] = t;
+    if (t > S.capElem) { atomicOr(&S.cnt[C_ERR], ERR_CAP_ELEM); t = 0; }
+    S.cnt[C_NELEM] = t;
   }
-}
-__global__ void sz_k_elem_fill(State S) {
-  int M = S.cnt[C_M];
-  int E = S.cnt[C_NELEM];
-  if (E > S.capElem) { if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&S.cnt[C_ERR], ERR_CAP_ELEM); S.cnt[C_NELEM] = 0; } return; }
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
-    int o = S.el_off[k];
-    elem_candidates(S, k, [&](int e) { S.el_floe[o] = k; S.el_elem[o] = e; o++; });
-  }
+  if (o + c > S.capElem) return;
+  elem_candidates(S, k, [&](int e) { S.el_floe[o] = k; S.el_elem[o] = e; o++; });
 }
 
 // ============================================================================ narrow phase (A4-A10)

@@ -92,7 +92,7 @@ struct State {
   int *out_mask, *n_work, *work_off;   // per floe: which of its outgoing pairs have overlapping ring boxes (bit r = rank r)
   int4* work;                // compacted pair items: {pair slot, i, j, -}
   // ---- element items
-  int *el_cnt, *el_off, *el_floe, *el_elem;
+  int *el_off, *el_floe, *el_elem;
   // ---- contact rows per item (pairs first, then element items at capPairs + e)
   double* it_rows; int* it_nrows; int* it_flags;
   // ---- per-floe interaction lists
