@@ -767,12 +767,27 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     STAMP(st, 11);
 #ifdef SZ_STAMPS
     if (st.on) { if (nrows > 0) { S.stamps[0] = st.n; st.on = false; } else { st.n = 0; st.t0 = clock64(); } }
+    st.maxrows = st.maxrows > nrows ? st.maxrows : nrows;
 #endif
    }
   }
   gsync();
   if (gl == 0 && m.err) atomicOr(&S.cnt[C_ERR], m.err);
   if (gl == 0 && m.ntracefail) atomicAdd(&S.cnt[C_TRACE_FAIL], m.ntracefail);
+#ifdef SZ_STAMPS
+  // lifetimes of the wavefronts (4096-cycle buckets: stamps[256 + bucket]) and their mean by the largest row
+  // count among the wavefront's items (stamps[400 + 2r] cycles, [401 + 2r] wavefronts)
+  if (CLS == 0) {
+    int mr = st.maxrows;
+    for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(mr, d); mr = mr > o ? mr : o; }
+    if (threadIdx.x == 0) {
+      long long el = clock64() - st.t0w; int bkt = (int)(el >> 12); if (bkt > 127) bkt = 127;
+      atomicAdd((unsigned long long*)&S.stamps[256 + bkt], 1ull);
+      atomicAdd((unsigned long long*)&S.stamps[400 + 2 * mr], (unsigned long long)el);
+      atomicAdd((unsigned long long*)&S.stamps[401 + 2 * mr], 1ull);
+    }
+  }
+#endif
 }
 
 constexpr int NARROW_CAP0 = 20, NARROW_CAP1 = 32, NARROW_CAP2 = 128;   // ring points per variant

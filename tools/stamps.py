@@ -30,3 +30,20 @@ for blk in range(0, 40):
             print(f"  {names.get(k, k):24s} t={t:8d}  +{t - prev:7d}")
             prev = t
         break
+
+# lifetimes of all wavefronts of the narrow kernel in the last step (4096-cycle buckets)
+w = fields.build_world(subzero_jl_amd.World(0), cfg)
+os.environ["SZ_DEBUG"] = str(1 << 30)
+w.run(3, 0, cfg["dt"], coupling_dt=1)
+out = np.zeros(512, np.int64)
+w._chk(w.L.sz_debug_stamps(w.h, capi.ptr(out, capi._lp)))
+w.run(1, 3, cfg["dt"], coupling_dt=1)
+w._chk(w.L.sz_debug_stamps(w.h, capi.ptr(out, capi._lp)))
+h = out[256:384]
+tot = h.sum()
+print("wavefront lifetimes (k cycles: count):", {int(4 * k): int(v) for k, v in enumerate(h) if v})
+cum = np.cumsum(h) / max(tot, 1)
+print("median %.0f k cycles, 90 %% %.0f k, 99 %% %.0f k, max %.0f k" % tuple(4.096 * (np.searchsorted(cum, q) + 1) for q in (0.5, 0.9, 0.99, 1.0)))
+for r in range(5):
+    if out[401 + 2 * r]:
+        print(f"wavefronts whose heaviest item made {r} rows: {int(out[401 + 2 * r])}, mean lifetime {out[400 + 2 * r] / out[401 + 2 * r] / 1e3:.0f} k cycles")
