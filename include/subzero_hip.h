@@ -188,7 +188,9 @@ int sz_kernel_time_ms(sz_ctx *ctx, int32_t kclass, double *ms, int64_t *launches
    that the host hands to RCCL (torch.distributed all_to_all_single).
      sz_tile_enable   after sz_upload_floes of the owned floes: gidx[i] = global index of owned
                       floe i; all order-dependent rules then use global indices.  max_ring = largest
-                      ring (points) over the floes of ALL ranks, 0 if unknown
+                      ring (points) over the floes of ALL ranks, 0 if unknown; max_rmax = largest rmax
+                      over the floes of ALL ranks (the resident steps' fixed broad-phase grid must hold
+                      for halo floes too), 0 if unknown (the grid is then fitted every step)
      sz_owned_box     bounding box of the owned centroids + largest rmax: xmin,xmax,ymin,ymax,rmax
      sz_halo_set_boxes  nranks x {xmin,xmax,ymin,ymax}, already expanded by the interaction range
      sz_halo_pack     ASYNC. Exchange buffers have one region per peer: 1 header record (count in
@@ -200,7 +202,7 @@ int sz_kernel_time_ms(sz_ctx *ctx, int32_t kclass, double *ms, int64_t *launches
      sz_sync          waits for everything enqueued, reports sticky device errors
      sz_set_stream    enqueue on the caller's HIP stream (torch.cuda.current_stream().cuda_stream) so
                       that the framework's collectives order with the kernels without host syncs */
-int sz_tile_enable(sz_ctx *ctx, const int64_t *gidx, double max_ring);
+int sz_tile_enable(sz_ctx *ctx, const int64_t *gidx, double max_ring, double max_rmax);
 int sz_owned_box(sz_ctx *ctx, double *out5);
 int sz_halo_record_doubles(void);
 int sz_halo_set_boxes(sz_ctx *ctx, int32_t nranks, const double *boxes);

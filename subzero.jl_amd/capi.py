@@ -113,7 +113,7 @@ def load(build_if_missing=True):
     L.sz_profile_enable.argtypes = [C.c_void_p, C.c_int32]
     L.sz_profile_reset.argtypes = [C.c_void_p]
     L.sz_kernel_time_ms.argtypes = [C.c_void_p, C.c_int32, _dp, _lp]
-    L.sz_tile_enable.argtypes = [C.c_void_p, _lp, C.c_double]
+    L.sz_tile_enable.argtypes = [C.c_void_p, _lp, C.c_double, C.c_double]
     L.sz_owned_box.argtypes = [C.c_void_p, _dp]
     L.sz_halo_record_doubles.argtypes = []
     L.sz_halo_set_boxes.argtypes = [C.c_void_p, C.c_int32, _dp]

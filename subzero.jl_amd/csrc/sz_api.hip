@@ -65,6 +65,9 @@ struct sz_ctx {
   // two-way coupling (off by default, like CouplingSettings())
   bool two_way = false; int tw_dt = 10; int tw_capM = 0; size_t tw_ncell = 0;
   std::vector<void*> tw_allocs, tw_field_allocs;
+  // static broad-phase grid of the resident steps (fixed by the host: no bounds reduction per step)
+  bool no_static_grid = false;      // SZ_STATIC_GRID=0: fit the grid to the centroids every step (sz_k_bounds), as process mode does
+  double rmax_max = 0.0, rmax_hint = 0.0; bool grid_ok = false, grid_live = false; double h_grid[8] = { 0 };
   unsigned scan_epoch = 0;      // launch counter of the look-back scans (their flags carry it: no reset pass)
   bool tile_dirty = false;      // ghosts / halo floes of the last sz_tile_step still appended
   int dbg = 0;   // SZ_DEBUG bits: timing experiments only (1 skip contact rows, 2 skip direction check, 4 skip clip)
@@ -229,29 +232,60 @@ unsigned next_epoch(sz_ctx* c) {
   return c->scan_epoch;
 }
 
+// Grid for the resident steps: the domain box cut into cells of at least 2 max(rmax) (so that touching circles
+// are in adjacent cells), indices wrapped in a periodic direction and clamped otherwise (sz_kernels.hpp, GridGeo).
+void setup_grid(sz_ctx* c) {
+  c->grid_ok = false; c->grid_live = false;
+  const double rm = std::max(c->rmax_max, c->rmax_hint);
+  if (!c->have_domain || !c->have_floes || !(rm > 0.0)) return;
+  const double x0 = c->h_vals[3], xf = c->h_vals[2], y0 = c->h_vals[1], yf = c->h_vals[0];     // W, E, S, N
+  if (!(xf > x0) || !(yf > y0)) return;
+  long long ncx = std::max(1LL, (long long)std::floor((xf - x0) / (2.0 * rm)));
+  long long ncy = std::max(1LL, (long long)std::floor((yf - y0) / (2.0 * rm)));
+  while (ncx * ncy > (long long)c->S.capCells) { ncx = std::max(1LL, ncx / 2); ncy = std::max(1LL, ncy / 2); }
+  double* g = c->h_grid;
+  g[0] = x0; g[1] = y0; g[2] = (xf - x0) / (double)ncx; g[3] = (yf - y0) / (double)ncy; g[4] = (double)ncx; g[5] = (double)ncy;
+  g[6] = c->S.any_periodic_ew ? 1.0 : 0.0; g[7] = c->S.any_periodic_ns ? 1.0 : 0.0;
+  c->grid_ok = true;
+}
+// make the static grid the live one (a process-mode call may have fitted a grid to the centroids meanwhile)
+void use_static_grid(sz_ctx* c) {
+  if (c->grid_live) return;
+  (void)hipMemcpyAsync(c->S.bounds, c->h_grid, 8 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  (void)hipMemsetAsync(c->S.cell_cnt, 0, ((size_t)c->S.capCells + 1) * sizeof(int), c->stream);
+  c->grid_live = true;
+}
+
 // ---------------------------------------------------------------- pipeline stages
 // in_step: the previous step's ghosts are dropped by the flag kernel and the commit is done by
 // the bounds kernel of the broad phase (which always follows inside a step)
-void stage_ghosts(sz_ctx* c, bool in_step = false) {
+// commit: the flag/scan kernel commits the new counts itself (resident steps with the static grid, where no
+// bounds kernel follows); otherwise the bounds kernel (in_step) or a commit launch does
+void stage_ghosts(sz_ctx* c, bool in_step = false, bool commit = false) {
   State& S = c->S;
   if (!S.any_periodic_ew && !S.any_periodic_ns) return;
   Timed t(c, SZ_K_GHOSTS);
   const int nb = grid_for(S.capM, SCAN_B, 1 << 20);
-  hipLaunchKernelGGL(sz_k_ghost_flag_scan, dim3(nb), dim3(SCAN_B), 0, c->stream, S, in_step ? 1 : 0, next_epoch(c));
-  hipLaunchKernelGGL(sz_k_ghost_fill, dim3(grid_for(S.capM, 32, 2048)), dim3(256), 0, c->stream, S);
+  hipLaunchKernelGGL(sz_k_ghost_flag_scan, dim3(nb), dim3(SCAN_B), 0, c->stream, S, in_step ? 1 : 0, commit ? 1 : 0, next_epoch(c));
+  hipLaunchKernelGGL(sz_k_ghost_fill, dim3(grid_for(S.capM, 32, 2048)), dim3(256), 0, c->stream, S, commit ? 1 : 0);
   if (!in_step) hipLaunchKernelGGL(sz_k_ghost_commit, dim3(1), dim3(64), 0, c->stream, S);
   t.end();
 }
 
-void stage_broad(sz_ctx* c, bool commit_ghosts = false) {
+// static_grid: the geometry in S.bounds is the host's (use_static_grid), no bounds kernel; the pair kernel does
+// the housekeeping the bounds kernel would have done
+void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false) {
   State& S = c->S;
   Timed t(c, SZ_K_BROAD);
   int gM = grid_for(S.capM, 256);
-  hipLaunchKernelGGL(sz_k_bounds, dim3(1), dim3(1024), 0, c->stream, S, commit_ghosts ? 1 : 0);
+  if (!static_grid) {
+    hipLaunchKernelGGL(sz_k_bounds, dim3(1), dim3(1024), 0, c->stream, S, commit_ghosts ? 1 : 0);
+    c->grid_live = false;
+  }
   hipLaunchKernelGGL(sz_k_cell_build, dim3(gM), dim3(256), 0, c->stream, S);
   hipLaunchKernelGGL(sz_k_neighbors, dim3(grid_for(S.capM, NB_TPB / NB_G, 8192)), dim3(NB_TPB), 0, c->stream, S);
   int nb = grid_for(S.capM, SCAN_B, 1 << 20);
-  hipLaunchKernelGGL(sz_k_pscan_fill, dim3(nb), dim3(SCAN_B), 0, c->stream, S, next_epoch(c));
+  hipLaunchKernelGGL(sz_k_pscan_fill, dim3(nb), dim3(SCAN_B), 0, c->stream, S, next_epoch(c), static_grid ? 1 : 0);
   t.end();
 }
 
@@ -317,8 +351,8 @@ void stage_reduce(sz_ctx* c, int mirror, int n_init, int dt) {
   t.end();
 }
 
-void collisions(sz_ctx* c, int n_init, int dt, bool commit_ghosts = false) {
-  stage_broad(c, commit_ghosts);
+void collisions(sz_ctx* c, int n_init, int dt, bool commit_ghosts = false, bool static_grid = false) {
+  stage_broad(c, commit_ghosts, static_grid);
   stage_elems(c, true);
   stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap);
   stage_reduce(c, 1, n_init, dt);
@@ -481,7 +515,9 @@ int sz_set_domain(sz_ctx* c, const int32_t* kinds, const double* vals, const dou
   for (int k = 0; k < 4; k++) { c->h_kinds[k] = kinds[k]; c->h_vals[k] = vals[k]; c->h_bu[k] = bu ? bu[k] : 0.0; c->h_bv[k] = bv ? bv[k] : 0.0; }
   memcpy(c->h_rects, rects, 16 * sizeof(double));
   // keep the grid fields alive across the element re-upload
-  return upload_elements(c);
+  int rc = upload_elements(c);
+  if (!rc) setup_grid(c);
+  return rc;
 }
 
 int sz_set_topography(sz_ctx* c, int32_t ntopo, const int32_t* off, const double* x, const double* y, const double* cx,
@@ -602,6 +638,9 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   hipLaunchKernelGGL(sz_k_osign, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->hostM = M; c->hostN = N; c->have_floes = true; c->tile_dirty = false;
+  c->rmax_max = 0.0; c->rmax_hint = 0.0;
+  if (f->rmax) for (int i = 0; i < M; i++) c->rmax_max = std::max(c->rmax_max, f->rmax[i]);
+  setup_grid(c);
   c->fuse_lists.assign(M, {});
   return SZ_OK;
 }
@@ -885,15 +924,17 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     if (c->S.tiled) { c->err = "two-way coupling is not available in tiled runs"; return SZ_E_STATE; }
     int rc = ensure_two_way(c); if (rc) return rc;
   }
+  const bool sg = coll && c->grid_ok && !c->no_static_grid;
+  if (sg) use_static_grid(c);
   for (int s = 0; s < nsteps; s++) {
     int tstep = tstep0 + s;
     const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
     const bool overlap = coupling && !c->two_way && (c->overlap_forcing < 0 ? c->hostN >= 32768 : c->overlap_forcing != 0);
     // with collisions on, the ghosts of step s are detached by the ghost kernels of step s+1 (nothing
     // in between looks past the parents) and committed by the bounds kernel: two launches less
-    if (coll) stage_ghosts(c, true);
+    if (coll) stage_ghosts(c, true, sg);
     if (overlap) stage_forcing_fork(c);      // after the ghost pass: it may wrap a parent around the domain
-    if (coll) collisions(c, c->hostN, dt, periodic);
+    if (coll) collisions(c, c->hostN, dt, periodic && !sg, sg);
     if (coupling && !overlap) stage_forcing(c, dt);
     if (overlap) stage_forcing_join(c);
     stage_integrate(c, dt, !coll, coupling);
@@ -922,7 +963,7 @@ int sz_kernel_time_ms(sz_ctx* c, int32_t k, double* ms, int64_t* launches) {
 
 
 // ---------------------------------------------------------------- multi-GPU halo API
-int sz_tile_enable(sz_ctx* c, const int64_t* gidx, double halo_capacity_factor) {
+int sz_tile_enable(sz_ctx* c, const int64_t* gidx, double halo_capacity_factor, double max_rmax) {
   if (!c || !c->have_floes || !gidx) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
   State& S = c->S;
@@ -934,6 +975,10 @@ int sz_tile_enable(sz_ctx* c, const int64_t* gidx, double halo_capacity_factor) 
   S.tiled = 1;
   // largest ring among ALL ranks' floes (halo floes arrive unseen): decides which narrow variants can be needed
   c->max_ring_tiled = halo_capacity_factor > 0 ? (int)halo_capacity_factor : HALO_RING;
+  // largest rmax among ALL ranks' floes: the static broad-phase grid must hold for halo floes too (0: unknown ->
+  // the grid is fitted to the centroids every step instead)
+  c->rmax_hint = max_rmax; c->rmax_max = max_rmax > 0 ? c->rmax_max : 0.0;
+  setup_grid(c);
   return SZ_OK;
 }
 
@@ -997,9 +1042,11 @@ int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int
   // floes of the LAST step are dropped when the host next looks at the state (tile_cleanup).
   // n_init = every local parent (owned + halo): totals of halo floes are computed and then ignored
   const bool coll = (flags & SZ_COLLISIONS_ON) != 0;
-  if (coll) stage_ghosts(c, true);
+  const bool sg = coll && c->grid_ok && !c->no_static_grid;
+  if (sg) use_static_grid(c);
+  if (coll) stage_ghosts(c, true, sg);
   if (overlap) stage_forcing_fork(c);               // owned floes only (C_NOWN); after the ghost pass, which may wrap a parent
-  if (coll) collisions(c, -1, dt, periodic);
+  if (coll) collisions(c, -1, dt, periodic && !sg, sg);
   if (coupling && !overlap) stage_forcing(c);
   if (overlap) stage_forcing_join(c);
   stage_integrate(c, dt, false, coupling);

@@ -250,11 +250,11 @@ __device__ __forceinline__ int ghost_dir(const State& S, int i, int axis) {
 // plan of both passes for every parent: gplan[i] = {E/W ghosts, E/W points, N/S ghosts, N/S points}
 // `drop_old`: ghosts of the previous step are still attached (their removal, simulation.jl:138-144,
 // was deferred because nothing after the collision kernels looks at them): detach them here.
-__device__ __forceinline__ int4 ghost_plan(State& S, int i, int N, int drop_old) {
+__device__ __forceinline__ int4 ghost_plan(State& S, int i, int N, int drop_old, int commit) {
   if (drop_old) {
     S.ngh[i] = 0;
     for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = -1;
-    if (i == 0) { S.cnt[C_M] = N; S.cnt[C_NV] = S.voff[N]; }
+    if (i == 0 && !commit) { S.cnt[C_M] = N; S.cnt[C_NV] = S.voff[N]; }
   }
   int dx = 0, dy = 0;
   if (S.status[i] == SZ_ACTIVE && S.ghost_id[i] == 0) {
@@ -263,25 +263,36 @@ __device__ __forceinline__ int4 ghost_plan(State& S, int i, int N, int drop_old)
   }
   int nv = S.voff[i + 1] - S.voff[i];
   int gew = dx != 0 ? 1 : 0, gns = dy != 0 ? 1 + gew : 0;
-  if (i == 0) S.cnt[C_NGHOSTS] = 0;               // last step's count is kept until here for the stats
+  if (i == 0 && !commit) S.cnt[C_NGHOSTS] = 0;    // last step's count is kept until here for the stats
   S.gflag[i] = (dx + 1) | ((dy + 1) << 2);
   int4 plan = make_int4(gew, gew * nv, gns, gns * nv);
   S.gplan[i] = plan;
   return plan;
 }
-// flag kernel + the whole int4 scan of the plan in one launch (look-back scan)
-__global__ void __launch_bounds__(SCAN_B) sz_k_ghost_flag_scan(State S, int drop_old, unsigned epoch) {
+// flag kernel + the whole int4 scan of the plan in one launch (look-back scan).  commit (resident steps, always
+// with drop_old): the thread that sees the totals also commits the new counts (ghost_commit below), so that no
+// single-workgroup launch has to follow the fill kernel; the fill kernel then takes its base from C_N.
+__global__ void __launch_bounds__(SCAN_B) sz_k_ghost_flag_scan(State S, int drop_old, int commit, unsigned epoch) {
   __shared__ int4 tot;
   const int n = S.cnt[C_N];
   const int base = blockIdx.x * SCAN_B;
   if (base >= n && blockIdx.x != 0) return;          // tiles past the end: nobody waits for them
   const int i = base + threadIdx.x;
-  const int4 v = i < n ? ghost_plan(S, i, n, drop_old) : make_int4(0, 0, 0, 0);
+  const int4 v = i < n ? ghost_plan(S, i, n, drop_old, commit) : make_int4(0, 0, 0, 0);
   const int4 ex = block_exclusive_scan4(v, &tot);
   const int4 before = lookback_prefix4(S, tot, epoch);
   if (i < n) S.gscan4[i] = add4(ex, before);
-  if (n == 0) { if (i == 0) S.gtot4[0] = make_int4(0, 0, 0, 0); }
-  else if (i == n - 1) S.gtot4[0] = add4(add4(ex, before), v);
+  if (n == 0 ? i == 0 : i == n - 1) {
+    const int4 T = n == 0 ? make_int4(0, 0, 0, 0) : add4(add4(ex, before), v);
+    S.gtot4[0] = T;
+    if (commit) {
+      const int newg = T.x + T.z, newv = T.y + T.w, nv0 = S.voff[n];
+      const bool fits = n + newg <= S.capM && nv0 + newv <= S.capV;       // else the fill kernel raises the error
+      const int M = fits ? n + newg : n;
+      S.cnt[C_M] = M; S.cnt[C_NV] = fits ? nv0 + newv : nv0; S.cnt[C_NGHOSTS] = fits ? newg : 0;
+      if (fits) S.voff[M] = nv0 + newv;
+    }
+  }
 }
 
 __device__ __forceinline__ void copy_floe_row(State& S, int dst, int src) {
@@ -314,8 +325,8 @@ __device__ __forceinline__ void rig_store(State& S, int lane, int f, int vo, int
 }
 
 // gscan4 holds the exclusive int4 scan of gplan, gtot4[0] the totals
-__global__ void __launch_bounds__(256) sz_k_ghost_fill(State S) {
-  int N = S.cnt[C_N], M0 = S.cnt[C_M], NV0 = S.cnt[C_NV];
+__global__ void __launch_bounds__(256) sz_k_ghost_fill(State S, int committed) {
+  int N = S.cnt[C_N], M0 = committed ? N : S.cnt[C_M], NV0 = committed ? S.voff[N] : S.cnt[C_NV];
   int4 T = S.gtot4[0];
   if (M0 + T.x + T.z > S.capM) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
   if (NV0 + T.y + T.w > S.capV) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); return; }
@@ -466,7 +477,8 @@ __global__ void __launch_bounds__(1024) sz_k_bounds(State S, int commit_ghosts) 
     }
     S.cnt[C_ITEMCLASS] = 0;                              // narrow-phase size classes of this step
     S.cnt[C_WARN_H] = 0; S.cnt[C_WARN_F] = 0; S.cnt[C_WARN_V] = 0; S.cnt[C_WARN_XI] = 0;   // guards of the coming update
-    S.bounds[0] = x0; S.bounds[1] = y0; S.bounds[2] = cs; S.bounds[3] = (double)ncx; S.bounds[4] = (double)ncy;
+    S.bounds[0] = x0; S.bounds[1] = y0; S.bounds[2] = cs; S.bounds[3] = cs; S.bounds[4] = (double)ncx; S.bounds[5] = (double)ncy;
+    S.bounds[6] = 0.0; S.bounds[7] = 0.0;       // a grid fitted to the centroids neither wraps nor clamps
     S.cnt[C_NCELLS] = (int)(ncx * ncy);
     s_ncells = (int)(ncx * ncy);
   }
@@ -475,12 +487,32 @@ __global__ void __launch_bounds__(1024) sz_k_bounds(State S, int commit_ghosts) 
 }
 // uniform-grid binning as per-cell linked lists (atomic exchange on the cell heads): no counting
 // pass, no scan.  The order inside a cell is arbitrary; the consumers sort by order key.
+// Grid geometry lives in bounds[0..7] = x0, y0, cell size x / y, cells x / y, wrap x / y.  It is either fitted to
+// the centroids every call (sz_k_bounds: no wrap, every floe inside) or fixed by the host for the resident steps
+// (static grid: the domain box, indices WRAP in a periodic direction -- a ghost then shares the cell of its
+// parent's image -- and are CLAMPED in a non-periodic one; both maps are 1-Lipschitz in cell units, so floes
+// closer than one cell size still land in adjacent cells).
+struct GridGeo { double x0, y0, csx, csy; int ncx, ncy, wrapx, wrapy; };
+__device__ __forceinline__ GridGeo grid_geo(const State& S) {
+  GridGeo g;
+  g.x0 = S.bounds[0]; g.y0 = S.bounds[1]; g.csx = S.bounds[2]; g.csy = S.bounds[3];
+  g.ncx = (int)S.bounds[4]; g.ncy = (int)S.bounds[5]; g.wrapx = (int)S.bounds[6]; g.wrapy = (int)S.bounds[7];
+  return g;
+}
+__device__ __forceinline__ int cell_fold(int i, int n, int wrap) {
+  if (wrap) { i %= n; return i < 0 ? i + n : i; }
+  return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+__device__ __forceinline__ void cell_of(const GridGeo& g, double x, double y, int& ix, int& iy) {
+  ix = cell_fold((int)floor((x - g.x0) / g.csx), g.ncx, g.wrapx);
+  iy = cell_fold((int)floor((y - g.y0) / g.csy), g.ncy, g.wrapy);
+}
 __global__ void sz_k_cell_build(State S) {
   int M = S.cnt[C_M];
-  double x0 = S.bounds[0], y0 = S.bounds[1], cs = S.bounds[2]; int ncx = (int)S.bounds[3];
+  const GridGeo g = grid_geo(S);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
-    int ix = (int)floor((S.cx[i] - x0) / cs), iy = (int)floor((S.cy[i] - y0) / cs);
-    int c = iy * ncx + ix;
+    int ix, iy; cell_of(g, S.cx[i], S.cy[i], ix, iy);
+    int c = iy * g.ncx + ix;
     S.cell_items[i] = atomicExch(&S.cell_cnt[c], i + 1) - 1;   // cell_cnt holds head + 1 (0 = empty)
   }
 }
@@ -531,20 +563,28 @@ __global__ void __launch_bounds__(NB_TPB) sz_k_neighbors(State S) {
   __shared__ int wmask[GPB];
   const int gl = threadIdx.x % NB_G, gi = threadIdx.x / NB_G;
   int M = S.cnt[C_M];
-  double x0 = S.bounds[0], y0 = S.bounds[1], cs = S.bounds[2]; int ncx = (int)S.bounds[3], ncy = (int)S.bounds[4];
+  const GridGeo g = grid_geo(S);
+  const int ncx = g.ncx, ncy = g.ncy;
   for (int k = blockIdx.x * GPB + gi; k < M; k += gridDim.x * GPB) {
     gsync();
     if (gl == 0) { cnts[gi][0] = 0; cnts[gi][1] = 0; wmask[gi] = 0; }
     gsync();
     double ckx = S.cx[k], cky = S.cy[k], rk = S.rmax[k];
     const double kx0 = S.bbx0[k], kx1 = S.bbx1[k], ky0 = S.bby0[k], ky1 = S.bby1[k];
-    int ix = (int)floor((ckx - x0) / cs), iy = (int)floor((cky - y0) / cs);
+    int ix, iy; cell_of(g, ckx, cky, ix, iy);
     long long idk = S.id[k], okk = S.okey[k];
     const bool kplain = S.parent[k] == k && S.ngh[k] == 0;
     bool ovf = false;
     if (gl < 9) {
-      int cy = iy + gl / 3 - 1, cxi = ix + gl % 3 - 1;
-      if (cy >= 0 && cy < ncy && cxi >= 0 && cxi < ncx) {
+      const int oy = gl / 3 - 1, ox = gl % 3 - 1;
+      int cy = iy + oy, cxi = ix + ox;
+      bool visit = true;
+      // a wrapped direction with fewer than three cells would meet the same cell twice
+      if (g.wrapx) { cxi = cell_fold(cxi, ncx, 1); if ((ncx == 1 && ox != 0) || (ncx == 2 && ox > 0)) visit = false; }
+      else if (cxi < 0 || cxi >= ncx) visit = false;
+      if (g.wrapy) { cy = cell_fold(cy, ncy, 1); if ((ncy == 1 && oy != 0) || (ncy == 2 && oy > 0)) visit = false; }
+      else if (cy < 0 || cy >= ncy) visit = false;
+      if (visit) {
         for (int o = S.cell_cnt[cy * ncx + cxi] - 1, nxt; o >= 0; o = nxt) {
           // everything the tests below may need about o is requested at once (one round trip per list node)
           nxt = S.cell_items[o];
@@ -593,10 +633,21 @@ __global__ void __launch_bounds__(NB_TPB) sz_k_neighbors(State S) {
 // Scan of {outgoing pairs, pairs to run} per floe (look-back scan) and the pair fill in one launch: thread i
 // gets out_off[i] and its work-list offset, writes the pairs floe i owns and appends those with overlapping ring
 // boxes to the work list of the narrow phase; the others get their (empty) result here.
-__global__ void __launch_bounds__(SCAN_B) sz_k_pscan_fill(State S, unsigned epoch) {
+// housekeeping (static grid: no bounds kernel runs): the cell heads, which the neighbour kernel has consumed, are
+// cleared for the next step and the per-step counters reset
+__global__ void __launch_bounds__(SCAN_B) sz_k_pscan_fill(State S, unsigned epoch, int housekeeping) {
   __shared__ int4 tot;
   const int n = S.cnt[C_M];
   const int base = blockIdx.x * SCAN_B;
+  if (housekeeping) {
+    const int ncells = (int)S.bounds[4] * (int)S.bounds[5];
+    const int nlive = (n + SCAN_B - 1) / SCAN_B > 0 ? (n + SCAN_B - 1) / SCAN_B : 1;      // workgroups that do not return below
+    if ((int)blockIdx.x < nlive) for (int q = base + threadIdx.x; q <= ncells; q += nlive * SCAN_B) S.cell_cnt[q] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      S.cnt[C_ITEMCLASS] = 0;
+      S.cnt[C_WARN_H] = 0; S.cnt[C_WARN_F] = 0; S.cnt[C_WARN_V] = 0; S.cnt[C_WARN_XI] = 0;
+    }
+  }
   if (base >= n && blockIdx.x != 0) return;
   const int i = base + threadIdx.x;
   const int nk = i < n ? S.n_out[i] : 0, mask = i < n ? S.out_mask[i] : 0;

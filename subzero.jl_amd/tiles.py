@@ -102,7 +102,8 @@ class TiledWorld:
         w._push()
         g = np.ascontiguousarray(self.gidx, np.int64)
         max_ring = float(np.diff(cfg["vert_off"]).max())        # over ALL floes: halo floes arrive unseen
-        w._chk(w.L.sz_tile_enable(w.h, capi.ptr(g, capi._lp), max_ring))
+        max_rmax = float(cfg["derived"]["rmax"].max())          # over ALL floes, like max_ring
+        w._chk(w.L.sz_tile_enable(w.h, capi.ptr(g, capi._lp), max_ring, max_rmax))
         self.world = w
         self.REC = w.L.sz_halo_record_doubles()
         self.dev = torch.device("cuda", device)
