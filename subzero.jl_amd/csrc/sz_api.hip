@@ -240,8 +240,11 @@ void setup_grid(sz_ctx* c) {
   if (!c->have_domain || !c->have_floes || !(rm > 0.0)) return;
   const double x0 = c->h_vals[3], xf = c->h_vals[2], y0 = c->h_vals[1], yf = c->h_vals[0];     // W, E, S, N
   if (!(xf > x0) || !(yf > y0)) return;
-  long long ncx = std::max(1LL, (long long)std::floor((xf - x0) / (2.0 * rm)));
-  long long ncy = std::max(1LL, (long long)std::floor((yf - y0) / (2.0 * rm)));
+  // cells a hair wider than 2 max(rmax): a floe binned one cell off by round-off at a cell edge (e.g. a parent
+  // wrapped by exactly one domain length after it was binned) still meets every floe whose circle touches its own
+  const double cmin = 2.0 * rm * (1.0 + 1e-9);
+  long long ncx = std::max(1LL, (long long)std::floor((xf - x0) / cmin));
+  long long ncy = std::max(1LL, (long long)std::floor((yf - y0) / cmin));
   while (ncx * ncy > (long long)c->S.capCells) { ncx = std::max(1LL, ncx / 2); ncy = std::max(1LL, ncy / 2); }
   double* g = c->h_grid;
   g[0] = x0; g[1] = y0; g[2] = (xf - x0) / (double)ncx; g[3] = (yf - y0) / (double)ncy; g[4] = (double)ncx; g[5] = (double)ncy;
@@ -253,6 +256,7 @@ void use_static_grid(sz_ctx* c) {
   if (c->grid_live) return;
   (void)hipMemcpyAsync(c->S.bounds, c->h_grid, 8 * sizeof(double), hipMemcpyHostToDevice, c->stream);
   (void)hipMemsetAsync(c->S.cell_cnt, 0, ((size_t)c->S.capCells + 1) * sizeof(int), c->stream);
+  hipLaunchKernelGGL(sz_k_cell_build, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 1);
   c->grid_live = true;
 }
 
@@ -267,7 +271,7 @@ void stage_ghosts(sz_ctx* c, bool in_step = false, bool commit = false) {
   Timed t(c, SZ_K_GHOSTS);
   const int nb = grid_for(S.capM, SCAN_B, 1 << 20);
   hipLaunchKernelGGL(sz_k_ghost_flag_scan, dim3(nb), dim3(SCAN_B), 0, c->stream, S, in_step ? 1 : 0, commit ? 1 : 0, next_epoch(c));
-  hipLaunchKernelGGL(sz_k_ghost_fill, dim3(grid_for(S.capM, 32, 2048)), dim3(256), 0, c->stream, S, commit ? 1 : 0);
+  hipLaunchKernelGGL(sz_k_ghost_fill, dim3(grid_for(S.capM, 32, 2048)), dim3(256), 0, c->stream, S, commit ? 1 : 0, commit ? 1 : 0);
   if (!in_step) hipLaunchKernelGGL(sz_k_ghost_commit, dim3(1), dim3(64), 0, c->stream, S);
   t.end();
 }
@@ -278,11 +282,11 @@ void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false
   State& S = c->S;
   Timed t(c, SZ_K_BROAD);
   int gM = grid_for(S.capM, 256);
-  if (!static_grid) {
+  if (!static_grid) {          // with the static grid the lists are already current (see sz_k_cell_build)
     hipLaunchKernelGGL(sz_k_bounds, dim3(1), dim3(1024), 0, c->stream, S, commit_ghosts ? 1 : 0);
+    hipLaunchKernelGGL(sz_k_cell_build, dim3(gM), dim3(256), 0, c->stream, S, 0);
     c->grid_live = false;
   }
-  hipLaunchKernelGGL(sz_k_cell_build, dim3(gM), dim3(256), 0, c->stream, S);
   hipLaunchKernelGGL(sz_k_neighbors, dim3(grid_for(S.capM, NB_TPB / NB_G, 8192)), dim3(NB_TPB), 0, c->stream, S);
   int nb = grid_for(S.capM, SCAN_B, 1 << 20);
   hipLaunchKernelGGL(sz_k_pscan_fill, dim3(nb), dim3(SCAN_B), 0, c->stream, S, next_epoch(c), static_grid ? 1 : 0);
@@ -417,13 +421,14 @@ void stage_forcing(sz_ctx* c, int dt = -1) {      // in-order variant (process m
   }
   t.end();
 }
-void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc) {
+void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool bin = false) {
   // the guard counters describe the last timestep_floe_properties! call (inside a step the
   // ghost-removal kernel has already cleared them)
   if (reset_guards) (void)hipMemsetAsync(c->S.cnt + C_WARN_H, 0, 4 * sizeof(int), c->stream);
   Timed t(c, SZ_K_INTEGRATE);
   hipLaunchKernelGGL(sz_k_integrate, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0);
-  hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 0);
+  hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 0, bin ? 1 : 0);
+  if (!bin) c->grid_live = false;          // floes moved without re-binning: the resident steps' cell lists are stale
   t.end();
 }
 
@@ -910,7 +915,7 @@ int sz_calc_stress(sz_ctx* c) {
 int sz_calc_strain(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
-  hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 1);
+  hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 1, 0);
   return sync_and_check(c);
 }
 
@@ -937,7 +942,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     if (coll) collisions(c, c->hostN, dt, periodic && !sg, sg);
     if (coupling && !overlap) stage_forcing(c, dt);
     if (overlap) stage_forcing_join(c);
-    stage_integrate(c, dt, !coll, coupling);
+    stage_integrate(c, dt, !coll, coupling, sg);
   }
   if (coll && periodic) hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
   return sync_and_check(c);
@@ -1030,8 +1035,11 @@ int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
   State& S = c->S;
+  const bool coll = (flags & SZ_COLLISIONS_ON) != 0;
+  const bool sg = coll && c->grid_ok && !c->no_static_grid;
+  if (sg) use_static_grid(c);
   if (d_recv && nranks > 0) {
-    hipLaunchKernelGGL(sz_k_halo_unpack, dim3(1), dim3(1024), 0, c->stream, S, (const double*)d_recv, nranks, cap);
+    hipLaunchKernelGGL(sz_k_halo_unpack, dim3(1), dim3(1024), 0, c->stream, S, (const double*)d_recv, nranks, cap, sg ? 1 : 0);
   }
   const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
   const bool overlap = coupling && (c->overlap_forcing < 0 ? c->hostN >= 32768 : c->overlap_forcing != 0);
@@ -1041,15 +1049,12 @@ int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int
   // between two steps looks past the owned floes, so no clean-up launch is needed per step: the ghosts and halo
   // floes of the LAST step are dropped when the host next looks at the state (tile_cleanup).
   // n_init = every local parent (owned + halo): totals of halo floes are computed and then ignored
-  const bool coll = (flags & SZ_COLLISIONS_ON) != 0;
-  const bool sg = coll && c->grid_ok && !c->no_static_grid;
-  if (sg) use_static_grid(c);
   if (coll) stage_ghosts(c, true, sg);
   if (overlap) stage_forcing_fork(c);               // owned floes only (C_NOWN); after the ghost pass, which may wrap a parent
   if (coll) collisions(c, -1, dt, periodic && !sg, sg);
   if (coupling && !overlap) stage_forcing(c);
   if (overlap) stage_forcing_join(c);
-  stage_integrate(c, dt, false, coupling);
+  stage_integrate(c, dt, false, coupling, sg);
   c->tile_dirty = true;
   return SZ_OK;
 }

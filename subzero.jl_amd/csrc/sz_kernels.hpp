@@ -130,6 +130,33 @@ __global__ void sz_k_elem_osign(State S) {
   }
 }
 
+// Grid geometry lives in bounds[0..7] = x0, y0, cell size x / y, cells x / y, wrap x / y.  It is either fitted to
+// the centroids every call (sz_k_bounds: no wrap, every floe inside) or fixed by the host for the resident steps
+// (static grid: the domain box, indices WRAP in a periodic direction -- a ghost then shares the cell of its
+// parent's image -- and are CLAMPED in a non-periodic one; both maps are 1-Lipschitz in cell units, so floes
+// closer than one cell size still land in adjacent cells).
+struct GridGeo { double x0, y0, csx, csy; int ncx, ncy, wrapx, wrapy; };
+__device__ __forceinline__ GridGeo grid_geo(const State& S) {
+  GridGeo g;
+  g.x0 = S.bounds[0]; g.y0 = S.bounds[1]; g.csx = S.bounds[2]; g.csy = S.bounds[3];
+  g.ncx = (int)S.bounds[4]; g.ncy = (int)S.bounds[5]; g.wrapx = (int)S.bounds[6]; g.wrapy = (int)S.bounds[7];
+  return g;
+}
+__device__ __forceinline__ int cell_fold(int i, int n, int wrap) {
+  if (wrap) { i %= n; return i < 0 ? i + n : i; }
+  return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+__device__ __forceinline__ void cell_of(const GridGeo& g, double x, double y, int& ix, int& iy) {
+  ix = cell_fold((int)floor((x - g.x0) / g.csx), g.ncx, g.wrapx);
+  iy = cell_fold((int)floor((y - g.y0) / g.csy), g.ncy, g.wrapy);
+}
+// one floe into the per-cell linked lists (cell_cnt holds head + 1, 0 = empty; the order inside a cell is arbitrary,
+// the consumers sort by order key)
+__device__ __forceinline__ void cell_insert(const State& S, const GridGeo& g, int i, double x, double y) {
+  int ix, iy; cell_of(g, x, y, ix, iy);
+  S.cell_items[i] = atomicExch(&S.cell_cnt[iy * g.ncx + ix], i + 1) - 1;
+}
+
 // ============================================================================ ghosts (A1)
 // add_ghosts! (collisions.jl:1060-1174) runs an east/west pass and then a north/south pass over
 // the parents.  Whether a parent gets a ghost in a pass depends on that parent alone (the x-swap of
@@ -325,7 +352,8 @@ __device__ __forceinline__ void rig_store(State& S, int lane, int f, int vo, int
 }
 
 // gscan4 holds the exclusive int4 scan of gplan, gtot4[0] the totals
-__global__ void __launch_bounds__(256) sz_k_ghost_fill(State S, int committed) {
+__global__ void __launch_bounds__(256) sz_k_ghost_fill(State S, int committed, int bin) {
+  const GridGeo geo = grid_geo(S);
   int N = S.cnt[C_N], M0 = committed ? N : S.cnt[C_M], NV0 = committed ? S.voff[N] : S.cnt[C_NV];
   int4 T = S.gtot4[0];
   if (M0 + T.x + T.z > S.capM) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
@@ -394,6 +422,7 @@ __global__ void __launch_bounds__(256) sz_k_ghost_fill(State S, int committed) {
         rig_store(S, lane, g, vbs[w], n, Gs[w]);
         S.voff[g] = vbs[w]; S.voff[g + 1] = vbs[w] + n;   // neighbours write the same values: rings are packed back to back
         S.ghost_id[g] = (long long)gid[w]; S.parent[g] = i; S.okey[g] = key[w];
+        if (bin && lane == 0) cell_insert(S, geo, g, Gs[w].cx, Gs[w].cy);
         if (lane < MAX_GHOSTS) S.gh[g * MAX_GHOSTS + lane] = -1;
       }
       if (moved) rig_store(S, lane, i, vo, n, P);
@@ -485,36 +514,13 @@ __global__ void __launch_bounds__(1024) sz_k_bounds(State S, int commit_ghosts) 
   __syncthreads();
   for (int q = threadIdx.x; q <= s_ncells; q += blockDim.x) S.cell_cnt[q] = 0;
 }
-// uniform-grid binning as per-cell linked lists (atomic exchange on the cell heads): no counting
-// pass, no scan.  The order inside a cell is arbitrary; the consumers sort by order key.
-// Grid geometry lives in bounds[0..7] = x0, y0, cell size x / y, cells x / y, wrap x / y.  It is either fitted to
-// the centroids every call (sz_k_bounds: no wrap, every floe inside) or fixed by the host for the resident steps
-// (static grid: the domain box, indices WRAP in a periodic direction -- a ghost then shares the cell of its
-// parent's image -- and are CLAMPED in a non-periodic one; both maps are 1-Lipschitz in cell units, so floes
-// closer than one cell size still land in adjacent cells).
-struct GridGeo { double x0, y0, csx, csy; int ncx, ncy, wrapx, wrapy; };
-__device__ __forceinline__ GridGeo grid_geo(const State& S) {
-  GridGeo g;
-  g.x0 = S.bounds[0]; g.y0 = S.bounds[1]; g.csx = S.bounds[2]; g.csy = S.bounds[3];
-  g.ncx = (int)S.bounds[4]; g.ncy = (int)S.bounds[5]; g.wrapx = (int)S.bounds[6]; g.wrapy = (int)S.bounds[7];
-  return g;
-}
-__device__ __forceinline__ int cell_fold(int i, int n, int wrap) {
-  if (wrap) { i %= n; return i < 0 ? i + n : i; }
-  return i < 0 ? 0 : (i >= n ? n - 1 : i);
-}
-__device__ __forceinline__ void cell_of(const GridGeo& g, double x, double y, int& ix, int& iy) {
-  ix = cell_fold((int)floor((x - g.x0) / g.csx), g.ncx, g.wrapx);
-  iy = cell_fold((int)floor((y - g.y0) / g.csy), g.ncy, g.wrapy);
-}
-__global__ void sz_k_cell_build(State S) {
-  int M = S.cnt[C_M];
+// uniform-grid binning as per-cell linked lists (atomic exchange on the cell heads): no counting pass, no scan.
+// parents_only: the resident steps keep the lists current themselves (the kernels that place a floe -- integrator,
+// ghost fill, halo unpack -- also bin it); this launch then only seeds them with the parents once.
+__global__ void sz_k_cell_build(State S, int parents_only) {
+  int M = parents_only ? S.cnt[C_N] : S.cnt[C_M];
   const GridGeo g = grid_geo(S);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
-    int ix, iy; cell_of(g, S.cx[i], S.cy[i], ix, iy);
-    int c = iy * g.ncx + ix;
-    S.cell_items[i] = atomicExch(&S.cell_cnt[c], i + 1) - 1;   // cell_cnt holds head + 1 (0 = empty)
-  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) cell_insert(S, g, i, S.cx[i], S.cy[i]);
 }
 
 // potential_interaction, collisions.jl:705-710 (bounding circles, strict <)
@@ -1253,7 +1259,8 @@ __global__ void sz_k_integrate(State S, Params P, int dt, int apply_frc) {
 // coordinates recomputed in registers (same expression as the store, hence the same bits), the
 // ring is overwritten afterwards, and the per-edge terms are summed in ring order.
 // strain_only: calc_strain! on its own -- the ring stays where it is and nothing but the strain is written
-__global__ void __launch_bounds__(256) sz_k_move_strain(State S, int strain_only) {
+__global__ void __launch_bounds__(256) sz_k_move_strain(State S, int strain_only, int bin) {
+  const GridGeo geo = grid_geo(S);
   constexpr int G = 16;
   __shared__ double t11[256 / G][64], t12[256 / G][64], t22[256 / G][64];
   int N = S.cnt[C_NOWN];
@@ -1305,6 +1312,7 @@ __global__ void __launch_bounds__(256) sz_k_move_strain(State S, int strain_only
       double d = 2 * S.area[i];
       S.strain[i * 4 + 0] = e11 / d; S.strain[i * 4 + 1] = e12 / d; S.strain[i * 4 + 2] = e12 / d; S.strain[i * 4 + 3] = e22 / d;
       if (!strain_only) { S.cx[i] = ncx; S.cy[i] = ncy; }
+      if (bin) cell_insert(S, geo, i, ncx, ncy);          // for the next step's neighbour search
     }
   }
 }
@@ -1357,7 +1365,8 @@ __global__ void __launch_bounds__(1024) sz_k_halo_pack(State S, int nranks, int 
 // `cap` record slots.  The host never needs the counts, so a whole step is enqueued without a sync.
 // One block appends the received floes as extra parents [nown, nown + nrec): ring offsets by an
 // in-kernel scan of the ring sizes, then the copy.
-__global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* recv, int nranks, int cap) {
+__global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* recv, int nranks, int cap, int bin) {
+  const GridGeo geo = grid_geo(S);
   __shared__ int before[65];
   __shared__ int tot, carry_s;
   if (threadIdx.x == 0) {
@@ -1406,6 +1415,7 @@ __global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* 
     }
     S.osign[g] = ring_signed_area(r + 12, r + 12 + HALO_RING, nv) >= 0.0 ? 1 : -1;
     S.bbx0[g] = x0; S.bbx1[g] = x1; S.bby0[g] = y0; S.bby1[g] = y1;
+    if (bin) cell_insert(S, geo, g, r[3], r[4]);
   }
   if (threadIdx.x == 0) {
     S.cnt[C_M] = nown + nrec; S.cnt[C_N] = nown + nrec; S.cnt[C_NV] = vbase + totv; S.cnt[C_NHALO] = nrec;
