@@ -108,6 +108,8 @@ def main():
                          "converge/diverge flow; 3 = four collision walls + topography, strait flow; 4 = 25 %% concentration")
     ap.add_argument("--two-way", action="store_true", help="two-way coupling on (ice-on-ocean stress per centre cell; "
                                                            "off in the metric's config, as in CouplingSettings())")
+    ap.add_argument("--precision", default="f64", choices=["f64", "mixed"],
+                    help="mixed: per-point forcing arithmetic in fp32 (BASELINE configs[4]); the metric's config is f64")
     ap.add_argument("--coupling-dt", type=int, default=1, help="couple every k-th step (reference default: 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-tiled", action="store_true", help="run the halo/RCCL path even with one rank")
@@ -147,6 +149,7 @@ def main():
         hw = fields.build_world(subzero_jl_amd.World(local), cfg)
         if args.two_way:
             hw.set_two_way(True, dt=cfg["dt"]); hw.set_temps(0.0, -10.0)
+        hw.set_precision(args.precision)
         runner = lambda n, t0: hw.run(n, t0, cfg["dt"], coupling_dt=coupling_dt)
     else:
         from subzero_jl_amd import tiles
@@ -198,7 +201,7 @@ def main():
             "metric": "floe_steps_per_sec", "value": cfg["n_floes"] * args.steps / el, "unit": "floe-steps/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
             "higher_is_better": True, "scaling": "strong" if args.total_floes > 0 else "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64" if args.precision == "f64" else "f64 (forcings: fp32 per point)", "data": "synthetic",
             "config": {"workload": f"{'configs[1]' if world == 1 else 'configs[1] field x ' + str(world) + ' GPUs (tiled, ghost-floe halo)'}: {cfg['n_floes']} random-polygon floes (8-16 verts), doubly periodic "
                                    f"box {cfg['L'] / 1e3:.0f} km, uniform_flow ocean 0.1 m/s, collisions + one-way "
                                    f"coupling every step + rigid-body update, dt={cfg['dt']} s" if args.workload == "configs1" else

@@ -62,6 +62,8 @@ struct sz_ctx {
                                   // SZ_OVERLAP=0/1 forces it off / on.
   int max_ring = 0, max_elem_ring = 5, max_ring_tiled = 0;   // largest ring sizes (host knowledge: which narrow variants can be needed)
   int narrow_grid0 = 0;
+  // mixed precision (sz_set_precision): fp32 copies for the forcing kernel, rebuilt when their sources change
+  int precision = 0; bool mixed_pts_ok = false, mixed_nodes_ok = false; std::vector<void*> mixed_pt_allocs, mixed_node_allocs;
   // two-way coupling (off by default, like CouplingSettings())
   bool two_way = false; int tw_dt = 10; int tw_capM = 0; size_t tw_ncell = 0;
   std::vector<void*> tw_allocs, tw_field_allocs;
@@ -370,11 +372,31 @@ void stage_forcing_fork(sz_ctx* c) {
   (void)hipEventRecord(c->ev_fork, c->stream);
   (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
   Timed t(c, SZ_K_FORCING, c->stream2);
-  hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream2, c->S, c->P);
+  if (c->precision == 1) hipLaunchKernelGGL(sz_k_forcing_mixed, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream2, c->S, c->P);
+  else hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream2, c->S, c->P);
   t.end();
   (void)hipEventRecord(c->ev_join, c->stream2);
 }
 void stage_forcing_join(sz_ctx* c) { (void)hipStreamWaitEvent(c->stream, c->ev_join, 0); }
+// fp32 copies of the sub-floe points and of the lattice for the mixed-precision forcing kernel
+int ensure_mixed(sz_ctx* c) {
+  State& S = c->S;
+  int rc;
+  if (!c->mixed_pts_ok) {
+    free_pool(c->mixed_pt_allocs);
+    if ((rc = dalloc(c, &S.s32, (size_t)std::max(S.capS, 1), c->mixed_pt_allocs))) return rc;
+    hipLaunchKernelGGL(sz_k_to_f32_points, dim3(grid_for(S.capS, 256)), dim3(256), 0, c->stream, S, S.capS);
+    c->mixed_pts_ok = true;
+  }
+  if (!c->mixed_nodes_ok) {
+    free_pool(c->mixed_node_allocs);
+    const size_t n = (size_t)(S.Nx + 1) * (S.Ny + 1) * 8;
+    if ((rc = dalloc(c, &S.nodes32, n, c->mixed_node_allocs))) return rc;
+    hipLaunchKernelGGL(sz_k_to_f32_nodes, dim3(grid_for((long long)n, 256)), dim3(256), 0, c->stream, S);
+    c->mixed_nodes_ok = true;
+  }
+  return SZ_OK;
+}
 // buffers of the two-way coupling: per-floe cell slots follow the floe capacity, per-cell arrays the lattice
 int ensure_two_way(sz_ctx* c) {
   State& S = c->S;
@@ -403,7 +425,9 @@ int ensure_two_way(sz_ctx* c) {
 }
 void stage_forcing(sz_ctx* c, int dt = -1) {      // in-order variant (process mode, profiling)
   Timed t(c, SZ_K_FORCING);
-  if (!c->two_way) {
+  if (!c->two_way && c->precision == 1) {
+    hipLaunchKernelGGL(sz_k_forcing_mixed, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream, c->S, c->P);
+  } else if (!c->two_way) {
     hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream, c->S, c->P);
   } else {
     // timestep_coupling! with two_way_coupling_on (coupling.jl:1705-1738): one-way forcings + per-floe cell slots,
@@ -495,6 +519,7 @@ void sz_destroy(sz_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   free_pool(c->allocs); free_pool(c->static_allocs); free_pool(c->field_allocs); free_pool(c->tw_allocs); free_pool(c->tw_field_allocs);
+  free_pool(c->mixed_pt_allocs); free_pool(c->mixed_node_allocs);
   for (auto& e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   (void)hipFree(c->d_stats);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -563,7 +588,7 @@ int sz_set_fields(sz_ctx* c, int32_t Nx, int32_t Ny, double x0, double xf, doubl
   S.Nx = Nx; S.Ny = Ny; S.gx0 = x0; S.gxf = xf; S.gy0 = y0; S.gyf = yf; S.gdx = (xf - x0) / Nx; S.gdy = (yf - y0) / Ny; S.rdx = 1.0 / S.gdx; S.rdy = 1.0 / S.gdy;
   hipLaunchKernelGGL(sz_k_interleave_fields, dim3(grid_for((long long)n, 256)), dim3(256), 0, c->stream, S);
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->have_fields = true;
+  c->have_fields = true; c->mixed_nodes_ok = false;
   return SZ_OK;
 }
 
@@ -642,7 +667,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   H2D(S.cnt, h, C_COUNT, int);
   hipLaunchKernelGGL(sz_k_osign, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0);
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->hostM = M; c->hostN = N; c->have_floes = true; c->tile_dirty = false;
+  c->hostM = M; c->hostN = N; c->have_floes = true; c->tile_dirty = false; c->mixed_pts_ok = false;
   c->rmax_max = 0.0; c->rmax_hint = 0.0;
   if (f->rmax) for (int i = 0; i < M; i++) c->rmax_max = std::max(c->rmax_max, f->rmax[i]);
   setup_grid(c);
@@ -845,11 +870,18 @@ int sz_timestep_coupling(sz_ctx* c) {
   if (!c->have_fields) { c->err = "sz_set_fields must be called before sz_timestep_coupling"; return SZ_E_STATE; }
   (void)hipSetDevice(c->device);
   if (c->two_way) { if (c->S.tiled) { c->err = "two-way coupling is not available in tiled runs"; return SZ_E_STATE; } int rc = ensure_two_way(c); if (rc) return rc; }
+  if (c->precision == 1 && !c->two_way) { int rc = ensure_mixed(c); if (rc) return rc; }
   stage_forcing(c);
   hipLaunchKernelGGL(sz_k_apply_frc, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
   return sync_and_check(c);
 }
 
+// ---- precision of the forcings: 0 = fp64 (default), 1 = mixed (per-point arithmetic in fp32, sz_kernels.hpp)
+int sz_set_precision(sz_ctx* c, int32_t mode) {
+  if (!c || mode < 0 || mode > 1) return SZ_E_ARG;
+  c->precision = mode;
+  return SZ_OK;
+}
 // ---- two-way coupling (coupling.jl:1617-1680; CouplingSettings(two_way_coupling_on = true))
 int sz_set_two_way(sz_ctx* c, int32_t on, double Cd_ao, double k, double L, int32_t dt) {
   if (!c) return SZ_E_ARG;
@@ -931,6 +963,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   }
   const bool sg = coll && c->grid_ok && !c->no_static_grid;
   if (sg) use_static_grid(c);
+  if (c->precision == 1 && !c->two_way && (flags & SZ_COUPLING_ON)) { int rc = ensure_mixed(c); if (rc) return rc; }
   for (int s = 0; s < nsteps; s++) {
     int tstep = tstep0 + s;
     const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
@@ -1042,6 +1075,7 @@ int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int
     hipLaunchKernelGGL(sz_k_halo_unpack, dim3(1), dim3(1024), 0, c->stream, S, (const double*)d_recv, nranks, cap, sg ? 1 : 0);
   }
   const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
+  if (coupling && c->precision == 1 && !c->two_way) { int rc = ensure_mixed(c); if (rc) return rc; }
   const bool overlap = coupling && (c->overlap_forcing < 0 ? c->hostN >= 32768 : c->overlap_forcing != 0);
   const bool periodic = S.any_periodic_ew || S.any_periodic_ns;
   // As in sz_step, the ghosts of the previous step are detached by this step's flag kernel and the new ones

@@ -1177,6 +1177,85 @@ __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) {
   }
 }
 
+// ---------------------------------------------------------------- mixed precision (BASELINE configs[4])
+// The forcings are sums of ~100 smooth per-point terms per floe: they do not need fp64 per point.  In mixed mode
+// the point's offset from the centroid, its velocity, the bilinear interpolation and the stresses are fp32 (the
+// sub-floe points and the lattice are kept as fp32 copies: half the bytes, and sqrt / reciprocal are a handful of
+// instructions instead of dozens); the absolute position -- needed for the in-bounds test and the lattice cell
+// -- and the per-floe totals stay fp64.  Everything else (contacts, integrator) is unchanged fp64.  The
+// reference has no Float32 answers to match (documentation.md:25: only Float64 is tested and supported): the
+// mixed path is held to the fp64 path with a stated tolerance (tests/test_hip_parity.py::test_mixed_precision).
+__global__ void sz_k_to_f32_points(State S, int n) {
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) S.s32[q] = make_float2((float)S.sx[q], (float)S.sy[q]);
+}
+__global__ void sz_k_to_f32_nodes(State S) {
+  int n = (S.Nx + 1) * (S.Ny + 1) * 8;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) S.nodes32[q] = (float)S.nodes[q];
+}
+__device__ __forceinline__ float sample_field32(const float* nodes, int f, const LatticeCell& c, float tx, float ty) {
+  float c0 = (1.0f - ty) * nodes[(size_t)c.o00 * 8 + f] + ty * nodes[(size_t)c.o01 * 8 + f];
+  float c1 = (1.0f - ty) * nodes[(size_t)c.o10 * 8 + f] + ty * nodes[(size_t)c.o11 * 8 + f];
+  return (1.0f - tx) * c0 + tx * c1;
+}
+__global__ void __launch_bounds__(256) sz_k_forcing_mixed(State S, Params P) {
+  int N = S.cnt[C_NOWN];
+  int lane = threadIdx.x % FRC_G, wpb = blockDim.x / FRC_G, wid = threadIdx.x / FRC_G;
+  int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
+  const float cturn = (float)cos(P.turn), sturn = (float)sin(P.turn);
+  const float ka = (float)(P.rho_a * P.Cd_ia), ko = (float)(P.rho_o * P.Cd_io);
+  for (int i = blockIdx.x * wpb + wid; i < N; i += gridDim.x * wpb) {
+    const double cxf = S.cx[i], cyf = S.cy[i], u = S.u[i], v = S.v[i];
+    const float uf = (float)u, vf = (float)v, xif = (float)S.xi[i];
+    const float ca = (float)S.trig[2 * i], sa = (float)S.trig[2 * i + 1];
+    const double ma_ratio = S.mass[i] / S.area[i];
+    const float mf = (float)(ma_ratio * P.fcor);
+    int o = S.soff[i], ns = S.soff[i + 1] - o;
+    float tx = 0, ty = 0, ttrq = 0, th = 0; int np = 0;
+    for (int k = lane; k < ns; k += FRC_G) {
+      const float2 sp = S.s32[o + k];
+      const float px = ca * sp.x - sa * sp.y, py = sa * sp.x + ca * sp.y;      // offset from the centroid
+      const double x = cxf + (double)px, y = cyf + (double)py;
+      bool inb = (per_x || (S.gx0 <= x && x <= S.gxf)) && (per_y || (S.gy0 <= y && y <= S.gyf));
+      if (!inb) continue;
+      np++;
+      const float rad = sqrtf(px * px + py * py);
+      const float irad = rad > 0.0f ? 1.0f / rad : 0.0f;
+      const float st = py * irad, ct = rad > 0.0f ? px * irad : 1.0f;
+      const float up = uf - xif * rad * st, vp = vf + xif * rad * ct;
+      const LatticeCell lc = lattice_cell(S, x, y, per_x, per_y);
+      const float wx = (float)lc.tx, wy = (float)lc.ty;
+      const float uatm = sample_field32(S.nodes32, 3, lc, wx, wy), vatm = sample_field32(S.nodes32, 4, lc, wx, wy);
+      const float du = uatm - up, dv = vatm - vp;
+      const float nrm = sqrtf(du * du + dv * dv);
+      const float tax = ka * nrm * du, tay = ka * nrm * dv;
+      const float uocn = sample_field32(S.nodes32, 0, lc, wx, wy), vocn = sample_field32(S.nodes32, 1, lc, wx, wy);
+      const float hfl = sample_field32(S.nodes32, 2, lc, wx, wy);
+      const float duo = uocn - up, dvo = vocn - vp;
+      const float nrmo = sqrtf(duo * duo + dvo * dvo);
+      const float tox = ko * nrmo * (cturn * duo - sturn * dvo), toy = ko * nrmo * (sturn * duo + cturn * dvo);
+      const float tpx = -mf * vocn, tpy = mf * uocn;
+      const float fx = tax + tpx + tox, fy = tay + tpy + toy;
+      tx += fx; ty += fy; ttrq += (-fx * st + fy * ct) * rad; th += hfl;
+    }
+    double dtx = tx, dty = ty, dtq = ttrq, dth = th;
+    for (int d = FRC_G / 2; d >= 1; d >>= 1) {
+      dtx += __shfl_xor(dtx, d, FRC_G); dty += __shfl_xor(dty, d, FRC_G); dtq += __shfl_xor(dtq, d, FRC_G); dth += __shfl_xor(dth, d, FRC_G);
+    }
+    int npt = np;
+    for (int d = FRC_G / 2; d >= 1; d >>= 1) npt += __shfl_xor(npt, d, FRC_G);
+    if (lane == 0) {
+      S.frc_remove[i] = npt == 0 ? 1 : 0;
+      if (npt != 0) {
+        double xcor = ma_ratio * P.fcor * v, ycor = ma_ratio * P.fcor * u;
+        double totx = npt * xcor + dtx, toty = -npt * ycor + dty;
+        double area = S.area[i];
+        S.fxOA[i] = totx / npt * area; S.fyOA[i] = toty / npt * area;
+        S.trqOA[i] = dtq / npt * area; S.hflx[i] = dth / npt;
+      }
+    }
+  }
+}
+
 // ============================================================================ rigid-body update (A12)
 __device__ __forceinline__ double sgn(double x) { return (double)((x > 0) - (x < 0)); }
 

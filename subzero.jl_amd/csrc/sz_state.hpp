@@ -75,6 +75,9 @@ struct State {
   int Nx, Ny; double gx0, gxf, gy0, gyf, gdx, gdy, rdx, rdy;   // rdx = 1/gdx
   double *uo, *vo, *hf, *ua, *va;
   double* nodes;             // the five lattices interleaved per node (8 doubles each)
+  // ---- mixed precision (sz_set_precision): fp32 copies the forcing kernel reads -- sub-floe points (x, y) and
+  // the interleaved lattice (8 floats per node: uo, vo, hf, ua, va, -, -, -)
+  float2* s32; float* nodes32;
   // ---- two-way coupling (allocated by sz_set_two_way): per floe the centre cells its sub-floe points fall into
   // (FC_CAP slots per floe: cell id, shift code, sum of -tau_ocn, points), per cell the entries sorted by floe
   int *fc_key, *fc_n, *fc_cnt; signed char* fc_code; double *fc_tx, *fc_ty, *fc_area;

@@ -114,6 +114,10 @@ class World:
                                        *(capi.ptr(a) for a in arrs)))
         self._grid = (int(Nx), int(Ny))
 
+    def set_precision(self, mode):
+        """"f64" (default) or "mixed": the per-point arithmetic of the forcings in fp32 (BASELINE configs[4])"""
+        self._chk(self.L.sz_set_precision(self.h, {"f64": 0, "mixed": 1}[mode]))
+
     # ---- two-way coupling (coupling.jl:1617-1680); off by default like CouplingSettings()
     def set_two_way(self, on=True, Cd_ao=1.25e-3, k=2.14, L=2.93e5, dt=10):
         self._chk(self.L.sz_set_two_way(self.h, int(on), float(Cd_ao), float(k), float(L), int(dt)))

@@ -56,6 +56,26 @@ def test_two_way_coupling_random(walls):
     parity.compare_worlds(hw, ow, rtol=1e-9, fields=["fxOA", "fyOA", "trqOA", "hflx_factor"])
 
 
+def test_mixed_precision_forcings():
+    """BASELINE configs[4]: mixed precision.  The reference has no Float32 answers (documentation.md:25), so the
+    mixed path (per-point forcing arithmetic in fp32, totals fp64) is held to the fp64 path: forcings to 1e-5 of
+    the field's largest value, 10-step trajectories to 1e-6 on velocities."""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=2000, seed=13, concentration=0.25, ocean="converge_diverge")
+    h64 = fields.build_world(mk(), cfg); h32 = fields.build_world(mk(), cfg)
+    h32.set_precision("mixed")
+    h64.timestep_coupling(); h32.timestep_coupling()
+    for k in ("fxOA", "fyOA", "trqOA", "hflx_factor"):
+        a, b = h32.get(k), h64.get(k)
+        assert np.max(np.abs(a - b)) <= 1e-5 * max(np.max(np.abs(b)), 1e-300), k
+    assert not np.array_equal(h32.get("fxOA"), h64.get("fxOA"))        # it really is the other kernel
+    h64.run(10, 0, cfg["dt"], coupling_dt=1); h32.run(10, 0, cfg["dt"], coupling_dt=1)
+    for k in ("u", "v", "xi"):
+        a, b = h32.get(k), h64.get(k)
+        assert np.max(np.abs(a - b)) <= 1e-6 * np.max(np.abs(b)), k
+    assert np.max(np.abs(h32.get("cx") - h64.get("cx"))) < 1e-3        # metres, after 200 s
+
+
 def test_config0_shear_flow_two_way():
     """BASELINE configs[0] (examples/shear_flow.jl): ~100 floes in a 100 km doubly periodic box, shear ocean,
     collisions on, two-way coupling on; 20 timesteps against the oracle."""
