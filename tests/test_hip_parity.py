@@ -216,6 +216,44 @@ def test_trajectories(n, seed, steps):
     assert np.array_equal(hw.warn_counts(), ow.warn_counts())
 
 
+@pytest.mark.parametrize("walls", [False, True])
+def test_resident_and_process_mode_interleaved(walls):
+    """Resident steps keep a fixed broad-phase grid and its cell lists across steps; process-mode calls fit their
+    own grid and move floes without re-binning.  Interleaving both (and a host-side edit in between) must give
+    the oracle's trajectory."""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=600, seed=17, walls=walls, topography=walls)
+    hw, ow = _pair(cfg)
+    dt = cfg["dt"]
+    t = 0
+
+    def both_resident(k):
+        nonlocal t
+        hw.run(k, t, dt, coupling_dt=1)
+        for q in range(k):
+            ow.timestep_sim(t + q, dt, coupling_dt=1)
+        t += k
+
+    def both_process():
+        nonlocal t
+        for w in (hw, ow):
+            n = w.M
+            w.add_ghosts(); w.timestep_collisions(n, dt); w.remove_ghosts(n)
+            w.timestep_coupling(); w.timestep_floe_properties(dt)
+        t += 1
+
+    both_resident(3)
+    both_process()
+    both_resident(2)
+    for w in (hw, ow):                      # host-side edit: forces a new upload
+        u = w.get("u"); u[::7] += 0.05; w.set("u", u)
+    both_resident(2)
+    both_process()
+    both_resident(3)
+    parity.compare_worlds(hw, ow, rtol=1e-9)
+    parity.compare_pairs(hw, ow)
+
+
 def test_narrow_variant_retry_many_crossings():
     """two 8-spike stars crossing 16 times: more crossings than the small narrow-phase working set
     holds, so the item is redone by the largest variant; rows must still match the oracle."""
