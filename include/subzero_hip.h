@@ -202,6 +202,9 @@ int sz_kernel_time_ms(sz_ctx *ctx, int32_t kclass, double *ms, int64_t *launches
      sz_halo_pack     ASYNC. Exchange buffers have one region per peer: 1 header record (count in
                       double [0]) + cap record slots.  Fills d_send with the owned floes whose
                       centroid, or a periodic image of it, lies in the peer's box
+     sz_tile_forcing  ASYNC, optional.  The forcings of step tstep (they need nothing from the halo); called between
+                      sz_halo_pack and the collective they run beside the exchange, and sz_tile_step(tstep)
+                      skips them
      sz_tile_step     ASYNC. Appends the records of d_recv (same layout, region r = from rank r) as
                       halo floes, runs one timestep_sim! on owned + halo floes; only owned floes are
                       integrated, the halo is dropped at the end.  d_recv may be NULL (no peers)
@@ -215,6 +218,7 @@ int sz_halo_set_boxes(sz_ctx *ctx, int32_t nranks, const double *boxes);
 int sz_halo_pack(sz_ctx *ctx, int32_t nranks, int32_t my_rank, double Lx, double Ly, int32_t periodic_x,
                  int32_t periodic_y, void *d_send, int32_t cap);
 int sz_halo_counts(sz_ctx *ctx, int32_t nranks, int32_t *counts_out);   /* of the last pack; d_send NULL = count only */
+int sz_tile_forcing(sz_ctx *ctx, int32_t tstep, int32_t coupling_dt, int32_t flags);
 int sz_tile_step(sz_ctx *ctx, const void *d_recv, int32_t nranks, int32_t cap, int32_t tstep, int32_t dt,
                  int32_t coupling_dt, int32_t flags);
 int sz_sync(sz_ctx *ctx);

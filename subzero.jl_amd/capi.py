@@ -57,7 +57,7 @@ EXPORTS = [
     "sz_upload_interactions", "sz_calc_stress", "sz_calc_strain",
     "sz_set_two_way", "sz_set_temps", "sz_download_ocean_stress", "sz_set_precision",
     "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms",
-    "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps",
+    "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_forcing", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps",
 ]
 
 _LIB = None
@@ -121,6 +121,7 @@ def load(build_if_missing=True):
     L.sz_halo_pack.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32,
                                C.c_void_p, C.c_int32]
     L.sz_halo_counts.argtypes = [C.c_void_p, C.c_int32, _ip]
+    L.sz_tile_forcing.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     L.sz_tile_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.sz_sync.argtypes = [C.c_void_p]
     L.sz_set_stream.argtypes = [C.c_void_p, C.c_void_p]

@@ -71,6 +71,7 @@ struct sz_ctx {
   bool no_static_grid = false;      // SZ_STATIC_GRID=0: fit the grid to the centroids every step (sz_k_bounds), as process mode does
   double rmax_max = 0.0, rmax_hint = 0.0; bool grid_ok = false, grid_live = false; double h_grid[8] = { 0 };
   unsigned scan_epoch = 0;      // launch counter of the look-back scans (their flags carry it: no reset pass)
+  int tile_forcing_tstep = -1;      // timestep whose forcings sz_tile_forcing has already enqueued
   bool tile_dirty = false;      // ghosts / halo floes of the last sz_tile_step still appended
   int dbg = 0;   // SZ_DEBUG bits: timing experiments only (1 skip contact rows, 2 skip direction check, 4 skip clip)
 };
@@ -970,10 +971,14 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     const bool overlap = coupling && !c->two_way && (c->overlap_forcing < 0 ? c->hostN >= 32768 : c->overlap_forcing != 0);
     // with collisions on, the ghosts of step s are detached by the ghost kernels of step s+1 (nothing
     // in between looks past the parents) and committed by the bounds kernel: two launches less
-    if (coll) stage_ghosts(c, true, sg);
-    if (overlap) stage_forcing_fork(c);      // after the ghost pass: it may wrap a parent around the domain
-    if (coll) collisions(c, c->hostN, dt, periodic && !sg, sg);
+    // The forcings only need the floes as the previous step left them, so they go first (the tiled step runs them
+    // beside the halo exchange, and both paths keep the same order: a parent that the ghost pass wraps around the
+    // domain is sampled at the periodic image it had before -- the same lattice values).  With the forcings on a
+    // second stream the fork comes after the ghost pass instead, so that nothing they read is being rewritten.
     if (coupling && !overlap) stage_forcing(c, dt);
+    if (coll) stage_ghosts(c, true, sg);
+    if (overlap) stage_forcing_fork(c);
+    if (coll) collisions(c, c->hostN, dt, periodic && !sg, sg);
     if (overlap) stage_forcing_join(c);
     stage_integrate(c, dt, !coll, coupling, sg);
   }
@@ -1063,6 +1068,16 @@ int sz_halo_pack(sz_ctx* c, int32_t nranks, int32_t me, double Lx, double Ly, in
 
 // asynchronous: unpack d_recv (same layout, region r = records from rank r) and run one timestep_sim!
 // on owned + halo floes; only owned floes are integrated, the halo is dropped afterwards
+namespace {
+int tile_forcing(sz_ctx* c) {
+  if (!c->have_fields) { c->err = "sz_set_fields must be called before coupling"; return SZ_E_STATE; }
+  if (c->two_way) { c->err = "two-way coupling is not available in tiled runs"; return SZ_E_STATE; }
+  if (c->precision == 1) { int rc = ensure_mixed(c); if (rc) return rc; }
+  stage_forcing(c);
+  return SZ_OK;
+}
+}  // namespace
+
 int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int32_t tstep, int32_t dt, int32_t coupling_dt,
                  int32_t flags) {
   if (!c || !c->have_floes) return SZ_E_STATE;
@@ -1075,21 +1090,32 @@ int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int
     hipLaunchKernelGGL(sz_k_halo_unpack, dim3(1), dim3(1024), 0, c->stream, S, (const double*)d_recv, nranks, cap, sg ? 1 : 0);
   }
   const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
-  if (coupling && c->precision == 1 && !c->two_way) { int rc = ensure_mixed(c); if (rc) return rc; }
-  const bool overlap = coupling && (c->overlap_forcing < 0 ? c->hostN >= 32768 : c->overlap_forcing != 0);
   const bool periodic = S.any_periodic_ew || S.any_periodic_ns;
+  // the forcings of this step: already enqueued by sz_tile_forcing (beside the exchange), else now -- in either
+  // case before the ghost pass, like sz_step
+  if (coupling && c->tile_forcing_tstep != tstep) { int rc = tile_forcing(c); if (rc) return rc; }
+  c->tile_forcing_tstep = -1;
   // As in sz_step, the ghosts of the previous step are detached by this step's flag kernel and the new ones
-  // committed by the bounds kernel; the halo of the previous step was overwritten by the unpack kernel.  Nothing
+  // committed by the flag/scan kernel; the halo of the previous step was overwritten by the unpack kernel.  Nothing
   // between two steps looks past the owned floes, so no clean-up launch is needed per step: the ghosts and halo
   // floes of the LAST step are dropped when the host next looks at the state (tile_cleanup).
   // n_init = every local parent (owned + halo): totals of halo floes are computed and then ignored
   if (coll) stage_ghosts(c, true, sg);
-  if (overlap) stage_forcing_fork(c);               // owned floes only (C_NOWN); after the ghost pass, which may wrap a parent
   if (coll) collisions(c, -1, dt, periodic && !sg, sg);
-  if (coupling && !overlap) stage_forcing(c);
-  if (overlap) stage_forcing_join(c);
   stage_integrate(c, dt, false, coupling, sg);
   c->tile_dirty = true;
+  return SZ_OK;
+}
+
+// ASYNC: the forcings of step `tstep` (owned floes only; they need nothing from the halo), to be enqueued between
+// sz_halo_pack and the collective so that they run beside the exchange; sz_tile_step(tstep) then skips them
+int sz_tile_forcing(sz_ctx* c, int32_t tstep, int32_t coupling_dt, int32_t flags) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
+  if (!coupling) return SZ_OK;
+  int rc = tile_forcing(c); if (rc) return rc;
+  c->tile_forcing_tstep = tstep;
   return SZ_OK;
 }
 

@@ -144,8 +144,10 @@ class TiledWorld:
             self.send = self.torch.zeros(n, dtype=self.torch.float64, device=self.dev)
             self.recv = self.torch.zeros(n, dtype=self.torch.float64, device=self.dev)
 
-    def exchange(self):
-        """steps 1-2 of the module docstring, asynchronous on the device: fills self.recv."""
+    def exchange(self, between=None):
+        """steps 1-2 of the module docstring, asynchronous on the device: fills self.recv.  `between` is enqueued
+        after the pack kernel and before the wait for the collective: work that does not need the halo (the
+        forcings of the owned floes) then runs beside the exchange."""
         torch, dist, w = self.torch, self.dist, self.world
         if self.boxes is None or self.steps_since_box >= self.rebox_every:
             self._allgather_boxes()
@@ -153,20 +155,25 @@ class TiledWorld:
         w._chk(w.L.sz_halo_pack(w.h, self.nranks, self.rank, self.L, self.L, int(self.per_x), int(self.per_y),
                                 C.c_void_p(self.send.data_ptr()), self.cap))
         if self.host_staging:                       # gloo: through the host
+            if between:
+                between()
             w._chk(w.L.sz_sync(w.h))
             sb = self.send.cpu(); rb = torch.zeros_like(sb)
             dist.all_to_all_single(rb, sb)
             self.recv.copy_(rb)
             torch.cuda.synchronize()
         else:                                       # RCCL: equal splits, device to device
-            dist.all_to_all_single(self.recv, self.send)
+            work = dist.all_to_all_single(self.recv, self.send, async_op=True)
+            if between:
+                between()
+            work.wait()                             # stream-level: the kernels enqueued next wait for the collective
 
     def step(self, tstep, dt, coupling_dt=10, collisions_on=True, coupling_on=True):
         w = self.world
         flags = (capi.COLLISIONS_ON if collisions_on else 0) | (capi.COUPLING_ON if coupling_on else 0)
         peers = self.nranks > 1 or self.always_exchange
         if peers:
-            self.exchange()
+            self.exchange(lambda: w._chk(w.L.sz_tile_forcing(w.h, int(tstep), int(coupling_dt), flags)))
         w._chk(w.L.sz_tile_step(w.h, C.c_void_p(self.recv.data_ptr()) if peers else None, self.nranks if peers else 0,
                                 self.cap, int(tstep), int(dt), int(coupling_dt), flags))
         w._host_stale = True
