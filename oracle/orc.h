@@ -14,10 +14,15 @@
  *   - ocean/atmosphere forcings: PINNED by test/test_physical_processes/test_coupling.jl:464-639
  *     with the sub-floe points decoded from test/inputs/test_mc_points.jld2
  *     (tests/golden/make_golden.py).
- *   - calc_stress!/calc_strain!/timestep_floe_properties!: formula-level restatement; the
- *     reference's own fixture (test/inputs/stress_strain.jld2) is a JLD2 object graph that
- *     no reader in this image can open  => "parity unpinned" for the integrator beyond
- *     the conservation properties checked in tests/.
+ *   - calc_stress! / calc_strain!: PINNED by test/test_physical_processes/test_update_floe.jl:10-39 with
+ *     the two floes of test/inputs/stress_strain.jld2 decoded into tests/golden/update_floe.json.
+ *   - two-way coupling bookkeeping (find_center_cell_index, center_cell_coords, shift_cell_idx,
+ *     floe_to_grid_info!): PINNED by test/test_physical_processes/test_coupling.jl:165-180, 276-460
+ *     (tests/golden/coupling_grid.json); calc_two_way_coupling! itself has no reference fixture and is
+ *     checked on an analytic case.
+ *   - the rest of timestep_floe_properties! (guards, thermodynamics, AB2 update): formula-level
+ *     restatement, no reference fixture exists => "parity unpinned" for those lines beyond the
+ *     conservation properties checked in tests/.
  *
  * The polygon arithmetic of the reference lives in GeometryOps.jl 0.1.x (Project.toml:38),
  * which is NOT under /root/reference.  orc_geom.c restates its published algorithms
