@@ -343,7 +343,7 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo) {
     if (larger)
       hipLaunchKernelGGL((sz_k_narrow<16, NARROW_CAP1, 16, 80, 6, 64, NARROW_CAP0, 1>), dim3(grid_for(capItems, 4, 2048)), dim3(64), 0,
                          c->stream, S, c->P, dt, ffmo, fdmo, c->dbg);
-    hipLaunchKernelGGL((sz_k_narrow<64, NARROW_CAP2, 64, 320, 6, 64, NARROW_CAP1, 2>), dim3(grid_for(capItems, 1, larger ? 2048 : 256)), dim3(64), 0,
+    hipLaunchKernelGGL((sz_k_narrow<64, NARROW_CAP2, 64, 320, 16, 64, NARROW_CAP1, 2>), dim3(grid_for(capItems, 1, larger ? 2048 : 256)), dim3(64), 0,
                        c->stream, S, c->P, dt, ffmo, fdmo, c->dbg);
     t.end();
   }

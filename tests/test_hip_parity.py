@@ -254,6 +254,23 @@ def test_resident_and_process_mode_interleaved(walls):
     parity.compare_pairs(hw, ow)
 
 
+@pytest.mark.parametrize("seed,periodic", [(500, True), (505, False)])
+def test_rough_shapes(seed, periodic):
+    """3 to 40 vertices, deep radial variation (concave, spiky), heavy overlaps: several contact regions per pair,
+    rings above the 8-lane kernels' capacity (the 16- and 64-lane variants run), working-set retries."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_parity_shapes", os.path.join(os.path.dirname(__file__), "..", "tools", "rough_shapes.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    hw = mod.rough_world(mk, seed, 12, periodic); ow = mod.rough_world(omk, seed, 12, periodic)
+    for w in (hw, ow):
+        n = w.M
+        w.add_ghosts(); w.timestep_collisions(n, 10)
+    assert parity.compare_pairs(hw, ow) > 300
+    parity.compare_interactions(hw, ow, 1e-9)
+    parity.compare_worlds(hw, ow, rtol=1e-9, fields=["coll_fx", "coll_fy", "coll_trq", "overarea"])
+    assert max(len(r) for r in (hw.ring(i) for i in range(0, 144, 7))) > 20
+
+
 def test_narrow_variant_retry_many_crossings():
     """two 8-spike stars crossing 16 times: more crossings than the small narrow-phase working set
     holds, so the item is redone by the largest variant; rows must still match the oracle."""
