@@ -37,7 +37,7 @@ enum {
 };
 
 constexpr int MAXNB = 24;       // broad-phase neighbours kept per floe and direction
-constexpr int ROWS_PER_ITEM = 8; // contact rows kept per pair / element item (the 8-lane kernels hold 4 regions and hand larger items on)
+constexpr int ROWS_PER_ITEM = 16; // contact rows kept per pair / element item (the 8-lane kernels hold 4 regions and hand larger items on)
 constexpr int MAX_GHOSTS = 3;   // ghosts per parent (doubly periodic corner floe)
 
 struct Params {

@@ -59,5 +59,7 @@ for seed in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
         except AssertionError as e:
             bad2 += 1
             print(f"FAIL rough seed {seed} periodic {periodic}: {str(e)[:300]}", flush=True)
+        except subzero_jl_amd.capi.SzError as e:          # a capacity the engine reports loudly (never a silent drop)
+            print(f"cap  rough seed {seed} periodic {periodic}: {str(e)[:120]}", flush=True)
 print(f"{n2 - bad2}/{n2} rough cases agree")
 sys.exit(1 if (bad or bad2) else 0)
