@@ -2,7 +2,7 @@
 
 One process per GPU.  The domain box is cut into px x py tiles; a rank OWNS the floes whose
 centroid lies in its tile at partition time and keeps them for the whole run (floes move metres
-per step against tile sizes of hundreds of kilometres; `repartition` is a rare host-side
+per step against tile sizes of hundreds of kilometres; `repartition()` is a rare host-side
 operation).  Every step each rank
 
   1. packs, on the device, the owned floes that any other rank may need: those whose centroid --
@@ -103,6 +103,7 @@ class TiledWorld:
         g = np.ascontiguousarray(self.gidx, np.int64)
         max_ring = float(np.diff(cfg["vert_off"]).max())        # over ALL floes: halo floes arrive unseen
         max_rmax = float(cfg["derived"]["rmax"].max())          # over ALL floes, like max_ring
+        self._max_ring, self._max_rmax = max_ring, max_rmax
         w._chk(w.L.sz_tile_enable(w.h, capi.ptr(g, capi._lp), max_ring, max_rmax))
         self.world = w
         self.REC = w.L.sz_halo_record_doubles()
@@ -177,6 +178,76 @@ class TiledWorld:
         w._chk(w.L.sz_tile_step(w.h, C.c_void_p(self.recv.data_ptr()) if peers else None, self.nranks if peers else 0,
                                 self.cap, int(tstep), int(dt), int(coupling_dt), flags))
         w._host_stale = True
+
+    # ---- migration: rare, host-side
+    def repartition(self, owner_fn=None):
+        """Re-assign every floe to the tile its centroid lies in now and move the floes that changed tile to
+        their new owner with their complete state (all columns incl. the previous-step tendencies, tensors,
+        status, ring, sub-floe points), so that the run continues exactly as it would have.  Floes move metres per
+        step against tiles of hundreds of kilometres: this is a rare operation, done on the host (download,
+        all_gather_object of the movers, upload).  Returns the number of floes this rank gave away.
+        owner_fn(cx, cy) -> rank array overrides the tile rule (tests)."""
+        w, dist, rank = self.world, self.dist, self.rank
+        self.sync(); w._host_stale = True; w._pull()
+        col = w.col; n = len(self.gidx)
+        assert w._M == n, "repartition needs a ghost-free state"
+        cx, cy = col["cx"].copy(), col["cy"].copy()
+        if self.per_x: cx %= self.L
+        if self.per_y: cy %= self.L
+        owner = np.asarray(owner_fn(cx, cy) if owner_fn else assign_tiles(cx, cy, self.L, self.nranks))
+        mv = np.nonzero(owner != rank)[0]; keep = np.nonzero(owner == rank)[0]
+
+        def pick(idx):
+            """the rows `idx` of the local columns as one record batch"""
+            off = col["vert_off"]; so = col["sub_off"]
+            rec = {"gidx": self.gidx[idx], "owner": owner[idx]}
+            for k in capi.DCOLS + capi.TCOLS + ["id", "status"]:
+                rec[k] = col[k][idx]
+            rec["nv"] = np.diff(off)[idx]; rec["ns"] = np.diff(so)[idx]
+            sel = np.concatenate([np.arange(off[i], off[i + 1]) for i in idx]) if len(idx) else np.zeros(0, int)
+            ssel = np.concatenate([np.arange(so[i], so[i + 1]) for i in idx]) if len(idx) else np.zeros(0, int)
+            rec["vx"], rec["vy"] = col["vx"][sel], col["vy"][sel]
+            rec["sx"], rec["sy"] = col["sx"][ssel], col["sy"][ssel]
+            return rec
+
+        out = pick(mv)
+        gathered = [None] * self.nranks
+        dist.all_gather_object(gathered, out)
+        parts = [pick(keep)]
+        for r, rec in enumerate(gathered):
+            if r == rank or len(rec["gidx"]) == 0:
+                continue
+            m = np.nonzero(rec["owner"] == rank)[0]
+            if len(m) == 0:
+                continue
+            vo = np.concatenate([[0], np.cumsum(rec["nv"])]); so = np.concatenate([[0], np.cumsum(rec["ns"])])
+            sub = {k: rec[k][m] for k in rec if k not in ("vx", "vy", "sx", "sy")}
+            vs = np.concatenate([np.arange(vo[i], vo[i + 1]) for i in m]); ss = np.concatenate([np.arange(so[i], so[i + 1]) for i in m])
+            sub["vx"], sub["vy"], sub["sx"], sub["sy"] = rec["vx"][vs], rec["vy"][vs], rec["sx"][ss], rec["sy"][ss]
+            parts.append(sub)
+        total_moved = int(sum(len(g["gidx"]) for g in gathered))
+        if total_moved == 0:
+            return 0
+        # merge, ordered by global index (any fixed order would do: order-dependent rules use the global index)
+        g_all = np.concatenate([p_["gidx"] for p_ in parts]); order = np.argsort(g_all, kind="stable")
+        nv_all = np.concatenate([p_["nv"] for p_ in parts]); ns_all = np.concatenate([p_["ns"] for p_ in parts])
+        vstart = np.concatenate([[0], np.cumsum(nv_all)]); sstart = np.concatenate([[0], np.cumsum(ns_all)])
+        vx_all = np.concatenate([p_["vx"] for p_ in parts]); vy_all = np.concatenate([p_["vy"] for p_ in parts])
+        sx_all = np.concatenate([p_["sx"] for p_ in parts]); sy_all = np.concatenate([p_["sy"] for p_ in parts])
+        cols = {k: np.concatenate([p_[k] for p_ in parts])[order] for k in capi.DCOLS + capi.TCOLS + ["id", "status"]}
+        nv = nv_all[order]; ns = ns_all[order]
+        cols["vert_off"] = np.concatenate([[0], np.cumsum(nv)]).astype(np.int32)
+        vsel = np.concatenate([np.arange(vstart[i], vstart[i + 1]) for i in order]) if len(order) else np.zeros(0, int)
+        ssel = np.concatenate([np.arange(sstart[i], sstart[i + 1]) for i in order]) if len(order) else np.zeros(0, int)
+        cols["vx"], cols["vy"] = vx_all[vsel], vy_all[vsel]
+        soff = np.concatenate([[0], np.cumsum(ns)]).astype(np.int32)
+        self.gidx = g_all[order]
+        w.load_columns(cols); w.set_subpoints_csr(soff, sx_all[ssel], sy_all[ssel])
+        w._push()
+        g = np.ascontiguousarray(self.gidx, np.int64)
+        w._chk(w.L.sz_tile_enable(w.h, capi.ptr(g, capi._lp), self._max_ring, self._max_rmax))
+        self.boxes = None                      # owned boxes and halo capacity are re-established at the next exchange
+        return len(mv)
 
     def run(self, nsteps, tstep0, dt, coupling_dt=10, collisions_on=True, coupling_on=True):
         for s in range(nsteps):

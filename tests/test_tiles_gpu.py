@@ -16,7 +16,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n, seed, steps, q):
+def _worker(rank, world, port, n, seed, steps, q, repartition=False):
     import torch
     import torch.distributed as dist
     from subzero_jl_amd import fields, tiles
@@ -25,7 +25,17 @@ def _worker(rank, world, port, n, seed, steps, q):
     try:
         cfg = fields.make_config(n_floes=n, seed=seed)
         tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True)
-        tw.run(steps, 0, cfg["dt"], coupling_dt=1)
+        if repartition:
+            # half way through, hand every floe to the other kind of tiling (split along y instead of x): most
+            # floes change owner with their complete state, and the run must go on as if nothing had happened
+            half = steps // 2
+            tw.run(half, 0, cfg["dt"], coupling_dt=1)
+            L = cfg["L"]
+            moved = tw.repartition(owner_fn=lambda cx, cy: (cy > 0.5 * L).astype(int))
+            assert moved > 0 and len(tw.gidx) > 0
+            tw.run(steps - half, half, cfg["dt"], coupling_dt=1)
+        else:
+            tw.run(steps, 0, cfg["dt"], coupling_dt=1)
         out = {f: tw.owned(f) for f in FIELDS}
         off, x, y = tw.world.rings()
         q.put((rank, tw.gidx, out, tw.n_halo_last, x[:off[len(tw.gidx)]].copy()))
@@ -33,8 +43,8 @@ def _worker(rank, world, port, n, seed, steps, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,seed,steps", [(600, 31, 4)])
-def test_two_ranks_equal_single(n, seed, steps):
+@pytest.mark.parametrize("n,seed,steps,repartition", [(600, 31, 4, False), (600, 33, 6, True)])
+def test_two_ranks_equal_single(n, seed, steps, repartition):
     import torch.multiprocessing as mp
     import subzero_jl_amd
     from subzero_jl_amd import fields
@@ -42,7 +52,7 @@ def test_two_ranks_equal_single(n, seed, steps):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, seed, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, seed, steps, q, repartition)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
