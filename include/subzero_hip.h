@@ -163,11 +163,16 @@ int sz_set_precision(sz_ctx *ctx, int32_t mode);
    ocean, the sea-ice fraction and the heat-flux factor per centre cell ((Nx+1) x (Ny+1) values, element
    [ix][iy] at ix*(Ny+1)+iy); the heat-flux factor replaces the hflx lattice given to sz_set_fields, as
    ocean.hflx_factor is overwritten in the reference.  Cd_ao, k, L: Constants() (simulation.jl:10-14); dt is the
-   timestep used for the heat-flux factor by sz_timestep_coupling (sz_step uses its own).  Not available in
-   tiled (multi-GPU) runs. */
+   timestep used for the heat-flux factor by sz_timestep_coupling (sz_step uses its own).
+   Tiled (multi-GPU) runs: a floe only contributes on the rank that owns it, so after a tiled coupling step every
+   rank calls sz_two_way_partial (its per-cell sums -> a device buffer of 3 (Nx+1)(Ny+1) doubles: stress numerators
+   x, y and ice area), the host adds the buffers up across the ranks (all-reduce) and sz_two_way_finish turns the
+   sums into the ocean fields on every rank (both ASYNC on the context's stream). */
 int sz_set_two_way(sz_ctx *ctx, int32_t on, double Cd_ao, double k, double L, int32_t dt);
 int sz_set_temps(sz_ctx *ctx, const double *t_ocn, const double *t_atm);
 int sz_download_ocean_stress(sz_ctx *ctx, double *tau_x, double *tau_y, double *si_frac, double *hflx);
+int sz_two_way_partial(sz_ctx *ctx, void *d_partial);
+int sz_two_way_finish(sz_ctx *ctx, const void *d_partial, int32_t dt);
 /* calc_stress! (update_floe.jl:392-414, with _update_stress_accum!, stress_calculators.jl:118-122) and
    calc_strain! (update_floe.jl:425-453) on their own, for every floe, as the reference's tests call them
    (test_update_floe.jl:10-39).  sz_upload_interactions replaces floe.interactions of every floe by hand-made

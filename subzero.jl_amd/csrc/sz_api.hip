@@ -442,7 +442,8 @@ void stage_forcing(sz_ctx* c, int dt = -1) {      // in-order variant (process m
     hipLaunchKernelGGL(sz_k_tw_fill, dim3(ge), dim3(256), 0, c->stream, S);
     hipLaunchKernelGGL(sz_k_tw_sort, dim3(grid_for(ncell, 256)), dim3(256), 0, c->stream, S, ncell);
     hipLaunchKernelGGL(sz_k_tw_area, dim3(grid_for((long long)S.capM * FC_CAP, 64 / TW_G, 4096)), dim3(64), 0, c->stream, S);
-    hipLaunchKernelGGL(sz_k_tw_reduce, dim3(grid_for(ncell, 256)), dim3(256), 0, c->stream, S, c->P, ncell, dt >= 0 ? dt : c->tw_dt);
+    // tiled runs finish the cells after the partial sums of all ranks have been added up (sz_two_way_partial / _finish)
+    if (!S.tiled) hipLaunchKernelGGL(sz_k_tw_reduce, dim3(grid_for(ncell, 256)), dim3(256), 0, c->stream, S, c->P, ncell, dt >= 0 ? dt : c->tw_dt);
   }
   t.end();
 }
@@ -870,7 +871,7 @@ int sz_timestep_coupling(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   if (!c->have_fields) { c->err = "sz_set_fields must be called before sz_timestep_coupling"; return SZ_E_STATE; }
   (void)hipSetDevice(c->device);
-  if (c->two_way) { if (c->S.tiled) { c->err = "two-way coupling is not available in tiled runs"; return SZ_E_STATE; } int rc = ensure_two_way(c); if (rc) return rc; }
+  if (c->two_way) { if (c->S.tiled) { c->err = "tiled contexts couple through sz_tile_step + sz_two_way_partial / sz_two_way_finish"; return SZ_E_STATE; } int rc = ensure_two_way(c); if (rc) return rc; }
   if (c->precision == 1 && !c->two_way) { int rc = ensure_mixed(c); if (rc) return rc; }
   stage_forcing(c);
   hipLaunchKernelGGL(sz_k_apply_frc, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
@@ -959,7 +960,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   const bool periodic = c->S.any_periodic_ew || c->S.any_periodic_ns;
   const bool coll = (flags & SZ_COLLISIONS_ON) != 0;
   if (c->two_way && (flags & SZ_COUPLING_ON)) {
-    if (c->S.tiled) { c->err = "two-way coupling is not available in tiled runs"; return SZ_E_STATE; }
+    if (c->S.tiled) { c->err = "tiled contexts couple through sz_tile_step + sz_two_way_partial / sz_two_way_finish"; return SZ_E_STATE; }
     int rc = ensure_two_way(c); if (rc) return rc;
   }
   const bool sg = coll && c->grid_ok && !c->no_static_grid;
@@ -1071,8 +1072,8 @@ int sz_halo_pack(sz_ctx* c, int32_t nranks, int32_t me, double Lx, double Ly, in
 namespace {
 int tile_forcing(sz_ctx* c) {
   if (!c->have_fields) { c->err = "sz_set_fields must be called before coupling"; return SZ_E_STATE; }
-  if (c->two_way) { c->err = "two-way coupling is not available in tiled runs"; return SZ_E_STATE; }
-  if (c->precision == 1) { int rc = ensure_mixed(c); if (rc) return rc; }
+  if (c->two_way) { int rc = ensure_two_way(c); if (rc) return rc; }
+  else if (c->precision == 1) { int rc = ensure_mixed(c); if (rc) return rc; }
   stage_forcing(c);
   return SZ_OK;
 }
@@ -1104,6 +1105,24 @@ int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int
   if (coll) collisions(c, -1, dt, periodic && !sg, sg);
   stage_integrate(c, dt, false, coupling, sg);
   c->tile_dirty = true;
+  return SZ_OK;
+}
+
+// Two-way coupling across tiles.  After a tiled coupling step: sz_two_way_partial writes this rank's per-cell sums
+// (3 x (Nx+1)(Ny+1) doubles: stress numerators x / y, ice area) to a DEVICE buffer of the caller, the caller adds
+// the buffers of all ranks up (all-reduce), sz_two_way_finish turns the sums into the ocean fields on every rank.
+int sz_two_way_partial(sz_ctx* c, void* d_partial) {
+  if (!c || !c->have_floes || !c->two_way || !d_partial) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  const int ncell = (int)c->tw_ncell;
+  hipLaunchKernelGGL(sz_k_tw_partial, dim3(grid_for(ncell, 256)), dim3(256), 0, c->stream, c->S, ncell, (double*)d_partial);
+  return SZ_OK;
+}
+int sz_two_way_finish(sz_ctx* c, const void* d_partial, int32_t dt) {
+  if (!c || !c->have_floes || !c->two_way || !d_partial) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  const int ncell = (int)c->tw_ncell;
+  hipLaunchKernelGGL(sz_k_tw_finish, dim3(grid_for(ncell, 256)), dim3(256), 0, c->stream, c->S, c->P, ncell, dt, (const double*)d_partial);
   return SZ_OK;
 }
 

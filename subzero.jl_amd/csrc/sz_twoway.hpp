@@ -93,34 +93,56 @@ __global__ void __launch_bounds__(64) sz_k_tw_area(State S) {
   if (gl == 0 && (m.err & (ERR_CAP_XING | ERR_CAP_REGION))) atomicOr(&S.cnt[C_ERR], m.err);
   if (gl == 0 && m.ntracefail) atomicAdd(&S.cnt[C_TRACE_FAIL], m.ntracefail);
 }
-// per centre cell: ice stress as the area-weighted mean over the floes in it, sea-ice fraction, atmosphere-on-ocean
-// stress on the open part, heat-flux factor (coupling.jl:1631-1677)
-__global__ void sz_k_tw_reduce(State S, Params P, int ncell, int dt) {
-  const double cell_area = S.gdx * S.gdy;
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < ncell; q += gridDim.x * blockDim.x) {
-    double tx = 0.0, ty = 0.0, si = 0.0;
-    const int lo = S.cl_off[q], hi = S.cl_off[q + 1];
-    for (int a = lo; a < hi;) {
-      // one entry per floe and cell: a floe that reached this cell through two different unshifted cells was
-      // merged by add_point! under its first shift (coupling.jl:1345)
-      const int e0 = S.cl_ent[a], i = e0 / FC_CAP;
-      double ex = S.fc_tx[e0], ey = S.fc_ty[e0]; int n = S.fc_n[e0];
-      int b = a + 1;
-      while (b < hi && S.cl_ent[b] / FC_CAP == i) { int e = S.cl_ent[b]; ex += S.fc_tx[e]; ey += S.fc_ty[e]; n += S.fc_n[e]; b++; }
-      const double area = S.fc_area[e0];
-      if (area > 0) { tx += (ex / n) * area; ty += (ey / n) * area; si += area; }
-      a = b;
-    }
-    if (si > 0) { tx /= si; ty /= si; si /= cell_area; }
-    const double du = S.ua[q] - S.uo[q], dv = S.va[q] - S.vo[q];
-    const double ocn_frac = 1 - si;
-    const double nrm = sqrt(du * du + dv * dv);
-    tx += P.rho_a * P.Cd_ao * ocn_frac * nrm * du;
-    ty += P.rho_a * P.Cd_ao * ocn_frac * nrm * dv;
-    S.tau_x[q] = tx; S.tau_y[q] = ty; S.si_frac[q] = si;
-    const double hf = dt * P.k_ice / (P.rho_i * P.L_ice) * (S.t_ocn[q] - S.t_atm[q]);
-    S.hf[q] = hf; S.nodes[(size_t)q * 8 + 2] = hf;
+// per centre cell, first half: sums over the floes in it, in floe order -- the ice stress weighted by the area of
+// floe in cell (numerators) and that area (coupling.jl:1631-1662)
+__device__ __forceinline__ void tw_cell_sums(const State& S, int q, double& tx, double& ty, double& si) {
+  tx = 0.0; ty = 0.0; si = 0.0;
+  const int lo = S.cl_off[q], hi = S.cl_off[q + 1];
+  for (int a = lo; a < hi;) {
+    // one entry per floe and cell: a floe that reached this cell through two different unshifted cells was
+    // merged by add_point! under its first shift (coupling.jl:1345)
+    const int e0 = S.cl_ent[a], i = e0 / FC_CAP;
+    double ex = S.fc_tx[e0], ey = S.fc_ty[e0]; int n = S.fc_n[e0];
+    int b = a + 1;
+    while (b < hi && S.cl_ent[b] / FC_CAP == i) { int e = S.cl_ent[b]; ex += S.fc_tx[e]; ey += S.fc_ty[e]; n += S.fc_n[e]; b++; }
+    const double area = S.fc_area[e0];
+    if (area > 0) { tx += (ex / n) * area; ty += (ey / n) * area; si += area; }
+    a = b;
   }
+}
+// second half: area-weighted mean, sea-ice fraction, atmosphere-on-ocean stress on the open part, heat-flux factor
+// (coupling.jl:1663-1677)
+__device__ __forceinline__ void tw_cell_finish(State& S, const Params& P, int q, double tx, double ty, double si, int dt) {
+  const double cell_area = S.gdx * S.gdy;
+  if (si > 0) { tx /= si; ty /= si; si /= cell_area; }
+  const double du = S.ua[q] - S.uo[q], dv = S.va[q] - S.vo[q];
+  const double ocn_frac = 1 - si;
+  const double nrm = sqrt(du * du + dv * dv);
+  tx += P.rho_a * P.Cd_ao * ocn_frac * nrm * du;
+  ty += P.rho_a * P.Cd_ao * ocn_frac * nrm * dv;
+  S.tau_x[q] = tx; S.tau_y[q] = ty; S.si_frac[q] = si;
+  const double hf = dt * P.k_ice / (P.rho_i * P.L_ice) * (S.t_ocn[q] - S.t_atm[q]);
+  S.hf[q] = hf; S.nodes[(size_t)q * 8 + 2] = hf;
+}
+__global__ void sz_k_tw_reduce(State S, Params P, int ncell, int dt) {
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < ncell; q += gridDim.x * blockDim.x) {
+    double tx, ty, si;
+    tw_cell_sums(S, q, tx, ty, si);
+    tw_cell_finish(S, P, q, tx, ty, si, dt);
+  }
+}
+// tiled runs: every rank sums over the floes it owns (partial[q], [ncell + q], [2 ncell + q]), the host adds the
+// partial fields up across the ranks (all-reduce), then every rank finishes the cells
+__global__ void sz_k_tw_partial(State S, int ncell, double* partial) {
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < ncell; q += gridDim.x * blockDim.x) {
+    double tx, ty, si;
+    tw_cell_sums(S, q, tx, ty, si);
+    partial[q] = tx; partial[ncell + q] = ty; partial[2 * (size_t)ncell + q] = si;
+  }
+}
+__global__ void sz_k_tw_finish(State S, Params P, int ncell, int dt, const double* partial) {
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < ncell; q += gridDim.x * blockDim.x)
+    tw_cell_finish(S, P, q, partial[q], partial[ncell + q], partial[2 * (size_t)ncell + q], dt);
 }
 
 }  // namespace sz

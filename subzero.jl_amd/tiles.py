@@ -116,6 +116,7 @@ class TiledWorld:
         self.margin, self.rebox_every = drift_margin, rebox_every
         self.boxes = None
         self.steps_since_box = 0
+        self.tw_buf = None                                    # per-cell partial sums of the two-way coupling
 
     # ---- collectives
     def _allgather_boxes(self):
@@ -177,7 +178,30 @@ class TiledWorld:
             self.exchange(lambda: w._chk(w.L.sz_tile_forcing(w.h, int(tstep), int(coupling_dt), flags)))
         w._chk(w.L.sz_tile_step(w.h, C.c_void_p(self.recv.data_ptr()) if peers else None, self.nranks if peers else 0,
                                 self.cap, int(tstep), int(dt), int(coupling_dt), flags))
+        if self.tw_buf is not None and coupling_on and coupling_dt > 0 and tstep % coupling_dt == 0:
+            self._two_way_reduce(dt)
         w._host_stale = True
+
+    # ---- two-way coupling across tiles
+    def set_two_way(self, t_ocn, t_atm, dt, Cd_ao=1.25e-3, k=2.14, L=2.93e5):
+        """calc_two_way_coupling! (coupling.jl:1617-1680) in a tiled run: every rank sums the ice stress per centre
+        cell over the floes it owns, the partial fields are added up with one all-reduce per coupling step, and
+        every rank finishes the cells (so every rank holds the full ocean fields, like the single-process run)."""
+        w = self.world
+        w.set_two_way(True, Cd_ao=Cd_ao, k=k, L=L, dt=dt); w.set_temps(t_ocn, t_atm)
+        Nx, Ny = w._grid
+        self.tw_buf = self.torch.zeros(3 * (Nx + 1) * (Ny + 1), dtype=self.torch.float64, device=self.dev)
+
+    def _two_way_reduce(self, dt):
+        w, torch = self.world, self.torch
+        w._chk(w.L.sz_two_way_partial(w.h, C.c_void_p(self.tw_buf.data_ptr())))
+        if self.nranks > 1:
+            if self.host_staging:
+                w._chk(w.L.sz_sync(w.h))
+                hb = self.tw_buf.cpu(); self.dist.all_reduce(hb); self.tw_buf.copy_(hb); torch.cuda.synchronize()
+            else:
+                self.dist.all_reduce(self.tw_buf)
+        w._chk(w.L.sz_two_way_finish(w.h, C.c_void_p(self.tw_buf.data_ptr()), int(dt)))
 
     # ---- migration (SURVEY.md §8e, step 3): rare, host-side
     def repartition(self, owner_fn=None):

@@ -70,3 +70,49 @@ def test_two_ranks_equal_single(n, seed, steps, repartition):
             ref = hw.get(f)[gidx]
             assert np.array_equal(out[f], ref), (rank, f, np.max(np.abs(out[f] - ref)))
     assert seen.all()
+
+
+def _worker_two_way(rank, world, port, n, seed, steps, q):
+    import torch.distributed as dist
+    from subzero_jl_amd import fields, tiles
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = fields.make_config(n_floes=n, seed=seed, ocean="shear")
+        tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True)
+        tw.set_two_way(0.5, -8.0, cfg["dt"])
+        tw.run(steps, 0, cfg["dt"], coupling_dt=2)
+        tw.sync()
+        q.put((rank, tw.gidx, {f: tw.owned(f) for f in ("cx", "cy", "u", "v", "xi", "height")}, [a.copy() for a in tw.world.ocean_stress()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_way_coupling_across_tiles():
+    """Two ranks, two-way coupling on: the per-cell sums of both ranks added up give the single-context ocean
+    fields (to round-off: the cross-rank sum order differs), and the run -- which feeds on the heat-flux factor
+    the coupling writes -- follows the single-context trajectory."""
+    import torch.multiprocessing as mp
+    import subzero_jl_amd
+    from subzero_jl_amd import fields
+    n, seed, steps, world = 500, 41, 6, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_worker_two_way, args=(r, world, port, n, seed, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert all(p.exitcode == 0 for p in procs)
+    cfg = fields.make_config(n_floes=n, seed=seed, ocean="shear")
+    hw = fields.build_world(subzero_jl_amd.World(0), cfg)
+    hw.set_two_way(True, dt=cfg["dt"]); hw.set_temps(0.5, -8.0)
+    hw.run(steps, 0, cfg["dt"], coupling_dt=2)
+    ref = hw.ocean_stress()
+    for rank, gidx, out, fields_ in res:
+        for name, g, r in zip(("tau_x", "tau_y", "si_frac", "hflx"), fields_, ref):
+            assert np.max(np.abs(g - r)) <= 1e-12 * max(np.max(np.abs(r)), 1e-300), (rank, name)
+        for f, v in out.items():
+            assert np.max(np.abs(v - hw.get(f)[gidx])) <= 1e-12 * np.max(np.abs(hw.get(f))), (rank, f)
+    assert np.count_nonzero(ref[2]) > 100
