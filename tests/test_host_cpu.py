@@ -82,3 +82,13 @@ def test_oracle_momentum_bookkeeping():
     scale = np.abs(fx).max()
     assert abs(fx.sum()) < 1e-9 * scale * 400 and abs(fy.sum()) < 1e-9 * scale * 400
     assert np.all(w.get("coll_fx")[400:] == 0)
+
+
+def test_header_is_plain_c_and_the_c_example_compiles():
+    """include/subzero_hip.h must be consumable by a C compiler (the boundary is a C-ABI): the C example is
+    compiled (not linked, not run: no GPU here) with gcc -std=c11 -Wall -Werror."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), "-fsyntax-only",
+                        os.path.join(root, "examples", "minimal.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
