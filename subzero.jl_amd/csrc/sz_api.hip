@@ -68,6 +68,7 @@ struct sz_ctx {
   bool two_way = false; int tw_dt = 10; int tw_capM = 0; size_t tw_ncell = 0;
   std::vector<void*> tw_allocs, tw_field_allocs;
   // static broad-phase grid of the resident steps (fixed by the host: no bounds reduction per step)
+  bool no_queue = false;            // SZ_NARROW_QUEUE=0: static split of the narrow items over the workgroups
   bool no_static_grid = false;      // SZ_STATIC_GRID=0: fit the grid to the centroids every step (sz_k_bounds), as process mode does
   double rmax_max = 0.0, rmax_hint = 0.0; bool grid_ok = false, grid_live = false; double h_grid[8] = { 0 };
   unsigned scan_epoch = 0;      // launch counter of the look-back scans (their flags carry it: no reset pass)
@@ -311,8 +312,10 @@ void stage_elems(sz_ctx* c, bool enabled) {
   t.end();
 }
 
-void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo) {
+void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = false) {
   State& S = c->S;
+  // dynamic rounds (see sz_k_narrow) where the queue heads were just cleared (static-grid steps); SZ_NARROW_QUEUE=0: off
+  const int queue = housekept && !c->no_queue ? 1 : 0;
   long long capItems = (long long)S.capPairs + S.capElem;
   // Rings never change size inside the hot path, so the host knows whether any item can need a
   // larger variant (halo floes of a tiled run arrive unseen: then always check on the device).
@@ -333,7 +336,7 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo) {
       if (getenv("SZ_VERBOSE")) fprintf(stderr, "[subzero-hip] narrow: %d workgroups per CU x %d CUs\n", per_cu, cus);
     }
     hipLaunchKernelGGL(kern, dim3(grid_for(capItems, TPB / G, grid)), dim3(TPB), 0,
-                       c->stream, S, c->P, dt, ffmo, fdmo, c->dbg);
+                       c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue);
     t.end();
   }
   {
@@ -342,9 +345,9 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo) {
     Timed t(c, K_NARROW_LARGE);
     if (larger)
       hipLaunchKernelGGL((sz_k_narrow<16, NARROW_CAP1, 16, 80, 6, 64, NARROW_CAP0, 1>), dim3(grid_for(capItems, 4, 2048)), dim3(64), 0,
-                         c->stream, S, c->P, dt, ffmo, fdmo, c->dbg);
+                         c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue);
     hipLaunchKernelGGL((sz_k_narrow<64, NARROW_CAP2, 64, 320, 16, 64, NARROW_CAP1, 2>), dim3(grid_for(capItems, 1, larger ? 2048 : 256)), dim3(64), 0,
-                       c->stream, S, c->P, dt, ffmo, fdmo, c->dbg);
+                       c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue);
     t.end();
   }
 }
@@ -361,7 +364,7 @@ void stage_reduce(sz_ctx* c, int mirror, int n_init, int dt) {
 void collisions(sz_ctx* c, int n_init, int dt, bool commit_ghosts = false, bool static_grid = false) {
   stage_broad(c, commit_ghosts, static_grid);
   stage_elems(c, true);
-  stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap);
+  stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, static_grid);
   stage_reduce(c, 1, n_init, dt);
 }
 
@@ -501,6 +504,8 @@ sz_ctx* sz_create(int device_id) {
   c->device = device_id;
   if (const char* e = getenv("SZ_DEBUG")) c->dbg = atoi(e);
   if (const char* e = getenv("SZ_OVERLAP")) c->overlap_forcing = atoi(e) != 0 ? 1 : 0;
+  if (const char* e = getenv("SZ_NARROW_QUEUE")) c->no_queue = atoi(e) == 0;
+  if (const char* e = getenv("SZ_STATIC_GRID")) c->no_static_grid = atoi(e) == 0;
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     // lo = least urgent, hi = most urgent
   if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_hi) != hipSuccess) { delete c; return nullptr; }
@@ -655,7 +660,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1);
   DA(cell_items, S.capM);
   DA(nb_out, (size_t)S.capM * MAXNB); DA(nb_in, (size_t)S.capM * MAXNB); DA(n_out, S.capM + 1); DA(n_in, S.capM + 1);
-  DA(out_off, S.capM + 2); DA(out_mask, S.capM + 1); DA(n_work, S.capM + 1); DA(work_off, S.capM + 2); DA(work, S.capPairs + 1); DA(pair_i, S.capPairs); DA(pair_j, S.capPairs);
+  DA(out_off, S.capM + 2); DA(out_mask, S.capM + 1); DA(n_work, S.capM + 1); DA(work_off, S.capM + 2); DA(work, S.capPairs + 1); DA(wq, 8 * 32); DA(pair_i, S.capPairs); DA(pair_j, S.capPairs);
   DA(el_off, S.capM + 2); DA(el_floe, S.capElem); DA(el_elem, S.capElem);
   size_t items = (size_t)S.capPairs + S.capElem;
   DA(it_rows, items * ROWS_PER_ITEM * 5); DA(it_nrows, items); DA(it_flags, items);

@@ -649,6 +649,7 @@ __global__ void __launch_bounds__(SCAN_B) sz_k_pscan_fill(State S, unsigned epoc
     const int ncells = (int)S.bounds[4] * (int)S.bounds[5];
     const int nlive = (n + SCAN_B - 1) / SCAN_B > 0 ? (n + SCAN_B - 1) / SCAN_B : 1;      // workgroups that do not return below
     if ((int)blockIdx.x < nlive) for (int q = base + threadIdx.x; q <= ncells; q += nlive * SCAN_B) S.cell_cnt[q] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 8) S.wq[threadIdx.x * 32] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       S.cnt[C_ITEMCLASS] = 0;
       S.cnt[C_WARN_H] = 0; S.cnt[C_WARN_F] = 0; S.cnt[C_WARN_V] = 0; S.cnt[C_WARN_XI] = 0;
@@ -732,7 +733,7 @@ __global__ void __launch_bounds__(SCAN_B) sz_k_elem_scan_fill(State S, unsigned 
 // whose rings both fit LO..CAP points.
 // WPE: wavefronts per SIMD the kernel is compiled for (register budget 512 / WPE)
 template <int G, int CAP, int KC, int RC, int RM, int TPB, int LO, int CLS, int WPE = 1>
-__global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int dt, double ff_max_overlap, double fd_max_overlap, int dbg) {
+__global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int dt, double ff_max_overlap, double fd_max_overlap, int dbg, int queue) {
   constexpr int GPB = TPB / G;
   static_assert(4 * KC <= 2 * RC, "raw crossing slots alias reg[1]");
   if (CLS > 0 && S.cnt[C_ITEMCLASS] < CLS) return;   // no item needs this (larger) variant this step
@@ -750,7 +751,19 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
   // items at a time and the wavefront then works the flagged ones off one by one.
   constexpr bool SCAN = (G == 64 && TPB == 64);
   constexpr int STRIDE = SCAN ? 64 : GPB;
-  for (int t0 = blockIdx.x * STRIDE; t0 < nitems; t0 += gridDim.x * STRIDE) {
+  // Rounds after the first are handed out dynamically (queue != 0): a round of 8 items takes anything between a
+  // few thousand cycles (no overlap) and 150 k (items with two contact regions), so with a static split the
+  // slowest workgroup sets the time of a deep launch.  The items are cut into 8 ranges with one queue head each
+  // (one cache line per head; a single head costs ~20 ns per ticket, serialised across the XCDs: measured slower
+  // than the static split), a workgroup draws from the queue of its index modulo 8; the first round is static,
+  // so a one-round launch never touches a queue.  Narrow kernel 374 -> 242 us at 100 k floes, 151 -> 124 us at
+  // 40 k, 96 -> 88 us at 20 k, unchanged at 10 k (tools/queue_ab.sh); the results do not depend on who runs an item.
+  const bool useq = CLS == 0 && !SCAN && queue != 0;
+  const int qk = (int)(blockIdx.x & 7);
+  const int nper = useq ? ((nitems + 7) / 8 + GPB - 1) / GPB * GPB : 0;
+  const int limit = useq ? (qk * nper + nper < nitems ? qk * nper + nper : nitems) : nitems;
+  const int nbq = useq ? ((int)gridDim.x + 7 - qk) / 8 : 0;
+  for (int t0 = useq ? qk * nper + (int)(blockIdx.x >> 3) * GPB : (int)blockIdx.x * STRIDE; t0 < limit;) {
    unsigned long long todo = 1;
    if (SCAN) {
      const int tt = t0 + (int)threadIdx.x;
@@ -767,7 +780,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
    while (todo) {
     int t;
     if (SCAN) { t = t0 + __ffsll((long long)todo) - 1; todo &= todo - 1; }
-    else { todo = 0; t = t0 + gi; if (t >= nitems) break; }
+    else { todo = 0; t = t0 + gi; if (t >= limit) break; }
     const bool is_pair = t < npairs;
     int i, j = -1, e = -1, item;
     if (is_pair) { int4 w = S.work[t]; item = w.x; i = w.y; j = w.z; }
@@ -827,6 +840,11 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     st.maxrows = st.maxrows > nrows ? st.maxrows : nrows;
 #endif
    }
+   if (useq) {
+     int tk = 0;
+     if (threadIdx.x == 0) tk = atomicAdd(&S.wq[qk * 32], GPB);
+     t0 = qk * nper + nbq * GPB + __shfl(tk, 0);
+   } else t0 += (int)gridDim.x * STRIDE;
   }
   gsync();
   if (gl == 0 && m.err) atomicOr(&S.cnt[C_ERR], m.err);

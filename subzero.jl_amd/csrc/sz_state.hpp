@@ -94,6 +94,7 @@ struct State {
   int *pair_i, *pair_j;
   int *out_mask, *n_work, *work_off;   // per floe: which of its outgoing pairs have overlapping ring boxes (bit r = rank r)
   int4* work;                // compacted pair items: {pair slot, i, j, -}
+  int* wq;                   // 8 work-queue heads of the narrow phase, one cache line each (deep launches only)
   // ---- element items
   int *el_off, *el_floe, *el_elem;
   // ---- contact rows per item (pairs first, then element items at capPairs + e)
