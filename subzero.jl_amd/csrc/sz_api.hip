@@ -68,6 +68,7 @@ struct sz_ctx {
   bool two_way = false; int tw_dt = 10; int tw_capM = 0; size_t tw_ncell = 0;
   std::vector<void*> tw_allocs, tw_field_allocs;
   // static broad-phase grid of the resident steps (fixed by the host: no bounds reduction per step)
+  bool fuse_forcing = true;         // forcings inside the neighbour launch (sz_k_neighbors_forcing); SZ_FUSE_FORCING=0: own launch
   bool no_queue = false;            // SZ_NARROW_QUEUE=0: static split of the narrow items over the workgroups
   bool no_static_grid = false;      // SZ_STATIC_GRID=0: fit the grid to the centroids every step (sz_k_bounds), as process mode does
   double rmax_max = 0.0, rmax_hint = 0.0; bool grid_ok = false, grid_live = false; double h_grid[8] = { 0 };
@@ -282,7 +283,7 @@ void stage_ghosts(sz_ctx* c, bool in_step = false, bool commit = false) {
 
 // static_grid: the geometry in S.bounds is the host's (use_static_grid), no bounds kernel; the pair kernel does
 // the housekeeping the bounds kernel would have done
-void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false) {
+void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false, bool fuse_forcing = false) {
   State& S = c->S;
   Timed t(c, SZ_K_BROAD);
   int gM = grid_for(S.capM, 256);
@@ -291,7 +292,12 @@ void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false
     hipLaunchKernelGGL(sz_k_cell_build, dim3(gM), dim3(256), 0, c->stream, S, 0);
     c->grid_live = false;
   }
-  hipLaunchKernelGGL(sz_k_neighbors, dim3(grid_for(S.capM, NB_TPB / NB_G, 8192)), dim3(NB_TPB), 0, c->stream, S);
+  if (fuse_forcing) {          // the step's forcings ride in the neighbour launch (sz_k_neighbors_forcing)
+    const int nbn = grid_for(S.capM, 256 / NB_G, 8192), nbf = grid_for(S.capM, 256 / FRC_G, 8192);
+    if (c->precision == 1) hipLaunchKernelGGL(sz_k_neighbors_forcing<2>, dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn);
+    else hipLaunchKernelGGL(sz_k_neighbors_forcing<1>, dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn);
+  } else
+    hipLaunchKernelGGL(sz_k_neighbors, dim3(grid_for(S.capM, NB_TPB / NB_G, 8192)), dim3(NB_TPB), 0, c->stream, S);
   int nb = grid_for(S.capM, SCAN_B, 1 << 20);
   hipLaunchKernelGGL(sz_k_pscan_fill, dim3(nb), dim3(SCAN_B), 0, c->stream, S, next_epoch(c), static_grid ? 1 : 0);
   t.end();
@@ -361,8 +367,8 @@ void stage_reduce(sz_ctx* c, int mirror, int n_init, int dt) {
   t.end();
 }
 
-void collisions(sz_ctx* c, int n_init, int dt, bool commit_ghosts = false, bool static_grid = false) {
-  stage_broad(c, commit_ghosts, static_grid);
+void collisions(sz_ctx* c, int n_init, int dt, bool commit_ghosts = false, bool static_grid = false, bool fuse_forcing = false) {
+  stage_broad(c, commit_ghosts, static_grid, fuse_forcing);
   stage_elems(c, true);
   stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, static_grid);
   stage_reduce(c, 1, n_init, dt);
@@ -505,6 +511,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_DEBUG")) c->dbg = atoi(e);
   if (const char* e = getenv("SZ_OVERLAP")) c->overlap_forcing = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("SZ_NARROW_QUEUE")) c->no_queue = atoi(e) == 0;
+  if (const char* e = getenv("SZ_FUSE_FORCING")) c->fuse_forcing = atoi(e) != 0;
   if (const char* e = getenv("SZ_STATIC_GRID")) c->no_static_grid = atoi(e) == 0;
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     // lo = least urgent, hi = most urgent
@@ -981,10 +988,11 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     // beside the halo exchange, and both paths keep the same order: a parent that the ghost pass wraps around the
     // domain is sampled at the periodic image it had before -- the same lattice values).  With the forcings on a
     // second stream the fork comes after the ghost pass instead, so that nothing they read is being rewritten.
-    if (coupling && !overlap) stage_forcing(c, dt);
+    const bool fuse = coupling && !overlap && coll && !c->two_way && !(c->pmask >> SZ_K_FORCING & 1u) && c->fuse_forcing;
+    if (coupling && !overlap && !fuse) stage_forcing(c, dt);
     if (coll) stage_ghosts(c, true, sg);
     if (overlap) stage_forcing_fork(c);
-    if (coll) collisions(c, c->hostN, dt, periodic && !sg, sg);
+    if (coll) collisions(c, c->hostN, dt, periodic && !sg, sg, fuse);
     if (overlap) stage_forcing_join(c);
     stage_integrate(c, dt, !coll, coupling, sg);
   }
