@@ -57,9 +57,8 @@ struct sz_ctx {
   long long* d_stats = nullptr;
   int last_dt = 0;
   bool any_moving = false;
-  int overlap_forcing = -1;       // forcings on a second stream beside the broad / narrow / reduce kernels.  -1 = by field size:
-                                  // the fork/join costs ~10 us, measured -5 % at 10k floes, +3 % at 40k, +6 % at 100k.
-                                  // SZ_OVERLAP=0/1 forces it off / on.
+  int overlap_forcing = 0;        // SZ_OVERLAP=1: forcings on a second stream beside the broad / narrow / reduce kernels.  The fork/join
+                                  // costs ~10 us; riding in the neighbour launch (fuse_forcing) is as good or better at every size
   int max_ring = 0, max_elem_ring = 5, max_ring_tiled = 0;   // largest ring sizes (host knowledge: which narrow variants can be needed)
   int narrow_grid0 = 0;
   // mixed precision (sz_set_precision): fp32 copies for the forcing kernel, rebuilt when their sources change
@@ -69,6 +68,7 @@ struct sz_ctx {
   std::vector<void*> tw_allocs, tw_field_allocs;
   // static broad-phase grid of the resident steps (fixed by the host: no bounds reduction per step)
   bool fuse_forcing = true;         // forcings inside the neighbour launch (sz_k_neighbors_forcing); SZ_FUSE_FORCING=0: own launch
+  bool fused_move = true;           // integrate + move/strain in one thread-per-floe launch when rings are small (-2 us at 10k); SZ_FUSED_MOVE=0: two launches
   bool no_queue = false;            // SZ_NARROW_QUEUE=0: static split of the narrow items over the workgroups
   bool no_static_grid = false;      // SZ_STATIC_GRID=0: fit the grid to the centroids every step (sz_k_bounds), as process mode does
   double rmax_max = 0.0, rmax_hint = 0.0; bool grid_ok = false, grid_live = false; double h_grid[8] = { 0 };
@@ -461,8 +461,13 @@ void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool 
   // ghost-removal kernel has already cleared them)
   if (reset_guards) (void)hipMemsetAsync(c->S.cnt + C_WARN_H, 0, 4 * sizeof(int), c->stream);
   Timed t(c, SZ_K_INTEGRATE);
-  hipLaunchKernelGGL(sz_k_integrate, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0);
-  hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 0, bin ? 1 : 0);
+  // resident steps with small rings: one launch (thread per floe) integrates, moves the ring and bins the floe
+  if (bin && c->max_ring <= MV_RING && c->fused_move) {
+    hipLaunchKernelGGL(sz_k_integrate<true>, dim3(grid_for(c->S.capM, 128)), dim3(128), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 1);
+  } else {
+    hipLaunchKernelGGL(sz_k_integrate<false>, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 0);
+    hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 0, bin ? 1 : 0);
+  }
   if (!bin) c->grid_live = false;          // floes moved without re-binning: the resident steps' cell lists are stale
   t.end();
 }
@@ -511,6 +516,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_DEBUG")) c->dbg = atoi(e);
   if (const char* e = getenv("SZ_OVERLAP")) c->overlap_forcing = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("SZ_NARROW_QUEUE")) c->no_queue = atoi(e) == 0;
+  if (const char* e = getenv("SZ_FUSED_MOVE")) c->fused_move = atoi(e) != 0;
   if (const char* e = getenv("SZ_FUSE_FORCING")) c->fuse_forcing = atoi(e) != 0;
   if (const char* e = getenv("SZ_STATIC_GRID")) c->no_static_grid = atoi(e) == 0;
   int prio_lo = 0, prio_hi = 0;
@@ -981,7 +987,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   for (int s = 0; s < nsteps; s++) {
     int tstep = tstep0 + s;
     const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
-    const bool overlap = coupling && !c->two_way && (c->overlap_forcing < 0 ? c->hostN >= 32768 : c->overlap_forcing != 0);
+    const bool overlap = coupling && !c->two_way && (c->overlap_forcing != 0);
     // with collisions on, the ghosts of step s are detached by the ghost kernels of step s+1 (nothing
     // in between looks past the parents) and committed by the bounds kernel: two launches less
     // The forcings only need the floes as the previous step left them, so they go first (the tiled step runs them

@@ -1320,8 +1320,15 @@ __global__ void sz_k_calc_stress(State S, Params P) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) floe_stress(S, P, i, S.cx[i], S.cy[i]);
 }
 
-// one thread per floe: stress, guards, thermodynamics, AB2 velocity update; stores the motion
-__global__ void sz_k_integrate(State S, Params P, int dt, int apply_frc) {
+// one thread per floe: stress, guards, thermodynamics, AB2 velocity update; stores the motion.
+// MOVE (resident steps, rings of at most MV_RING points): the same thread also moves the ring, refreshes its
+// box, evaluates the strain and bins the floe -- what sz_k_move_strain does with 16 lanes per floe in a
+// second launch.  The ring is read into registers in one go (one memory round trip), the per-edge strain terms
+// are the same expressions summed in the same order.
+constexpr int MV_RING = 20;
+template <bool MOVE>
+__global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Params P, int dt, int apply_frc, int bin) {
+  const GridGeo geo = grid_geo(S);
   int N = S.cnt[C_NOWN];
   int wh = 0, wf = 0, wv = 0, wx = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
@@ -1345,7 +1352,8 @@ __global__ void sz_k_integrate(State S, Params P, int dt, int apply_frc) {
     const double al = S.alpha[i] + da;
     S.alpha[i] = al;
     S.trig[2 * i] = cos(al); S.trig[2 * i + 1] = sin(al);   // for the forcing kernel (32 lanes per floe: not the place for it)
-    S.mot[i * 4 + 0] = dx; S.mot[i * 4 + 1] = dy; S.mot[i * 4 + 2] = cos(da); S.mot[i * 4 + 3] = sin(da);
+    const double cda = cos(da), sda = sin(da);
+    if (!MOVE) { S.mot[i * 4 + 0] = dx; S.mot[i * 4 + 1] = dy; S.mot[i * 4 + 2] = cda; S.mot[i * 4 + 3] = sda; }
     S.p_dxdt[i] = u; S.p_dydt[i] = v; S.p_dalphadt[i] = xi;
     double dudt = (S.fxOA[i] + cfx) / mass, dvdt = (S.fyOA[i] + cfy) / mass;
     double frac = 1.0, au = fabs(dt * dudt), av = fabs(dt * dvdt), h2 = h / 2;
@@ -1363,6 +1371,43 @@ __global__ void sz_k_integrate(State S, Params P, int dt, int apply_frc) {
     double nxi = xi + 1.5 * dt * dxidt - 0.5 * dt * S.p_dxidt[i];
     if (fabs(nxi) > P.max_xi) { nxi = sgn(nxi) * P.max_xi; wx++; }
     S.xi[i] = nxi; S.p_dxidt[i] = dxidt;
+    if (MOVE) {
+      // _move_floe! (floe_utils.jl:82-93) and calc_strain! (update_floe.jl:425-453) with the new velocities
+      const double nu = S.u[i];                     // as stored above
+      const int o = S.voff[i], n = S.voff[i + 1] - o;
+      double px[MV_RING], py[MV_RING];
+#pragma unroll
+      for (int k = 0; k < MV_RING; k++) { px[k] = k < n ? S.vx[o + k] : 0.0; py[k] = k < n ? S.vy[o + k] : 0.0; }
+      const double ncx = cx + dx, ncy = cy + dy;
+      double e11 = 0, e12 = 0, e22 = 0;
+      double bx0 = __builtin_inf(), bx1 = -__builtin_inf(), by0 = __builtin_inf(), by1 = -__builtin_inf();
+      double ax = 0.0, ay = 0.0;
+#pragma unroll
+      for (int k = 0; k < MV_RING; k++) {
+        if (k < n) {
+          const double x = px[k] + (-cx), y = py[k] + (-cy);
+          const double xr = cda * x - sda * y, yr = sda * x + cda * y;
+          const double mx = xr + (cx + dx), my = yr + (cy + dy);
+          if (k > 0) {
+            const double x1 = ax + (-ncx), y1 = ay + (-ncy), x2 = mx + (-ncx), y2 = my + (-ncy);
+            const double xd = x2 - x1, yd = y2 - y1;
+            const double u1 = nu - nxi * y1, u2 = nu - nxi * y2;
+            const double v1 = nu + nxi * x1, v2 = nu + nxi * x2;
+            const double ud = u2 - u1, vd = v2 - v1;
+            e11 += ud * yd; e12 += ud * xd + vd * yd; e22 += vd * xd;
+          }
+          S.vx[o + k] = mx; S.vy[o + k] = my;
+          bx0 = fmin(bx0, mx); bx1 = fmax(bx1, mx); by0 = fmin(by0, my); by1 = fmax(by1, my);
+          ax = mx; ay = my;
+        }
+      }
+      S.bbx0[i] = bx0; S.bbx1[i] = bx1; S.bby0[i] = by0; S.bby1[i] = by1;
+      e12 *= 0.5;
+      const double d = 2 * S.area[i];
+      S.strain[i * 4 + 0] = e11 / d; S.strain[i * 4 + 1] = e12 / d; S.strain[i * 4 + 2] = e12 / d; S.strain[i * 4 + 3] = e22 / d;
+      S.cx[i] = ncx; S.cy[i] = ncy;
+      if (bin) cell_insert(S, geo, i, ncx, ncy);
+    }
   }
   if (wh) atomicAdd(&S.cnt[C_WARN_H], wh);
   if (wf) atomicAdd(&S.cnt[C_WARN_F], wf);

@@ -1,5 +1,6 @@
 """Tiled (multi-rank) engine on the real GPU: 2 ranks share the one MI355X of the test box and trade
 their halos through gloo (host staging); results must equal the single-context run."""
+import datetime
 import os
 import socket
 
@@ -12,6 +13,28 @@ FIELDS = ["cx", "cy", "u", "v", "xi", "alpha", "coll_fx", "coll_fy", "coll_trq",
           "sa11", "sa22", "e11", "e22"]
 
 
+def _guard(fn):
+    """run a worker body; an exception goes to the parent through the queue instead of leaving it waiting"""
+    def run(rank, world, port, *args):
+        q = args[-1] if not isinstance(args[-1], bool) else args[-2]
+        try:
+            fn(rank, world, port, *args)
+        except BaseException as e:          # noqa: BLE001
+            import traceback
+            q.put(("error", rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))[-3000:]))
+            raise
+    return run
+
+
+def _collect(q, world):
+    res = []
+    for _ in range(world):
+        r = q.get(timeout=180)
+        assert r[0] != "error", f"rank {r[1]} failed:\n{r[2]}"
+        res.append(r)
+    return res
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -21,7 +44,7 @@ def _worker(rank, world, port, n, seed, steps, q, repartition=False):
     import torch.distributed as dist
     from subzero_jl_amd import fields, tiles
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         cfg = fields.make_config(n_floes=n, seed=seed)
         tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True)
@@ -43,6 +66,14 @@ def _worker(rank, world, port, n, seed, steps, q, repartition=False):
         dist.destroy_process_group()
 
 
+def _run_worker(*a):
+    _guard(_worker)(*a)
+
+
+def _run_worker_two_way(*a):
+    _guard(_worker_two_way)(*a)
+
+
 @pytest.mark.parametrize("n,seed,steps,repartition", [(600, 31, 4, False), (600, 33, 6, True)])
 def test_two_ranks_equal_single(n, seed, steps, repartition):
     import torch.multiprocessing as mp
@@ -52,13 +83,18 @@ def test_two_ranks_equal_single(n, seed, steps, repartition):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, seed, steps, q, repartition)) for r in range(world)]
+    procs = [ctx.Process(target=_run_worker, args=(r, world, port, n, seed, steps, q, repartition)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
-    for p in procs:
-        p.join(60)
-    assert all(p.exitcode == 0 for p in procs)
+    try:
+        res = _collect(q, world)
+        for p in procs:
+            p.join(60)
+        assert all(p.exitcode == 0 for p in procs)
+    finally:
+        for p in procs:                      # a rank left waiting in a collective by a failed peer
+            if p.is_alive():
+                p.terminate()
     cfg = fields.make_config(n_floes=n, seed=seed)
     hw = fields.build_world(subzero_jl_amd.World(0), cfg)
     hw.run(steps, 0, cfg["dt"], coupling_dt=1)
@@ -76,7 +112,7 @@ def _worker_two_way(rank, world, port, n, seed, steps, q):
     import torch.distributed as dist
     from subzero_jl_amd import fields, tiles
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         cfg = fields.make_config(n_floes=n, seed=seed, ocean="shear")
         tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True)
@@ -98,13 +134,18 @@ def test_two_way_coupling_across_tiles():
     n, seed, steps, world = 500, 41, 6, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue(); port = _free_port()
-    procs = [ctx.Process(target=_worker_two_way, args=(r, world, port, n, seed, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run_worker_two_way, args=(r, world, port, n, seed, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
-    for p in procs:
-        p.join(60)
-    assert all(p.exitcode == 0 for p in procs)
+    try:
+        res = _collect(q, world)
+        for p in procs:
+            p.join(60)
+        assert all(p.exitcode == 0 for p in procs)
+    finally:
+        for p in procs:                      # a rank left waiting in a collective by a failed peer
+            if p.is_alive():
+                p.terminate()
     cfg = fields.make_config(n_floes=n, seed=seed, ocean="shear")
     hw = fields.build_world(subzero_jl_amd.World(0), cfg)
     hw.set_two_way(True, dt=cfg["dt"]); hw.set_temps(0.5, -8.0)
