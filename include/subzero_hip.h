@@ -229,6 +229,26 @@ int sz_tile_step(sz_ctx *ctx, const void *d_recv, int32_t nranks, int32_t cap, i
 int sz_sync(sz_ctx *ctx);
 int sz_set_stream(sz_ctx *ctx, void *hip_stream);
 
+/* ---- output path on the resident state
+   sz_eulerian_data: calc_eulerian_data! (output.jl:793-914), the GridOutputWriter averages, over the rows the
+   context holds -- write_data! runs after add_ghosts! (simulation.jl:102-105), so callers that step with sz_step
+   bracket it with sz_add_ghosts / sz_remove_ghosts.  xg (nx + 1) and yg (ny + 1) are the writer's grid lines (evenly
+   spaced, as GridOutputWriter builds them, output.jl:352-353); outputs lists nout of the SZ_EUL_* codes;
+   data[k][ix][iy] at (k * nx + ix) * ny + iy is writer.data[ix + 1, iy + 1, k + 1].  Topography is taken out of
+   the cells as the reference does (elements must not overlap one another).
+   The FloeOutputWriter (write_floe_data!, output.jl:558-574) writes whole columns: sz_download_floes with only
+   the wanted columns non-NULL is its device-side packing.
+   sz_simplify_check: what simplify_floes! (simplification.jl:339-378) would find to do -- out4 = floes tagged remove,
+   tagged fuse, rings with more than max_vertices points (smooth_floes!, :66) and floes under min_floe_area /
+   min_floe_height that are not tagged remove (remove_floes!, :287-290).  All four zero: the pass changes nothing and
+   no geometry needs to leave the device. */
+enum { SZ_EUL_U = 0, SZ_EUL_V, SZ_EUL_DUDT, SZ_EUL_DVDT, SZ_EUL_OVERAREA, SZ_EUL_MASS, SZ_EUL_AREA, SZ_EUL_HEIGHT,
+       SZ_EUL_SI_FRAC, SZ_EUL_STRESS_XX, SZ_EUL_STRESS_YX, SZ_EUL_STRESS_XY, SZ_EUL_STRESS_YY, SZ_EUL_STRESS_EIG,
+       SZ_EUL_STRAIN_UX, SZ_EUL_STRAIN_VX, SZ_EUL_STRAIN_UY, SZ_EUL_STRAIN_VY, SZ_EUL_COUNT };
+int sz_eulerian_data(sz_ctx *ctx, int32_t nx, int32_t ny, const double *xg, const double *yg, int32_t nout,
+                     const int32_t *outputs, double *data);
+int sz_simplify_check(sz_ctx *ctx, int32_t max_vertices, double min_floe_area, double min_floe_height, int64_t *out4);
+
 /* diagnostic build (-DSZ_STAMPS) only: stamp log of one lane group of the narrow phase
    (out512[0] = entries, then (stage << 48) | cycles since the wave started) */
 int sz_debug_stamps(sz_ctx *ctx, long long *out512);

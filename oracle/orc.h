@@ -20,6 +20,8 @@
  *     floe_to_grid_info!): PINNED by test/test_physical_processes/test_coupling.jl:165-180, 276-460
  *     (tests/golden/coupling_grid.json); calc_two_way_coupling! itself has no reference fixture and is
  *     checked on an analytic case.
+ *   - calc_eulerian_data! (output.jl:793-914, the GridOutputWriter averages): no numeric fixture in the reference
+ *     (test/test_output.jl checks only names and shapes) => "parity unpinned"; checked on analytic cases.
  *   - the rest of timestep_floe_properties! (guards, thermodynamics, AB2 update): formula-level
  *     restatement, no reference fixture exists => "parity unpinned" for those lines beyond the
  *     conservation properties checked in tests/.
@@ -158,6 +160,15 @@ void orc_timestep_floe_properties(orc_world *w, int dt);             /* update_f
 void orc_set_interactions(orc_world *w, int i, int k, const double *rows);   /* floe.interactions = k x 7 matrix, row-major */
 void orc_calc_stress(orc_world *w, int i);                            /* calc_stress!, update_floe.jl:392-414 */
 void orc_calc_strain(orc_world *w, int i);                            /* calc_strain!, update_floe.jl:425-453 */
+/* ---- output path */
+/* grid outputs of calc_eulerian_data! (output.jl:855-905) */
+enum {
+  ORC_EUL_U = 0, ORC_EUL_V, ORC_EUL_DUDT, ORC_EUL_DVDT, ORC_EUL_OVERAREA, ORC_EUL_MASS, ORC_EUL_AREA, ORC_EUL_HEIGHT,
+  ORC_EUL_SI_FRAC, ORC_EUL_STRESS_XX, ORC_EUL_STRESS_YX, ORC_EUL_STRESS_XY, ORC_EUL_STRESS_YY, ORC_EUL_STRESS_EIG,
+  ORC_EUL_STRAIN_UX, ORC_EUL_STRAIN_VX, ORC_EUL_STRAIN_UY, ORC_EUL_STRAIN_VY, ORC_EUL_COUNT
+};
+void orc_calc_eulerian_data(const orc_world *w, int nx, int ny, const double *xg, const double *yg, double *data); /* output.jl:793-914 */
+void orc_simplify_check(const orc_world *w, int max_vertices, double min_floe_area, double min_floe_height, int64_t *out4); /* simplification.jl:66,287-290 */
 /* timestep_sim! (simulation.jl:94-170) restricted to the hot path */
 void orc_timestep_sim(orc_world *w, int tstep, int dt, int coupling_dt, int collisions_on, int coupling_on);
 

@@ -26,6 +26,13 @@ OPEN, PERIODIC, COLLISION, MOVING = 0, 1, 2, 3
 NORTH, SOUTH, EAST, WEST = 0, 1, 2, 3
 ACTIVE, REMOVE, FUSE = 1, 2, 3
 
+# grid outputs of calc_eulerian_data! in the order of ORC_EUL_* (output.jl:855-905)
+EUL_OUTPUTS = [
+    "u_grid", "v_grid", "dudt_grid", "dvdt_grid", "overarea_grid", "mass_grid", "area_grid", "height_grid",
+    "si_frac_grid", "stress_xx_grid", "stress_yx_grid", "stress_xy_grid", "stress_yy_grid", "stress_eig_grid",
+    "strain_ux_grid", "strain_vx_grid", "strain_uy_grid", "strain_vy_grid",
+]
+
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 _lp = C.POINTER(C.c_int64)
@@ -260,6 +267,20 @@ class World:
         self.L.orc_set_threads(self.h, int(n))
 
     # ---- the reference's process API
+    def eulerian_data(self, xg, yg):
+        """calc_eulerian_data! (output.jl:793-914): array [len(EUL_OUTPUTS), nx, ny]."""
+        xg, yg = _d(xg), _d(yg)
+        nx, ny = len(xg) - 1, len(yg) - 1
+        out = np.zeros((len(EUL_OUTPUTS), nx, ny))
+        self.L.orc_calc_eulerian_data(self.h, C.c_int(nx), C.c_int(ny), _p(xg), _p(yg), _p(out))
+        return out
+
+    def simplify_check(self, max_vertices, min_floe_area, min_floe_height):
+        out = np.zeros(4, dtype=np.int64)
+        self.L.orc_simplify_check(self.h, C.c_int(max_vertices), C.c_double(min_floe_area), C.c_double(min_floe_height),
+                                  _p(out, _lp))
+        return out
+
     def add_ghosts(self):
         self.L.orc_add_ghosts(self.h)
 

@@ -926,6 +926,98 @@ void orc_calc_two_way_coupling(orc_world *w) {
   }
 }
 
+/* ------------------------------------------------------------------ output path */
+/* calc_eulerian_data!, output.jl:793-914: floe data averaged on the writer's grid (lines xg: nx+1, yg: ny+1).
+   data[k][ix][iy] at (k * nx + ix) * ny + iy, k in the order of ORC_EUL_* (orc.h); cell (ix, iy) is
+   [xg[ix], xg[ix+1]] x [yg[iy], yg[iy+1]] (writer.data[j, i, k] with j = ix + 1, i = iy + 1).
+   Topography (the cell polygon minus the topography, :829-832) is restated through the set identity
+   area(floe ∩ (cell \ topo)) = area(floe ∩ cell) - sum_t area((floe ∩ cell) ∩ topo_t), valid for topography
+   elements that do not overlap one another (the reference's diff_polys lives in GeometryOps). */
+static double regions_area(const orc_regions *rg) {
+  double a = 0.0;
+  for (int r = 0; r < rg->n; r++) a += orc_area(&rg->r[r]);
+  return a;
+}
+void orc_calc_eulerian_data(const orc_world *w, int nx, int ny, const double *xg, const double *yg, double *data) {
+  const double dx = xg[1] - xg[0], dy = yg[1] - yg[0];
+  const double cell_rmax = sqrt(dx * dx + dy * dy);
+  const int M = w->M;
+  int *idx = (int *)malloc((size_t)(M > 0 ? M : 1) * sizeof(int));
+  double *pic = (double *)malloc((size_t)(M > 0 ? M : 1) * sizeof(double));
+  orc_ring cell; orc_regions rg, rg2;
+  orc_ring_init(&cell); orc_regions_init(&rg); orc_regions_init(&rg2);
+  for (int ix = 0; ix < nx; ix++) for (int iy = 0; iy < ny; iy++) {
+    double *out[ORC_EUL_COUNT];
+    for (int k = 0; k < ORC_EUL_COUNT; k++) { out[k] = &data[((size_t)k * nx + ix) * ny + iy]; *out[k] = 0.0; }
+    /* potential interactions (:808-819): cell centre within rmax + cell_rmax of the centroid */
+    const double xc = xg[ix] + 0.5 * dx, yc = yg[iy] + 0.5 * dy;
+    int n = 0;
+    for (int i = 0; i < M; i++) {
+      const floe_t *f = &w->f[i];
+      double d = sqrt((xc - f->cx) * (xc - f->cx) + (yc - f->cy) * (yc - f->cy)) - (f->rmax + cell_rmax);
+      if (d < 0) idx[n++] = i;
+    }
+    if (n == 0) continue;
+    cell.n = 0;
+    orc_ring_push(&cell, xg[ix], yg[iy]); orc_ring_push(&cell, xg[ix], yg[iy + 1]); orc_ring_push(&cell, xg[ix + 1], yg[iy + 1]);
+    orc_ring_push(&cell, xg[ix + 1], yg[iy]); orc_ring_push(&cell, xg[ix], yg[iy]);
+    double cell_area = orc_area(&cell);
+    for (int t = 0; t < w->ntopo; t++) {
+      orc_intersection(&cell, &w->topo[t].poly, &rg);
+      cell_area -= regions_area(&rg);
+    }
+    if (!(cell_area > 0)) continue;          /* length(cell_poly_list) == 0, :834-837 */
+    int m = 0;
+    for (int k = 0; k < n; k++) {
+      const floe_t *f = &w->f[idx[k]];
+      orc_intersection(&f->poly, &cell, &rg);
+      double a = regions_area(&rg);
+      for (int t = 0; t < w->ntopo && a > 0; t++)
+        for (int r = 0; r < rg.n; r++) { orc_intersection(&rg.r[r], &w->topo[t].poly, &rg2); a -= regions_area(&rg2); }
+      if (a > 0) { idx[m] = idx[k]; pic[m] = a; m++; }
+    }
+    double area_tot = 0.0, mass_tot = 0.0;
+    for (int k = 0; k < m; k++) { const floe_t *f = &w->f[idx[k]]; area_tot += pic[k]; mass_tot += f->mass * (pic[k] / f->area); }
+    if (!(mass_tot > 0)) continue;
+    double s[ORC_EUL_COUNT] = { 0 }, over = 0.0;
+    for (int k = 0; k < m; k++) {
+      const floe_t *f = &w->f[idx[k]];
+      const double r = (pic[k] / f->area) * (f->mass / mass_tot);     /* ma_ratios */
+      s[ORC_EUL_U] += f->u * r; s[ORC_EUL_V] += f->v * r; s[ORC_EUL_DUDT] += f->p_dudt * r; s[ORC_EUL_DVDT] += f->p_dvdt * r;
+      s[ORC_EUL_HEIGHT] += f->height * r;
+      s[ORC_EUL_STRESS_XX] += f->sa[0] * r; s[ORC_EUL_STRESS_YX] += f->sa[1] * r;
+      s[ORC_EUL_STRESS_XY] += f->sa[2] * r; s[ORC_EUL_STRESS_YY] += f->sa[3] * r;
+      s[ORC_EUL_STRAIN_UX] += f->strain[0] * r; s[ORC_EUL_STRAIN_VX] += f->strain[1] * r;
+      s[ORC_EUL_STRAIN_UY] += f->strain[2] * r; s[ORC_EUL_STRAIN_VY] += f->strain[3] * r;
+      over += f->overarea;
+    }
+    s[ORC_EUL_OVERAREA] = over / m; s[ORC_EUL_MASS] = mass_tot; s[ORC_EUL_AREA] = area_tot;
+    s[ORC_EUL_SI_FRAC] = area_tot / cell_area;
+    {   /* maximum(eigvals([xx yx; xy yy])), zeroed beyond 1e8 (:882-891) */
+      double xx = s[ORC_EUL_STRESS_XX], yx = s[ORC_EUL_STRESS_YX], xy = s[ORC_EUL_STRESS_XY], yy = s[ORC_EUL_STRESS_YY];
+      double hm = 0.5 * (xx + yy), hd = 0.5 * (xx - yy);
+      double e = hm + sqrt(hd * hd + xy * yx);
+      if (fabs(e) > 1e8) e = 0.0;
+      s[ORC_EUL_STRESS_EIG] = e;
+    }
+    for (int k = 0; k < ORC_EUL_COUNT; k++) *out[k] = s[k];
+  }
+  orc_ring_free(&cell); orc_regions_free(&rg); orc_regions_free(&rg2); free(idx); free(pic);
+}
+/* what simplify_floes! (simplification.jl:339-378) would have to do: out4 = floes tagged remove, floes tagged
+   fuse, floes with more than max_vertices ring points (smooth_floes!, :66: GI.npoint counts the closing point),
+   floes not tagged remove under min_floe_area / min_floe_height (remove_floes!, :287-290) */
+void orc_simplify_check(const orc_world *w, int max_vertices, double min_floe_area, double min_floe_height, int64_t *out4) {
+  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  for (int i = 0; i < w->M; i++) {
+    const floe_t *f = &w->f[i];
+    if (f->status == ORC_REMOVE) out4[0]++;
+    if (f->status == ORC_FUSE) out4[1]++;
+    if (f->poly.n > max_vertices) out4[2]++;
+    if (f->status != ORC_REMOVE && (f->area < min_floe_area || f->height < min_floe_height)) out4[3]++;
+  }
+}
+
 /* calc_one_way_coupling!, coupling.jl:1486-1589 (with calc_subfloe_values! :627-657,
    in_bounds :494-597, calc_atmosphere_forcing :1212-1232, calc_ocean_forcing! :1277-1299) */
 void orc_timestep_coupling(orc_world *w) {

@@ -11,6 +11,8 @@
 #include "../../include/subzero_hip.h"
 #include "sz_kernels.hpp"
 #include "sz_twoway.hpp"
+#include "sz_output.hpp"
+#include <rocprim/rocprim.hpp>      // device radix sort of the output-grid entries (sz_eulerian_data)
 
 using namespace sz;
 
@@ -1142,6 +1144,84 @@ int sz_two_way_finish(sz_ctx* c, const void* d_partial, int32_t dt) {
   (void)hipSetDevice(c->device);
   const int ncell = (int)c->tw_ncell;
   hipLaunchKernelGGL(sz_k_tw_finish, dim3(grid_for(ncell, 256)), dim3(256), 0, c->stream, c->S, c->P, ncell, dt, (const double*)d_partial);
+  return SZ_OK;
+}
+
+// ---------------------------------------------------------------- output path
+namespace { struct PoolGuard { std::vector<void*> v; ~PoolGuard() { free_pool(v); } }; }
+
+// calc_eulerian_data! (output.jl:793-914) on the rows the context holds (parents and, if the caller ran
+// sz_add_ghosts, ghosts -- write_data! runs after add_ghosts!, simulation.jl:102-105)
+int sz_eulerian_data(sz_ctx* c, int32_t nx, int32_t ny, const double* xg, const double* yg, int32_t nout,
+                     const int32_t* outputs, double* data) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  if (nx < 1 || ny < 1 || !xg || !yg || nout < 0 || (nout > 0 && (!outputs || !data))) return SZ_E_ARG;
+  for (int k = 0; k < nout; k++) if (outputs[k] < 0 || outputs[k] >= EUL_COUNT) { c->err = "unknown grid output"; return SZ_E_ARG; }
+  if (c->S.tiled) { c->err = "sz_eulerian_data: not available on tiled contexts (gather the floes first)"; return SZ_E_STATE; }
+  const double dx = xg[1] - xg[0], dy = yg[1] - yg[0];
+  if (!(dx > 0) || !(dy > 0)) { c->err = "grid lines must ascend"; return SZ_E_ARG; }
+  for (int k = 0; k <= nx; k++) if (fabs(xg[k] - (xg[0] + k * dx)) > 1e-6 * dx) { c->err = "x grid lines must be evenly spaced"; return SZ_E_ARG; }
+  for (int k = 0; k <= ny; k++) if (fabs(yg[k] - (yg[0] + k * dy)) > 1e-6 * dy) { c->err = "y grid lines must be evenly spaced"; return SZ_E_ARG; }
+  (void)hipSetDevice(c->device);
+  int rc = sync_and_check(c);          // hostM current, nothing pending
+  if (rc) return rc;
+  State& S = c->S;
+  const int ncell = nx * ny;
+  PoolGuard pool;
+  EulGrid E{};
+  E.nx = nx; E.ny = ny; E.M = c->hostM > 0 ? c->hostM : 1;
+  double *d_xg, *d_yg;
+  if ((rc = dalloc(c, &d_xg, nx + 1, pool.v)) || (rc = dalloc(c, &d_yg, ny + 1, pool.v)) || (rc = dalloc(c, &E.count, 1, pool.v)) ||
+      (rc = dalloc(c, &E.cell_area, ncell, pool.v)) || (rc = dalloc(c, &E.data, (size_t)EUL_COUNT * ncell, pool.v))) return rc;
+  H2D(d_xg, xg, nx + 1, double); H2D(d_yg, yg, ny + 1, double);
+  E.xg = d_xg; E.yg = d_yg;
+  // entries: count, size, fill, sort
+  hipLaunchKernelGGL(sz_k_eul_entries, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, E, 0);
+  int nent = 0;
+  HIPCHK(c, hipMemcpyAsync(&nent, E.count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (nent < 0) { c->err = "output grid: entry count overflow"; return SZ_E_CAPACITY; }
+  unsigned long long* keys_in = nullptr;
+  E.cap = nent;
+  if ((rc = dalloc(c, &keys_in, nent, pool.v)) || (rc = dalloc(c, &E.keys, nent, pool.v)) || (rc = dalloc(c, &E.pic, nent, pool.v))) return rc;
+  if (nent > 0) {
+    HIPCHK(c, hipMemsetAsync(E.count, 0, sizeof(int), c->stream));
+    EulGrid Ein = E; Ein.keys = keys_in;
+    hipLaunchKernelGGL(sz_k_eul_entries, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, Ein, 1);
+    unsigned long long top = (unsigned long long)ncell * (unsigned long long)E.M;
+    unsigned bits = 1; while (bits < 64 && (top >> bits)) bits++;
+    size_t tmp_bytes = 0; void* tmp = nullptr;
+    HIPCHK(c, rocprim::radix_sort_keys(nullptr, tmp_bytes, keys_in, E.keys, (size_t)nent, 0u, bits, c->stream));
+    char* tmpc = nullptr;
+    if ((rc = dalloc(c, &tmpc, tmp_bytes, pool.v))) return rc;
+    tmp = tmpc;
+    HIPCHK(c, rocprim::radix_sort_keys(tmp, tmp_bytes, keys_in, E.keys, (size_t)nent, 0u, bits, c->stream));
+  }
+  hipLaunchKernelGGL(sz_k_eul_cell_area, dim3(grid_for(ncell, 64 / EU_G, 8192)), dim3(64), 0, c->stream, S, E);
+  if (nent > 0) hipLaunchKernelGGL(sz_k_eul_area, dim3(grid_for(nent, 64 / EU_G, 1 << 16)), dim3(64), 0, c->stream, S, E, nent);
+  hipLaunchKernelGGL(sz_k_eul_reduce, dim3(grid_for(ncell, 64)), dim3(64), 0, c->stream, S, E, nent);
+  for (int k = 0; k < nout; k++)
+    HIPCHK(c, hipMemcpyAsync(data + (size_t)k * ncell, E.data + (size_t)outputs[k] * ncell, (size_t)ncell * sizeof(double),
+                             hipMemcpyDeviceToHost, c->stream));
+  return sync_and_check(c);
+}
+
+// what simplify_floes! (simplification.jl:339-378) would find to do, without downloading a floe
+int sz_simplify_check(sz_ctx* c, int32_t max_vertices, double min_floe_area, double min_floe_height, int64_t* out4) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  if (!out4) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  PoolGuard pool;
+  unsigned long long* d = nullptr;
+  int rc = dalloc(c, &d, 4, pool.v);
+  if (rc) return rc;
+  hipLaunchKernelGGL(sz_k_simplify_check, dim3(grid_for(c->S.capM, 256, 1024)), dim3(256), 0, c->stream, c->S, max_vertices,
+                     min_floe_area, min_floe_height, d);
+  unsigned long long h[4];
+  HIPCHK(c, hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  rc = sync_and_check(c);
+  if (rc) return rc;
+  for (int k = 0; k < 4; k++) out4[k] = (int64_t)h[k];
   return SZ_OK;
 }
 

@@ -345,6 +345,46 @@ class World:
         return np.array([s["warn_height"], s["warn_force"], s["warn_vel"], s["warn_xi"]], _I64)
 
     # ------------------------------------------------------------------ the reference's process API
+    # ------------------------------------------------------------------ output path
+    EUL_OUTPUTS = [
+        "u_grid", "v_grid", "dudt_grid", "dvdt_grid", "overarea_grid", "mass_grid", "area_grid", "height_grid",
+        "si_frac_grid", "stress_xx_grid", "stress_yx_grid", "stress_xy_grid", "stress_yy_grid", "stress_eig_grid",
+        "strain_ux_grid", "strain_vx_grid", "strain_uy_grid", "strain_vy_grid",
+    ]
+
+    def eulerian_data(self, xg, yg, outputs=None):
+        """calc_eulerian_data! (output.jl:793-914) over the rows the context holds: array [len(outputs), nx, ny]
+        (writer.data[ix + 1, iy + 1, k + 1]); outputs: names out of EUL_OUTPUTS (get_known_grid_outputs), default all."""
+        self._push()
+        names = list(self.EUL_OUTPUTS if outputs is None else outputs)
+        for n in names:
+            if n not in self.EUL_OUTPUTS:
+                raise SzError(f"{n} is not a known grid output")
+        codes = np.array([self.EUL_OUTPUTS.index(n) for n in names], _I32)
+        xg = np.ascontiguousarray(xg, np.float64); yg = np.ascontiguousarray(yg, np.float64)
+        nx, ny = len(xg) - 1, len(yg) - 1
+        out = np.zeros((max(len(names), 1), nx, ny))
+        self._chk(self.L.sz_eulerian_data(self.h, nx, ny, capi.ptr(xg), capi.ptr(yg), len(names), capi.ptr(codes, capi._ip),
+                                          capi.ptr(out)))
+        return out[:len(names)]
+
+    def write_grid_data(self, xg, yg, outputs=None):
+        """write_grid_data! as timestep_sim! reaches it (simulation.jl:102-105): ghosts on, averages, ghosts off"""
+        self.add_ghosts()
+        try:
+            return self.eulerian_data(xg, yg, outputs)
+        finally:
+            self.remove_ghosts()
+
+    def simplify_check(self, max_vertices=30, min_floe_area=1e6, min_floe_height=0.1):
+        """counts of what simplify_floes! (simplification.jl:339-378) would act on: remove, fuse, rings over
+        max_vertices, floes under the minimum area / height; all zero = the pass is a no-op"""
+        self._push()
+        out = np.zeros(4, _I64)
+        self._chk(self.L.sz_simplify_check(self.h, int(max_vertices), float(min_floe_area), float(min_floe_height),
+                                           capi.ptr(out, capi._lp)))
+        return dict(zip(("remove", "fuse", "over_max_vertices", "dissolve"), (int(v) for v in out)))
+
     def add_ghosts(self):
         self._push()
         self._chk(self.L.sz_add_ghosts(self.h)); self._host_stale = True
