@@ -247,6 +247,13 @@ enum { SZ_EUL_U = 0, SZ_EUL_V, SZ_EUL_DUDT, SZ_EUL_DVDT, SZ_EUL_OVERAREA, SZ_EUL
        SZ_EUL_STRAIN_UX, SZ_EUL_STRAIN_VX, SZ_EUL_STRAIN_UY, SZ_EUL_STRAIN_VY, SZ_EUL_COUNT };
 int sz_eulerian_data(sz_ctx *ctx, int32_t nx, int32_t ny, const double *xg, const double *yg, int32_t nout,
                      const int32_t *outputs, double *data);
+/* tiled (multi-GPU) runs: a floe and its ghosts count on the rank that owns it.  Every rank calls
+   sz_eulerian_partial (its per-cell sums -> SZ_EUL_PARTIAL * nx * ny doubles in device memory), the host adds the
+   buffers up across the ranks (all-reduce), sz_eulerian_finish turns the sums into the averages on every rank. */
+enum { SZ_EUL_PARTIAL = 17 };
+int sz_eulerian_partial(sz_ctx *ctx, int32_t nx, int32_t ny, const double *xg, const double *yg, void *d_partial);
+int sz_eulerian_finish(sz_ctx *ctx, int32_t nx, int32_t ny, const double *xg, const double *yg, const void *d_partial,
+                       int32_t nout, const int32_t *outputs, double *data);
 int sz_simplify_check(sz_ctx *ctx, int32_t max_vertices, double min_floe_area, double min_floe_height, int64_t *out4);
 
 /* diagnostic build (-DSZ_STAMPS) only: stamp log of one lane group of the narrow phase

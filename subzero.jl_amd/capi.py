@@ -56,10 +56,12 @@ EXPORTS = [
     "sz_timestep_coupling", "sz_timestep_floe_properties", "sz_step",
     "sz_upload_interactions", "sz_calc_stress", "sz_calc_strain",
     "sz_set_two_way", "sz_set_temps", "sz_download_ocean_stress", "sz_two_way_partial", "sz_two_way_finish", "sz_set_precision",
-    "sz_eulerian_data", "sz_simplify_check",
+    "sz_eulerian_data", "sz_eulerian_partial", "sz_eulerian_finish", "sz_simplify_check",
     "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms",
     "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_forcing", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps",
 ]
+
+EUL_PARTIAL = 17      # SZ_EUL_PARTIAL: per-cell partial fields of sz_eulerian_partial
 
 _LIB = None
 
@@ -112,6 +114,8 @@ def load(build_if_missing=True):
     L.sz_two_way_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.sz_download_ocean_stress.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
     L.sz_eulerian_data.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, C.c_int32, _ip, _dp]
+    L.sz_eulerian_partial.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, C.c_void_p]
+    L.sz_eulerian_finish.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, C.c_void_p, C.c_int32, _ip, _dp]
     L.sz_simplify_check.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double, _lp]
     L.sz_upload_interactions.argtypes = [C.c_void_p, _ip, _dp]
     L.sz_calc_stress.argtypes = [C.c_void_p]

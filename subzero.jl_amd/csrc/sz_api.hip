@@ -1150,14 +1150,9 @@ int sz_two_way_finish(sz_ctx* c, const void* d_partial, int32_t dt) {
 // ---------------------------------------------------------------- output path
 namespace { struct PoolGuard { std::vector<void*> v; ~PoolGuard() { free_pool(v); } }; }
 
-// calc_eulerian_data! (output.jl:793-914) on the rows the context holds (parents and, if the caller ran
-// sz_add_ghosts, ghosts -- write_data! runs after add_ghosts!, simulation.jl:102-105)
-int sz_eulerian_data(sz_ctx* c, int32_t nx, int32_t ny, const double* xg, const double* yg, int32_t nout,
-                     const int32_t* outputs, double* data) {
-  if (!c || !c->have_floes) return SZ_E_STATE;
-  if (nx < 1 || ny < 1 || !xg || !yg || nout < 0 || (nout > 0 && (!outputs || !data))) return SZ_E_ARG;
-  for (int k = 0; k < nout; k++) if (outputs[k] < 0 || outputs[k] >= EUL_COUNT) { c->err = "unknown grid output"; return SZ_E_ARG; }
-  if (c->S.tiled) { c->err = "sz_eulerian_data: not available on tiled contexts (gather the floes first)"; return SZ_E_STATE; }
+// shared front of the grid-output calls: argument checks, grid lines to the device, cell areas
+int eul_grid(sz_ctx* c, int32_t nx, int32_t ny, const double* xg, const double* yg, PoolGuard& pool, EulGrid& E) {
+  if (nx < 1 || ny < 1 || !xg || !yg) return SZ_E_ARG;
   const double dx = xg[1] - xg[0], dy = yg[1] - yg[0];
   if (!(dx > 0) || !(dy > 0)) { c->err = "grid lines must ascend"; return SZ_E_ARG; }
   for (int k = 0; k <= nx; k++) if (fabs(xg[k] - (xg[0] + k * dx)) > 1e-6 * dx) { c->err = "x grid lines must be evenly spaced"; return SZ_E_ARG; }
@@ -1165,45 +1160,88 @@ int sz_eulerian_data(sz_ctx* c, int32_t nx, int32_t ny, const double* xg, const 
   (void)hipSetDevice(c->device);
   int rc = sync_and_check(c);          // hostM current, nothing pending
   if (rc) return rc;
-  State& S = c->S;
   const int ncell = nx * ny;
-  PoolGuard pool;
-  EulGrid E{};
+  E = EulGrid{};
   E.nx = nx; E.ny = ny; E.M = c->hostM > 0 ? c->hostM : 1;
   double *d_xg, *d_yg;
   if ((rc = dalloc(c, &d_xg, nx + 1, pool.v)) || (rc = dalloc(c, &d_yg, ny + 1, pool.v)) || (rc = dalloc(c, &E.count, 1, pool.v)) ||
       (rc = dalloc(c, &E.cell_area, ncell, pool.v)) || (rc = dalloc(c, &E.data, (size_t)EUL_COUNT * ncell, pool.v))) return rc;
   H2D(d_xg, xg, nx + 1, double); H2D(d_yg, yg, ny + 1, double);
   E.xg = d_xg; E.yg = d_yg;
-  // entries: count, size, fill, sort
+  hipLaunchKernelGGL(sz_k_eul_cell_area, dim3(grid_for(ncell, 64 / EU_G, 8192)), dim3(64), 0, c->stream, c->S, E);
+  return SZ_OK;
+}
+// entries (count, size, fill, sort) and the area of every entry
+int eul_entries(sz_ctx* c, PoolGuard& pool, EulGrid& E, int& nent) {
+  State& S = c->S;
+  int rc;
   hipLaunchKernelGGL(sz_k_eul_entries, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, E, 0);
-  int nent = 0;
+  nent = 0;
   HIPCHK(c, hipMemcpyAsync(&nent, E.count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (nent < 0) { c->err = "output grid: entry count overflow"; return SZ_E_CAPACITY; }
   unsigned long long* keys_in = nullptr;
   E.cap = nent;
   if ((rc = dalloc(c, &keys_in, nent, pool.v)) || (rc = dalloc(c, &E.keys, nent, pool.v)) || (rc = dalloc(c, &E.pic, nent, pool.v))) return rc;
-  if (nent > 0) {
-    HIPCHK(c, hipMemsetAsync(E.count, 0, sizeof(int), c->stream));
-    EulGrid Ein = E; Ein.keys = keys_in;
-    hipLaunchKernelGGL(sz_k_eul_entries, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, Ein, 1);
-    unsigned long long top = (unsigned long long)ncell * (unsigned long long)E.M;
-    unsigned bits = 1; while (bits < 64 && (top >> bits)) bits++;
-    size_t tmp_bytes = 0; void* tmp = nullptr;
-    HIPCHK(c, rocprim::radix_sort_keys(nullptr, tmp_bytes, keys_in, E.keys, (size_t)nent, 0u, bits, c->stream));
-    char* tmpc = nullptr;
-    if ((rc = dalloc(c, &tmpc, tmp_bytes, pool.v))) return rc;
-    tmp = tmpc;
-    HIPCHK(c, rocprim::radix_sort_keys(tmp, tmp_bytes, keys_in, E.keys, (size_t)nent, 0u, bits, c->stream));
-  }
-  hipLaunchKernelGGL(sz_k_eul_cell_area, dim3(grid_for(ncell, 64 / EU_G, 8192)), dim3(64), 0, c->stream, S, E);
-  if (nent > 0) hipLaunchKernelGGL(sz_k_eul_area, dim3(grid_for(nent, 64 / EU_G, 1 << 16)), dim3(64), 0, c->stream, S, E, nent);
-  hipLaunchKernelGGL(sz_k_eul_reduce, dim3(grid_for(ncell, 64)), dim3(64), 0, c->stream, S, E, nent);
+  if (nent == 0) return SZ_OK;
+  HIPCHK(c, hipMemsetAsync(E.count, 0, sizeof(int), c->stream));
+  EulGrid Ein = E; Ein.keys = keys_in;
+  hipLaunchKernelGGL(sz_k_eul_entries, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, Ein, 1);
+  unsigned long long top = (unsigned long long)E.nx * E.ny * (unsigned long long)E.M;
+  unsigned bits = 1; while (bits < 64 && (top >> bits)) bits++;
+  size_t tmp_bytes = 0;
+  HIPCHK(c, rocprim::radix_sort_keys(nullptr, tmp_bytes, keys_in, E.keys, (size_t)nent, 0u, bits, c->stream));
+  char* tmp = nullptr;
+  if ((rc = dalloc(c, &tmp, tmp_bytes, pool.v))) return rc;
+  HIPCHK(c, rocprim::radix_sort_keys((void*)tmp, tmp_bytes, keys_in, E.keys, (size_t)nent, 0u, bits, c->stream));
+  hipLaunchKernelGGL(sz_k_eul_area, dim3(grid_for(nent, 64 / EU_G, 1 << 16)), dim3(64), 0, c->stream, S, E, nent);
+  return SZ_OK;
+}
+int eul_check_outputs(sz_ctx* c, int32_t nout, const int32_t* outputs, const double* data) {
+  if (nout < 0 || (nout > 0 && (!outputs || !data))) return SZ_E_ARG;
+  for (int k = 0; k < nout; k++) if (outputs[k] < 0 || outputs[k] >= EUL_COUNT) { c->err = "unknown grid output"; return SZ_E_ARG; }
+  return SZ_OK;
+}
+int eul_copy_out(sz_ctx* c, const EulGrid& E, int32_t nout, const int32_t* outputs, double* data) {
+  const size_t ncell = (size_t)E.nx * E.ny;
   for (int k = 0; k < nout; k++)
-    HIPCHK(c, hipMemcpyAsync(data + (size_t)k * ncell, E.data + (size_t)outputs[k] * ncell, (size_t)ncell * sizeof(double),
-                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(data + (size_t)k * ncell, E.data + (size_t)outputs[k] * ncell, ncell * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   return sync_and_check(c);
+}
+
+// calc_eulerian_data! (output.jl:793-914) on the rows the context holds (parents and, if the caller ran
+// sz_add_ghosts, ghosts -- write_data! runs after add_ghosts!, simulation.jl:102-105)
+int sz_eulerian_data(sz_ctx* c, int32_t nx, int32_t ny, const double* xg, const double* yg, int32_t nout,
+                     const int32_t* outputs, double* data) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  int rc = eul_check_outputs(c, nout, outputs, data);
+  if (rc) return rc;
+  if (c->S.tiled) { c->err = "tiled contexts: sz_eulerian_partial, all-reduce, sz_eulerian_finish"; return SZ_E_STATE; }
+  PoolGuard pool; EulGrid E; int nent = 0;
+  if ((rc = eul_grid(c, nx, ny, xg, yg, pool, E)) || (rc = eul_entries(c, pool, E, nent))) return rc;
+  hipLaunchKernelGGL(sz_k_eul_reduce, dim3(grid_for(nx * ny, 64)), dim3(64), 0, c->stream, c->S, E, nent);
+  return eul_copy_out(c, E, nout, outputs, data);
+}
+// tiled runs, first half: this rank's per-cell sums into d_partial (SZ_EUL_PARTIAL * nx * ny doubles on the device)
+int sz_eulerian_partial(sz_ctx* c, int32_t nx, int32_t ny, const double* xg, const double* yg, void* d_partial) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  if (!d_partial) return SZ_E_ARG;
+  PoolGuard pool; EulGrid E; int nent = 0, rc;
+  if ((rc = eul_grid(c, nx, ny, xg, yg, pool, E)) || (rc = eul_entries(c, pool, E, nent))) return rc;
+  hipLaunchKernelGGL(sz_k_eul_partial, dim3(grid_for(nx * ny, 64)), dim3(64), 0, c->stream, c->S, E, nent, (double*)d_partial);
+  return sync_and_check(c);
+}
+// second half: the summed buffer -> the averages
+int sz_eulerian_finish(sz_ctx* c, int32_t nx, int32_t ny, const double* xg, const double* yg, const void* d_partial, int32_t nout,
+                       const int32_t* outputs, double* data) {
+  if (!c || !c->have_floes) return SZ_E_STATE;
+  if (!d_partial) return SZ_E_ARG;
+  int rc = eul_check_outputs(c, nout, outputs, data);
+  if (rc) return rc;
+  PoolGuard pool; EulGrid E;
+  if ((rc = eul_grid(c, nx, ny, xg, yg, pool, E))) return rc;
+  hipLaunchKernelGGL(sz_k_eul_finish, dim3(grid_for(nx * ny, 64)), dim3(64), 0, c->stream, E, (const double*)d_partial);
+  return eul_copy_out(c, E, nout, outputs, data);
 }
 
 // what simplify_floes! (simplification.jl:339-378) would find to do, without downloading a floe

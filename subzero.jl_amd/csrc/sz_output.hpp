@@ -235,6 +235,53 @@ __global__ void sz_k_eul_reduce(State S, EulGrid E, int nent) {
   }
 }
 
+// tiled runs: a floe (and its ghosts) lives on the rank that owns it, so every rank sums what its floes put into
+// each cell -- area, mass, entry count, overarea and the 13 weighted sums, EUL_PARTIAL fields per cell, field-major
+// -- the host adds the buffers up across the ranks (all-reduce) and every rank finishes the cells.  The weights are
+// the reference's ma_ratios with the division by the cell's mass moved to the end (the same numbers up to round-off).
+constexpr int EUL_PARTIAL = 17;
+__global__ void sz_k_eul_partial(State S, EulGrid E, int nent, double* partial) {
+  const int ncell = E.nx * E.ny, N = S.cnt[C_N];
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < ncell; q += gridDim.x * blockDim.x) {
+    double s[EUL_PARTIAL];
+    for (int k = 0; k < EUL_PARTIAL; k++) s[k] = 0.0;
+    const unsigned long long base = (unsigned long long)q * (unsigned long long)E.M;
+    const int lo = eul_lower_bound(E.keys, nent, base), hi = eul_lower_bound(E.keys, nent, base + (unsigned long long)E.M);
+    for (int t = lo; t < hi; t++) {
+      const double a = E.pic[t];
+      if (!(a > 0)) continue;
+      const int i = (int)(E.keys[t] - base);
+      const int p = i < N ? i : S.parent[i];
+      const double r = S.mass[i] * (a / S.area[i]);
+      s[0] += a; s[1] += r; s[2] += 1.0; s[3] += S.overarea[i];
+      s[4] += S.u[i] * r; s[5] += S.v[i] * r; s[6] += S.p_dudt[p] * r; s[7] += S.p_dvdt[p] * r; s[8] += S.height[i] * r;
+      for (int c = 0; c < 4; c++) { s[9 + c] += S.sa[4 * p + c] * r; s[13 + c] += S.strain[4 * p + c] * r; }
+    }
+    for (int k = 0; k < EUL_PARTIAL; k++) partial[(size_t)k * ncell + q] = s[k];
+  }
+}
+__global__ void sz_k_eul_finish(EulGrid E, const double* partial) {
+  const int ncell = E.nx * E.ny;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < ncell; q += gridDim.x * blockDim.x) {
+    double s[EUL_COUNT];
+    for (int k = 0; k < EUL_COUNT; k++) s[k] = 0.0;
+    const double cell_area = E.cell_area[q];
+    const double area_tot = partial[q], mass_tot = partial[(size_t)ncell + q], cnt = partial[2 * (size_t)ncell + q];
+    if (cell_area > 0 && mass_tot > 0) {
+      auto w = [&](int f) { return partial[(size_t)f * ncell + q] / mass_tot; };
+      s[0] = w(4); s[1] = w(5); s[2] = w(6); s[3] = w(7); s[7] = w(8);
+      s[9] = w(9); s[10] = w(10); s[11] = w(11); s[12] = w(12);
+      s[14] = w(13); s[15] = w(14); s[16] = w(15); s[17] = w(16);
+      s[4] = partial[3 * (size_t)ncell + q] / cnt; s[5] = mass_tot; s[6] = area_tot; s[8] = area_tot / cell_area;
+      const double hm = 0.5 * (s[9] + s[12]), hd = 0.5 * (s[9] - s[12]);
+      double e = hm + sqrt(hd * hd + s[11] * s[10]);
+      if (fabs(e) > 1e8) e = 0.0;
+      s[13] = e;
+    }
+    for (int k = 0; k < EUL_COUNT; k++) E.data[(size_t)k * ncell + q] = s[k];
+  }
+}
+
 // simplify_floes! has work if any of these is non-zero: floes tagged remove, tagged fuse, rings with more than
 // max_vertices points (GI.npoint counts the closing point, simplification.jl:66), floes not tagged remove under
 // the minimum area / height (:287-290)

@@ -203,6 +203,34 @@ class TiledWorld:
                 self.dist.all_reduce(self.tw_buf)
         w._chk(w.L.sz_two_way_finish(w.h, C.c_void_p(self.tw_buf.data_ptr()), int(dt)))
 
+    # ---- grid output across tiles
+    def write_grid_data(self, xg, yg, outputs=None):
+        """write_grid_data! (output.jl:588-605) in a tiled run: every rank sums what its own floes and their ghosts
+        put into each output cell, one all-reduce adds the partial fields up, every rank finishes the averages
+        (array [len(outputs), nx, ny] on every rank, as World.write_grid_data gives it)."""
+        w, torch = self.world, self.torch
+        names = list(w.EUL_OUTPUTS if outputs is None else outputs)
+        codes = np.array([w.EUL_OUTPUTS.index(n) for n in names], np.int32)
+        xg = np.ascontiguousarray(xg, np.float64); yg = np.ascontiguousarray(yg, np.float64)
+        nx, ny = len(xg) - 1, len(yg) - 1
+        buf = torch.zeros(capi.EUL_PARTIAL * nx * ny, dtype=torch.float64, device=self.dev)
+        self.sync()
+        w.add_ghosts()
+        try:
+            w._chk(w.L.sz_eulerian_partial(w.h, nx, ny, capi.ptr(xg), capi.ptr(yg), C.c_void_p(buf.data_ptr())))
+        finally:
+            w.remove_ghosts()
+        if self.nranks > 1:
+            if self.host_staging:
+                hb = buf.cpu(); self.dist.all_reduce(hb); buf.copy_(hb)
+            else:
+                self.dist.all_reduce(buf)
+            torch.cuda.synchronize()
+        out = np.zeros((max(len(names), 1), nx, ny))
+        w._chk(w.L.sz_eulerian_finish(w.h, nx, ny, capi.ptr(xg), capi.ptr(yg), C.c_void_p(buf.data_ptr()), len(names),
+                                      capi.ptr(codes, capi._ip), capi.ptr(out)))
+        return out[:len(names)]
+
     # ---- migration (SURVEY.md §8e, step 3): rare, host-side
     def repartition(self, owner_fn=None):
         """Re-assign every floe to the tile its centroid lies in now and move the floes that changed tile to

@@ -119,7 +119,9 @@ def _worker_two_way(rank, world, port, n, seed, steps, q):
         tw.set_two_way(0.5, -8.0, cfg["dt"])
         tw.run(steps, 0, cfg["dt"], coupling_dt=2)
         tw.sync()
-        q.put((rank, tw.gidx, {f: tw.owned(f) for f in ("cx", "cy", "u", "v", "xi", "height")}, [a.copy() for a in tw.world.ocean_stress()]))
+        L = cfg["L"]
+        grid = tw.write_grid_data(np.linspace(0, L, 13), np.linspace(0, L, 10))      # GridOutputWriter averages across the tiles
+        q.put((rank, tw.gidx, {f: tw.owned(f) for f in ("cx", "cy", "u", "v", "xi", "height")}, [a.copy() for a in tw.world.ocean_stress()], grid))
     finally:
         dist.destroy_process_group()
 
@@ -151,7 +153,14 @@ def test_two_way_coupling_across_tiles():
     hw.set_two_way(True, dt=cfg["dt"]); hw.set_temps(0.5, -8.0)
     hw.run(steps, 0, cfg["dt"], coupling_dt=2)
     ref = hw.ocean_stress()
-    for rank, gidx, out, fields_ in res:
+    L = cfg["L"]
+    gref = hw.write_grid_data(np.linspace(0, L, 13), np.linspace(0, L, 10))
+    assert np.count_nonzero(gref[6]) > 60
+    for rank, gidx, out, fields_, grid in res:
+        # every rank holds the full grid output; the cross-rank sums differ from the serial ones by round-off only
+        for k in range(len(gref)):
+            scale = max(np.abs(gref[j]).max() for j in (range(9, 13) if 9 <= k <= 13 else range(14, 18) if k >= 14 else (k,)))
+            assert np.abs(grid[k] - gref[k]).max() <= 1e-11 * scale, (rank, k)
         for name, g, r in zip(("tau_x", "tau_y", "si_frac", "hflx"), fields_, ref):
             assert np.max(np.abs(g - r)) <= 1e-12 * max(np.max(np.abs(r)), 1e-300), (rank, name)
         for f, v in out.items():
