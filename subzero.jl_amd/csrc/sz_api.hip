@@ -30,6 +30,15 @@ constexpr int K_NARROW_LARGE = SZ_K_COUNT;
 
 struct EvPair { int k; hipEvent_t a, b; };
 
+// Device allocations of one lifetime.  The ~130 columns and work arrays are carved out of a few large chunks
+// instead of one hipMalloc each: the chunks are mapped with 2 MB fragments, so a kernel that walks 60 columns
+// needs a handful of TLB entries instead of several per column.
+struct Pool {
+  std::vector<void*> chunks; char* cur = nullptr; size_t left = 0, next = 8u << 20;
+  bool empty() const { return chunks.empty(); }
+  void push_back(void* q) { chunks.push_back(q); }      // a stand-alone allocation handed to the pool
+};
+
 }  // namespace
 
 struct sz_ctx {
@@ -41,9 +50,9 @@ struct sz_ctx {
   State S{};
   Params P{};
   std::string err;
-  std::vector<void*> allocs;        // per-upload allocations
-  std::vector<void*> static_allocs; // domain element table
-  std::vector<void*> field_allocs;  // ocean / atmosphere lattices
+  Pool allocs;        // per-upload allocations
+  Pool static_allocs; // domain element table
+  Pool field_allocs;  // ocean / atmosphere lattices
   bool have_floes = false, have_domain = false, have_fields = false;
   int hostM = 0, hostN = 0;
   // element table (host copy, rebuilt on set_domain / set_topography)
@@ -64,10 +73,10 @@ struct sz_ctx {
   int max_ring = 0, max_elem_ring = 5, max_ring_tiled = 0;   // largest ring sizes (host knowledge: which narrow variants can be needed)
   int narrow_grid0 = 0;
   // mixed precision (sz_set_precision): fp32 copies for the forcing kernel, rebuilt when their sources change
-  int precision = 0; bool mixed_pts_ok = false, mixed_nodes_ok = false; std::vector<void*> mixed_pt_allocs, mixed_node_allocs;
+  int precision = 0; bool mixed_pts_ok = false, mixed_nodes_ok = false; Pool mixed_pt_allocs, mixed_node_allocs;
   // two-way coupling (off by default, like CouplingSettings())
   bool two_way = false; int tw_dt = 10; int tw_capM = 0; size_t tw_ncell = 0;
-  std::vector<void*> tw_allocs, tw_field_allocs;
+  Pool tw_allocs, tw_field_allocs;
   // static broad-phase grid of the resident steps (fixed by the host: no bounds reduction per step)
   bool fuse_forcing = true;         // forcings inside the neighbour launch (sz_k_neighbors_forcing); SZ_FUSE_FORCING=0: own launch
   bool fused_move = true;           // integrate + move/strain in one thread-per-floe launch when rings are small (-2 us at 10k); SZ_FUSED_MOVE=0: two launches
@@ -92,16 +101,21 @@ namespace {
   } while (0)
 
 template <typename T>
-int dalloc(sz_ctx* c, T** p, size_t n, std::vector<void*>& pool) {
-  void* q = nullptr;
-  size_t bytes = (n ? n : 1) * sizeof(T);
-  HIPCHK(c, hipMalloc(&q, bytes));
+int dalloc(sz_ctx* c, T** p, size_t n, Pool& pool) {
+  const size_t bytes = (((n ? n : 1) * sizeof(T)) + 255) & ~(size_t)255;
+  if (bytes > pool.left) {
+    const size_t chunk = std::max(bytes, pool.next);
+    void* q = nullptr;
+    HIPCHK(c, hipMalloc(&q, chunk));
+    pool.chunks.push_back(q); pool.cur = (char*)q; pool.left = chunk;
+    if (pool.next < ((size_t)256 << 20)) pool.next *= 2;
+  }
+  void* q = pool.cur; pool.cur += bytes; pool.left -= bytes;
   HIPCHK(c, hipMemsetAsync(q, 0, bytes, c->stream));
-  pool.push_back(q);
   *p = (T*)q;
   return SZ_OK;
 }
-void free_pool(std::vector<void*>& pool) { for (void* p : pool) (void)hipFree(p); pool.clear(); }
+void free_pool(Pool& pool) { for (void* p : pool.chunks) (void)hipFree(p); pool.chunks.clear(); pool.cur = nullptr; pool.left = 0; pool.next = 8u << 20; }
 
 inline int grid_for(long long n, int tpb, int maxb = 4096) {
   long long b = (n + tpb - 1) / tpb;
@@ -1148,7 +1162,7 @@ int sz_two_way_finish(sz_ctx* c, const void* d_partial, int32_t dt) {
 }
 
 // ---------------------------------------------------------------- output path
-namespace { struct PoolGuard { std::vector<void*> v; ~PoolGuard() { free_pool(v); } }; }
+namespace { struct PoolGuard { Pool v; PoolGuard() { v.next = 2u << 20; } ~PoolGuard() { free_pool(v); } }; }
 
 // shared front of the grid-output calls: argument checks, grid lines to the device, cell areas
 int eul_grid(sz_ctx* c, int32_t nx, int32_t ny, const double* xg, const double* yg, PoolGuard& pool, EulGrid& E) {
