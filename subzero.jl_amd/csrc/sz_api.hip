@@ -288,11 +288,13 @@ void use_static_grid(sz_ctx* c) {
 // bounds kernel follows); otherwise the bounds kernel (in_step) or a commit launch does
 void stage_ghosts(sz_ctx* c, bool in_step = false, bool commit = false) {
   State& S = c->S;
+  // the parents' count is the host's in resident single-context steps (nothing creates or removes floes there)
+  const int nh = in_step && !S.tiled ? c->hostN : -1;
   if (!S.any_periodic_ew && !S.any_periodic_ns) return;
   Timed t(c, SZ_K_GHOSTS);
   const int nb = grid_for(S.capM, SCAN_B, 1 << 20);
-  hipLaunchKernelGGL(sz_k_ghost_flag_scan, dim3(nb), dim3(SCAN_B), 0, c->stream, S, in_step ? 1 : 0, commit ? 1 : 0, next_epoch(c));
-  hipLaunchKernelGGL(sz_k_ghost_fill, dim3(grid_for(S.capM, 32, 2048)), dim3(256), 0, c->stream, S, commit ? 1 : 0, commit ? 1 : 0);
+  hipLaunchKernelGGL(sz_k_ghost_flag_scan, dim3(nb), dim3(SCAN_B), 0, c->stream, S, in_step ? 1 : 0, commit ? 1 : 0, next_epoch(c), nh);
+  hipLaunchKernelGGL(sz_k_ghost_fill, dim3(grid_for(S.capM, 32, 2048)), dim3(256), 0, c->stream, S, commit ? 1 : 0, commit ? 1 : 0, nh);
   if (!in_step) hipLaunchKernelGGL(sz_k_ghost_commit, dim3(1), dim3(64), 0, c->stream, S);
   t.end();
 }
@@ -473,15 +475,16 @@ void stage_forcing(sz_ctx* c, int dt = -1) {      // in-order variant (process m
   t.end();
 }
 void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool bin = false) {
+  const int nh = bin && !c->S.tiled ? c->hostN : -1;     // resident single-context steps: the host knows the count
   // the guard counters describe the last timestep_floe_properties! call (inside a step the
   // ghost-removal kernel has already cleared them)
   if (reset_guards) (void)hipMemsetAsync(c->S.cnt + C_WARN_H, 0, 4 * sizeof(int), c->stream);
   Timed t(c, SZ_K_INTEGRATE);
   // resident steps with small rings: one launch (thread per floe) integrates, moves the ring and bins the floe
   if (bin && c->max_ring <= MV_RING && c->fused_move) {
-    hipLaunchKernelGGL(sz_k_integrate<true>, dim3(grid_for(c->S.capM, 128)), dim3(128), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 1);
+    hipLaunchKernelGGL(sz_k_integrate<true>, dim3(grid_for(c->S.capM, 128)), dim3(128), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 1, nh);
   } else {
-    hipLaunchKernelGGL(sz_k_integrate<false>, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 0);
+    hipLaunchKernelGGL(sz_k_integrate<false>, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 0, nh);
     hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 0, bin ? 1 : 0);
   }
   if (!bin) c->grid_live = false;          // floes moved without re-binning: the resident steps' cell lists are stale

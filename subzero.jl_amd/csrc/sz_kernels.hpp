@@ -299,9 +299,11 @@ __device__ __forceinline__ int4 ghost_plan(State& S, int i, int N, int drop_old,
 // flag kernel + the whole int4 scan of the plan in one launch (look-back scan).  commit (resident steps, always
 // with drop_old): the thread that sees the totals also commits the new counts (ghost_commit below), so that no
 // single-workgroup launch has to follow the fill kernel; the fill kernel then takes its base from C_N.
-__global__ void __launch_bounds__(SCAN_B) sz_k_ghost_flag_scan(State S, int drop_old, int commit, unsigned epoch) {
+// nh: the number of parents when the host knows it (resident steps: it never changes) -- the first loads then do
+// not wait for the counter block; < 0: read it
+__global__ void __launch_bounds__(SCAN_B) sz_k_ghost_flag_scan(State S, int drop_old, int commit, unsigned epoch, int nh) {
   __shared__ int4 tot;
-  const int n = S.cnt[C_N];
+  const int n = nh >= 0 ? nh : S.cnt[C_N];
   const int base = blockIdx.x * SCAN_B;
   if (base >= n && blockIdx.x != 0) return;          // tiles past the end: nobody waits for them
   const int i = base + threadIdx.x;
@@ -352,26 +354,35 @@ __device__ __forceinline__ void rig_store(State& S, int lane, int f, int vo, int
 }
 
 // gscan4 holds the exclusive int4 scan of gplan, gtot4[0] the totals
-__global__ void __launch_bounds__(256) sz_k_ghost_fill(State S, int committed, int bin) {
+__global__ void __launch_bounds__(256) sz_k_ghost_fill(State S, int committed, int bin, int nh) {
   const GridGeo geo = grid_geo(S);
-  int N = S.cnt[C_N], M0 = committed ? N : S.cnt[C_M], NV0 = committed ? S.voff[N] : S.cnt[C_NV];
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int N = nh >= 0 ? nh : S.cnt[C_N];
+  // the first chunk's flags are asked for together with the totals (one round trip, not two)
+  int flm0 = 5;
+  {
+    unsigned np2 = 1; while ((int)np2 < N) np2 <<= 1;
+    const unsigned qv = (unsigned)(wave * 8 + lane);
+    const int mine = (int)((qv * 0x9E3779B1u) & (np2 - 1));
+    if (lane < 8 && qv < np2 && mine < N) flm0 = S.gflag[mine];
+  }
+  const int M0 = committed ? N : S.cnt[C_M], NV0 = committed ? S.voff[N] : S.cnt[C_NV];
   int4 T = S.gtot4[0];
   if (M0 + T.x + T.z > S.capM) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
   if (NV0 + T.y + T.w > S.capV) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); return; }
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   // chunk c looks at parents c, c + nchunks, c + 2 nchunks, ..: floes near one wall have consecutive
   // indices, striding spreads them over the wavefronts
   // Only GH_CH parents per wavefront visit, taken in a scattered order (multiplicative permutation of
   // [0, 2^k)): flagged parents are a few per cent but sit in rows/columns of the index space, and a
   // wavefront works its flagged parents off one after the other.
-  constexpr int GH_CH = 8;
+  constexpr int GH_CH = 8;                 // (the prefetch above assumes 8)
   unsigned np2 = 1; while ((int)np2 < N) np2 <<= 1;
   const int nchunks = (int)(np2 / GH_CH) > 0 ? (int)(np2 / GH_CH) : 1;
   for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
     unsigned qv = (unsigned)(chunk * GH_CH + lane);
     int mine = (int)((qv * 0x9E3779B1u) & (np2 - 1));
-    int flm = (lane < GH_CH && qv < np2 && mine < N) ? S.gflag[mine] : 5;          // 5 = (0+1) | (0+1)<<2: no ghost
+    int flm = chunk == wave ? flm0 : ((lane < GH_CH && qv < np2 && mine < N) ? S.gflag[mine] : 5);   // 5 = (0+1) | (0+1)<<2: no ghost
     unsigned long long todo = __ballot(flm != 5);
     while (todo) {
       int src_lane = __ffsll((long long)todo) - 1;
@@ -1327,9 +1338,9 @@ __global__ void sz_k_calc_stress(State S, Params P) {
 // are the same expressions summed in the same order.
 constexpr int MV_RING = 20;
 template <bool MOVE>
-__global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Params P, int dt, int apply_frc, int bin) {
+__global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Params P, int dt, int apply_frc, int bin, int nh) {
   const GridGeo geo = grid_geo(S);
-  int N = S.cnt[C_NOWN];
+  const int N = nh >= 0 ? nh : S.cnt[C_NOWN];     // nh: see sz_k_ghost_flag_scan
   int wh = 0, wf = 0, wv = 0, wx = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
     // Memory order is the whole cost of this kernel (a store in between keeps the compiler from hoisting the
