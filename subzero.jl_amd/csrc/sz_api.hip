@@ -478,7 +478,7 @@ void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool 
   const int nh = bin && !c->S.tiled ? c->hostN : -1;     // resident single-context steps: the host knows the count
   // the guard counters describe the last timestep_floe_properties! call (inside a step the
   // ghost-removal kernel has already cleared them)
-  if (reset_guards) (void)hipMemsetAsync(c->S.cnt + C_WARN_H, 0, 4 * sizeof(int), c->stream);
+  if (reset_guards) (void)hipMemsetAsync(c->S.warn, 0, (size_t)WARN_SLOTS * 32 * sizeof(int), c->stream);
   Timed t(c, SZ_K_INTEGRATE);
   // resident steps with small rings: one launch (thread per floe) integrates, moves the ring and bins the floe
   if (bin && c->max_ring <= MV_RING && c->fused_move) {
@@ -549,7 +549,7 @@ sz_ctx* sz_create(int device_id) {
   P.fcor = 1.4e-4; P.turn = 15.0 * 3.14159265358979323846 / 180.0; P.ff_max_overlap = 0.55; P.fd_max_overlap = 0.75;
   P.rho_i = 920.0; P.max_h = 10.0; P.max_xi = 1e-5; P.lambda = 0.2; P.dd = 1;
   P.Cd_ao = 1.25e-3; P.k_ice = 2.14; P.L_ice = 2.93e5;
-  if (hipMalloc((void**)&c->d_stats, 8 * sizeof(long long)) != hipSuccess) { delete c; return nullptr; }
+  if (hipMalloc((void**)&c->d_stats, 12 * sizeof(long long)) != hipSuccess) { delete c; return nullptr; }
   return c;
 }
 
@@ -648,7 +648,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   S.capRows = S.capPairs * 3 + S.capElem * 2; S.capCells = 4 * S.capM + 64; S.capS = NS;
   int rc;
 #define DA(field, n) if ((rc = dalloc(c, &S.field, (size_t)(n), c->allocs))) return rc
-  DA(cnt, C_COUNT + 64);
+  DA(cnt, C_COUNT + 64); DA(warn, WARN_SLOTS * 32);
   double** dcols[] = { &S.cx, &S.cy, &S.rmax, &S.area, &S.height, &S.mass, &S.moment, &S.alpha, &S.u, &S.v, &S.xi,
                        &S.p_dxdt, &S.p_dydt, &S.p_dalphadt, &S.p_dudt, &S.p_dvdt, &S.p_dxidt, &S.fxOA, &S.fyOA, &S.trqOA,
                        &S.hflx, &S.overarea, &S.cfx, &S.cfy, &S.ctrq };
@@ -719,9 +719,9 @@ int sz_get_stats(sz_ctx* c, sz_stats* out) {
   (void)hipSetDevice(c->device);
   tile_cleanup(c);
   State& S = c->S;
-  HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(long long), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 12 * sizeof(long long), c->stream));
   hipLaunchKernelGGL(sz_k_stats, dim3(grid_for((long long)S.capPairs + S.capElem, 256, 1024)), dim3(256), 0, c->stream, S, c->d_stats);
-  int h[C_COUNT]; long long st[8];
+  int h[C_COUNT]; long long st[12];
   HIPCHK(c, hipMemcpyAsync(st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(h, S.cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -730,7 +730,7 @@ int sz_get_stats(sz_ctx* c, sz_stats* out) {
   out->M = h[C_M]; out->N = h[C_N]; out->n_ring_points = h[C_NV]; out->n_sub_points = soffN;
   out->n_pairs = h[C_NPAIRS]; out->n_pair_ring_points = st[0]; out->n_pair_rows = st[1];
   out->n_elem_items = h[C_NELEM]; out->n_elem_rows = st[2]; out->n_inter_rows = st[3]; out->n_ghosts = h[C_NGHOSTS];
-  out->warn_height = h[C_WARN_H]; out->warn_force = h[C_WARN_F]; out->warn_vel = h[C_WARN_V]; out->warn_xi = h[C_WARN_XI];
+  out->warn_height = st[6]; out->warn_force = st[7]; out->warn_vel = st[8]; out->warn_xi = st[9];
   out->n_trace_fail = h[C_TRACE_FAIL];
   out->n_halo = h[C_NHALO];
   out->n_pairs_clipped = h[C_NWORK];
@@ -1165,7 +1165,7 @@ int sz_two_way_finish(sz_ctx* c, const void* d_partial, int32_t dt) {
 }
 
 // ---------------------------------------------------------------- output path
-namespace { struct PoolGuard { Pool v; PoolGuard() { v.next = 2u << 20; } ~PoolGuard() { free_pool(v); } }; }
+namespace { struct PoolGuard { Pool v; PoolGuard() { v.next = 1u << 16; } ~PoolGuard() { free_pool(v); } }; }
 
 // shared front of the grid-output calls: argument checks, grid lines to the device, cell areas
 int eul_grid(sz_ctx* c, int32_t nx, int32_t ny, const double* xg, const double* yg, PoolGuard& pool, EulGrid& E) {

@@ -475,6 +475,7 @@ __global__ void sz_k_remove_ghosts(State S, int drop_halo) {
 __global__ void __launch_bounds__(1024) sz_k_bounds(State S, int commit_ghosts) {
   __shared__ double sh[5][16];
   __shared__ int s_ncells;
+  if (threadIdx.x < WARN_SLOTS * 4) S.warn[(threadIdx.x >> 2) * 32 + (threadIdx.x & 3)] = 0;   // guards of the coming update
   if (commit_ghosts) {
     if (threadIdx.x == 0) ghost_commit(S);
     __syncthreads();
@@ -516,7 +517,6 @@ __global__ void __launch_bounds__(1024) sz_k_bounds(State S, int commit_ghosts) 
       cs *= 2.0;
     }
     S.cnt[C_ITEMCLASS] = 0;                              // narrow-phase size classes of this step
-    S.cnt[C_WARN_H] = 0; S.cnt[C_WARN_F] = 0; S.cnt[C_WARN_V] = 0; S.cnt[C_WARN_XI] = 0;   // guards of the coming update
     S.bounds[0] = x0; S.bounds[1] = y0; S.bounds[2] = cs; S.bounds[3] = cs; S.bounds[4] = (double)ncx; S.bounds[5] = (double)ncy;
     S.bounds[6] = 0.0; S.bounds[7] = 0.0;       // a grid fitted to the centroids neither wraps nor clamps
     S.cnt[C_NCELLS] = (int)(ncx * ncy);
@@ -664,10 +664,8 @@ __global__ void __launch_bounds__(SCAN_B) sz_k_pscan_fill(State S, unsigned epoc
     const int nlive = (n + SCAN_B - 1) / SCAN_B > 0 ? (n + SCAN_B - 1) / SCAN_B : 1;      // workgroups that do not return below
     if ((int)blockIdx.x < nlive) for (int q = base + threadIdx.x; q <= ncells; q += nlive * SCAN_B) S.cell_cnt[q] = 0;
     if (blockIdx.x == 0 && threadIdx.x < 8) S.wq[threadIdx.x * 32] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      S.cnt[C_ITEMCLASS] = 0;
-      S.cnt[C_WARN_H] = 0; S.cnt[C_WARN_F] = 0; S.cnt[C_WARN_V] = 0; S.cnt[C_WARN_XI] = 0;
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) S.cnt[C_ITEMCLASS] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < WARN_SLOTS * 4) S.warn[(threadIdx.x >> 2) * 32 + (threadIdx.x & 3)] = 0;
   }
   if (base >= n && blockIdx.x != 0) return;
   const int i = base + threadIdx.x;
@@ -1449,14 +1447,16 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
       if (bin) cell_insert(S, geo, i, ncx, ncy);
     }
   }
-  // one atomic per wavefront and counter: with the guards firing for most floes, a same-address atomic per thread
-  // serialises in one L2 channel (100k floes: 82 -> 76 us)
+  // one atomic per wavefront and counter, spread over WARN_SLOTS lines: the guards fire for most floes of a stiff
+  // field, and atomics on one address are worked off one at a time for the whole chip (~8 ns each: with a single
+  // counter word this kernel took 56 us at 100k floes instead of 16)
   for (int d = 32; d >= 1; d >>= 1) { wh += __shfl_xor(wh, d); wf += __shfl_xor(wf, d); wv += __shfl_xor(wv, d); wx += __shfl_xor(wx, d); }
   if ((threadIdx.x & 63) == 0) {
-    if (wh) atomicAdd(&S.cnt[C_WARN_H], wh);
-    if (wf) atomicAdd(&S.cnt[C_WARN_F], wf);
-    if (wv) atomicAdd(&S.cnt[C_WARN_V], wv);
-    if (wx) atomicAdd(&S.cnt[C_WARN_XI], wx);
+    int* w = S.warn + (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) % WARN_SLOTS) * 32;
+    if (wh) atomicAdd(w + 0, wh);
+    if (wf) atomicAdd(w + 1, wf);
+    if (wv) atomicAdd(w + 2, wv);
+    if (wx) atomicAdd(w + 3, wx);
   }
 }
 
@@ -1654,29 +1654,28 @@ __global__ void __launch_bounds__(1024) sz_k_owned_box(State S, double* out) {
 // ============================================================================ stats
 __global__ void sz_k_stats(State S, long long* out) {
   // out[0] = sum ring points over the pairs the narrow phase ran, out[1] = pair rows, out[2] = elem rows,
-  // out[3] = interaction rows
+  // out[3] = interaction rows, out[4], out[5]: floes tagged remove / fuse (what simplify_floes!, simulation.jl:206,
+  // has to act on), out[6..9]: the guard counters of the last timestep_floe_properties! (sum over the slots)
   int npairs = S.cnt[C_NWORK], nel = S.cnt[C_NELEM];
-  long long a = 0, b = 0, c = 0;
+  long long v[10] = { 0 };
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < npairs + nel; t += gridDim.x * blockDim.x) {
     if (t < npairs) {
       int4 w = S.work[t];
-      a += (S.voff[w.y + 1] - S.voff[w.y]) + (S.voff[w.z + 1] - S.voff[w.z]);
-      b += S.it_nrows[w.x];
-    } else c += S.it_nrows[S.capPairs + (t - npairs)];
+      v[0] += (S.voff[w.y + 1] - S.voff[w.y]) + (S.voff[w.z + 1] - S.voff[w.z]);
+      v[1] += S.it_nrows[w.x];
+    } else v[2] += S.it_nrows[S.capPairs + (t - npairs)];
   }
-  atomicAdd((unsigned long long*)&out[0], (unsigned long long)a);
-  atomicAdd((unsigned long long*)&out[1], (unsigned long long)b);
-  atomicAdd((unsigned long long*)&out[2], (unsigned long long)c);
-  // out[4], out[5]: floes tagged remove / fuse (what simplify_floes!, simulation.jl:206, has to act on)
-  long long d = 0, nr = 0, nf = 0;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < S.cnt[C_M]; k += gridDim.x * blockDim.x) {
-    d += S.inter_cnt[k];
+    v[3] += S.inter_cnt[k];
     int st = S.status[k];
-    nr += st == SZ_REMOVE; nf += st == SZ_FUSE;
+    v[4] += st == SZ_REMOVE; v[5] += st == SZ_FUSE;
   }
-  atomicAdd((unsigned long long*)&out[3], (unsigned long long)d);
-  if (nr) atomicAdd((unsigned long long*)&out[4], (unsigned long long)nr);
-  if (nf) atomicAdd((unsigned long long*)&out[5], (unsigned long long)nf);
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < WARN_SLOTS * 4; q += gridDim.x * blockDim.x) v[6 + (q & 3)] += S.warn[(q >> 2) * 32 + (q & 3)];
+  for (int k = 0; k < 10; k++) {
+    long long x = v[k];
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    if ((threadIdx.x & 63) == 0 && x) atomicAdd((unsigned long long*)&out[k], (unsigned long long)x);
+  }
 }
 
 }  // namespace sz

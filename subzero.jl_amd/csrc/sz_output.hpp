@@ -46,15 +46,25 @@ __device__ __forceinline__ void eul_range(const double* g, int n, double b0, dou
 }
 __global__ void sz_k_eul_entries(State S, EulGrid E, int fill) {
   const int M = S.cnt[C_M];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
-    int lx, hx, ly, hy;
-    eul_range(E.xg, E.nx, S.bbx0[i], S.bbx1[i], lx, hx);
-    eul_range(E.yg, E.ny, S.bby0[i], S.bby1[i], ly, hy);
-    if (lx > hx || ly > hy) continue;
-    const int n = (hx - lx + 1) * (hy - ly + 1);
-    const int pos = atomicAdd(E.count, n);
-    if (!fill || pos + n > E.cap) continue;
-    int k = pos;
+  const int lane = threadIdx.x & 63;
+  // whole wavefronts go round together: one atomic per wavefront reserves the entries of its 64 floes (atomics on
+  // one address are worked off one at a time chip-wide)
+  for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; i0 < M; i0 += gridDim.x * blockDim.x) {
+    const int i = i0 + lane;
+    int lx = 0, hx = -1, ly = 0, hy = -1;
+    if (i < M) {
+      eul_range(E.xg, E.nx, S.bbx0[i], S.bbx1[i], lx, hx);
+      eul_range(E.yg, E.ny, S.bby0[i], S.bby1[i], ly, hy);
+    }
+    const int n = (lx > hx || ly > hy) ? 0 : (hx - lx + 1) * (hy - ly + 1);
+    int inc = n;
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    const int tot = __shfl(inc, 63);
+    int base = 0;
+    if (lane == 0 && tot) base = atomicAdd(E.count, tot);
+    base = __shfl(base, 0);
+    if (!fill || n == 0 || base + inc > E.cap) continue;
+    int k = base + inc - n;
     for (int ix = lx; ix <= hx; ix++)
       for (int iy = ly; iy <= hy; iy++) E.keys[k++] = (unsigned long long)(ix * E.ny + iy) * (unsigned long long)E.M + (unsigned long long)i;
   }

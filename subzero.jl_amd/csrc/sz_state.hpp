@@ -38,6 +38,7 @@ enum {
 
 constexpr int MAXNB = 24;       // broad-phase neighbours kept per floe and direction
 constexpr int ROWS_PER_ITEM = 16; // contact rows kept per pair / element item (the 8-lane kernels hold 4 regions and hand larger items on)
+constexpr int WARN_SLOTS = 256;
 constexpr int MAX_GHOSTS = 3;   // ghosts per parent (doubly periodic corner floe)
 
 struct Params {
@@ -56,6 +57,8 @@ struct State {
   int tiled;                 // halo mode: order keys are global indices
   // ---- counters
   int* cnt;
+  int* warn;                 // guard counters of timestep_floe_properties!: WARN_SLOTS slots of 32 ints (one 128-byte line each; words 0..3 =
+                             // height, force, velocity, xi) -- a single counter word serialises the whole chip's atomics (8 ns each)
   // ---- floe columns
   double *cx, *cy, *rmax, *area, *height, *mass, *moment, *alpha, *u, *v, *xi;
   double *p_dxdt, *p_dydt, *p_dalphadt, *p_dudt, *p_dvdt, *p_dxidt;
