@@ -70,11 +70,13 @@ struct sz_ctx {
   bool any_moving = false;
   int overlap_forcing = 0;        // SZ_OVERLAP=1: forcings on a second stream beside the broad / narrow / reduce kernels.  The fork/join
                                   // costs ~10 us; riding in the neighbour launch (fuse_forcing) is as good or better at every size
+  int max_sub = 0;                  // most sub-floe points of one floe (sizes the LDS of the two-way forcing kernel)
   int max_ring = 0, max_elem_ring = 5, max_ring_tiled = 0;   // largest ring sizes (host knowledge: which narrow variants can be needed)
   int narrow_grid0 = 0;
   // mixed precision (sz_set_precision): fp32 copies for the forcing kernel, rebuilt when their sources change
   int precision = 0; bool mixed_pts_ok = false, mixed_nodes_ok = false; Pool mixed_pt_allocs, mixed_node_allocs;
   // two-way coupling (off by default, like CouplingSettings())
+  bool tw_general_clip = false;   // SZ_TW_GENERAL_CLIP=1: floe-in-cell areas by the general clipper (8 lanes per entry) instead of the rectangle pipeline
   bool two_way = false; int tw_dt = 10; int tw_capM = 0; size_t tw_ncell = 0;
   Pool tw_allocs, tw_field_allocs;
   // static broad-phase grid of the resident steps (fixed by the host: no bounds reduction per step)
@@ -401,7 +403,7 @@ void stage_forcing_fork(sz_ctx* c) {
   (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
   Timed t(c, SZ_K_FORCING, c->stream2);
   if (c->precision == 1) hipLaunchKernelGGL(sz_k_forcing_mixed, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream2, c->S, c->P);
-  else hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream2, c->S, c->P);
+  else hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream2, c->S, c->P, 0);
   t.end();
   (void)hipEventRecord(c->ev_join, c->stream2);
 }
@@ -456,19 +458,22 @@ void stage_forcing(sz_ctx* c, int dt = -1) {      // in-order variant (process m
   if (!c->two_way && c->precision == 1) {
     hipLaunchKernelGGL(sz_k_forcing_mixed, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream, c->S, c->P);
   } else if (!c->two_way) {
-    hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream, c->S, c->P);
+    hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream, c->S, c->P, 0);
   } else {
     // timestep_coupling! with two_way_coupling_on (coupling.jl:1705-1738): one-way forcings + per-floe cell slots,
     // then calc_two_way_coupling! (:1617-1680) as a counting sort by cell, one clip per (floe, cell) entry, a reduction
     State& S = c->S;
     const int ncell = (int)c->tw_ncell;
-    hipLaunchKernelGGL(sz_k_forcing<true>, dim3(grid_for(S.capM, TW_FPB, 16384)), dim3(TW_FPB * FRC_G), 0, c->stream, S, c->P);
+    // LDS for the largest floe's points only (capacity TW_PMAX): the kernel is bound by the floes in flight per CU
+    const int pmax = std::min(TW_PMAX, std::max(32, (c->max_sub + 31) / 32 * 32));
+    hipLaunchKernelGGL(sz_k_forcing<true>, dim3(grid_for(S.capM, TW_FPB, 16384)), dim3(TW_FPB * FRC_G), tw_forcing_lds(pmax), c->stream, S, c->P, pmax);
     const int ge = grid_for((long long)S.capM * FC_CAP, 256, 8192);
     hipLaunchKernelGGL(sz_k_tw_count, dim3(ge), dim3(256), 0, c->stream, S);
     scan(c, S.cl_cnt, S.cl_off, ncell, -1, ncell, C_NENT);
     hipLaunchKernelGGL(sz_k_tw_fill, dim3(ge), dim3(256), 0, c->stream, S);
     hipLaunchKernelGGL(sz_k_tw_sort, dim3(grid_for(ncell, 256)), dim3(256), 0, c->stream, S, ncell);
-    hipLaunchKernelGGL(sz_k_tw_area, dim3(grid_for((long long)S.capM * FC_CAP, 64 / TW_G, 4096)), dim3(64), 0, c->stream, S);
+    if (c->tw_general_clip) hipLaunchKernelGGL(sz_k_tw_area, dim3(grid_for((long long)S.capM * FC_CAP, 64 / TW_G, 4096)), dim3(64), 0, c->stream, S);
+    else hipLaunchKernelGGL(sz_k_tw_area_rect, dim3(grid_for((long long)S.capM * 16, 256, 8192)), dim3(256), 0, c->stream, S);
     // tiled runs finish the cells after the partial sums of all ranks have been added up (sz_two_way_partial / _finish)
     if (!S.tiled) hipLaunchKernelGGL(sz_k_tw_reduce, dim3(grid_for(ncell, 256)), dim3(256), 0, c->stream, S, c->P, ncell, dt >= 0 ? dt : c->tw_dt);
   }
@@ -536,6 +541,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_OVERLAP")) c->overlap_forcing = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("SZ_NARROW_QUEUE")) c->no_queue = atoi(e) == 0;
   if (const char* e = getenv("SZ_FUSED_MOVE")) c->fused_move = atoi(e) != 0;
+  if (const char* e = getenv("SZ_TW_GENERAL_CLIP")) c->tw_general_clip = atoi(e) != 0;
   if (const char* e = getenv("SZ_FUSE_FORCING")) c->fuse_forcing = atoi(e) != 0;
   if (const char* e = getenv("SZ_STATIC_GRID")) c->no_static_grid = atoi(e) == 0;
   int prio_lo = 0, prio_hi = 0;
@@ -686,6 +692,8 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   H2D(S.voff, f->vert_off, M + 1, int); H2D(S.vx, f->vx, V, double); H2D(S.vy, f->vy, V, double);
   DA(soff, S.capM + 1); DA(sx, NS); DA(sy, NS);
   if (f->sub_off) { H2D(S.soff, f->sub_off, N + 1, int); H2D(S.sx, f->sx, NS, double); H2D(S.sy, f->sy, NS, double); }
+  c->max_sub = 0;
+  if (f->sub_off) for (int i = 0; i < N; i++) c->max_sub = std::max(c->max_sub, f->sub_off[i + 1] - f->sub_off[i]);
   DA(gplan, S.capM + 1); DA(gscan4, S.capM + 1); DA(gtot4, 4);
   DA(lb_agg, S.capM / SCAN_B + 8); DA(lb_inc, S.capM / SCAN_B + 8); DA(lb_flag, S.capM / SCAN_B + 8); c->scan_epoch = 0;
   DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2);

@@ -1082,15 +1082,20 @@ constexpr int FRC_G = 32;      // lanes per floe (sub-floe points per floe ~ 100
 constexpr int FC_CAP = 64;      // distinct centre cells per floe
 constexpr int TW_PMAX = 512;    // sub-floe points per floe with two-way coupling on
 constexpr int TW_FPB = 4;       // floes per workgroup of the two-way variant (128 threads)
+// pmax (two-way only): sub-floe points per floe the launch provides LDS for (dynamic: 21 bytes per point and floe;
+// the host sizes it from the largest floe, so that as many floes as possible are in flight per CU)
 template <bool TW>
-__device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid, int nblk) {
-  __shared__ int pkey[TW ? TW_FPB : 1][TW ? TW_PMAX : 1];
-  __shared__ double ptx[TW ? TW_FPB : 1][TW ? TW_PMAX : 1], pty[TW ? TW_FPB : 1][TW ? TW_PMAX : 1];
-  __shared__ signed char pcode[TW ? TW_FPB : 1][TW ? TW_PMAX : 1];
-  __shared__ int skey[TW ? TW_FPB : 1][TW ? FC_CAP : 1];
-  __shared__ signed char scode[TW ? TW_FPB : 1][TW ? FC_CAP : 1];
-  int N = S.cnt[C_NOWN];
+__device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid, int nblk, int pmax = 0) {
+  extern __shared__ double tw_lds[];
   int lane = threadIdx.x % FRC_G, wpb = blockDim.x / FRC_G, wid = threadIdx.x / FRC_G;
+  // per floe of the workgroup: ptx[pmax], pty[pmax] | pkey[pmax], skey[FC_CAP] | pcode[pmax], scode[FC_CAP]
+  double* const ptx_w = TW ? tw_lds + (size_t)wid * 2 * pmax : nullptr;
+  double* const pty_w = TW ? ptx_w + pmax : nullptr;
+  int* const pkey_w = TW ? (int*)(tw_lds + (size_t)TW_FPB * 2 * pmax) + (size_t)wid * (pmax + FC_CAP) : nullptr;
+  int* const skey_w = TW ? pkey_w + pmax : nullptr;
+  signed char* const pcode_w = TW ? (signed char*)((int*)(tw_lds + (size_t)TW_FPB * 2 * pmax) + (size_t)TW_FPB * (pmax + FC_CAP)) + (size_t)wid * (pmax + FC_CAP) : nullptr;
+  signed char* const scode_w = TW ? pcode_w + pmax : nullptr;
+  int N = S.cnt[C_NOWN];
   int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
   double cturn = cos(P.turn), sturn = sin(P.turn);
   for (int i = bid * wpb + wid; i < N; i += nblk * wpb) {
@@ -1099,9 +1104,9 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
     double ma_ratio = S.mass[i] / S.area[i];
     int o = S.soff[i], ns = S.soff[i + 1] - o;
     if (TW) {
-      if (ns > TW_PMAX) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_CELLS); ns = TW_PMAX; }
+      if (ns > pmax) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_CELLS); ns = pmax; }
       gsync();
-      for (int k = lane; k < ns; k += FRC_G) pkey[wid][k] = -1;
+      for (int k = lane; k < ns; k += FRC_G) pkey_w[k] = -1;
       gsync();
     }
     double tx = 0, ty = 0, ttrq = 0, th = 0; int np = 0;
@@ -1140,10 +1145,10 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
         if (per_x) sxi = xidx < 1 ? xidx + S.Nx : (S.Nx < xidx ? xidx - S.Nx : xidx);
         if (per_y) syi = yidx < 1 ? yidx + S.Ny : (S.Ny < yidx ? yidx - S.Ny : yidx);
         if (sxi >= 1 && sxi <= S.Nx + 1 && syi >= 1 && syi <= S.Ny + 1) {
-          pkey[wid][k] = (sxi - 1) * (S.Ny + 1) + (syi - 1);
-          ptx[wid][k] = -tox; pty[wid][k] = -toy;
+          pkey_w[k] = (sxi - 1) * (S.Ny + 1) + (syi - 1);
+          ptx_w[k] = -tox; pty_w[k] = -toy;
           int cx3 = sxi == xidx ? 1 : (sxi > xidx ? 2 : 0), cy3 = syi == yidx ? 1 : (syi > yidx ? 2 : 0);
-          pcode[wid][k] = (signed char)(cx3 + 3 * cy3);
+          pcode_w[k] = (signed char)(cx3 + 3 * cy3);
         }
       }
     }
@@ -1174,33 +1179,33 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
       for (int base = 0; base < ns; base += FRC_G) {
         const int k = base + lane;
         bool first = false;
-        if (k < ns && pkey[wid][k] >= 0) {
-          const int key = pkey[wid][k];
+        if (k < ns && pkey_w[k] >= 0) {
+          const int key = pkey_w[k];
           first = true;
-          for (int s = 0; s < nslots && s < FC_CAP; s++) if (skey[wid][s] == key) { first = false; break; }
-          for (int j = base; first && j < k; j++) if (pkey[wid][j] == key) first = false;
+          for (int s = 0; s < nslots && s < FC_CAP; s++) if (skey_w[s] == key) { first = false; break; }
+          for (int j = base; first && j < k; j++) if (pkey_w[j] == key) first = false;
         }
         const unsigned long long mask = __ballot(first) & half;
         if (first) {
           const int slot = nslots + __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1));
-          if (slot < FC_CAP) { skey[wid][slot] = pkey[wid][k]; scode[wid][slot] = pcode[wid][k]; }
+          if (slot < FC_CAP) { skey_w[slot] = pkey_w[k]; scode_w[slot] = pcode_w[k]; }
         }
         nslots += __popcll(mask);
         gsync();
       }
       if (nslots > FC_CAP) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_CELLS); nslots = FC_CAP; }
       // ordered sums: lane owns slots lane and lane + 32
-      const int k0 = lane < nslots ? skey[wid][lane] : -2, k1 = lane + 32 < nslots ? skey[wid][lane + 32] : -2;
+      const int k0 = lane < nslots ? skey_w[lane] : -2, k1 = lane + 32 < nslots ? skey_w[lane + 32] : -2;
       double ax0 = 0, ay0 = 0, ax1 = 0, ay1 = 0; int n0 = 0, n1 = 0;
       bool f0 = true, f1 = true;
       for (int j = 0; j < ns; j++) {
-        const int key = pkey[wid][j];
-        if (key == k0) { if (f0) { ax0 = ptx[wid][j]; ay0 = pty[wid][j]; f0 = false; } else { ax0 += ptx[wid][j]; ay0 += pty[wid][j]; } n0++; }
-        if (key == k1) { if (f1) { ax1 = ptx[wid][j]; ay1 = pty[wid][j]; f1 = false; } else { ax1 += ptx[wid][j]; ay1 += pty[wid][j]; } n1++; }
+        const int key = pkey_w[j];
+        if (key == k0) { if (f0) { ax0 = ptx_w[j]; ay0 = pty_w[j]; f0 = false; } else { ax0 += ptx_w[j]; ay0 += pty_w[j]; } n0++; }
+        if (key == k1) { if (f1) { ax1 = ptx_w[j]; ay1 = pty_w[j]; f1 = false; } else { ax1 += ptx_w[j]; ay1 += pty_w[j]; } n1++; }
       }
       const size_t fb = (size_t)i * FC_CAP;
-      if (lane < nslots) { S.fc_key[fb + lane] = k0; S.fc_code[fb + lane] = scode[wid][lane]; S.fc_tx[fb + lane] = ax0; S.fc_ty[fb + lane] = ay0; S.fc_n[fb + lane] = n0; }
-      if (lane + 32 < nslots) { S.fc_key[fb + lane + 32] = k1; S.fc_code[fb + lane + 32] = scode[wid][lane + 32]; S.fc_tx[fb + lane + 32] = ax1; S.fc_ty[fb + lane + 32] = ay1; S.fc_n[fb + lane + 32] = n1; }
+      if (lane < nslots) { S.fc_key[fb + lane] = k0; S.fc_code[fb + lane] = scode_w[lane]; S.fc_tx[fb + lane] = ax0; S.fc_ty[fb + lane] = ay0; S.fc_n[fb + lane] = n0; }
+      if (lane + 32 < nslots) { S.fc_key[fb + lane + 32] = k1; S.fc_code[fb + lane + 32] = scode_w[lane + 32]; S.fc_tx[fb + lane + 32] = ax1; S.fc_ty[fb + lane + 32] = ay1; S.fc_n[fb + lane + 32] = n1; }
       if (lane == 0) S.fc_cnt[i] = npt == 0 ? 0 : nslots;
       gsync();
     }
@@ -1208,7 +1213,9 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
 }
 
 template <bool TW>
-__global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P) { forcing_body<TW>(S, P, blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P, int pmax) { forcing_body<TW>(S, P, blockIdx.x, gridDim.x, pmax); }
+// dynamic LDS of sz_k_forcing<true> for pmax points per floe
+inline size_t tw_forcing_lds(int pmax) { return (size_t)TW_FPB * ((size_t)2 * pmax * sizeof(double) + (size_t)(pmax + FC_CAP) * (sizeof(int) + 1)); }
 
 // ---------------------------------------------------------------- mixed precision (BASELINE configs[4])
 // The forcings are sums of ~100 smooth per-point terms per floe: they do not need fp64 per point.  In mixed mode

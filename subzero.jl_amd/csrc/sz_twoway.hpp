@@ -93,6 +93,83 @@ __global__ void __launch_bounds__(64) sz_k_tw_area(State S) {
   if (gl == 0 && (m.err & (ERR_CAP_XING | ERR_CAP_REGION))) atomicOr(&S.cnt[C_ERR], m.err);
   if (gl == 0 && m.ntracefail) atomicAdd(&S.cnt[C_TRACE_FAIL], m.ntracefail);
 }
+// ---- the same areas, one thread per entry.  The clip window is an axis-parallel rectangle, so the intersection
+// is what the re-entrant Sutherland-Hodgman pipeline produces: every ring vertex is pushed through the four
+// half-plane stages (left, right, bottom, top), each stage remembers its first and previous point only, and what
+// leaves the last stage is summed into the shoelace area on the fly -- no polygon is stored, no LDS, no lane sits
+// idle behind a neighbour's different path.  For a floe that leaves the window in several pieces the pipeline
+// emits one ring whose connecting edges run along the window's boundary back and forth and cancel in the area,
+// so the sum equals the total of the pieces (what the reference adds up over intersect_polys' regions).
+// Coordinates are taken relative to the window's corner: the result carries less round-off than the general
+// clipper's (differences of a few 1e-11 relative at 2000 km; the tests state 1e-9).
+struct RectClip {
+  double w, h;                  // window [0, w] x [0, h]
+  double fx[4], fy[4], px[4], py[4];
+  bool have[4];
+  double ox0, oy0, oxp, oyp, acc; bool hout;
+  __device__ __forceinline__ bool inside(int s, double x, double y) const {
+    return s == 0 ? x >= 0.0 : s == 1 ? x <= w : s == 2 ? y >= 0.0 : y <= h;
+  }
+  __device__ __forceinline__ void cross(int s, double ax, double ay, double bx, double by, double& ix, double& iy) const {
+    if (s < 2) { const double c = s == 0 ? 0.0 : w; const double t = (c - ax) / (bx - ax); ix = c; iy = ay + t * (by - ay); }
+    else { const double c = s == 2 ? 0.0 : h; const double t = (c - ay) / (by - ay); iy = c; ix = ax + t * (bx - ax); }
+  }
+  __device__ __forceinline__ void out(double x, double y) {
+    if (!hout) { ox0 = x; oy0 = y; hout = true; } else acc += oxp * y - x * oyp;
+    oxp = x; oyp = y;
+  }
+  template <int SS>
+  __device__ __forceinline__ void feed(double x, double y) {
+    if constexpr (SS == 4) out(x, y);
+    else {
+      if (!have[SS]) { fx[SS] = x; fy[SS] = y; have[SS] = true; }
+      else if (inside(SS, px[SS], py[SS]) != inside(SS, x, y)) { double ix, iy; cross(SS, px[SS], py[SS], x, y, ix, iy); feed<SS + 1>(ix, iy); }
+      px[SS] = x; py[SS] = y;
+      if (inside(SS, x, y)) feed<SS + 1>(x, y);
+    }
+  }
+  template <int SS>
+  __device__ __forceinline__ void close_from() {
+    if constexpr (SS < 4) {
+      if (have[SS] && inside(SS, px[SS], py[SS]) != inside(SS, fx[SS], fy[SS])) {
+        double ix, iy; cross(SS, px[SS], py[SS], fx[SS], fy[SS], ix, iy); feed<SS + 1>(ix, iy);
+      }
+      close_from<SS + 1>();
+    }
+  }
+  __device__ __forceinline__ double finish() {
+    close_from<0>();
+    if (!hout) return 0.0;
+    acc += oxp * oy0 - ox0 * oyp;
+    return fabs(acc) * 0.5;
+  }
+};
+__global__ void __launch_bounds__(256) sz_k_tw_area_rect(State S) {
+  const int nent = S.cnt[C_NENT];
+  const int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nent; t += gridDim.x * blockDim.x) {
+    const int ent = S.cl_ent[t];
+    const int i = ent / FC_CAP, q = S.fc_key[ent], code = S.fc_code[ent];
+    const int ix0 = q / (S.Ny + 1), iy0 = q % (S.Ny + 1);
+    const double dx = (double)((code % 3 - 1) * S.Nx) * S.gdx, dy = (double)((code / 3 - 1) * S.Ny) * S.gdy;
+    double xmin, xmax, ymin, ymax;
+    center_cell(S, ix0, iy0, per_x, per_y, xmin, xmax, ymin, ymax);
+    const int bo = S.voff[i], nb = S.voff[i + 1] - bo;
+    RectClip rc;
+    rc.w = xmax - xmin; rc.h = ymax - ymin; rc.acc = 0.0; rc.hout = false;
+    rc.ox0 = rc.oy0 = rc.oxp = rc.oyp = 0.0;
+    for (int k = 0; k < 4; k++) { rc.have[k] = false; rc.fx[k] = rc.fy[k] = rc.px[k] = rc.py[k] = 0.0; }
+    double a = 0.0;
+    // the ring box decides the two cheap cases: no overlap, and (for a window inside the box nothing is known)
+    const double b0 = S.bbx0[i] + dx, b1 = S.bbx1[i] + dx, b2 = S.bby0[i] + dy, b3 = S.bby1[i] + dy;
+    if (!(b1 < xmin || xmax < b0 || b3 < ymin || ymax < b2) && rc.w > 0.0 && rc.h > 0.0) {
+      for (int k = 0; k + 1 < nb; k++) rc.feed<0>((S.vx[bo + k] + dx) - xmin, (S.vy[bo + k] + dy) - ymin);   // _translate_poly, then window coordinates
+      a = rc.finish();
+    }
+    S.fc_area[ent] = a;
+  }
+}
+
 // per centre cell, first half: sums over the floes in it, in floe order -- the ice stress weighted by the area of
 // floe in cell (numerators) and that area (coupling.jl:1631-1662)
 __device__ __forceinline__ void tw_cell_sums(const State& S, int q, double& tx, double& ty, double& si) {
