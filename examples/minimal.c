@@ -1,5 +1,5 @@
-/* minimal.c -- the C-ABI from plain C: two overlapping floes in a periodic box, one timestep_collisions! call and
- * ten resident timesteps.  Build (on a box with an MI355X):
+/* minimal.c -- the C-ABI from plain C: two overlapping floes in a periodic box, one timestep_collisions! call,
+ * ten resident timesteps, the simplify check and a grid output.  Build (on a box with an MI355X):
  *   gcc -std=c11 -Iinclude examples/minimal.c -Lsubzero.jl_amd -lsubzero_hip -Wl,-rpath,$PWD/subzero.jl_amd -lm -o minimal
  * The host computes the derived floe columns (centroid, area, mass, moment, rmax) exactly as Floe(...) does in the
  * reference (floe.jl:144-200); here by the textbook formulas for the two squares used. */
@@ -51,6 +51,21 @@ int main(void) {
   memset(&c, 0, sizeof(c)); c.u = ucol;
   CHECK(sz_download_floes(ctx, &c));
   printf("u after 10 steps: %.6f %.6f (the floes push each other apart)\n", ucol[0], ucol[1]);
+  /* output step: does simplify_floes! have anything to do, and the GridOutputWriter averages on a 4 x 4 grid
+     (write_data! sees the ghosts: add them for the call) */
+  int64_t todo[4];
+  CHECK(sz_simplify_check(ctx, 30, 1e6, 0.1, todo));
+  printf("simplify: %lld remove, %lld fuse, %lld over max_vertices, %lld to dissolve\n", (long long)todo[0], (long long)todo[1],
+         (long long)todo[2], (long long)todo[3]);
+  double xg[5], yg[5], grid[2 * 4 * 4];
+  for (int k = 0; k <= 4; k++) { xg[k] = k * L / 4; yg[k] = k * L / 4; }
+  int32_t outs[2] = { SZ_EUL_SI_FRAC, SZ_EUL_U };
+  CHECK(sz_add_ghosts(ctx));
+  CHECK(sz_eulerian_data(ctx, 4, 4, xg, yg, 2, outs, grid));
+  CHECK(sz_remove_ghosts(ctx));
+  double ice = 0.0;
+  for (int q = 0; q < 16; q++) ice += grid[q] * (L / 4) * (L / 4);
+  printf("ice area from the grid output: %.4e m^2 (two floes of %.1e m^2)\n", ice, s * s);
   sz_destroy(ctx);
   return 0;
 }
