@@ -21,7 +21,7 @@ enum {
   C_NPAIR_PTS,    // sum of ring points over pairs (stats)
   C_NPAIR_ROWS,   // contact rows before mirroring (stats)
   C_NELEM_ROWS,
-  C_WARN_H, C_WARN_F, C_WARN_V, C_WARN_XI,
+  C_UNUSED0, C_UNUSED1, C_UNUSED2, C_UNUSED3,   // (the guard counters live in State::warn: one word each serialised the chip)
   C_NG_NEW,       // ghosts created by the current pass
   C_NGHOSTS,
   C_NCELLS,
