@@ -74,12 +74,13 @@ def _run_worker_two_way(*a):
     _guard(_worker_two_way)(*a)
 
 
-@pytest.mark.parametrize("n,seed,steps,repartition", [(600, 31, 4, False), (600, 33, 6, True)])
-def test_two_ranks_equal_single(n, seed, steps, repartition):
+@pytest.mark.parametrize("world,n,seed,steps,repartition", [(2, 600, 31, 4, False), (2, 600, 33, 6, True), (4, 1000, 35, 4, False)])
+def test_ranks_equal_single(world, n, seed, steps, repartition):
+    """2 ranks (two tiles side by side) and 4 ranks (2 x 2 tiles: corner halos, both periodic directions across
+    tile boundaries) against the single-context run: bit-equal columns for every owned floe"""
     import torch.multiprocessing as mp
     import subzero_jl_amd
     from subzero_jl_amd import fields
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
