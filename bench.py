@@ -193,11 +193,11 @@ def main():
         b_narrow = narrow_algorithmic_bytes(st)
         achieved = b_narrow / (narrow_ms * 1e-3) / 1e9 if narrow_ms > 0 else 0.0
         # HBM bytes per launch of the narrow kernel from the PMC passes committed under profiles/
-        # (r01_pmc_fetch_size.csv, r01_pmc_write_size.csv, made by tools/profile_round.sh: FETCH_SIZE 1956.6 KB,
+        # (r01_pmc_fetch_size.csv, r01_pmc_write_size.csv, made by tools/profile_round.sh: FETCH_SIZE 1952.7 KB,
         # WRITE_SIZE 899.6 KB per launch on the default workload; gfx950 correction: 2 x FETCH_SIZE + WRITE_SIZE; less
         # than the algorithmic bytes: part of the rings is still in the last-level cache from the kernels before).
         # Only valid for that workload.
-        traffic = (2 * 1956.6 + 899.6) * 1024 if (world == 1 and cfg["n_floes"] == 10000 and args.workload == "configs1") else None
+        traffic = (2 * 1952.7 + 899.6) * 1024 if (world == 1 and cfg["n_floes"] == 10000 and args.workload == "configs1") else None
         out = {
             "metric": "floe_steps_per_sec", "value": cfg["n_floes"] * args.steps / el, "unit": "floe-steps/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
