@@ -65,6 +65,50 @@ def measured_hbm_ceiling(torch, device):
     return best
 
 
+def reference_cpu(cfg, cores, budget_s=60.0):
+    """The reference package itself, if this machine has Julia with Subzero.jl installed (preferred over the
+    port; the GPU box is not expected to have it).  bench/subzero_cpu.jl builds the same field through the package's
+    public constructors and times timestep_sim!.  Returns a cpu_baseline dict of kind "reference" or None."""
+    import shutil
+    import subprocess
+    import tempfile
+    import numpy as np
+    julia = shutil.which("julia")
+    uo_field = np.asarray(cfg["uo"], float)
+    if (not julia or any(k != "periodic" for k in cfg["kinds"]) or cfg.get("topography") or np.ptp(uo_field) > 0
+            or np.ptp(np.asarray(cfg["vo"], float)) > 0 or np.any(np.asarray(cfg["vo"], float) != 0)):
+        return None          # the script covers the periodic, uniform-flow workload (BASELINE configs[1])
+    try:
+        probe = subprocess.run([julia, "-e", "using Subzero"], capture_output=True, timeout=600)
+        if probe.returncode != 0:
+            return None
+        off, vx, vy = cfg["vert_off"], cfg["vx"], cfg["vy"]
+        steps = 5
+        with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+            uo = float(uo_field.ravel()[0]); dgrid = cfg["L"] / cfg["Nx"]
+            hmean = float(np.asarray(cfg["height"], float).ravel()[0])
+            npc = max(1, int(round(dgrid / cfg["dg"])))          # SubGridPointsGenerator(grid, npc): sub-grid spacing dgrid / npc
+            f.write(f"{cfg['n_floes']} {cfg['L']!r} {cfg['dt']} {dgrid!r} {hmean!r} {float(cfg['E'])!r} {uo!r} {npc}\n")
+            for i in range(cfg["n_floes"]):
+                o0, o1 = off[i], off[i + 1]
+                pts = " ".join(f"{x!r} {y!r}" for x, y in zip(vx[o0:o1].tolist(), vy[o0:o1].tolist()))
+                f.write(f"{o1 - o0} {float(cfg['u'][i])!r} {float(cfg['v'][i])!r} {float(cfg['xi'][i])!r} {pts}\n")
+            path = f.name
+        here = os.path.dirname(os.path.abspath(__file__))
+        out = subprocess.run([julia, "-t", str(cores), os.path.join(here, "bench", "subzero_cpu.jl"), path, str(steps)],
+                             capture_output=True, text=True, timeout=max(600.0, 10 * budget_s))
+        os.unlink(path)
+        line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+        if out.returncode != 0 or not line:
+            return None
+        kv = dict(t.split("=") for t in line[0].split()[1:])
+        return {"value": float(kv["floe_steps_per_sec"]), "unit": "floe-steps/s", "cores": int(kv["threads"]), "kind": "reference",
+                "sample": f"Subzero.jl (julia {kv['julia']}) timestep_sim! x {kv['steps']} on the same {cfg['n_floes']}-floe field, "
+                          f"collisions + coupling every step, other processes off"}
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, budget_s=20.0):
     """The oracle (kind: port) on a bounded sample of the same workload: the same 10k-floe field,
     as many whole timesteps as fit the budget (at least 2), all host cores of this process."""
@@ -77,6 +121,9 @@ def cpu_baseline(cfg, budget_s=20.0):
             cores = max(1, min(cores, int(quota) // int(period)))
     except Exception:
         pass
+    ref = reference_cpu(cfg, cores)
+    if ref is not None:
+        return ref
     w = fields.build_world(orc.World(), cfg)
     w.set_threads(cores)
     w.timestep_sim(0, cfg["dt"], coupling_dt=1)        # warm-up step (page-in, allocator)
