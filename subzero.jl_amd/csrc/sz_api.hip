@@ -1240,7 +1240,8 @@ int eul_entries(sz_ctx* c, PoolGuard& pool, EulGrid& E, int& nent) {
   char* tmp = nullptr;
   if ((rc = dalloc(c, &tmp, tmp_bytes, pool.v))) return rc;
   HIPCHK(c, rocprim::radix_sort_keys((void*)tmp, tmp_bytes, keys_in, E.keys, (size_t)nent, 0u, bits, c->stream));
-  hipLaunchKernelGGL(sz_k_eul_area, dim3(grid_for(nent, 64 / EU_G, 1 << 16)), dim3(64), 0, c->stream, S, E, nent);
+  if (S.nelem > 4) hipLaunchKernelGGL(sz_k_eul_area, dim3(grid_for(nent, 64 / EU_G, 1 << 16)), dim3(64), 0, c->stream, S, E, nent);
+  else hipLaunchKernelGGL(sz_k_eul_area_rect, dim3(grid_for(nent, 256, 1 << 16)), dim3(256), 0, c->stream, S, E, nent);
   return SZ_OK;
 }
 int eul_check_outputs(sz_ctx* c, int32_t nout, const int32_t* outputs, const double* data) {

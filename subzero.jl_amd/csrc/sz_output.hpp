@@ -15,6 +15,7 @@
 // come from area(f ∩ (c \ t)) = area(f ∩ c) - sum_t area((f ∩ c) ∩ t) for elements that do not overlap one another.
 #pragma once
 #include "sz_kernels.hpp"
+#include "sz_twoway.hpp"      // RectClip: the rectangle pipeline
 
 namespace sz {
 
@@ -194,6 +195,24 @@ __global__ void __launch_bounds__(64) sz_k_eul_area(State S, EulGrid E, int nent
   gsync();
   if (gl == 0 && (cap_err || m.err)) atomicOr(&S.cnt[C_ERR], (cap_err ? ERR_CAP_RING : 0) | (m.err & (ERR_CAP_XING | ERR_CAP_REGION)));
   if (gl == 0 && m.ntracefail) atomicAdd(&S.cnt[C_TRACE_FAIL], m.ntracefail);
+}
+
+// without topography the window is a plain rectangle: one thread per entry, the rectangle pipeline of the two-way
+// coupling (sz_twoway.hpp)
+__global__ void __launch_bounds__(256) sz_k_eul_area_rect(State S, EulGrid E, int nent) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nent; t += gridDim.x * blockDim.x) {
+    const unsigned long long key = E.keys[t];
+    const int i = (int)(key % (unsigned long long)E.M), q = (int)(key / (unsigned long long)E.M);
+    const int ix = q / E.ny, iy = q % E.ny;
+    const double xmin = E.xg[ix], ymin = E.yg[iy];
+    const int bo = S.voff[i], nb = S.voff[i + 1] - bo;
+    RectClip rc;
+    rc.w = E.xg[ix + 1] - xmin; rc.h = E.yg[iy + 1] - ymin; rc.acc = 0.0; rc.hout = false;
+    rc.ox0 = rc.oy0 = rc.oxp = rc.oyp = 0.0;
+    for (int k = 0; k < 4; k++) { rc.have[k] = false; rc.fx[k] = rc.fy[k] = rc.px[k] = rc.py[k] = 0.0; }
+    for (int k = 0; k + 1 < nb; k++) rc.feed<0>(S.vx[bo + k] - xmin, S.vy[bo + k] - ymin);
+    E.pic[t] = rc.finish();
+  }
 }
 
 __device__ __forceinline__ int eul_lower_bound(const unsigned long long* k, int n, unsigned long long v) {
