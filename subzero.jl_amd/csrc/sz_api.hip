@@ -1042,7 +1042,9 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     // beside the halo exchange, and both paths keep the same order: a parent that the ghost pass wraps around the
     // domain is sampled at the periodic image it had before -- the same lattice values).  With the forcings on a
     // second stream the fork comes after the ghost pass instead, so that nothing they read is being rewritten.
-    const bool fuse = coupling && !overlap && coll && !c->two_way && !(c->pmask >> SZ_K_FORCING & 1u) && c->fuse_forcing;
+    // (riding in the neighbour launch pays while both kernels leave the chip idle: measured better up to 40 k floes,
+    // neutral at 100 k dense, worse at 100 k sparse -- there the forcings get their own launch)
+    const bool fuse = coupling && !overlap && coll && !c->two_way && !(c->pmask >> SZ_K_FORCING & 1u) && c->fuse_forcing && c->hostN <= 65536;
     if (coupling && !overlap && !fuse) stage_forcing(c, dt);
     if (coll) stage_ghosts(c, true, sg);
     if (overlap) stage_forcing_fork(c);
