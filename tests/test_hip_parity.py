@@ -349,3 +349,19 @@ def test_full_size_properties():
     assert np.all(np.abs(tot) <= 1e-9 * fscale * len(rows)), tot     # internal forces cancel over the parents
     assert abs(hw.get("coll_fx")[:n].sum()) <= 1e-9 * fscale * len(rows)
     assert np.all(hw.get("coll_fx")[n:] == 0)
+
+
+def test_reupload_into_the_same_context():
+    """A shim uploads before every replaced call: fields of changing size through ONE context (the device chunks of the
+    previous upload are carved again, unused ones returned) step exactly like a fresh context does."""
+    from subzero_jl_amd import fields
+    w = mk()
+    for n in (700, 3000, 1200, 3000, 200):
+        cfg = fields.make_config(n_floes=n, seed=n)
+        fields.build_world(w, cfg)
+        w.run(3, 0, cfg["dt"], coupling_dt=1)
+        ref = fields.build_world(mk(), cfg)
+        ref.run(3, 0, cfg["dt"], coupling_dt=1)
+        for f in ("cx", "cy", "u", "v", "xi", "alpha", "coll_fx", "overarea", "fxOA"):
+            assert np.array_equal(w.get(f), ref.get(f)), (n, f)
+        assert w.stats()["n_pairs"] == ref.stats()["n_pairs"] > n
