@@ -7,10 +7,10 @@ A "step" is one timestep_sim! of the hot path (add_ghosts! -> timestep_collision
 removal -> timestep_coupling! -> timestep_floe_properties!) over the whole synthetic floe field,
 state resident in HBM.  At N=1 the workload is BASELINE.json configs[1]: 10 000 random-polygon
 floes (8-16 vertices), doubly periodic box, uniform_flow ocean forcing, fp64.  For N>1 (one
-process per GPU under torch.distributed / RCCL) the field has N x 10 000 floes (same floe size and
-concentration, larger box: N=8 is the scale of configs[2]) and is sharded by spatial tile with a
-ghost-floe halo traded by one all-to-all per step (subzero_jl_amd.tiles): per-GPU work is fixed,
-i.e. weak scaling; `--total-floes` fixes the job size instead (strong scaling).
+process per GPU under torch.distributed / RCCL) the default is the metric's multi-GPU workload,
+BASELINE.json configs[2]: 100 000 floes, converge/diverge flow, sharded by spatial tile with a
+ghost-floe halo traded every step (subzero_jl_amd.tiles) -- the job size is fixed, i.e. STRONG
+scaling; `--floes K` runs N x K floes of the configs[1] field instead (weak scaling).
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the narrow phase) with
 the algorithmic byte count of SURVEY.md §8(d) against HBM peak; `cpu_baseline` is the CPU oracle
@@ -143,16 +143,39 @@ def cpu_baseline(cfg, budget_s=20.0):
             "value_1core": cfg["n_floes"] * s1 / el1}
 
 
+def pmc_traffic(workload, n_floes, kernel):
+    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (separate rocprofv3 --pmc runs of
+    this same command, summarised by tools/pmc_summary.py into profiles/pmc_traffic.json with the gfx950 correction
+    2 x FETCH_SIZE + WRITE_SIZE).  None -- with the reason -- when no committed pass covers this workload: the counters
+    cannot be collected inside a timed run."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None, "profiles/pmc_traffic.json not found"
+    ent = table.get(f"{workload}:{n_floes}", {}).get(kernel)
+    if ent is None:
+        return None, f"no committed PMC pass for {workload} at {n_floes} floes (tools/profile_round.sh makes one)"
+    return float(ent["hbm_bytes_per_launch"]), ent.get("source", path)
+
+
+NARROW_KERNEL = "sz_k_narrow<8,20,8,16,4,64,0,0,3>"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--floes", type=int, default=10000, help="floes per GPU")
-    ap.add_argument("--total-floes", type=int, default=0, help="fix the job size instead (strong scaling)")
-    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs3", "configs4"],
-                    help="BASELINE.json configs[k]: 1 = periodic box + uniform flow (the metric's config, default); 2 = "
-                         "converge/diverge flow; 3 = four collision walls + topography, strait flow; 4 = 25 %% concentration")
+    ap.add_argument("--repeats", type=int, default=10, help="the block of --steps steps is timed this many times; value and ms_per_step "
+                                                            "are the median block (min / max reported beside it)")
+    ap.add_argument("--floes", type=int, default=0, help="floes per GPU (weak scaling of the configs[1] field); default: 10000 on one "
+                                                         "GPU, and for N > 1 the metric's strong-scaling workload instead")
+    ap.add_argument("--total-floes", type=int, default=0, help="fix the job size (strong scaling)")
+    ap.add_argument("--workload", default=None, choices=["configs1", "configs2", "configs3", "configs4"],
+                    help="BASELINE.json configs[k]: 1 = periodic box + uniform flow (the metric's 1-GPU config, default for N = 1); 2 = "
+                         "100k floes converge/diverge flow (the metric's multi-GPU config, default for N > 1); 3 = four collision "
+                         "walls + topography, strait flow; 4 = 25 %% concentration")
     ap.add_argument("--two-way", action="store_true", help="two-way coupling on (ice-on-ocean stress per centre cell; "
                                                            "off in the metric's config, as in CouplingSettings())")
     ap.add_argument("--precision", default="f64", choices=["f64", "mixed"],
@@ -168,6 +191,7 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    import numpy as np
     import torch
     import subzero_jl_amd
     from subzero_jl_amd import fields
@@ -186,18 +210,32 @@ def main():
             os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29533"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    n_total = args.total_floes if args.total_floes > 0 else args.floes * world
+    # BASELINE.json: "floe-steps/sec at 10k/100k floes, 1/2/4/8 MI355X" -- one GPU: configs[1] (10 000 floes, uniform flow);
+    # several GPUs: the strong-scaling workload, configs[2] (100 000 floes, converge/diverge flow) cut into spatial tiles.
+    # --floes asks for weak scaling of the configs[1] field instead.
+    if args.total_floes > 0:
+        n_total, scaling = args.total_floes, "strong"
+    elif args.floes > 0:
+        n_total, scaling = args.floes * world, "weak"
+    elif world > 1:
+        n_total, scaling = 100000, "strong"
+    else:
+        n_total, scaling = 10000, "weak"
+    workload = args.workload or ("configs2" if (world > 1 and args.floes == 0) else "configs1")
     wl = {"configs1": dict(seed=12345), "configs2": dict(seed=12346, ocean="converge_diverge"),
           "configs3": dict(seed=12345, walls=True, topography=True, ocean="strait"),
-          "configs4": dict(seed=12347, concentration=0.25)}[args.workload]
+          "configs4": dict(seed=12347, concentration=0.25)}[workload]
     cfg = fields.make_config(n_floes=n_total, **wl)
     coupling_dt = args.coupling_dt
-    if world == 1 and not args.force_tiled:
+    tiled = not (world == 1 and not args.force_tiled)
+    if not tiled:
         hw = fields.build_world(subzero_jl_amd.World(local), cfg)
         if args.two_way:
             hw.set_two_way(True, dt=cfg["dt"]); hw.set_temps(0.0, -10.0)
         hw.set_precision(args.precision)
-        runner = lambda n, t0: hw.run(n, t0, cfg["dt"], coupling_dt=coupling_dt)
+        # the batches run through even if a floe gets tagged (the host's simplify_floes! is not part of the timed path);
+        # the tag counts at the end of the timed window are printed, so the reader sees whether that ever mattered
+        runner = lambda n, t0: hw.run(n, t0, cfg["dt"], coupling_dt=coupling_dt, stop_on_tags=False)
     else:
         from subzero_jl_amd import tiles
         tw = tiles.TiledWorld(cfg, rank, world, local, dist, always_exchange=args.force_tiled)
@@ -213,60 +251,74 @@ def main():
     runner(args.warmup, 0)
     # inside the timed region only the dominant kernel is bracketed by HIP events (one pair per step,
     # on the stream it is launched on): timing all seven classes costs ~20 % of a 0.25 ms step
-    hw.profile(True, only="narrow")
-    barrier()
-    t0 = time.perf_counter()
-    runner(args.steps, args.warmup)
-    barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    hw.profile(True, only="narrow")          # also clears the cumulative narrow-phase work counters
+    blocks = []
+    tstep = args.warmup
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        runner(args.steps, tstep)
+        barrier()
+        el = time.perf_counter() - t0
+        tstep += args.steps
+        if dist is not None:
+            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        blocks.append(el)
+    el = float(np.median(blocks))
     kt = hw.kernel_times()
+    st = hw.stats()                           # counts of the last step + the cumulative ones of the whole timed window
     ceiling = measured_hbm_ceiling(torch, torch.device("cuda", local)) if rank == 0 else 0.0
     # per-class breakdown from a second, untimed pass with every class event-timed
     nb = max(1, min(args.steps, 50))
     hw.profile(True)
-    runner(nb, args.warmup + args.steps)
+    runner(nb, tstep)
     torch.cuda.synchronize()
     kt_all = hw.kernel_times()
     hw.profile(False)
-    st = hw.stats()
 
     if rank == 0:
         n_ms, n_launch = kt["narrow"]
         narrow_ms = n_ms / max(n_launch, 1)
-        b_narrow = narrow_algorithmic_bytes(st)
+        # algorithmic bytes of the SAME launches the event time averages: cumulative device counters over the window
+        nl = max(st["acc_narrow_launches"], 1)
+        win = {"n_pair_ring_points": st["acc_pair_ring_points"] / nl, "n_pairs_clipped": st["acc_pair_items"] / nl,
+               "n_pair_rows": st["acc_pair_rows"] / nl, "n_elem_rows": st["acc_elem_rows"] / nl}
+        b_narrow = narrow_algorithmic_bytes(win)
         achieved = b_narrow / (narrow_ms * 1e-3) / 1e9 if narrow_ms > 0 else 0.0
-        # HBM bytes per launch of the narrow kernel from the PMC passes committed under profiles/
-        # (r01_pmc_fetch_size.csv, r01_pmc_write_size.csv, made by tools/profile_round.sh: FETCH_SIZE 1952.7 KB,
-        # WRITE_SIZE 899.6 KB per launch on the default workload; gfx950 correction: 2 x FETCH_SIZE + WRITE_SIZE; less
-        # than the algorithmic bytes: part of the rings is still in the last-level cache from the kernels before).
-        # Only valid for that workload.
-        traffic = (2 * 1952.7 + 899.6) * 1024 if (world == 1 and cfg["n_floes"] == 10000 and args.workload == "configs1") else None
+        traffic, traffic_src = pmc_traffic(workload, cfg["n_floes"], NARROW_KERNEL) if not tiled else (None, "tiled run")
+        step_bytes = step_algorithmic_bytes({**st, **win})
         out = {
             "metric": "floe_steps_per_sec", "value": cfg["n_floes"] * args.steps / el, "unit": "floe-steps/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
-            "higher_is_better": True, "scaling": "strong" if args.total_floes > 0 else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64" if args.precision == "f64" else "f64 (forcings: fp32 per point)", "data": "synthetic",
-            "config": {"workload": f"{'configs[1]' if world == 1 else 'configs[1] field x ' + str(world) + ' GPUs (tiled, ghost-floe halo)'}: {cfg['n_floes']} random-polygon floes (8-16 verts), doubly periodic "
-                                   f"box {cfg['L'] / 1e3:.0f} km, uniform_flow ocean 0.1 m/s, collisions + one-way "
-                                   f"coupling every step + rigid-body update, dt={cfg['dt']} s" if args.workload == "configs1" else
-                                   f"configs[{args.workload[-1]}]-style field ({wl}): {cfg['n_floes']} floes, box {cfg['L'] / 1e3:.0f} km, "
-                                   f"boundaries {cfg['kinds'][0]}, {len(cfg['topography'])} topography elements, dt={cfg['dt']} s",
+            "repeats": len(blocks), "ms_per_step_min": 1e3 * min(blocks) / args.steps, "ms_per_step_max": 1e3 * max(blocks) / args.steps,
+            "value_note": f"median of {len(blocks)} timed blocks of {args.steps} steps each (barrier + device sync on both sides of every block)",
+            "config": {"workload": (f"configs[1]: {cfg['n_floes']} random-polygon floes (8-16 verts), doubly periodic box {cfg['L'] / 1e3:.0f} km, "
+                                    f"uniform_flow ocean 0.1 m/s" if workload == "configs1" else
+                                    f"configs[2]: {cfg['n_floes']} random-polygon floes, doubly periodic box {cfg['L'] / 1e3:.0f} km, converge_diverge_flow ocean"
+                                    if workload == "configs2" else
+                                    f"configs[{int(workload[-1])}]-style field ({wl}): {cfg['n_floes']} floes, box {cfg['L'] / 1e3:.0f} km, boundaries {cfg['kinds'][0]}, "
+                                    f"{len(cfg['topography'])} topography elements") +
+                                   f"; collisions + one-way coupling every {coupling_dt} step(s) + rigid-body update, dt={cfg['dt']} s" +
+                                   (f"; {world} spatial tiles, one-deep ghost-floe halo per step" if tiled else ""),
                        "n_floes": cfg["n_floes"], "seed": cfg["seed"], "coupling_dt": coupling_dt, "two_way_coupling": bool(args.two_way),
-                       "tiles": 1 if world == 1 else world},
-            "roofline": {"bound": "hbm", "kernel": "sz_k_narrow<8,20,8,16,4,64,0,0,3>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                       "tiles": world if tiled else 1},
+            "roofline": {"bound": "hbm", "kernel": NARROW_KERNEL, "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "measured_copy_ceiling": ceiling, "frac_of_measured_ceiling": achieved / ceiling if ceiling > 0 else None,
-                         "kernel_ms": narrow_ms, "algorithmic_bytes_per_launch": b_narrow,
-                         "step_algorithmic_bytes": step_algorithmic_bytes(st),
-                         "step_frac": step_algorithmic_bytes(st) / (el / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         "kernel_ms": narrow_ms, "kernel_launches_timed": n_launch, "algorithmic_bytes_per_launch": b_narrow,
+                         "counts_per_launch": win, "counts_note": "device counters accumulated over the launches the event time averages",
+                         "step_algorithmic_bytes": step_bytes,
+                         "step_frac": step_bytes / (el / args.steps) / 1e9 / HBM_PEAK_GBS},
             "kernel_ms_per_step": {k: (v[0] / nb) for k, v in kt_all.items()},
             "kernel_ms_per_step_note": f"separate untimed pass of {nb} steps with all kernel classes event-timed",
             "counts": {k: st[k] for k in ("M", "N", "n_ghosts", "n_pairs", "n_pairs_clipped", "n_pair_rows", "n_elem_rows",
                                            "n_inter_rows", "n_ring_points", "n_sub_points", "n_trace_fail", "n_retry")},
+            "tags_at_end_of_timed_window": {"n_status_remove": st["n_status_remove"], "n_status_fuse": st["n_status_fuse"],
+                                            "note": "floes the reference's simplify_floes! would have acted on during the run (0 = the timed steps are the reference's trajectory)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg)

@@ -46,7 +46,9 @@ int main(void) {
   CHECK(sz_get_stats(ctx, &st));
   printf("pairs %lld, contact rows %lld\n", (long long)st.n_pairs, (long long)st.n_inter_rows);
   CHECK(sz_remove_ghosts(ctx));
-  CHECK(sz_step(ctx, 10, 0, 10, 10, SZ_COLLISIONS_ON));      /* ten timesteps, state resident on the device */
+  int32_t done = 0;
+  CHECK(sz_step(ctx, 10, 0, 10, 10, SZ_COLLISIONS_ON, &done));      /* ten timesteps, state resident on the device */
+  if (done != 10) { fprintf(stderr, "the batch stopped after %d steps: a floe was tagged\n", done); return 1; }
   double ucol[2];
   memset(&c, 0, sizeof(c)); c.u = ucol;
   CHECK(sz_download_floes(ctx, &c));

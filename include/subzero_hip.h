@@ -53,7 +53,9 @@ enum { SZ_OPEN = 0, SZ_PERIODIC = 1, SZ_COLLISION = 2, SZ_MOVING = 3 };       /*
 enum { SZ_NORTH = 0, SZ_SOUTH = 1, SZ_EAST = 2, SZ_WEST = 3 };                /* boundary order  */
 enum { SZ_ACTIVE = 1, SZ_REMOVE = 2, SZ_FUSE = 3 };                           /* floe.jl:8-12    */
 /* process switches for sz_step (CollisionSettings.collisions_on, CouplingSettings.coupling_on) */
-enum { SZ_COLLISIONS_ON = 1, SZ_COUPLING_ON = 2 };
+enum { SZ_COLLISIONS_ON = 1, SZ_COUPLING_ON = 2,
+       SZ_NO_STOP = 4 };   /* sz_step: run all nsteps even when a floe gets tagged remove / fuse (departs from the reference,
+                              which runs simplify_floes! after every step: measurement and soak runs only) */
 
 typedef struct {
   double E, nu, mu, rho_o, rho_a, Cd_io, Cd_ia, f, turn_theta;
@@ -97,6 +99,14 @@ typedef struct {
   int64_t n_status_remove;      /* floes tagged remove / fuse: when both are zero the host-side simplify_floes!  */
   int64_t n_status_fuse;        /* (simulation.jl:206) has no removal or fusion to do and needs no download       */
   int64_t n_retry;              /* narrow-phase items redone by the largest kernel variant (working set overflow), cumulative */
+  /* cumulative since the last sz_profile_reset: what the narrow phase did over a window of steps (bench.py prices the
+     dominant kernel's algorithmic bytes with the counts of the very launches whose time it averages) */
+  int64_t acc_narrow_launches;  /* launches of the first narrow variant (= collision steps)                    */
+  int64_t acc_pair_items;       /* pair items run (pairs whose ring boxes overlap)                              */
+  int64_t acc_pair_ring_points; /* sum over those items of both rings' point counts                              */
+  int64_t acc_pair_rows;        /* floe-floe contact rows before mirroring                                       */
+  int64_t acc_elem_items;       /* floe-boundary / floe-topography items run                                     */
+  int64_t acc_elem_rows;
 } sz_stats;
 
 /* kernel classes for sz_kernel_time_ms */
@@ -126,7 +136,13 @@ int sz_set_fields(sz_ctx *ctx, int32_t Nx, int32_t Ny, double x0, double xf, dou
 
 /* ---- floe state */
 /* M rows, of which the first N are parents; M > N only when the caller ran add_ghosts!
-   itself, in which case ghost_off/ghost_idx must be given */
+   itself, in which case ghost_off/ghost_idx must be given.
+   floe.interactions is ragged and not part of the column struct: the rows the last collision call left on the
+   device stay valid across an upload of the same M (the shim's re-upload between timestep_collisions! and
+   timestep_floe_properties!, whose calc_stress! reads them); an upload of another size drops them, and
+   sz_timestep_floe_properties / sz_calc_stress then fail with SZ_E_STATE until sz_upload_interactions (the
+   matrices the host holds, possibly empty) or a collision call provides rows again.  A context that is given
+   a DIFFERENT field of the same size must be told so with sz_upload_interactions. */
 int sz_upload_floes(sz_ctx *ctx, int64_t M, int64_t N, const sz_floe_columns *cols);
 int sz_get_stats(sz_ctx *ctx, sz_stats *out);
 /* copies every non-NULL column (sized from sz_get_stats) */
@@ -180,9 +196,16 @@ int sz_two_way_finish(sz_ctx *ctx, const void *d_partial, int32_t dt);
 int sz_upload_interactions(sz_ctx *ctx, const int32_t *inter_off, const double *rows);
 int sz_calc_stress(sz_ctx *ctx);
 int sz_calc_strain(sz_ctx *ctx);
-/* nsteps x timestep_sim! with the state resident in HBM; tstep counts from tstep0 */
+/* nsteps x timestep_sim! with the state resident in HBM; tstep counts from tstep0.
+   The reference runs simplify_floes! (host work: fuse, remove, smooth, simulation.jl:205-214) at the end of EVERY
+   step.  The batch therefore ends after the first step that leaves a parent tagged remove or fuse: the launches of
+   the remaining steps are already enqueued and return at once.  *steps_done (may be NULL) = steps actually run
+   (== nsteps when nothing was tagged); the state is that of the reference after steps_done steps, status.fuse_idx
+   (sz_download_fuse) included, and the host resumes with sz_step(nsteps - steps_done, tstep0 + steps_done, ...) after
+   its simplify_floes! (and the upload that follows it).  Floes already tagged at entry end the batch after one
+   step.  SZ_NO_STOP in flags runs all steps regardless. */
 int sz_step(sz_ctx *ctx, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupling_dt,
-            int32_t flags);
+            int32_t flags, int32_t *steps_done);
 
 /* ---- measurement: HIP-event time per kernel class, accumulated since the last reset, on the
    stream the kernels are launched on; launches = number of timed launches of that class.

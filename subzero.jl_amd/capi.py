@@ -16,7 +16,7 @@ _lp = C.POINTER(C.c_int64)
 OPEN, PERIODIC, COLLISION, MOVING = 0, 1, 2, 3
 NORTH, SOUTH, EAST, WEST = 0, 1, 2, 3
 ACTIVE, REMOVE, FUSE = 1, 2, 3
-COLLISIONS_ON, COUPLING_ON = 1, 2
+COLLISIONS_ON, COUPLING_ON, NO_STOP = 1, 2, 4
 K_GHOSTS, K_BROAD, K_NARROW, K_REDUCE, K_FORCING, K_INTEGRATE, K_NARROW_LARGE = range(7)
 KERNEL_CLASS_NAMES = ["ghosts", "broad", "narrow", "reduce", "forcing", "integrate", "narrow_large"]
 
@@ -45,7 +45,8 @@ class SzStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in
                 ("M", "N", "n_ring_points", "n_sub_points", "n_pairs", "n_pair_ring_points", "n_pair_rows",
                  "n_elem_items", "n_elem_rows", "n_inter_rows", "n_ghosts",
-                 "warn_height", "warn_force", "warn_vel", "warn_xi", "n_trace_fail", "n_halo", "n_pairs_clipped", "n_status_remove", "n_status_fuse", "n_retry")]
+                 "warn_height", "warn_force", "warn_vel", "warn_xi", "n_trace_fail", "n_halo", "n_pairs_clipped", "n_status_remove", "n_status_fuse", "n_retry",
+                 "acc_narrow_launches", "acc_pair_items", "acc_pair_ring_points", "acc_pair_rows", "acc_elem_items", "acc_elem_rows")]
 
 
 EXPORTS = [
@@ -106,7 +107,7 @@ def load(build_if_missing=True):
     L.sz_collide_domain.argtypes = [C.c_void_p, C.c_int32, C.c_double]
     L.sz_timestep_coupling.argtypes = [C.c_void_p]
     L.sz_timestep_floe_properties.argtypes = [C.c_void_p, C.c_int32]
-    L.sz_step.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.sz_step.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip]
     L.sz_set_two_way.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32]
     L.sz_set_temps.argtypes = [C.c_void_p, _dp, _dp]
     L.sz_set_precision.argtypes = [C.c_void_p, C.c_int32]

@@ -53,6 +53,9 @@ struct sz_ctx {
   Params P{};
   std::string err;
   Pool allocs;        // per-upload allocations
+  Pool inter_allocs;  // floe.interactions (inter_cnt, inter_rows): survive an upload of the same size -- a shim uploads between
+                      // timestep_collisions! and timestep_floe_properties!, and calc_stress! reads the rows of the collisions
+  int inter_capM = 0; bool inter_any = false, inter_lost = false;
   Pool static_allocs; // domain element table
   Pool field_allocs;  // ocean / atmosphere lattices
   bool have_floes = false, have_domain = false, have_fields = false;
@@ -79,7 +82,7 @@ struct sz_ctx {
   int precision = 0; bool mixed_pts_ok = false, mixed_nodes_ok = false; Pool mixed_pt_allocs, mixed_node_allocs;
   // two-way coupling (off by default, like CouplingSettings())
   bool tw_general_clip = false;   // SZ_TW_GENERAL_CLIP=1: floe-in-cell areas by the general clipper (8 lanes per entry) instead of the rectangle pipeline
-  bool two_way = false; int tw_dt = 10; int tw_capM = 0; size_t tw_ncell = 0;
+  bool two_way = false; int tw_dt = 10; int tw_capM = 0; size_t tw_ncell = 0; bool temps_set = false;
   Pool tw_allocs, tw_field_allocs;
   // static broad-phase grid of the resident steps (fixed by the host: no bounds reduction per step)
   bool fuse_forcing = true;         // forcings inside the neighbour launch (sz_k_neighbors_forcing); SZ_FUSE_FORCING=0: own launch
@@ -518,9 +521,12 @@ void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool 
 
 // exact host replay of the fuse bookkeeping (collisions.jl:367-368 and :801-806) for the rare
 // steps in which a pair exceeded max_overlap
-int host_fuse_fixup(sz_ctx* c, const int* h, bool mirror) {
+// after_step (sz_step): the ghosts of the step have already been detached (C_M == N; their rows and the pair arrays are
+// still in place) and the integrator has run since: a floe the coupling marked for removal stays `remove`
+// (timestep_coupling! follows timestep_collisions! in timestep_sim!, simulation.jl:109-161)
+int host_fuse_fixup(sz_ctx* c, const int* h, bool mirror, bool after_step = false, bool coupled = false) {
   State& S = c->S;
-  int M = h[C_M], P = h[C_NPAIRS];
+  int M = after_step ? h[C_N] + h[C_NGHOSTS] : h[C_M], P = h[C_NPAIRS];
   if ((int)c->fuse_lists.size() < M) c->fuse_lists.resize(M);
   if (P == 0) return SZ_OK;
   std::vector<int> fl(P), pi(P), pj(P);
@@ -539,6 +545,11 @@ int host_fuse_fixup(sz_ctx* c, const int* h, bool mirror) {
       size_t n = c->fuse_lists[i].size();
       for (size_t k = 0; k < n; k++) { int idx = c->fuse_lists[i][k]; tag[idx] = SZ_FUSE; c->fuse_lists[idx].push_back(i); }
     }
+  }
+  if (after_step && coupled) {
+    std::vector<int> rm(h[C_N]);
+    HIPCHK(c, hipMemcpy(rm.data(), S.frc_remove, (size_t)h[C_N] * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < h[C_N]; i++) if (rm[i]) tag[i] = SZ_REMOVE;
   }
   HIPCHK(c, hipMemcpy(S.status, tag.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice));
   return SZ_OK;
@@ -575,7 +586,9 @@ sz_ctx* sz_create(int device_id) {
   P.fcor = 1.4e-4; P.turn = 15.0 * 3.14159265358979323846 / 180.0; P.ff_max_overlap = 0.55; P.fd_max_overlap = 0.75;
   P.rho_i = 920.0; P.max_h = 10.0; P.max_xi = 1e-5; P.lambda = 0.2; P.dd = 1;
   P.Cd_ao = 1.25e-3; P.k_ice = 2.14; P.L_ice = 2.93e5;
-  if (hipMalloc((void**)&c->d_stats, 12 * sizeof(long long)) != hipSuccess) { delete c; return nullptr; }
+  if (hipMalloc((void**)&c->d_stats, 16 * sizeof(long long)) != hipSuccess) { delete c; return nullptr; }
+  if (hipMalloc((void**)&c->S.acc, (size_t)ACC_SLOTS * 8 * sizeof(unsigned long long)) != hipSuccess) { delete c; return nullptr; }
+  (void)hipMemset(c->S.acc, 0, (size_t)ACC_SLOTS * 8 * sizeof(unsigned long long));
   return c;
 }
 
@@ -583,10 +596,10 @@ void sz_destroy(sz_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  free_pool(c->allocs); free_pool(c->static_allocs); free_pool(c->field_allocs); free_pool(c->tw_allocs); free_pool(c->tw_field_allocs);
+  free_pool(c->allocs); free_pool(c->inter_allocs); free_pool(c->static_allocs); free_pool(c->field_allocs); free_pool(c->tw_allocs); free_pool(c->tw_field_allocs);
   free_pool(c->mixed_pt_allocs); free_pool(c->mixed_node_allocs);
   for (auto& e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  (void)hipFree(c->d_stats);
+  (void)hipFree(c->d_stats); (void)hipFree(c->S.acc);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2);
   (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
@@ -634,7 +647,10 @@ int sz_set_fields(sz_ctx* c, int32_t Nx, int32_t Ny, double x0, double xf, doubl
   (void)hipSetDevice(c->device);
   State& S = c->S;
   size_t n = (size_t)(Nx + 1) * (Ny + 1);
-  free_pool(c->field_allocs); free_pool(c->tw_field_allocs); c->tw_ncell = 0;
+  free_pool(c->field_allocs);
+  // the ocean / atmosphere temperatures (sz_set_temps) and the stress fields stay when the lattice keeps its shape:
+  // re-uploading changing currents into one context must not reset them to zero
+  if (c->tw_ncell != n) { free_pool(c->tw_field_allocs); c->tw_ncell = 0; c->temps_set = false; }
   double** dst[5] = { &S.uo, &S.vo, &S.hf, &S.ua, &S.va };
   const double* src[5] = { uocn, vocn, hflx, uatm, vatm };
   for (int k = 0; k < 5; k++) {
@@ -724,7 +740,17 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(el_off, S.capM + 2); DA(el_floe, S.capElem); DA(el_elem, S.capElem);
   size_t items = (size_t)S.capPairs + S.capElem;
   DA(it_rows, items * ROWS_PER_ITEM * 5); DA(it_nrows, items); DA(it_flags, items);
-  DA(inter_cnt, S.capM + 1); DA(inter_off, S.capM + 2); DA(inter_rows, (size_t)S.capM * ROWCAP * 7);
+  DA(inter_off, S.capM + 2);
+  // floe.interactions is part of the floe state, but not of sz_floe_columns (it is ragged): the rows the last
+  // collision call left stay valid across an upload of the same size; after an upload of another size they are
+  // gone, and sz_timestep_floe_properties / sz_calc_stress refuse to run on nothing (SZ_E_STATE) until
+  // sz_upload_interactions or a collision call provides them again
+  if (c->inter_capM != S.capM || c->inter_allocs.empty()) {
+    free_pool(c->inter_allocs);
+    if ((rc = dalloc(c, &S.inter_cnt, (size_t)S.capM + 1, c->inter_allocs))) return rc;
+    if ((rc = dalloc(c, &S.inter_rows, (size_t)S.capM * ROWCAP * 7, c->inter_allocs))) return rc;
+    c->inter_capM = S.capM; c->inter_lost = c->inter_any; c->inter_any = false;
+  }
   DA(blk, std::max(S.capCells, std::max(S.capM, 1024)) / SCAN_B + 1024);
   DA(tagA, S.capM + 1);
   DA(stamps, 512);
@@ -748,9 +774,9 @@ int sz_get_stats(sz_ctx* c, sz_stats* out) {
   (void)hipSetDevice(c->device);
   tile_cleanup(c);
   State& S = c->S;
-  HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 12 * sizeof(long long), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 16 * sizeof(long long), c->stream));
   hipLaunchKernelGGL(sz_k_stats, dim3(grid_for((long long)S.capPairs + S.capElem, 256, 1024)), dim3(256), 0, c->stream, S, c->d_stats);
-  int h[C_COUNT]; long long st[12];
+  int h[C_COUNT]; long long st[16];
   HIPCHK(c, hipMemcpyAsync(st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(h, S.cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -765,6 +791,8 @@ int sz_get_stats(sz_ctx* c, sz_stats* out) {
   out->n_pairs_clipped = h[C_NWORK];
   out->n_status_remove = st[4]; out->n_status_fuse = st[5];
   out->n_retry = h[C_NRETRY];
+  out->acc_narrow_launches = st[10]; out->acc_pair_items = st[11]; out->acc_pair_ring_points = st[12];
+  out->acc_pair_rows = st[13]; out->acc_elem_items = st[14]; out->acc_elem_rows = st[15];
   return SZ_OK;
 }
 
@@ -891,6 +919,7 @@ int sz_timestep_collisions(sz_ctx* c, int64_t n_init, int32_t dt) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
   collisions(c, (int)n_init, dt);
+  c->inter_any = true; c->inter_lost = false;
   int h[C_COUNT];
   int rc = sync_and_check(c, h);
   if (rc) return rc;
@@ -916,6 +945,7 @@ int sz_collide_pairs(sz_ctx* c, int64_t np, const int32_t* pi, const int32_t* pj
   stage_elems(c, false);
   stage_narrow(c, dt, max_overlap, c->P.fd_max_overlap);
   stage_reduce(c, 0, c->hostN, dt);
+  c->inter_any = true; c->inter_lost = false;
   int h[C_COUNT];
   int rc = sync_and_check(c, h);
   if (rc) return rc;
@@ -930,6 +960,7 @@ int sz_collide_domain(sz_ctx* c, int32_t dt, double max_overlap) {
   stage_elems(c, true);
   stage_narrow(c, dt, c->P.ff_max_overlap, max_overlap);
   stage_reduce(c, 0, c->hostN, dt);
+  c->inter_any = true; c->inter_lost = false;
   return sync_and_check(c);
 }
 
@@ -963,6 +994,7 @@ int sz_set_temps(sz_ctx* c, const double* t_ocn, const double* t_atm) {
   int rc = ensure_two_way(c); if (rc) return rc;
   H2D(c->S.t_ocn, t_ocn, c->tw_ncell, double); H2D(c->S.t_atm, t_atm, c->tw_ncell, double);
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->temps_set = true;
   return SZ_OK;
 }
 int sz_download_ocean_stress(sz_ctx* c, double* tau_x, double* tau_y, double* si_frac, double* hflx) {
@@ -978,8 +1010,17 @@ int sz_download_ocean_stress(sz_ctx* c, double* tau_x, double* tau_y, double* si
   return SZ_OK;
 }
 
+namespace {
+int need_interactions(sz_ctx* c) {
+  if (!c->inter_lost) return SZ_OK;
+  c->err = "the interaction rows of the last collision call were dropped by an upload of another size: "
+           "sz_upload_interactions (floe.interactions of every floe, possibly empty) or a collision call must come first";
+  return SZ_E_STATE;
+}
+}  // namespace
 int sz_timestep_floe_properties(sz_ctx* c, int32_t dt) {
   if (!c || !c->have_floes) return SZ_E_STATE;
+  if (int rc = need_interactions(c)) return rc;
   (void)hipSetDevice(c->device);
   stage_integrate(c, dt, true, false);
   return sync_and_check(c);
@@ -993,6 +1034,13 @@ int sz_upload_interactions(sz_ctx* c, const int32_t* off, const double* rows) {
   tile_cleanup(c);
   State& S = c->S;
   const int M = c->hostM;
+  if (off[M] == 0) {           // no floe has interactions (fresh floes): the counts are all there is to say
+    HIPCHK(c, hipMemsetAsync(S.inter_cnt, 0, (size_t)M * sizeof(int), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->inter_any = true; c->inter_lost = false;
+    return SZ_OK;
+  }
+  if (!rows) return SZ_E_ARG;
   std::vector<int> cnt(M); std::vector<double> buf((size_t)M * ROWCAP * 7, 0.0);
   for (int i = 0; i < M; i++) {
     int k = off[i + 1] - off[i];
@@ -1003,11 +1051,13 @@ int sz_upload_interactions(sz_ctx* c, const int32_t* off, const double* rows) {
   H2D(S.inter_cnt, cnt.data(), M, int);
   H2D(S.inter_rows, buf.data(), (size_t)M * ROWCAP * 7, double);
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->inter_any = true; c->inter_lost = false;
   return SZ_OK;
 }
 // calc_stress! (update_floe.jl:392-414) and calc_strain! (:425-453) on their own, for every floe
 int sz_calc_stress(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;
+  if (int rc = need_interactions(c)) return rc;
   (void)hipSetDevice(c->device);
   hipLaunchKernelGGL(sz_k_calc_stress, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P);
   return sync_and_check(c);
@@ -1019,21 +1069,31 @@ int sz_calc_strain(sz_ctx* c) {
   return sync_and_check(c);
 }
 
-int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupling_dt, int32_t flags) {
+int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupling_dt, int32_t flags, int32_t* steps_done) {
+  if (steps_done) *steps_done = 0;
   if (!c || !c->have_floes) return SZ_E_STATE;
+  if (nsteps < 0) return SZ_E_ARG;
   if ((flags & SZ_COUPLING_ON) && !c->have_fields) { c->err = "sz_set_fields must be called before coupling"; return SZ_E_STATE; }
   (void)hipSetDevice(c->device);
   const bool periodic = c->S.any_periodic_ew || c->S.any_periodic_ns;
   const bool coll = (flags & SZ_COLLISIONS_ON) != 0;
   if (c->two_way && (flags & SZ_COUPLING_ON)) {
     if (c->S.tiled) { c->err = "tiled contexts couple through sz_tile_step + sz_two_way_partial / sz_two_way_finish"; return SZ_E_STATE; }
+    if (!c->temps_set) { c->err = "two-way coupling needs sz_set_temps (after the sz_set_fields that fixed the lattice shape)"; return SZ_E_STATE; }
     int rc = ensure_two_way(c); if (rc) return rc;
   }
+  if (!coll) { if (int rc = need_interactions(c)) return rc; }
+  // the batch ends after the first step that leaves a parent tagged remove / fuse (simplify_floes!, simulation.jl:205-214,
+  // is the host's): the launches of the later steps are enqueued all the same and return at once (stopped())
+  c->S.stop_on_tags = (flags & SZ_NO_STOP) ? 0 : 1;
+  HIPCHK(c, hipMemsetAsync(c->S.cnt + C_STOP, 0, sizeof(int), c->stream));
+  bool last_coupled = false;
   const bool sg = coll && c->grid_ok && !c->no_static_grid;
   if (sg) use_static_grid(c);
   if (c->precision == 1 && !c->two_way && (flags & SZ_COUPLING_ON)) { int rc = ensure_mixed(c); if (rc) return rc; }
   for (int s = 0; s < nsteps; s++) {
     int tstep = tstep0 + s;
+    c->S.step = s + 1;
     const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
     const bool overlap = coupling && !c->two_way && (c->overlap_forcing != 0);
     // with collisions on, the ghosts of step s are detached by the ghost kernels of step s+1 (nothing
@@ -1052,8 +1112,25 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     if (overlap) stage_forcing_join(c);
     stage_integrate(c, dt, !coll, coupling, sg);
   }
+  c->S.step = 0;
+  if (coll) { c->inter_any = true; c->inter_lost = false; }
   if (coll && periodic) hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
-  return sync_and_check(c);
+  int h[C_COUNT];
+  int rc = sync_and_check(c, h);
+  if (rc) return rc;
+  const int done = h[C_STOP] > 0 ? h[C_STOP] : nsteps;
+  if (steps_done) *steps_done = done;
+  // status.fuse_idx of the step that ended the batch: the reference's serial propagation, replayed on the host as
+  // sz_timestep_collisions does (only that step can have produced fuse pairs: the batch stops on the first tag)
+  if (coll && done > 0) {
+    const int tlast = tstep0 + done - 1;
+    last_coupled = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tlast % coupling_dt) == 0;
+    if (h[C_STOP] > 0 || (flags & SZ_NO_STOP)) {
+      rc = host_fuse_fixup(c, h, true, true, last_coupled);
+      c->fuse_lists.resize(c->hostM);
+    }
+  }
+  return rc;
 }
 
 int sz_profile_enable(sz_ctx* c, int32_t on) {
@@ -1065,6 +1142,9 @@ int sz_profile_reset(sz_ctx* c) {
   if (!c) return SZ_E_ARG;
   for (int k = 0; k < NK; k++) { c->kms[k] = 0; c->kl[k] = 0; }
   c->ev_used = 0;
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipMemsetAsync(c->S.acc, 0, (size_t)ACC_SLOTS * 8 * sizeof(unsigned long long), c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return SZ_OK;
 }
 int sz_kernel_time_ms(sz_ctx* c, int32_t k, double* ms, int64_t* launches) {

@@ -52,28 +52,33 @@ SZ_DEV void gsync() {
 template <int CAP, int KC, int RC, int RM>
 struct GroupMem {
   static constexpr int RMAXV = RM;
+  // (members ordered by alignment -- doubles, 4-byte, 2-byte, bytes -- so that the struct has no padding: eight of
+  //  them must stay within 16 KB for ten workgroups per CU)
   double ax[CAP], ay[CAP], bx[CAP], by[CAP];
   double cta[KC], ctb[KC], cx[KC], cy[KC];   // crossings in canonical (ia, ib) order
   double reg[2][2][RC];                      // region rings [clip][x|y][point]; reg[1] doubles as the
                                              // raw crossing slots during detection (4*KC <= 2*RC)
   double rarea[2][RM];
   double rcx[RM], rcy[RM];                   // centroids of the regions of clip 0
-  uint32_t cinfo[KC];                        // per crossing: ia | ib<<7 | rankA<<14 | rankB<<20 | flags<<26
-  int16_t cia[KC], cib[KC], ria[KC], rib[KC];
-  int16_t rnkB[KC];                          // scratch of match_vertices
-  int16_t midx[KC];                          // matched region-vertex index per ipoint
-  uint8_t ordA[KC], ordB[KC];                // crossing id at rank r along a / b
-  int16_t roff[2][RM + 2];
-  uint8_t cfl[KC], rfl[KC], uniq[KC];
-  int8_t ecode[RC];                          // many-intersect per-edge class
-  uint8_t ea[CAP], eb[CAP];                  // edges of a / b that reach into the overlap box
   // per-item scalars live here rather than in registers across the clips (the kernel's register
   // budget decides how many items the chip holds in flight):
   double kin[14];                            // i: cx cy u v xi, j: cx cy u v xi, area_i h_i area_j h_j
   double dlv[RM], dxv[RM], dyv[RM];          // per kept region: contact length and force direction
-  int8_t keep[RM];
+  uint32_t cinfo[KC];                        // per crossing: ia | ib<<7 | rankA<<14 | rankB<<20 | flags<<26
   int nraw, nx, nreg[2], flag, err, ntracefail, nea, neb;
+  unsigned acc[2];                           // work counters of the group: ring points of its pair items, pair rows
+  uint16_t acc16[3];                         // ... pair items, element items, element rows (a group runs a few dozen items per launch)
+  int16_t cia[KC], cib[KC], ria[KC], rib[KC];
+  int16_t rnkB[KC];                          // scratch of match_vertices
+  int16_t midx[KC];                          // matched region-vertex index per ipoint
+  int16_t roff[2][RM + 2];
+  uint8_t ordA[KC], ordB[KC];                // crossing id at rank r along a / b
+  uint8_t cfl[KC], rfl[KC], uniq[KC];
+  int8_t ecode[RC];                          // many-intersect per-edge class
+  uint8_t ea[CAP], eb[CAP];                  // edges of a / b that reach into the overlap box
+  int8_t keep[RM];
 };
+static_assert(sizeof(GroupMem<20, 8, 16, 4>) <= 2048, "eight groups of the first narrow variant must fit 16 KB");
 
 enum { ERR_CAP_RING = 1, ERR_CAP_XING = 2, ERR_CAP_REGION = 4, ERR_CAP_ROWS = 8, ERR_TRACE = 16,
        ERR_CAP_NEIGH = 32, ERR_CAP_PAIRS = 64, ERR_CAP_ELEM = 128, ERR_CAP_INTER = 256,

@@ -22,6 +22,18 @@ using namespace szg;
 #define SZ_REMOVE 2
 #define SZ_FUSE 3
 
+// Resident batches (sz_step) stop after the step in which a floe was tagged remove / fuse: the reference runs
+// simplify_floes! after every step (simulation.jl:205-214), and that is host work.  The launches of the later steps
+// are already enqueued; each of them asks this first and returns at once.  S.step is the 1-based step of the launch
+// inside its batch (kernarg), cnt[C_STOP] the step that asked for the stop (0: none).
+__device__ __forceinline__ bool stopped(const State& S) {
+  const int s = S.cnt[C_STOP];
+  return s != 0 && S.step > s;
+}
+__device__ __forceinline__ void request_stop(const State& S) {
+  if (S.step > 0 && S.stop_on_tags) S.cnt[C_STOP] = S.step;      // every requester of a step writes the same value
+}
+
 // ============================================================================ scan (exclusive, int)
 constexpr int SCAN_B = 1024;
 
@@ -303,6 +315,7 @@ __device__ __forceinline__ int4 ghost_plan(State& S, int i, int N, int drop_old,
 // not wait for the counter block; < 0: read it
 __global__ void __launch_bounds__(SCAN_B) sz_k_ghost_flag_scan(State S, int drop_old, int commit, unsigned epoch, int nh) {
   __shared__ int4 tot;
+  if (stopped(S)) return;
   const int n = nh >= 0 ? nh : S.cnt[C_N];
   const int base = blockIdx.x * SCAN_B;
   if (base >= n && blockIdx.x != 0) return;          // tiles past the end: nobody waits for them
@@ -355,6 +368,7 @@ __device__ __forceinline__ void rig_store(State& S, int lane, int f, int vo, int
 
 // gscan4 holds the exclusive int4 scan of gplan, gtot4[0] the totals
 __global__ void __launch_bounds__(256) sz_k_ghost_fill(State S, int committed, int bin, int nh) {
+  if (stopped(S)) return;
   const GridGeo geo = grid_geo(S);
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -475,6 +489,7 @@ __global__ void sz_k_remove_ghosts(State S, int drop_halo) {
 __global__ void __launch_bounds__(1024) sz_k_bounds(State S, int commit_ghosts) {
   __shared__ double sh[5][16];
   __shared__ int s_ncells;
+  if (stopped(S)) return;
   if (threadIdx.x < WARN_SLOTS * 4) S.warn[(threadIdx.x >> 2) * 32 + (threadIdx.x & 3)] = 0;   // guards of the coming update
   if (commit_ghosts) {
     if (threadIdx.x == 0) ghost_commit(S);
@@ -529,6 +544,7 @@ __global__ void __launch_bounds__(1024) sz_k_bounds(State S, int commit_ghosts) 
 // parents_only: the resident steps keep the lists current themselves (the kernels that place a floe -- integrator,
 // ghost fill, halo unpack -- also bin it); this launch then only seeds them with the parents once.
 __global__ void sz_k_cell_build(State S, int parents_only) {
+  if (stopped(S)) return;
   int M = parents_only ? S.cnt[C_N] : S.cnt[C_M];
   const GridGeo g = grid_geo(S);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) cell_insert(S, g, i, S.cx[i], S.cy[i]);
@@ -580,6 +596,7 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   __shared__ int cnts[GPB][2];
   __shared__ int wmask[GPB];
   const int gl = threadIdx.x % NB_G, gi = threadIdx.x / NB_G;
+  if (stopped(S)) return;
   int M = S.cnt[C_M];
   const GridGeo g = grid_geo(S);
   const int ncx = g.ncx, ncy = g.ncy;
@@ -657,6 +674,7 @@ __global__ void __launch_bounds__(NB_TPB) sz_k_neighbors(State S) { neighbors_bo
 // cleared for the next step and the per-step counters reset
 __global__ void __launch_bounds__(SCAN_B) sz_k_pscan_fill(State S, unsigned epoch, int housekeeping) {
   __shared__ int4 tot;
+  if (stopped(S)) return;
   const int n = S.cnt[C_M];
   const int base = blockIdx.x * SCAN_B;
   if (housekeeping) {
@@ -719,6 +737,7 @@ __device__ __forceinline__ void elem_candidates(const State& S, int k, F&& emit)
 // count, scan (look-back) and fill of the floe-element items in one launch
 __global__ void __launch_bounds__(SCAN_B) sz_k_elem_scan_fill(State S, unsigned epoch) {
   __shared__ int4 tot;
+  if (stopped(S)) return;
   const int M = S.cnt[C_M];
   const int base = blockIdx.x * SCAN_B;
   if (base >= M && blockIdx.x != 0) return;
@@ -749,12 +768,13 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
   constexpr int GPB = TPB / G;
   static_assert(4 * KC <= 2 * RC, "raw crossing slots alias reg[1]");
   if (CLS > 0 && S.cnt[C_ITEMCLASS] < CLS) return;   // no item needs this (larger) variant this step
+  if (stopped(S)) return;
   __shared__ GroupMem<CAP, KC, RC, RM> mem[GPB];
   const int gl = threadIdx.x % G, gi = threadIdx.x / G;
   GroupMem<CAP, KC, RC, RM>& m = mem[gi];
   const int npairs = S.cnt[C_NWORK], nel = S.cnt[C_NELEM];     // pair items = the work list (ring boxes overlap)
   const int nitems = npairs + nel;
-  if (gl == 0) { m.err = 0; m.ntracefail = 0; }
+  if (gl == 0) { m.err = 0; m.ntracefail = 0; m.acc[0] = m.acc[1] = 0; m.acc16[0] = m.acc16[1] = m.acc16[2] = 0; }   // acc: work done by this group (in LDS: no register held across the rounds)
   Stamps st; STAMP_INIT(st);
 #ifdef SZ_STAMPS
   st.on = (CLS == 0 && blockIdx.x == (unsigned)(dbg >> 8) && threadIdx.x == 0); st.log = S.stamps + 1;
@@ -845,7 +865,12 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       gsync();
       if (gl == 0) { m.err &= ~CAPBITS; atomicMax(&S.cnt[C_ITEMCLASS], 2); atomicAdd(&S.cnt[C_NRETRY], 1); }   // the largest variant retries
     }
-    if (gl == 0) { S.it_nrows[item] = nrows; S.it_flags[item] = flags; }
+    if (gl == 0) {
+      S.it_nrows[item] = nrows; S.it_flags[item] = flags;
+      if (!(flags & IT_RETRY)) {                           // counted by the variant that finishes the item
+        if (is_pair) { m.acc16[0]++; m.acc[0] += (unsigned)(na + nb); m.acc[1] += (unsigned)nrows; } else { m.acc16[1]++; m.acc16[2] += (uint16_t)nrows; }
+      }
+    }
     STAMP(st, 11);
 #ifdef SZ_STAMPS
     if (st.on) { if (nrows > 0) { S.stamps[0] = st.n; st.on = false; } else { st.n = 0; st.t0 = clock64(); } }
@@ -861,6 +886,16 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
   gsync();
   if (gl == 0 && m.err) atomicOr(&S.cnt[C_ERR], m.err);
   if (gl == 0 && m.ntracefail) atomicAdd(&S.cnt[C_TRACE_FAIL], m.ntracefail);
+  {
+    // one set of atomics per wavefront, spread over ACC_SLOTS lines (same-address atomics serialise chip-wide)
+    unsigned v[5];
+    for (int k = 0; k < 5; k++) { v[k] = gl != 0 ? 0u : k == 0 ? m.acc16[0] : k == 1 ? m.acc[0] : k == 2 ? m.acc[1] : k == 3 ? m.acc16[1] : m.acc16[2]; for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d); }
+    if ((threadIdx.x & 63) == 0) {
+      unsigned long long* a = S.acc + (size_t)((blockIdx.x * (TPB / 64) + (threadIdx.x >> 6)) % ACC_SLOTS) * 8;
+      for (int k = 0; k < 5; k++) if (v[k]) atomicAdd(a + 1 + k, (unsigned long long)v[k]);
+      if (CLS == 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a, 1ull);
+    }
+  }
 #ifdef SZ_STAMPS
   // lifetimes of the wavefronts (4096-cycle buckets: stamps[256 + bucket]) and their mean by the largest row
   // count among the wavefront's items (stamps[400 + 2r] cycles, [401 + 2r] wavefronts)
@@ -881,6 +916,7 @@ constexpr int NARROW_CAP0 = 20, NARROW_CAP1 = 32, NARROW_CAP2 = 128;   // ring p
 
 // items not touched by any narrow variant would keep stale row counts: clear them first
 __global__ void sz_k_items_clear(State S) {
+  if (stopped(S)) return;
   int npairs = S.cnt[C_NWORK], nel = S.cnt[C_NELEM];
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < npairs + nel; t += gridDim.x * blockDim.x) {
     // size class of the item: which narrow-phase variant takes it
@@ -956,7 +992,9 @@ __device__ __forceinline__ int emit_rows(const State& S, int lane, int f, double
 }
 // mirror pass, ghost fold, torque and totals (collisions.jl:799-862)
 __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int n_init_arg) {
+  if (stopped(S)) return;
   const int M = S.cnt[C_M];
+  const int nparents = S.cnt[C_NOWN];
   const int n_init = n_init_arg >= 0 ? n_init_arg : S.cnt[C_N];   // < 0: every parent on the device
   const int lane = threadIdx.x % IF_G, gpb = blockDim.x / IF_G;
   for (int k = blockIdx.x * gpb + threadIdx.x / IF_G; k < M; k += gridDim.x * gpb) {
@@ -997,6 +1035,7 @@ __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int 
     }
     if (lane == 0) {
       S.status[k] = st; S.tagA[k] = tagA;
+      if (st != SZ_ACTIVE && k < nparents) request_stop(S);        // simplify_floes! has work after this step
       S.inter_cnt[k] = c;
       S.cfx[k] = totals ? fx : 0.0; S.cfy[k] = totals ? fy : 0.0; S.ctrq[k] = totals ? tq : 0.0;
       S.overarea[k] += over;
@@ -1015,7 +1054,7 @@ __global__ void sz_k_inter_compact(State S, double* dst) {
 // update_boundaries!, collisions.jl:565-571, boundaries.jl:526-568 (MovingBoundary only)
 __global__ void sz_k_update_boundaries(State S, int dt) {
   int e = threadIdx.x;
-  if (blockIdx.x != 0 || e >= 4 || S.ekind[e] != 3) return;
+  if (blockIdx.x != 0 || e >= 4 || S.ekind[e] != 3 || stopped(S)) return;
   double* rc = S.erect + e * 4;   // xmin, xmax, ymin, ymax
   if (e < 2) { double dy = S.ev[e] * dt; rc[2] += dy; rc[3] += dy; S.eval[e] += dy; }
   else { double dx = S.eu[e] * dt; rc[0] += dx; rc[1] += dx; S.eval[e] += dx; }
@@ -1095,6 +1134,7 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
   int* const skey_w = TW ? pkey_w + pmax : nullptr;
   signed char* const pcode_w = TW ? (signed char*)((int*)(tw_lds + (size_t)TW_FPB * 2 * pmax) + (size_t)TW_FPB * (pmax + FC_CAP)) + (size_t)wid * (pmax + FC_CAP) : nullptr;
   signed char* const scode_w = TW ? pcode_w + pmax : nullptr;
+  if (stopped(S)) return;
   int N = S.cnt[C_NOWN];
   int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
   double cturn = cos(P.turn), sturn = sin(P.turn);
@@ -1238,6 +1278,7 @@ __device__ __forceinline__ float sample_field32(const float* nodes, int f, const
   return (1.0f - tx) * c0 + tx * c1;
 }
 __device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, int bid, int nblk) {
+  if (stopped(S)) return;
   int N = S.cnt[C_NOWN];
   int lane = threadIdx.x % FRC_G, wpb = blockDim.x / FRC_G, wid = threadIdx.x / FRC_G;
   int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
@@ -1345,6 +1386,7 @@ constexpr int MV_RING = 20;
 template <bool MOVE>
 __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Params P, int dt, int apply_frc, int bin, int nh) {
   const GridGeo geo = grid_geo(S);
+  if (stopped(S)) return;
   const int N = nh >= 0 ? nh : S.cnt[C_NOWN];     // nh: see sz_k_ghost_flag_scan
   int wh = 0, wf = 0, wv = 0, wx = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
@@ -1411,7 +1453,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
     double nxi = xi + 1.5 * dt * dxidt - 0.5 * dt * p_dxidt;
     if (fabs(nxi) > P.max_xi) { nxi = sgn(nxi) * P.max_xi; wx++; }
     // ---- stores
-    if (frc_rm) S.status[i] = SZ_REMOVE;
+    if (frc_rm) { S.status[i] = SZ_REMOVE; request_stop(S); }
     for (int k = 0; k < 4; k++) { S.sa[i * 4 + k] = (1 - l) * sa0[k] + l * sv[k]; S.si[i * 4 + k] = sv[k]; }
     S.mass[i] = mass; S.moment[i] = moment; S.height[i] = h;
     S.alpha[i] = al;
@@ -1476,6 +1518,7 @@ __global__ void __launch_bounds__(256) sz_k_move_strain(State S, int strain_only
   const GridGeo geo = grid_geo(S);
   constexpr int G = 16;
   __shared__ double t11[256 / G][64], t12[256 / G][64], t22[256 / G][64];
+  if (stopped(S)) return;
   int N = S.cnt[C_NOWN];
   int gl = threadIdx.x % G, gi = threadIdx.x / G, gpb = blockDim.x / G;
   for (int i = blockIdx.x * gpb + gi; i < N; i += gridDim.x * gpb) {
@@ -1682,6 +1725,12 @@ __global__ void sz_k_stats(State S, long long* out) {
     long long x = v[k];
     for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
     if ((threadIdx.x & 63) == 0 && x) atomicAdd((unsigned long long*)&out[k], (unsigned long long)x);
+  }
+  // out[10..15]: the cumulative narrow-phase work counters (sum over the slots)
+  if (blockIdx.x == 0 && threadIdx.x < 6) {
+    unsigned long long t = 0;
+    for (int q = 0; q < ACC_SLOTS; q++) t += S.acc[(size_t)q * 8 + threadIdx.x];
+    out[10 + threadIdx.x] = (long long)t;
   }
 }
 

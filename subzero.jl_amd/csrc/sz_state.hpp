@@ -33,12 +33,15 @@ enum {
   C_NRETRY,       // items handed on to the largest narrow variant (diagnostic, cumulative)
   C_NWORK,        // pairs whose ring boxes overlap: the pair items the narrow phase runs
   C_NENT,         // two-way coupling: (floe, centre cell) entries of the current coupling step
+  C_STOP,         // resident batches (sz_step): 0, or 1 + the batch-relative step after which the batch stops -- a floe was tagged
+                  // remove / fuse (or fell under the dissolve thresholds), so the host's simplify_floes! (simulation.jl:205-214) has work
   C_COUNT = 32
 };
 
 constexpr int MAXNB = 24;       // broad-phase neighbours kept per floe and direction
 constexpr int ROWS_PER_ITEM = 16; // contact rows kept per pair / element item (the 8-lane kernels hold 4 regions and hand larger items on)
 constexpr int WARN_SLOTS = 256;
+constexpr int ACC_SLOTS = 256;
 constexpr int MAX_GHOSTS = 3;   // ghosts per parent (doubly periodic corner floe)
 
 struct Params {
@@ -55,6 +58,9 @@ struct State {
   int nelem;                 // 4 boundaries + topography elements
   int any_periodic_ew, any_periodic_ns, any_domain_work;
   int tiled;                 // halo mode: order keys are global indices
+  int step;                  // 1-based index of the step inside the running sz_step batch (0: process-mode call): kernels of
+                             // steps after a stop request return at once (stopped(), sz_kernels.hpp)
+  int stop_on_tags;          // sz_step: raise C_STOP when a parent is tagged (off with SZ_NO_STOP)
   // ---- counters
   int* cnt;
   int* warn;                 // guard counters of timestep_floe_properties!: WARN_SLOTS slots of 32 ints (one 128-byte line each; words 0..3 =
@@ -110,6 +116,9 @@ struct State {
   double* mot;               // 4 per floe: dx, dy, cos, sin
   double* trig;              // 2 per floe: cos(alpha), sin(alpha), kept current by the upload and the integrator
   long long* stamps;         // diagnostic build (-DSZ_STAMPS) only
+  unsigned long long* acc;   // cumulative work counters of the narrow phase (ACC_SLOTS lines of 8 words: launches, pair items run,
+                             // their ring points, pair rows, element items, element rows): what a launch averaged over a window of
+                             // steps really did, for the roofline of bench.py (sz_get_stats acc_*, cleared by sz_profile_reset)
 };
 
 using szg_flags_note = int;   // IT_FUSE / IT_REMOVE are defined in sz_geom.hpp

@@ -177,6 +177,7 @@ class World:
         self.col.setdefault("status", np.full(M, capi.ACTIVE, _I32))
         self._sub = {}
         self._dirty = True; self._host_stale = False
+        self._new_field = True    # a different field: the interaction rows the device may still hold are not its rows
 
     def set_subpoints(self, i, sx, sy):
         self._sub[int(i)] = (np.ascontiguousarray(sx, np.float64), np.ascontiguousarray(sy, np.float64))
@@ -231,6 +232,10 @@ class World:
         f = self._columns_struct(col, keep)
         self._chk(self.L.sz_upload_floes(self.h, int(self._M), int(self.N), C.byref(f)))
         self._dirty = False; self._host_stale = False
+        if getattr(self, "_new_field", False):
+            off = np.zeros(self._M + 1, _I32)
+            self._chk(self.L.sz_upload_interactions(self.h, capi.ptr(off, capi._ip), None))
+            self._new_field = False
 
     def stats(self):
         s = capi.SzStats()
@@ -446,12 +451,18 @@ class World:
         self._push()
         self._chk(self.L.sz_timestep_floe_properties(self.h, int(dt))); self._host_stale = True
 
-    def run(self, nsteps, tstep0, dt, coupling_dt=10, collisions_on=True, coupling_on=True):
-        """nsteps x timestep_sim! with the state resident in HBM."""
+    def run(self, nsteps, tstep0, dt, coupling_dt=10, collisions_on=True, coupling_on=True, stop_on_tags=True):
+        """nsteps x timestep_sim! with the state resident in HBM.  Returns the number of steps run: the batch ends
+        after the first step that tags a floe remove / fuse (the reference runs simplify_floes! after every step,
+        simulation.jl:205-214); stop_on_tags=False runs on regardless (measurement / soak runs)."""
         self._push()
         flags = (capi.COLLISIONS_ON if collisions_on else 0) | (capi.COUPLING_ON if coupling_on else 0)
-        self._chk(self.L.sz_step(self.h, int(nsteps), int(tstep0), int(dt), int(coupling_dt), flags))
+        if not stop_on_tags:
+            flags |= capi.NO_STOP
+        done = C.c_int32(0)
+        self._chk(self.L.sz_step(self.h, int(nsteps), int(tstep0), int(dt), int(coupling_dt), flags, C.byref(done)))
         self._host_stale = True
+        return int(done.value)
 
     def timestep_sim(self, tstep, dt, coupling_dt=10, collisions_on=True, coupling_on=True):
         self.run(1, tstep, dt, coupling_dt, collisions_on, coupling_on)

@@ -209,7 +209,7 @@ def test_trajectories(n, seed, steps):
     from subzero_jl_amd import fields
     cfg = fields.make_config(n_floes=n, seed=seed)
     hw, ow = _pair(cfg)
-    hw.run(steps, 0, cfg["dt"], coupling_dt=1)
+    assert hw.run(steps, 0, cfg["dt"], coupling_dt=1) == steps        # no floe is tagged: the batch runs through
     for t in range(steps):
         ow.timestep_sim(t, cfg["dt"], coupling_dt=1)
     parity.compare_worlds(hw, ow, rtol=1e-9)
@@ -229,7 +229,8 @@ def test_resident_and_process_mode_interleaved(walls):
 
     def both_resident(k):
         nonlocal t
-        hw.run(k, t, dt, coupling_dt=1)
+        # (the walled field has a floe removed by the topography in step 0; the oracle does not simplify either)
+        hw.run(k, t, dt, coupling_dt=1, stop_on_tags=False)
         for q in range(k):
             ow.timestep_sim(t + q, dt, coupling_dt=1)
         t += k
@@ -288,8 +289,9 @@ def test_narrow_variant_retry_many_crossings():
     h, o = res
     assert len(o) >= 1 and h.shape == o.shape
     assert np.array_equal(h[:, 0], o[:, 0])
-    for c in (1, 2, 3, 4, 6):
-        assert parity.relerr(h[:, c], o[:, c]) <= 1e-10, c
+    fl = parity.force_floors(o, 1.0e4)
+    for c, floor in ((1, fl["force"]), (2, fl["force"]), (3, 1e-10 * fl["Lc"]), (4, 1e-10 * fl["Lc"]), (6, fl["area"])):
+        parity.assert_elementwise(f"column {c}", h[:, c], o[:, c], 1e-10, floor)
     from oracle import orc
     assert len(orc.intersection_points(cases.closed(star(0.0, 1.0e4)), cases.closed(star(np.pi / 8, 1.05e4)))) > 12
 
@@ -365,3 +367,95 @@ def test_reupload_into_the_same_context():
         for f in ("cx", "cy", "u", "v", "xi", "alpha", "coll_fx", "overarea", "fxOA"):
             assert np.array_equal(w.get(f), ref.get(f)), (n, f)
         assert w.stats()["n_pairs"] == ref.stats()["n_pairs"] > n
+
+
+# ---------------------------------------------------------------- state that must survive uploads / batches that must stop
+def test_interactions_survive_a_reupload_of_the_same_size():
+    """The shim's per-call pattern: upload, timestep_collisions!, (host work), upload, timestep_floe_properties!.
+    calc_stress! (update_floe.jl:392-414) reads the rows the collisions left: they must still be there after the
+    second upload (a host-side edit marks the columns dirty, so the second upload really happens)."""
+    from subzero_jl_amd import fields
+    from subzero_jl_amd.capi import SzError
+    cfg = fields.make_config(n_floes=600, seed=31)
+    hw, ow = _pair(cfg)
+    for w in (hw, ow):
+        w.add_ghosts(); w.timestep_collisions(600, cfg["dt"]); w.remove_ghosts(600)
+        u = w.get("u"); u[::5] *= 0.5; w.set("u", u)                   # host edit -> dirty -> upload on the next call
+        w.timestep_floe_properties(cfg["dt"])
+    assert np.abs(ow.get("si11")).max() > 0                            # the stress really comes from contact rows
+    parity.compare_worlds(hw, ow, rtol=1e-10, check_pairs=False, check_inter=False)
+    # an upload of ANOTHER size drops the rows: the update then refuses to run on nothing ...
+    cfg2 = fields.make_config(n_floes=500, seed=32)
+    fields.build_world(hw, cfg2)
+    hw._new_field = False                                              # (World would declare the new field itself)
+    with pytest.raises(SzError, match="interaction rows"):
+        hw.timestep_floe_properties(cfg2["dt"])
+    # ... until the host says what the interactions are (here: none, fresh floes)
+    hw._new_field = True; hw._dirty = True
+    hw.timestep_floe_properties(cfg2["dt"])
+    assert np.all(hw.get("si11") == 0)
+
+
+def _tag_scenario(w, kind):
+    sq = lambda x0, y0, s=1e4: np.array([[x0, y0], [x0, y0 + s], [x0 + s, y0 + s], [x0 + s, y0], [x0, y0]])
+    w.set_consts(E=1e3); w.set_settings()
+    if kind == "fuse":          # two floes closing in until their overlap passes floe_floe_max_overlap (collisions.jl:366)
+        w.set_domain([1, 1, 1, 1], 0.0, 1e5, 0.0, 1e5)
+        rings = [sq(4.0e4, 4.5e4), sq(4.41e4, 4.6e4), sq(8.0e4, 1.0e4), sq(9.6e4, 6.0e4)]      # the last one has a ghost
+        u = [3.0, -3.0, 0.0, 0.0]
+    else:                       # a floe drifting into an open boundary is tagged remove (collisions.jl:438)
+        w.set_domain([0, 0, 0, 0], 0.0, 1e5, 0.0, 1e5)
+        rings = [sq(2.0e4, 4.5e4), sq(8.9e4 + 380.0, 2.0e4), sq(5.0e4, 7.0e4)]
+        u = [0.0, 20.0, 0.0]
+    w.set_grid_fields(10, 10, 0.0, 1e5, 0.0, 1e5, 0.0, 0.0, 0.0, 0.0, 0.0)
+    for r in rings:
+        w.add_floe(r, 0.5)
+    w.set("u", np.array(u))
+    return w
+
+
+@pytest.mark.parametrize("kind", ["fuse", "open"])
+def test_resident_batch_stops_when_a_floe_is_tagged(kind):
+    """The reference runs simplify_floes! after EVERY step (simulation.jl:205-214).  A resident batch therefore ends
+    after the step that tags a floe, reports how many steps it ran, and leaves the reference's state of that step --
+    status.fuse_idx included -- for the host's simplification."""
+    hw = _tag_scenario(mk(), kind); ow = _tag_scenario(omk(), kind)
+    k = 0
+    while k < 12:
+        ow.timestep_sim(k, 10, coupling_dt=10, coupling_on=False); k += 1
+        if np.any(ow.ids()[2] != cases.ACTIVE):
+            break
+    assert 2 <= k < 12                                     # the tag comes in the middle of the batch
+    done = hw.run(12, 0, 10, coupling_dt=10, coupling_on=False)
+    assert done == k
+    assert np.array_equal(hw.ids()[2], ow.ids()[2]) and np.any(hw.ids()[2] == (cases.FUSE if kind == "fuse" else cases.REMOVE))
+    assert [list(map(int, f)) for f in hw.fuse()] == [list(map(int, f)) for f in ow.fuse()]
+    parity.compare_worlds(hw, ow, rtol=1e-9, check_pairs=False)
+    st = hw.stats()
+    assert st["n_status_fuse"] + st["n_status_remove"] == int(np.sum(ow.ids()[2] != cases.ACTIVE))
+    # floes tagged at entry end the next batch after one step (the host has not simplified yet) ...
+    assert hw.run(5, k, 10, coupling_dt=10, coupling_on=False) == 1
+    # ... unless told to run on regardless
+    assert hw.run(3, k + 1, 10, coupling_dt=10, coupling_on=False, stop_on_tags=False) == 3
+
+
+def test_field_reupload_keeps_the_temperatures():
+    """sz_set_fields with an unchanged lattice shape keeps the ocean / atmosphere temperatures of sz_set_temps (the
+    heat-flux factor of calc_two_way_coupling!, coupling.jl:1676, depends on them)."""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=300, seed=41, ocean="shear")
+    L, Nx, Ny = cfg["L"], cfg["Nx"], cfg["Ny"]
+    res = []
+    for again in (False, True):
+        w = fields.build_world(mk(), cfg)
+        w.set_two_way(True, dt=cfg["dt"]); w.set_temps(0.7, -12.0)
+        w.run(2, 0, cfg["dt"], coupling_dt=1)
+        w.set_grid_fields(Nx, Ny, 0.0, L, 0.0, L, 0.5 * cfg["uo"], cfg["vo"] + 0.05, cfg["hf"], cfg["ua"], cfg["va"])
+        if again:
+            w.set_temps(0.7, -12.0)
+        w.run(2, 2, cfg["dt"], coupling_dt=1)
+        res.append((w.ocean_stress(), w.get("height"), w.get("u")))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert np.any(res[0][0][3] != 0)                      # a heat-flux factor that is not the zero-temperature one
