@@ -159,7 +159,7 @@ def pmc_traffic(workload, n_floes, kernel):
     return float(ent["hbm_bytes_per_launch"]), ent.get("source", path)
 
 
-NARROW_KERNEL = "sz_k_narrow<8,20,8,16,4,64,0,0,3>"
+NARROW_KERNEL = "sz_k_narrow<8,18,8,16,4,64,0,0,3>"
 
 
 def main():

@@ -91,6 +91,10 @@ struct sz_ctx {
   bool no_static_grid = false;      // SZ_STATIC_GRID=0: fit the grid to the centroids every step (sz_k_bounds), as process mode does
   double rmax_max = 0.0, rmax_hint = 0.0; bool grid_ok = false, grid_live = false; double h_grid[8] = { 0 };
   unsigned scan_epoch = 0;      // launch counter of the look-back scans (their flags carry it: no reset pass)
+  // ghost-candidate lists of the resident steps (sz_k_ghost_list): gl_cur = the list the next step consumes, gl_valid = it is
+  // current (kept so by the integrator / halo unpack; any process-mode call or upload makes it stale: it is then seeded again),
+  // gl_est = how long it is (host estimate at upload, device count after every batch): long lists take the two-launch path
+  int gl_cur = 0; bool gl_valid = false; int gl_est = 0; bool no_ghost_list = false; int gl_max = 2048;
   int tile_forcing_tstep = -1;      // timestep whose forcings sz_tile_forcing has already enqueued
   bool tile_dirty = false;      // ghosts / halo floes of the last sz_tile_step still appended
   int dbg = 0;   // SZ_DEBUG bits: timing experiments only (1 skip contact rows, 2 skip direction check, 4 skip clip)
@@ -306,17 +310,36 @@ void use_static_grid(sz_ctx* c) {
   c->grid_live = true;
 }
 
+// the candidate list of the coming step, seeded from the parents as they lie
+void use_ghost_list(sz_ctx* c) {
+  if (c->gl_valid) return;
+  (void)hipMemsetAsync(c->S.cnt + C_NGCAND, 0, 2 * sizeof(int), c->stream);
+  c->gl_cur = 0;
+  hipLaunchKernelGGL(sz_k_ghost_seed, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
+  c->gl_valid = true;
+}
+bool ghost_list_wanted(const sz_ctx* c, bool sg) {
+  return sg && !c->no_ghost_list && (c->S.any_periodic_ew || c->S.any_periodic_ns) && c->gl_est <= c->gl_max;
+}
+
 // ---------------------------------------------------------------- pipeline stages
 // in_step: the previous step's ghosts are dropped by the flag kernel and the commit is done by
 // the bounds kernel of the broad phase (which always follows inside a step)
 // commit: the flag/scan kernel commits the new counts itself (resident steps with the static grid, where no
 // bounds kernel follows); otherwise the bounds kernel (in_step) or a commit launch does
-void stage_ghosts(sz_ctx* c, bool in_step = false, bool commit = false) {
+// use_list: the candidate-list pass (one launch) instead of flag/scan + fill
+void stage_ghosts(sz_ctx* c, bool in_step = false, bool commit = false, bool use_list = false) {
   State& S = c->S;
   // the parents' count is the host's in resident single-context steps (nothing creates or removes floes there)
   const int nh = in_step && !S.tiled ? c->hostN : -1;
   if (!S.any_periodic_ew && !S.any_periodic_ns) return;
   Timed t(c, SZ_K_GHOSTS);
+  if (use_list) {
+    const int waves = std::min(std::max(2 * c->gl_est + 64, 256), 8192);
+    hipLaunchKernelGGL(sz_k_ghost_list, dim3((waves + 3) / 4), dim3(256), 0, c->stream, S, c->gl_cur, 1, nh);
+    t.end();
+    return;
+  }
   const int nb = grid_for(S.capM, SCAN_B, 1 << 20);
   hipLaunchKernelGGL(sz_k_ghost_flag_scan, dim3(nb), dim3(SCAN_B), 0, c->stream, S, in_step ? 1 : 0, commit ? 1 : 0, next_epoch(c), nh);
   hipLaunchKernelGGL(sz_k_ghost_fill, dim3(grid_for(S.capM, 32, 2048)), dim3(256), 0, c->stream, S, commit ? 1 : 0, commit ? 1 : 0, nh);
@@ -502,7 +525,8 @@ void stage_forcing(sz_ctx* c, int dt = -1) {      // in-order variant (process m
   }
   t.end();
 }
-void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool bin = false) {
+// gl_fill: ghost-candidate list the integrator appends to (resident steps on the list path), -1: none
+void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool bin = false, int gl_fill = -1) {
   const int nh = bin && !c->S.tiled ? c->hostN : -1;     // resident single-context steps: the host knows the count
   // the guard counters describe the last timestep_floe_properties! call (inside a step the
   // ghost-removal kernel has already cleared them)
@@ -510,10 +534,10 @@ void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool 
   Timed t(c, SZ_K_INTEGRATE);
   // resident steps with small rings: one launch (thread per floe) integrates, moves the ring and bins the floe
   if (bin && c->max_ring <= MV_RING && c->fused_move) {
-    hipLaunchKernelGGL(sz_k_integrate<true>, dim3(grid_for(c->S.capM, 128)), dim3(128), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 1, nh);
+    hipLaunchKernelGGL(sz_k_integrate<true>, dim3(grid_for(c->S.capM, 128)), dim3(128), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 1, nh, gl_fill);
   } else {
-    hipLaunchKernelGGL(sz_k_integrate<false>, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 0, nh);
-    hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 0, bin ? 1 : 0);
+    hipLaunchKernelGGL(sz_k_integrate<false>, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 0, nh, gl_fill);
+    hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 0, bin ? 1 : 0, gl_fill);
   }
   if (!bin) c->grid_live = false;          // floes moved without re-binning: the resident steps' cell lists are stale
   t.end();
@@ -575,6 +599,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_TW_GENERAL_CLIP")) c->tw_general_clip = atoi(e) != 0;
   if (const char* e = getenv("SZ_FUSE_FORCING")) c->fuse_forcing = atoi(e) != 0;
   if (const char* e = getenv("SZ_STATIC_GRID")) c->no_static_grid = atoi(e) == 0;
+  if (const char* e = getenv("SZ_GHOST_LIST")) { c->no_ghost_list = atoi(e) == 0; if (atoi(e) > 1) c->gl_max = atoi(e); }
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     // lo = least urgent, hi = most urgent
   if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_hi) != hipSuccess) { delete c; return nullptr; }
@@ -732,7 +757,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   if (f->sub_off) for (int i = 0; i < N; i++) c->max_sub = std::max(c->max_sub, f->sub_off[i + 1] - f->sub_off[i]);
   DA(gplan, S.capM + 1); DA(gscan4, S.capM + 1); DA(gtot4, 4);
   DA(lb_agg, S.capM / SCAN_B + 8); DA(lb_inc, S.capM / SCAN_B + 8); DA(lb_flag, S.capM / SCAN_B + 8); c->scan_epoch = 0;
-  DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2);
+  DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2); DA(gcand, (size_t)2 * S.capM);
   DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1);
   DA(cell_items, S.capM);
   DA(nb_out, (size_t)S.capM * MAXNB); DA(nb_in, (size_t)S.capM * MAXNB); DA(n_out, S.capM + 1); DA(n_in, S.capM + 1);
@@ -762,6 +787,16 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   hipLaunchKernelGGL(sz_k_osign, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->hostM = M; c->hostN = N; c->have_floes = true; c->tile_dirty = false; c->mixed_pts_ok = false;
+  c->gl_valid = false; c->gl_est = 0;
+  if (f->rmax) {          // parents near a periodic wall: how long the ghost-candidate list will be (a superset of it)
+    const double x0 = c->h_vals[3], xf = c->h_vals[2], y0 = c->h_vals[1], yf = c->h_vals[0];
+    const bool pew = c->h_kinds[SZ_EAST] == SZ_PERIODIC && c->h_kinds[SZ_WEST] == SZ_PERIODIC;
+    const bool pns = c->h_kinds[SZ_NORTH] == SZ_PERIODIC && c->h_kinds[SZ_SOUTH] == SZ_PERIODIC;
+    for (int i = 0; i < N; i++) {
+      const double r = f->rmax[i];
+      if ((pew && (f->cx[i] - r < x0 || f->cx[i] + r > xf)) || (pns && (f->cy[i] - r < y0 || f->cy[i] + r > yf))) c->gl_est++;
+    }
+  } else c->gl_est = N;
   c->rmax_max = 0.0; c->rmax_hint = 0.0;
   if (f->rmax) for (int i = 0; i < M; i++) c->rmax_max = std::max(c->rmax_max, f->rmax[i]);
   setup_grid(c);
@@ -891,6 +926,7 @@ int sz_get_boundary_vals(sz_ctx* c, double* vals4) {
 int sz_add_ghosts(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
+  c->gl_valid = false;          // a process-mode call: the resident steps' ghost-candidate list is stale
   int oldM = c->hostM;
   stage_ghosts(c);
   int rc = sync_and_check(c);
@@ -908,6 +944,7 @@ int sz_add_ghosts(sz_ctx* c) {
 int sz_remove_ghosts(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
+  c->gl_valid = false;          // a process-mode call: the resident steps' ghost-candidate list is stale
   hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
   int rc = sync_and_check(c);
   if (rc) return rc;
@@ -918,6 +955,7 @@ int sz_remove_ghosts(sz_ctx* c) {
 int sz_timestep_collisions(sz_ctx* c, int64_t n_init, int32_t dt) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
+  c->gl_valid = false;          // a process-mode call: the resident steps' ghost-candidate list is stale
   collisions(c, (int)n_init, dt);
   c->inter_any = true; c->inter_lost = false;
   int h[C_COUNT];
@@ -929,6 +967,7 @@ int sz_timestep_collisions(sz_ctx* c, int64_t n_init, int32_t dt) {
 int sz_collide_pairs(sz_ctx* c, int64_t np, const int32_t* pi, const int32_t* pj, int32_t dt, double max_overlap) {
   if (!c || !c->have_floes || np < 0 || (np > 0 && (!pi || !pj))) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
+  c->gl_valid = false;
   State& S = c->S;
   if (np > S.capPairs) { c->err = "too many explicit pairs"; return SZ_E_CAPACITY; }
   std::vector<std::pair<int, int>> ps(np);
@@ -955,6 +994,7 @@ int sz_collide_pairs(sz_ctx* c, int64_t np, const int32_t* pi, const int32_t* pj
 int sz_collide_domain(sz_ctx* c, int32_t dt, double max_overlap) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
+  c->gl_valid = false;          // a process-mode call: the resident steps' ghost-candidate list is stale
   State& S = c->S;
   hipLaunchKernelGGL(sz_k_pairs_explicit, dim3(grid_for(S.capM + 1, 256)), dim3(256), 0, c->stream, S, 0);
   stage_elems(c, true);
@@ -968,6 +1008,7 @@ int sz_timestep_coupling(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   if (!c->have_fields) { c->err = "sz_set_fields must be called before sz_timestep_coupling"; return SZ_E_STATE; }
   (void)hipSetDevice(c->device);
+  c->gl_valid = false;          // a process-mode call: the resident steps' ghost-candidate list is stale
   if (c->two_way) { if (c->S.tiled) { c->err = "tiled contexts couple through sz_tile_step + sz_two_way_partial / sz_two_way_finish"; return SZ_E_STATE; } int rc = ensure_two_way(c); if (rc) return rc; }
   if (c->precision == 1 && !c->two_way) { int rc = ensure_mixed(c); if (rc) return rc; }
   stage_forcing(c);
@@ -1022,6 +1063,7 @@ int sz_timestep_floe_properties(sz_ctx* c, int32_t dt) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   if (int rc = need_interactions(c)) return rc;
   (void)hipSetDevice(c->device);
+  c->gl_valid = false;          // a process-mode call: the resident steps' ghost-candidate list is stale
   stage_integrate(c, dt, true, false);
   return sync_and_check(c);
 }
@@ -1065,7 +1107,7 @@ int sz_calc_stress(sz_ctx* c) {
 int sz_calc_strain(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
-  hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 1, 0);
+  hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 1, 0, -1);
   return sync_and_check(c);
 }
 
@@ -1090,6 +1132,11 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   bool last_coupled = false;
   const bool sg = coll && c->grid_ok && !c->no_static_grid;
   if (sg) use_static_grid(c);
+  const bool gl = ghost_list_wanted(c, sg);
+  // (ghosts a process-mode sz_add_ghosts left attached are dropped first: the list pass only visits the parents that get new ones)
+  if (gl && periodic && c->hostM != c->hostN) hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
+  if (gl) use_ghost_list(c); else c->gl_valid = false;
+  const int gl0 = c->gl_cur;
   if (c->precision == 1 && !c->two_way && (flags & SZ_COUPLING_ON)) { int rc = ensure_mixed(c); if (rc) return rc; }
   for (int s = 0; s < nsteps; s++) {
     int tstep = tstep0 + s;
@@ -1106,11 +1153,12 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     // neutral at 100 k dense, worse at 100 k sparse -- there the forcings get their own launch)
     const bool fuse = coupling && !overlap && coll && !c->two_way && !(c->pmask >> SZ_K_FORCING & 1u) && c->fuse_forcing && c->hostN <= 65536;
     if (coupling && !overlap && !fuse) stage_forcing(c, dt);
-    if (coll) stage_ghosts(c, true, sg);
+    if (coll) stage_ghosts(c, true, sg, gl);
     if (overlap) stage_forcing_fork(c);
     if (coll) collisions(c, c->hostN, dt, periodic && !sg, sg, fuse);
     if (overlap) stage_forcing_join(c);
-    stage_integrate(c, dt, !coll, coupling, sg);
+    stage_integrate(c, dt, !coll, coupling, sg, gl ? 1 - c->gl_cur : -1);
+    if (gl) c->gl_cur ^= 1;
   }
   c->S.step = 0;
   if (coll) { c->inter_any = true; c->inter_lost = false; }
@@ -1120,6 +1168,10 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   if (rc) return rc;
   const int done = h[C_STOP] > 0 ? h[C_STOP] : nsteps;
   if (steps_done) *steps_done = done;
+  if (gl) {               // the list the last step that RAN has filled, and how long it is
+    c->gl_cur = (gl0 + done) & 1;
+    c->gl_est = h[C_NGCAND + c->gl_cur];
+  }
   // status.fuse_idx of the step that ended the batch: the reference's serial propagation, replayed on the host as
   // sz_timestep_collisions does (only that step can have produced fuse pairs: the batch stops on the first tag)
   if (coll && done > 0) {
@@ -1128,6 +1180,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     if (h[C_STOP] > 0 || (flags & SZ_NO_STOP)) {
       rc = host_fuse_fixup(c, h, true, true, last_coupled);
       c->fuse_lists.resize(c->hostM);
+      c->gl_valid = false;          // the replay may have changed status tags
     }
   }
   return rc;
@@ -1159,6 +1212,7 @@ int sz_kernel_time_ms(sz_ctx* c, int32_t k, double* ms, int64_t* launches) {
 int sz_tile_enable(sz_ctx* c, const int64_t* gidx, double halo_capacity_factor, double max_rmax) {
   if (!c || !c->have_floes || !gidx) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
+  c->gl_valid = false;
   State& S = c->S;
   if (c->hostM != c->hostN) { c->err = "sz_tile_enable needs a ghost-free upload"; return SZ_E_STATE; }
   std::vector<long long> ok(c->hostN);
@@ -1236,8 +1290,11 @@ int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int
   const bool coll = (flags & SZ_COLLISIONS_ON) != 0;
   const bool sg = coll && c->grid_ok && !c->no_static_grid;
   if (sg) use_static_grid(c);
+  const bool gl = ghost_list_wanted(c, sg);
+  if (gl) use_ghost_list(c); else c->gl_valid = false;
   if (d_recv && nranks > 0) {
-    hipLaunchKernelGGL(sz_k_halo_unpack, dim3(1), dim3(1024), 0, c->stream, S, (const double*)d_recv, nranks, cap, sg ? 1 : 0);
+    // halo floes join the candidate list of THIS step (the owned floes were appended by the last integrator)
+    hipLaunchKernelGGL(sz_k_halo_unpack, dim3(1), dim3(1024), 0, c->stream, S, (const double*)d_recv, nranks, cap, sg ? 1 : 0, gl ? c->gl_cur : -1);
   }
   const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
   const bool periodic = S.any_periodic_ew || S.any_periodic_ns;
@@ -1250,9 +1307,10 @@ int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int
   // between two steps looks past the owned floes, so no clean-up launch is needed per step: the ghosts and halo
   // floes of the LAST step are dropped when the host next looks at the state (tile_cleanup).
   // n_init = every local parent (owned + halo): totals of halo floes are computed and then ignored
-  if (coll) stage_ghosts(c, true, sg);
+  if (coll) stage_ghosts(c, true, sg, gl);
   if (coll) collisions(c, -1, dt, periodic && !sg, sg);
-  stage_integrate(c, dt, false, coupling, sg);
+  stage_integrate(c, dt, false, coupling, sg, gl ? 1 - c->gl_cur : -1);
+  if (gl) { c->gl_cur ^= 1; c->gl_est = std::max(c->gl_est, 64); }
   c->tile_dirty = true;
   return SZ_OK;
 }

@@ -64,12 +64,13 @@ struct GroupMem {
   // budget decides how many items the chip holds in flight):
   double kin[14];                            // i: cx cy u v xi, j: cx cy u v xi, area_i h_i area_j h_j
   double dlv[RM], dxv[RM], dyv[RM];          // per kept region: contact length and force direction
+  double box[8];                             // ring boxes of the item: a x0 x1 y0 y1, b x0 x1 y0 y1 (a direction check of this item may be
+  double ff;                                 // run by another lane group of the wavefront, which finds them here); force factor
   uint32_t cinfo[KC];                        // per crossing: ia | ib<<7 | rankA<<14 | rankB<<20 | flags<<26
-  int nraw, nx, nreg[2], flag, err, ntracefail, nea, neb;
+  int nraw, nx, nreg[2], flag, err, ierr, ntracefail, nea, neb;   // err: bits raised while this group's memory was the scratch; ierr: bits of ITS item
   unsigned acc[2];                           // work counters of the group: ring points of its pair items, pair rows
   uint16_t acc16[3];                         // ... pair items, element items, element rows (a group runs a few dozen items per launch)
-  int16_t cia[KC], cib[KC], ria[KC], rib[KC];
-  int16_t rnkB[KC];                          // scratch of match_vertices
+  int16_t cia[KC], cib[KC], ria[KC], rib[KC];   // (ria doubles as the scratch of match_vertices: the raw slots are dead after the clip)
   int16_t midx[KC];                          // matched region-vertex index per ipoint
   int16_t roff[2][RM + 2];
   uint8_t ordA[KC], ordB[KC];                // crossing id at rank r along a / b
@@ -77,8 +78,11 @@ struct GroupMem {
   int8_t ecode[RC];                          // many-intersect per-edge class
   uint8_t ea[CAP], eb[CAP];                  // edges of a / b that reach into the overlap box
   int8_t keep[RM];
+  int8_t chk[RM];                            // the kept regions (positions in keep) that need the direction check
+  uint8_t rna, rnb; int8_t roa, rob;         // ring sizes and orientation signs of the item
+  int8_t nchk, nkeep;
 };
-static_assert(sizeof(GroupMem<20, 8, 16, 4>) <= 2048, "eight groups of the first narrow variant must fit 16 KB");
+static_assert(sizeof(GroupMem<18, 8, 16, 4>) <= 2048, "eight groups of the first narrow variant must fit 16 KB");
 
 enum { ERR_CAP_RING = 1, ERR_CAP_XING = 2, ERR_CAP_REGION = 4, ERR_CAP_ROWS = 8, ERR_TRACE = 16,
        ERR_CAP_NEIGH = 32, ERR_CAP_PAIRS = 64, ERR_CAP_ELEM = 128, ERR_CAP_INTER = 256,
@@ -244,13 +248,16 @@ SZ_DEV double gmax(double v) { for (int d = G / 2; d >= 1; d >>= 1) v = fmax(v, 
 // b = (m.bx, m.by, nb) are closed rings in LDS; oa/ob their orientation signs.  The translation
 // is applied on the fly (x + 0.0 == x, so the untranslated clip is unchanged).
 // Group-uniform: every lane of the group calls it with the same arguments.
+// `ring` holds the two rings, `m` is the working set the clip writes (crossings, regions of buffer `buf`): the same
+// GroupMem for an item's own clips; the direction check of an item may be run by ANOTHER lane group of the wavefront,
+// which then reads the rings from the owner's memory and works in its own (narrow phase, sz_kernels.hpp).
 template <int G, class MEM>
-SZ_DEV void clip(MEM& m, int gl, double ox, double oy, int na, int oa, int nb, int ob, int buf, const Box& ba, const Box& bb,
+SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, int oa, int nb, int ob, int buf, const Box& ba, const Box& bb,
                  Stamps& st) {
   constexpr int KC = sizeof(m.cta) / sizeof(double);
   constexpr int RC = sizeof(m.ecode);
   constexpr int RM = MEM::RMAXV;
-  const double* pax = m.ax; const double* pay = m.ay; const double* pbx = m.bx; const double* pby = m.by;
+  const double* pax = ring.ax; const double* pay = ring.ay; const double* pbx = ring.bx; const double* pby = ring.by;
   double* rgx = m.reg[buf][0]; double* rgy = m.reg[buf][1];
   if (gl == 0) { m.nraw = 0; m.nreg[buf] = 0; m.roff[buf][0] = 0; m.nea = 0; m.neb = 0; }
   if (na < 4 || nb < 4) { if (gl == 0) m.nx = 0; gsync(); return; }
@@ -445,6 +452,11 @@ SZ_DEV void clip(MEM& m, int gl, double ox, double oy, int na, int oa, int nb, i
   STAMP(st, 7);
 }
 
+template <int G, class MEM>
+SZ_DEV void clip(MEM& m, int gl, double ox, double oy, int na, int oa, int nb, int ob, int buf, const Box& ba, const Box& bb, Stamps& st) {
+  clip<G>(m, m, gl, ox, oy, na, oa, nb, ob, buf, ba, bb, st);
+}
+
 // ---------------------------------------------------------------------------------------------
 // which_vertices_match_points (floe_utils.jl:331-352) of the unique crossing points against one
 // region ring; fills m.midx[0..mcount) sorted ascending and returns mcount.  The nearest vertex
@@ -469,15 +481,15 @@ SZ_DEV int match_vertices(MEM& m, int gl, int nuniq, const double* rx, const dou
       }
       if (sqrt(sqrt(md)) < 1.0) res = mv;
     }
-    m.rnkB[k] = (int16_t)res;     // rnkB is free after the trace
+    m.ria[k] = (int16_t)res;      // the raw crossing slots are free after the clip
   }
   gsync();
   int cnt = 0;
-  for (int k = 0; k < K; k++) if (m.rnkB[k] >= 0) cnt++;
+  for (int k = 0; k < K; k++) if (m.ria[k] >= 0) cnt++;
   if (gl == 0) {
     int c = 0;
     for (int k = 0; k < K; k++) {
-      int v = m.rnkB[k];
+      int v = m.ria[k];
       if (v < 0) continue;
       int u = c - 1;
       while (u >= 0 && m.midx[u] > v) { m.midx[u + 1] = m.midx[u]; u--; }
@@ -572,111 +584,141 @@ struct ItemCtx {
   int rigid_j;         // 1: boundary/topography: the velocity of side j is (u, v) everywhere
 };
 
-// One work item, start to finish: floe_floe_interaction! (collisions.jl:347-408) or
-// floe_domain_element_interaction! (:427-557) on the rings staged in m.ax/ay, m.bx/by.
-// rows: out[k*5 + {fx, fy, px, py, overlap}]; zero-force rows are dropped exactly like
-// add_interactions! (:288).  Returns the number of rows, sets IT_FUSE / IT_REMOVE in `flags`.
-//
-// The contact clip and the per-region direction-check clips (collisions.jl:58-68) are iterations
-// -1, 0, 1, .. of ONE loop, so that clip() -- by far the largest routine -- is instantiated once:
-// the kernel then fits the instruction cache, which matters more than anything else for a
-// divergent, latency-bound kernel like this one.
+// One work item = floe_floe_interaction! (collisions.jl:347-408) or floe_domain_element_interaction! (:427-557) on the
+// rings staged in m.ax/ay, m.bx/by, in three phases so that the expensive part -- the reference's direction check, a
+// second clip of the translated polygon per contact region (collisions.jl:58-68) -- can be handed to whichever lane
+// group of the wavefront is free (the groups of a wavefront share LDS):
+//   contact_phase  the contact clip, overlap tests (fuse / remove), force factor, min-area filter, and per kept region
+//                  the normal direction up to its sign (m.keep / dlv / dxv / dyv; m.chk = the regions that need the check)
+//   check_task     ONE direction check: region q of the item in `own`, working set `scr` (any group's)
+//   finish_phase   friction and the rows, in region order (zero-force rows dropped like add_interactions!, :288)
+// rows: out[k*5 + {fx, fy, px, py, overlap}].  clip() -- by far the largest routine -- has two call sites, both cold
+// in the instruction cache only once per round.
+constexpr int CAPBITS = ERR_CAP_XING | ERR_CAP_REGION | ERR_CAP_ROWS;
+
 template <int G, class MEM>
-SZ_DEV int collide_item(MEM& m, int gl, int na, int oa, int nb, int ob, const Box& ba, const Box& bb, const ItemCtx& cx_,
-                        double* out, int max_rows, int& flags, Stamps& st) {
-  constexpr int RM = MEM::RMAXV;
-  int nkeep = 0, nrows = 0;
+SZ_DEV void contact_phase(MEM& m, int gl, int na, int oa, int nb, int ob, const Box& ba, const Box& bb, const ItemCtx& cx_, int& flags, Stamps& st) {
+  int nkeep = 0, nchk = 0;
   double force_factor = 0.0;
   flags = 0;
-  for (int q = -1; q < nkeep; q++) {
-    const int r = q < 0 ? 0 : m.keep[q];
-    const double area = q < 0 ? 0.0 : m.rarea[0][r];
-    const double dl = q < 0 ? 0.0 : m.dlv[q];
-    double dirx = q < 0 ? 0.0 : m.dxv[q], diry = q < 0 ? 0.0 : m.dyv[q];
-    const bool check = q >= 0 && area != 0 && dl > 0.1 && !(cx_.dbg & 2);
-    if (q < 0 || check) clip<G>(m, gl, dirx, diry, na, oa, nb, ob, q < 0 ? 0 : 1, ba, bb, st);
-    if (q < 0) {
-      // ---------------- after the contact clip: overlap tests, force factor, per-region direction
-      const int nreg = m.nreg[0];
-      double total = 0.0, amax = 0.0;
-      for (int t = 0; t < nreg; t++) { double a = m.rarea[0][t]; total += a; if (a > amax) amax = a; }
-      const double area_i = m.kin[KIN_AREA_I], h_i = m.kin[KIN_H_I];
-      if (cx_.mode == ITEM_PAIR) {
-        if (!(total > 0)) break;
-        const double area_j = m.kin[KIN_AREA_J], h_j = m.kin[KIN_H_J];
-        double r1 = total / area_i, r2 = total / area_j;
-        if ((r1 > r2 ? r1 : r2) > cx_.max_overlap) { flags |= IT_FUSE; break; }
-        double ih = h_i, ir = sqrt(area_i), jh = h_j, jr = sqrt(area_j);
-        if (ir > 1e5 || jr > 1e5) force_factor = cx_.E * (ih < jh ? ih : jh) / (ir < jr ? ir : jr);
-        else force_factor = cx_.E * (ih * jh) / (ih * jr + jh * ir);
-      } else if (cx_.mode == ITEM_OPEN) {
-        if (total > 0) flags |= IT_REMOVE;
-        break;
-      } else {
-        if (!(amax > 0)) break;
-        if (amax / area_i > cx_.max_overlap) { flags |= IT_REMOVE; break; }
-        force_factor = cx_.E * h_i / sqrt(area_i);
-      }
-      if (cx_.dbg & 1) break;
-      STAMP(st, 12);
-      // unique crossing points (GO.intersection_points): first occurrences in canonical order
-      const int K = m.nx;
-      for (int k = gl; k < K; k += G) {
-        bool dup = false;
-        for (int l = 0; l < k; l++) if (m.cx[l] == m.cx[k] && m.cy[l] == m.cy[k]) { dup = true; break; }
-        m.uniq[k] = dup ? 0 : 1;
-      }
-      gsync();
-      int nip = 0;
-      for (int k = 0; k < K; k++) nip += m.uniq[k];
-      // min-area filter (collisions.jl:158-170)
-      if (nip >= 2) {
-        int n1 = na - 1, n2 = nb - 1;
-        double min_area = (double)((n1 < n2 ? n1 : n2) * 100) / 1.75;
-        for (int t = 0; t < nreg; t++) if (!(m.rarea[0][t] < min_area)) { if (gl == 0) m.keep[nkeep] = (int8_t)t; nkeep++; }
-      }
-      gsync();
-      // calc_normal_force up to the direction check, for every kept region (the direction-check
-      // clips overwrite the crossing arrays, so all matching happens here)
-      for (int w = 0; w < nkeep; w++) {
-        int rr = m.keep[w];
-        const double* rx = &m.reg[0][0][m.roff[0][rr]]; const double* ry = &m.reg[0][1][m.roff[0][rr]];
-        int nr = m.roff[0][rr + 1] - m.roff[0][rr];
-        double ddx = 0.0, ddy = 0.0, ddl = 0.0;
-        if (m.rarea[0][rr] != 0) {
-          int mc = match_vertices<G>(m, gl, nip, rx, ry, nr);
-          if (mc == 2) {
-            int i1 = m.midx[0], i2 = m.midx[1];
-            double ex = rx[i2] - rx[i1], ey = ry[i2] - ry[i1];
-            ddl = sqrt(ex * ex + ey * ey);
-            if (ddl > 0.1) { ddx = -ey / ddl; ddy = ex / ddl; }
-          } else if (mc != 0) {
-            ddl = many_intersect<G>(m, gl, rx, ry, nr, na, force_factor, ddx, ddy);
-          }
-          gsync();
-        }
-        if (gl == 0) { m.dlv[w] = ddl; m.dxv[w] = ddx; m.dyv[w] = ddy; }
-      }
-      gsync();
-      STAMP(st, 8);
-      continue;
+  if (gl == 0) {
+    m.box[0] = ba.x0; m.box[1] = ba.x1; m.box[2] = ba.y0; m.box[3] = ba.y1; m.box[4] = bb.x0; m.box[5] = bb.x1; m.box[6] = bb.y0; m.box[7] = bb.y1;
+    m.rna = (uint8_t)na; m.rnb = (uint8_t)nb; m.roa = (int8_t)oa; m.rob = (int8_t)ob; m.nkeep = 0; m.nchk = 0;
+  }
+  clip<G>(m, m, gl, 0.0, 0.0, na, oa, nb, ob, 0, ba, bb, st);
+  do {
+    // ---------------- after the contact clip: overlap tests, force factor, per-region direction
+    const int nreg = m.nreg[0];
+    double total = 0.0, amax = 0.0;
+    for (int t = 0; t < nreg; t++) { double a = m.rarea[0][t]; total += a; if (a > amax) amax = a; }
+    const double area_i = m.kin[KIN_AREA_I], h_i = m.kin[KIN_H_I];
+    if (cx_.mode == ITEM_PAIR) {
+      if (!(total > 0)) break;
+      const double area_j = m.kin[KIN_AREA_J], h_j = m.kin[KIN_H_J];
+      double r1 = total / area_i, r2 = total / area_j;
+      if ((r1 > r2 ? r1 : r2) > cx_.max_overlap) { flags |= IT_FUSE; break; }
+      double ih = h_i, ir = sqrt(area_i), jh = h_j, jr = sqrt(area_j);
+      if (ir > 1e5 || jr > 1e5) force_factor = cx_.E * (ih < jh ? ih : jh) / (ir < jr ? ir : jr);
+      else force_factor = cx_.E * (ih * jh) / (ih * jr + jh * ir);
+    } else if (cx_.mode == ITEM_OPEN) {
+      if (total > 0) flags |= IT_REMOVE;
+      break;
+    } else {
+      if (!(amax > 0)) break;
+      if (amax / area_i > cx_.max_overlap) { flags |= IT_REMOVE; break; }
+      force_factor = cx_.E * h_i / sqrt(area_i);
     }
-    // ---------------- region q: direction check, friction, row
-    const double* rx = &m.reg[0][0][m.roff[0][r]]; const double* ry = &m.reg[0][1][m.roff[0][r]];
-    const int nr = m.roff[0][r + 1] - m.roff[0][r];
+    if (cx_.dbg & 1) break;
+    STAMP(st, 12);
+    // unique crossing points (GO.intersection_points): first occurrences in canonical order
+    const int K = m.nx;
+    for (int k = gl; k < K; k += G) {
+      bool dup = false;
+      for (int l = 0; l < k; l++) if (m.cx[l] == m.cx[k] && m.cy[l] == m.cy[k]) { dup = true; break; }
+      m.uniq[k] = dup ? 0 : 1;
+    }
+    gsync();
+    int nip = 0;
+    for (int k = 0; k < K; k++) nip += m.uniq[k];
+    // min-area filter (collisions.jl:158-170)
+    if (nip >= 2) {
+      int n1 = na - 1, n2 = nb - 1;
+      double min_area = (double)((n1 < n2 ? n1 : n2) * 100) / 1.75;
+      for (int t = 0; t < nreg; t++) if (!(m.rarea[0][t] < min_area)) { if (gl == 0) m.keep[nkeep] = (int8_t)t; nkeep++; }
+    }
+    gsync();
+    // calc_normal_force up to the direction check, for every kept region (the check clips overwrite the crossing
+    // arrays of whichever group runs them, so all matching happens here)
+    for (int w = 0; w < nkeep; w++) {
+      int rr = m.keep[w];
+      const double* rx = &m.reg[0][0][m.roff[0][rr]]; const double* ry = &m.reg[0][1][m.roff[0][rr]];
+      int nr = m.roff[0][rr + 1] - m.roff[0][rr];
+      double ddx = 0.0, ddy = 0.0, ddl = 0.0;
+      if (m.rarea[0][rr] != 0) {
+        int mc = match_vertices<G>(m, gl, nip, rx, ry, nr);
+        if (mc == 2) {
+          int i1 = m.midx[0], i2 = m.midx[1];
+          double ex = rx[i2] - rx[i1], ey = ry[i2] - ry[i1];
+          ddl = sqrt(ex * ex + ey * ey);
+          if (ddl > 0.1) { ddx = -ey / ddl; ddy = ex / ddl; }
+        } else if (mc != 0) {
+          ddl = many_intersect<G>(m, gl, rx, ry, nr, na, force_factor, ddx, ddy);
+        }
+        gsync();
+      }
+      // the direction check runs for a region with area and a contact length (collisions.jl:58)
+      const bool check = m.rarea[0][rr] != 0 && ddl > 0.1 && !(cx_.dbg & 2);
+      if (gl == 0) { m.dlv[w] = ddl; m.dxv[w] = ddx; m.dyv[w] = ddy; if (check) m.chk[nchk] = (int8_t)w; }
+      if (check) nchk++;
+    }
+    STAMP(st, 8);
+  } while (false);
+  if (gl == 0) { m.nkeep = (int8_t)nkeep; m.nchk = (int8_t)nchk; m.ff = force_factor; m.ierr = m.err & CAPBITS; m.err &= ~CAPBITS; }
+  gsync();
+}
+
+// The direction check of calc_normal_force (collisions.jl:58-68) for kept region q of the item whose rings and contact
+// regions are in `own`: p1 translated by the unit normal, clipped against p2 again; every new region that intersects
+// the old one and is larger flips the sign.  Works in `scr` (crossing arrays, region buffer 1), touches nothing of `own`
+// but the sign of (dxv, dyv)[q] and its error word.
+template <int G, class MEM>
+SZ_DEV void check_task(MEM& own, MEM& scr, int gl, int q, Stamps& st) {
+  const int r = own.keep[q];
+  const double area = own.rarea[0][r];
+  const double dirx = own.dxv[q], diry = own.dyv[q];
+  const Box ba{ own.box[0], own.box[1], own.box[2], own.box[3] }, bb{ own.box[4], own.box[5], own.box[6], own.box[7] };
+  clip<G>(own, scr, gl, dirx, diry, (int)own.rna, (int)own.roa, (int)own.rnb, (int)own.rob, 1, ba, bb, st);
+  const double* rx = &own.reg[0][0][own.roff[0][r]]; const double* ry = &own.reg[0][1][own.roff[0][r]];
+  const int nr = own.roff[0][r + 1] - own.roff[0][r];
+  const int nn = scr.nreg[1];
+  bool flip = false;
+  for (int t = 0; t < nn; t++) {
+    const double* nx_ = &scr.reg[1][0][scr.roff[1][t]]; const double* ny_ = &scr.reg[1][1][scr.roff[1][t]];
+    int nnr = scr.roff[1][t + 1] - scr.roff[1][t];
+    // area ratio first: `intersects && ratio > 1` needs the (costlier) predicate only then
+    if (scr.rarea[1][t] / area > 1 && rings_intersect<G>(scr, gl, nx_, ny_, nnr, rx, ry, nr)) flip = !flip;
+  }
+  gsync();
+  if (gl == 0) {
+    if (flip) { own.dxv[q] = dirx * -1; own.dyv[q] = diry * -1; }
+    const int e = scr.err & CAPBITS;           // a working set that was too small is the ITEM's problem (it is retried)
+    if (e) { atomicOr(&own.ierr, e); scr.err &= ~CAPBITS; }
+  }
+  STAMP(st, 10);
+}
+
+template <int G, class MEM>
+SZ_DEV int finish_phase(MEM& m, int gl, const ItemCtx& cx_, double* out, int max_rows, Stamps& st) {
+  const int nkeep = m.nkeep;
+  const double force_factor = m.ff;
+  int nrows = 0;
+  for (int q = 0; q < nkeep; q++) {
+    const int r = m.keep[q];
+    const double area = m.rarea[0][r], dl = m.dlv[q];
+    const double dirx = m.dxv[q], diry = m.dyv[q];
     double fxn = 0.0, fyn = 0.0, px = 0.0, py = 0.0;
     if (area != 0) {
       px = m.rcx[r]; py = m.rcy[r];
-      if (check) {
-        int nn = m.nreg[1];
-        for (int t = 0; t < nn; t++) {
-          const double* nx_ = &m.reg[1][0][m.roff[1][t]]; const double* ny_ = &m.reg[1][1][m.roff[1][t]];
-          int nnr = m.roff[1][t + 1] - m.roff[1][t];
-          // area ratio first: `intersects && ratio > 1` needs the (costlier) predicate only then
-          if (m.rarea[1][t] / area > 1 && rings_intersect<G>(m, gl, nx_, ny_, nnr, rx, ry, nr)) { dirx *= -1; diry *= -1; }
-        }
-        STAMP(st, 10);
-      }
       fxn = dirx * area * force_factor;
       fyn = diry * area * force_factor;
     }
@@ -707,10 +749,9 @@ SZ_DEV int collide_item(MEM& m, int gl, int na, int oa, int nb, int ob, const Bo
     if (fx != 0 || fy != 0) {
       if (nrows < max_rows) {
         if (gl == 0) { double* o = out + nrows * 5; o[0] = fx; o[1] = fy; o[2] = px; o[3] = py; o[4] = area; }
-      } else if (gl == 0) m.err |= ERR_CAP_ROWS;
+      } else if (gl == 0) m.ierr |= ERR_CAP_ROWS;
       nrows++;
     }
-    gsync();
   }
   return nrows < max_rows ? nrows : max_rows;
 }

@@ -366,6 +366,75 @@ __device__ __forceinline__ void rig_store(State& S, int lane, int f, int vo, int
   if (lane + 64 < n) { S.vx[vo + lane + 64] = r.x1; S.vy[vo + lane + 64] = r.y1; }
 }
 
+// One flagged parent, by a whole wavefront: both passes of add_ghosts! for parent i.  fl: its flags (dx+1 | (dy+1)<<2),
+// sc: the exclusive prefix of {E/W ghosts, E/W points, N/S ghosts, N/S points} over the flagged parents before it
+// (storage order), T: the totals, M0 / NV0: first free floe row / ring point; vo, n: the parent's ring.
+// Memory order is the whole cost (every dependent batch is one HBM round trip): everything the parent's row holds is
+// asked for in ONE batch -- the scalar columns one per lane, the ring one point per lane -- and stored afterwards.
+__device__ __forceinline__ void ghost_fill_parent(State& S, const GridGeo& geo, int lane, int i, int fl, int4 sc, int4 T, int M0, int NV0, int bin,
+                                                  int vo, int n, const double* wall) {
+  const int dirs[2] = { (fl & 3) - 1, ((fl >> 2) & 3) - 1 };
+  // ---- loads
+  const int ngh_old = S.ngh[i];
+  Rig P;
+  P.cx = S.cx[i]; P.cy = S.cy[i]; P.b0 = S.bbx0[i]; P.b1 = S.bbx1[i]; P.b2 = S.bby0[i]; P.b3 = S.bby1[i];
+  P.x0 = lane < n ? S.vx[vo + lane] : 0.0; P.y0 = lane < n ? S.vy[vo + lane] : 0.0;
+  P.x1 = lane + 64 < n ? S.vx[vo + lane + 64] : 0.0; P.y1 = lane + 64 < n ? S.vy[vo + lane + 64] : 0.0;
+  // the copied scalar columns (deepcopy of the parent, collisions.jl:893): lane q < 10 carries double column q
+  double* const dcol = lane == 0 ? S.rmax : lane == 1 ? S.area : lane == 2 ? S.height : lane == 3 ? S.mass : lane == 4 ? S.moment :
+                       lane == 5 ? S.alpha : lane == 6 ? S.u : lane == 7 ? S.v : lane == 8 ? S.xi : S.overarea;
+  const double dval = lane < 10 ? dcol[i] : 0.0;
+  const long long idv = S.id[i]; const int stv = S.status[i]; const signed char osv = S.osign[i];
+  const long long oki = S.tiled ? S.okey[i] : 0;
+  if (ngh_old != 0) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_GHOSTS_PER_PARENT); return; }
+  if (n > 128) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); return; }
+  // ---- the two passes, in registers
+  Rig Gs[MAX_GHOSTS]; int slot[MAX_GHOSTS], vbs[MAX_GHOSTS], gid[MAX_GHOSTS]; long long key[MAX_GHOSTS];
+  int ng = 0; bool moved = false;
+  for (int axis = 0; axis < 2; axis++) {
+    int dir = dirs[axis];
+    if (dir == 0) continue;
+    const int maxb = axis == 0 ? 2 : 0, minb = axis == 0 ? 3 : 1;
+    double maxv = wall[maxb], minv = wall[minb], L = maxv - minv;
+    double t = dir > 0 ? L : -L;
+    double tx = axis == 0 ? t : 0.0, ty = axis == 0 ? 0.0 : t;
+    int gbase = axis == 0 ? M0 + sc.x : M0 + T.x + sc.z;
+    int vb = axis == 0 ? NV0 + sc.y : NV0 + T.y + sc.w;
+    // ghosts of the existing ghosts first, then the parent's (every copy has the parent's ring size)
+    for (int k = 0; k <= ng; k++) {
+      int w = ng + k;
+      Gs[w] = rig_shift(k < ng ? Gs[k] : P, tx, ty);
+      slot[w] = gbase + k; vbs[w] = vb + k * n; gid[w] = k + 1 + ng;
+      key[w] = S.tiled ? ((long long)(axis + 1) << 40) + oki * 4 + k : (long long)(gbase + k);
+    }
+    // parent centroid outside the domain: swap roles with its own new ghost
+    double c = axis == 0 ? P.cx : P.cy;
+    double sp = 0.0;
+    if (c < minv) sp = L; else if (maxv < c) sp = -L;
+    if (sp != 0.0) {
+      double px = axis == 0 ? sp : 0.0, py = axis == 0 ? 0.0 : sp;
+      P = rig_shift(P, px, py); moved = true;
+      Gs[ng + ng] = rig_shift(Gs[ng + ng], -px, -py);
+    }
+    ng = ng + ng + 1;
+  }
+  // ---- stores
+  for (int w = 0; w < ng; w++) {
+    const int g = slot[w];
+    if (lane < 10) dcol[g] = dval;
+    if (lane == 10) { S.id[g] = idv; S.ghost_id[g] = (long long)gid[w]; S.okey[g] = key[w]; }
+    if (lane == 11) { S.status[g] = stv; S.parent[g] = i; S.ngh[g] = 0; S.osign[g] = osv; }
+    if (lane == 12) { S.cfx[g] = 0.0; S.cfy[g] = 0.0; S.ctrq[g] = 0.0; }
+    rig_store(S, lane, g, vbs[w], n, Gs[w]);
+    if (lane == 13) { S.voff[g] = vbs[w]; S.voff[g + 1] = vbs[w] + n; }   // neighbours write the same values: rings are packed back to back
+    if (bin && lane == 14) cell_insert(S, geo, g, Gs[w].cx, Gs[w].cy);
+    if (lane < MAX_GHOSTS) S.gh[g * MAX_GHOSTS + lane] = -1;
+  }
+  if (moved) rig_store(S, lane, i, vo, n, P);
+  if (lane < MAX_GHOSTS) S.gh[i * MAX_GHOSTS + lane] = lane < ng ? slot[lane] : -1;
+  if (lane == 0) S.ngh[i] = ng;
+}
+
 // gscan4 holds the exclusive int4 scan of gplan, gtot4[0] the totals
 __global__ void __launch_bounds__(256) sz_k_ghost_fill(State S, int committed, int bin, int nh) {
   if (stopped(S)) return;
@@ -382,6 +451,7 @@ __global__ void __launch_bounds__(256) sz_k_ghost_fill(State S, int committed, i
     if (lane < 8 && qv < np2 && mine < N) flm0 = S.gflag[mine];
   }
   const int M0 = committed ? N : S.cnt[C_M], NV0 = committed ? S.voff[N] : S.cnt[C_NV];
+  const double wall[4] = { S.eval[0], S.eval[1], S.eval[2], S.eval[3] };
   int4 T = S.gtot4[0];
   if (M0 + T.x + T.z > S.capM) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
   if (NV0 + T.y + T.w > S.capV) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); return; }
@@ -403,57 +473,95 @@ __global__ void __launch_bounds__(256) sz_k_ghost_fill(State S, int committed, i
       todo &= todo - 1;
       const int i = __shfl(mine, src_lane);
       const int fl = __shfl(flm, src_lane);
-      const int dirs[2] = { (fl & 3) - 1, ((fl >> 2) & 3) - 1 };
-      const int4 sc = S.gscan4[i];
-      const int vo = S.voff[i], n = S.voff[i + 1] - vo;
-      if (S.ngh[i] != 0) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_GHOSTS_PER_PARENT); continue; }
-      if (n > 128) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); continue; }
-      Rig P;
-      P.cx = S.cx[i]; P.cy = S.cy[i]; P.b0 = S.bbx0[i]; P.b1 = S.bbx1[i]; P.b2 = S.bby0[i]; P.b3 = S.bby1[i];
-      P.x0 = lane < n ? S.vx[vo + lane] : 0.0; P.y0 = lane < n ? S.vy[vo + lane] : 0.0;
-      P.x1 = lane + 64 < n ? S.vx[vo + lane + 64] : 0.0; P.y1 = lane + 64 < n ? S.vy[vo + lane + 64] : 0.0;
-      Rig Gs[MAX_GHOSTS]; int slot[MAX_GHOSTS], vbs[MAX_GHOSTS], gid[MAX_GHOSTS]; long long key[MAX_GHOSTS];
-      int ng = 0; bool moved = false;
-      for (int axis = 0; axis < 2; axis++) {
-        int dir = dirs[axis];
-        if (dir == 0) continue;
-        const int maxb = axis == 0 ? 2 : 0, minb = axis == 0 ? 3 : 1;
-        double maxv = S.eval[maxb], minv = S.eval[minb], L = maxv - minv;
-        double t = dir > 0 ? L : -L;
-        double tx = axis == 0 ? t : 0.0, ty = axis == 0 ? 0.0 : t;
-        int gbase = axis == 0 ? M0 + sc.x : M0 + T.x + sc.z;
-        int vb = axis == 0 ? NV0 + sc.y : NV0 + T.y + sc.w;
-        // ghosts of the existing ghosts first, then the parent's (every copy has the parent's ring size)
-        for (int k = 0; k <= ng; k++) {
-          int w = ng + k;
-          Gs[w] = rig_shift(k < ng ? Gs[k] : P, tx, ty);
-          slot[w] = gbase + k; vbs[w] = vb + k * n; gid[w] = k + 1 + ng;
-          key[w] = S.tiled ? ((long long)(axis + 1) << 40) + S.okey[i] * 4 + k : (long long)(gbase + k);
-        }
-        // parent centroid outside the domain: swap roles with its own new ghost
-        double c = axis == 0 ? P.cx : P.cy;
-        double sp = 0.0;
-        if (c < minv) sp = L; else if (maxv < c) sp = -L;
-        if (sp != 0.0) {
-          double px = axis == 0 ? sp : 0.0, py = axis == 0 ? 0.0 : sp;
-          P = rig_shift(P, px, py); moved = true;
-          Gs[ng + ng] = rig_shift(Gs[ng + ng], -px, -py);
-        }
-        ng = ng + ng + 1;
-      }
-      for (int w = 0; w < ng; w++) {
-        int g = slot[w];
-        copy_floe_row(S, g, i);
-        rig_store(S, lane, g, vbs[w], n, Gs[w]);
-        S.voff[g] = vbs[w]; S.voff[g + 1] = vbs[w] + n;   // neighbours write the same values: rings are packed back to back
-        S.ghost_id[g] = (long long)gid[w]; S.parent[g] = i; S.okey[g] = key[w];
-        if (bin && lane == 0) cell_insert(S, geo, g, Gs[w].cx, Gs[w].cy);
-        if (lane < MAX_GHOSTS) S.gh[g * MAX_GHOSTS + lane] = -1;
-      }
-      if (moved) rig_store(S, lane, i, vo, n, P);
-      if (lane < ng) S.gh[i * MAX_GHOSTS + lane] = slot[lane < MAX_GHOSTS ? lane : 0];
-      if (lane == 0) S.ngh[i] = ng;
+      const int vo = S.voff[i];
+      ghost_fill_parent(S, geo, lane, i, fl, S.gscan4[i], T, M0, NV0, bin, vo, S.voff[i + 1] - vo, wall);
     }
+  }
+}
+
+// ---------------------------------------------------------------- the ghost pass of the resident steps: ONE launch
+// Whether a parent gets ghosts depends on its centroid, rmax, ring box and status alone (ghost_dir), i.e. on what the
+// kernel that last placed the floe already had in registers.  In the resident steps that kernel (integrator, halo
+// unpack; the seeding launch after an upload) appends the few parents near a periodic wall -- 2 % of a 10 k field -- to a
+// candidate list {parent, flags, ring points}; this kernel gives every entry a wavefront, which finds its place in the
+// reference's ghost order (all E/W ghosts by parent, then all N/S ghosts by parent: the prefix over the entries with a
+// smaller parent index, read straight off the list), makes the parent's ghosts (ghost_fill_parent) and, in the first
+// wavefront, commits the new counts.  It replaces flag + scan over ALL parents and the fill launch (8.6 + 14.6 us at
+// 10 k floes for ~240 ghosts).  Two lists alternate: the integrator of a step fills the one the next step consumes, and
+// the consumer clears the counter of the other one.  The host falls back to the two-launch path when the list is long
+// (the prefix is quadratic in its length) or stale (process-mode calls).
+__device__ __forceinline__ int ghost_flag_of(const double* ev, int per_ew, int per_ns, double cx, double cy, double r,
+                                             double bx0, double bx1, double by0, double by1, bool active) {
+  int dx = 0, dy = 0;
+  if (active) {
+    if (per_ew) { if (cx - r < ev[3]) dx = bx0 < ev[3] ? 1 : 0; else if (cx + r > ev[2]) dx = bx1 > ev[2] ? -1 : 0; }
+    if (per_ns) { if (cy - r < ev[1]) dy = by0 < ev[1] ? 1 : 0; else if (cy + r > ev[0]) dy = by1 > ev[0] ? -1 : 0; }
+  }
+  return (dx + 1) | ((dy + 1) << 2);
+}
+// thread-per-floe kernels: one counter atomic per wavefront
+__device__ __forceinline__ void ghost_candidate_wave(const State& S, int list, bool have, int i, int flag, int nv, int vo) {
+  const unsigned long long mask = __ballot(have);
+  if (!mask) return;
+  const int lane = threadIdx.x & 63, first = __ffsll((long long)mask) - 1;
+  int base = 0;
+  if (lane == first) base = atomicAdd(&S.cnt[C_NGCAND + list], __popcll(mask));
+  base = __shfl(base, first);
+  if (have) S.gcand[(size_t)list * S.capM + base + __popcll(mask & ((1ull << lane) - 1ull))] = make_int4(i, flag, nv, vo);
+}
+__device__ __forceinline__ void ghost_candidate_one(const State& S, int list, int i, int flag, int nv, int vo) {
+  S.gcand[(size_t)list * S.capM + atomicAdd(&S.cnt[C_NGCAND + list], 1)] = make_int4(i, flag, nv, vo);
+}
+__global__ void __launch_bounds__(256) sz_k_ghost_list(State S, int list, int bin, int nh) {
+  if (stopped(S)) return;
+  const GridGeo geo = grid_geo(S);
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int n = S.cnt[C_NGCAND + list];
+  const int N = nh >= 0 ? nh : S.cnt[C_N];
+  const int NV0 = S.voff[N];
+  const double wall[4] = { S.eval[0], S.eval[1], S.eval[2], S.eval[3] };
+  const int4* L = S.gcand + (size_t)list * S.capM;
+  for (int e = wave; e < (n > 0 ? n : 1); e += nwaves) {
+    const int4 mine = e < n ? L[e] : make_int4(0x7fffffff, 5, 0, 0);
+    int4 ex = make_int4(0, 0, 0, 0), T = make_int4(0, 0, 0, 0);
+    for (int q = lane; q < n; q += 64) {
+      const int4 o = L[q];
+      const int gew = (o.y & 3) != 1 ? 1 : 0, gns = ((o.y >> 2) & 3) != 1 ? 1 + gew : 0;
+      const int4 p = make_int4(gew, gew * o.z, gns, gns * o.z);
+      T = add4(T, p);
+      if (o.x < mine.x) ex = add4(ex, p);
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      ex = add4(ex, make_int4(__shfl_xor(ex.x, d), __shfl_xor(ex.y, d), __shfl_xor(ex.z, d), __shfl_xor(ex.w, d)));
+      T = add4(T, make_int4(__shfl_xor(T.x, d), __shfl_xor(T.y, d), __shfl_xor(T.z, d), __shfl_xor(T.w, d)));
+    }
+    const int newg = T.x + T.z, newv = T.y + T.w;
+    const bool fits = N + newg <= S.capM && NV0 + newv <= S.capV;
+    if (e == 0 && lane == 0) {                       // commit (as sz_k_ghost_flag_scan does with commit = 1)
+      const int M = fits ? N + newg : N;
+      S.cnt[C_M] = M; S.cnt[C_NV] = fits ? NV0 + newv : NV0; S.cnt[C_NGHOSTS] = fits ? newg : 0;
+      if (fits) S.voff[M] = NV0 + newv;
+      else atomicOr(&S.cnt[C_ERR], N + newg > S.capM ? ERR_CAP_FLOES : ERR_CAP_VERTS);
+      S.cnt[C_NGCAND + (1 - list)] = 0;              // the list this step's integrator fills
+    }
+    if (!fits || e >= n) break;
+    ghost_fill_parent(S, geo, lane, mine.x, mine.y, ex, T, N, NV0, bin, mine.w, mine.z, wall);
+  }
+}
+// seeds candidate list `list` from the parents as they lie (after an upload / a process-mode call), thread per parent
+__global__ void sz_k_ghost_seed(State S, int list) {
+  const int N = S.cnt[C_N];
+  const double ev[4] = { S.eval[0], S.eval[1], S.eval[2], S.eval[3] };
+  for (int i0 = blockIdx.x * blockDim.x; i0 < N; i0 += gridDim.x * blockDim.x) {
+    const int i = i0 + threadIdx.x;
+    int fl = 5, nv = 0, vo = 0;
+    if (i < N) {
+      fl = ghost_flag_of(ev, S.any_periodic_ew, S.any_periodic_ns, S.cx[i], S.cy[i], S.rmax[i], S.bbx0[i], S.bbx1[i], S.bby0[i], S.bby1[i],
+                         S.status[i] == SZ_ACTIVE && S.ghost_id[i] == 0);
+      vo = S.voff[i]; nv = S.voff[i + 1] - vo;
+    }
+    ghost_candidate_wave(S, list, fl != 5, i, fl, nv, vo);
   }
 }
 __device__ __forceinline__ void ghost_commit(State& S) {
@@ -774,7 +882,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
   GroupMem<CAP, KC, RC, RM>& m = mem[gi];
   const int npairs = S.cnt[C_NWORK], nel = S.cnt[C_NELEM];     // pair items = the work list (ring boxes overlap)
   const int nitems = npairs + nel;
-  if (gl == 0) { m.err = 0; m.ntracefail = 0; m.acc[0] = m.acc[1] = 0; m.acc16[0] = m.acc16[1] = m.acc16[2] = 0; }   // acc: work done by this group (in LDS: no register held across the rounds)
+  if (gl == 0) { m.err = 0; m.ierr = 0; m.ntracefail = 0; m.nchk = 0; m.nkeep = 0; m.acc[0] = m.acc[1] = 0; m.acc16[0] = m.acc16[1] = m.acc16[2] = 0; }   // acc: work done by this group (in LDS: no register held across the rounds)
   Stamps st; STAMP_INIT(st);
 #ifdef SZ_STAMPS
   st.on = (CLS == 0 && blockIdx.x == (unsigned)(dbg >> 8) && threadIdx.x == 0); st.log = S.stamps + 1;
@@ -810,72 +918,97 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
      todo = __ballot(want);
    }
    while (todo) {
+    // ================= phase A: every lane group stages its own item and runs the contact clip
     int t;
     if (SCAN) { t = t0 + __ffsll((long long)todo) - 1; todo &= todo - 1; }
-    else { todo = 0; t = t0 + gi; if (t >= limit) break; }
+    else { todo = 0; t = t0 + gi; }
+    bool have = t < limit;
     const bool is_pair = t < npairs;
-    int i, j = -1, e = -1, item;
-    if (is_pair) { int4 w = S.work[t]; item = w.x; i = w.y; j = w.z; }
-    else { int q = t - npairs; i = S.el_floe[q]; e = S.el_elem[q]; item = S.capPairs + q; }
-    const int ao = S.voff[i], na = S.voff[i + 1] - ao;
-    const int bo = is_pair ? S.voff[j] : S.eoff[e];
-    const int nb = (is_pair ? S.voff[j + 1] : S.eoff[e + 1]) - bo;
-    const int big = na > nb ? na : nb;
-    // an item belongs to the first variant whose ring capacity fits it; an item a smaller variant
-    // gave up on (more crossings / region points / regions than its working set holds) is handed to
-    // the largest one through IT_RETRY
-    const bool retry = CLS == 2 && (S.it_flags[item] & IT_RETRY);
-    if (big <= LO && !retry) continue;
-    if (big > CAP) { if (CLS == 2 && gl == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); continue; }
-    const double* bxs = is_pair ? S.vx : S.ex; const double* bys = is_pair ? S.vy : S.ey;
-    gsync();
-    for (int q = gl; q < na; q += G) { m.ax[q] = S.vx[ao + q]; m.ay[q] = S.vy[ao + q]; }
-    for (int q = gl; q < nb; q += G) { m.bx[q] = bxs[bo + q]; m.by[q] = bys[bo + q]; }
-    const int ekind = is_pair ? 0 : S.ekind[e];
-    for (int q = gl; q < 14; q += G) {          // the item's scalars, one lane each
-      const int c = q < 10 ? q % 5 : 5 + (q & 1);                  // cx cy u v xi | area height
-      const bool side_j = q < 10 ? q >= 5 : q >= 12;
-      const double* col = c == 0 ? S.cx : c == 1 ? S.cy : c == 2 ? S.u : c == 3 ? S.v : c == 4 ? S.xi : c == 5 ? S.area : S.height;
-      double val;
-      if (!side_j) val = col[i];
-      else if (is_pair) val = col[j];
-      else val = (ekind == 3 && c == 2) ? S.eu[e] : (ekind == 3 && c == 3) ? S.ev[e] : 0.0;   // a wall / topography: rigid (u, v)
-      m.kin[q] = val;
+    int i = 0, j = -1, e = -1, item = 0, na = 0, nb = 0, ao = 0, bo = 0;
+    if (have) {
+      if (is_pair) { int4 w = S.work[t]; item = w.x; i = w.y; j = w.z; }
+      else { int q = t - npairs; i = S.el_floe[q]; e = S.el_elem[q]; item = S.capPairs + q; }
+      ao = S.voff[i]; na = S.voff[i + 1] - ao;
+      bo = is_pair ? S.voff[j] : S.eoff[e];
+      nb = (is_pair ? S.voff[j + 1] : S.eoff[e + 1]) - bo;
+      const int big = na > nb ? na : nb;
+      // an item belongs to the first variant whose ring capacity fits it; an item a smaller variant
+      // gave up on (more crossings / region points / regions than its working set holds) is handed to
+      // the largest one through IT_RETRY
+      const bool retry = CLS == 2 && (S.it_flags[item] & IT_RETRY);
+      if (big <= LO && !retry) have = false;
+      else if (big > CAP) { if (CLS == 2 && gl == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); have = false; }
     }
-    gsync();
-    const int oa = S.osign[i], ob = is_pair ? S.osign[j] : S.eosign[e];
-    STAMP(st, 0);
     ItemCtx ic;
     ic.E = P.E; ic.nu = P.nu; ic.mu = P.mu; ic.dt = dt; ic.dbg = dbg;
-    if (is_pair) {
-      ic.mode = ITEM_PAIR; ic.max_overlap = ff_max_overlap; ic.elem_dir = -1; ic.elem_val = 0.0; ic.rigid_j = 0;
-    } else {
-      ic.mode = ekind == 0 ? ITEM_OPEN : ITEM_SOLID; ic.max_overlap = fd_max_overlap;
-      ic.elem_dir = e < 4 ? e : -1; ic.elem_val = S.eval[e]; ic.rigid_j = 1;
-    }
-    int nrows = 0, flags = 0;
-    double* out = S.it_rows + (size_t)item * ROWS_PER_ITEM * 5;
-    Box ba{ S.bbx0[i], S.bbx1[i], S.bby0[i], S.bby1[i] };
-    Box bb = is_pair ? Box{ S.bbx0[j], S.bbx1[j], S.bby0[j], S.bby1[j] } : Box{ S.ebb[4 * e], S.ebb[4 * e + 1], S.ebb[4 * e + 2], S.ebb[4 * e + 3] };
-    if (!(dbg & 4)) nrows = collide_item<G>(m, gl, na, oa, nb, ob, ba, bb, ic, out, ROWS_PER_ITEM, flags, st);
+    ic.mode = ITEM_PAIR; ic.max_overlap = ff_max_overlap; ic.elem_dir = -1; ic.elem_val = 0.0; ic.rigid_j = 0;
+    int flags = 0;
     gsync();
-    constexpr int CAPBITS = ERR_CAP_XING | ERR_CAP_REGION | ERR_CAP_ROWS;
-    if (CLS < 2 && (m.err & CAPBITS)) {                // working set too small: let the next variant redo the item
-      nrows = 0; flags = IT_RETRY;
+    if (have) {
+      const double* bxs = is_pair ? S.vx : S.ex; const double* bys = is_pair ? S.vy : S.ey;
+      for (int q = gl; q < na; q += G) { m.ax[q] = S.vx[ao + q]; m.ay[q] = S.vy[ao + q]; }
+      for (int q = gl; q < nb; q += G) { m.bx[q] = bxs[bo + q]; m.by[q] = bys[bo + q]; }
+      const int ekind = is_pair ? 0 : S.ekind[e];
+      for (int q = gl; q < 14; q += G) {          // the item's scalars, one lane each
+        const int c = q < 10 ? q % 5 : 5 + (q & 1);                  // cx cy u v xi | area height
+        const bool side_j = q < 10 ? q >= 5 : q >= 12;
+        const double* col = c == 0 ? S.cx : c == 1 ? S.cy : c == 2 ? S.u : c == 3 ? S.v : c == 4 ? S.xi : c == 5 ? S.area : S.height;
+        double val;
+        if (!side_j) val = col[i];
+        else if (is_pair) val = col[j];
+        else val = (ekind == 3 && c == 2) ? S.eu[e] : (ekind == 3 && c == 3) ? S.ev[e] : 0.0;   // a wall / topography: rigid (u, v)
+        m.kin[q] = val;
+      }
+      const int oa = S.osign[i], ob = is_pair ? S.osign[j] : S.eosign[e];
+      if (!is_pair) {
+        ic.mode = ekind == 0 ? ITEM_OPEN : ITEM_SOLID; ic.max_overlap = fd_max_overlap;
+        ic.elem_dir = e < 4 ? e : -1; ic.elem_val = S.eval[e]; ic.rigid_j = 1;
+      }
+      const Box ba{ S.bbx0[i], S.bbx1[i], S.bby0[i], S.bby1[i] };
+      const Box bb = is_pair ? Box{ S.bbx0[j], S.bbx1[j], S.bby0[j], S.bby1[j] } : Box{ S.ebb[4 * e], S.ebb[4 * e + 1], S.ebb[4 * e + 2], S.ebb[4 * e + 3] };
       gsync();
-      if (gl == 0) { m.err &= ~CAPBITS; atomicMax(&S.cnt[C_ITEMCLASS], 2); atomicAdd(&S.cnt[C_NRETRY], 1); }   // the largest variant retries
-    }
-    if (gl == 0) {
-      S.it_nrows[item] = nrows; S.it_flags[item] = flags;
-      if (!(flags & IT_RETRY)) {                           // counted by the variant that finishes the item
-        if (is_pair) { m.acc16[0]++; m.acc[0] += (unsigned)(na + nb); m.acc[1] += (unsigned)nrows; } else { m.acc16[1]++; m.acc16[2] += (uint16_t)nrows; }
+      STAMP(st, 0);
+      if (!(dbg & 4)) contact_phase<G>(m, gl, na, oa, nb, ob, ba, bb, ic, flags, st);
+      else if (gl == 0) { m.nkeep = 0; m.nchk = 0; m.ierr = 0; }
+    } else if (gl == 0) { m.nkeep = 0; m.nchk = 0; m.ierr = 0; }
+    gsync();
+    // ================= phase B: the direction checks of ALL items of the wavefront, one per lane group and turn.  An item
+    // with two or three contact regions no longer works its checks off one after the other while the other groups idle:
+    // 14 % of the wavefronts hold such an item, and they used to set the kernel's duration.
+    {
+      int pre = 0, total = 0;
+      for (int g = 0; g < GPB; g++) total += mem[g].nchk;
+      for (int base = 0; base < total; base += GPB) {
+        const int idx = base + gi;
+        if (idx < total) {
+          int g = 0; pre = 0;
+          while (pre + mem[g].nchk <= idx) { pre += mem[g].nchk; g++; }
+          check_task<G>(mem[g], m, gl, (int)mem[g].chk[idx - pre], st);
+        }
+        gsync();
       }
     }
-    STAMP(st, 11);
+    // ================= phase C: friction and the rows of the own item, in region order
+    if (have) {
+      double* out = S.it_rows + (size_t)item * ROWS_PER_ITEM * 5;
+      int nrows = finish_phase<G>(m, gl, ic, out, ROWS_PER_ITEM, st);
+      gsync();
+      if (CLS < 2 && (m.ierr & CAPBITS)) {                // working set too small: let the largest variant redo the item
+        nrows = 0; flags = IT_RETRY;
+        if (gl == 0) { atomicMax(&S.cnt[C_ITEMCLASS], 2); atomicAdd(&S.cnt[C_NRETRY], 1); }
+      } else if (gl == 0 && m.ierr) m.err |= m.ierr;
+      if (gl == 0) {
+        S.it_nrows[item] = nrows; S.it_flags[item] = flags;
+        if (!(flags & IT_RETRY)) {                           // counted by the variant that finishes the item
+          if (is_pair) { m.acc16[0]++; m.acc[0] += (unsigned)(na + nb); m.acc[1] += (unsigned)nrows; } else { m.acc16[1]++; m.acc16[2] += (uint16_t)nrows; }
+        }
+      }
+      STAMP(st, 11);
 #ifdef SZ_STAMPS
-    if (st.on) { if (nrows > 0) { S.stamps[0] = st.n; st.on = false; } else { st.n = 0; st.t0 = clock64(); } }
-    st.maxrows = st.maxrows > nrows ? st.maxrows : nrows;
+      if (st.on) { if (nrows > 0) { S.stamps[0] = st.n; st.on = false; } else { st.n = 0; st.t0 = clock64(); } }
+      st.maxrows = st.maxrows > nrows ? st.maxrows : nrows;
 #endif
+    }
    }
    if (useq) {
      int tk = 0;
@@ -912,7 +1045,8 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
 #endif
 }
 
-constexpr int NARROW_CAP0 = 20, NARROW_CAP1 = 32, NARROW_CAP2 = 128;   // ring points per variant
+constexpr int NARROW_CAP0 = 18, NARROW_CAP1 = 32, NARROW_CAP2 = 128;   // ring points per variant (18: rings of up to 17 vertices; the
+                                                                       // working set of the first variant is cut to fit 2 KB of LDS per item)
 
 // items not touched by any narrow variant would keep stale row counts: clear them first
 __global__ void sz_k_items_clear(State S) {
@@ -1384,12 +1518,16 @@ __global__ void sz_k_calc_stress(State S, Params P) {
 // are the same expressions summed in the same order.
 constexpr int MV_RING = 20;
 template <bool MOVE>
-__global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Params P, int dt, int apply_frc, int bin, int nh) {
+// gl_fill (resident steps): the ghost-candidate list to append to (sz_k_ghost_list), -1: none
+__global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Params P, int dt, int apply_frc, int bin, int nh, int gl_fill) {
   const GridGeo geo = grid_geo(S);
   if (stopped(S)) return;
   const int N = nh >= 0 ? nh : S.cnt[C_NOWN];     // nh: see sz_k_ghost_flag_scan
   int wh = 0, wf = 0, wv = 0, wx = 0;
+  const double wall[4] = { S.eval[0], S.eval[1], S.eval[2], S.eval[3] };
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    const int st0 = gl_fill >= 0 ? S.status[i] : SZ_ACTIVE, ngh0 = gl_fill >= 0 ? S.ngh[i] : 0;
+    const double rmx = MOVE && gl_fill >= 0 ? S.rmax[i] : 0.0;
     // Memory order is the whole cost of this kernel (a store in between keeps the compiler from hoisting the
     // loads behind it, and every batch of loads is one HBM round trip): everything is read first -- the
     // columns, then what their values address (contact rows, ring) -- then computed, then stored.
@@ -1454,6 +1592,9 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
     if (fabs(nxi) > P.max_xi) { nxi = sgn(nxi) * P.max_xi; wx++; }
     // ---- stores
     if (frc_rm) { S.status[i] = SZ_REMOVE; request_stop(S); }
+    // the ghosts of this step are detached here (nothing after the reduce looks at them): the next step's ghost pass
+    // then only visits the parents that get new ones
+    if (ngh0 != 0) { S.ngh[i] = 0; for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = -1; }
     for (int k = 0; k < 4; k++) { S.sa[i * 4 + k] = (1 - l) * sa0[k] + l * sv[k]; S.si[i * 4 + k] = sv[k]; }
     S.mass[i] = mass; S.moment[i] = moment; S.height[i] = h;
     S.alpha[i] = al;
@@ -1494,6 +1635,10 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
       S.strain[i * 4 + 0] = e11 / d; S.strain[i * 4 + 1] = e12 / d; S.strain[i * 4 + 2] = e12 / d; S.strain[i * 4 + 3] = e22 / d;
       S.cx[i] = ncx; S.cy[i] = ncy;
       if (bin) cell_insert(S, geo, i, ncx, ncy);
+      if (gl_fill >= 0) {
+        const int gf = ghost_flag_of(wall, S.any_periodic_ew, S.any_periodic_ns, ncx, ncy, rmx, bx0, bx1, by0, by1, (frc_rm ? SZ_REMOVE : st0) == SZ_ACTIVE);
+        ghost_candidate_wave(S, gl_fill, gf != 5, i, gf, n, o);
+      }
     }
   }
   // one atomic per wavefront and counter, spread over WARN_SLOTS lines: the guards fire for most floes of a stiff
@@ -1514,7 +1659,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
 // coordinates recomputed in registers (same expression as the store, hence the same bits), the
 // ring is overwritten afterwards, and the per-edge terms are summed in ring order.
 // strain_only: calc_strain! on its own -- the ring stays where it is and nothing but the strain is written
-__global__ void __launch_bounds__(256) sz_k_move_strain(State S, int strain_only, int bin) {
+__global__ void __launch_bounds__(256) sz_k_move_strain(State S, int strain_only, int bin, int gl_fill) {
   const GridGeo geo = grid_geo(S);
   constexpr int G = 16;
   __shared__ double t11[256 / G][64], t12[256 / G][64], t22[256 / G][64];
@@ -1569,6 +1714,11 @@ __global__ void __launch_bounds__(256) sz_k_move_strain(State S, int strain_only
       S.strain[i * 4 + 0] = e11 / d; S.strain[i * 4 + 1] = e12 / d; S.strain[i * 4 + 2] = e12 / d; S.strain[i * 4 + 3] = e22 / d;
       if (!strain_only) { S.cx[i] = ncx; S.cy[i] = ncy; }
       if (bin) cell_insert(S, geo, i, ncx, ncy);          // for the next step's neighbour search
+      if (gl_fill >= 0) {                                 // ... and its ghost pass
+        const double wall[4] = { S.eval[0], S.eval[1], S.eval[2], S.eval[3] };
+        const int gf = ghost_flag_of(wall, S.any_periodic_ew, S.any_periodic_ns, ncx, ncy, S.rmax[i], bx0, bx1, by0, by1, S.status[i] == SZ_ACTIVE);
+        if (gf != 5) ghost_candidate_one(S, gl_fill, i, gf, n, o);
+      }
     }
   }
 }
@@ -1621,7 +1771,7 @@ __global__ void __launch_bounds__(1024) sz_k_halo_pack(State S, int nranks, int 
 // `cap` record slots.  The host never needs the counts, so a whole step is enqueued without a sync.
 // One block appends the received floes as extra parents [nown, nown + nrec): ring offsets by an
 // in-kernel scan of the ring sizes, then the copy.
-__global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* recv, int nranks, int cap, int bin) {
+__global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* recv, int nranks, int cap, int bin, int gl_fill) {
   const GridGeo geo = grid_geo(S);
   __shared__ int before[65];
   __shared__ int tot, carry_s;
@@ -1672,6 +1822,11 @@ __global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* 
     S.osign[g] = ring_signed_area(r + 12, r + 12 + HALO_RING, nv) >= 0.0 ? 1 : -1;
     S.bbx0[g] = x0; S.bbx1[g] = x1; S.bby0[g] = y0; S.bby1[g] = y1;
     if (bin) cell_insert(S, geo, g, r[3], r[4]);
+    if (gl_fill >= 0) {
+      const double wall[4] = { S.eval[0], S.eval[1], S.eval[2], S.eval[3] };
+      const int gf = ghost_flag_of(wall, S.any_periodic_ew, S.any_periodic_ns, r[3], r[4], r[5], x0, x1, y0, y1, (int)r[1] == SZ_ACTIVE);
+      if (gf != 5) ghost_candidate_one(S, gl_fill, g, gf, nv, vb);
+    }
   }
   if (threadIdx.x == 0) {
     S.cnt[C_M] = nown + nrec; S.cnt[C_N] = nown + nrec; S.cnt[C_NV] = vbase + totv; S.cnt[C_NHALO] = nrec;

@@ -21,7 +21,8 @@ enum {
   C_NPAIR_PTS,    // sum of ring points over pairs (stats)
   C_NPAIR_ROWS,   // contact rows before mirroring (stats)
   C_NELEM_ROWS,
-  C_UNUSED0, C_UNUSED1, C_UNUSED2, C_UNUSED3,   // (the guard counters live in State::warn: one word each serialised the chip)
+  C_NGCAND, C_NGCAND1,   // entries of the two ghost-candidate lists (State::gcand), used alternately step by step
+  C_UNUSED2, C_UNUSED3,   // (the guard counters live in State::warn: one word each serialised the chip)
   C_NG_NEW,       // ghosts created by the current pass
   C_NGHOSTS,
   C_NCELLS,
@@ -95,6 +96,8 @@ struct State {
   // ---- ghosts workspace
   int *gflag, *gvscan;        // gvscan: ring offsets of the halo records being unpacked
   int4 *gplan, *gscan4, *gtot4;
+  int4* gcand;                // two lists of capM entries {parent, ghost flags, ring points, -}: the parents that get ghosts in the next
+                              // step, appended by whoever places a floe (integrator, halo unpack) -- see sz_k_ghost_list
   int4 *lb_agg, *lb_inc; unsigned* lb_flag;   // decoupled look-back scan: per workgroup aggregate, inclusive prefix, (epoch << 2 | status)
   // ---- broad phase
   double* bounds;            // xmin, ymin, cell size, (ncx, ncy as doubles)

@@ -459,3 +459,39 @@ def test_field_reupload_keeps_the_temperatures():
         assert np.array_equal(a, b)
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
     assert np.any(res[0][0][3] != 0)                      # a heat-flux factor that is not the zero-temperature one
+
+
+def test_ghost_candidate_list_equals_the_two_launch_pass():
+    """The resident steps make the periodic ghosts from a candidate list kept by the integrator (one launch); the
+    process-mode pass (flag + scan over all parents, fill) is pinned by the reference's add_ghosts! cases.  Both must
+    give the same run bit for bit -- fast floes, so that parents cross the walls and swap with their ghosts
+    (collisions.jl:942-950), and a host edit in the middle (the list is seeded again)."""
+    import os
+    from subzero_jl_amd import fields
+    from subzero_jl_amd import floe as floe_mod
+    cfg = fields.make_config(n_floes=500, seed=77)
+    cfg["u"] = np.abs(cfg["u"]) * 60.0 + 2.0; cfg["v"] = cfg["v"] * 60.0        # eastward, 2 to 8 m/s: up to 160 m per step
+    # the lattice keeps centroids 8 km off the walls: shift the field so that the last column's centroids straddle the
+    # east wall (some parents start outside the domain and swap in step 0, others cross during the run)
+    cfg["vx"] = cfg["vx"] + 9800.0; cfg["vy"] = cfg["vy"] + 9900.0
+    cfg["derived"] = floe_mod.derive(cfg["vert_off"], cfg["vx"], cfg["vy"], cfg["height"])
+    runs = []
+    for env in ("1", "0"):
+        os.environ["SZ_GHOST_LIST"] = env
+        try:
+            w = fields.build_world(mk(), cfg)
+        finally:
+            del os.environ["SZ_GHOST_LIST"]
+        w.run(40, 0, cfg["dt"], coupling_dt=1, stop_on_tags=False)
+        u = w.get("u"); u[::9] *= -1.0; w.set("u", u)
+        w.run(35, 40, cfg["dt"], coupling_dt=1, stop_on_tags=False)
+        w.run(5, 75, cfg["dt"], coupling_dt=1, stop_on_tags=False)
+        runs.append({f: w.get(f) for f in ("cx", "cy", "u", "v", "xi", "alpha", "coll_fx", "coll_fy", "overarea", "sa11")} | {"rings": w.rings()[1], "ng": w.stats()["n_ghosts"]})
+    a, b = runs
+    assert a["ng"] == b["ng"] > 20
+    for f in a:
+        assert np.array_equal(a[f], b[f]), f
+    L = cfg["L"]
+    wrapped = np.abs(a["cx"] - cfg["derived"]["cx"]) > 0.5 * L
+    assert wrapped.sum() >= 3                            # parents went through the east wall and came back in the west
+    assert np.any(wrapped & (cfg["derived"]["cx"] <= L)) # ... also some that started inside
