@@ -306,6 +306,7 @@ void use_static_grid(sz_ctx* c) {
   if (c->grid_live) return;
   (void)hipMemcpyAsync(c->S.bounds, c->h_grid, 8 * sizeof(double), hipMemcpyHostToDevice, c->stream);
   (void)hipMemsetAsync(c->S.cell_cnt, 0, ((size_t)c->S.capCells + 1) * sizeof(int), c->stream);
+  (void)hipMemsetAsync(c->S.cell_ovf, 0, ((size_t)c->S.capCells + 1) * sizeof(int), c->stream);
   hipLaunchKernelGGL(sz_k_cell_build, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 1);
   c->grid_live = true;
 }
@@ -353,19 +354,18 @@ void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false
   State& S = c->S;
   Timed t(c, SZ_K_BROAD);
   int gM = grid_for(S.capM, 256);
-  if (!static_grid) {          // with the static grid the lists are already current (see sz_k_cell_build)
+  if (!static_grid) {          // with the static grid the cells are already current (see sz_k_cell_build)
     hipLaunchKernelGGL(sz_k_bounds, dim3(1), dim3(1024), 0, c->stream, S, commit_ghosts ? 1 : 0);
     hipLaunchKernelGGL(sz_k_cell_build, dim3(gM), dim3(256), 0, c->stream, S, 0);
     c->grid_live = false;
   }
+  // the neighbour search appends the pair items to the narrow phase's work list itself: no scan, no pair-list launch
   if (fuse_forcing) {          // the step's forcings ride in the neighbour launch (sz_k_neighbors_forcing)
     const int nbn = grid_for(S.capM, 256 / NB_G, 8192), nbf = grid_for(S.capM, 256 / FRC_G, 8192);
     if (c->precision == 1) hipLaunchKernelGGL(sz_k_neighbors_forcing<2>, dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn);
     else hipLaunchKernelGGL(sz_k_neighbors_forcing<1>, dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn);
   } else
     hipLaunchKernelGGL(sz_k_neighbors, dim3(grid_for(S.capM, NB_TPB / NB_G, 8192)), dim3(NB_TPB), 0, c->stream, S);
-  int nb = grid_for(S.capM, SCAN_B, 1 << 20);
-  hipLaunchKernelGGL(sz_k_pscan_fill, dim3(nb), dim3(SCAN_B), 0, c->stream, S, next_epoch(c), static_grid ? 1 : 0);
   t.end();
 }
 
@@ -387,7 +387,8 @@ void stage_elems(sz_ctx* c, bool enabled) {
 void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = false) {
   State& S = c->S;
   // dynamic rounds (see sz_k_narrow) where the queue heads were just cleared (static-grid steps); SZ_NARROW_QUEUE=0: off
-  const int queue = housekept && !c->no_queue ? 1 : 0;
+  const int queue = c->no_queue ? 0 : 1;      // (the reduce kernel resets the queue heads after every narrow phase)
+  (void)housekept;
   long long capItems = (long long)S.capPairs + S.capElem;
   // Rings never change size inside the hot path, so the host knows whether any item can need a
   // larger variant (halo floes of a tiled run arrive unseen: then always check on the device).
@@ -550,19 +551,19 @@ void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool 
 // (timestep_coupling! follows timestep_collisions! in timestep_sim!, simulation.jl:109-161)
 int host_fuse_fixup(sz_ctx* c, const int* h, bool mirror, bool after_step = false, bool coupled = false) {
   State& S = c->S;
-  int M = after_step ? h[C_N] + h[C_NGHOSTS] : h[C_M], P = h[C_NPAIRS];
+  int M = after_step ? h[C_N] + h[C_NGHOSTS] : h[C_M];
   if ((int)c->fuse_lists.size() < M) c->fuse_lists.resize(M);
-  if (P == 0) return SZ_OK;
-  std::vector<int> fl(P), pi(P), pj(P);
-  HIPCHK(c, hipMemcpy(fl.data(), S.it_flags, (size_t)P * sizeof(int), hipMemcpyDeviceToHost));
-  bool any = false;
-  for (int p = 0; p < P; p++) if (fl[p] & IT_FUSE) { any = true; break; }
-  if (!any) return SZ_OK;
-  HIPCHK(c, hipMemcpy(pi.data(), S.pair_i, (size_t)P * sizeof(int), hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(pj.data(), S.pair_j, (size_t)P * sizeof(int), hipMemcpyDeviceToHost));
+  if (h[C_NFUSE] == 0 || M == 0) return SZ_OK;          // no pair asked for a fuse (the narrow phase counts them)
+  // the pairs in the reference's serial order (i asc, j asc): per floe its sorted list of owned pairs
+  std::vector<int> nout(M), nbo((size_t)M * MAXNB); std::vector<int2> info((size_t)M * MAXNB);
+  HIPCHK(c, hipMemcpy(nout.data(), S.n_out, (size_t)M * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(nbo.data(), S.nb_out, (size_t)M * MAXNB * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(info.data(), S.it_info, (size_t)M * MAXNB * sizeof(int2), hipMemcpyDeviceToHost));
   std::vector<int> tag(M);
   HIPCHK(c, hipMemcpy(tag.data(), c->S.tagA, (size_t)M * sizeof(int), hipMemcpyDeviceToHost));
-  for (int p = 0; p < P; p++) if (fl[p] & IT_FUSE) c->fuse_lists[pi[p]].push_back(pj[p]);
+  for (int i = 0; i < M; i++)
+    for (int r = 0; r < nout[i]; r++)
+      if ((info[(size_t)i * MAXNB + r].x >> 8) & IT_FUSE) c->fuse_lists[i].push_back(nbo[(size_t)i * MAXNB + r]);
   if (mirror) {
     for (int i = 0; i < M; i++) {
       if (tag[i] != SZ_FUSE) continue;
@@ -611,7 +612,7 @@ sz_ctx* sz_create(int device_id) {
   P.fcor = 1.4e-4; P.turn = 15.0 * 3.14159265358979323846 / 180.0; P.ff_max_overlap = 0.55; P.fd_max_overlap = 0.75;
   P.rho_i = 920.0; P.max_h = 10.0; P.max_xi = 1e-5; P.lambda = 0.2; P.dd = 1;
   P.Cd_ao = 1.25e-3; P.k_ice = 2.14; P.L_ice = 2.93e5;
-  if (hipMalloc((void**)&c->d_stats, 16 * sizeof(long long)) != hipSuccess) { delete c; return nullptr; }
+  if (hipMalloc((void**)&c->d_stats, 18 * sizeof(long long)) != hipSuccess) { delete c; return nullptr; }
   if (hipMalloc((void**)&c->S.acc, (size_t)ACC_SLOTS * 8 * sizeof(unsigned long long)) != hipSuccess) { delete c; return nullptr; }
   (void)hipMemset(c->S.acc, 0, (size_t)ACC_SLOTS * 8 * sizeof(unsigned long long));
   return c;
@@ -758,13 +759,13 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(gplan, S.capM + 1); DA(gscan4, S.capM + 1); DA(gtot4, 4);
   DA(lb_agg, S.capM / SCAN_B + 8); DA(lb_inc, S.capM / SCAN_B + 8); DA(lb_flag, S.capM / SCAN_B + 8); c->scan_epoch = 0;
   DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2); DA(gcand, (size_t)2 * S.capM);
-  DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1);
+  DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1); DA(cell_ovf, S.capCells + 1); DA(cell_slots, (size_t)S.capCells * CELL_K + 8);
   DA(cell_items, S.capM);
   DA(nb_out, (size_t)S.capM * MAXNB); DA(nb_in, (size_t)S.capM * MAXNB); DA(n_out, S.capM + 1); DA(n_in, S.capM + 1);
-  DA(out_off, S.capM + 2); DA(out_mask, S.capM + 1); DA(n_work, S.capM + 1); DA(work_off, S.capM + 2); DA(work, S.capPairs + 1); DA(wq, 8 * 32); DA(pair_i, S.capPairs); DA(pair_j, S.capPairs);
+  DA(out_off, S.capM + 2); DA(out_mask, S.capM + 1); DA(work, S.capPairs + NSEG); DA(wq, NSEG * 32); DA(pair_i, S.capPairs); DA(pair_j, S.capPairs);
   DA(el_off, S.capM + 2); DA(el_floe, S.capElem); DA(el_elem, S.capElem);
   size_t items = (size_t)S.capPairs + S.capElem;
-  DA(it_rows, items * ROWS_PER_ITEM * 5); DA(it_nrows, items); DA(it_flags, items);
+  DA(it_rows, items * ROWS_PER_ITEM * 5); DA(it_info, (size_t)S.capM * MAXNB + S.capElem + 1);
   DA(inter_off, S.capM + 2);
   // floe.interactions is part of the floe state, but not of sz_floe_columns (it is ragged): the rows the last
   // collision call left stay valid across an upload of the same size; after an upload of another size they are
@@ -809,21 +810,21 @@ int sz_get_stats(sz_ctx* c, sz_stats* out) {
   (void)hipSetDevice(c->device);
   tile_cleanup(c);
   State& S = c->S;
-  HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 16 * sizeof(long long), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 18 * sizeof(long long), c->stream));
   hipLaunchKernelGGL(sz_k_stats, dim3(grid_for((long long)S.capPairs + S.capElem, 256, 1024)), dim3(256), 0, c->stream, S, c->d_stats);
-  int h[C_COUNT]; long long st[16];
+  int h[C_COUNT]; long long st[18];
   HIPCHK(c, hipMemcpyAsync(st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(h, S.cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int soffN = 0;
   HIPCHK(c, hipMemcpy(&soffN, S.soff + h[C_N], sizeof(int), hipMemcpyDeviceToHost));
   out->M = h[C_M]; out->N = h[C_N]; out->n_ring_points = h[C_NV]; out->n_sub_points = soffN;
-  out->n_pairs = h[C_NPAIRS]; out->n_pair_ring_points = st[0]; out->n_pair_rows = st[1];
+  out->n_pairs = st[16]; out->n_pair_ring_points = st[0]; out->n_pair_rows = st[1];
   out->n_elem_items = h[C_NELEM]; out->n_elem_rows = st[2]; out->n_inter_rows = st[3]; out->n_ghosts = h[C_NGHOSTS];
   out->warn_height = st[6]; out->warn_force = st[7]; out->warn_vel = st[8]; out->warn_xi = st[9];
   out->n_trace_fail = h[C_TRACE_FAIL];
   out->n_halo = h[C_NHALO];
-  out->n_pairs_clipped = h[C_NWORK];
+  out->n_pairs_clipped = st[17];
   out->n_status_remove = st[4]; out->n_status_fuse = st[5];
   out->n_retry = h[C_NRETRY];
   out->acc_narrow_launches = st[10]; out->acc_pair_items = st[11]; out->acc_pair_ring_points = st[12];
@@ -893,8 +894,17 @@ int sz_download_pairs(sz_ctx* c, int32_t* pi, int32_t* pj) {
   if (!c || !pi || !pj || !c->have_floes) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
   tile_cleanup(c);
+  State& S = c->S;
+  // the compact list is made here, on demand: the steps themselves only keep the per-floe sorted lists (the ghosts of the
+  // last resident step own pairs too: their rows outlive their removal)
   int h[C_COUNT];
-  HIPCHK(c, hipMemcpy(h, c->S.cnt, sizeof(h), hipMemcpyDeviceToHost));
+  int rc = sync_and_check(c, h);
+  if (rc) return rc;
+  const int mlast = std::max(h[C_M], h[C_N] + h[C_NGHOSTS]);
+  scan(c, S.n_out, S.out_off, S.capM, -1, mlast, C_NPAIRS);
+  hipLaunchKernelGGL(sz_k_pairs_fill, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, mlast);
+  rc = sync_and_check(c, h);
+  if (rc) return rc;
   if (h[C_NPAIRS] > 0) {
     HIPCHK(c, hipMemcpy(pi, c->S.pair_i, (size_t)h[C_NPAIRS] * sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(pj, c->S.pair_j, (size_t)h[C_NPAIRS] * sizeof(int), hipMemcpyDeviceToHost));

@@ -162,11 +162,14 @@ __device__ __forceinline__ void cell_of(const GridGeo& g, double x, double y, in
   ix = cell_fold((int)floor((x - g.x0) / g.csx), g.ncx, g.wrapx);
   iy = cell_fold((int)floor((y - g.y0) / g.csy), g.ncy, g.wrapy);
 }
-// one floe into the per-cell linked lists (cell_cnt holds head + 1, 0 = empty; the order inside a cell is arbitrary,
-// the consumers sort by order key)
+// one floe into its cell: the first CELL_K arrivals sit in the cell's bucket, later ones on its overflow chain (the order
+// inside a cell is arbitrary, the consumers sort by order key)
 __device__ __forceinline__ void cell_insert(const State& S, const GridGeo& g, int i, double x, double y) {
   int ix, iy; cell_of(g, x, y, ix, iy);
-  S.cell_items[i] = atomicExch(&S.cell_cnt[iy * g.ncx + ix], i + 1) - 1;
+  const int c = iy * g.ncx + ix;
+  const int s = atomicAdd(&S.cell_cnt[c], 1);
+  if (s < CELL_K) S.cell_slots[(size_t)c * CELL_K + s] = i;
+  else S.cell_items[i] = atomicExch(&S.cell_ovf[c], i + 1) - 1;
 }
 
 // ============================================================================ ghosts (A1)
@@ -646,7 +649,7 @@ __global__ void __launch_bounds__(1024) sz_k_bounds(State S, int commit_ghosts) 
     s_ncells = (int)(ncx * ncy);
   }
   __syncthreads();
-  for (int q = threadIdx.x; q <= s_ncells; q += blockDim.x) S.cell_cnt[q] = 0;
+  for (int q = threadIdx.x; q <= s_ncells; q += blockDim.x) { S.cell_cnt[q] = 0; S.cell_ovf[q] = 0; }
 }
 // uniform-grid binning as per-cell linked lists (atomic exchange on the cell heads): no counting pass, no scan.
 // parents_only: the resident steps keep the lists current themselves (the kernels that place a floe -- integrator,
@@ -692,10 +695,34 @@ __device__ bool pair_allowed(const State& S, int i, int j) {   // i < j, ids dif
   return (A && B) || (A != B);
 }
 
-// 16 lanes per floe, 9 of them walk one cell of the 3x3 neighbourhood each: neighbours that come
-// later in the serial order (outgoing: the pairs this floe owns) and earlier ones (incoming: the
-// pairs mirrored onto it).  Candidates are collected unsorted in LDS, then rank-sorted by order key.
-constexpr int NB_G = 16, NB_TPB = 128;
+// Work list of the narrow phase: NSEG segments of capPairs / NSEG pair items, filled by the neighbour search (segment =
+// workgroup index modulo NSEG, one tail counter per segment a cache line apart: same-address atomics serialise chip-wide).
+// The element items of a step (el_floe / el_elem, compact) are dealt out to the segments round robin.  Item t of
+// segment s: t < pairs(s): work[s * segcap + t]; else element (t - pairs(s)) * NSEG + s.
+struct Seg { int s, np, ne, n; };
+__device__ __forceinline__ int seg_cap(const State& S) { return S.capPairs / NSEG; }
+__device__ __forceinline__ Seg seg_of(const State& S, int s) {
+  Seg g; g.s = s; g.np = S.wq[s * 32 + 1];
+  const int nel = S.cnt[C_NELEM];
+  g.ne = nel > s ? (nel - s + NSEG - 1) / NSEG : 0;
+  g.n = g.np + g.ne;
+  return g;
+}
+struct Item { int i, j, e, rows, info; bool is_pair; };      // rows: index into it_rows (units of items), info: index into it_info
+__device__ __forceinline__ Item item_of(const State& S, const Seg& g, int t) {
+  Item it; it.is_pair = t < g.np;
+  if (it.is_pair) { const int w = g.s * seg_cap(S) + t; const int4 k = S.work[w]; it.info = k.x; it.i = k.y; it.j = k.z; it.e = -1; it.rows = w; }
+  else { const int q = (t - g.np) * NSEG + g.s; it.i = S.el_floe[q]; it.e = S.el_elem[q]; it.j = -1; it.rows = S.capPairs + q; it.info = S.capM * MAXNB + q; }
+  return it;
+}
+
+// 16 lanes per floe.  Nine of them fetch one cell of the 3x3 neighbourhood each -- count and bucket in one round trip --
+// and pool the floes they find; then all 16 lanes take one candidate each: everything the tests need about it is asked
+// for at once (second round trip).  Neighbours that come later in the serial order are the pairs this floe owns
+// (outgoing), earlier ones the pairs mirrored onto it (incoming).  Candidates are rank-sorted by order key in LDS.  The
+// owned pairs whose ring boxes overlap are appended to the narrow phase's work list here (one tail atomic per workgroup);
+// the others get their (empty) result at once.
+constexpr int NB_G = 16, NB_TPB = 128, NB_POOL = 96;
 template <int TPB>
 __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   constexpr int GPB = TPB / NB_G;
@@ -703,22 +730,33 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   __shared__ long long ckey[GPB][2][MAXNB];
   __shared__ int cnts[GPB][2];
   __shared__ int wmask[GPB];
+  __shared__ int pool[GPB][NB_POOL];
+  __shared__ int npool[GPB];
+  __shared__ int wbase[GPB + 1];
   const int gl = threadIdx.x % NB_G, gi = threadIdx.x / NB_G;
   if (stopped(S)) return;
   int M = S.cnt[C_M];
   const GridGeo g = grid_geo(S);
   const int ncx = g.ncx, ncy = g.ncy;
-  for (int k = bid * GPB + gi; k < M; k += nblk * GPB) {
-    gsync();
-    if (gl == 0) { cnts[gi][0] = 0; cnts[gi][1] = 0; wmask[gi] = 0; }
-    gsync();
-    double ckx = S.cx[k], cky = S.cy[k], rk = S.rmax[k];
-    const double kx0 = S.bbx0[k], kx1 = S.bbx1[k], ky0 = S.bby0[k], ky1 = S.bby1[k];
-    int ix, iy; cell_of(g, ckx, cky, ix, iy);
-    long long idk = S.id[k], okk = S.okey[k];
-    const bool kplain = S.parent[k] == k && S.ngh[k] == 0;
+  const int seg = bid % NSEG, segcap = seg_cap(S);
+  if (bid == 0 && threadIdx.x == 0) { S.cnt[C_ITEMCLASS] = 0; S.cnt[C_NFUSE] = 0; }     // per-step counters the narrow phase raises
+  for (int kb = bid * GPB; kb < M; kb += nblk * GPB) {
+    const int k = kb + gi;
+    const bool act = k < M;
+    __syncthreads();
+    if (gl == 0) { cnts[gi][0] = 0; cnts[gi][1] = 0; wmask[gi] = 0; npool[gi] = 0; }
+    __syncthreads();
+    double ckx = 0, cky = 0, rk = 0, kx0 = 0, kx1 = 0, ky0 = 0, ky1 = 0;
+    long long idk = 0, okk = 0; bool kplain = true; int ix = 0, iy = 0;
+    if (act) {
+      ckx = S.cx[k]; cky = S.cy[k]; rk = S.rmax[k];
+      kx0 = S.bbx0[k]; kx1 = S.bbx1[k]; ky0 = S.bby0[k]; ky1 = S.bby1[k];
+      idk = S.id[k]; okk = S.okey[k];
+      kplain = S.parent[k] == k && S.ngh[k] == 0;
+      cell_of(g, ckx, cky, ix, iy);
+    }
     bool ovf = false;
-    if (gl < 9) {
+    if (act && gl < 9) {
       const int oy = gl / 3 - 1, ox = gl % 3 - 1;
       int cy = iy + oy, cxi = ix + ox;
       bool visit = true;
@@ -728,30 +766,49 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
       if (g.wrapy) { cy = cell_fold(cy, ncy, 1); if ((ncy == 1 && oy != 0) || (ncy == 2 && oy > 0)) visit = false; }
       else if (cy < 0 || cy >= ncy) visit = false;
       if (visit) {
-        for (int o = S.cell_cnt[cy * ncx + cxi] - 1, nxt; o >= 0; o = nxt) {
-          // everything the tests below may need about o is requested at once (one round trip per list node)
-          nxt = S.cell_items[o];
-          const double ocx = S.cx[o], ocy = S.cy[o], orm = S.rmax[o];
-          const double ox0 = S.bbx0[o], ox1 = S.bbx1[o], oy0 = S.bby0[o], oy1 = S.bby1[o];
-          const long long oid = S.id[o], ko = S.okey[o];
-          const bool oplain = S.parent[o] == o && S.ngh[o] == 0;     // a parent without ghosts
-          if (o == k) continue;
-          // potential_interaction (collisions.jl:705-710), symmetric in its arguments
-          double ddx = ckx - ocx, ddy = cky - ocy, rr = rk + orm;
-          if (!((ddx * ddx + ddy * ddy) < rr * rr)) continue;
-          if (oid == idk) continue;
-          bool after = ko > okk;                   // o comes after k in the serial order
-          // the Dict rule only bites when one of the two floes has periodic images
-          if (!(kplain && oplain) && !pair_allowed(S, after ? k : o, after ? o : k)) continue;
-          int w = after ? 0 : 1;
-          int slot = atomicAdd(&cnts[gi][w], 1);
-          // AABB cull of the pairs this floe owns: rings whose boxes are disjoint cannot overlap, the item would
-          // end at the first test of the clip (sz_geom.hpp clip()) with no row and no flag -- it is not run at all
-          int boxes = 1;
-          if (after) boxes = !(kx1 < ox0 || ox1 < kx0 || ky1 < oy0 || oy1 < ky0);
-          if (slot < MAXNB) { cand[gi][w][slot] = o | (boxes << 30); ckey[gi][w][slot] = ko; } else ovf = true;
+        const int c = cy * ncx + cxi;
+        const int n = S.cell_cnt[c];
+        const int4 s0 = *(const int4*)(S.cell_slots + (size_t)c * CELL_K), s1 = *(const int4*)(S.cell_slots + (size_t)c * CELL_K + 4);
+        const int sl[CELL_K] = { s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w };
+        const int nbk = n < CELL_K ? n : CELL_K;
+        int take = 0;
+#pragma unroll
+        for (int q = 0; q < CELL_K; q++) take += (q < nbk && sl[q] != k) ? 1 : 0;
+        int at = take ? atomicAdd(&npool[gi], take) : 0;
+#pragma unroll
+        for (int q = 0; q < CELL_K; q++) if (q < nbk && sl[q] != k) { if (at < NB_POOL) pool[gi][at] = sl[q]; else ovf = true; at++; }
+        if (n > CELL_K) {            // a crowded cell: the floes beyond the bucket are on a chain
+          for (int o = S.cell_ovf[c] - 1; o >= 0; o = S.cell_items[o]) {
+            if (o == k) continue;
+            const int a2 = atomicAdd(&npool[gi], 1);
+            if (a2 < NB_POOL) pool[gi][a2] = o; else ovf = true;
+          }
         }
       }
+    }
+    gsync();
+    const int np = npool[gi] < NB_POOL ? npool[gi] : NB_POOL;
+    for (int e = gl; e < np; e += NB_G) {
+      const int o = pool[gi][e];
+      // everything the tests below may need about o is requested at once
+      const double ocx = S.cx[o], ocy = S.cy[o], orm = S.rmax[o];
+      const double ox0 = S.bbx0[o], ox1 = S.bbx1[o], oy0 = S.bby0[o], oy1 = S.bby1[o];
+      const long long oid = S.id[o], ko = S.okey[o];
+      const bool oplain = S.parent[o] == o && S.ngh[o] == 0;     // a parent without ghosts
+      // potential_interaction (collisions.jl:705-710), symmetric in its arguments
+      double ddx = ckx - ocx, ddy = cky - ocy, rr = rk + orm;
+      if (!((ddx * ddx + ddy * ddy) < rr * rr)) continue;
+      if (oid == idk) continue;
+      bool after = ko > okk;                   // o comes after k in the serial order
+      // the Dict rule only bites when one of the two floes has periodic images
+      if (!(kplain && oplain) && !pair_allowed(S, after ? k : o, after ? o : k)) continue;
+      int w = after ? 0 : 1;
+      int slot = atomicAdd(&cnts[gi][w], 1);
+      // AABB cull of the pairs this floe owns: rings whose boxes are disjoint cannot overlap, the item would
+      // end at the first test of the clip (sz_geom.hpp clip()) with no row and no flag -- it is not run at all
+      int boxes = 1;
+      if (after) boxes = !(kx1 < ox0 || ox1 < kx0 || ky1 < oy0 || oy1 < ky0);
+      if (slot < MAXNB) { cand[gi][w][slot] = o | (boxes << 30); ckey[gi][w][slot] = ko; } else ovf = true;
     }
     if (ovf) atomicOr(&S.cnt[C_ERR], ERR_CAP_NEIGH);
     gsync();
@@ -763,71 +820,72 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
         for (int f = 0; f < n; f++) r += ckey[gi][w][f] < ke;
         const int cv = cand[gi][w][e];
         dst[r] = cv & 0x3fffffff;
+        if (w == 0) pool[gi][r] = cv & 0x3fffffff;          // (the pool is free by now: the sorted owned list, for the work items below)
         if (w == 0 && (cv >> 30)) atomicOr(&wmask[gi], 1 << r);
       }
       gsync();
-      if (gl == 0) {
-        if (w == 0) { S.n_out[k] = n; S.out_mask[k] = wmask[gi]; S.n_work[k] = __popc(wmask[gi]); }
+      if (gl == 0 && act) {
+        if (w == 0) { S.n_out[k] = n; S.out_mask[k] = wmask[gi]; }
         else S.n_in[k] = n;
+      }
+    }
+    // ---- this workgroup's share of the work list: one tail atomic for all its floes
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int q = 0; q < GPB; q++) { wbase[q] = tot; tot += __popc(wmask[q]); }
+      int base = tot ? atomicAdd(&S.wq[seg * 32 + 1], tot) : 0;
+      if (base + tot > segcap) { atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS); base = -1; }
+      wbase[GPB] = base;
+    }
+    __syncthreads();
+    if (act) {
+      const int base = wbase[GPB], mask = wmask[gi], nk = cnts[gi][0] < MAXNB ? cnts[gi][0] : MAXNB;
+      for (int r = gl; r < nk; r += NB_G) {
+        const int slot = k * MAXNB + r;
+        if ((mask >> r & 1) && base >= 0) {
+          const int j = pool[gi][r];
+          S.work[(size_t)seg * segcap + base + wbase[gi] + __popc(mask & ((1 << r) - 1))] = make_int4(slot, k, j, 0);
+        } else S.it_info[slot] = make_int2(0, -1);      // boxes disjoint: no region, no row, no flag (the clip's own first test)
       }
     }
   }
 }
 __global__ void __launch_bounds__(NB_TPB) sz_k_neighbors(State S) { neighbors_body<NB_TPB>(S, blockIdx.x, gridDim.x); }
 
-// Scan of {outgoing pairs, pairs to run} per floe (look-back scan) and the pair fill in one launch: thread i
-// gets out_off[i] and its work-list offset, writes the pairs floe i owns and appends those with overlapping ring
-// boxes to the work list of the narrow phase; the others get their (empty) result here.
-// housekeeping (static grid: no bounds kernel runs): the cell heads, which the neighbour kernel has consumed, are
-// cleared for the next step and the per-step counters reset
-__global__ void __launch_bounds__(SCAN_B) sz_k_pscan_fill(State S, unsigned epoch, int housekeeping) {
-  __shared__ int4 tot;
-  if (stopped(S)) return;
-  const int n = S.cnt[C_M];
-  const int base = blockIdx.x * SCAN_B;
-  if (housekeeping) {
-    const int ncells = (int)S.bounds[4] * (int)S.bounds[5];
-    const int nlive = (n + SCAN_B - 1) / SCAN_B > 0 ? (n + SCAN_B - 1) / SCAN_B : 1;      // workgroups that do not return below
-    if ((int)blockIdx.x < nlive) for (int q = base + threadIdx.x; q <= ncells; q += nlive * SCAN_B) S.cell_cnt[q] = 0;
-    if (blockIdx.x == 0 && threadIdx.x < 8) S.wq[threadIdx.x * 32] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) S.cnt[C_ITEMCLASS] = 0;
-    if (blockIdx.x == 0 && threadIdx.x < WARN_SLOTS * 4) S.warn[(threadIdx.x >> 2) * 32 + (threadIdx.x & 3)] = 0;
-  }
-  if (base >= n && blockIdx.x != 0) return;
-  const int i = base + threadIdx.x;
-  const int nk = i < n ? S.n_out[i] : 0, mask = i < n ? S.out_mask[i] : 0;
-  const int4 ex = block_exclusive_scan4(make_int4(nk, __popc(mask), 0, 0), &tot);
-  const int4 before = lookback_prefix4(S, tot, epoch);
-  if (n == 0) { if (i == 0) { S.out_off[0] = 0; S.cnt[C_NPAIRS] = 0; S.cnt[C_NWORK] = 0; } return; }
-  if (i >= n) return;
-  const int o = ex.x + before.x; int wo = ex.y + before.y;
-  S.out_off[i] = o;
-  if (i == n - 1) {
-    int t = o + nk, tw = wo + __popc(mask); S.out_off[n] = t;
-    if (t > S.capPairs) { atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS); t = 0; tw = 0; }
-    S.cnt[C_NPAIRS] = t; S.cnt[C_NWORK] = tw;
-  }
-  if (o + nk > S.capPairs) return;
-  for (int t = 0; t < nk; t++) {
-    const int j = S.nb_out[(size_t)i * MAXNB + t], p = o + t;
-    S.pair_i[p] = i; S.pair_j[p] = j;
-    if (mask >> t & 1) S.work[wo++] = make_int4(p, i, j, 0);
-    else { S.it_nrows[p] = 0; S.it_flags[p] = 0; }
+// The compact pair list in the reference's serial order (i asc, j asc) -- out_off, pair_i, pair_j -- is only made when
+// the host asks for it (sz_download_pairs): fill after a scan of n_out.
+__global__ void sz_k_pairs_fill(State S, int M) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+    const int o = S.out_off[i], nk = S.n_out[i];
+    if (o + nk > S.capPairs) { atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS); continue; }
+    for (int t = 0; t < nk; t++) { S.pair_i[o + t] = i; S.pair_j[o + t] = S.nb_out[(size_t)i * MAXNB + t]; }
   }
 }
-// explicit pair list (sz_collide_pairs): out lists from the given pairs, no incoming lists
+// explicit pair list (sz_collide_pairs; sorted by (i, j) on the host): out lists from the given pairs, no incoming
+// lists, every pair is run as given (floe_floe_interaction! has no broad phase); item p goes to segment p % NSEG
 __global__ void sz_k_pairs_explicit(State S, int np) {
   int M = S.cnt[C_M];
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= M; k += gridDim.x * blockDim.x) {
-    // pairs are sorted by i on the host; out_off[k] = first pair with i >= k
+  const int segcap = seg_cap(S);
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
     int lo = 0, hi = np;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (S.pair_i[mid] < k) lo = mid + 1; else hi = mid; }
-    S.out_off[k] = lo;
-    if (k < M) S.n_in[k] = 0;
+    int e = lo; while (e < np && S.pair_i[e] == k) e++;
+    int nk = e - lo;
+    if (nk > MAXNB) { atomicOr(&S.cnt[C_ERR], ERR_CAP_NEIGH); nk = MAXNB; }
+    S.n_out[k] = nk; S.n_in[k] = 0; S.out_mask[k] = nk >= 32 ? -1 : (1 << nk) - 1;
+    for (int r = 0; r < nk; r++) {
+      const int p = lo + r, j = S.pair_j[p];
+      S.nb_out[(size_t)k * MAXNB + r] = j;
+      if (p / NSEG < segcap) S.work[(size_t)(p % NSEG) * segcap + p / NSEG] = make_int4(k * MAXNB + r, k, j, 0);
+      else atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS);
+    }
   }
-  // an explicit list is run as given (floe_floe_interaction! has no broad phase)
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < np; p += gridDim.x * blockDim.x) S.work[p] = make_int4(p, S.pair_i[p], S.pair_j[p], 0);
-  if (blockIdx.x == 0 && threadIdx.x == 0) { S.cnt[C_NPAIRS] = np; S.cnt[C_NWORK] = np; }
+  if (blockIdx.x == 0 && threadIdx.x < NSEG) {
+    const int s = threadIdx.x;
+    S.wq[s * 32] = 0; S.wq[s * 32 + 1] = np > s ? (np - s + NSEG - 1) / NSEG : 0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { S.cnt[C_ITEMCLASS] = 0; S.cnt[C_NFUSE] = 0; }
 }
 // ============================================================================ domain element items (A10 prefilter)
 template <typename F>
@@ -880,9 +938,23 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
   __shared__ GroupMem<CAP, KC, RC, RM> mem[GPB];
   const int gl = threadIdx.x % G, gi = threadIdx.x / G;
   GroupMem<CAP, KC, RC, RM>& m = mem[gi];
-  const int npairs = S.cnt[C_NWORK], nel = S.cnt[C_NELEM];     // pair items = the work list (ring boxes overlap)
-  const int nitems = npairs + nel;
+  // Items: segment `qk` of the work list (pair items appended by the neighbour search + this segment's share of the element
+  // items).  The first round is static (lane group `gi` of the r-th workgroup of the segment takes item r * GPB + gi); the
+  // rounds after it are handed out dynamically from the segment's queue head: a round of 8 items takes anything between a
+  // few thousand cycles (no overlap) and 150 k, so with a static split the slowest workgroup sets the time of a deep launch
+  // (narrow kernel 374 -> 242 us at 100 k floes; one head for the whole chip costs ~20 ns per ticket, serialised across the
+  // XCDs: measured slower than the static split).  The results do not depend on who runs an item.
+  const int qk = (int)(blockIdx.x % NSEG);
+  const Seg sg = seg_of(S, qk);
+  const int nitems = sg.n;
   if (gl == 0) { m.err = 0; m.ierr = 0; m.ntracefail = 0; m.nchk = 0; m.nkeep = 0; m.acc[0] = m.acc[1] = 0; m.acc16[0] = m.acc16[1] = m.acc16[2] = 0; }   // acc: work done by this group (in LDS: no register held across the rounds)
+  if (CLS == 0) {
+    // housekeeping of the step (the neighbour search has consumed the cells; the integrator fills them again): cell counts
+    // and overflow heads cleared, the guard counters of the coming update reset
+    const int ncells = (int)S.bounds[4] * (int)S.bounds[5];
+    for (int q = blockIdx.x * TPB + threadIdx.x; q <= ncells; q += gridDim.x * TPB) { S.cell_cnt[q] = 0; S.cell_ovf[q] = 0; }
+    if (blockIdx.x == 0) for (int q = threadIdx.x; q < WARN_SLOTS * 4; q += TPB) S.warn[(q >> 2) * 32 + (q & 3)] = 0;
+  }
   Stamps st; STAMP_INIT(st);
 #ifdef SZ_STAMPS
   st.on = (CLS == 0 && blockIdx.x == (unsigned)(dbg >> 8) && threadIdx.x == 0); st.log = S.stamps + 1;
@@ -891,29 +963,19 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
   // items at a time and the wavefront then works the flagged ones off one by one.
   constexpr bool SCAN = (G == 64 && TPB == 64);
   constexpr int STRIDE = SCAN ? 64 : GPB;
-  // Rounds after the first are handed out dynamically (queue != 0): a round of 8 items takes anything between a
-  // few thousand cycles (no overlap) and 150 k (items with two contact regions), so with a static split the
-  // slowest workgroup sets the time of a deep launch.  The items are cut into 8 ranges with one queue head each
-  // (one cache line per head; a single head costs ~20 ns per ticket, serialised across the XCDs: measured slower
-  // than the static split), a workgroup draws from the queue of its index modulo 8; the first round is static,
-  // so a one-round launch never touches a queue.  Narrow kernel 374 -> 242 us at 100 k floes, 151 -> 124 us at
-  // 40 k, 96 -> 88 us at 20 k, unchanged at 10 k (tools/queue_ab.sh); the results do not depend on who runs an item.
-  const bool useq = CLS == 0 && !SCAN && queue != 0;
-  const int qk = (int)(blockIdx.x & 7);
-  const int nper = useq ? ((nitems + 7) / 8 + GPB - 1) / GPB * GPB : 0;
-  const int limit = useq ? (qk * nper + nper < nitems ? qk * nper + nper : nitems) : nitems;
-  const int nbq = useq ? ((int)gridDim.x + 7 - qk) / 8 : 0;
-  for (int t0 = useq ? qk * nper + (int)(blockIdx.x >> 3) * GPB : (int)blockIdx.x * STRIDE; t0 < limit;) {
+  const bool useq = CLS == 0 && !SCAN && queue != 0;       // (the larger variants look at every item of their segment: static rounds)
+  const int rb = (int)(blockIdx.x / NSEG), nbq = ((int)gridDim.x + NSEG - 1 - qk) / NSEG;    // this workgroup's rank in its segment, workgroups per segment
+  const int limit = nitems;
+  for (int t0 = rb * STRIDE; t0 < limit;) {
    unsigned long long todo = 1;
    if (SCAN) {
      const int tt = t0 + (int)threadIdx.x;
      bool want = false;
      if (tt < nitems) {
-       int i_, nb_, item_;
-       if (tt < npairs) { int4 w_ = S.work[tt]; i_ = w_.y; int j_ = w_.z; nb_ = S.voff[j_ + 1] - S.voff[j_]; item_ = w_.x; }
-       else { int q = tt - npairs; i_ = S.el_floe[q]; int e_ = S.el_elem[q]; nb_ = S.eoff[e_ + 1] - S.eoff[e_]; item_ = S.capPairs + q; }
-       int na_ = S.voff[i_ + 1] - S.voff[i_];
-       want = (na_ > nb_ ? na_ : nb_) > LO || (S.it_flags[item_] & IT_RETRY);
+       const Item it_ = item_of(S, sg, tt);
+       const int nb_ = it_.is_pair ? S.voff[it_.j + 1] - S.voff[it_.j] : S.eoff[it_.e + 1] - S.eoff[it_.e];
+       const int na_ = S.voff[it_.i + 1] - S.voff[it_.i];
+       want = (na_ > nb_ ? na_ : nb_) > LO || ((S.it_info[it_.info].x >> 8) & IT_RETRY);
      }
      todo = __ballot(want);
    }
@@ -923,11 +985,12 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     if (SCAN) { t = t0 + __ffsll((long long)todo) - 1; todo &= todo - 1; }
     else { todo = 0; t = t0 + gi; }
     bool have = t < limit;
-    const bool is_pair = t < npairs;
-    int i = 0, j = -1, e = -1, item = 0, na = 0, nb = 0, ao = 0, bo = 0;
+    Item it; it.i = 0; it.j = -1; it.e = -1; it.rows = 0; it.info = 0; it.is_pair = true;
+    if (have) it = item_of(S, sg, t);
+    const bool is_pair = it.is_pair;
+    const int i = it.i, j = it.j, e = it.e;
+    int na = 0, nb = 0, ao = 0, bo = 0;
     if (have) {
-      if (is_pair) { int4 w = S.work[t]; item = w.x; i = w.y; j = w.z; }
-      else { int q = t - npairs; i = S.el_floe[q]; e = S.el_elem[q]; item = S.capPairs + q; }
       ao = S.voff[i]; na = S.voff[i + 1] - ao;
       bo = is_pair ? S.voff[j] : S.eoff[e];
       nb = (is_pair ? S.voff[j + 1] : S.eoff[e + 1]) - bo;
@@ -935,7 +998,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       // an item belongs to the first variant whose ring capacity fits it; an item a smaller variant
       // gave up on (more crossings / region points / regions than its working set holds) is handed to
       // the largest one through IT_RETRY
-      const bool retry = CLS == 2 && (S.it_flags[item] & IT_RETRY);
+      const bool retry = CLS == 2 && ((S.it_info[it.info].x >> 8) & IT_RETRY);
       if (big <= LO && !retry) have = false;
       else if (big > CAP) { if (CLS == 2 && gl == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); have = false; }
     }
@@ -990,7 +1053,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     }
     // ================= phase C: friction and the rows of the own item, in region order
     if (have) {
-      double* out = S.it_rows + (size_t)item * ROWS_PER_ITEM * 5;
+      double* out = S.it_rows + (size_t)it.rows * ROWS_PER_ITEM * 5;
       int nrows = finish_phase<G>(m, gl, ic, out, ROWS_PER_ITEM, st);
       gsync();
       if (CLS < 2 && (m.ierr & CAPBITS)) {                // working set too small: let the largest variant redo the item
@@ -998,7 +1061,8 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
         if (gl == 0) { atomicMax(&S.cnt[C_ITEMCLASS], 2); atomicAdd(&S.cnt[C_NRETRY], 1); }
       } else if (gl == 0 && m.ierr) m.err |= m.ierr;
       if (gl == 0) {
-        S.it_nrows[item] = nrows; S.it_flags[item] = flags;
+        S.it_info[it.info] = make_int2(nrows | (flags << 8), it.rows);
+        if (flags & IT_FUSE) atomicAdd(&S.cnt[C_NFUSE], 1);
         if (!(flags & IT_RETRY)) {                           // counted by the variant that finishes the item
           if (is_pair) { m.acc16[0]++; m.acc[0] += (unsigned)(na + nb); m.acc[1] += (unsigned)nrows; } else { m.acc16[1]++; m.acc16[2] += (uint16_t)nrows; }
         }
@@ -1013,8 +1077,8 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
    if (useq) {
      int tk = 0;
      if (threadIdx.x == 0) tk = atomicAdd(&S.wq[qk * 32], GPB);
-     t0 = qk * nper + nbq * GPB + __shfl(tk, 0);
-   } else t0 += (int)gridDim.x * STRIDE;
+     t0 = nbq * GPB + __shfl(tk, 0);
+   } else t0 += nbq * STRIDE;
   }
   gsync();
   if (gl == 0 && m.err) atomicOr(&S.cnt[C_ERR], m.err);
@@ -1051,17 +1115,18 @@ constexpr int NARROW_CAP0 = 18, NARROW_CAP1 = 32, NARROW_CAP2 = 128;   // ring p
 // items not touched by any narrow variant would keep stale row counts: clear them first
 __global__ void sz_k_items_clear(State S) {
   if (stopped(S)) return;
-  int npairs = S.cnt[C_NWORK], nel = S.cnt[C_NELEM];
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < npairs + nel; t += gridDim.x * blockDim.x) {
-    // size class of the item: which narrow-phase variant takes it
-    int item, i, nb;
-    if (t < npairs) { int4 w = S.work[t]; item = w.x; i = w.y; nb = S.voff[w.z + 1] - S.voff[w.z]; }
-    else { int q = t - npairs; item = S.capPairs + q; i = S.el_floe[q]; int e = S.el_elem[q]; nb = S.eoff[e + 1] - S.eoff[e]; }
-    S.it_nrows[item] = 0; S.it_flags[item] = 0;
-    int na = S.voff[i + 1] - S.voff[i];
-    int big = na > nb ? na : nb;
-    int cls = big <= NARROW_CAP0 ? 0 : (big <= NARROW_CAP1 ? 1 : 2);
-    if (cls > 0) atomicMax(&S.cnt[C_ITEMCLASS], cls);
+  for (int s = 0; s < NSEG; s++) {
+    const Seg sg = seg_of(S, s);
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < sg.n; t += gridDim.x * blockDim.x) {
+      // size class of the item: which narrow-phase variant takes it
+      const Item it = item_of(S, sg, t);
+      const int nb = it.is_pair ? S.voff[it.j + 1] - S.voff[it.j] : S.eoff[it.e + 1] - S.eoff[it.e];
+      S.it_info[it.info] = make_int2(0, it.rows);
+      int na = S.voff[it.i + 1] - S.voff[it.i];
+      int big = na > nb ? na : nb;
+      int cls = big <= NARROW_CAP0 ? 0 : (big <= NARROW_CAP1 ? 1 : 2);
+      if (cls > 0) atomicMax(&S.cnt[C_ITEMCLASS], cls);
+    }
   }
 }
 
@@ -1081,7 +1146,7 @@ constexpr int ROWCAP = 32;
 constexpr int IF_G = 8;
 __device__ __forceinline__ int emit_rows(const State& S, int lane, int f, double* dst, int c, int cap, double sx, double sy,
                                          int mirror, bool& ovf, int* st, int* tagA) {
-  const int o0 = S.out_off[f], nown = S.out_off[f + 1] - o0;
+  const int nown = S.n_out[f];
   const int e0 = S.el_off[f], nel = S.el_off[f + 1] - e0;
   const int nin = mirror ? S.n_in[f] : 0;
   const int T = nown + nel + nin;
@@ -1089,24 +1154,24 @@ __device__ __forceinline__ int emit_rows(const State& S, int lane, int f, double
   unsigned fuse_own = 0, rem_el = 0, fuse_in = 0;
   for (int base = 0; base < T; base += IF_G) {
     const int s = base + lane;
-    int item = -1, n = 0, kind = -1; double idx = 0.0, sign = 1.0;
-    if (s < nown) { item = o0 + s; idx = (double)(S.okey[S.pair_j[item]] + 1); kind = 0; }
-    else if (s < nown + nel) { int q = e0 + (s - nown); item = S.capPairs + q; idx = -(double)(S.el_elem[q] + 1); kind = 1; }
+    int info = -1, n = 0, kind = -1; double idx = 0.0, sign = 1.0;
+    if (s < nown) { info = f * MAXNB + s; idx = (double)(S.okey[S.nb_out[info]] + 1); kind = 0; }
+    else if (s < nown + nel) { int q = e0 + (s - nown); info = S.capM * MAXNB + q; idx = -(double)(S.el_elem[q] + 1); kind = 1; }
     else if (s < T) {
       const int i = S.nb_in[(size_t)f * MAXNB + (s - nown - nel)];
-      const int lo = S.out_off[i], hi = S.out_off[i + 1];
-      for (int q = lo; q < hi; q++) if (S.pair_j[q] == f) item = q;     // pair (i, f); absent if the Dict rule dropped it
+      const int ni = S.n_out[i];
+      for (int q = 0; q < ni; q++) if (S.nb_out[(size_t)i * MAXNB + q] == f) info = i * MAXNB + q;     // pair (i, f); absent if the Dict rule dropped it
       idx = (double)(S.okey[i] + 1); sign = -1.0; kind = 2;
     }
-    int fl = 0;
-    if (item >= 0) { n = S.it_nrows[item]; fl = S.it_flags[item]; }
+    int fl = 0; int2 iv = make_int2(0, 0);
+    if (info >= 0) { iv = S.it_info[info]; n = iv.x & 0xff; fl = iv.x >> 8; }
     fuse_own |= (unsigned)(__ballot(kind == 0 && (fl & IT_FUSE)) >> gshift) & 0xffu;
     rem_el |= (unsigned)(__ballot(kind == 1 && (fl & IT_REMOVE)) >> gshift) & 0xffu;
     fuse_in |= (unsigned)(__ballot(kind == 2 && (fl & IT_FUSE)) >> gshift) & 0xffu;
     int inc = n;
     for (int d = 1; d < IF_G; d <<= 1) { int t = __shfl_up(inc, d, IF_G); if (lane >= d) inc += t; }
     const int tot = __shfl(inc, IF_G - 1, IF_G), off = inc - n;
-    const double* src = S.it_rows + (size_t)(item < 0 ? 0 : item) * ROWS_PER_ITEM * 5;
+    const double* src = S.it_rows + (size_t)(n > 0 ? iv.y : 0) * ROWS_PER_ITEM * 5;
     for (int r = 0; r < n; r++) {
       const int pos = c + off + r;
       if (pos < cap) {
@@ -1129,6 +1194,9 @@ __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int 
   if (stopped(S)) return;
   const int M = S.cnt[C_M];
   const int nparents = S.cnt[C_NOWN];
+  // the narrow phase has consumed the work list: heads and lengths of its segments start from zero for the next step
+  // (a launch whose grid is smaller than NSEG * 2 ints would be odd: threads 0 .. 15 of workgroup 0 do it)
+  if (blockIdx.x == 0 && threadIdx.x < 2 * NSEG) S.wq[(threadIdx.x >> 1) * 32 + (threadIdx.x & 1)] = 0;
   const int n_init = n_init_arg >= 0 ? n_init_arg : S.cnt[C_N];   // < 0: every parent on the device
   const int lane = threadIdx.x % IF_G, gpb = blockDim.x / IF_G;
   for (int k = blockIdx.x * gpb + threadIdx.x / IF_G; k < M; k += gridDim.x * gpb) {
@@ -1861,25 +1929,31 @@ __global__ void sz_k_stats(State S, long long* out) {
   // out[0] = sum ring points over the pairs the narrow phase ran, out[1] = pair rows, out[2] = elem rows,
   // out[3] = interaction rows, out[4], out[5]: floes tagged remove / fuse (what simplify_floes!, simulation.jl:206,
   // has to act on), out[6..9]: the guard counters of the last timestep_floe_properties! (sum over the slots)
-  int npairs = S.cnt[C_NWORK], nel = S.cnt[C_NELEM];
-  long long v[10] = { 0 };
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < npairs + nel; t += gridDim.x * blockDim.x) {
-    if (t < npairs) {
-      int4 w = S.work[t];
-      v[0] += (S.voff[w.y + 1] - S.voff[w.y]) + (S.voff[w.z + 1] - S.voff[w.z]);
-      v[1] += S.it_nrows[w.x];
-    } else v[2] += S.it_nrows[S.capPairs + (t - npairs)];
+  const int nel = S.cnt[C_NELEM];
+  long long v[12] = { 0 };
+  // pairs of the last step: per floe its owned pairs (all / those with overlapping ring boxes = the items run)
+  const int mlast = S.cnt[C_M] > S.cnt[C_N] ? S.cnt[C_M] : S.cnt[C_N] + S.cnt[C_NGHOSTS];      // the ghosts of the last step own pairs too
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < mlast; k += gridDim.x * blockDim.x) {
+    const int nk = S.n_out[k], mask = S.out_mask[k];
+    v[10] += nk; v[11] += __popc(mask);
+    const int nvk = S.voff[k + 1] - S.voff[k];
+    for (int r = 0; r < nk; r++) if (mask >> r & 1) {
+      const int j = S.nb_out[(size_t)k * MAXNB + r];
+      v[0] += nvk + (S.voff[j + 1] - S.voff[j]);
+      v[1] += S.it_info[k * MAXNB + r].x & 0xff;
+    }
   }
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nel; q += gridDim.x * blockDim.x) v[2] += S.it_info[S.capM * MAXNB + q].x & 0xff;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < S.cnt[C_M]; k += gridDim.x * blockDim.x) {
     v[3] += S.inter_cnt[k];
     int st = S.status[k];
     v[4] += st == SZ_REMOVE; v[5] += st == SZ_FUSE;
   }
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < WARN_SLOTS * 4; q += gridDim.x * blockDim.x) v[6 + (q & 3)] += S.warn[(q >> 2) * 32 + (q & 3)];
-  for (int k = 0; k < 10; k++) {
+  for (int k = 0; k < 12; k++) {
     long long x = v[k];
     for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-    if ((threadIdx.x & 63) == 0 && x) atomicAdd((unsigned long long*)&out[k], (unsigned long long)x);
+    if ((threadIdx.x & 63) == 0 && x) atomicAdd((unsigned long long*)&out[k < 10 ? k : k + 6], (unsigned long long)x);     // pairs, pairs run: out[16], out[17]
   }
   // out[10..15]: the cumulative narrow-phase work counters (sum over the slots)
   if (blockIdx.x == 0 && threadIdx.x < 6) {

@@ -22,7 +22,8 @@ enum {
   C_NPAIR_ROWS,   // contact rows before mirroring (stats)
   C_NELEM_ROWS,
   C_NGCAND, C_NGCAND1,   // entries of the two ghost-candidate lists (State::gcand), used alternately step by step
-  C_UNUSED2, C_UNUSED3,   // (the guard counters live in State::warn: one word each serialised the chip)
+  C_NFUSE,        // pair items that asked for a fuse in the last collision call (the host replays the fuse lists only then)
+  C_UNUSED3,      // (the guard counters live in State::warn: one word each serialised the chip)
   C_NG_NEW,       // ghosts created by the current pass
   C_NGHOSTS,
   C_NCELLS,
@@ -40,6 +41,8 @@ enum {
 };
 
 constexpr int MAXNB = 24;       // broad-phase neighbours kept per floe and direction
+constexpr int CELL_K = 8;       // floes a broad-phase cell holds in its bucket (more: overflow chain)
+constexpr int NSEG = 8;         // segments of the narrow phase's work list (one tail counter and one queue head each, a cache line apart)
 constexpr int ROWS_PER_ITEM = 16; // contact rows kept per pair / element item (the 8-lane kernels hold 4 regions and hand larger items on)
 constexpr int WARN_SLOTS = 256;
 constexpr int ACC_SLOTS = 256;
@@ -101,16 +104,23 @@ struct State {
   int4 *lb_agg, *lb_inc; unsigned* lb_flag;   // decoupled look-back scan: per workgroup aggregate, inclusive prefix, (epoch << 2 | status)
   // ---- broad phase
   double* bounds;            // xmin, ymin, cell size, (ncx, ncy as doubles)
-  int *cell_cnt, *cell_items;   // per-cell list head (+1) and next links
-  int *nb_out, *nb_in, *n_out, *n_in, *out_off;
-  int *pair_i, *pair_j;
-  int *out_mask, *n_work, *work_off;   // per floe: which of its outgoing pairs have overlapping ring boxes (bit r = rank r)
-  int4* work;                // compacted pair items: {pair slot, i, j, -}
-  int* wq;                   // 8 work-queue heads of the narrow phase, one cache line each (deep launches only)
+  // cells: a bucket of CELL_K floes per cell (count in cell_cnt; readers fetch count and bucket in ONE round trip instead of
+  // walking a list node by node), floes beyond that on an overflow chain (cell_ovf: head + 1, cell_items: next links)
+  int *cell_cnt, *cell_slots, *cell_ovf, *cell_items;
+  // per floe k: the neighbours that come later in the serial order (nb_out: the pairs k owns, sorted by order key; pair SLOT
+  // = k * MAXNB + rank) and earlier (nb_in: the pairs mirrored onto it); out_mask: which owned pairs have overlapping ring boxes
+  int *nb_out, *nb_in, *n_out, *n_in, *out_mask;
+  int *out_off, *pair_i, *pair_j;      // the compact pair list in serial order: made on demand (sz_download_pairs) / given (sz_collide_pairs)
+  // work list of the narrow phase: the pair items to run {slot, i, j, -}, appended by the neighbour search in NSEG segments of
+  // capPairs / NSEG items; wq[s * 32] = queue head of segment s (rounds after the first), wq[s * 32 + 1] = its length
+  int4* work;
+  int* wq;
   // ---- element items
   int *el_off, *el_floe, *el_elem;
   // ---- contact rows per item (pairs first, then element items at capPairs + e)
-  double* it_rows; int* it_nrows; int* it_flags;
+  // results per item: rows at work index w (pairs: segment * (capPairs / NSEG) + position; elements: capPairs + e);
+  // it_info[pair slot] / it_info[capM * MAXNB + e] = {rows | flags << 8, w}
+  double* it_rows; int2* it_info;
   // ---- per-floe interaction lists
   int *inter_cnt, *inter_off, *tagA; double* inter_rows;   // ROWCAP rows per floe; inter_off: download scratch
   // ---- scan scratch
