@@ -361,7 +361,7 @@ void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false
   }
   // the neighbour search appends the pair items to the narrow phase's work list itself: no scan, no pair-list launch
   if (fuse_forcing) {          // the step's forcings ride in the neighbour launch (sz_k_neighbors_forcing)
-    const int nbn = grid_for(S.capM, 256 / NB_G, 8192), nbf = grid_for(S.capM, 256 / FRC_G, 8192);
+    const int nbn = grid_for(S.capM, 256 / NB_G, 8192), nbf = grid_for(S.capM, 256 / FRC_PLAIN, 8192);
     if (c->precision == 1) hipLaunchKernelGGL(sz_k_neighbors_forcing<2>, dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn);
     else hipLaunchKernelGGL(sz_k_neighbors_forcing<1>, dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn);
   } else
@@ -410,6 +410,8 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = 
     }
     hipLaunchKernelGGL(kern, dim3(grid_for(capItems, TPB / G, grid)), dim3(TPB), 0,
                        c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue);
+    if (c->dbg & 8)       // timing experiment: the same launch again (same results) -- how much of a launch is a cold instruction cache?
+      hipLaunchKernelGGL(kern, dim3(grid_for(capItems, TPB / G, grid)), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue);
     t.end();
   }
   {
@@ -449,8 +451,8 @@ void stage_forcing_fork(sz_ctx* c) {
   (void)hipEventRecord(c->ev_fork, c->stream);
   (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
   Timed t(c, SZ_K_FORCING, c->stream2);
-  if (c->precision == 1) hipLaunchKernelGGL(sz_k_forcing_mixed, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream2, c->S, c->P);
-  else hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream2, c->S, c->P, 0);
+  if (c->precision == 1) hipLaunchKernelGGL(sz_k_forcing_mixed, dim3(grid_for(c->S.capM, 256 / FRC_PLAIN, 8192)), dim3(256), 0, c->stream2, c->S, c->P);
+  else hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_PLAIN, 8192)), dim3(256), 0, c->stream2, c->S, c->P, 0);
   t.end();
   (void)hipEventRecord(c->ev_join, c->stream2);
 }
@@ -503,9 +505,9 @@ int ensure_two_way(sz_ctx* c) {
 void stage_forcing(sz_ctx* c, int dt = -1) {      // in-order variant (process mode, profiling)
   Timed t(c, SZ_K_FORCING);
   if (!c->two_way && c->precision == 1) {
-    hipLaunchKernelGGL(sz_k_forcing_mixed, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream, c->S, c->P);
+    hipLaunchKernelGGL(sz_k_forcing_mixed, dim3(grid_for(c->S.capM, 256 / FRC_PLAIN, 8192)), dim3(256), 0, c->stream, c->S, c->P);
   } else if (!c->two_way) {
-    hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_G, 8192)), dim3(256), 0, c->stream, c->S, c->P, 0);
+    hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_PLAIN, 8192)), dim3(256), 0, c->stream, c->S, c->P, 0);
   } else {
     // timestep_coupling! with two_way_coupling_on (coupling.jl:1705-1738): one-way forcings + per-floe cell slots,
     // then calc_two_way_coupling! (:1617-1680) as a counting sort by cell, one clip per (floe, cell) entry, a reduction
@@ -762,7 +764,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1); DA(cell_ovf, S.capCells + 1); DA(cell_slots, (size_t)S.capCells * CELL_K + 8);
   DA(cell_items, S.capM);
   DA(nb_out, (size_t)S.capM * MAXNB); DA(nb_in, (size_t)S.capM * MAXNB); DA(n_out, S.capM + 1); DA(n_in, S.capM + 1);
-  DA(out_off, S.capM + 2); DA(out_mask, S.capM + 1); DA(work, S.capPairs + NSEG); DA(wq, NSEG * 32); DA(pair_i, S.capPairs); DA(pair_j, S.capPairs);
+  DA(out_off, S.capM + 2); DA(out_mask, S.capM + 1); DA(work, 2 * ((size_t)S.capPairs + NSEG)); DA(wq, NSEG * 32); DA(pair_i, S.capPairs); DA(pair_j, S.capPairs);
   DA(el_off, S.capM + 2); DA(el_floe, S.capElem); DA(el_elem, S.capElem);
   size_t items = (size_t)S.capPairs + S.capElem;
   DA(it_rows, items * ROWS_PER_ITEM * 5); DA(it_info, (size_t)S.capM * MAXNB + S.capElem + 1);

@@ -695,6 +695,25 @@ __device__ bool pair_allowed(const State& S, int i, int j) {   // i < j, ids dif
   return (A && B) || (A != B);
 }
 
+// Workgroups are dealt round robin over the 8 XCDs (blocks b and b + 8 share one, MI355X_MICROARCH.md), each XCD has its own
+// L2, and every launch starts with cold L2s: a floe's columns and ring are fetched once per XCD that touches them.  Kernels in
+// which a floe is read on behalf of its neighbours (neighbour search, narrow phase, reduce) therefore give the workgroups of one
+// XCD a CONTIGUOUS range of floes -- neighbours in space are neighbours in index -- instead of every eighth group of 16:
+// virtual workgroup id such that the ids of one XCD are consecutive (bijective for any grid size; speed only, never correctness).
+// nact: the virtual ids that have work (the grid is sized from a capacity, the live count is only known on the device); when the
+// grid covers them all, the nact ids are cut into 8 consecutive runs, one per XCD, and a workgroup beyond its XCD's run gets -1
+// (nothing to do); otherwise (grid-stride launches) the whole grid is permuted.
+__device__ __forceinline__ int xcd_contiguous(int bid, int nblk, int nact) {
+  const int x = bid % 8, idx = bid / 8;
+  if (nact <= nblk) {
+    const int q = nact / 8, r = nact % 8;
+    const int cnt = q + (x < r ? 1 : 0), start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return idx < cnt ? start + idx : -1;        // (an XCD always has at least as many workgroups as its run: nact <= nblk)
+  }
+  const int q = nblk / 8, r = nblk % 8;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+}
+
 // Work list of the narrow phase: NSEG segments of capPairs / NSEG pair items, filled by the neighbour search (segment =
 // workgroup index modulo NSEG, one tail counter per segment a cache line apart: same-address atomics serialise chip-wide).
 // The element items of a step (el_floe / el_elem, compact) are dealt out to the segments round robin.  Item t of
@@ -708,11 +727,19 @@ __device__ __forceinline__ Seg seg_of(const State& S, int s) {
   g.n = g.np + g.ne;
   return g;
 }
-struct Item { int i, j, e, rows, info; bool is_pair; };      // rows: index into it_rows (units of items), info: index into it_info
+// rows: index into it_rows (units of items), info: index into it_info; ao, na / bo, nb: ring offsets and sizes (a pair item
+// carries them -- the neighbour search had them at hand -- so that staging an item is one round trip less)
+struct Item { int i, j, e, rows, info, ao, na, bo, nb; bool is_pair; };
 __device__ __forceinline__ Item item_of(const State& S, const Seg& g, int t) {
   Item it; it.is_pair = t < g.np;
-  if (it.is_pair) { const int w = g.s * seg_cap(S) + t; const int4 k = S.work[w]; it.info = k.x; it.i = k.y; it.j = k.z; it.e = -1; it.rows = w; }
-  else { const int q = (t - g.np) * NSEG + g.s; it.i = S.el_floe[q]; it.e = S.el_elem[q]; it.j = -1; it.rows = S.capPairs + q; it.info = S.capM * MAXNB + q; }
+  if (it.is_pair) {
+    const int w = g.s * seg_cap(S) + t;
+    const int4 k = S.work[2 * (size_t)w], r = S.work[2 * (size_t)w + 1];
+    it.info = k.x; it.i = k.y; it.j = k.z; it.e = -1; it.rows = w; it.ao = k.w; it.na = r.x; it.bo = r.y; it.nb = r.z;
+  } else {
+    const int q = (t - g.np) * NSEG + g.s; it.i = S.el_floe[q]; it.e = S.el_elem[q]; it.j = -1; it.rows = S.capPairs + q; it.info = S.capM * MAXNB + q;
+    it.ao = S.voff[it.i]; it.na = S.voff[it.i + 1] - it.ao; it.bo = S.eoff[it.e]; it.nb = S.eoff[it.e + 1] - it.bo;
+  }
   return it;
 }
 
@@ -733,6 +760,7 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   __shared__ int pool[GPB][NB_POOL];
   __shared__ int npool[GPB];
   __shared__ int wbase[GPB + 1];
+  __shared__ int cvo[GPB][MAXNB], cnv[GPB][MAXNB], svo[GPB][MAXNB], snv[GPB][MAXNB];    // ring offset / size of the owned pairs' partners (unsorted, sorted)
   const int gl = threadIdx.x % NB_G, gi = threadIdx.x / NB_G;
   if (stopped(S)) return;
   int M = S.cnt[C_M];
@@ -740,15 +768,17 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   const int ncx = g.ncx, ncy = g.ncy;
   const int seg = bid % NSEG, segcap = seg_cap(S);
   if (bid == 0 && threadIdx.x == 0) { S.cnt[C_ITEMCLASS] = 0; S.cnt[C_NFUSE] = 0; }     // per-step counters the narrow phase raises
-  for (int kb = bid * GPB; kb < M; kb += nblk * GPB) {
+  const int vb0 = xcd_contiguous(bid, nblk, (M + GPB - 1) / GPB);
+  for (int kb = vb0 < 0 ? M : vb0 * GPB; kb < M; kb += nblk * GPB) {
     const int k = kb + gi;
     const bool act = k < M;
     __syncthreads();
     if (gl == 0) { cnts[gi][0] = 0; cnts[gi][1] = 0; wmask[gi] = 0; npool[gi] = 0; }
     __syncthreads();
     double ckx = 0, cky = 0, rk = 0, kx0 = 0, kx1 = 0, ky0 = 0, ky1 = 0;
-    long long idk = 0, okk = 0; bool kplain = true; int ix = 0, iy = 0;
+    long long idk = 0, okk = 0; bool kplain = true; int ix = 0, iy = 0, vok = 0, nvk = 0;
     if (act) {
+      vok = S.voff[k]; nvk = S.voff[k + 1] - vok;
       ckx = S.cx[k]; cky = S.cy[k]; rk = S.rmax[k];
       kx0 = S.bbx0[k]; kx1 = S.bbx1[k]; ky0 = S.bby0[k]; ky1 = S.bby1[k];
       idk = S.id[k]; okk = S.okey[k];
@@ -795,6 +825,7 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
       const double ox0 = S.bbx0[o], ox1 = S.bbx1[o], oy0 = S.bby0[o], oy1 = S.bby1[o];
       const long long oid = S.id[o], ko = S.okey[o];
       const bool oplain = S.parent[o] == o && S.ngh[o] == 0;     // a parent without ghosts
+      const int voo = S.voff[o], nvo = S.voff[o + 1] - voo;
       // potential_interaction (collisions.jl:705-710), symmetric in its arguments
       double ddx = ckx - ocx, ddy = cky - ocy, rr = rk + orm;
       if (!((ddx * ddx + ddy * ddy) < rr * rr)) continue;
@@ -808,7 +839,7 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
       // end at the first test of the clip (sz_geom.hpp clip()) with no row and no flag -- it is not run at all
       int boxes = 1;
       if (after) boxes = !(kx1 < ox0 || ox1 < kx0 || ky1 < oy0 || oy1 < ky0);
-      if (slot < MAXNB) { cand[gi][w][slot] = o | (boxes << 30); ckey[gi][w][slot] = ko; } else ovf = true;
+      if (slot < MAXNB) { cand[gi][w][slot] = o | (boxes << 30); ckey[gi][w][slot] = ko; if (after) { cvo[gi][slot] = voo; cnv[gi][slot] = nvo; } } else ovf = true;
     }
     if (ovf) atomicOr(&S.cnt[C_ERR], ERR_CAP_NEIGH);
     gsync();
@@ -820,7 +851,7 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
         for (int f = 0; f < n; f++) r += ckey[gi][w][f] < ke;
         const int cv = cand[gi][w][e];
         dst[r] = cv & 0x3fffffff;
-        if (w == 0) pool[gi][r] = cv & 0x3fffffff;          // (the pool is free by now: the sorted owned list, for the work items below)
+        if (w == 0) { pool[gi][r] = cv & 0x3fffffff; svo[gi][r] = cvo[gi][e]; snv[gi][r] = cnv[gi][e]; }   // (the pool is free by now: the sorted owned list, for the work items below)
         if (w == 0 && (cv >> 30)) atomicOr(&wmask[gi], 1 << r);
       }
       gsync();
@@ -845,7 +876,8 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
         const int slot = k * MAXNB + r;
         if ((mask >> r & 1) && base >= 0) {
           const int j = pool[gi][r];
-          S.work[(size_t)seg * segcap + base + wbase[gi] + __popc(mask & ((1 << r) - 1))] = make_int4(slot, k, j, 0);
+          const size_t w2 = 2 * ((size_t)seg * segcap + base + wbase[gi] + __popc(mask & ((1 << r) - 1)));
+          S.work[w2] = make_int4(slot, k, j, vok); S.work[w2 + 1] = make_int4(nvk, svo[gi][r], snv[gi][r], 0);
         } else S.it_info[slot] = make_int2(0, -1);      // boxes disjoint: no region, no row, no flag (the clip's own first test)
       }
     }
@@ -877,8 +909,10 @@ __global__ void sz_k_pairs_explicit(State S, int np) {
     for (int r = 0; r < nk; r++) {
       const int p = lo + r, j = S.pair_j[p];
       S.nb_out[(size_t)k * MAXNB + r] = j;
-      if (p / NSEG < segcap) S.work[(size_t)(p % NSEG) * segcap + p / NSEG] = make_int4(k * MAXNB + r, k, j, 0);
-      else atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS);
+      if (p / NSEG < segcap) {
+        const size_t w2 = 2 * ((size_t)(p % NSEG) * segcap + p / NSEG);
+        S.work[w2] = make_int4(k * MAXNB + r, k, j, S.voff[k]); S.work[w2 + 1] = make_int4(S.voff[k + 1] - S.voff[k], S.voff[j], S.voff[j + 1] - S.voff[j], 0);
+      } else atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS);
     }
   }
   if (blockIdx.x == 0 && threadIdx.x < NSEG) {
@@ -933,8 +967,13 @@ template <int G, int CAP, int KC, int RC, int RM, int TPB, int LO, int CLS, int 
 __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int dt, double ff_max_overlap, double fd_max_overlap, int dbg, int queue) {
   constexpr int GPB = TPB / G;
   static_assert(4 * KC <= 2 * RC, "raw crossing slots alias reg[1]");
+  Stamps st; STAMP_INIT(st);
+#ifdef SZ_STAMPS
+  st.on = (CLS == 0 && blockIdx.x == (unsigned)(dbg >> 8) && threadIdx.x == 0); st.log = S.stamps + 1;
+#endif
   if (CLS > 0 && S.cnt[C_ITEMCLASS] < CLS) return;   // no item needs this (larger) variant this step
   if (stopped(S)) return;
+  STAMP(st, 20);
   __shared__ GroupMem<CAP, KC, RC, RM> mem[GPB];
   const int gl = threadIdx.x % G, gi = threadIdx.x / G;
   GroupMem<CAP, KC, RC, RM>& m = mem[gi];
@@ -955,10 +994,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     for (int q = blockIdx.x * TPB + threadIdx.x; q <= ncells; q += gridDim.x * TPB) { S.cell_cnt[q] = 0; S.cell_ovf[q] = 0; }
     if (blockIdx.x == 0) for (int q = threadIdx.x; q < WARN_SLOTS * 4; q += TPB) S.warn[(q >> 2) * 32 + (q & 3)] = 0;
   }
-  Stamps st; STAMP_INIT(st);
-#ifdef SZ_STAMPS
-  st.on = (CLS == 0 && blockIdx.x == (unsigned)(dbg >> 8) && threadIdx.x == 0); st.log = S.stamps + 1;
-#endif
+  STAMP(st, 21);
   // The one-item-per-wavefront variant mostly looks for the few items meant for it: its lanes test 64
   // items at a time and the wavefront then works the flagged ones off one by one.
   constexpr bool SCAN = (G == 64 && TPB == 64);
@@ -973,8 +1009,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
      bool want = false;
      if (tt < nitems) {
        const Item it_ = item_of(S, sg, tt);
-       const int nb_ = it_.is_pair ? S.voff[it_.j + 1] - S.voff[it_.j] : S.eoff[it_.e + 1] - S.eoff[it_.e];
-       const int na_ = S.voff[it_.i + 1] - S.voff[it_.i];
+       const int nb_ = it_.nb, na_ = it_.na;
        want = (na_ > nb_ ? na_ : nb_) > LO || ((S.it_info[it_.info].x >> 8) & IT_RETRY);
      }
      todo = __ballot(want);
@@ -985,15 +1020,13 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     if (SCAN) { t = t0 + __ffsll((long long)todo) - 1; todo &= todo - 1; }
     else { todo = 0; t = t0 + gi; }
     bool have = t < limit;
-    Item it; it.i = 0; it.j = -1; it.e = -1; it.rows = 0; it.info = 0; it.is_pair = true;
+    Item it; it.i = 0; it.j = -1; it.e = -1; it.rows = 0; it.info = 0; it.is_pair = true; it.ao = it.na = it.bo = it.nb = 0;
     if (have) it = item_of(S, sg, t);
+    STAMP(st, 22);
     const bool is_pair = it.is_pair;
     const int i = it.i, j = it.j, e = it.e;
-    int na = 0, nb = 0, ao = 0, bo = 0;
+    const int na = it.na, nb = it.nb, ao = it.ao, bo = it.bo;
     if (have) {
-      ao = S.voff[i]; na = S.voff[i + 1] - ao;
-      bo = is_pair ? S.voff[j] : S.eoff[e];
-      nb = (is_pair ? S.voff[j + 1] : S.eoff[e + 1]) - bo;
       const int big = na > nb ? na : nb;
       // an item belongs to the first variant whose ring capacity fits it; an item a smaller variant
       // gave up on (more crossings / region points / regions than its working set holds) is handed to
@@ -1002,25 +1035,32 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       if (big <= LO && !retry) have = false;
       else if (big > CAP) { if (CLS == 2 && gl == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); have = false; }
     }
+    STAMP(st, 23);
     ItemCtx ic;
     ic.E = P.E; ic.nu = P.nu; ic.mu = P.mu; ic.dt = dt; ic.dbg = dbg;
     ic.mode = ITEM_PAIR; ic.max_overlap = ff_max_overlap; ic.elem_dir = -1; ic.elem_val = 0.0; ic.rigid_j = 0;
     int flags = 0;
     gsync();
     if (have) {
+      // Staging: every load of the item -- rings, scalars, signs, boxes -- is asked for BEFORE the first LDS store (a loop of
+      // load -> store pairs waits for each load in turn: seven dependent round trips of ~2.5 k cycles instead of one).
       const double* bxs = is_pair ? S.vx : S.ex; const double* bys = is_pair ? S.vy : S.ey;
-      for (int q = gl; q < na; q += G) { m.ax[q] = S.vx[ao + q]; m.ay[q] = S.vy[ao + q]; }
-      for (int q = gl; q < nb; q += G) { m.bx[q] = bxs[bo + q]; m.by[q] = bys[bo + q]; }
+      constexpr int NIT = (CAP + G - 1) / G, NKI = (14 + G - 1) / G;
+      double rax[NIT], ray[NIT], rbx[NIT], rby[NIT], kv[NKI];
       const int ekind = is_pair ? 0 : S.ekind[e];
-      for (int q = gl; q < 14; q += G) {          // the item's scalars, one lane each
+#pragma unroll
+      for (int r = 0; r < NKI; r++) {             // the item's scalars, one lane each
+        const int q = gl + r * G;
         const int c = q < 10 ? q % 5 : 5 + (q & 1);                  // cx cy u v xi | area height
         const bool side_j = q < 10 ? q >= 5 : q >= 12;
         const double* col = c == 0 ? S.cx : c == 1 ? S.cy : c == 2 ? S.u : c == 3 ? S.v : c == 4 ? S.xi : c == 5 ? S.area : S.height;
-        double val;
-        if (!side_j) val = col[i];
-        else if (is_pair) val = col[j];
-        else val = (ekind == 3 && c == 2) ? S.eu[e] : (ekind == 3 && c == 3) ? S.ev[e] : 0.0;   // a wall / topography: rigid (u, v)
-        m.kin[q] = val;
+        double val = 0.0;
+        if (q < 14) {
+          if (!side_j) val = col[i];
+          else if (is_pair) val = col[j];
+          else val = (ekind == 3 && c == 2) ? S.eu[e] : (ekind == 3 && c == 3) ? S.ev[e] : 0.0;   // a wall / topography: rigid (u, v)
+        }
+        kv[r] = val;
       }
       const int oa = S.osign[i], ob = is_pair ? S.osign[j] : S.eosign[e];
       if (!is_pair) {
@@ -1029,6 +1069,20 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       }
       const Box ba{ S.bbx0[i], S.bbx1[i], S.bby0[i], S.bby1[i] };
       const Box bb = is_pair ? Box{ S.bbx0[j], S.bbx1[j], S.bby0[j], S.bby1[j] } : Box{ S.ebb[4 * e], S.ebb[4 * e + 1], S.ebb[4 * e + 2], S.ebb[4 * e + 3] };
+#pragma unroll
+      for (int r = 0; r < NIT; r++) {
+        const int q = gl + r * G;
+        rax[r] = q < na ? S.vx[ao + q] : 0.0; ray[r] = q < na ? S.vy[ao + q] : 0.0;
+        rbx[r] = q < nb ? bxs[bo + q] : 0.0; rby[r] = q < nb ? bys[bo + q] : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < NIT; r++) {
+        const int q = gl + r * G;
+        if (q < na) { m.ax[q] = rax[r]; m.ay[q] = ray[r]; }
+        if (q < nb) { m.bx[q] = rbx[r]; m.by[q] = rby[r]; }
+      }
+#pragma unroll
+      for (int r = 0; r < NKI; r++) { const int q = gl + r * G; if (q < 14) m.kin[q] = kv[r]; }
       gsync();
       STAMP(st, 0);
       if (!(dbg & 4)) contact_phase<G>(m, gl, na, oa, nb, ob, ba, bb, ic, flags, st);
@@ -1069,11 +1123,14 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       }
       STAMP(st, 11);
 #ifdef SZ_STAMPS
-      if (st.on) { if (nrows > 0) { S.stamps[0] = st.n; st.on = false; } else { st.n = 0; st.t0 = clock64(); } }
+      if (st.on) { if (nrows > 0) { S.stamps[0] = st.n; if (!(dbg & 16) || st.pass) st.on = false; } else { st.n = 0; st.t0 = clock64(); } }
       st.maxrows = st.maxrows > nrows ? st.maxrows : nrows;
 #endif
     }
    }
+#ifdef SZ_STAMPS
+   if ((dbg & 16) && !st.pass) { st.pass = 1; continue; }      // timing experiment: the same round again, now with a warm instruction cache
+#endif
    if (useq) {
      int tk = 0;
      if (threadIdx.x == 0) tk = atomicAdd(&S.wq[qk * 32], GPB);
@@ -1199,7 +1256,8 @@ __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int 
   if (blockIdx.x == 0 && threadIdx.x < 2 * NSEG) S.wq[(threadIdx.x >> 1) * 32 + (threadIdx.x & 1)] = 0;
   const int n_init = n_init_arg >= 0 ? n_init_arg : S.cnt[C_N];   // < 0: every parent on the device
   const int lane = threadIdx.x % IF_G, gpb = blockDim.x / IF_G;
-  for (int k = blockIdx.x * gpb + threadIdx.x / IF_G; k < M; k += gridDim.x * gpb) {
+  const int vb0 = xcd_contiguous((int)blockIdx.x, (int)gridDim.x, (M + gpb - 1) / gpb);
+  for (int k = vb0 < 0 ? M : vb0 * gpb + threadIdx.x / IF_G; k < M; k += gridDim.x * gpb) {
     double* dst = S.inter_rows + (size_t)k * ROWCAP * 7;
     const bool is_ghost = S.ghost_id[k] != 0;
     const double cx = S.cx[k], cy = S.cy[k];
@@ -1314,7 +1372,12 @@ __global__ void sz_k_apply_frc(State S) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
     if (S.frc_remove[i]) S.status[i] = SZ_REMOVE;
 }
-constexpr int FRC_G = 32;      // lanes per floe (sub-floe points per floe ~ 100: 32 lanes keep every wavefront resident at 10k floes)
+constexpr int FRC_G = 32;      // lanes per floe of the two-way variant
+#ifndef FRC_PLAIN_LANES
+#define FRC_PLAIN_LANES 32
+#endif
+constexpr int FRC_PLAIN = FRC_PLAIN_LANES;   // lanes per floe of the one-way kernels (measured at 10 k floes: 64 lanes -- half as many trips over a floe's
+                                             // ~100 points -- is SLOWER, 24.4 against 21.4 us: the kernel is bound by the scattered lattice reads, not the chain)
 // Two-way coupling (TW): the kernel also fills the floe's part of grid.floe_locations / ocean.scells
 // (floe_to_grid_info!, coupling.jl:1417-1454): per distinct centre cell its sub-floe points fall into, the
 // periodic shift of the first such point, the sum of minus the ocean stress over the points IN POINT ORDER, and
@@ -1328,7 +1391,8 @@ constexpr int TW_FPB = 4;       // floes per workgroup of the two-way variant (1
 template <bool TW>
 __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid, int nblk, int pmax = 0) {
   extern __shared__ double tw_lds[];
-  int lane = threadIdx.x % FRC_G, wpb = blockDim.x / FRC_G, wid = threadIdx.x / FRC_G;
+  constexpr int FG = TW ? FRC_G : FRC_PLAIN;      // lanes per floe
+  int lane = threadIdx.x % FG, wpb = blockDim.x / FG, wid = threadIdx.x / FG;
   // per floe of the workgroup: ptx[pmax], pty[pmax] | pkey[pmax], skey[FC_CAP] | pcode[pmax], scode[FC_CAP]
   double* const ptx_w = TW ? tw_lds + (size_t)wid * 2 * pmax : nullptr;
   double* const pty_w = TW ? ptx_w + pmax : nullptr;
@@ -1348,11 +1412,11 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
     if (TW) {
       if (ns > pmax) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_CELLS); ns = pmax; }
       gsync();
-      for (int k = lane; k < ns; k += FRC_G) pkey_w[k] = -1;
+      for (int k = lane; k < ns; k += FG) pkey_w[k] = -1;
       gsync();
     }
     double tx = 0, ty = 0, ttrq = 0, th = 0; int np = 0;
-    for (int k = lane; k < ns; k += FRC_G) {
+    for (int k = lane; k < ns; k += FG) {
       double sxk = S.sx[o + k], syk = S.sy[o + k];
       double x = (ca * sxk - sa * syk) + cxf;
       double y = (sa * sxk + ca * syk) + cyf;
@@ -1367,12 +1431,28 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
       double st = yc * irad, ct = rad > 0.0 ? xc * irad : 1.0;
       double up = u - xi * rad * st, vp = v + xi * rad * ct;
       LatticeCell lc = lattice_cell(S, x, y, per_x, per_y);
-      double uatm = sample_field(S.nodes, 3, lc), vatm = sample_field(S.nodes, 4, lc);
+      // the four corner nodes, two wide loads each (uo vo hf ua | va) instead of five 8-byte ones: the kernel is bound by
+      // the number of scattered load instructions, not by bytes
+      double n4[4][5];
+      {
+        const int oo[4] = { lc.o00, lc.o01, lc.o10, lc.o11 };
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const double4 a = *(const double4*)(S.nodes + (size_t)oo[q] * 8);
+          n4[q][0] = a.x; n4[q][1] = a.y; n4[q][2] = a.z; n4[q][3] = a.w; n4[q][4] = S.nodes[(size_t)oo[q] * 8 + 4];
+        }
+      }
+      auto sample = [&](int f) {          // sample_field() on the values just read: same expression, same bits
+        double c0 = (1.0 - lc.ty) * n4[0][f] + lc.ty * n4[1][f];
+        double c1 = (1.0 - lc.ty) * n4[2][f] + lc.ty * n4[3][f];
+        return (1.0 - lc.tx) * c0 + lc.tx * c1;
+      };
+      double uatm = sample(3), vatm = sample(4);
       double du = uatm - up, dv = vatm - vp;
       double nrm = sqrt(du * du + dv * dv);
       double tax = P.rho_a * P.Cd_ia * nrm * du, tay = P.rho_a * P.Cd_ia * nrm * dv;
-      double uocn = sample_field(S.nodes, 0, lc), vocn = sample_field(S.nodes, 1, lc);
-      double hfl = sample_field(S.nodes, 2, lc);
+      double uocn = sample(0), vocn = sample(1);
+      double hfl = sample(2);
       double duo = uocn - up, dvo = vocn - vp;
       double nrmo = sqrt(duo * duo + dvo * dvo);
       double tox = P.rho_o * P.Cd_io * nrmo * (cturn * duo - sturn * dvo);
@@ -1394,11 +1474,11 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
         }
       }
     }
-    for (int d = FRC_G / 2; d >= 1; d >>= 1) {
-      tx += __shfl_xor(tx, d, FRC_G); ty += __shfl_xor(ty, d, FRC_G); ttrq += __shfl_xor(ttrq, d, FRC_G); th += __shfl_xor(th, d, FRC_G);
+    for (int d = FG / 2; d >= 1; d >>= 1) {
+      tx += __shfl_xor(tx, d, FG); ty += __shfl_xor(ty, d, FG); ttrq += __shfl_xor(ttrq, d, FG); th += __shfl_xor(th, d, FG);
     }
     int npt = np;
-    for (int d = FRC_G / 2; d >= 1; d >>= 1) npt += __shfl_xor(npt, d, FRC_G);
+    for (int d = FG / 2; d >= 1; d >>= 1) npt += __shfl_xor(npt, d, FG);
     if (lane == 0) {
       // no in-bounds point: the floe is marked for removal (coupling.jl:1507-1508).  The tag itself is
       // written by the integrate kernel: this kernel may run beside the collision kernels, which also
@@ -1418,7 +1498,7 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
       // slots in order of first appearance (add_point!, coupling.jl:1336-1360, keeps one entry per floe and cell)
       int nslots = 0;
       const unsigned long long half = 0xffffffffull << (32 * ((threadIdx.x >> 5) & 1));
-      for (int base = 0; base < ns; base += FRC_G) {
+      for (int base = 0; base < ns; base += FG) {
         const int k = base + lane;
         bool first = false;
         if (k < ns && pkey_w[k] >= 0) {
@@ -1482,7 +1562,7 @@ __device__ __forceinline__ float sample_field32(const float* nodes, int f, const
 __device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, int bid, int nblk) {
   if (stopped(S)) return;
   int N = S.cnt[C_NOWN];
-  int lane = threadIdx.x % FRC_G, wpb = blockDim.x / FRC_G, wid = threadIdx.x / FRC_G;
+  int lane = threadIdx.x % FRC_PLAIN, wpb = blockDim.x / FRC_PLAIN, wid = threadIdx.x / FRC_PLAIN;
   int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
   const float cturn = (float)cos(P.turn), sturn = (float)sin(P.turn);
   const float ka = (float)(P.rho_a * P.Cd_ia), ko = (float)(P.rho_o * P.Cd_io);
@@ -1494,7 +1574,7 @@ __device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, in
     const float mf = (float)(ma_ratio * P.fcor);
     int o = S.soff[i], ns = S.soff[i + 1] - o;
     float tx = 0, ty = 0, ttrq = 0, th = 0; int np = 0;
-    for (int k = lane; k < ns; k += FRC_G) {
+    for (int k = lane; k < ns; k += FRC_PLAIN) {
       const float2 sp = S.s32[o + k];
       const float px = ca * sp.x - sa * sp.y, py = sa * sp.x + ca * sp.y;      // offset from the centroid
       const double x = cxf + (double)px, y = cyf + (double)py;
@@ -1521,11 +1601,11 @@ __device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, in
       tx += fx; ty += fy; ttrq += (-fx * st + fy * ct) * rad; th += hfl;
     }
     double dtx = tx, dty = ty, dtq = ttrq, dth = th;
-    for (int d = FRC_G / 2; d >= 1; d >>= 1) {
-      dtx += __shfl_xor(dtx, d, FRC_G); dty += __shfl_xor(dty, d, FRC_G); dtq += __shfl_xor(dtq, d, FRC_G); dth += __shfl_xor(dth, d, FRC_G);
+    for (int d = FRC_PLAIN / 2; d >= 1; d >>= 1) {
+      dtx += __shfl_xor(dtx, d, FRC_PLAIN); dty += __shfl_xor(dty, d, FRC_PLAIN); dtq += __shfl_xor(dtq, d, FRC_PLAIN); dth += __shfl_xor(dth, d, FRC_PLAIN);
     }
     int npt = np;
-    for (int d = FRC_G / 2; d >= 1; d >>= 1) npt += __shfl_xor(npt, d, FRC_G);
+    for (int d = FRC_PLAIN / 2; d >= 1; d >>= 1) npt += __shfl_xor(npt, d, FRC_PLAIN);
     if (lane == 0) {
       S.frc_remove[i] = npt == 0 ? 1 : 0;
       if (npt != 0) {

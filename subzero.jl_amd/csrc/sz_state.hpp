@@ -111,7 +111,7 @@ struct State {
   // = k * MAXNB + rank) and earlier (nb_in: the pairs mirrored onto it); out_mask: which owned pairs have overlapping ring boxes
   int *nb_out, *nb_in, *n_out, *n_in, *out_mask;
   int *out_off, *pair_i, *pair_j;      // the compact pair list in serial order: made on demand (sz_download_pairs) / given (sz_collide_pairs)
-  // work list of the narrow phase: the pair items to run {slot, i, j, -}, appended by the neighbour search in NSEG segments of
+  // work list of the narrow phase: the pair items to run, two int4 each {slot, i, j, ring offset i} {ring size i, ring offset j, ring size j, -}, appended by the neighbour search in NSEG segments of
   // capPairs / NSEG items; wq[s * 32] = queue head of segment s (rounds after the first), wq[s * 32 + 1] = its length
   int4* work;
   int* wq;
