@@ -155,6 +155,9 @@ int sz_download_pairs(sz_ctx *ctx, int32_t *pi, int32_t *pj);
    idx == NULL to get only the offsets (off[M] = total) */
 int sz_download_fuse(sz_ctx *ctx, int32_t *off, int32_t *idx);
 int sz_get_boundary_vals(sz_ctx *ctx, double *vals4);
+/* the boundary rectangles as they stand, {xmin, xmax, ymin, ymax} for N, S, E, W (MovingBoundary walls move with
+   update_boundaries!, collisions.jl:565-571) */
+int sz_get_boundary_rects(sz_ctx *ctx, double *rects16);
 
 /* ---- processes (each mirrors one reference function, see the header comment) */
 int sz_add_ghosts(sz_ctx *ctx);
@@ -279,6 +282,10 @@ int sz_eulerian_finish(sz_ctx *ctx, int32_t nx, int32_t ny, const double *xg, co
                        int32_t nout, const int32_t *outputs, double *data);
 int sz_simplify_check(sz_ctx *ctx, int32_t max_vertices, double min_floe_area, double min_floe_height, int64_t *out4);
 
+/* test hook: which_vertices_match_points(points, region) (floe_utils.jl:331-352) as the narrow phase evaluates it, on
+   given points (<= 64) and a given closed region ring; idx = sorted 0-based vertex indices */
+int sz_debug_match_vertices(sz_ctx *ctx, int32_t npts, const double *px, const double *py, int32_t nr, const double *rx,
+                            const double *ry, int32_t *idx, int32_t *n_out);
 /* diagnostic build (-DSZ_STAMPS) only: stamp log of one lane group of the narrow phase
    (out512[0] = entries, then (stage << 48) | cycles since the wave started) */
 int sz_debug_stamps(sz_ctx *ctx, long long *out512);

@@ -136,6 +136,8 @@ void orc_get_ghosts(const orc_world *w, int32_t *off /*M+1*/, int32_t *idx /* 0-
 int  orc_total_fuse(const orc_world *w);
 void orc_get_fuse(const orc_world *w, int32_t *off /*M+1*/, int32_t *idx /* 0-based */);
 void orc_get_boundary_vals(const orc_world *w, double *vals4);
+void orc_get_boundary_polys(const orc_world *w, double *xy40);
+int orc_which_vertices_match_points(int npts, const double *px, const double *py, int nr, const double *rx, const double *ry, int32_t *idx);
 
 /* the reference's process API */
 void orc_add_ghosts(orc_world *w);                                   /* collisions.jl:1060-1174 */

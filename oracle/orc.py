@@ -56,7 +56,7 @@ def lib():
         L.orc_add_floe.restype = C.c_int
         for name in ("orc_num_floes", "orc_total_ring_points", "orc_total_interactions",
                      "orc_total_ghost_links", "orc_total_fuse", "orc_num_pairs",
-                     "orc_clip_flat", "orc_ipoints_flat", "orc_cell_count", "orc_shift_cell_idx"):
+                     "orc_clip_flat", "orc_ipoints_flat", "orc_cell_count", "orc_shift_cell_idx", "orc_which_vertices_match_points"):
             getattr(L, name).restype = C.c_int
     return _LIB
 
@@ -78,6 +78,15 @@ def clip(a, b, max_regions=16, max_pts=4096):
                             _p(off, _ip), _p(rx), _p(ry))
     assert n >= 0, "oracle clip capacity exceeded"
     return [np.stack([rx[off[k]:off[k + 1]], ry[off[k]:off[k + 1]]], 1) for k in range(n)]
+
+
+def which_vertices_match_points(points, region):
+    """which_vertices_match_points(points, region) (floe_utils.jl:331-352): sorted 1-based vertex indices"""
+    p = _d(points); r = _d(region)
+    px, py, rx, ry = _d(p[:, 0]), _d(p[:, 1]), _d(r[:, 0]), _d(r[:, 1])
+    idx = np.zeros(max(len(px), 1), np.int32)
+    n = lib().orc_which_vertices_match_points(len(px), _p(px), _p(py), len(rx), _p(rx), _p(ry), _p(idx, _ip))
+    return [int(v) + 1 for v in idx[:n]]
 
 
 def intersection_points(a, b, max_pts=1024):
@@ -257,6 +266,12 @@ class World:
         v = np.zeros(4)
         self.L.orc_get_boundary_vals(self.h, _p(v))
         return v
+
+    def boundary_polys(self):
+        """the four boundary polygons (N, S, E, W) as (5, 2) arrays"""
+        v = np.zeros(40)
+        self.L.orc_get_boundary_polys(self.h, _p(v))
+        return [np.stack([v[k * 10:k * 10 + 5], v[k * 10 + 5:k * 10 + 10]], 1) for k in range(4)]
 
     def warn_counts(self):
         v = np.zeros(4, np.int64)

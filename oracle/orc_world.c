@@ -192,6 +192,10 @@ void orc_set_domain_extent(orc_world *w, const int *kinds, double x0, double xf,
   }
 }
 void orc_get_boundary_vals(const orc_world *w, double *vals4) { for (int k = 0; k < 4; k++) vals4[k] = w->b[k].val; }
+/* the boundary polygons as they stand (5 points each, x then y: 10 doubles per boundary, order N, S, E, W) */
+void orc_get_boundary_polys(const orc_world *w, double *xy40) {
+  for (int k = 0; k < 4; k++) for (int q = 0; q < 5; q++) { xy40[k * 10 + q] = w->b[k].poly.p[q].x; xy40[k * 10 + 5 + q] = w->b[k].poly.p[q].y; }
+}
 void orc_set_topography(orc_world *w, int ntopo, const int *off, const double *x, const double *y) {
   for (int k = 0; k < w->ntopo; k++) orc_ring_free(&w->topo[k].poly);
   free(w->topo);
@@ -330,6 +334,19 @@ static int which_vertices_match_points(const orc_pt *pts, int npts, const orc_ri
     if (min_dist < 1.0) idx[m++] = min_vert;
   }
   for (int u = 1; u < m; u++) { int k = idx[u], v = u - 1; while (v >= 0 && idx[v] > k) { idx[v + 1] = idx[v]; v--; } idx[v + 1] = k; }
+  return m;
+}
+
+/* which_vertices_match_points on plain arrays (tests: test_floe_utils.jl:74-137): 0-based indices out, returns the count */
+int orc_which_vertices_match_points(int npts, const double *px, const double *py, int nr, const double *rx, const double *ry, int32_t *idx) {
+  orc_pt *pts = (orc_pt *)malloc(sizeof(orc_pt) * (size_t)(npts > 0 ? npts : 1));
+  orc_ring region; region.n = nr; region.cap = nr; region.p = (orc_pt *)malloc(sizeof(orc_pt) * (size_t)(nr > 0 ? nr : 1));
+  for (int i = 0; i < npts; i++) { pts[i].x = px[i]; pts[i].y = py[i]; }
+  for (int j = 0; j < nr; j++) { region.p[j].x = rx[j]; region.p[j].y = ry[j]; }
+  int *tmp = (int *)malloc(sizeof(int) * (size_t)(npts > 0 ? npts : 1));
+  int m = which_vertices_match_points(pts, npts, &region, tmp);
+  for (int k = 0; k < m; k++) idx[k] = tmp[k];
+  free(tmp); free(pts); free(region.p);
   return m;
 }
 

@@ -60,6 +60,7 @@ EXPORTS = [
     "sz_eulerian_data", "sz_eulerian_partial", "sz_eulerian_finish", "sz_simplify_check",
     "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms",
     "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_forcing", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps",
+    "sz_get_boundary_rects", "sz_debug_match_vertices",
 ]
 
 EUL_PARTIAL = 17      # SZ_EUL_PARTIAL: per-cell partial fields of sz_eulerian_partial
@@ -136,6 +137,8 @@ def load(build_if_missing=True):
     L.sz_sync.argtypes = [C.c_void_p]
     L.sz_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.sz_debug_stamps.argtypes = [C.c_void_p, _lp]
+    L.sz_get_boundary_rects.argtypes = [C.c_void_p, _dp]
+    L.sz_debug_match_vertices.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, C.c_int32, _dp, _dp, _ip, _ip]
     for n in EXPORTS:
         if n not in ("sz_create", "sz_destroy", "sz_last_error", "sz_version"):
             getattr(L, n).restype = C.c_int

@@ -146,6 +146,8 @@ void trim_pool(Pool& pool) {
   pool.chunks.resize(keep); pool.sizes.resize(keep);
 }
 
+struct PoolGuard { Pool v; PoolGuard() { v.next = 1u << 16; } ~PoolGuard() { free_pool(v); } };
+
 inline int grid_for(long long n, int tpb, int maxb = 4096) {
   long long b = (n + tpb - 1) / tpb;
   if (b < 1) b = 1;
@@ -934,6 +936,35 @@ int sz_get_boundary_vals(sz_ctx* c, double* vals4) {
   return SZ_OK;
 }
 
+// the four boundary rectangles as they stand: {xmin, xmax, ymin, ymax} each, order N, S, E, W (MovingBoundary walls move)
+int sz_get_boundary_rects(sz_ctx* c, double* rects16) {
+  if (!c || !rects16 || !c->have_domain) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  tile_cleanup(c);
+  HIPCHK(c, hipMemcpy(rects16, c->S.erect, 16 * sizeof(double), hipMemcpyDeviceToHost));
+  return SZ_OK;
+}
+
+// which_vertices_match_points on given points and a given region ring (the reference's test vectors for it)
+int sz_debug_match_vertices(sz_ctx* c, int32_t npts, const double* px, const double* py, int32_t nr, const double* rx, const double* ry,
+                            int32_t* idx, int32_t* n_out) {
+  if (!c || npts < 0 || npts > 64 || nr < 1 || nr > 320 || !idx || !n_out) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  PoolGuard pool;
+  double *dpx, *dpy, *drx, *dry; int* dout;
+  int rc;
+  if ((rc = dalloc(c, &dpx, npts, pool.v)) || (rc = dalloc(c, &dpy, npts, pool.v)) || (rc = dalloc(c, &drx, nr, pool.v)) ||
+      (rc = dalloc(c, &dry, nr, pool.v)) || (rc = dalloc(c, &dout, npts + 1, pool.v))) return rc;
+  H2D(dpx, px, npts, double); H2D(dpy, py, npts, double); H2D(drx, rx, nr, double); H2D(dry, ry, nr, double);
+  hipLaunchKernelGGL(sz_k_debug_match_vertices, dim3(1), dim3(64), 0, c->stream, npts, dpx, dpy, nr, drx, dry, dout);
+  std::vector<int> h(npts + 1);
+  HIPCHK(c, hipMemcpyAsync(h.data(), dout, (size_t)(npts + 1) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_out = h[0];
+  for (int k = 0; k < h[0]; k++) idx[k] = h[1 + k];
+  return SZ_OK;
+}
+
 // ---------------------------------------------------------------- processes
 int sz_add_ghosts(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;
@@ -1346,7 +1377,6 @@ int sz_two_way_finish(sz_ctx* c, const void* d_partial, int32_t dt) {
 }
 
 // ---------------------------------------------------------------- output path
-namespace { struct PoolGuard { Pool v; PoolGuard() { v.next = 1u << 16; } ~PoolGuard() { free_pool(v); } }; }
 
 // shared front of the grid-output calls: argument checks, grid lines to the device, cell areas
 int eul_grid(sz_ctx* c, int32_t nx, int32_t ny, const double* xg, const double* yg, PoolGuard& pool, EulGrid& E) {

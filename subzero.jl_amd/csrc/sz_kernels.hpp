@@ -2004,6 +2004,21 @@ __global__ void __launch_bounds__(1024) sz_k_owned_box(State S, double* out) {
   }
 }
 
+// which_vertices_match_points (floe_utils.jl:331-352) on its own, for the reference's test vectors: the narrow phase's
+// match_vertices() -- the crossing points of an item against one contact region -- fed with given points and a given ring.
+// One wavefront; out[0] = count, out[1..] = sorted 0-based vertex indices.
+__global__ void __launch_bounds__(64) sz_k_debug_match_vertices(int npts, const double* px, const double* py, int nr, const double* rx,
+                                                               const double* ry, int* out) {
+  __shared__ GroupMem<NARROW_CAP2, 64, 320, 16> m;
+  const int gl = threadIdx.x;
+  for (int k = gl; k < npts; k += 64) { m.cx[k] = px[k]; m.cy[k] = py[k]; m.uniq[k] = 1; }
+  for (int k = gl; k < nr; k += 64) { m.reg[0][0][k] = rx[k]; m.reg[0][1][k] = ry[k]; }
+  if (gl == 0) m.nx = npts;
+  __syncthreads();
+  const int n = match_vertices<64>(m, gl, npts, m.reg[0][0], m.reg[0][1], nr);
+  if (gl == 0) { out[0] = n; for (int k = 0; k < n; k++) out[1 + k] = m.midx[k]; }
+}
+
 // ============================================================================ stats
 __global__ void sz_k_stats(State S, long long* out) {
   // out[0] = sum ring points over the pairs the narrow phase ran, out[1] = pair rows, out[2] = elem rows,

@@ -345,6 +345,27 @@ class World:
         self._chk(self.L.sz_get_boundary_vals(self.h, capi.ptr(v)))
         return v
 
+    def boundary_polys(self):
+        """the four boundary polygons (N, S, E, W) as (5, 2) arrays, as _make_bounding_box_polygon orders them"""
+        r = np.zeros(16)
+        self._chk(self.L.sz_get_boundary_rects(self.h, capi.ptr(r)))
+        out = []
+        for k in range(4):
+            x0, x1, y0, y1 = r[4 * k:4 * k + 4]
+            out.append(np.array([[x0, y0], [x0, y1], [x1, y1], [x1, y0], [x0, y0]]))
+        return out
+
+    def which_vertices_match_points(self, points, region):
+        """which_vertices_match_points(points, region) (floe_utils.jl:331-352) by the narrow phase's device routine: sorted
+        1-based vertex indices"""
+        p = np.ascontiguousarray(points, np.float64); r = np.ascontiguousarray(region, np.float64)
+        px, py = np.ascontiguousarray(p[:, 0]), np.ascontiguousarray(p[:, 1])
+        rx, ry = np.ascontiguousarray(r[:, 0]), np.ascontiguousarray(r[:, 1])
+        idx = np.zeros(max(len(px), 1), _I32); n = C.c_int32(0)
+        self._chk(self.L.sz_debug_match_vertices(self.h, len(px), capi.ptr(px), capi.ptr(py), len(rx), capi.ptr(rx), capi.ptr(ry),
+                                                 capi.ptr(idx, capi._ip), C.byref(n)))
+        return [int(v) + 1 for v in idx[:n.value]]
+
     def warn_counts(self):
         s = self.stats()
         return np.array([s["warn_height"], s["warn_force"], s["warn_vel"], s["warn_xi"]], _I64)

@@ -16,4 +16,4 @@ def pytest_configure(config):
 def golden():
     import json
     d = os.path.join(ROOT, "tests", "golden")
-    return {n: json.load(open(os.path.join(d, n + ".json"))) for n in ("collisions", "floe_utils", "forcings", "update_floe", "coupling_grid")}
+    return {n: json.load(open(os.path.join(d, n + ".json"))) for n in ("collisions", "floe_utils", "forcings", "update_floe", "coupling_grid", "boundaries", "conservation")}

@@ -8,7 +8,11 @@ data file.  No reference source text is copied.
 
   collisions.json  <- test/test_physical_processes/test_collisions.jl:43-362 (literal inputs,
                       MATLAB-derived expected values, tolerances as the reference states them)
-  floe_utils.json  <- test/test_floe_utils.jl:66-71
+  floe_utils.json  <- test/test_floe_utils.jl:52-63 (translate), :66-71 (moment of inertia), :74-137
+                      (which_vertices_match_points), :173-192 (rotate_radians!)
+  boundaries.json  <- test/test_simulation_components/domain_components/boundaries.jl:5-127 (boundary rectangles,
+                      _update_boundary!)
+  conservation.json <- test/test_conservation.jl:58-146 (the three energy / momentum conservation runs with literal floes)
   forcings.json    <- test/test_physical_processes/test_coupling.jl:464-639, with the sub-floe
                       points X, Y decoded from test/inputs/test_mc_points.jld2 (two contiguous
                       little-endian Float64 datasets of 241 values each inside the JLD2/HDF5
@@ -163,13 +167,91 @@ def collisions():
 
 
 def floe_utils():
+    ext = [[0.0, 1.0], [0.0, 0.0], [1.0, 0.0], [1.0, 1.0], [0.0, 1.0]]
+    r2 = 2.0 ** 0.5
     return {
-        "_source": "test/test_floe_utils.jl:66-71",
+        "_source": "test/test_floe_utils.jl:12-14,52-63,66-71,74-137,173-192",
         "moment": [
-            {"coords": [[0.0, 1.0], [0.0, 0.0], [1.0, 0.0], [1.0, 1.0], [0.0, 1.0]], "height": 0.25,
-             "expected": 38.333, "atol": 1e-3},
+            {"coords": ext, "height": 0.25, "expected": 38.333, "atol": 1e-3},
             {"coords": [[0.0, 6.67], [0.0, 0.0], [6.67, 0.0], [0.0, 6.67]], "height": 0.5,
              "expected": 50581.145, "atol": 1e-3},
+        ],
+        # :52-63  translate / translate!: exact equality in the reference
+        "translate": [
+            {"coords": ext, "dx": 0.0, "dy": 0.0, "expected": ext},
+            {"coords": ext, "dx": 1.0, "dy": 2.0, "expected": [[1.0, 3.0], [1.0, 2.0], [2.0, 2.0], [2.0, 3.0], [1.0, 3.0]]},
+            {"coords": [[-2.0, 2.0], [-2.0, 1.0], [-1.0, 1.0], [-1.0, 2.0]], "dx": 1.5, "dy": -1.5,
+             "expected": [[-0.5, 0.5], [-0.5, -0.5], [0.5, -0.5], [0.5, 0.5]]},
+        ],
+        # :173-192  rotate_radians! about the origin, isapprox (rtol sqrt(eps)) in the reference
+        "rotate": [
+            {"coords": [[-1.0, -1.0], [-1.0, 1.0], [1.0, 1.0], [1.0, -1.0], [-1.0, -1.0]], "angle": "pi/4",
+             "expected": [[0.0, -r2], [-r2, 0.0], [0.0, r2], [r2, 0.0], [0.0, -r2]]},
+            {"coords": [[0.0, -r2], [-r2, 0.0], [0.0, r2], [r2, 0.0], [0.0, -r2]], "angle": "7pi/4",
+             "expected": [[-1.0, -1.0], [-1.0, 1.0], [1.0, 1.0], [1.0, -1.0], [-1.0, -1.0]]},
+        ],
+        # :74-137  which_vertices_match_points(points = first ring, region = second polygon): 1-based vertex indices
+        "which_vertices_match_points": [
+            {"name": "two_shared_v",
+             "points": [[0.0, 0.0], [0.0, 20.0], [20.0, 20.0], [20.0, 0.0], [0.0, 0.0]],
+             "region": [[20.0, 0.0], [20.0, 20.0], [40.0, 20.0], [40.0, 0.0], [20.0, 0.0]], "expected": [1, 2]},
+            {"name": "three_shared_v",
+             "points": [[0.0, 0.0], [0.0, 20.0], [20.0, 20.0], [20.0, 10.0], [20.0, 0.0], [0.0, 0.0]],
+             "region": [[40.0, 20.0], [40.0, 0.0], [20.0, 0.0], [20.0, 10.0], [20.0, 20.0], [40.0, 20.0]], "expected": [3, 4, 5]},
+            {"name": "four_shared_v",
+             "points": [[0.0, 0.0], [0.0, 20.0], [20.0, 20.0], [20.0, 18.0], [20.0, 15.0], [20.0, 0.0], [0.0, 0.0]],
+             "region": [[20.0, 18.0], [20.0, 20.0], [40.0, 20.0], [40.0, 0.0], [20.0, 0.0], [20.0, 15.0], [20.0, 18.0]],
+             "expected": [1, 2, 5, 6]},
+            {"name": "triange_shared_v",
+             "points": [[0.0, 0.0], [0.0, 20.0], [20.0, 20.0], [5.0, 5.0], [0.0, 0.0]],
+             "region": [[0.0, 0.0], [5.0, 5.0], [20.0, 20.0], [20.0, 0.0], [0.0, 0.0]], "expected": [1, 2, 3]},
+        ],
+    }
+
+
+def boundaries():
+    """test/test_simulation_components/domain_components/boundaries.jl: the boundary rectangles of an extent (:5-31,
+    :33-83 -- corner point sets and wall values), and _update_boundary! (:103-127: only MovingBoundary moves, the
+    southern one by dt * v in y, the western one by dt * u in x; val follows).  The reference's western wall is a
+    Float32 boundary with u = 0.1f0; the fixture states the same case in Float64."""
+    return {
+        "_source": "test/test_simulation_components/domain_components/boundaries.jl:5-31,33-83,90-127",
+        "directions": {"extent": [0.0, 1e5, -5e4, 5e4],         # x0, xf, y0, yf
+                       "north": {"val": 5e4, "points": [[-5e4, 5e4], [-5e4, 1e5], [1.5e5, 1e5], [1.5e5, 5e4]]},
+                       "south": {"val": -5e4, "points": [[-5e4, -5e4], [-5e4, -1e5], [1.5e5, -1e5], [1.5e5, -5e4]]},
+                       "east": {"val": 1e5, "points": [[1e5, -1e5], [1e5, 1e5], [1.5e5, -1e5], [1.5e5, 1e5]]},
+                       "west": {"val": 0.0, "points": [[0.0, -1e5], [0.0, 1e5], [-5e4, -1e5], [-5e4, 1e5]]}},
+        "boundaries": {"extent": [0.0, 4e5, 0.0, 3e5],
+                       "north": {"val": 3e5, "area": 8e5 * 1.5e5, "points": [[-2e5, 3e5], [-2e5, 4.5e5], [6e5, 4.5e5], [6e5, 3e5]]},
+                       "east": {"val": 4e5, "area": 2e5 * 6e5, "points": [[4e5, -1.5e5], [4e5, 4.5e5], [6e5, 4.5e5], [6e5, -1.5e5]]},
+                       "south": {"val": 0.0, "area": 8e5 * 1.5e5, "points": [[-2e5, -1.5e5], [-2e5, 0.0], [6e5, 0.0], [6e5, -1.5e5]]},
+                       "west": {"val": 0.0, "area": 2e5 * 6e5, "points": [[-2e5, -1.5e5], [-2e5, 4.5e5], [0.0, 4.5e5], [0.0, -1.5e5]]}},
+        # _update_boundary!(b, dt = 20): kinds N, S, E, W = open, moving (u 1, v 2), collision, moving (u 0.1, v -0.1)
+        "update": {"extent": [0.0, 4e5, 0.0, 3e5], "dt": 20, "kinds": ["open", "moving", "collision", "moving"],
+                   "u": [0.0, 1.0, 0.0, 0.1], "v": [0.0, 2.0, 0.0, -0.1],
+                   "expected_vals": [3e5, 0.0 + 20 * 2.0, 4e5, 0.0 + 20 * 0.1],
+                   "expected_shift": [[0.0, 0.0], [0.0, 20 * 2.0], [0.0, 0.0], [20 * 0.1, 0.0]]},
+    }
+
+
+def conservation():
+    """test/test_conservation.jl:58-146: the three runs with literal floes (two blocks head on, offset, and with a
+    triangle between them).  dt = 1 s, 5000 steps, E = 1.5e3 (mean sqrt(area) + min sqrt(area)), mu = 0, coupling off,
+    open domain, hmean 0.25 (:1-56); pass = |change| of total kinetic energy, x momentum, y momentum and total angular
+    momentum (src/tools/conservation_em.jl:16-67) from the first to the last output below 1 %.  (The two runs with
+    shapes from test/inputs/floe_shapes.jld2 are not transcribed.)"""
+    floe1 = [[2e4, 2e4], [2e4, 5e4], [5e4, 5e4], [5e4, 2e4], [2e4, 2e4]]
+    floe2 = [[6e4, 2e4], [6e4, 5e4], [9e4, 5e4], [9e4, 2e4], [6e4, 2e4]]
+    floe3 = [[5.5e4, 2e4], [5.25e4, 4e4], [5.75e4, 4e4], [5.5e4, 2e4]]
+    return {
+        "_source": "test/test_conservation.jl:1-146, src/tools/conservation_em.jl:16-67",
+        "grid": {"x0": -2e4, "xf": 1e5, "y0": 0.0, "yf": 1e5, "dx": 1e4, "dy": 1e4},
+        "dt": 1, "nsteps": 5000, "mu": 0.0, "hmean": 0.25, "boundaries": "open", "max_percent_change": 1.0,
+        "cases": [
+            {"name": "head_on", "floes": [floe1, floe2], "u": [0.15, -0.1], "v": [0.02, 0.02], "xi": [1e-7, 0.0]},
+            {"name": "offset", "floes": [floe1, translate(floe2, 0.0, 1e4)], "u": [0.11, -0.1], "v": [0.02, 0.02], "xi": [1e-7, 0.0]},
+            {"name": "rotating", "floes": [floe1, floe2, floe3], "u": [0.11, -0.1, 0.0], "v": [0.001, 0.001, 0.001],
+             "xi": [0.0, 0.0, 1e-5]},
         ],
     }
 
@@ -333,7 +415,8 @@ def coupling_grid():
 
 def main():
     for name, fn in (("collisions.json", collisions), ("floe_utils.json", floe_utils), ("forcings.json", forcings),
-                     ("update_floe.json", update_floe), ("coupling_grid.json", coupling_grid)):
+                     ("update_floe.json", update_floe), ("coupling_grid.json", coupling_grid), ("boundaries.json", boundaries),
+                     ("conservation.json", conservation)):
         with open(os.path.join(HERE, name), "w") as f:
             json.dump(fn(), f, indent=1)
         print("wrote", name)

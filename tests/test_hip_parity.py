@@ -495,3 +495,52 @@ def test_ghost_candidate_list_equals_the_two_launch_pass():
     wrapped = np.abs(a["cx"] - cfg["derived"]["cx"]) > 0.5 * L
     assert wrapped.sum() >= 3                            # parents went through the east wall and came back in the west
     assert np.any(wrapped & (cfg["derived"]["cx"] <= L)) # ... also some that started inside
+
+
+# ---------------------------------------------------------------- further reference-held vectors, through the C-ABI
+def test_which_vertices_match_points(golden):
+    """test_floe_utils.jl:74-137, by the narrow phase's own device routine"""
+    w = mk()
+    for case in golden["floe_utils"]["which_vertices_match_points"]:
+        assert w.which_vertices_match_points(case["points"], case["region"]) == case["expected"], case["name"]
+
+
+def test_translate_rotate(golden):
+    """test_floe_utils.jl:52-63, 173-192 through _move_floe! of timestep_floe_properties!"""
+    cases.check_translate_rotate(mk, golden["floe_utils"])
+
+
+def test_boundary_rectangles_and_update(golden):
+    """boundaries.jl (test):5-83 and :103-127 (_update_boundary!: only MovingBoundary walls move)"""
+    for key in ("directions", "boundaries"):
+        B = golden["boundaries"][key]
+        x0, xf, y0, yf = B["extent"]
+        w = mk(); w.set_domain([0, 0, 0, 0], x0, xf, y0, yf)
+        cases.check_boundary_polys(w.boundary_polys(), w.boundary_vals(), B)
+    U = golden["boundaries"]["update"]
+    cases.check_update_boundaries(cases.run_update_boundaries(mk, U), U)
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_conservation(golden, k):
+    """test_conservation.jl:58-146 through resident batches: < 1 % change of kinetic energy, linear and angular momentum over
+    the reference's 5000 steps (in these runs the floes never reach one another -- 10 km apart at 0.25 m/s, dt = 1 s --
+    so the criterion pins the free-flight AB2 update, update_floe.jl:502-545); and, with dt = 10 s, where they DO collide
+    for thousands of steps, the HIP path against the oracle on the same four quantities."""
+    C = golden["conservation"]; case = C["cases"][k]
+
+    def stepper(w, n, dt):
+        t = 0
+        while t < n:
+            done = w.run(min(500, n - t), t, dt, coupling_dt=10, coupling_on=False)
+            assert done > 0
+            t += done
+    change = cases.run_conservation(mk, C, case, stepper)
+    assert np.all(np.isfinite(change)) and np.all(np.abs(change) < C["max_percent_change"]), (case["name"], change)
+    # colliding variant
+    res = []
+    for make, step in ((mk, lambda w, n, dt: stepper(w, n, 10)),
+                       (omk, lambda w, n, dt: [w.timestep_sim(t, 10, coupling_dt=10, coupling_on=False) for t in range(n)])):
+        res.append(cases.run_conservation(make, C, case, step))
+    assert np.any(np.abs(res[1]) > 1.0)                      # contacts really happened (energy is not conserved by them)
+    assert np.allclose(res[0], res[1], rtol=1e-6, atol=1e-9), (case["name"], res)

@@ -133,3 +133,48 @@ def test_find_center_cell_index(golden):
 
 def test_two_way_coupling_analytic():
     cases.check_two_way_analytic(*cases.run_two_way_analytic(mk))
+
+
+# ------------------------------------------------------------------ further reference-held vectors
+def test_which_vertices_match_points(golden):
+    """test_floe_utils.jl:74-137"""
+    for case in golden["floe_utils"]["which_vertices_match_points"]:
+        assert orc.which_vertices_match_points(case["points"], case["region"]) == case["expected"], case["name"]
+
+
+def test_translate_rotate(golden):
+    """test_floe_utils.jl:52-63 (translate: exact) and :173-192 (rotate_radians!: isapprox), through _move_floe!"""
+    cases.check_translate_rotate(mk, golden["floe_utils"])
+
+
+def test_boundary_rectangles(golden):
+    """boundaries.jl (test):5-83 -- the oracle's boundary polygons and the product's host-side boundary_rects"""
+    from subzero_jl_amd import floe
+    for key in ("directions", "boundaries"):
+        B = golden["boundaries"][key]
+        x0, xf, y0, yf = B["extent"]
+        w = mk(); w.set_domain([0, 0, 0, 0], x0, xf, y0, yf)
+        cases.check_boundary_polys(w.boundary_polys(), w.boundary_vals(), B)
+        rects, vals = floe.boundary_rects(x0, xf, y0, yf)
+        polys = [np.array([[r[0], r[2]], [r[0], r[3]], [r[1], r[3]], [r[1], r[2]], [r[0], r[2]]]) for r in rects]
+        cases.check_boundary_polys(polys, vals, B)
+
+
+def test_update_boundaries(golden):
+    """boundaries.jl (test):103-127"""
+    U = golden["boundaries"]["update"]
+    cases.check_update_boundaries(cases.run_update_boundaries(mk, U), U)
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_conservation(golden, k):
+    """test_conservation.jl:58-146: kinetic energy, linear and angular momentum change by less than 1 % over 5000 steps of
+    two / three colliding floes (this is the reference-held criterion that reaches the integrator body,
+    update_floe.jl:482-545)"""
+    C = golden["conservation"]; case = C["cases"][k]
+
+    def stepper(w, n, dt):
+        for t in range(n):
+            w.timestep_sim(t, dt, coupling_dt=10, coupling_on=False)
+    change = cases.run_conservation(mk, C, case, stepper)
+    assert np.all(np.isfinite(change)) and np.all(np.abs(change) < C["max_percent_change"]), (case["name"], change)
