@@ -544,3 +544,23 @@ def test_conservation(golden, k):
         res.append(cases.run_conservation(make, C, case, step))
     assert np.any(np.abs(res[1]) > 1.0)                      # contacts really happened (energy is not conserved by them)
     assert np.allclose(res[0], res[1], rtol=1e-6, atol=1e-9), (case["name"], res)
+
+
+def test_c_example_links_and_runs(tmp_path):
+    """examples/minimal.c: the C-ABI from plain C, linked against libsubzero_hip.so and RUN on the GPU (the CPU suite only
+    compiles it)."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "subzero.jl_amd")
+    exe = str(tmp_path / "minimal")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "minimal.c"),
+                           "-L" + libdir, "-lsubzero_hip", "-L/opt/rocm/lib", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+                           "-Wl,--allow-shlib-undefined", "-lm", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    lines = out.stdout.splitlines()
+    assert lines[0].startswith("pairs 1, contact rows 2"), lines
+    u = [float(x) for x in lines[1].split(":")[1].split("(")[0].split()]
+    assert u[0] < 0.1 and u[1] > -0.1                      # the two floes have pushed each other apart
+    assert "0 remove, 0 fuse" in lines[2]
+    assert abs(float(lines[3].split(":")[1].split()[0]) - 2e8) < 1e-3 * 2e8      # the grid output adds up to the ice area

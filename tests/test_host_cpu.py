@@ -92,3 +92,78 @@ def test_header_is_plain_c_and_the_c_example_compiles():
     r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), "-fsyntax-only",
                         os.path.join(root, "examples", "minimal.c")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def _julia_structs():
+    """the C-ABI mirrors of julia/SubzeroHIP.jl: {struct name: [(field, julia type)]}"""
+    src = open(os.path.join(ROOT, "julia", "SubzeroHIP.jl")).read()
+    out = {}
+    for m in re.finditer(r"^(?:mutable )?struct (Sz\w+)\n(.*?)^end", src, re.S | re.M):
+        out[m.group(1)] = re.findall(r"^\s+(\w+)::([\w{}]+)\s*$", m.group(2), re.M)
+    return out
+
+
+def test_julia_struct_mirrors_match_the_header(tmp_path):
+    """julia/SubzeroHIP.jl cannot be run here (no Julia in the image).  What CAN be checked without Julia: its three
+    struct mirrors have the same fields, in the same order, at the same offsets and of the same sizes as the C structs a
+    C compiler lays out from include/subzero_hip.h (Julia lays out isbits / pointer fields like C does)."""
+    import subprocess
+    js = _julia_structs()
+    cnames = {"SzParams": "sz_params", "SzFloeColumns": "sz_floe_columns", "SzStats": "sz_stats"}
+    assert set(js) == set(cnames)
+    size_of = {"Float64": 8, "Int64": 8, "Int32": 4}
+    hdr = open(os.path.join(ROOT, "include", "subzero_hip.h")).read()
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "subzero_hip.h"', 'int main(void) {']
+    expect = []
+    for jn, cn in cnames.items():
+        # every member the header declares must be mirrored: count the declarators of the C struct
+        body = {m.group(2): m.group(1) for m in re.finditer(r"typedef struct \{([^{}]*)\}\s*(\w+)\s*;", hdr)}[cn]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        cfields = [f.strip().lstrip("*") for decl in body.split(";") if decl.strip()
+                   for f in re.sub(r"^\s*(?:const\s+)?\w+\s+", "", decl.strip()).split(",")]
+        assert [f for f, _ in js[jn]] == cfields, (jn, cfields)
+        off = 0
+        for f, t in js[jn]:
+            sz = 8 if t.startswith("Ptr{") else size_of[t]
+            off = (off + sz - 1) // sz * sz
+            expect.append(f"{cn}.{f} {off} {sz}")
+            prog.append(f'  printf("{cn}.{f} %zu %zu\\n", offsetof({cn}, {f}), sizeof((({cn}*)0)->{f}));')
+            off += sz
+        expect.append(f"{cn} {(off + 7) // 8 * 8}")
+        prog.append(f'  printf("{cn} %zu\\n", sizeof({cn}));')
+    prog += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"; exe = tmp_path / "layout"
+    src.write_text("\n".join(prog))
+    subprocess.check_call(["gcc", "-std=c11", "-I" + os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = subprocess.check_output([str(exe)], text=True).split("\n")
+    assert [g for g in got if g] == expect
+    # ... and the ctypes mirrors of the Python binding agree with the same C layout
+    assert ctypes.sizeof(capi.SzParams) == int(expect[[e.split()[0] for e in expect].index("sz_params")].split()[1])
+    assert ctypes.sizeof(capi.SzFloeColumns) == 39 * 8 and ctypes.sizeof(capi.SzStats) == 27 * 8
+
+
+def test_julia_shim_binds_existing_symbols():
+    """every @ccall in julia/SubzeroHIP.jl names a function the header declares, with the declared number of arguments"""
+    src = open(os.path.join(ROOT, "julia", "SubzeroHIP.jl")).read()
+    hdr = open(os.path.join(ROOT, "include", "subzero_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    decl = {m.group(1): m.group(2) for m in re.finditer(r"\b(sz_\w+)\s*\(([^;{]*?)\)\s*;", hdr)}
+    calls = []
+    for m in re.finditer(r"@ccall lib\.(sz_\w+)\(", src):
+        depth, k, nargs, any_arg = 1, m.end(), 0, False
+        while depth:                                   # the balanced argument list: top-level commas separate arguments
+            ch = src[k]
+            depth += ch in "([{"; depth -= ch in ")]}"
+            if depth == 1 and ch == ",":
+                nargs += 1
+            any_arg = any_arg or (depth >= 1 and not ch.isspace() and ch != ")")
+            k += 1
+        calls.append((m.group(1), nargs + 1 if any_arg else 0))
+    assert len(calls) > 20
+    for name, na in calls:
+        assert name in decl, name
+        nd = 0 if decl[name].strip() in ("", "void") else decl[name].count(",") + 1
+        assert na == nd, (name, na, nd)
+    for need in ("sz_timestep_collisions", "sz_timestep_coupling", "sz_timestep_floe_properties", "sz_step", "sz_upload_interactions",
+                 "sz_download_fuse", "sz_simplify_check", "sz_get_boundary_rects"):
+        assert any(n == need for n, _ in calls), need
