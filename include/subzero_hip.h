@@ -255,6 +255,28 @@ int sz_tile_step(sz_ctx *ctx, const void *d_recv, int32_t nranks, int32_t cap, i
 int sz_sync(sz_ctx *ctx);
 int sz_set_stream(sz_ctx *ctx, void *hip_stream);
 
+/* ---- the same halo exchange INSIDE the library: RCCL over xGMI, one process per GPU, no Python / torch involved.
+   (The single-process reference has no counterpart: it keeps all floes in one address space, and its periodic ghost floes
+   -- collisions.jl:881-1047, folded back at :830-850 -- are the pattern this generalises to tiles.)
+     sz_comm_unique_id   on ONE rank: 128 bytes (an ncclUniqueId) that the host passes to every rank by its own channel
+                         (MPI broadcast, a file, ...)
+     sz_comm_init        on every rank, collectively: the communicator of this context (nranks == 1: no RCCL needed)
+     sz_tile_setup       after sz_upload_floes + sz_tile_enable: domain lengths and periodicity, the drift margin (metres a
+                         floe may move between two box gathers, on top of the interaction range) and the gather interval
+     sz_tile_run         nsteps x timestep_sim! of the tiled run, collectively, same arguments on every rank.  Per step:
+                         pack kernel, grouped ncclSend / ncclRecv with the neighbouring tiles only (real counts in the header
+                         records, slots per pair sized at the last gather), forcings of the owned floes beside the exchange,
+                         unpack + step.  Two-way coupling partial sums are all-reduced.  A floe that moves further than half
+                         the margin between two gathers is an error (halo-drift bit), never a silently missed contact.
+     sz_comm_allreduce   sum of n doubles in device memory over the ranks, in place (sz_eulerian_partial / sz_two_way_partial) */
+int sz_comm_unique_id(void *id128);
+int sz_comm_init(sz_ctx *ctx, int32_t nranks, int32_t rank, const void *id128);
+int sz_comm_destroy(sz_ctx *ctx);
+int sz_comm_allreduce(sz_ctx *ctx, void *d_buf, int64_t n);
+int sz_tile_setup(sz_ctx *ctx, double Lx, double Ly, int32_t periodic_x, int32_t periodic_y, double drift_margin,
+                  int32_t rebox_every);
+int sz_tile_run(sz_ctx *ctx, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupling_dt, int32_t flags);
+
 /* ---- output path on the resident state
    sz_eulerian_data: calc_eulerian_data! (output.jl:793-914), the GridOutputWriter averages, over the rows the
    context holds -- write_data! runs after add_ghosts! (simulation.jl:102-105), so callers that step with sz_step

@@ -2,6 +2,7 @@
 // declared in include/subzero_hip.h.  Host code here is plumbing; the arithmetic is in
 // sz_kernels.hpp / sz_geom.hpp.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -95,6 +96,14 @@ struct sz_ctx {
   // current (kept so by the integrator / halo unpack; any process-mode call or upload makes it stale: it is then seeded again),
   // gl_est = how long it is (host estimate at upload, device count after every batch): long lists take the two-launch path
   int gl_cur = 0; bool gl_valid = false; int gl_est = 0; bool no_ghost_list = false; int gl_max = 2048;
+  // tiled runs with the exchange inside the library (sz_comm_init / sz_tile_setup / sz_tile_run): the RCCL communicator, a second
+  // stream for the sends / receives (the forcings of the owned floes run beside them), the exchange buffers and their layout
+  void* comm = nullptr; int comm_n = 0, comm_rank = 0;
+  hipStream_t comm_stream = nullptr; hipEvent_t ev_packed = nullptr, ev_recv = nullptr;
+  Pool comm_allocs; double *d_send = nullptr, *d_recv = nullptr, *d_ref = nullptr, *d_gather = nullptr; int* d_dcap = nullptr;
+  int halo_cap = 0; std::vector<int> cap_send, cap_recv;      // slots per peer region (stride) and what is really sent to / received from each peer
+  double tile_Lx = 0, tile_Ly = 0, tile_margin = 0; int tile_per_x = 0, tile_per_y = 0, tile_rebox_every = 50, tile_since_box = -1;
+  Pool tw_part_allocs; double* d_tw_partial = nullptr;
   int tile_forcing_tstep = -1;      // timestep whose forcings sz_tile_forcing has already enqueued
   bool tile_dirty = false;      // ghosts / halo floes of the last sz_tile_step still appended
   int dbg = 0;   // SZ_DEBUG bits: timing experiments only (1 skip contact rows, 2 skip direction check, 4 skip clip)
@@ -202,10 +211,10 @@ int sync_and_check(sz_ctx* c, int* cnt_out = nullptr) {
   c->hostM = h[C_M]; c->hostN = h[C_N];
   if (cnt_out) memcpy(cnt_out, h, sizeof(h));
   if (h[C_ERR]) {
-    char buf[320];
+    char buf[360];
     snprintf(buf, sizeof(buf),
              "device capacity/consistency error bits 0x%x (ring=1 crossings=2 regions=4 rows=8 trace=16 neighbours=32 "
-             "pairs=64 elems=128 inter=256 floes=512 verts=1024 cells=2048 ghosts/parent=4096 scan=8192)", h[C_ERR]);
+             "pairs=64 elems=128 inter=256 floes=512 verts=1024 cells=2048 ghosts/parent=4096 scan=8192 halo-drift=16384)", h[C_ERR]);
     c->err = buf;
     int z = 0;
     (void)hipMemcpy(c->S.cnt + C_ERR, &z, sizeof(int), hipMemcpyHostToDevice);
@@ -627,7 +636,8 @@ void sz_destroy(sz_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   free_pool(c->allocs); free_pool(c->inter_allocs); free_pool(c->static_allocs); free_pool(c->field_allocs); free_pool(c->tw_allocs); free_pool(c->tw_field_allocs);
-  free_pool(c->mixed_pt_allocs); free_pool(c->mixed_node_allocs);
+  free_pool(c->mixed_pt_allocs); free_pool(c->mixed_node_allocs); free_pool(c->comm_allocs); free_pool(c->tw_part_allocs);
+  (void)sz_comm_destroy(c);
   for (auto& e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   (void)hipFree(c->d_stats); (void)hipFree(c->S.acc);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -1309,7 +1319,7 @@ int sz_halo_pack(sz_ctx* c, int32_t nranks, int32_t me, double Lx, double Ly, in
   State& S = c->S;
   int* dcnt = S.cnt + C_COUNT;                  // 64 ints reserved behind the counter block
   hipLaunchKernelGGL(sz_k_halo_pack, dim3(1), dim3(1024), 0, c->stream, S, nranks, me, S.bounds + 16, Lx, Ly,
-                     per_x, per_y, (double*)d_send, cap, dcnt);
+                     per_x, per_y, (double*)d_send, cap, dcnt, (const int*)nullptr, (const double*)nullptr, 0.0);
   return SZ_OK;
 }
 
@@ -1502,6 +1512,216 @@ int sz_tile_forcing(sz_ctx* c, int32_t tstep, int32_t coupling_dt, int32_t flags
   int rc = tile_forcing(c); if (rc) return rc;
   c->tile_forcing_tstep = tstep;
   return SZ_OK;
+}
+
+// ---------------------------------------------------------------- the halo exchange inside the library (RCCL over xGMI)
+// "library owns device buffers, streams, RCCL communicators inside the opaque sz_ctx".  A host that is not
+// Python (the reference's is Julia: one process per GPU, e.g. under MPI.jl) drives a tiled run with
+//     sz_comm_unique_id (rank 0)  ->  the 128 bytes to every rank by any host channel  ->  sz_comm_init
+//     sz_upload_floes (the owned floes) / sz_tile_enable  ->  sz_tile_setup  ->  sz_tile_run(nsteps) on every rank.
+// Per step: pack kernel -> grouped ncclSend / ncclRecv with the NEIGHBOUR tiles only (the all-to-all-v of the halo records;
+// a peer's region carries its real count in the header record and is sized per pair from the counts at the last box gather)
+// on a second stream, beside the forcings of the owned floes -> unpack + the ordinary step.  The boxes are gathered again
+// (ncclAllGather) every `rebox_every` steps; a floe that out-runs the drift margin in between raises ERR_HALO_DRIFT.
+// RCCL is bound at run time (dlopen: the library has no link-time dependency on it, and a process that already holds an
+// RCCL -- torch's -- shares that copy).
+namespace {
+struct UId { char b[128]; };
+struct Rccl {
+  void* h = nullptr;
+  int (*GetUniqueId)(UId*) = nullptr;
+  int (*CommInitRank)(void**, int, UId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+constexpr int NCCL_INT32 = 2, NCCL_FLOAT64 = 8, NCCL_SUM = 0;
+bool rccl_load(std::string& err) {
+  if (g_rccl.h) return true;
+  const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+  for (const char* n : names) if ((g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!g_rccl.h) { err = std::string("RCCL not found: ") + dlerror(); return false; }
+#define RSYM(field, name) g_rccl.field = (decltype(g_rccl.field))dlsym(g_rccl.h, name); if (!g_rccl.field) { err = std::string("RCCL symbol missing: ") + name; g_rccl.h = nullptr; return false; }
+  RSYM(GetUniqueId, "ncclGetUniqueId") RSYM(CommInitRank, "ncclCommInitRank") RSYM(CommDestroy, "ncclCommDestroy")
+  RSYM(Send, "ncclSend") RSYM(Recv, "ncclRecv") RSYM(AllGather, "ncclAllGather") RSYM(AllReduce, "ncclAllReduce")
+  RSYM(GroupStart, "ncclGroupStart") RSYM(GroupEnd, "ncclGroupEnd") RSYM(GetErrorString, "ncclGetErrorString")
+#undef RSYM
+  return true;
+}
+#define NCCLCHK(ctx, call)                                                                             \
+  do {                                                                                                 \
+    int r_ = (call);                                                                                   \
+    if (r_ != 0) { (ctx)->err = std::string(#call) + ": " + g_rccl.GetErrorString(r_); return SZ_E_HIP; } \
+  } while (0)
+
+// do the expanded box of rank d and the (margin-expanded) owned box of rank s meet, periodic images included?
+bool tiles_adjacent(const double* owned_s, const double* expanded_d, double margin, double Lx, double Ly, int per_x, int per_y) {
+  for (int kx = (per_x ? -1 : 0); kx <= (per_x ? 1 : 0); kx++)
+    for (int ky = (per_y ? -1 : 0); ky <= (per_y ? 1 : 0); ky++) {
+      const double x0 = owned_s[0] - margin + kx * Lx, x1 = owned_s[1] + margin + kx * Lx;
+      const double y0 = owned_s[2] - margin + ky * Ly, y1 = owned_s[3] + margin + ky * Ly;
+      if (!(x1 < expanded_d[0] || expanded_d[1] < x0 || y1 < expanded_d[2] || expanded_d[3] < y0)) return true;
+    }
+  return false;
+}
+
+// collective: owned boxes of all ranks -> expanded boxes on the device, neighbour relation, per-pair slot counts, buffers,
+// reference positions of the drift check.  Synchronises (it runs once per rebox_every steps).
+int tile_rebox(sz_ctx* c) {
+  State& S = c->S;
+  const int n = c->comm_n, me = c->comm_rank;
+  int rc = sync_and_check(c); if (rc) return rc;
+  hipLaunchKernelGGL(sz_k_owned_box, dim3(1), dim3(1024), 0, c->stream, S, c->d_gather);
+  std::vector<double> all((size_t)5 * n);
+  if (n > 1) NCCLCHK(c, g_rccl.AllGather(c->d_gather, c->d_gather + 8, 5, NCCL_FLOAT64, c->comm, c->stream));
+  else HIPCHK(c, hipMemcpyAsync(c->d_gather + 8, c->d_gather, 5 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(all.data(), c->d_gather + 8, all.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double rmax = 0.0;
+  for (int r = 0; r < n; r++) rmax = std::max(rmax, all[5 * r + 4]);
+  const double reach = 2.0 * rmax + c->tile_margin;
+  std::vector<double> boxes((size_t)4 * n);
+  for (int r = 0; r < n; r++) { boxes[4 * r] = all[5 * r] - reach; boxes[4 * r + 1] = all[5 * r + 1] + reach; boxes[4 * r + 2] = all[5 * r + 2] - reach; boxes[4 * r + 3] = all[5 * r + 3] + reach; }
+  HIPCHK(c, hipMemcpyAsync(S.bounds + 16, boxes.data(), boxes.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  // counting pass, then the count matrix of all ranks (row s: what s sends to every d)
+  int* dcnt = S.cnt + C_COUNT;
+  hipLaunchKernelGGL(sz_k_halo_pack, dim3(1), dim3(1024), 0, c->stream, S, n, me, S.bounds + 16, c->tile_Lx, c->tile_Ly, c->tile_per_x,
+                     c->tile_per_y, (double*)nullptr, 1, dcnt, (const int*)nullptr, (const double*)nullptr, 0.0);
+  int* d_mat = (int*)(c->d_gather + 8 + 5 * 64);
+  std::vector<int> mat((size_t)n * n);
+  if (n > 1) NCCLCHK(c, g_rccl.AllGather(dcnt, d_mat, (size_t)n, NCCL_INT32, c->comm, c->stream));
+  else HIPCHK(c, hipMemcpyAsync(d_mat, dcnt, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(mat.data(), d_mat, mat.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // slots per ordered pair: neighbours get 1.5 x the present count + 32, the others nothing (every rank computes the same table)
+  c->cap_send.assign(n, 0); c->cap_recv.assign(n, 0);
+  int cap = 32;
+  for (int s = 0; s < n; s++)
+    for (int d = 0; d < n; d++) {
+      if (s == d) continue;
+      const bool adj = tiles_adjacent(&all[5 * s], &boxes[4 * d], c->tile_margin, c->tile_Lx, c->tile_Ly, c->tile_per_x, c->tile_per_y);
+      const int k = adj || mat[(size_t)s * n + d] > 0 ? mat[(size_t)s * n + d] * 3 / 2 + 32 : 0;
+      if (s == me) c->cap_send[d] = k;
+      if (d == me) c->cap_recv[s] = k;
+      cap = std::max(cap, k);
+    }
+  if (cap > c->halo_cap || !c->d_send) {
+    free_pool(c->comm_allocs);
+    c->halo_cap = cap;
+    const size_t nd = (size_t)n * (cap + 1) * HALO_REC;
+    if ((rc = dalloc(c, &c->d_send, nd, c->comm_allocs)) || (rc = dalloc(c, &c->d_recv, nd, c->comm_allocs)) ||
+        (rc = dalloc(c, &c->d_ref, (size_t)2 * S.capM, c->comm_allocs)) || (rc = dalloc(c, &c->d_dcap, 64, c->comm_allocs))) return rc;
+  }
+  // regions of ranks that send nothing keep a zero count in their header record
+  HIPCHK(c, hipMemsetAsync(c->d_recv, 0, (size_t)n * (c->halo_cap + 1) * HALO_REC * sizeof(double), c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_dcap, c->cap_send.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_ref, S.cx, (size_t)c->hostN * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_ref + S.capM, S.cy, (size_t)c->hostN * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->tile_since_box = 0;
+  return SZ_OK;
+}
+}  // namespace
+
+int sz_comm_unique_id(void* id128) {
+  std::string err;
+  if (!id128 || !rccl_load(err)) return SZ_E_STATE;
+  return g_rccl.GetUniqueId((UId*)id128) == 0 ? SZ_OK : SZ_E_HIP;
+}
+int sz_comm_init(sz_ctx* c, int32_t nranks, int32_t rank, const void* id128) {
+  if (!c || nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks || (nranks > 1 && !id128)) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  (void)sz_comm_destroy(c);
+  if (nranks > 1) {
+    if (!rccl_load(c->err)) return SZ_E_STATE;
+    UId id; memcpy(&id, id128, sizeof(id));
+    NCCLCHK(c, g_rccl.CommInitRank(&c->comm, nranks, id, rank));
+  }
+  c->comm_n = nranks; c->comm_rank = rank;
+  HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_recv, hipEventDisableTiming));
+  return SZ_OK;
+}
+int sz_comm_destroy(sz_ctx* c) {
+  if (!c) return SZ_E_ARG;
+  if (c->comm) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+  if (c->comm_stream) { (void)hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
+  if (c->ev_packed) { (void)hipEventDestroy(c->ev_packed); c->ev_packed = nullptr; }
+  if (c->ev_recv) { (void)hipEventDestroy(c->ev_recv); c->ev_recv = nullptr; }
+  c->comm_n = 0; c->d_send = c->d_recv = c->d_ref = nullptr; c->d_dcap = nullptr; c->halo_cap = 0; c->tile_since_box = -1;
+  if (c->d_gather) { (void)hipFree(c->d_gather); c->d_gather = nullptr; }
+  free_pool(c->comm_allocs);
+  return SZ_OK;
+}
+// sum of n doubles in device memory over all ranks, in place, on the context's stream (per-cell partial sums of the
+// two-way coupling and of the grid output)
+int sz_comm_allreduce(sz_ctx* c, void* d_buf, int64_t n) {
+  if (!c || !d_buf || n < 0 || c->comm_n < 1) return SZ_E_STATE;
+  (void)hipSetDevice(c->device);
+  if (c->comm_n > 1) NCCLCHK(c, g_rccl.AllReduce(d_buf, d_buf, (size_t)n, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream));
+  return SZ_OK;
+}
+int sz_tile_setup(sz_ctx* c, double Lx, double Ly, int32_t per_x, int32_t per_y, double drift_margin, int32_t rebox_every) {
+  if (!c || !c->have_floes || !c->S.tiled || c->comm_n < 1 || !(drift_margin > 0) || rebox_every < 1) {
+    if (c) c->err = "sz_tile_setup needs sz_upload_floes, sz_tile_enable and sz_comm_init first, a positive drift margin and rebox interval";
+    return SZ_E_STATE;
+  }
+  (void)hipSetDevice(c->device);
+  c->tile_Lx = Lx; c->tile_Ly = Ly; c->tile_per_x = per_x; c->tile_per_y = per_y; c->tile_margin = drift_margin; c->tile_rebox_every = rebox_every;
+  c->tile_since_box = -1; c->halo_cap = 0; c->d_send = nullptr;
+  free_pool(c->comm_allocs);
+  if (!c->d_gather) {          // own box | all boxes | count matrix (ints): lives as long as the communicator
+    HIPCHK(c, hipMalloc((void**)&c->d_gather, (8 + 5 * 64 + 64 * 64 / 2 + 64) * sizeof(double)));
+  }
+  return SZ_OK;
+}
+// nsteps x timestep_sim! of a tiled run, collectively on every rank (same arguments everywhere)
+int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupling_dt, int32_t flags) {
+  if (!c || !c->have_floes || c->comm_n < 1 || c->tile_margin <= 0) { if (c) c->err = "sz_tile_run needs sz_tile_setup"; return SZ_E_STATE; }
+  (void)hipSetDevice(c->device);
+  State& S = c->S;
+  const int n = c->comm_n, me = c->comm_rank;
+  for (int s = 0; s < nsteps; s++) {
+    const int tstep = tstep0 + s;
+    if (c->tile_since_box < 0 || c->tile_since_box >= c->tile_rebox_every) { int rc = tile_rebox(c); if (rc) return rc; }
+    c->tile_since_box++;
+    const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
+    const size_t stride = (size_t)(c->halo_cap + 1) * HALO_REC;
+    int* dcnt = S.cnt + C_COUNT;
+    hipLaunchKernelGGL(sz_k_halo_pack, dim3(1), dim3(1024), 0, c->stream, S, n, me, S.bounds + 16, c->tile_Lx, c->tile_Ly, c->tile_per_x,
+                       c->tile_per_y, c->d_send, c->halo_cap, dcnt, (const int*)c->d_dcap, (const double*)c->d_ref, c->tile_margin);
+    if (n > 1) {
+      HIPCHK(c, hipEventRecord(c->ev_packed, c->stream));
+      HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
+      NCCLCHK(c, g_rccl.GroupStart());
+      for (int d = 0; d < n; d++) {
+        if (d == me) continue;
+        if (c->cap_send[d] > 0) NCCLCHK(c, g_rccl.Send(c->d_send + d * stride, (size_t)(c->cap_send[d] + 1) * HALO_REC, NCCL_FLOAT64, d, c->comm, c->comm_stream));
+        if (c->cap_recv[d] > 0) NCCLCHK(c, g_rccl.Recv(c->d_recv + d * stride, (size_t)(c->cap_recv[d] + 1) * HALO_REC, NCCL_FLOAT64, d, c->comm, c->comm_stream));
+      }
+      NCCLCHK(c, g_rccl.GroupEnd());
+      HIPCHK(c, hipEventRecord(c->ev_recv, c->comm_stream));
+    }
+    // the forcings of the owned floes need nothing from the halo: they run beside the exchange
+    if (coupling) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return rc; }
+    if (n > 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_recv, 0));
+    int rc = sz_tile_step(c, c->d_recv, n, c->halo_cap, tstep, dt, coupling_dt, flags);
+    if (rc) return rc;
+    if (c->two_way && coupling) {       // ice-on-ocean stress: per-cell partial sums, summed over the ranks, finished on every rank
+      const size_t nc = 3 * c->tw_ncell;
+      if (!c->d_tw_partial) { int r2 = dalloc(c, &c->d_tw_partial, nc, c->tw_part_allocs); if (r2) return r2; }
+      if ((rc = sz_two_way_partial(c, c->d_tw_partial)) || (rc = sz_comm_allreduce(c, c->d_tw_partial, (int64_t)nc)) ||
+          (rc = sz_two_way_finish(c, c->d_tw_partial, dt))) return rc;
+    }
+  }
+  return sz_sync(c);
 }
 
 // counts of the last sz_halo_pack per destination rank (synchronises); used to size the exchange buffers

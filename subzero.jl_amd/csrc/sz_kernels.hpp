@@ -1880,14 +1880,27 @@ constexpr int HALO_REC = 12 + 2 * HALO_RING;   // doubles
 // (already expanded) box is written to that rank's region of the send buffer.  One block: the
 // per-destination counters live in LDS and the header records are written by the same launch.
 // With send == nullptr only the counts are produced (sizing pass).
+// dcap (may be null): slots the region of every destination really has (<= cap, the stride of the regions; 0: not a
+// neighbour -- a floe that should go there all the same means the boxes are out of date).  ref (may be null): the owned
+// centroids when the boxes were gathered, 2 x capM doubles: the halo selection is only valid while no floe has moved
+// further than half the drift margin built into the boxes -- beyond that a neighbour across a tile edge could be missed
+// silently, so it is an error (ERR_HALO_DRIFT), raised one step early enough.
+constexpr int ERR_HALO_DRIFT = 16384;
 __global__ void __launch_bounds__(1024) sz_k_halo_pack(State S, int nranks, int me, const double* boxes, double Lx, double Ly,
-                                                       int per_x, int per_y, double* send, int cap, int* counts) {
+                                                       int per_x, int per_y, double* send, int cap, int* counts,
+                                                       const int* dcap, const double* ref, double margin) {
   __shared__ int lc[64];
   if (threadIdx.x < 64) lc[threadIdx.x] = 0;
   __syncthreads();
   int n = S.cnt[C_NOWN];
   for (int q = threadIdx.x; q < n; q += blockDim.x) {
     double cx = S.cx[q], cy = S.cy[q];
+    if (ref) {
+      double ddx = fabs(cx - ref[q]), ddy = fabs(cy - ref[S.capM + q]);
+      if (per_x && ddx > 0.5 * Lx) ddx = fabs(ddx - Lx);          // a parent the ghost pass wrapped around the domain
+      if (per_y && ddy > 0.5 * Ly) ddy = fabs(ddy - Ly);
+      if (2.0 * fmax(ddx, ddy) > margin) atomicOr(&S.cnt[C_ERR], ERR_HALO_DRIFT);
+    }
     int o = S.voff[q], nv = S.voff[q + 1] - o;
     for (int d = 0; d < nranks; d++) {
       if (d == me) continue;
@@ -1901,7 +1914,7 @@ __global__ void __launch_bounds__(1024) sz_k_halo_pack(State S, int nranks, int 
       if (!hit) continue;
       int slot = atomicAdd(&lc[d], 1);
       if (send == nullptr) continue;                 // counting pass (sizing of the exchange buffers)
-      if (slot >= cap || nv > HALO_RING) { atomicOr(&S.cnt[C_ERR], nv > HALO_RING ? ERR_CAP_RING : ERR_CAP_FLOES); continue; }
+      if (slot >= (dcap ? dcap[d] : cap) || nv > HALO_RING) { atomicOr(&S.cnt[C_ERR], nv > HALO_RING ? ERR_CAP_RING : ERR_CAP_FLOES); continue; }
       double* r = send + ((size_t)d * (cap + 1) + 1 + slot) * HALO_REC;
       r[0] = (double)S.okey[q]; r[1] = (double)S.status[q]; r[2] = (double)nv; r[3] = cx; r[4] = cy; r[5] = S.rmax[q];
       r[6] = S.area[q]; r[7] = S.height[q]; r[8] = S.u[q]; r[9] = S.v[q]; r[10] = S.xi[q]; r[11] = (double)S.id[q];
@@ -1912,7 +1925,8 @@ __global__ void __launch_bounds__(1024) sz_k_halo_pack(State S, int nranks, int 
   if ((int)threadIdx.x < nranks) {
     int d = threadIdx.x;
     counts[d] = lc[d];
-    if (send) send[(size_t)d * (cap + 1) * HALO_REC] = (double)(lc[d] < cap ? lc[d] : cap);
+    const int room = dcap ? dcap[d] : cap;
+    if (send) send[(size_t)d * (cap + 1) * HALO_REC] = (double)(lc[d] < room ? lc[d] : room);
   }
 }
 // ---- fixed-layout exchange buffers: region of peer r = 1 header record (count in [0]) followed by

@@ -80,10 +80,15 @@ class TiledWorld:
     """One rank of a tiled run.  `dist` is torch.distributed (initialised) or None for world == 1."""
 
     def __init__(self, cfg, rank, world, device, dist, drift_margin=2000.0, rebox_every=50, host_staging=False,
-                 always_exchange=False):
+                 always_exchange=False, backend="torch"):
+        """backend: "library" -- the exchange runs inside libsubzero_hip.so (sz_comm_init / sz_tile_setup / sz_tile_run: RCCL
+        bound by the library, grouped send / receive with the neighbouring tiles only; `dist` is then only used to hand the
+        communicator id to the ranks); "torch" -- one torch.distributed all_to_all_single per step on buffers the library
+        packs and unpacks (and, with host_staging, through the host: the gloo tests)."""
         import torch
         self.torch = torch
         self.cfg, self.rank, self.nranks, self.dist = cfg, rank, world, dist
+        self.backend = backend
         self.host_staging = host_staging          # gloo: exchange through CPU tensors
         self.always_exchange = always_exchange    # run the collectives even with one rank (tests)
         self.L = cfg["L"]
@@ -110,19 +115,60 @@ class TiledWorld:
         self.dev = torch.device("cuda", device)
         self.cap = 0                                          # record slots per peer, sized from a counting pass
         self.send = self.recv = None
-        if not host_staging:
+        if backend == "library":
+            uid = (C.c_char * 128)()
+            if world > 1:
+                if rank == 0:
+                    w._chk(w.L.sz_comm_unique_id(C.cast(uid, C.c_void_p)))
+                box = [bytes(uid)]
+                dist.broadcast_object_list(box, src=0)          # any host channel does: the id is 128 opaque bytes
+                uid = (C.c_char * 128).from_buffer_copy(box[0])
+            w._chk(w.L.sz_comm_init(w.h, world, rank, C.cast(uid, C.c_void_p)))
+            w._chk(w.L.sz_tile_setup(w.h, self.L, self.L, int(self.per_x), int(self.per_y), float(drift_margin), int(rebox_every)))
+        elif not host_staging:
             # kernels and RCCL collectives are ordered by ONE stream: no host sync inside a step
             w._chk(w.L.sz_set_stream(w.h, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
         self.margin, self.rebox_every = drift_margin, rebox_every
+        self.rebox_every_max = rebox_every
+        self._ref = None                                      # owned centroids at the last box gather (drift check)
+        self.repartition_every = 500                          # steps between ownership checks (run())
+        self.repartition_fraction = 0.1                       # ... re-tile when this share of the floes has left its tile
+        self._since_check = 0
         self.boxes = None
         self.steps_since_box = 0
         self.tw_buf = None                                    # per-cell partial sums of the two-way coupling
 
     # ---- collectives
+    def _drift_since_last_gather(self):
+        """largest centroid displacement of an owned floe since the last box gather, over all ranks (collective).  The
+        halo selection is only valid while 2 x that stays under the drift margin built into the boxes: beyond it a
+        contact across a tile edge could be missed silently, so it is an error; the gather interval adapts to the
+        measured speed (40 % of the margin)."""
+        w = self.world
+        w._host_stale = True
+        n = len(self.gidx)
+        cx, cy = w.get("cx")[:n].copy(), w.get("cy")[:n].copy()
+        d = 0.0
+        if self._ref is not None and len(self._ref[0]) == n and n:
+            dx, dy = np.abs(cx - self._ref[0]), np.abs(cy - self._ref[1])
+            if self.per_x: dx = np.minimum(dx, np.abs(dx - self.L))       # a parent the ghost pass wrapped around
+            if self.per_y: dy = np.minimum(dy, np.abs(dy - self.L))
+            d = float(max(dx.max(), dy.max()))
+        t = self.torch.tensor([d], dtype=self.torch.float64, device="cpu" if self.host_staging else self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        d = float(t.item())
+        if 2.0 * d > self.margin:
+            raise capi.SzError(f"halo drift: a floe moved {d:.1f} m in {self.steps_since_box} steps, the margin is {self.margin:.1f} m "
+                               f"(gather the boxes more often or widen the margin)")
+        if d > 0 and self.steps_since_box > 0:
+            self.rebox_every = int(max(1, min(self.rebox_every_max, 0.4 * self.margin / (d / self.steps_since_box))))
+        self._ref = (cx, cy)
+
     def _allgather_boxes(self):
         w = self.world
         b5 = np.zeros(5)
         w._chk(w.L.sz_sync(w.h))
+        self._drift_since_last_gather()
         w._chk(w.L.sz_owned_box(w.h, capi.ptr(b5)))
         t = self.torch.tensor(b5, dtype=self.torch.float64, device="cpu" if self.host_staging else self.dev)
         out = [self.torch.zeros_like(t) for _ in range(self.nranks)]
@@ -156,6 +202,8 @@ class TiledWorld:
         self.steps_since_box += 1
         w._chk(w.L.sz_halo_pack(w.h, self.nranks, self.rank, self.L, self.L, int(self.per_x), int(self.per_y),
                                 C.c_void_p(self.send.data_ptr()), self.cap))
+        # (this path sizes every region alike and has no per-step drift check: after a box gather the floes may move
+        #  margin / 2 -- _allgather_boxes measures what they really moved and shortens the interval when needed)
         if self.host_staging:                       # gloo: through the host
             if between:
                 between()
@@ -298,13 +346,45 @@ class TiledWorld:
         w._push()
         g = np.ascontiguousarray(self.gidx, np.int64)
         w._chk(w.L.sz_tile_enable(w.h, capi.ptr(g, capi._lp), self._max_ring, self._max_rmax))
+        if self.backend == "library":
+            w._chk(w.L.sz_tile_setup(w.h, self.L, self.L, int(self.per_x), int(self.per_y), float(self.margin), int(self.rebox_every_max)))
         self.boxes = None                      # owned boxes and halo capacity are re-established at the next exchange
+        self._ref = None
         return len(mv)
 
+    def maybe_repartition(self):
+        """Ownership is static between calls of repartition(); floes drift.  Collective: re-tile when more than
+        `repartition_fraction` of all floes has left the tile that owns it (cheap test: the owned centroids against the
+        tile rule).  Returns the number of floes this rank gave away (0: nothing done)."""
+        self.sync(); w = self.world; w._host_stale = True
+        n = len(self.gidx)
+        cx, cy = w.get("cx")[:n].copy(), w.get("cy")[:n].copy()
+        if self.per_x: cx %= self.L
+        if self.per_y: cy %= self.L
+        away = int(np.count_nonzero(assign_tiles(cx, cy, self.L, self.nranks) != self.rank)) if n else 0
+        t = self.torch.tensor([away, n], dtype=self.torch.int64, device="cpu" if self.host_staging else self.dev)
+        self.dist.all_reduce(t)
+        if int(t[0]) <= self.repartition_fraction * max(int(t[1]), 1):
+            return 0
+        return self.repartition()
+
     def run(self, nsteps, tstep0, dt, coupling_dt=10, collisions_on=True, coupling_on=True):
-        for s in range(nsteps):
-            self.step(tstep0 + s, dt, coupling_dt, collisions_on, coupling_on)
-        self.sync()
+        done = 0
+        while done < nsteps:
+            k = min(nsteps - done, self.repartition_every - self._since_check) if self.nranks > 1 else nsteps - done
+            if self.backend == "library":
+                w = self.world
+                flags = (capi.COLLISIONS_ON if collisions_on else 0) | (capi.COUPLING_ON if coupling_on else 0)
+                w._chk(w.L.sz_tile_run(w.h, int(k), int(tstep0 + done), int(dt), int(coupling_dt), flags))
+                w._host_stale = True
+            else:
+                for s in range(k):
+                    self.step(tstep0 + done + s, dt, coupling_dt, collisions_on, coupling_on)
+                self.sync()
+            done += k; self._since_check += k
+            if self.nranks > 1 and self._since_check >= self.repartition_every:
+                self._since_check = 0
+                self.maybe_repartition()
 
     def sync(self):
         self.world._chk(self.world.L.sz_sync(self.world.h))

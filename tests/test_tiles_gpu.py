@@ -167,3 +167,34 @@ def test_two_way_coupling_across_tiles():
         for f, v in out.items():
             assert np.max(np.abs(v - hw.get(f)[gidx])) <= 1e-12 * np.max(np.abs(hw.get(f))), (rank, f)
     assert np.count_nonzero(ref[2]) > 100
+
+
+def test_library_exchange_path_one_rank():
+    """The exchange inside the library (sz_comm_init / sz_tile_setup / sz_tile_run: box gather, per-pair slots, pack,
+    unpack, drift reference) with one rank -- all of it but the RCCL calls themselves, which need one GPU per rank --
+    against the single-context run over more steps than one gather interval: bit-equal columns."""
+    import subzero_jl_amd
+    from subzero_jl_amd import fields, tiles
+    cfg = fields.make_config(n_floes=800, seed=51)
+    tw = tiles.TiledWorld(cfg, 0, 1, 0, None, backend="library", rebox_every=20)
+    tw.run(45, 0, cfg["dt"], coupling_dt=1)
+    hw = fields.build_world(subzero_jl_amd.World(0), cfg)
+    hw.run(45, 0, cfg["dt"], coupling_dt=1, stop_on_tags=False)
+    for f in FIELDS:
+        assert np.array_equal(tw.owned(f), hw.get(f)), f
+
+
+def test_halo_drift_is_an_error_not_a_missed_contact():
+    """floes that out-run the drift margin between two box gathers: the pack kernel raises the halo-drift bit one step
+    before a neighbour across a tile edge could be missed"""
+    from subzero_jl_amd import fields, tiles
+    from subzero_jl_amd.capi import SzError
+    cfg = fields.make_config(n_floes=400, seed=52)
+    cfg["u"] = np.abs(cfg["u"]) * 40.0 + 4.0                     # 4 .. 8 m/s: 80 .. 160 m per step
+    tw = tiles.TiledWorld(cfg, 0, 1, 0, None, backend="library", drift_margin=1500.0, rebox_every=50)
+    tw.run(4, 0, cfg["dt"], coupling_dt=1)                       # 4 steps: at most 640 m, 2 x 640 < 1500
+    with pytest.raises(SzError, match="halo-drift"):
+        tw.run(30, 4, cfg["dt"], coupling_dt=1)
+    # a gather interval that fits the speed is fine
+    tw2 = tiles.TiledWorld(cfg, 0, 1, 0, None, backend="library", drift_margin=1500.0, rebox_every=3)
+    tw2.run(30, 0, cfg["dt"], coupling_dt=1)
