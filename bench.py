@@ -238,7 +238,11 @@ def main():
         runner = lambda n, t0: hw.run(n, t0, cfg["dt"], coupling_dt=coupling_dt, stop_on_tags=False)
     else:
         from subzero_jl_amd import tiles
-        tw = tiles.TiledWorld(cfg, rank, world, local, dist, always_exchange=args.force_tiled)
+        # the halo exchange runs inside the library (RCCL bound by libsubzero_hip.so: grouped send / receive with the
+        # neighbouring tiles); SZ_TILES_BACKEND=torch: one torch.distributed all_to_all_single per step instead
+        backend = os.environ.get("SZ_TILES_BACKEND", "library")
+        tw = tiles.TiledWorld(cfg, rank, world, local, dist, always_exchange=args.force_tiled, backend=backend)
+        tw.repartition_every = 10 ** 9        # floes drift metres per step against tiles of hundreds of km: no re-tiling inside a bench run
         hw = tw.world
         runner = lambda n, t0: tw.run(n, t0, cfg["dt"], coupling_dt=coupling_dt)
 
@@ -277,6 +281,24 @@ def main():
     torch.cuda.synchronize()
     kt_all = hw.kernel_times()
     hw.profile(False)
+    # strong scaling: the same workload on ONE GPU (rank 0, a second context beside its tile), so that the line carries its
+    # own reference point; the other ranks wait at the barrier
+    one_gpu = None
+    if tiled and world > 1:
+        if rank == 0:
+            try:
+                ref = fields.build_world(subzero_jl_amd.World(local), cfg)
+                ref.set_precision(args.precision)
+                ref.run(10, 0, cfg["dt"], coupling_dt=coupling_dt, stop_on_tags=False)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                k1 = max(10, min(args.steps, 50))
+                ref.run(k1, 10, cfg["dt"], coupling_dt=coupling_dt, stop_on_tags=False)
+                torch.cuda.synchronize()
+                one_gpu = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / k1, "steps": k1, "note": "same field, one context on rank 0's GPU, steps 10.. of the run"}
+                del ref
+            except Exception as e:      # noqa: BLE001
+                one_gpu = {"error": str(e)[:200]}
+        barrier()
 
     if rank == 0:
         n_ms, n_launch = kt["narrow"]
@@ -320,6 +342,12 @@ def main():
             "tags_at_end_of_timed_window": {"n_status_remove": st["n_status_remove"], "n_status_fuse": st["n_status_fuse"],
                                             "note": "floes the reference's simplify_floes! would have acted on during the run (0 = the timed steps are the reference's trajectory)"},
         }
+        if one_gpu is not None:
+            out["one_gpu_same_workload"] = one_gpu
+            if "ms_per_step" in one_gpu:
+                out["speedup_vs_one_gpu_same_workload"] = one_gpu["ms_per_step"] / (1e3 * el / args.steps)
+        if tiled:
+            out["config"]["halo_exchange"] = backend if world > 1 or args.force_tiled else None
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

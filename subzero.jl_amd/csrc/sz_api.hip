@@ -613,6 +613,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_TW_GENERAL_CLIP")) c->tw_general_clip = atoi(e) != 0;
   if (const char* e = getenv("SZ_FUSE_FORCING")) c->fuse_forcing = atoi(e) != 0;
   if (const char* e = getenv("SZ_STATIC_GRID")) c->no_static_grid = atoi(e) == 0;
+  if (const char* e = getenv("SZ_XCD")) c->S.xcd_neigh = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("SZ_GHOST_LIST")) { c->no_ghost_list = atoi(e) == 0; if (atoi(e) > 1) c->gl_max = atoi(e); }
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     // lo = least urgent, hi = most urgent

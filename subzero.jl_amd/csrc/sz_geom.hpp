@@ -588,24 +588,30 @@ struct ItemCtx {
 // rings staged in m.ax/ay, m.bx/by, in three phases so that the expensive part -- the reference's direction check, a
 // second clip of the translated polygon per contact region (collisions.jl:58-68) -- can be handed to whichever lane
 // group of the wavefront is free (the groups of a wavefront share LDS):
-//   contact_phase  the contact clip, overlap tests (fuse / remove), force factor, min-area filter, and per kept region
-//                  the normal direction up to its sign (m.keep / dlv / dxv / dyv; m.chk = the regions that need the check)
-//   check_task     ONE direction check: region q of the item in `own`, working set `scr` (any group's)
+//   contact clip + contact_post  overlap tests (fuse / remove), force factor, min-area filter, and per kept region the normal
+//                  direction up to its sign (m.keep / dlv / dxv / dyv; m.chk = the regions that need the check)
+//   check clip + check_post      ONE direction check: region q of the item in `own`, working set `scr` (any group's)
 //   finish_phase   friction and the rows, in region order (zero-force rows dropped like add_interactions!, :288)
-// rows: out[k*5 + {fx, fy, px, py, overlap}].  clip() -- by far the largest routine -- has two call sites, both cold
-// in the instruction cache only once per round.
+// rows: out[k*5 + {fx, fy, px, py, overlap}].  clip() -- by far the largest routine -- is called from ONE place in the
+// kernel (the passes of one loop: pass 0 = the contact clips, passes 1.. = the check clips), so that the kernel fits the
+// instruction cache: with two call sites it grew from 34 to 47 KB and lost 25 % at 100 k floes, where ten wavefronts
+// per CU are in different phases at any time.
 constexpr int CAPBITS = ERR_CAP_XING | ERR_CAP_REGION | ERR_CAP_ROWS;
 
-template <int G, class MEM>
-SZ_DEV void contact_phase(MEM& m, int gl, int na, int oa, int nb, int ob, const Box& ba, const Box& bb, const ItemCtx& cx_, int& flags, Stamps& st) {
-  int nkeep = 0, nchk = 0;
-  double force_factor = 0.0;
-  flags = 0;
+// before the contact clip: what another lane group needs to run a direction check of this item
+template <class MEM>
+SZ_DEV void contact_pre(MEM& m, int gl, int na, int oa, int nb, int ob, const Box& ba, const Box& bb) {
   if (gl == 0) {
     m.box[0] = ba.x0; m.box[1] = ba.x1; m.box[2] = ba.y0; m.box[3] = ba.y1; m.box[4] = bb.x0; m.box[5] = bb.x1; m.box[6] = bb.y0; m.box[7] = bb.y1;
     m.rna = (uint8_t)na; m.rnb = (uint8_t)nb; m.roa = (int8_t)oa; m.rob = (int8_t)ob; m.nkeep = 0; m.nchk = 0;
   }
-  clip<G>(m, m, gl, 0.0, 0.0, na, oa, nb, ob, 0, ba, bb, st);
+}
+// after the contact clip (clip<G>(m, m, gl, 0, 0, .., buffer 0, ..))
+template <int G, class MEM>
+SZ_DEV void contact_post(MEM& m, int gl, int na, int nb, const ItemCtx& cx_, int& flags, Stamps& st) {
+  int nkeep = 0, nchk = 0;
+  double force_factor = 0.0;
+  flags = 0;
   do {
     // ---------------- after the contact clip: overlap tests, force factor, per-region direction
     const int nreg = m.nreg[0];
@@ -681,13 +687,12 @@ SZ_DEV void contact_phase(MEM& m, int gl, int na, int oa, int nb, int ob, const 
 // regions are in `own`: p1 translated by the unit normal, clipped against p2 again; every new region that intersects
 // the old one and is larger flips the sign.  Works in `scr` (crossing arrays, region buffer 1), touches nothing of `own`
 // but the sign of (dxv, dyv)[q] and its error word.
+// after the check clip (clip<G>(own, scr, gl, dxv[q], dyv[q], .., buffer 1, ..))
 template <int G, class MEM>
-SZ_DEV void check_task(MEM& own, MEM& scr, int gl, int q, Stamps& st) {
+SZ_DEV void check_post(MEM& own, MEM& scr, int gl, int q, Stamps& st) {
   const int r = own.keep[q];
   const double area = own.rarea[0][r];
   const double dirx = own.dxv[q], diry = own.dyv[q];
-  const Box ba{ own.box[0], own.box[1], own.box[2], own.box[3] }, bb{ own.box[4], own.box[5], own.box[6], own.box[7] };
-  clip<G>(own, scr, gl, dirx, diry, (int)own.rna, (int)own.roa, (int)own.rnb, (int)own.rob, 1, ba, bb, st);
   const double* rx = &own.reg[0][0][own.roff[0][r]]; const double* ry = &own.reg[0][1][own.roff[0][r]];
   const int nr = own.roff[0][r + 1] - own.roff[0][r];
   const int nn = scr.nreg[1];

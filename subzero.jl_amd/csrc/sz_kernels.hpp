@@ -768,7 +768,10 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   const int ncx = g.ncx, ncy = g.ncy;
   const int seg = bid % NSEG, segcap = seg_cap(S);
   if (bid == 0 && threadIdx.x == 0) { S.cnt[C_ITEMCLASS] = 0; S.cnt[C_NFUSE] = 0; }     // per-step counters the narrow phase raises
-  const int vb0 = xcd_contiguous(bid, nblk, (M + GPB - 1) / GPB);
+  // (measured: contiguous ranges per XCD pay in the reduce kernel -- 12.9 -> 11.3 us at 10 k floes, 51 -> 44 at 100 k -- but cost
+  //  the neighbour search and, through the uneven segments of the work list, the narrow phase 20 % at 100 k floes: plain order
+  //  here unless SZ_XCD=1)
+  const int vb0 = S.xcd_neigh ? xcd_contiguous(bid, nblk, (M + GPB - 1) / GPB) : bid;
   for (int kb = vb0 < 0 ? M : vb0 * GPB; kb < M; kb += nblk * GPB) {
     const int k = kb + gi;
     const bool act = k < M;
@@ -1040,6 +1043,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     ic.E = P.E; ic.nu = P.nu; ic.mu = P.mu; ic.dt = dt; ic.dbg = dbg;
     ic.mode = ITEM_PAIR; ic.max_overlap = ff_max_overlap; ic.elem_dir = -1; ic.elem_val = 0.0; ic.rigid_j = 0;
     int flags = 0;
+    int pna = 0, pnb = 0, poa = 1, pob = 1; Box pba{ 0, 0, 0, 0 }, pbb{ 0, 0, 0, 0 };      // operands of the pass's clip
     gsync();
     if (have) {
       // Staging: every load of the item -- rings, scalars, signs, boxes -- is asked for BEFORE the first LDS store (a loop of
@@ -1085,24 +1089,40 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       for (int r = 0; r < NKI; r++) { const int q = gl + r * G; if (q < 14) m.kin[q] = kv[r]; }
       gsync();
       STAMP(st, 0);
-      if (!(dbg & 4)) contact_phase<G>(m, gl, na, oa, nb, ob, ba, bb, ic, flags, st);
-      else if (gl == 0) { m.nkeep = 0; m.nchk = 0; m.ierr = 0; }
+      pna = na; pnb = nb; poa = oa; pob = ob; pba = ba; pbb = bb;
+      contact_pre(m, gl, na, oa, nb, ob, ba, bb);
     } else if (gl == 0) { m.nkeep = 0; m.nchk = 0; m.ierr = 0; }
-    gsync();
-    // ================= phase B: the direction checks of ALL items of the wavefront, one per lane group and turn.  An item
-    // with two or three contact regions no longer works its checks off one after the other while the other groups idle:
-    // 14 % of the wavefronts hold such an item, and they used to set the kernel's duration.
+    // ================= phases A (pass 0: the contact clip of the own item) and B (passes 1..: the direction checks of ALL
+    // items of the wavefront, one per lane group and pass -- an item with two or three contact regions no longer works its
+    // checks off one after the other while the other groups idle: 14 % of the wavefronts hold such an item, and they used
+    // to set the kernel's duration).  One loop, ONE call site of clip().
     {
-      int pre = 0, total = 0;
-      for (int g = 0; g < GPB; g++) total += mem[g].nchk;
-      for (int base = 0; base < total; base += GPB) {
-        const int idx = base + gi;
-        if (idx < total) {
-          int g = 0; pre = 0;
-          while (pre + mem[g].nchk <= idx) { pre += mem[g].nchk; g++; }
-          check_task<G>(mem[g], m, gl, (int)mem[g].chk[idx - pre], st);
+      int total = 0;
+      for (int pass = 0; pass == 0 || (pass - 1) * GPB < total; pass++) {
+        bool run = false; int g = gi, q = 0, buf = 0; double ox = 0.0, oy = 0.0;
+        if (pass == 0) run = have && !(dbg & 4);
+        else {
+          const int idx = (pass - 1) * GPB + gi;
+          if (idx < total) {
+            int pre = 0; g = 0;
+            while (pre + mem[g].nchk <= idx) { pre += mem[g].nchk; g++; }
+            q = (int)mem[g].chk[idx - pre];
+            const auto& o = mem[g];
+            run = true; buf = 1; ox = o.dxv[q]; oy = o.dyv[q];
+            pna = o.rna; pnb = o.rnb; poa = o.roa; pob = o.rob;
+            pba = Box{ o.box[0], o.box[1], o.box[2], o.box[3] }; pbb = Box{ o.box[4], o.box[5], o.box[6], o.box[7] };
+          }
         }
-        gsync();
+        if (run) clip<G>(mem[g], m, gl, ox, oy, pna, poa, pnb, pob, buf, pba, pbb, st);
+        if (pass == 0) {
+          if (run) contact_post<G>(m, gl, na, nb, ic, flags, st);
+          else if (have && gl == 0) { m.nkeep = 0; m.nchk = 0; m.ierr = 0; m.ff = 0.0; }
+          gsync();
+          for (int k = 0; k < GPB; k++) total += mem[k].nchk;
+        } else {
+          if (run) check_post<G>(mem[g], m, gl, q, st);
+          gsync();
+        }
       }
     }
     // ================= phase C: friction and the rows of the own item, in region order

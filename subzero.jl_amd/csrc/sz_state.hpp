@@ -65,6 +65,7 @@ struct State {
   int step;                  // 1-based index of the step inside the running sz_step batch (0: process-mode call): kernels of
                              // steps after a stop request return at once (stopped(), sz_kernels.hpp)
   int stop_on_tags;          // sz_step: raise C_STOP when a parent is tagged (off with SZ_NO_STOP)
+  int xcd_neigh;             // SZ_XCD=1: XCD-contiguous floe ranges in the neighbour search too (A/B switch; default off)
   // ---- counters
   int* cnt;
   int* warn;                 // guard counters of timestep_floe_properties!: WARN_SLOTS slots of 32 ints (one 128-byte line each; words 0..3 =
