@@ -564,3 +564,44 @@ def test_c_example_links_and_runs(tmp_path):
     assert u[0] < 0.1 and u[1] > -0.1                      # the two floes have pushed each other apart
     assert "0 remove, 0 fuse" in lines[2]
     assert abs(float(lines[3].split(":")[1].split()[0]) - 2e8) < 1e-3 * 2e8      # the grid output adds up to the ice area
+
+
+def _size_spectrum(w, n_small, big_r):
+    """one large floe with n_small small ones around its rim, each overlapping it a little (a Voronoi field with a size
+    spectrum in miniature): the large floe has n_small neighbours, every broad-phase cell holds dozens of floes"""
+    w.set_consts(E=1e5); w.set_settings()
+    w.set_domain([0, 0, 0, 0], -4e5, 4e5, -4e5, 4e5)
+    w.set_grid_fields(8, 8, -4e5, 4e5, -4e5, 4e5, 0.0, 0.0, 0.0, 0.0, 0.0)
+    th = -np.arange(24) * (2 * np.pi / 24)
+    w.add_floe(cases.closed(np.stack([big_r * np.cos(th), big_r * np.sin(th)], 1)), 0.5)
+    small_r = 0.9 * np.pi * big_r / n_small
+    t6 = -np.arange(6) * (2 * np.pi / 6)
+    for k in range(n_small):
+        a = 2 * np.pi * k / n_small
+        c = (big_r + 0.6 * small_r) * np.array([np.cos(a), np.sin(a)])
+        w.add_floe(cases.closed(c + small_r * np.stack([np.cos(t6 + a), np.sin(t6 + a)], 1)), 0.3)
+    u = np.zeros(n_small + 1); v = np.zeros(n_small + 1)
+    ang = 2 * np.pi * np.arange(n_small) / n_small
+    u[1:] = -0.2 * np.cos(ang); v[1:] = -0.2 * np.sin(ang)            # the small floes press inward
+    w.set("u", u); w.set("v", v)
+    return w
+
+
+def test_size_spectrum_field_and_its_capacity_limit():
+    """A large floe among small ones (the reference's Voronoi fields have a size spectrum).  Within the neighbour
+    capacity (24 per floe and direction) the contact rows match the oracle -- crowded cells (bucket + overflow chain)
+    included; beyond it the step fails LOUDLY (SZ_E_CAPACITY, neighbours bit) instead of dropping contacts.  The
+    reference grows its lists (collisions.jl:290-296); the engine's capacities are fixed per upload."""
+    from subzero_jl_amd.capi import SzError
+    hw = _size_spectrum(mk(), 20, 3.0e4); ow = _size_spectrum(omk(), 20, 3.0e4)
+    for w in (hw, ow):
+        w.timestep_collisions(21, 10)
+    assert parity.compare_pairs(hw, ow) >= 20
+    parity.compare_interactions(hw, ow, 1e-10)
+    parity.compare_worlds(hw, ow, rtol=1e-10, fields=["coll_fx", "coll_fy", "coll_trq", "overarea"])
+    assert len(ow.inter(0)) >= 20                          # the large floe really carries all those contacts
+    hw.run(5, 0, 10, coupling_on=False); [ow.timestep_sim(t, 10, coupling_dt=10, coupling_on=False) for t in range(5)]
+    parity.compare_worlds(hw, ow, rtol=1e-9)
+    big = _size_spectrum(mk(), 40, 6.0e4)
+    with pytest.raises(SzError, match="neighbours"):
+        big.timestep_collisions(41, 10)
