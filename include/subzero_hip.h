@@ -170,11 +170,13 @@ int sz_collide_pairs(sz_ctx *ctx, int64_t npairs, const int32_t *pi, const int32
 int sz_collide_domain(sz_ctx *ctx, int32_t dt, double max_overlap);
 int sz_timestep_coupling(sz_ctx *ctx);
 int sz_timestep_floe_properties(sz_ctx *ctx, int32_t dt);
-/* ---- precision of timestep_coupling! (BASELINE configs[4]): 0 = fp64 (default); 1 = mixed: the per-point
-   arithmetic of calc_one_way_coupling! in fp32 on fp32 copies of the sub-floe points and the lattice, absolute
-   positions and per-floe totals in fp64.  The reference has no Float32 answers (documentation.md:25); the mixed
-   path agrees with the fp64 path to ~1e-6 relative on fxOA / fyOA / trqOA (stated in the tests).  Ignored while
-   two-way coupling is on. */
+/* ---- precision (BASELINE configs[4]): 0 = fp64 (default); 1 = mixed.  Mixed: the per-point arithmetic of
+   calc_one_way_coupling! in fp32 on fp32 copies of the sub-floe points and the lattice; the broad phase on 32-byte fp32
+   records with fp64 confirmation of the bounding-circle test (pair list bit-exact); in resident batches of single-context
+   runs the rings as fp32 offsets in the floe's body frame + fp64 pose, world coordinates rebuilt in fp64 for the
+   narrow-phase predicates.  Absolute positions, predicates, contact rows and per-floe totals stay
+   fp64.  The reference has no Float32 answers (documentation.md:25); the acceptance criterion against the fp64 path is
+   stated in tests/test_hip_parity.py.  Two-way coupling keeps its fp64 forcing kernel. */
 int sz_set_precision(sz_ctx *ctx, int32_t mode);
 /* ---- two-way coupling: calc_two_way_coupling! (coupling.jl:1617-1680) with floe_to_grid_info! (:1417-1454),
    center_cell_coords (:1116-1140) and shift_cell_idx (:1154-1178).  Off by default like CouplingSettings().

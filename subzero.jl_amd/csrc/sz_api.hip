@@ -81,6 +81,9 @@ struct sz_ctx {
   int narrow_grid0 = 0;
   // mixed precision (sz_set_precision): fp32 copies for the forcing kernel, rebuilt when their sources change
   int precision = 0; bool mixed_pts_ok = false, mixed_nodes_ok = false; Pool mixed_pt_allocs, mixed_node_allocs;
+  // mixed precision, geometry: fp32 broad-phase records and body-frame rings (sz_state.hpp); rings_stale: resident steps ran on the
+  // body rings, the world rings vx / vy are behind (rebuilt by world_rings() before anything else looks at them)
+  bool mixed_geom_ok = false, rings_stale = false, no_body_rings = false; Pool mixed_geom_allocs;
   // two-way coupling (off by default, like CouplingSettings())
   bool tw_general_clip = false;   // SZ_TW_GENERAL_CLIP=1: floe-in-cell areas by the general clipper (8 lanes per entry) instead of the rectangle pipeline
   bool two_way = false; int tw_dt = 10; int tw_capM = 0; size_t tw_ncell = 0; bool temps_set = false;
@@ -322,6 +325,15 @@ void use_static_grid(sz_ctx* c) {
   c->grid_live = true;
 }
 
+// resident steps of mixed precision run on body-frame rings: the world rings are rebuilt before anything else looks at them
+void world_rings(sz_ctx* c) {
+  if (!c->rings_stale) return;
+  hipLaunchKernelGGL(sz_k_world_rings, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
+  c->rings_stale = false;
+}
+// every call outside the resident steps: the candidate list they keep goes stale, the world rings must be current
+void leave_resident(sz_ctx* c) { c->gl_valid = false; world_rings(c); }
+
 // the candidate list of the coming step, seeded from the parents as they lie
 void use_ghost_list(sz_ctx* c) {
   if (c->gl_valid) return;
@@ -478,6 +490,15 @@ int ensure_mixed(sz_ctx* c) {
     hipLaunchKernelGGL(sz_k_to_f32_points, dim3(grid_for(S.capS, 256)), dim3(256), 0, c->stream, S, S.capS);
     c->mixed_pts_ok = true;
   }
+  if (!c->mixed_geom_ok) {
+    world_rings(c);                 // (the body rings are made from the world rings)
+    free_pool(c->mixed_geom_allocs);
+    if ((rc = dalloc(c, &S.rec32, (size_t)2 * S.capM, c->mixed_geom_allocs)) || (rc = dalloc(c, &S.ring32, (size_t)std::max(S.capV, 1), c->mixed_geom_allocs)) ||
+        (rc = dalloc(c, &S.rb_off, (size_t)S.capM, c->mixed_geom_allocs)) || (rc = dalloc(c, &S.rb_n, (size_t)S.capM, c->mixed_geom_allocs))) return rc;
+    hipLaunchKernelGGL(sz_k_rec32_seed, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S);
+    hipLaunchKernelGGL(sz_k_body_rings, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S);
+    c->mixed_geom_ok = true;
+  }
   if (!c->mixed_nodes_ok) {
     free_pool(c->mixed_node_allocs);
     const size_t n = (size_t)(S.Nx + 1) * (S.Ny + 1) * 8;
@@ -613,6 +634,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_TW_GENERAL_CLIP")) c->tw_general_clip = atoi(e) != 0;
   if (const char* e = getenv("SZ_FUSE_FORCING")) c->fuse_forcing = atoi(e) != 0;
   if (const char* e = getenv("SZ_STATIC_GRID")) c->no_static_grid = atoi(e) == 0;
+  if (const char* e = getenv("SZ_BODY_RINGS")) c->no_body_rings = atoi(e) == 0;
   if (const char* e = getenv("SZ_XCD")) c->S.xcd_neigh = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("SZ_GHOST_LIST")) { c->no_ghost_list = atoi(e) == 0; if (atoi(e) > 1) c->gl_max = atoi(e); }
   int prio_lo = 0, prio_hi = 0;
@@ -637,7 +659,7 @@ void sz_destroy(sz_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   free_pool(c->allocs); free_pool(c->inter_allocs); free_pool(c->static_allocs); free_pool(c->field_allocs); free_pool(c->tw_allocs); free_pool(c->tw_field_allocs);
-  free_pool(c->mixed_pt_allocs); free_pool(c->mixed_node_allocs); free_pool(c->comm_allocs); free_pool(c->tw_part_allocs);
+  free_pool(c->mixed_pt_allocs); free_pool(c->mixed_node_allocs); free_pool(c->mixed_geom_allocs); free_pool(c->comm_allocs); free_pool(c->tw_part_allocs);
   (void)sz_comm_destroy(c);
   for (auto& e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   (void)hipFree(c->d_stats); (void)hipFree(c->S.acc);
@@ -804,6 +826,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->hostM = M; c->hostN = N; c->have_floes = true; c->tile_dirty = false; c->mixed_pts_ok = false;
   c->gl_valid = false; c->gl_est = 0;
+  c->mixed_geom_ok = false; c->rings_stale = false; S.rec32 = nullptr; S.ring32 = nullptr; S.body_rings = 0;
   if (f->rmax) {          // parents near a periodic wall: how long the ghost-candidate list will be (a superset of it)
     const double x0 = c->h_vals[3], xf = c->h_vals[2], y0 = c->h_vals[1], yf = c->h_vals[0];
     const bool pew = c->h_kinds[SZ_EAST] == SZ_PERIODIC && c->h_kinds[SZ_WEST] == SZ_PERIODIC;
@@ -851,6 +874,8 @@ int sz_download_floes(sz_ctx* c, sz_floe_columns* f) {
   if (!c || !f || !c->have_floes) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
   tile_cleanup(c);
+  world_rings(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   State& S = c->S;
   int h[C_COUNT];
   HIPCHK(c, hipMemcpy(h, S.cnt, sizeof(h), hipMemcpyDeviceToHost));
@@ -980,7 +1005,7 @@ int sz_debug_match_vertices(sz_ctx* c, int32_t npts, const double* px, const dou
 int sz_add_ghosts(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
-  c->gl_valid = false;          // a process-mode call: the resident steps' ghost-candidate list is stale
+  leave_resident(c);            // a process-mode call: the resident steps' ghost-candidate list is stale, the world rings must be current
   int oldM = c->hostM;
   stage_ghosts(c);
   int rc = sync_and_check(c);
@@ -998,7 +1023,7 @@ int sz_add_ghosts(sz_ctx* c) {
 int sz_remove_ghosts(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
-  c->gl_valid = false;          // a process-mode call: the resident steps' ghost-candidate list is stale
+  leave_resident(c);            // a process-mode call: the resident steps' ghost-candidate list is stale, the world rings must be current
   hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
   int rc = sync_and_check(c);
   if (rc) return rc;
@@ -1009,7 +1034,7 @@ int sz_remove_ghosts(sz_ctx* c) {
 int sz_timestep_collisions(sz_ctx* c, int64_t n_init, int32_t dt) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
-  c->gl_valid = false;          // a process-mode call: the resident steps' ghost-candidate list is stale
+  leave_resident(c);            // a process-mode call: the resident steps' ghost-candidate list is stale, the world rings must be current
   collisions(c, (int)n_init, dt);
   c->inter_any = true; c->inter_lost = false;
   int h[C_COUNT];
@@ -1021,7 +1046,7 @@ int sz_timestep_collisions(sz_ctx* c, int64_t n_init, int32_t dt) {
 int sz_collide_pairs(sz_ctx* c, int64_t np, const int32_t* pi, const int32_t* pj, int32_t dt, double max_overlap) {
   if (!c || !c->have_floes || np < 0 || (np > 0 && (!pi || !pj))) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
-  c->gl_valid = false;
+  leave_resident(c);
   State& S = c->S;
   if (np > S.capPairs) { c->err = "too many explicit pairs"; return SZ_E_CAPACITY; }
   std::vector<std::pair<int, int>> ps(np);
@@ -1048,7 +1073,7 @@ int sz_collide_pairs(sz_ctx* c, int64_t np, const int32_t* pi, const int32_t* pj
 int sz_collide_domain(sz_ctx* c, int32_t dt, double max_overlap) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
-  c->gl_valid = false;          // a process-mode call: the resident steps' ghost-candidate list is stale
+  leave_resident(c);            // a process-mode call: the resident steps' ghost-candidate list is stale, the world rings must be current
   State& S = c->S;
   hipLaunchKernelGGL(sz_k_pairs_explicit, dim3(grid_for(S.capM + 1, 256)), dim3(256), 0, c->stream, S, 0);
   stage_elems(c, true);
@@ -1062,7 +1087,7 @@ int sz_timestep_coupling(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   if (!c->have_fields) { c->err = "sz_set_fields must be called before sz_timestep_coupling"; return SZ_E_STATE; }
   (void)hipSetDevice(c->device);
-  c->gl_valid = false;          // a process-mode call: the resident steps' ghost-candidate list is stale
+  leave_resident(c);            // a process-mode call: the resident steps' ghost-candidate list is stale, the world rings must be current
   if (c->two_way) { if (c->S.tiled) { c->err = "tiled contexts couple through sz_tile_step + sz_two_way_partial / sz_two_way_finish"; return SZ_E_STATE; } int rc = ensure_two_way(c); if (rc) return rc; }
   if (c->precision == 1 && !c->two_way) { int rc = ensure_mixed(c); if (rc) return rc; }
   stage_forcing(c);
@@ -1073,6 +1098,11 @@ int sz_timestep_coupling(sz_ctx* c) {
 // ---- precision of the forcings: 0 = fp64 (default), 1 = mixed (per-point arithmetic in fp32, sz_kernels.hpp)
 int sz_set_precision(sz_ctx* c, int32_t mode) {
   if (!c || mode < 0 || mode > 1) return SZ_E_ARG;
+  if (mode == 0 && c->precision == 1 && c->have_floes) {        // back to fp64: the world rings are the state again
+    (void)hipSetDevice(c->device);
+    world_rings(c);
+    c->S.rec32 = nullptr; c->S.body_rings = 0; c->mixed_geom_ok = false;
+  }
   c->precision = mode;
   return SZ_OK;
 }
@@ -1117,7 +1147,7 @@ int sz_timestep_floe_properties(sz_ctx* c, int32_t dt) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   if (int rc = need_interactions(c)) return rc;
   (void)hipSetDevice(c->device);
-  c->gl_valid = false;          // a process-mode call: the resident steps' ghost-candidate list is stale
+  leave_resident(c);            // a process-mode call: the resident steps' ghost-candidate list is stale, the world rings must be current
   stage_integrate(c, dt, true, false);
   return sync_and_check(c);
 }
@@ -1191,7 +1221,13 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   if (gl && periodic && c->hostM != c->hostN) hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
   if (gl) use_ghost_list(c); else c->gl_valid = false;
   const int gl0 = c->gl_cur;
-  if (c->precision == 1 && !c->two_way && (flags & SZ_COUPLING_ON)) { int rc = ensure_mixed(c); if (rc) return rc; }
+  const bool mixed = c->precision == 1 && !c->two_way;
+  if (mixed) { int rc = ensure_mixed(c); if (rc) return rc; }
+  // mixed precision: the steps run on body-frame rings (the integrator moves poses, not rings) when nothing else in the batch
+  // needs world rings -- single context, the list path for the ghosts, rings small enough for the fused integrator
+  const bool body = mixed && coll && sg && (gl || !periodic) && !c->S.tiled && c->fused_move && c->max_ring <= MV_RING && !c->no_body_rings;
+  if (!body) world_rings(c);
+  c->S.body_rings = body ? 1 : 0;
   for (int s = 0; s < nsteps; s++) {
     int tstep = tstep0 + s;
     c->S.step = s + 1;
@@ -1215,6 +1251,8 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     if (gl) c->gl_cur ^= 1;
   }
   c->S.step = 0;
+  if (body && nsteps > 0) c->rings_stale = true;
+  c->S.body_rings = 0;
   if (coll) { c->inter_any = true; c->inter_lost = false; }
   if (coll && periodic) hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
   int h[C_COUNT];
@@ -1266,7 +1304,7 @@ int sz_kernel_time_ms(sz_ctx* c, int32_t k, double* ms, int64_t* launches) {
 int sz_tile_enable(sz_ctx* c, const int64_t* gidx, double halo_capacity_factor, double max_rmax) {
   if (!c || !c->have_floes || !gidx) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
-  c->gl_valid = false;
+  leave_resident(c);
   State& S = c->S;
   if (c->hostM != c->hostN) { c->err = "sz_tile_enable needs a ghost-free upload"; return SZ_E_STATE; }
   std::vector<long long> ok(c->hostN);
@@ -1397,6 +1435,7 @@ int eul_grid(sz_ctx* c, int32_t nx, int32_t ny, const double* xg, const double* 
   for (int k = 0; k <= nx; k++) if (fabs(xg[k] - (xg[0] + k * dx)) > 1e-6 * dx) { c->err = "x grid lines must be evenly spaced"; return SZ_E_ARG; }
   for (int k = 0; k <= ny; k++) if (fabs(yg[k] - (yg[0] + k * dy)) > 1e-6 * dy) { c->err = "y grid lines must be evenly spaced"; return SZ_E_ARG; }
   (void)hipSetDevice(c->device);
+  world_rings(c);
   int rc = sync_and_check(c);          // hostM current, nothing pending
   if (rc) return rc;
   const int ncell = nx * ny;

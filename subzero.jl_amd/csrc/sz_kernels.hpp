@@ -34,6 +34,17 @@ __device__ __forceinline__ void request_stop(const State& S) {
   if (S.step > 0 && S.stop_on_tags) S.cnt[C_STOP] = S.step;      // every requester of a step writes the same value
 }
 
+// ring offset / size of floe i: into vx, vy (CSR offsets voff) or, on body-frame rings (mixed precision), into ring32
+__device__ __forceinline__ int ring_off(const State& S, int i) { return S.body_rings ? S.rb_off[i] : S.voff[i]; }
+__device__ __forceinline__ int ring_n(const State& S, int i) { return S.body_rings ? S.rb_n[i] : S.voff[i + 1] - S.voff[i]; }
+// margins of the fp32 broad-phase prefilter (metres): coordinates up to 2^23 m (8 388 km) round to <= 0.5 m in fp32, a
+// difference of two of them is off by <= 1 m, a sum of two radii by far less; the box margin covers both roundings
+constexpr float MIX_CIRCLE_MARGIN = 4.0f, MIX_BOX_MARGIN = 2.0f;
+__device__ __forceinline__ void rec32_store(const State& S, int i, double cx, double cy, double r, double x0, double x1, double y0, double y1) {
+  S.rec32[2 * (size_t)i] = make_float4((float)cx, (float)cy, (float)r, 0.0f);
+  S.rec32[2 * (size_t)i + 1] = make_float4((float)x0, (float)x1, (float)y0, (float)y1);
+}
+
 // ============================================================================ scan (exclusive, int)
 constexpr int SCAN_B = 1024;
 
@@ -365,6 +376,7 @@ __device__ __forceinline__ Rig rig_shift(Rig r, double dx, double dy) {
 }
 __device__ __forceinline__ void rig_store(State& S, int lane, int f, int vo, int n, const Rig& r) {
   S.cx[f] = r.cx; S.cy[f] = r.cy; S.bbx0[f] = r.b0; S.bbx1[f] = r.b1; S.bby0[f] = r.b2; S.bby1[f] = r.b3;
+  if (S.body_rings) return;                      // the ring is the parent's, in its body frame: only the pose moves
   if (lane < n) { S.vx[vo + lane] = r.x0; S.vy[vo + lane] = r.y0; }
   if (lane + 64 < n) { S.vx[vo + lane + 64] = r.x1; S.vy[vo + lane + 64] = r.y1; }
 }
@@ -381,8 +393,11 @@ __device__ __forceinline__ void ghost_fill_parent(State& S, const GridGeo& geo, 
   const int ngh_old = S.ngh[i];
   Rig P;
   P.cx = S.cx[i]; P.cy = S.cy[i]; P.b0 = S.bbx0[i]; P.b1 = S.bbx1[i]; P.b2 = S.bby0[i]; P.b3 = S.bby1[i];
-  P.x0 = lane < n ? S.vx[vo + lane] : 0.0; P.y0 = lane < n ? S.vy[vo + lane] : 0.0;
-  P.x1 = lane + 64 < n ? S.vx[vo + lane + 64] : 0.0; P.y1 = lane + 64 < n ? S.vy[vo + lane + 64] : 0.0;
+  const bool body = S.body_rings != 0;
+  P.x0 = !body && lane < n ? S.vx[vo + lane] : 0.0; P.y0 = !body && lane < n ? S.vy[vo + lane] : 0.0;
+  P.x1 = !body && lane + 64 < n ? S.vx[vo + lane + 64] : 0.0; P.y1 = !body && lane + 64 < n ? S.vy[vo + lane + 64] : 0.0;
+  const double tc = body ? S.trig[2 * i] : 0.0, ts = body ? S.trig[2 * i + 1] : 0.0;
+  const double rmx = S.rec32 ? S.rmax[i] : 0.0;
   // the copied scalar columns (deepcopy of the parent, collisions.jl:893): lane q < 10 carries double column q
   double* const dcol = lane == 0 ? S.rmax : lane == 1 ? S.area : lane == 2 ? S.height : lane == 3 ? S.mass : lane == 4 ? S.moment :
                        lane == 5 ? S.alpha : lane == 6 ? S.u : lane == 7 ? S.v : lane == 8 ? S.xi : S.overarea;
@@ -429,11 +444,15 @@ __device__ __forceinline__ void ghost_fill_parent(State& S, const GridGeo& geo, 
     if (lane == 11) { S.status[g] = stv; S.parent[g] = i; S.ngh[g] = 0; S.osign[g] = osv; }
     if (lane == 12) { S.cfx[g] = 0.0; S.cfy[g] = 0.0; S.ctrq[g] = 0.0; }
     rig_store(S, lane, g, vbs[w], n, Gs[w]);
-    if (lane == 13) { S.voff[g] = vbs[w]; S.voff[g + 1] = vbs[w] + n; }   // neighbours write the same values: rings are packed back to back
+    if (lane == 13) {
+      if (body) { S.rb_off[g] = vo; S.rb_n[g] = n; S.trig[2 * g] = tc; S.trig[2 * g + 1] = ts; }
+      else { S.voff[g] = vbs[w]; S.voff[g + 1] = vbs[w] + n; }   // neighbours write the same values: rings are packed back to back
+    }
+    if (lane == 15 && S.rec32) rec32_store(S, g, Gs[w].cx, Gs[w].cy, rmx, Gs[w].b0, Gs[w].b1, Gs[w].b2, Gs[w].b3);
     if (bin && lane == 14) cell_insert(S, geo, g, Gs[w].cx, Gs[w].cy);
     if (lane < MAX_GHOSTS) S.gh[g * MAX_GHOSTS + lane] = -1;
   }
-  if (moved) rig_store(S, lane, i, vo, n, P);
+  if (moved) { rig_store(S, lane, i, vo, n, P); if (lane == 15 && S.rec32) rec32_store(S, i, P.cx, P.cy, rmx, P.b0, P.b1, P.b2, P.b3); }
   if (lane < MAX_GHOSTS) S.gh[i * MAX_GHOSTS + lane] = lane < ng ? slot[lane] : -1;
   if (lane == 0) S.ngh[i] = ng;
 }
@@ -539,18 +558,49 @@ __global__ void __launch_bounds__(256) sz_k_ghost_list(State S, int list, int bi
       ex = add4(ex, make_int4(__shfl_xor(ex.x, d), __shfl_xor(ex.y, d), __shfl_xor(ex.z, d), __shfl_xor(ex.w, d)));
       T = add4(T, make_int4(__shfl_xor(T.x, d), __shfl_xor(T.y, d), __shfl_xor(T.z, d), __shfl_xor(T.w, d)));
     }
-    const int newg = T.x + T.z, newv = T.y + T.w;
+    const int newg = T.x + T.z, newv = S.body_rings ? 0 : T.y + T.w;      // (ghosts on body-frame rings need no ring points)
     const bool fits = N + newg <= S.capM && NV0 + newv <= S.capV;
     if (e == 0 && lane == 0) {                       // commit (as sz_k_ghost_flag_scan does with commit = 1)
       const int M = fits ? N + newg : N;
       S.cnt[C_M] = M; S.cnt[C_NV] = fits ? NV0 + newv : NV0; S.cnt[C_NGHOSTS] = fits ? newg : 0;
-      if (fits) S.voff[M] = NV0 + newv;
+      if (fits) { if (!S.body_rings) S.voff[M] = NV0 + newv; }
       else atomicOr(&S.cnt[C_ERR], N + newg > S.capM ? ERR_CAP_FLOES : ERR_CAP_VERTS);
       S.cnt[C_NGCAND + (1 - list)] = 0;              // the list this step's integrator fills
     }
     if (!fits || e >= n) break;
     ghost_fill_parent(S, geo, lane, mine.x, mine.y, ex, T, N, NV0, bin, mine.w, mine.z, wall);
   }
+}
+// mixed precision: the rings of the parents into their body frame (offsets from the centroid at alpha = 0, fp32) ...
+__global__ void sz_k_body_rings(State S) {
+  const int N = S.cnt[C_N];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    const int o = S.voff[i], n = S.voff[i + 1] - o;
+    const double cx = S.cx[i], cy = S.cy[i], ca = S.trig[2 * i], sa = S.trig[2 * i + 1];
+    for (int k = 0; k < n; k++) {
+      const double dx = S.vx[o + k] - cx, dy = S.vy[o + k] - cy;
+      S.ring32[o + k] = make_float2((float)(ca * dx + sa * dy), (float)(-sa * dx + ca * dy));
+    }
+    S.rb_off[i] = o; S.rb_n[i] = n;
+  }
+}
+// ... and back: world rings (and their boxes) from the body rings and the pose, for everything outside the resident steps
+__global__ void sz_k_world_rings(State S) {
+  const int N = S.cnt[C_N];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    const int o = S.voff[i], n = S.voff[i + 1] - o;
+    const double cx = S.cx[i], cy = S.cy[i], ca = S.trig[2 * i], sa = S.trig[2 * i + 1];
+    for (int k = 0; k < n; k++) {
+      const float2 b = S.ring32[o + k];
+      S.vx[o + k] = (ca * (double)b.x - sa * (double)b.y) + cx; S.vy[o + k] = (sa * (double)b.x + ca * (double)b.y) + cy;
+    }
+  }
+}
+// the fp32 broad-phase records of all floes as they lie
+__global__ void sz_k_rec32_seed(State S) {
+  const int M = S.cnt[C_M];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x)
+    rec32_store(S, i, S.cx[i], S.cy[i], S.rmax[i], S.bbx0[i], S.bbx1[i], S.bby0[i], S.bby1[i]);
 }
 // seeds candidate list `list` from the parents as they lie (after an upload / a process-mode call), thread per parent
 __global__ void sz_k_ghost_seed(State S, int list) {
@@ -562,7 +612,7 @@ __global__ void sz_k_ghost_seed(State S, int list) {
     if (i < N) {
       fl = ghost_flag_of(ev, S.any_periodic_ew, S.any_periodic_ns, S.cx[i], S.cy[i], S.rmax[i], S.bbx0[i], S.bbx1[i], S.bby0[i], S.bby1[i],
                          S.status[i] == SZ_ACTIVE && S.ghost_id[i] == 0);
-      vo = S.voff[i]; nv = S.voff[i + 1] - vo;
+      vo = ring_off(S, i); nv = ring_n(S, i);
     }
     ghost_candidate_wave(S, list, fl != 5, i, fl, nv, vo);
   }
@@ -738,7 +788,7 @@ __device__ __forceinline__ Item item_of(const State& S, const Seg& g, int t) {
     it.info = k.x; it.i = k.y; it.j = k.z; it.e = -1; it.rows = w; it.ao = k.w; it.na = r.x; it.bo = r.y; it.nb = r.z;
   } else {
     const int q = (t - g.np) * NSEG + g.s; it.i = S.el_floe[q]; it.e = S.el_elem[q]; it.j = -1; it.rows = S.capPairs + q; it.info = S.capM * MAXNB + q;
-    it.ao = S.voff[it.i]; it.na = S.voff[it.i + 1] - it.ao; it.bo = S.eoff[it.e]; it.nb = S.eoff[it.e + 1] - it.bo;
+    it.ao = ring_off(S, it.i); it.na = ring_n(S, it.i); it.bo = S.eoff[it.e]; it.nb = S.eoff[it.e + 1] - it.bo;
   }
   return it;
 }
@@ -781,7 +831,7 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
     double ckx = 0, cky = 0, rk = 0, kx0 = 0, kx1 = 0, ky0 = 0, ky1 = 0;
     long long idk = 0, okk = 0; bool kplain = true; int ix = 0, iy = 0, vok = 0, nvk = 0;
     if (act) {
-      vok = S.voff[k]; nvk = S.voff[k + 1] - vok;
+      vok = ring_off(S, k); nvk = ring_n(S, k);
       ckx = S.cx[k]; cky = S.cy[k]; rk = S.rmax[k];
       kx0 = S.bbx0[k]; kx1 = S.bbx1[k]; ky0 = S.bby0[k]; ky1 = S.bby1[k];
       idk = S.id[k]; okk = S.okey[k];
@@ -823,12 +873,21 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
     const int np = npool[gi] < NB_POOL ? npool[gi] : NB_POOL;
     for (int e = gl; e < np; e += NB_G) {
       const int o = pool[gi][e];
+      if (S.rec32) {
+        // mixed precision: the candidate's fp32 record first -- two 16-byte loads instead of seven scattered doubles; a
+        // candidate that fails the bounding-circle test even with the margin that covers the fp32 roundings is gone, the
+        // others are confirmed by the exact fp64 predicate below, so the pair list is the fp64 one bit for bit
+        const float4 oc = S.rec32[2 * (size_t)o];
+        const float fdx = (float)ckx - oc.x, fdy = (float)cky - oc.y;
+        const float frr = (float)rk + oc.z + MIX_CIRCLE_MARGIN + 1e-6f * fmaxf(fabsf((float)ckx), fabsf((float)cky));    // (+ 1 m per 1000 km of coordinate: fp32 spacing)
+        if (!(fdx * fdx + fdy * fdy < frr * frr)) continue;
+      }
       // everything the tests below may need about o is requested at once
       const double ocx = S.cx[o], ocy = S.cy[o], orm = S.rmax[o];
       const double ox0 = S.bbx0[o], ox1 = S.bbx1[o], oy0 = S.bby0[o], oy1 = S.bby1[o];
       const long long oid = S.id[o], ko = S.okey[o];
       const bool oplain = S.parent[o] == o && S.ngh[o] == 0;     // a parent without ghosts
-      const int voo = S.voff[o], nvo = S.voff[o + 1] - voo;
+      const int voo = ring_off(S, o), nvo = ring_n(S, o);
       // potential_interaction (collisions.jl:705-710), symmetric in its arguments
       double ddx = ckx - ocx, ddy = cky - ocy, rr = rk + orm;
       if (!((ddx * ddx + ddy * ddy) < rr * rr)) continue;
@@ -1073,11 +1132,29 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       }
       const Box ba{ S.bbx0[i], S.bbx1[i], S.bby0[i], S.bby1[i] };
       const Box bb = is_pair ? Box{ S.bbx0[j], S.bbx1[j], S.bby0[j], S.bby1[j] } : Box{ S.ebb[4 * e], S.ebb[4 * e + 1], S.ebb[4 * e + 2], S.ebb[4 * e + 3] };
+      if (S.body_rings) {
+        // mixed precision: rings live once, in the body frame, as fp32; the world coordinates the predicates work on are
+        // rebuilt here in fp64 from the fp64 pose -- the same expression the integrator's box and sz_k_world_rings use
+        const double cxi = S.cx[i], cyi = S.cy[i], cai = S.trig[2 * i], sai = S.trig[2 * i + 1];
+        const int jj = is_pair ? j : i;
+        const double cxj = S.cx[jj], cyj = S.cy[jj], caj = S.trig[2 * jj], saj = S.trig[2 * jj + 1];
 #pragma unroll
-      for (int r = 0; r < NIT; r++) {
-        const int q = gl + r * G;
-        rax[r] = q < na ? S.vx[ao + q] : 0.0; ray[r] = q < na ? S.vy[ao + q] : 0.0;
-        rbx[r] = q < nb ? bxs[bo + q] : 0.0; rby[r] = q < nb ? bys[bo + q] : 0.0;
+        for (int r = 0; r < NIT; r++) {
+          const int q = gl + r * G;
+          const float2 pa = q < na ? S.ring32[ao + q] : make_float2(0.f, 0.f);
+          rax[r] = (cai * (double)pa.x - sai * (double)pa.y) + cxi; ray[r] = (sai * (double)pa.x + cai * (double)pa.y) + cyi;
+          if (is_pair) {
+            const float2 pb = q < nb ? S.ring32[bo + q] : make_float2(0.f, 0.f);
+            rbx[r] = (caj * (double)pb.x - saj * (double)pb.y) + cxj; rby[r] = (saj * (double)pb.x + caj * (double)pb.y) + cyj;
+          } else { rbx[r] = q < nb ? bxs[bo + q] : 0.0; rby[r] = q < nb ? bys[bo + q] : 0.0; }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < NIT; r++) {
+          const int q = gl + r * G;
+          rax[r] = q < na ? S.vx[ao + q] : 0.0; ray[r] = q < na ? S.vy[ao + q] : 0.0;
+          rbx[r] = q < nb ? bxs[bo + q] : 0.0; rby[r] = q < nb ? bys[bo + q] : 0.0;
+        }
       }
 #pragma unroll
       for (int r = 0; r < NIT; r++) {
@@ -1197,9 +1274,9 @@ __global__ void sz_k_items_clear(State S) {
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < sg.n; t += gridDim.x * blockDim.x) {
       // size class of the item: which narrow-phase variant takes it
       const Item it = item_of(S, sg, t);
-      const int nb = it.is_pair ? S.voff[it.j + 1] - S.voff[it.j] : S.eoff[it.e + 1] - S.eoff[it.e];
+      const int nb = it.nb;
       S.it_info[it.info] = make_int2(0, it.rows);
-      int na = S.voff[it.i + 1] - S.voff[it.i];
+      int na = it.na;
       int big = na > nb ? na : nb;
       int cls = big <= NARROW_CAP0 ? 0 : (big <= NARROW_CAP1 ? 1 : 2);
       if (cls > 0) atomicMax(&S.cnt[C_ITEMCLASS], cls);
@@ -1695,7 +1772,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
   const double wall[4] = { S.eval[0], S.eval[1], S.eval[2], S.eval[3] };
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
     const int st0 = gl_fill >= 0 ? S.status[i] : SZ_ACTIVE, ngh0 = gl_fill >= 0 ? S.ngh[i] : 0;
-    const double rmx = MOVE && gl_fill >= 0 ? S.rmax[i] : 0.0;
+    const double rmx = MOVE && (gl_fill >= 0 || S.rec32) ? S.rmax[i] : 0.0;
     // Memory order is the whole cost of this kernel (a store in between keeps the compiler from hoisting the
     // loads behind it, and every batch of loads is one HBM round trip): everything is read first -- the
     // columns, then what their values address (contact rows, ring) -- then computed, then stored.
@@ -1710,11 +1787,17 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
     const double fxOA = S.fxOA[i], fyOA = S.fyOA[i], trqOA = S.trqOA[i];
     double sa0[4];
     for (int k = 0; k < 4; k++) sa0[k] = S.sa[i * 4 + k];
-    const int o = MOVE ? S.voff[i] : 0, n = MOVE ? S.voff[i + 1] - o : 0;
+    const int o = MOVE ? ring_off(S, i) : 0, n = MOVE ? ring_n(S, i) : 0;
+    const bool body = MOVE && S.body_rings;           // the ring in its body frame (fp32), pose in fp64: nothing to rewrite
     double px[MOVE ? MV_RING : 1], py[MOVE ? MV_RING : 1];
     if (MOVE) {
+      if (body) {
 #pragma unroll
-      for (int k = 0; k < MV_RING; k++) { px[k] = k < n ? S.vx[o + k] : 0.0; py[k] = k < n ? S.vy[o + k] : 0.0; }
+        for (int k = 0; k < MV_RING; k++) { const float2 b = k < n ? S.ring32[o + k] : make_float2(0.f, 0.f); px[k] = (double)b.x; py[k] = (double)b.y; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < MV_RING; k++) { px[k] = k < n ? S.vx[o + k] : 0.0; py[k] = k < n ? S.vy[o + k] : 0.0; }
+      }
     }
     // calc_stress! (update_floe.jl:392-414): as floe_stress(), on the values read above
     double s11 = 0, s12 = 0, s21 = 0, s22 = 0;
@@ -1781,8 +1864,11 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
 #pragma unroll
       for (int k = 0; k < MV_RING; k++) {
         if (k < n) {
-          const double x = px[k] + (-cx), y = py[k] + (-cy);
-          const double xr = cda * x - sda * y, yr = sda * x + cda * y;
+          // world position of the vertex after the move: the reference's rotate-about-the-centroid-then-translate on the
+          // old world ring, or -- body-frame rings -- the new pose applied to the constant body offsets
+          const double x = body ? px[k] : px[k] + (-cx), y = body ? py[k] : py[k] + (-cy);
+          const double rc = body ? cal : cda, rs = body ? sal : sda;
+          const double xr = rc * x - rs * y, yr = rs * x + rc * y;
           const double mx = xr + (cx + dx), my = yr + (cy + dy);
           if (k > 0) {
             const double x1 = ax + (-ncx), y1 = ay + (-ncy), x2 = mx + (-ncx), y2 = my + (-ncy);
@@ -1792,7 +1878,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
             const double ud = u2 - u1, vd = v2 - v1;
             e11 += ud * yd; e12 += ud * xd + vd * yd; e22 += vd * xd;
           }
-          S.vx[o + k] = mx; S.vy[o + k] = my;
+          if (!body) { S.vx[o + k] = mx; S.vy[o + k] = my; }
           bx0 = fmin(bx0, mx); bx1 = fmax(bx1, mx); by0 = fmin(by0, my); by1 = fmax(by1, my);
           ax = mx; ay = my;
         }
@@ -1802,6 +1888,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
       const double d = 2 * area;
       S.strain[i * 4 + 0] = e11 / d; S.strain[i * 4 + 1] = e12 / d; S.strain[i * 4 + 2] = e12 / d; S.strain[i * 4 + 3] = e22 / d;
       S.cx[i] = ncx; S.cy[i] = ncy;
+      if (S.rec32) rec32_store(S, i, ncx, ncy, rmx, bx0, bx1, by0, by1);
       if (bin) cell_insert(S, geo, i, ncx, ncy);
       if (gl_fill >= 0) {
         const int gf = ghost_flag_of(wall, S.any_periodic_ew, S.any_periodic_ns, ncx, ncy, rmx, bx0, bx1, by0, by1, (frc_rm ? SZ_REMOVE : st0) == SZ_ACTIVE);
@@ -1875,7 +1962,10 @@ __global__ void __launch_bounds__(256) sz_k_move_strain(State S, int strain_only
       bx0 = fmin(bx0, mx); bx1 = fmax(bx1, mx); by0 = fmin(by0, my); by1 = fmax(by1, my);
     }
     bx0 = gmin<G>(bx0); bx1 = gmax<G>(bx1); by0 = gmin<G>(by0); by1 = gmax<G>(by1);
-    if (gl == 0 && !strain_only) { S.bbx0[i] = bx0; S.bbx1[i] = bx1; S.bby0[i] = by0; S.bby1[i] = by1; }
+    if (gl == 0 && !strain_only) {
+      S.bbx0[i] = bx0; S.bbx1[i] = bx1; S.bby0[i] = by0; S.bby1[i] = by1;
+      if (S.rec32) rec32_store(S, i, ncx, ncy, S.rmax[i], bx0, bx1, by0, by1);
+    }
     if (gl == 0) {
       e12 *= 0.5;
       double d = 2 * S.area[i];
@@ -2003,6 +2093,7 @@ __global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* 
     }
     S.osign[g] = ring_signed_area(r + 12, r + 12 + HALO_RING, nv) >= 0.0 ? 1 : -1;
     S.bbx0[g] = x0; S.bbx1[g] = x1; S.bby0[g] = y0; S.bby1[g] = y1;
+    if (S.rec32) rec32_store(S, g, r[3], r[4], r[5], x0, x1, y0, y1);
     if (bin) cell_insert(S, geo, g, r[3], r[4]);
     if (gl_fill >= 0) {
       const double wall[4] = { S.eval[0], S.eval[1], S.eval[2], S.eval[3] };
@@ -2065,10 +2156,10 @@ __global__ void sz_k_stats(State S, long long* out) {
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < mlast; k += gridDim.x * blockDim.x) {
     const int nk = S.n_out[k], mask = S.out_mask[k];
     v[10] += nk; v[11] += __popc(mask);
-    const int nvk = S.voff[k + 1] - S.voff[k];
+    const int nvk = ring_n(S, k);
     for (int r = 0; r < nk; r++) if (mask >> r & 1) {
       const int j = S.nb_out[(size_t)k * MAXNB + r];
-      v[0] += nvk + (S.voff[j + 1] - S.voff[j]);
+      v[0] += nvk + ring_n(S, j);
       v[1] += S.it_info[k * MAXNB + r].x & 0xff;
     }
   }

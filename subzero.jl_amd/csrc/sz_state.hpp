@@ -92,6 +92,16 @@ struct State {
   // ---- mixed precision (sz_set_precision): fp32 copies the forcing kernel reads -- sub-floe points (x, y) and
   // the interleaved lattice (8 floats per node: uo, vo, hf, ua, va, -, -, -)
   float2* s32; float* nodes32;
+  // ---- mixed precision, geometry (sz_set_precision(1), resident steps of single-context runs with small rings): the ring of a
+  // floe is kept ONCE, in its body frame (offsets from the centroid at alpha = 0) as fp32, together with the fp64 pose (centroid,
+  // cos / sin alpha in `trig`); world coordinates are reconstructed in fp64 where a kernel needs them (narrow-phase staging, the
+  // integrator's box and strain), so the integrator does not rewrite rings and ghosts share their parent's ring.  rb_off / rb_n:
+  // ring offset into ring32 and ring size per floe (a ghost: its parent's).  body_rings: this launch works on them (kernarg);
+  // the world rings vx / vy are then stale until sz_k_world_rings rebuilds them (any call that needs them does that first).
+  float2* ring32; int *rb_off, *rb_n; int body_rings;
+  // fp32 broad-phase record per floe {cx, cy, rmax, -} {box x0, x1, y0, y1}: the neighbour search of mixed mode tests candidates
+  // on it with a conservative margin and confirms the survivors with the exact fp64 predicate (the pair list stays bit-exact)
+  float4* rec32;
   // ---- two-way coupling (allocated by sz_set_two_way): per floe the centre cells its sub-floe points fall into
   // (FC_CAP slots per floe: cell id, shift code, sum of -tau_ocn, points), per cell the entries sorted by floe
   int *fc_key, *fc_n, *fc_cnt; signed char* fc_code; double *fc_tx, *fc_ty, *fc_area;

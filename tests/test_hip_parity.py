@@ -605,3 +605,76 @@ def test_size_spectrum_field_and_its_capacity_limit():
     big = _size_spectrum(mk(), 40, 6.0e4)
     with pytest.raises(SzError, match="neighbours"):
         big.timestep_collisions(41, 10)
+
+
+# ---------------------------------------------------------------- mixed precision (BASELINE configs[4])
+def _mixed_vs_f64(cfg, steps):
+    from subzero_jl_amd import fields
+    h64 = fields.build_world(mk(), cfg); h32 = fields.build_world(mk(), cfg)
+    h32.set_precision("mixed")
+    h64.run(steps, 0, cfg["dt"], coupling_dt=1, stop_on_tags=False); h32.run(steps, 0, cfg["dt"], coupling_dt=1, stop_on_tags=False)
+    return h64, h32
+
+
+def _mixed_acceptance(h64, h32, cfg):
+    """The reference has no Float32 answers (documentation.md:25: only Float64 is tested and supported), so mixed precision
+    -- fp32 broad-phase records with fp64 confirmation, fp32 body-frame rings + fp64 pose with the narrow-phase predicates
+    in fp64 on the reconstructed coordinates, fp32 per-point forcings -- is held to the engine's own fp64 path:
+      * the pair list (bounding-circle test, Dict rule) is the fp64 one BIT FOR BIT while the positions agree;
+      * discrete decisions of the narrow phase (rows per pair, partner of every row) agree on >= 99.9 % of the pairs;
+      * on the agreeing pairs forces agree to 1e-5 relative above a geometric floor: a ring vertex reconstructed from fp32
+        body offsets is off by <= 1 mm (half an fp32 spacing at 16 km), which moves an overlap area by <= contact length x 1 mm;
+      * state: velocities to 1e-5 and angular velocities to 2e-4 of the column's scale (contact forces that differ by 1e-5
+        move them that much), positions to a centimetre."""
+    o64, r64 = h64.interactions(); o32, r32 = h32.interactions()
+    n = len(o64) - 1
+    c64, c32 = np.diff(o64), np.diff(o32)
+    same = c64 == c32
+    for i in np.nonzero(same)[0]:
+        if c64[i] and not np.array_equal(r64[o64[i]:o64[i + 1], 0], r32[o32[i]:o32[i + 1], 0]):
+            same[i] = False
+    assert same.mean() >= 0.999, same.mean()
+    idx = np.nonzero(same & (c64 > 0))[0]
+    a = np.concatenate([r32[o32[i]:o32[i + 1]] for i in idx]) if len(idx) else np.zeros((0, 7))
+    b = np.concatenate([r64[o64[i]:o64[i + 1]] for i in idx]) if len(idx) else np.zeros((0, 7))
+    if len(b):
+        per_area = np.max(np.hypot(b[:, 1], b[:, 2]) / b[:, 6])
+        floor = per_area * (4.0 * np.sqrt(cfg["derived"]["area"].max())) * 2e-3          # contact length <= the floe's size, 2 x 1 mm
+        for col in (1, 2):
+            parity.assert_elementwise(f"force column {col}", a[:, col], b[:, col], 1e-5, floor)
+    for k, tol in (("u", 1e-5), ("v", 1e-5), ("xi", 2e-4)):       # (xi: torques are lever arm x force, the force points move by millimetres)
+        assert np.max(np.abs(h32.get(k) - h64.get(k))) <= tol * np.max(np.abs(h64.get(k))), k
+    assert np.max(np.abs(h32.get("cx") - h64.get("cx"))) < 1e-2 and np.max(np.abs(h32.get("cy") - h64.get("cy"))) < 1e-2
+    return len(b)
+
+
+def test_mixed_precision_dense_field():
+    """contacts everywhere: one step from identical state (pair list bit-exact), then the acceptance criterion after 5"""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=2000, seed=61)
+    h64, h32 = _mixed_vs_f64(cfg, 1)
+    assert parity.compare_pairs(h32, h64) > 2000                    # bit-exact: same positions, fp64-confirmed circle test
+    assert _mixed_acceptance(h64, h32, cfg) > 1000
+    h64, h32 = _mixed_vs_f64(cfg, 5)
+    _mixed_acceptance(h64, h32, cfg)
+    # it really ran on body-frame rings: the rings that come back are rebuilt from the fp32 offsets (not bit-equal), to a millimetre
+    x64, x32 = h64.rings()[1], h32.rings()[1]
+    assert not np.array_equal(x64, x32) and np.max(np.abs(x64 - x32)) < 1.1e-2
+    # process-mode calls and further batches go on from the rebuilt rings
+    for w in (h64, h32):
+        w.add_ghosts(); w.timestep_collisions(2000, cfg["dt"]); w.remove_ghosts(2000); w.timestep_floe_properties(cfg["dt"])
+        w.run(3, 6, cfg["dt"], coupling_dt=1, stop_on_tags=False)
+    _mixed_acceptance(h64, h32, cfg)
+
+
+def test_mixed_precision_configs4_sparse_100k():
+    """BASELINE configs[4]: 100 000 floes at 25 % concentration (broad-phase compaction stress), mixed precision against the
+    fp64 path: pair list bit-exact after the first step, the acceptance criterion after 10"""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=100000, seed=12347, concentration=0.25)
+    h64, h32 = _mixed_vs_f64(cfg, 1)
+    a, b = h32.pairs(), h64.pairs()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    h64.run(9, 1, cfg["dt"], coupling_dt=1, stop_on_tags=False); h32.run(9, 1, cfg["dt"], coupling_dt=1, stop_on_tags=False)
+    _mixed_acceptance(h64, h32, cfg)
+    assert h32.stats()["n_trace_fail"] == 0
