@@ -1064,6 +1064,9 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
   const bool useq = CLS == 0 && !SCAN && queue != 0;       // (the larger variants look at every item of their segment: static rounds)
   const int rb = (int)(blockIdx.x / NSEG), nbq = ((int)gridDim.x + NSEG - 1 - qk) / NSEG;    // this workgroup's rank in its segment, workgroups per segment
   const int limit = nitems;
+  // (measured and dropped: spreading the only round of a small field over ALL resident workgroups -- 6 to 7 items per wavefront
+  //  instead of 8 -- made the launch 18 % SLOWER, 47 -> 56 us at 10 k floes: a SIMD issues the instruction streams of its
+  //  wavefronts one after the other, and a wavefront's stream is as long with 6 items as with 8)
   for (int t0 = rb * STRIDE; t0 < limit;) {
    unsigned long long todo = 1;
    if (SCAN) {
