@@ -636,6 +636,8 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_STATIC_GRID")) c->no_static_grid = atoi(e) == 0;
   if (const char* e = getenv("SZ_BODY_RINGS")) c->no_body_rings = atoi(e) == 0;
   if (const char* e = getenv("SZ_XCD")) c->S.xcd_neigh = atoi(e) != 0 ? 1 : 0;
+  c->S.xcd_forcing = 0;          // measured: no change at 10 k floes, 159 -> 203 us at 100 k
+  if (const char* e = getenv("SZ_XCD_FORCING")) c->S.xcd_forcing = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("SZ_GHOST_LIST")) { c->no_ghost_list = atoi(e) == 0; if (atoi(e) > 1) c->gl_max = atoi(e); }
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     // lo = least urgent, hi = most urgent

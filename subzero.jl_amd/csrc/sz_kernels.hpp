@@ -764,6 +764,23 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int nblk, int nact) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
 }
 
+// the same for workgroups [first, first + nblk) of a launch (horizontal fusion: the forcing workgroups come after the neighbour
+// search's): the XCD label is that of the PHYSICAL workgroup id, the rank counts the workgroups of the range on that XCD
+__device__ __forceinline__ int xcd_contiguous_from(int phys, int first, int nblk, int nact) {
+  const int x = phys % 8;
+  const int f0 = first + ((x - first % 8) + 8) % 8;            // first workgroup of the range on XCD x
+  const int idx = (phys - f0) / 8;
+  // workgroups of the range per XCD: labels in the range's own order are (x - first) mod 8
+  const int lx = ((x - first % 8) + 8) % 8;
+  if (nact <= nblk) {
+    const int q = nact / 8, r = nact % 8;
+    const int cnt = q + (lx < r ? 1 : 0), start = lx < r ? lx * (q + 1) : r * (q + 1) + (lx - r) * q;
+    return idx < cnt ? start + idx : -1;
+  }
+  const int q = nblk / 8, r = nblk % 8;
+  return (lx < r ? lx * (q + 1) : r * (q + 1) + (lx - r) * q) + idx;
+}
+
 // Work list of the narrow phase: NSEG segments of capPairs / NSEG pair items, filled by the neighbour search (segment =
 // workgroup index modulo NSEG, one tail counter per segment a cache line apart: same-address atomics serialise chip-wide).
 // The element items of a step (el_floe / el_elem, compact) are dealt out to the segments round robin.  Item t of
@@ -1488,8 +1505,11 @@ constexpr int TW_PMAX = 512;    // sub-floe points per floe with two-way couplin
 constexpr int TW_FPB = 4;       // floes per workgroup of the two-way variant (128 threads)
 // pmax (two-way only): sub-floe points per floe the launch provides LDS for (dynamic: 21 bytes per point and floe;
 // the host sizes it from the largest floe, so that as many floes as possible are in flight per CU)
+// bid / nblk: rank and number of the forcing workgroups; first: physical id of the first of them in the launch.  The floes of one
+// XCD's workgroups are a contiguous index range (= a region in space): a lattice node is then fetched by one or two XCDs' L2
+// instead of all eight
 template <bool TW>
-__device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid, int nblk, int pmax = 0) {
+__device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid, int nblk, int pmax = 0, int first = 0) {
   extern __shared__ double tw_lds[];
   constexpr int FG = TW ? FRC_G : FRC_PLAIN;      // lanes per floe
   int lane = threadIdx.x % FG, wpb = blockDim.x / FG, wid = threadIdx.x / FG;
@@ -1504,7 +1524,8 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
   int N = S.cnt[C_NOWN];
   int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
   double cturn = cos(P.turn), sturn = sin(P.turn);
-  for (int i = bid * wpb + wid; i < N; i += nblk * wpb) {
+  const int vb0 = S.xcd_forcing ? xcd_contiguous_from(first + bid, first, nblk, (N + wpb - 1) / wpb) : bid;
+  for (int i = vb0 < 0 ? N : vb0 * wpb + wid; i < N; i += nblk * wpb) {
     double cxf = S.cx[i], cyf = S.cy[i], u = S.u[i], v = S.v[i], xi = S.xi[i];
     double ca = S.trig[2 * i], sa = S.trig[2 * i + 1];   // cos(alpha), sin(alpha)
     double ma_ratio = S.mass[i] / S.area[i];
@@ -1659,14 +1680,15 @@ __device__ __forceinline__ float sample_field32(const float* nodes, int f, const
   float c1 = (1.0f - ty) * nodes[(size_t)c.o10 * 8 + f] + ty * nodes[(size_t)c.o11 * 8 + f];
   return (1.0f - tx) * c0 + tx * c1;
 }
-__device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, int bid, int nblk) {
+__device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, int bid, int nblk, int first = 0) {
   if (stopped(S)) return;
   int N = S.cnt[C_NOWN];
   int lane = threadIdx.x % FRC_PLAIN, wpb = blockDim.x / FRC_PLAIN, wid = threadIdx.x / FRC_PLAIN;
   int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
   const float cturn = (float)cos(P.turn), sturn = (float)sin(P.turn);
   const float ka = (float)(P.rho_a * P.Cd_ia), ko = (float)(P.rho_o * P.Cd_io);
-  for (int i = bid * wpb + wid; i < N; i += nblk * wpb) {
+  const int vb0 = S.xcd_forcing ? xcd_contiguous_from(first + bid, first, nblk, (N + wpb - 1) / wpb) : bid;
+  for (int i = vb0 < 0 ? N : vb0 * wpb + wid; i < N; i += nblk * wpb) {
     const double cxf = S.cx[i], cyf = S.cy[i], u = S.u[i], v = S.v[i];
     const float uf = (float)u, vf = (float)v, xif = (float)S.xi[i];
     const float ca = (float)S.trig[2 * i], sa = (float)S.trig[2 * i + 1];
@@ -1728,8 +1750,8 @@ __global__ void __launch_bounds__(256) sz_k_forcing_mixed(State S, Params P) { f
 template <int FRC>
 __global__ void __launch_bounds__(256) sz_k_neighbors_forcing(State S, Params P, int nb_neigh) {
   if ((int)blockIdx.x < nb_neigh) neighbors_body<256>(S, blockIdx.x, nb_neigh);
-  else if (FRC == 1) forcing_body<false>(S, P, (int)blockIdx.x - nb_neigh, (int)gridDim.x - nb_neigh);
-  else forcing_mixed_body(S, P, (int)blockIdx.x - nb_neigh, (int)gridDim.x - nb_neigh);
+  else if (FRC == 1) forcing_body<false>(S, P, (int)blockIdx.x - nb_neigh, (int)gridDim.x - nb_neigh, 0, nb_neigh);
+  else forcing_mixed_body(S, P, (int)blockIdx.x - nb_neigh, (int)gridDim.x - nb_neigh, nb_neigh);
 }
 
 // ============================================================================ rigid-body update (A12)

@@ -65,6 +65,7 @@ struct State {
   int step;                  // 1-based index of the step inside the running sz_step batch (0: process-mode call): kernels of
                              // steps after a stop request return at once (stopped(), sz_kernels.hpp)
   int stop_on_tags;          // sz_step: raise C_STOP when a parent is tagged (off with SZ_NO_STOP)
+  int xcd_forcing;           // SZ_XCD_FORCING=1: XCD-contiguous floe ranges in the forcing kernels (A/B switch; default off: slower at 100 k)
   int xcd_neigh;             // SZ_XCD=1: XCD-contiguous floe ranges in the neighbour search too (A/B switch; default off)
   // ---- counters
   int* cnt;
