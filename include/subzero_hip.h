@@ -274,6 +274,9 @@ int sz_set_stream(sz_ctx *ctx, void *hip_stream);
 int sz_comm_unique_id(void *id128);
 int sz_comm_init(sz_ctx *ctx, int32_t nranks, int32_t rank, const void *id128);
 int sz_comm_destroy(sz_ctx *ctx);
+/* one-rank self test of the RCCL binding (run-time loading, communicator of one rank, all-gather, all-reduce, grouped
+   send / receive to self with the stream hand-shake of sz_tile_run): what of the exchange can run on a one-GPU box */
+int sz_comm_selftest(sz_ctx *ctx);
 int sz_comm_allreduce(sz_ctx *ctx, void *d_buf, int64_t n);
 int sz_tile_setup(sz_ctx *ctx, double Lx, double Ly, int32_t periodic_x, int32_t periodic_y, double drift_margin,
                   int32_t rebox_every);

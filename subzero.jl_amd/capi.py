@@ -61,7 +61,7 @@ EXPORTS = [
     "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms",
     "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_forcing", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps",
     "sz_get_boundary_rects", "sz_debug_match_vertices",
-    "sz_comm_unique_id", "sz_comm_init", "sz_comm_destroy", "sz_comm_allreduce", "sz_tile_setup", "sz_tile_run",
+    "sz_comm_unique_id", "sz_comm_init", "sz_comm_destroy", "sz_comm_selftest", "sz_comm_allreduce", "sz_tile_setup", "sz_tile_run",
 ]
 
 EUL_PARTIAL = 17      # SZ_EUL_PARTIAL: per-cell partial fields of sz_eulerian_partial
@@ -141,6 +141,7 @@ def load(build_if_missing=True):
     L.sz_comm_unique_id.argtypes = [C.c_void_p]
     L.sz_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.sz_comm_destroy.argtypes = [C.c_void_p]
+    L.sz_comm_selftest.argtypes = [C.c_void_p]
     L.sz_comm_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.sz_tile_setup.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double, C.c_int32]
     L.sz_tile_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]

@@ -1586,8 +1586,11 @@ Rccl g_rccl;
 constexpr int NCCL_INT32 = 2, NCCL_FLOAT64 = 8, NCCL_SUM = 0;
 bool rccl_load(std::string& err) {
   if (g_rccl.h) return true;
-  const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-  for (const char* n : names) if ((g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  // an RCCL the process already holds comes first (a host framework's: two RCCL builds in one process each bring their own
+  // runtime threads), then the system's
+  const char* names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1" };
+  for (const char* n : names) if ((g_rccl.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+  if (!g_rccl.h) for (const char* n : names) if ((g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
   if (!g_rccl.h) { err = std::string("RCCL not found: ") + dlerror(); return false; }
 #define RSYM(field, name) g_rccl.field = (decltype(g_rccl.field))dlsym(g_rccl.h, name); if (!g_rccl.field) { err = std::string("RCCL symbol missing: ") + name; g_rccl.h = nullptr; return false; }
   RSYM(GetUniqueId, "ncclGetUniqueId") RSYM(CommInitRank, "ncclCommInitRank") RSYM(CommDestroy, "ncclCommDestroy")
@@ -1690,6 +1693,46 @@ int sz_comm_init(sz_ctx* c, int32_t nranks, int32_t rank, const void* id128) {
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_recv, hipEventDisableTiming));
   return SZ_OK;
+}
+// One-rank self test of the RCCL binding (the build box has one GPU, so the multi-rank exchange cannot run there): the
+// run-time binding, ncclGetUniqueId / ncclCommInitRank with the id passed by value, an all-gather, an all-reduce and a
+// grouped send / receive to self on the communication stream with the event hand-shake sz_tile_run uses.  Returns SZ_OK
+// when every buffer holds what it should.
+int sz_comm_selftest(sz_ctx* c) {
+  if (!c) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  if (!rccl_load(c->err)) return SZ_E_STATE;
+  UId id;
+  NCCLCHK(c, g_rccl.GetUniqueId(&id));
+  void* comm = nullptr;
+  NCCLCHK(c, g_rccl.CommInitRank(&comm, 1, id, 0));
+  hipStream_t cs = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIPCHK(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+  HIPCHK(c, hipEventCreateWithFlags(&e0, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+  const int n = 4096;
+  double* d = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d, (size_t)4 * n * sizeof(double)));
+  std::vector<double> h((size_t)4 * n, 0.0);
+  for (int k = 0; k < n; k++) h[k] = 1.0 + k;
+  HIPCHK(c, hipMemcpyAsync(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(cs, e0, 0));
+  int rc = SZ_OK;
+  NCCLCHK(c, g_rccl.GroupStart());
+  NCCLCHK(c, g_rccl.Send(d, (size_t)n, NCCL_FLOAT64, 0, comm, cs));
+  NCCLCHK(c, g_rccl.Recv(d + n, (size_t)n, NCCL_FLOAT64, 0, comm, cs));
+  NCCLCHK(c, g_rccl.GroupEnd());
+  HIPCHK(c, hipEventRecord(e1, cs));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, e1, 0));
+  NCCLCHK(c, g_rccl.AllGather(d + n, d + 2 * n, (size_t)n, NCCL_FLOAT64, comm, c->stream));
+  NCCLCHK(c, g_rccl.AllReduce(d + 2 * n, d + 3 * n, (size_t)n, NCCL_FLOAT64, NCCL_SUM, comm, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < n && rc == SZ_OK; k++)
+    if (h[n + k] != 1.0 + k || h[2 * n + k] != 1.0 + k || h[3 * n + k] != 1.0 + k) { c->err = "RCCL self test: wrong data"; rc = SZ_E_HIP; }
+  (void)hipFree(d); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(cs);
+  (void)g_rccl.CommDestroy(comm);
+  return rc;
 }
 int sz_comm_destroy(sz_ctx* c) {
   if (!c) return SZ_E_ARG;

@@ -198,3 +198,16 @@ def test_halo_drift_is_an_error_not_a_missed_contact():
     # a gather interval that fits the speed is fine
     tw2 = tiles.TiledWorld(cfg, 0, 1, 0, None, backend="library", drift_margin=1500.0, rebox_every=3)
     tw2.run(30, 0, cfg["dt"], coupling_dt=1)
+
+
+def test_rccl_binding_self_test():
+    """what of the library's RCCL path can run on a one-GPU box: run-time binding, a communicator of one rank, all-gather,
+    all-reduce, grouped send / receive to self on the communication stream -- with and without an RCCL already in the process"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n%s"
+            "import subzero_jl_amd; w = subzero_jl_amd.World(0); rc = w.L.sz_comm_selftest(w.h); "
+            "print('rc', rc, w.L.sz_last_error(w.h).decode()); sys.exit(0 if rc == 0 else 1)")
+    for pre in ("", "import torch, torch.distributed\n"):
+        out = subprocess.run([sys.executable, "-c", code % (root, pre)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
