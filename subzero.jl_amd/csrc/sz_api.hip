@@ -818,7 +818,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   }
   DA(blk, std::max(S.capCells, std::max(S.capM, 1024)) / SCAN_B + 1024);
   DA(tagA, S.capM + 1);
-  DA(stamps, 512);
+  DA(stamps, 512 + 8 * 8000);
   trim_pool(c->allocs);
   int h[C_COUNT] = { 0 };
   h[C_M] = M; h[C_N] = N; h[C_NV] = V; h[C_NGHOSTS] = M - N; h[C_NOWN] = N;
@@ -1338,8 +1338,8 @@ int sz_halo_record_doubles(void) { return HALO_REC; }
 int sz_debug_stamps(sz_ctx* c, long long* out16) {
   if (!c || !c->have_floes || !out16) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
-  HIPCHK(c, hipMemcpy(out16, c->S.stamps, 512 * sizeof(long long), hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemset(c->S.stamps, 0, 512 * sizeof(long long)));
+  HIPCHK(c, hipMemcpy(out16, c->S.stamps, (512 + 8 * 8000) * sizeof(long long), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemset(c->S.stamps, 0, (512 + 8 * 8000) * sizeof(long long)));
   return SZ_OK;
 }
 

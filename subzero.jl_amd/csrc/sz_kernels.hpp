@@ -1050,6 +1050,13 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
 #ifdef SZ_STAMPS
   st.on = (CLS == 0 && blockIdx.x == (unsigned)(dbg >> 8) && threadIdx.x == 0); st.log = S.stamps + 1;
 #endif
+  const int qk = (int)(blockIdx.x % NSEG);
+  // the first round's item of this lane group is known without the segment's length: its work-list entry is asked for
+  // together with the length (one dependent round trip less in the launch's chain; an entry past the end is read and ignored)
+  const int t_first = (int)(blockIdx.x / NSEG) * (TPB / G) + (int)(threadIdx.x / G);
+  const bool pre_ok = !(G == 64 && TPB == 64) && t_first < seg_cap(S);
+  int4 pre0 = make_int4(0, 0, 0, 0), pre1 = make_int4(0, 0, 0, 0);
+  if (pre_ok) { const size_t w2 = 2 * ((size_t)qk * seg_cap(S) + t_first); pre0 = S.work[w2]; pre1 = S.work[w2 + 1]; }
   if (CLS > 0 && S.cnt[C_ITEMCLASS] < CLS) return;   // no item needs this (larger) variant this step
   if (stopped(S)) return;
   STAMP(st, 20);
@@ -1062,7 +1069,6 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
   // few thousand cycles (no overlap) and 150 k, so with a static split the slowest workgroup sets the time of a deep launch
   // (narrow kernel 374 -> 242 us at 100 k floes; one head for the whole chip costs ~20 ns per ticket, serialised across the
   // XCDs: measured slower than the static split).  The results do not depend on who runs an item.
-  const int qk = (int)(blockIdx.x % NSEG);
   const Seg sg = seg_of(S, qk);
   const int nitems = sg.n;
   if (gl == 0) { m.err = 0; m.ierr = 0; m.ntracefail = 0; m.nchk = 0; m.nkeep = 0; m.acc[0] = m.acc[1] = 0; m.acc16[0] = m.acc16[1] = m.acc16[2] = 0; }   // acc: work done by this group (in LDS: no register held across the rounds)
@@ -1098,12 +1104,20 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
    }
    while (todo) {
     // ================= phase A: every lane group stages its own item and runs the contact clip
+#ifdef SZ_STAMPS
+    st.tmark = clock64();
+#endif
     int t;
     if (SCAN) { t = t0 + __ffsll((long long)todo) - 1; todo &= todo - 1; }
     else { todo = 0; t = t0 + gi; }
     bool have = t < limit;
     Item it; it.i = 0; it.j = -1; it.e = -1; it.rows = 0; it.info = 0; it.is_pair = true; it.ao = it.na = it.bo = it.nb = 0;
-    if (have) it = item_of(S, sg, t);
+    if (have) {
+      if (pre_ok && t == t_first && t < sg.np) {
+        it.is_pair = true; it.info = pre0.x; it.i = pre0.y; it.j = pre0.z; it.e = -1; it.rows = qk * seg_cap(S) + t;
+        it.ao = pre0.w; it.na = pre1.x; it.bo = pre1.y; it.nb = pre1.z;
+      } else it = item_of(S, sg, t);
+    }
     STAMP(st, 22);
     const bool is_pair = it.is_pair;
     const int i = it.i, j = it.j, e = it.e;
@@ -1186,6 +1200,9 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       for (int r = 0; r < NKI; r++) { const int q = gl + r * G; if (q < 14) m.kin[q] = kv[r]; }
       gsync();
       STAMP(st, 0);
+#ifdef SZ_STAMPS
+      { long long now = clock64(); st.cA1 += now - st.tmark; }
+#endif
       pna = na; pnb = nb; poa = oa; pob = ob; pba = ba; pbb = bb;
       contact_pre(m, gl, na, oa, nb, ob, ba, bb);
     } else if (gl == 0) { m.nkeep = 0; m.nchk = 0; m.ierr = 0; }
@@ -1195,6 +1212,9 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     // to set the kernel's duration).  One loop, ONE call site of clip().
     {
       int total = 0;
+#ifdef SZ_STAMPS
+      long long tA0 = clock64(); (void)tA0;
+#endif
       for (int pass = 0; pass == 0 || (pass - 1) * GPB < total; pass++) {
         bool run = false; int g = gi, q = 0, buf = 0; double ox = 0.0, oy = 0.0;
         if (pass == 0) run = have && !(dbg & 4);
@@ -1210,17 +1230,32 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
             pba = Box{ o.box[0], o.box[1], o.box[2], o.box[3] }; pbb = Box{ o.box[4], o.box[5], o.box[6], o.box[7] };
           }
         }
+#ifdef SZ_STAMPS
+        long long tc0 = clock64();
+#endif
         if (run) clip<G>(mem[g], m, gl, ox, oy, pna, poa, pnb, pob, buf, pba, pbb, st);
+#ifdef SZ_STAMPS
+        if (pass == 0) st.cA2 += clock64() - tc0;
+#endif
         if (pass == 0) {
           if (run) contact_post<G>(m, gl, na, nb, ic, flags, st);
           else if (have && gl == 0) { m.nkeep = 0; m.nchk = 0; m.ierr = 0; m.ff = 0.0; }
           gsync();
           for (int k = 0; k < GPB; k++) total += mem[k].nchk;
+#ifdef SZ_STAMPS
+          { long long now = clock64(); st.cA += now - st.tmark; st.tmark = now; st.ntask += total; int nl = 0; for (int k = 0; k < GPB; k++) nl += mem[k].nx > 0 && mem[k].nkeep > 0; st.nlive += nl; }
+#endif
         } else {
           if (run) check_post<G>(mem[g], m, gl, q, st);
           gsync();
+#ifdef SZ_STAMPS
+          st.npass++;
+#endif
         }
       }
+#ifdef SZ_STAMPS
+      { long long now = clock64(); st.cB += now - st.tmark; st.tmark = now; }
+#endif
     }
     // ================= phase C: friction and the rows of the own item, in region order
     if (have) {
@@ -1246,6 +1281,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     }
    }
 #ifdef SZ_STAMPS
+   { long long now = clock64(); st.cC += now - st.tmark; st.tmark = now; }
    if ((dbg & 16) && !st.pass) { st.pass = 1; continue; }      // timing experiment: the same round again, now with a warm instruction cache
 #endif
    if (useq) {
@@ -1278,6 +1314,13 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       atomicAdd((unsigned long long*)&S.stamps[256 + bkt], 1ull);
       atomicAdd((unsigned long long*)&S.stamps[400 + 2 * mr], (unsigned long long)el);
       atomicAdd((unsigned long long*)&S.stamps[401 + 2 * mr], 1ull);
+      // one record per wavefront (stamps[512 ..]): lifetime | passes of the check loop | check tasks | items with a contact clip that
+      // found crossings | cycles in phase A (staging + contact clip + contact_post), B (checks), C (rows)
+      const unsigned long long slot = atomicAdd((unsigned long long*)&S.stamps[511], 1ull);
+      if (slot < 8000) {
+        long long* r = S.stamps + 512 + slot * 8;
+        r[0] = el; r[1] = st.npass; r[2] = st.ntask; r[3] = st.nlive; r[4] = st.cA; r[5] = st.cB; r[6] = st.cC; r[7] = mr | ((st.cA1 >> 8) << 8) | ((st.cA2 >> 8) << 36);
+      }
     }
   }
 #endif
