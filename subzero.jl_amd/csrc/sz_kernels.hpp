@@ -1893,8 +1893,8 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
     double dy = 1.5 * dt * v - 0.5 * dt * p_dydt;
     double da = 1.5 * dt * xi - 0.5 * dt * p_dalphadt;
     const double al = alpha0 + da;
-    const double cal = cos(al), sal = sin(al);              // for the forcing kernel (32 lanes per floe: not the place for it)
-    const double cda = cos(da), sda = sin(da);
+    double cal, sal, cda, sda;                              // cos / sin alpha for the forcing kernel (32 lanes per floe: not the place for it)
+    sincos(al, &sal, &cal); sincos(da, &sda, &cda);         // (one argument reduction for each pair)
     double dudt = (fxOA + cfx) / mass, dvdt = (fyOA + cfy) / mass;
     double frac = 1.0, au = fabs(dt * dudt), av = fabs(dt * dvdt), h2 = h / 2;
     if (au > h2 && av > h2) {
