@@ -343,7 +343,8 @@ void use_ghost_list(sz_ctx* c) {
   c->gl_valid = true;
 }
 bool ghost_list_wanted(const sz_ctx* c, bool sg) {
-  return sg && !c->no_ghost_list && (c->S.any_periodic_ew || c->S.any_periodic_ns) && c->gl_est <= c->gl_max;
+  // (the list pass gives a parent one wavefront lane per ring point: rings of up to 64 points)
+  return sg && !c->no_ghost_list && (c->S.any_periodic_ew || c->S.any_periodic_ns) && c->gl_est <= c->gl_max && c->max_ring <= 64;
 }
 
 // ---------------------------------------------------------------- pipeline stages

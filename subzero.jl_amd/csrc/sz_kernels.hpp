@@ -368,17 +368,29 @@ __device__ __forceinline__ void copy_floe_row(State& S, int dst, int src) {
 // memory round trips instead of one per ghost and per swap.  The arithmetic is the reference's:
 // a ghost is a copy translated by (+-L, 0) / (0, +-L) (ghosts_on_bounds!, collisions.jl:881-901), the
 // swap translates parent and its own new ghost in opposite directions (:942-950, :994-1000).
-struct Rig { double cx, cy, b0, b1, b2, b3, x0, y0, x1, y1; };    // x1, y1: the lane's second point (rings of 65..128 points)
-__device__ __forceinline__ Rig rig_shift(Rig r, double dx, double dy) {
-  r.cx += dx; r.cy += dy; r.b0 += dx; r.b1 += dx; r.b2 += dy; r.b3 += dy;
-  r.x0 += dx; r.y0 += dy; r.x1 += dx; r.y1 += dy;
+// WIDE: rings of 65..128 points (a second point per lane: x1, y1); the candidate-list pass of the resident steps is compiled
+// without it (rings of at most 64 points) to stay inside the register budget of the launch it rides in
+// The wavefront-uniform part of a row -- centroid and ring box -- is spread over the lanes as well: lane q < 6 carries column q
+// of {cx, cy, bbx0, bbx1, bby0, bby1} in `pv` (a row is then 3 doubles per lane, not 8: four rows are live in the corner case).
+template <bool WIDE> struct RigT { double pv, x0, y0, x1, y1; };
+template <> struct RigT<false> { double pv, x0, y0; };
+__device__ __forceinline__ bool rig_lane_is_x(int lane) { return lane == 0 || lane == 2 || lane == 3; }
+template <bool WIDE>
+__device__ __forceinline__ RigT<WIDE> rig_shift(RigT<WIDE> r, int lane, double dx, double dy) {
+  r.pv += rig_lane_is_x(lane) ? dx : dy;
+  r.x0 += dx; r.y0 += dy;
+  if constexpr (WIDE) { r.x1 += dx; r.y1 += dy; }
   return r;
 }
-__device__ __forceinline__ void rig_store(State& S, int lane, int f, int vo, int n, const Rig& r) {
-  S.cx[f] = r.cx; S.cy[f] = r.cy; S.bbx0[f] = r.b0; S.bbx1[f] = r.b1; S.bby0[f] = r.b2; S.bby1[f] = r.b3;
+__device__ __forceinline__ double* rig_col(const State& S, int lane) {
+  return lane == 0 ? S.cx : lane == 1 ? S.cy : lane == 2 ? S.bbx0 : lane == 3 ? S.bbx1 : lane == 4 ? S.bby0 : S.bby1;
+}
+template <bool WIDE>
+__device__ __forceinline__ void rig_store(State& S, int lane, int f, int vo, int n, const RigT<WIDE>& r) {
+  if (lane < 6) rig_col(S, lane)[f] = r.pv;
   if (S.body_rings) return;                      // the ring is the parent's, in its body frame: only the pose moves
   if (lane < n) { S.vx[vo + lane] = r.x0; S.vy[vo + lane] = r.y0; }
-  if (lane + 64 < n) { S.vx[vo + lane + 64] = r.x1; S.vy[vo + lane + 64] = r.y1; }
+  if constexpr (WIDE) { if (lane + 64 < n) { S.vx[vo + lane + 64] = r.x1; S.vy[vo + lane + 64] = r.y1; } }
 }
 
 // One flagged parent, by a whole wavefront: both passes of add_ghosts! for parent i.  fl: its flags (dx+1 | (dy+1)<<2),
@@ -386,16 +398,20 @@ __device__ __forceinline__ void rig_store(State& S, int lane, int f, int vo, int
 // (storage order), T: the totals, M0 / NV0: first free floe row / ring point; vo, n: the parent's ring.
 // Memory order is the whole cost (every dependent batch is one HBM round trip): everything the parent's row holds is
 // asked for in ONE batch -- the scalar columns one per lane, the ring one point per lane -- and stored afterwards.
+// The up to three ghosts are named registers (no indexed arrays: those went to scratch memory): G0 is the E/W ghost, or the
+// N/S ghost of a parent that has no E/W one; G1 the N/S ghost of G0 and G2 the parent's own N/S ghost (corner parents).
+template <bool WIDE>
 __device__ __forceinline__ void ghost_fill_parent(State& S, const GridGeo& geo, int lane, int i, int fl, int4 sc, int4 T, int M0, int NV0, int bin,
                                                   int vo, int n, const double* wall) {
-  const int dirs[2] = { (fl & 3) - 1, ((fl >> 2) & 3) - 1 };
+  using R = RigT<WIDE>;
+  const int dir0 = (fl & 3) - 1, dir1 = ((fl >> 2) & 3) - 1;
   // ---- loads
   const int ngh_old = S.ngh[i];
-  Rig P;
-  P.cx = S.cx[i]; P.cy = S.cy[i]; P.b0 = S.bbx0[i]; P.b1 = S.bbx1[i]; P.b2 = S.bby0[i]; P.b3 = S.bby1[i];
+  R P;
+  P.pv = lane < 6 ? rig_col(S, lane)[i] : 0.0;
   const bool body = S.body_rings != 0;
   P.x0 = !body && lane < n ? S.vx[vo + lane] : 0.0; P.y0 = !body && lane < n ? S.vy[vo + lane] : 0.0;
-  P.x1 = !body && lane + 64 < n ? S.vx[vo + lane + 64] : 0.0; P.y1 = !body && lane + 64 < n ? S.vy[vo + lane + 64] : 0.0;
+  if constexpr (WIDE) { P.x1 = !body && lane + 64 < n ? S.vx[vo + lane + 64] : 0.0; P.y1 = !body && lane + 64 < n ? S.vy[vo + lane + 64] : 0.0; }
   const double tc = body ? S.trig[2 * i] : 0.0, ts = body ? S.trig[2 * i + 1] : 0.0;
   const double rmx = S.rec32 ? S.rmax[i] : 0.0;
   // the copied scalar columns (deepcopy of the parent, collisions.jl:893): lane q < 10 carries double column q
@@ -405,55 +421,71 @@ __device__ __forceinline__ void ghost_fill_parent(State& S, const GridGeo& geo, 
   const long long idv = S.id[i]; const int stv = S.status[i]; const signed char osv = S.osign[i];
   const long long oki = S.tiled ? S.okey[i] : 0;
   if (ngh_old != 0) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_GHOSTS_PER_PARENT); return; }
-  if (n > 128) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); return; }
-  // ---- the two passes, in registers
-  Rig Gs[MAX_GHOSTS]; int slot[MAX_GHOSTS], vbs[MAX_GHOSTS], gid[MAX_GHOSTS]; long long key[MAX_GHOSTS];
-  int ng = 0; bool moved = false;
-  for (int axis = 0; axis < 2; axis++) {
-    int dir = dirs[axis];
-    if (dir == 0) continue;
-    const int maxb = axis == 0 ? 2 : 0, minb = axis == 0 ? 3 : 1;
-    double maxv = wall[maxb], minv = wall[minb], L = maxv - minv;
-    double t = dir > 0 ? L : -L;
-    double tx = axis == 0 ? t : 0.0, ty = axis == 0 ? 0.0 : t;
-    int gbase = axis == 0 ? M0 + sc.x : M0 + T.x + sc.z;
-    int vb = axis == 0 ? NV0 + sc.y : NV0 + T.y + sc.w;
-    // ghosts of the existing ghosts first, then the parent's (every copy has the parent's ring size)
-    for (int k = 0; k <= ng; k++) {
-      int w = ng + k;
-      Gs[w] = rig_shift(k < ng ? Gs[k] : P, tx, ty);
-      slot[w] = gbase + k; vbs[w] = vb + k * n; gid[w] = k + 1 + ng;
-      key[w] = S.tiled ? ((long long)(axis + 1) << 40) + oki * 4 + k : (long long)(gbase + k);
-    }
-    // parent centroid outside the domain: swap roles with its own new ghost
-    double c = axis == 0 ? P.cx : P.cy;
-    double sp = 0.0;
-    if (c < minv) sp = L; else if (maxv < c) sp = -L;
-    if (sp != 0.0) {
-      double px = axis == 0 ? sp : 0.0, py = axis == 0 ? 0.0 : sp;
-      P = rig_shift(P, px, py); moved = true;
-      Gs[ng + ng] = rig_shift(Gs[ng + ng], -px, -py);
-    }
-    ng = ng + ng + 1;
-  }
-  // ---- stores
-  for (int w = 0; w < ng; w++) {
-    const int g = slot[w];
+  if (n > (WIDE ? 128 : 64)) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); return; }
+  // ---- the two passes, in registers; a ghost is stored as soon as nothing is derived from it any more (at most two
+  // ghosts and the parent are live at a time)
+  auto put = [&](const R& G, int g, int vb, int gid, long long key) {
     if (lane < 10) dcol[g] = dval;
-    if (lane == 10) { S.id[g] = idv; S.ghost_id[g] = (long long)gid[w]; S.okey[g] = key[w]; }
+    if (lane == 10) { S.id[g] = idv; S.ghost_id[g] = (long long)gid; S.okey[g] = key; }
     if (lane == 11) { S.status[g] = stv; S.parent[g] = i; S.ngh[g] = 0; S.osign[g] = osv; }
     if (lane == 12) { S.cfx[g] = 0.0; S.cfy[g] = 0.0; S.ctrq[g] = 0.0; }
-    rig_store(S, lane, g, vbs[w], n, Gs[w]);
+    rig_store<WIDE>(S, lane, g, vb, n, G);
     if (lane == 13) {
       if (body) { S.rb_off[g] = vo; S.rb_n[g] = n; S.trig[2 * g] = tc; S.trig[2 * g + 1] = ts; }
-      else { S.voff[g] = vbs[w]; S.voff[g + 1] = vbs[w] + n; }   // neighbours write the same values: rings are packed back to back
+      else { S.voff[g] = vb; S.voff[g + 1] = vb + n; }   // neighbours write the same values: rings are packed back to back
     }
-    if (lane == 15 && S.rec32) rec32_store(S, g, Gs[w].cx, Gs[w].cy, rmx, Gs[w].b0, Gs[w].b1, Gs[w].b2, Gs[w].b3);
-    if (bin && lane == 14) cell_insert(S, geo, g, Gs[w].cx, Gs[w].cy);
+    const double gcx = __shfl(G.pv, 0), gcy = __shfl(G.pv, 1);
+    if (S.rec32) {
+      const double g0 = __shfl(G.pv, 2), g1 = __shfl(G.pv, 3), g2 = __shfl(G.pv, 4), g3 = __shfl(G.pv, 5);
+      if (lane == 15) rec32_store(S, g, gcx, gcy, rmx, g0, g1, g2, g3);
+    }
+    if (bin && lane == 14) cell_insert(S, geo, g, gcx, gcy);
     if (lane < MAX_GHOSTS) S.gh[g * MAX_GHOSTS + lane] = -1;
+  };
+  int s0 = 0, s1 = 0, s2 = 0;
+  int ng = 0; bool moved = false;
+  R G0 = P;
+  if (dir0 != 0) {                          // E/W: the parent's ghost
+    const double maxv = wall[2], minv = wall[3], L = maxv - minv, t = dir0 > 0 ? L : -L;
+    G0 = rig_shift<WIDE>(P, lane, t, 0.0);
+    s0 = M0 + sc.x;
+    // parent centroid outside the domain: swap roles with its own new ghost
+    double sp = 0.0;
+    { const double pc = __shfl(P.pv, 0); if (pc < minv) sp = L; else if (maxv < pc) sp = -L; }
+    if (sp != 0.0) { P = rig_shift<WIDE>(P, lane, sp, 0.0); moved = true; G0 = rig_shift<WIDE>(G0, lane, -sp, -0.0); }
+    ng = 1;
   }
-  if (moved) { rig_store(S, lane, i, vo, n, P); if (lane == 15 && S.rec32) rec32_store(S, i, P.cx, P.cy, rmx, P.b0, P.b1, P.b2, P.b3); }
-  if (lane < MAX_GHOSTS) S.gh[i * MAX_GHOSTS + lane] = lane < ng ? slot[lane] : -1;
+  if (dir1 != 0) {                          // N/S: ghosts of the existing ghost first, then the parent's (every copy has the parent's ring size)
+    const double maxv = wall[0], minv = wall[1], L = maxv - minv, t = dir1 > 0 ? L : -L;
+    const int gbase = M0 + T.x + sc.z, vb = NV0 + T.y + sc.w;
+    double sp = 0.0;
+    { const double pc = __shfl(P.pv, 1); if (pc < minv) sp = L; else if (maxv < pc) sp = -L; }
+    if (ng == 1) {
+      {
+        const R G1 = rig_shift<WIDE>(G0, lane, 0.0, t);
+        put(G0, s0, NV0 + sc.y, 1, S.tiled ? ((long long)1 << 40) + oki * 4 : (long long)s0);
+        s1 = gbase;
+        put(G1, s1, vb, 2, S.tiled ? ((long long)2 << 40) + oki * 4 : (long long)gbase);
+      }
+      R G2 = rig_shift<WIDE>(P, lane, 0.0, t); s2 = gbase + 1;
+      if (sp != 0.0) { P = rig_shift<WIDE>(P, lane, 0.0, sp); moved = true; G2 = rig_shift<WIDE>(G2, lane, -0.0, -sp); }
+      put(G2, s2, vb + n, 3, S.tiled ? ((long long)2 << 40) + oki * 4 + 1 : (long long)(gbase + 1));
+      ng = 3;
+    } else {
+      G0 = rig_shift<WIDE>(P, lane, 0.0, t); s0 = gbase;
+      if (sp != 0.0) { P = rig_shift<WIDE>(P, lane, 0.0, sp); moved = true; G0 = rig_shift<WIDE>(G0, lane, -0.0, -sp); }
+      put(G0, s0, vb, 1, S.tiled ? ((long long)2 << 40) + oki * 4 : (long long)gbase);
+      ng = 1;
+    }
+  } else if (ng == 1) put(G0, s0, NV0 + sc.y, 1, S.tiled ? ((long long)1 << 40) + oki * 4 : (long long)s0);
+  if (moved) {
+    rig_store<WIDE>(S, lane, i, vo, n, P);
+    if (S.rec32) {
+      const double q0 = __shfl(P.pv, 0), q1 = __shfl(P.pv, 1), q2 = __shfl(P.pv, 2), q3 = __shfl(P.pv, 3), q4 = __shfl(P.pv, 4), q5 = __shfl(P.pv, 5);
+      if (lane == 15) rec32_store(S, i, q0, q1, rmx, q2, q3, q4, q5);
+    }
+  }
+  if (lane < MAX_GHOSTS) S.gh[i * MAX_GHOSTS + lane] = lane < ng ? (lane == 0 ? s0 : lane == 1 ? s1 : s2) : -1;
   if (lane == 0) S.ngh[i] = ng;
 }
 
@@ -496,7 +528,7 @@ __global__ void __launch_bounds__(256) sz_k_ghost_fill(State S, int committed, i
       const int i = __shfl(mine, src_lane);
       const int fl = __shfl(flm, src_lane);
       const int vo = S.voff[i];
-      ghost_fill_parent(S, geo, lane, i, fl, S.gscan4[i], T, M0, NV0, bin, vo, S.voff[i + 1] - vo, wall);
+      ghost_fill_parent<true>(S, geo, lane, i, fl, S.gscan4[i], T, M0, NV0, bin, vo, S.voff[i + 1] - vo, wall);
     }
   }
 }
@@ -568,7 +600,7 @@ __global__ void __launch_bounds__(256) sz_k_ghost_list(State S, int list, int bi
       S.cnt[C_NGCAND + (1 - list)] = 0;              // the list this step's integrator fills
     }
     if (!fits || e >= n) break;
-    ghost_fill_parent(S, geo, lane, mine.x, mine.y, ex, T, N, NV0, bin, mine.w, mine.z, wall);
+    ghost_fill_parent<false>(S, geo, lane, mine.x, mine.y, ex, T, N, NV0, bin, mine.w, mine.z, wall);
   }
 }
 // mixed precision: the rings of the parents into their body frame (offsets from the centroid at alpha = 0, fp32) ...
