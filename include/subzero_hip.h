@@ -219,6 +219,10 @@ int sz_step(sz_ctx *ctx, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t cou
 int sz_profile_enable(sz_ctx *ctx, int32_t on);
 int sz_profile_reset(sz_ctx *ctx);
 int sz_kernel_time_ms(sz_ctx *ctx, int32_t kclass, double *ms, int64_t *launches);
+/* which launch evaluated the forcings (timestep_coupling!, coupling.jl:1705) in the steps of the last sz_step: 0 their own,
+   1 the neighbour search's, 2 the narrow phase's first variant (class SZ_K_NARROW then times both: a small field's narrow
+   phase is one round with a long tail, and the forcings run in that tail), -1 no coupling step yet */
+int sz_forcing_launch(sz_ctx *ctx, int32_t *where);
 
 /* ---- multi-GPU halo support (no counterpart in the single-process reference:
    its periodic ghost floes, collisions.jl:881-1047, are the same pattern inside one address

@@ -58,7 +58,7 @@ EXPORTS = [
     "sz_upload_interactions", "sz_calc_stress", "sz_calc_strain",
     "sz_set_two_way", "sz_set_temps", "sz_download_ocean_stress", "sz_two_way_partial", "sz_two_way_finish", "sz_set_precision",
     "sz_eulerian_data", "sz_eulerian_partial", "sz_eulerian_finish", "sz_simplify_check",
-    "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms",
+    "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms", "sz_forcing_launch",
     "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_forcing", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps",
     "sz_get_boundary_rects", "sz_debug_match_vertices",
     "sz_comm_unique_id", "sz_comm_init", "sz_comm_destroy", "sz_comm_selftest", "sz_comm_allreduce", "sz_tile_setup", "sz_tile_run",
@@ -126,6 +126,7 @@ def load(build_if_missing=True):
     L.sz_profile_enable.argtypes = [C.c_void_p, C.c_int32]
     L.sz_profile_reset.argtypes = [C.c_void_p]
     L.sz_kernel_time_ms.argtypes = [C.c_void_p, C.c_int32, _dp, _lp]
+    L.sz_forcing_launch.argtypes = [C.c_void_p, _ip]
     L.sz_tile_enable.argtypes = [C.c_void_p, _lp, C.c_double, C.c_double]
     L.sz_owned_box.argtypes = [C.c_void_p, _dp]
     L.sz_halo_record_doubles.argtypes = []

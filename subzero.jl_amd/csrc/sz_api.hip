@@ -89,6 +89,9 @@ struct sz_ctx {
   bool two_way = false; int tw_dt = 10; int tw_capM = 0; size_t tw_ncell = 0; bool temps_set = false;
   Pool tw_allocs, tw_field_allocs;
   // static broad-phase grid of the resident steps (fixed by the host: no bounds reduction per step)
+  int forcing_where = -1;           // sz_forcing_launch
+  int fuse_forcing_mode = 0;        // ... 1: in the neighbour launch, 2: in the narrow launch (its tail), 0: by size -- the narrow launch while the narrow phase is one
+                                    // round with a long tail (measured better up to 20 k floes, even at 40 k, worse at 65 k); SZ_FUSE_FORCING=1|2 forces one
   bool fuse_forcing = true;         // forcings inside the neighbour launch (sz_k_neighbors_forcing); SZ_FUSE_FORCING=0: own launch
   bool fused_move = true;           // integrate + move/strain in one thread-per-floe launch when rings are small (-2 us at 10k); SZ_FUSED_MOVE=0: two launches
   bool no_queue = false;            // SZ_NARROW_QUEUE=0: static split of the narrow items over the workgroups
@@ -408,7 +411,8 @@ void stage_elems(sz_ctx* c, bool enabled) {
   t.end();
 }
 
-void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = false) {
+// frc: the step's forcings ride in the launch of the first variant (0: no, 1: fp64, 2: mixed precision)
+void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = false, int frc = 0) {
   State& S = c->S;
   // dynamic rounds (see sz_k_narrow) where the queue heads were just cleared (static-grid steps); SZ_NARROW_QUEUE=0: off
   const int queue = c->no_queue ? 0 : 1;      // (the reduce kernel resets the queue heads after every narrow phase)
@@ -422,7 +426,7 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = 
     Timed t(c, SZ_K_NARROW);
     constexpr int G = NARROW_G, TPB = 64;
     // 160 VGPRs (3 wavefronts per SIMD) and 16 KB of LDS per workgroup: 10 workgroups = 80 items in flight per CU
-    auto kern = sz_k_narrow<G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3>;
+    auto kern = sz_k_narrow<G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 0>;
     int& grid = c->narrow_grid0;
     if (grid == 0) {       // as many workgroups as the chip holds at once, so that every one of them runs the same number of rounds
       int per_cu = 0, cus = 0;
@@ -432,10 +436,13 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = 
       if (const char* e = getenv("SZ_NARROW_GRID")) { int v = atoi(e); if (v > 0) grid = v; }
       if (getenv("SZ_VERBOSE")) fprintf(stderr, "[subzero-hip] narrow: %d workgroups per CU x %d CUs\n", per_cu, cus);
     }
-    hipLaunchKernelGGL(kern, dim3(grid_for(capItems, TPB / G, grid)), dim3(TPB), 0,
-                       c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue);
+    const int nbn = grid_for(capItems, TPB / G, grid);
+    const int nbf = frc ? grid_for(S.capM, TPB / FRC_PLAIN, 32768) : 0;
+    if (frc == 1) hipLaunchKernelGGL((sz_k_narrow<G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 1>), dim3(nbn + nbf), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, nbf);
+    else if (frc == 2) hipLaunchKernelGGL((sz_k_narrow<G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 2>), dim3(nbn + nbf), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, nbf);
+    else hipLaunchKernelGGL(kern, dim3(nbn), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0);
     if (c->dbg & 8)       // timing experiment: the same launch again (same results) -- how much of a launch is a cold instruction cache?
-      hipLaunchKernelGGL(kern, dim3(grid_for(capItems, TPB / G, grid)), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue);
+      hipLaunchKernelGGL(kern, dim3(nbn), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0);
     t.end();
   }
   {
@@ -444,9 +451,9 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = 
     Timed t(c, K_NARROW_LARGE);
     if (larger)
       hipLaunchKernelGGL((sz_k_narrow<16, NARROW_CAP1, 16, 80, 6, 64, NARROW_CAP0, 1>), dim3(grid_for(capItems, 4, 2048)), dim3(64), 0,
-                         c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue);
+                         c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0);
     hipLaunchKernelGGL((sz_k_narrow<64, NARROW_CAP2, 64, 320, 16, 64, NARROW_CAP1, 2>), dim3(grid_for(capItems, 1, larger ? 2048 : 256)), dim3(64), 0,
-                       c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue);
+                       c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0);
     t.end();
   }
 }
@@ -460,10 +467,11 @@ void stage_reduce(sz_ctx* c, int mirror, int n_init, int dt) {
   t.end();
 }
 
-void collisions(sz_ctx* c, int n_init, int dt, bool commit_ghosts = false, bool static_grid = false, bool fuse_forcing = false) {
-  stage_broad(c, commit_ghosts, static_grid, fuse_forcing);
+// fuse_forcing: the step's forcings ride in another launch: 1 the neighbour search's, 2 the narrow phase's
+void collisions(sz_ctx* c, int n_init, int dt, bool commit_ghosts = false, bool static_grid = false, int fuse_forcing = 0) {
+  stage_broad(c, commit_ghosts, static_grid, fuse_forcing == 1);
   stage_elems(c, true);
-  stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, static_grid);
+  stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, static_grid, fuse_forcing == 2 ? (c->precision == 1 ? 2 : 1) : 0);
   stage_reduce(c, 1, n_init, dt);
 }
 
@@ -633,7 +641,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_NARROW_QUEUE")) c->no_queue = atoi(e) == 0;
   if (const char* e = getenv("SZ_FUSED_MOVE")) c->fused_move = atoi(e) != 0;
   if (const char* e = getenv("SZ_TW_GENERAL_CLIP")) c->tw_general_clip = atoi(e) != 0;
-  if (const char* e = getenv("SZ_FUSE_FORCING")) c->fuse_forcing = atoi(e) != 0;
+  if (const char* e = getenv("SZ_FUSE_FORCING")) { c->fuse_forcing = atoi(e) != 0; if (atoi(e) > 0) c->fuse_forcing_mode = atoi(e) >= 2 ? 2 : 1; }
   if (const char* e = getenv("SZ_STATIC_GRID")) c->no_static_grid = atoi(e) == 0;
   if (const char* e = getenv("SZ_BODY_RINGS")) c->no_body_rings = atoi(e) == 0;
   if (const char* e = getenv("SZ_XCD")) c->S.xcd_neigh = atoi(e) != 0 ? 1 : 0;
@@ -1248,7 +1256,9 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     if (coupling && !overlap && !fuse) stage_forcing(c, dt);
     if (coll) stage_ghosts(c, true, sg, gl);
     if (overlap) stage_forcing_fork(c);
-    if (coll) collisions(c, c->hostN, dt, periodic && !sg, sg, fuse);
+    const int fmode = !fuse ? 0 : c->fuse_forcing_mode ? c->fuse_forcing_mode : (c->hostN <= 30000 ? 2 : 1);
+    if (coupling) c->forcing_where = fmode;
+    if (coll) collisions(c, c->hostN, dt, periodic && !sg, sg, fmode);
     if (overlap) stage_forcing_join(c);
     stage_integrate(c, dt, !coll, coupling, sg, gl ? 1 - c->gl_cur : -1);
     if (gl) c->gl_cur ^= 1;
@@ -1284,6 +1294,11 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
 int sz_profile_enable(sz_ctx* c, int32_t on) {
   if (!c) return SZ_E_ARG;
   c->pmask = on == 1 ? ~0u : on > 1 ? (unsigned)on >> 1 : 0u;
+  return SZ_OK;
+}
+int sz_forcing_launch(sz_ctx* c, int32_t* where) {
+  if (!c || !where) return SZ_E_ARG;
+  *where = c->forcing_where;
   return SZ_OK;
 }
 int sz_profile_reset(sz_ctx* c) {

@@ -1074,9 +1074,22 @@ __global__ void __launch_bounds__(SCAN_B) sz_k_elem_scan_fill(State S, unsigned 
 // items [0, P): floe-floe pairs; [P, P+Q): floe-element items.  SMALL kernels take the items
 // whose rings both fit LO..CAP points.
 // WPE: wavefronts per SIMD the kernel is compiled for (register budget 512 / WPE)
-template <int G, int CAP, int KC, int RC, int RM, int TPB, int LO, int CLS, int WPE = 1>
-__global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int dt, double ff_max_overlap, double fd_max_overlap, int dbg, int queue) {
+// FRC / nbf: the step's forcings ride in this launch -- the last nbf workgroups evaluate them (FRC 1: fp64, 2: mixed precision).
+// Workgroups are handed out in index order: the narrow ones fill the chip first, the forcing ones move in as those finish.  The
+// narrow phase of a small field is ONE round whose length is set by its slowest wavefront (~47 us at 10 k floes, most
+// wavefronts are done after 20): the forcings (22 us as a launch of their own) run in that tail instead of beside the neighbour search.
+template <bool TW>
+__device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid, int nblk, int pmax, int first);
+__device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, int bid, int nblk, int first);
+template <int G, int CAP, int KC, int RC, int RM, int TPB, int LO, int CLS, int WPE = 1, int FRC = 0>
+__global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int dt, double ff_max_overlap, double fd_max_overlap, int dbg, int queue, int nbf) {
   constexpr int GPB = TPB / G;
+  const int nblk = (int)gridDim.x - (FRC != 0 ? nbf : 0);       // the narrow workgroups
+  if (FRC != 0 && (int)blockIdx.x >= nblk) {
+    if (FRC == 1) forcing_body<false>(S, P, (int)blockIdx.x - nblk, nbf, 0, nblk);
+    else forcing_mixed_body(S, P, (int)blockIdx.x - nblk, nbf, nblk);
+    return;
+  }
   static_assert(4 * KC <= 2 * RC, "raw crossing slots alias reg[1]");
   Stamps st; STAMP_INIT(st);
 #ifdef SZ_STAMPS
@@ -1108,7 +1121,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     // housekeeping of the step (the neighbour search has consumed the cells; the integrator fills them again): cell counts
     // and overflow heads cleared, the guard counters of the coming update reset
     const int ncells = (int)S.bounds[4] * (int)S.bounds[5];
-    for (int q = blockIdx.x * TPB + threadIdx.x; q <= ncells; q += gridDim.x * TPB) { S.cell_cnt[q] = 0; S.cell_ovf[q] = 0; }
+    for (int q = blockIdx.x * TPB + threadIdx.x; q <= ncells; q += nblk * TPB) { S.cell_cnt[q] = 0; S.cell_ovf[q] = 0; }
     if (blockIdx.x == 0) for (int q = threadIdx.x; q < WARN_SLOTS * 4; q += TPB) S.warn[(q >> 2) * 32 + (q & 3)] = 0;
   }
   STAMP(st, 21);
@@ -1117,7 +1130,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
   constexpr bool SCAN = (G == 64 && TPB == 64);
   constexpr int STRIDE = SCAN ? 64 : GPB;
   const bool useq = CLS == 0 && !SCAN && queue != 0;       // (the larger variants look at every item of their segment: static rounds)
-  const int rb = (int)(blockIdx.x / NSEG), nbq = ((int)gridDim.x + NSEG - 1 - qk) / NSEG;    // this workgroup's rank in its segment, workgroups per segment
+  const int rb = (int)(blockIdx.x / NSEG), nbq = (nblk + NSEG - 1 - qk) / NSEG;    // this workgroup's rank in its segment, workgroups per segment
   const int limit = nitems;
   // (measured and dropped: spreading the only round of a small field over ALL resident workgroups -- 6 to 7 items per wavefront
   //  instead of 8 -- made the launch 18 % SLOWER, 47 -> 56 us at 10 k floes: a SIMD issues the instruction streams of its
@@ -1584,7 +1597,7 @@ constexpr int TW_FPB = 4;       // floes per workgroup of the two-way variant (1
 // XCD's workgroups are a contiguous index range (= a region in space): a lattice node is then fetched by one or two XCDs' L2
 // instead of all eight
 template <bool TW>
-__device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid, int nblk, int pmax = 0, int first = 0) {
+__device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid, int nblk, int pmax, int first) {
   extern __shared__ double tw_lds[];
   constexpr int FG = TW ? FRC_G : FRC_PLAIN;      // lanes per floe
   int lane = threadIdx.x % FG, wpb = blockDim.x / FG, wid = threadIdx.x / FG;
@@ -1731,7 +1744,7 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
 }
 
 template <bool TW>
-__global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P, int pmax) { forcing_body<TW>(S, P, blockIdx.x, gridDim.x, pmax); }
+__global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P, int pmax) { forcing_body<TW>(S, P, blockIdx.x, gridDim.x, pmax, 0); }
 // dynamic LDS of sz_k_forcing<true> for pmax points per floe
 inline size_t tw_forcing_lds(int pmax) { return (size_t)TW_FPB * ((size_t)2 * pmax * sizeof(double) + (size_t)(pmax + FC_CAP) * (sizeof(int) + 1)); }
 
@@ -1755,7 +1768,7 @@ __device__ __forceinline__ float sample_field32(const float* nodes, int f, const
   float c1 = (1.0f - ty) * nodes[(size_t)c.o10 * 8 + f] + ty * nodes[(size_t)c.o11 * 8 + f];
   return (1.0f - tx) * c0 + tx * c1;
 }
-__device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, int bid, int nblk, int first = 0) {
+__device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, int bid, int nblk, int first) {
   if (stopped(S)) return;
   int N = S.cnt[C_NOWN];
   int lane = threadIdx.x % FRC_PLAIN, wpb = blockDim.x / FRC_PLAIN, wid = threadIdx.x / FRC_PLAIN;
@@ -1816,7 +1829,7 @@ __device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, in
   }
 }
 
-__global__ void __launch_bounds__(256) sz_k_forcing_mixed(State S, Params P) { forcing_mixed_body(S, P, blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(256) sz_k_forcing_mixed(State S, Params P) { forcing_mixed_body(S, P, blockIdx.x, gridDim.x, 0); }
 
 // Horizontal fusion: the neighbour search and the forcings are independent of each other (the forcings only need
 // the state the previous step left) and both are latency-bound per-floe kernels of ~20 us that leave most of the

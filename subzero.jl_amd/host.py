@@ -494,6 +494,12 @@ class World:
         mode = (2 << capi.KERNEL_CLASS_NAMES.index(only)) if (on and only) else int(bool(on))
         self._chk(self.L.sz_profile_enable(self.h, mode)); self._chk(self.L.sz_profile_reset(self.h))
 
+    def forcing_launch(self):
+        """0 / 1 / 2: the forcings of the last resident batch ran in their own / the neighbour / the narrow launch (-1: none yet)"""
+        w = np.zeros(1, np.int32)
+        self._chk(self.L.sz_forcing_launch(self.h, w.ctypes.data_as(C.POINTER(C.c_int32))))
+        return int(w[0])
+
     def kernel_times(self):
         out = {}
         for k, name in enumerate(capi.KERNEL_CLASS_NAMES):
