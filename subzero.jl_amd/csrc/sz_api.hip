@@ -89,6 +89,8 @@ struct sz_ctx {
   bool two_way = false; int tw_dt = 10; int tw_capM = 0; size_t tw_ncell = 0; bool temps_set = false;
   Pool tw_allocs, tw_field_allocs;
   // static broad-phase grid of the resident steps (fixed by the host: no bounds reduction per step)
+  bool retry_seen = false;          // an item has needed the largest narrow variant: sz_step enqueues it in every step from now on
+  bool no_lean_narrow = false;      // SZ_LEAN_NARROW=0: always enqueue it
   int forcing_where = -1;           // sz_forcing_launch
   int fuse_forcing_mode = 0;        // ... 1: in the neighbour launch, 2: in the narrow launch (its tail), 0: by size -- the narrow launch while the narrow phase is one
                                     // round with a long tail (measured better up to 20 k floes, even at 40 k, worse at 65 k); SZ_FUSE_FORCING=1|2 forces one
@@ -412,7 +414,14 @@ void stage_elems(sz_ctx* c, bool enabled) {
 }
 
 // frc: the step's forcings ride in the launch of the first variant (0: no, 1: fp64, 2: mixed precision)
-void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = false, int frc = 0) {
+// rings above the first narrow variant's capacity exist (rings never change size inside the hot path, so the host knows; halo floes of a
+// tiled run arrive unseen: their bound counts)
+bool larger_rings(const sz_ctx* c) {
+  return std::max(std::max(c->max_ring, c->max_elem_ring), c->S.tiled ? c->max_ring_tiled : 0) > NARROW_CAP0;
+}
+// parts: 0 everything (the largest variant is always enqueued: it takes the items the others hand on), 1 without the largest variant unless
+// rings that need it exist (sz_step's retry_stop mode), 2 only the larger variants (the rest of a paused step)
+void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = false, int frc = 0, int parts = 0) {
   State& S = c->S;
   // dynamic rounds (see sz_k_narrow) where the queue heads were just cleared (static-grid steps); SZ_NARROW_QUEUE=0: off
   const int queue = c->no_queue ? 0 : 1;      // (the reduce kernel resets the queue heads after every narrow phase)
@@ -420,9 +429,9 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = 
   long long capItems = (long long)S.capPairs + S.capElem;
   // Rings never change size inside the hot path, so the host knows whether any item can need a
   // larger variant (halo floes of a tiled run arrive unseen: then always check on the device).
-  const bool larger = std::max(std::max(c->max_ring, c->max_elem_ring), S.tiled ? c->max_ring_tiled : 0) > NARROW_CAP0;
-  if (larger) hipLaunchKernelGGL(sz_k_items_clear, dim3(grid_for(capItems, 256)), dim3(256), 0, c->stream, S);
-  {
+  const bool larger = larger_rings(c);
+  if (larger && parts != 2) hipLaunchKernelGGL(sz_k_items_clear, dim3(grid_for(capItems, 256)), dim3(256), 0, c->stream, S);
+  if (parts != 2) {
     Timed t(c, SZ_K_NARROW);
     constexpr int G = NARROW_G, TPB = 64;
     // 160 VGPRs (3 wavefronts per SIMD) and 16 KB of LDS per workgroup: 10 workgroups = 80 items in flight per CU
@@ -449,6 +458,7 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = 
     // larger working sets: items with larger rings (only if such rings can exist) and items the
     // smaller variant handed on; both kernels return at once when the step has no such item
     Timed t(c, K_NARROW_LARGE);
+    if (parts == 1 && !larger) { t.end(); return; }
     if (larger)
       hipLaunchKernelGGL((sz_k_narrow<16, NARROW_CAP1, 16, 80, 6, 64, NARROW_CAP0, 1>), dim3(grid_for(capItems, 4, 2048)), dim3(64), 0,
                          c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0);
@@ -467,6 +477,15 @@ void stage_reduce(sz_ctx* c, int mirror, int n_init, int dt) {
   t.end();
 }
 
+// a step of sz_step: `resume` = the rest of a step that paused after its narrow launch (see stopped_late())
+void collisions_step(sz_ctx* c, int n_init, int dt, bool commit_ghosts, bool static_grid, int fuse_forcing, bool lean, bool resume) {
+  if (!resume) {
+    stage_broad(c, commit_ghosts, static_grid, fuse_forcing == 1);
+    stage_elems(c, true);
+  }
+  stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, static_grid, fuse_forcing == 2 ? (c->precision == 1 ? 2 : 1) : 0, resume ? 2 : lean ? 1 : 0);
+  stage_reduce(c, 1, n_init, dt);
+}
 // fuse_forcing: the step's forcings ride in another launch: 1 the neighbour search's, 2 the narrow phase's
 void collisions(sz_ctx* c, int n_init, int dt, bool commit_ghosts = false, bool static_grid = false, int fuse_forcing = 0) {
   stage_broad(c, commit_ghosts, static_grid, fuse_forcing == 1);
@@ -641,6 +660,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_NARROW_QUEUE")) c->no_queue = atoi(e) == 0;
   if (const char* e = getenv("SZ_FUSED_MOVE")) c->fused_move = atoi(e) != 0;
   if (const char* e = getenv("SZ_TW_GENERAL_CLIP")) c->tw_general_clip = atoi(e) != 0;
+  if (const char* e = getenv("SZ_LEAN_NARROW")) c->no_lean_narrow = atoi(e) == 0;
   if (const char* e = getenv("SZ_FUSE_FORCING")) { c->fuse_forcing = atoi(e) != 0; if (atoi(e) > 0) c->fuse_forcing_mode = atoi(e) >= 2 ? 2 : 1; }
   if (const char* e = getenv("SZ_STATIC_GRID")) c->no_static_grid = atoi(e) == 0;
   if (const char* e = getenv("SZ_BODY_RINGS")) c->no_body_rings = atoi(e) == 0;
@@ -1224,6 +1244,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   // is the host's): the launches of the later steps are enqueued all the same and return at once (stopped())
   c->S.stop_on_tags = (flags & SZ_NO_STOP) ? 0 : 1;
   HIPCHK(c, hipMemsetAsync(c->S.cnt + C_STOP, 0, sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->S.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream));
   bool last_coupled = false;
   const bool sg = coll && c->grid_ok && !c->no_static_grid;
   if (sg) use_static_grid(c);
@@ -1239,38 +1260,55 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   const bool body = mixed && coll && sg && (gl || !periodic) && !c->S.tiled && c->fused_move && c->max_ring <= MV_RING && !c->no_body_rings;
   if (!body) world_rings(c);
   c->S.body_rings = body ? 1 : 0;
-  for (int s = 0; s < nsteps; s++) {
-    int tstep = tstep0 + s;
-    c->S.step = s + 1;
-    const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
-    const bool overlap = coupling && !c->two_way && (c->overlap_forcing != 0);
-    // with collisions on, the ghosts of step s are detached by the ghost kernels of step s+1 (nothing
-    // in between looks past the parents) and committed by the bounds kernel: two launches less
-    // The forcings only need the floes as the previous step left them, so they go first (the tiled step runs them
-    // beside the halo exchange, and both paths keep the same order: a parent that the ghost pass wraps around the
-    // domain is sampled at the periodic image it had before -- the same lattice values).  With the forcings on a
-    // second stream the fork comes after the ghost pass instead, so that nothing they read is being rewritten.
-    // (riding in the neighbour launch pays while both kernels leave the chip idle: measured better up to 40 k floes,
-    // neutral at 100 k dense, worse at 100 k sparse -- there the forcings get their own launch)
-    const bool fuse = coupling && !overlap && coll && !c->two_way && !(c->pmask >> SZ_K_FORCING & 1u) && c->fuse_forcing && c->hostN <= 65536;
-    if (coupling && !overlap && !fuse) stage_forcing(c, dt);
-    if (coll) stage_ghosts(c, true, sg, gl);
-    if (overlap) stage_forcing_fork(c);
-    const int fmode = !fuse ? 0 : c->fuse_forcing_mode ? c->fuse_forcing_mode : (c->hostN <= 30000 ? 2 : 1);
-    if (coupling) c->forcing_where = fmode;
-    if (coll) collisions(c, c->hostN, dt, periodic && !sg, sg, fmode);
-    if (overlap) stage_forcing_join(c);
-    stage_integrate(c, dt, !coll, coupling, sg, gl ? 1 - c->gl_cur : -1);
-    if (gl) c->gl_cur ^= 1;
+  // the largest narrow variant only takes items the small one hands on (none in most fields): it is left out of the steps until one
+  // shows up -- the batch then pauses inside that step (stopped_late()) and is finished below
+  bool lean = coll && !c->retry_seen && !c->no_lean_narrow && !c->S.tiled && !larger_rings(c);
+  int h[C_COUNT];
+  for (int s0 = 0, mid = 0;;) {
+    c->S.retry_stop = lean ? 1 : 0;
+    for (int s = s0; s < nsteps; s++) {
+      int tstep = tstep0 + s;
+      c->S.step = s + 1;
+      const bool resume = mid && s == s0;
+      const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
+      const bool overlap = coupling && !c->two_way && (c->overlap_forcing != 0);
+      // with collisions on, the ghosts of step s are detached by the ghost kernels of step s+1 (nothing
+      // in between looks past the parents) and committed by the bounds kernel: two launches less
+      // The forcings only need the floes as the previous step left them, so they go first (the tiled step runs them
+      // beside the halo exchange, and both paths keep the same order: a parent that the ghost pass wraps around the
+      // domain is sampled at the periodic image it had before -- the same lattice values).  With the forcings on a
+      // second stream the fork comes after the ghost pass instead, so that nothing they read is being rewritten.
+      // (riding in the neighbour launch pays while both kernels leave the chip idle: measured better up to 40 k floes,
+      // neutral at 100 k dense, worse at 100 k sparse -- there the forcings get their own launch)
+      const bool fuse = coupling && !overlap && coll && !c->two_way && !(c->pmask >> SZ_K_FORCING & 1u) && c->fuse_forcing && c->hostN <= 65536;
+      const int fmode = !fuse ? 0 : c->fuse_forcing_mode ? c->fuse_forcing_mode : (c->hostN <= 30000 ? 2 : 1);
+      if (!resume) {          // (a paused step has all of this behind it)
+        if (coupling && !overlap && !fuse) stage_forcing(c, dt);
+        if (coll) stage_ghosts(c, true, sg, gl);
+        if (overlap) stage_forcing_fork(c);
+        if (coupling) c->forcing_where = fmode;
+      }
+      if (coll) collisions_step(c, c->hostN, dt, periodic && !sg, sg, resume ? 0 : fmode, lean, resume);
+      if (overlap && !resume) stage_forcing_join(c);
+      stage_integrate(c, dt, !coll, coupling, sg, gl ? 1 - c->gl_cur : -1);
+      if (gl) c->gl_cur ^= 1;
+    }
+    c->S.step = 0;
+    if (coll && periodic) hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
+    int rc = sync_and_check(c, h);
+    if (rc) { c->S.retry_stop = 0; c->S.body_rings = 0; return rc; }
+    if (!lean || h[C_RETRYSTOP] == 0) break;
+    // paused after the narrow launch of step h[C_RETRYSTOP]: that variant is in from now on
+    c->retry_seen = true; lean = false;
+    s0 = h[C_RETRYSTOP] - 1; mid = 1;
+    if (gl) c->gl_cur = (gl0 + s0) & 1;
+    (void)hipMemsetAsync(c->S.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream);
   }
-  c->S.step = 0;
+  c->S.retry_stop = 0;
   if (body && nsteps > 0) c->rings_stale = true;
   c->S.body_rings = 0;
   if (coll) { c->inter_any = true; c->inter_lost = false; }
-  if (coll && periodic) hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
-  int h[C_COUNT];
-  int rc = sync_and_check(c, h);
-  if (rc) return rc;
+  int rc = SZ_OK;
   const int done = h[C_STOP] > 0 ? h[C_STOP] : nsteps;
   if (steps_done) *steps_done = done;
   if (gl) {               // the list the last step that RAN has filled, and how long it is

@@ -27,8 +27,18 @@ using namespace szg;
 // are already enqueued; each of them asks this first and returns at once.  S.step is the 1-based step of the launch
 // inside its batch (kernarg), cnt[C_STOP] the step that asked for the stop (0: none).
 __device__ __forceinline__ bool stopped(const State& S) {
-  const int s = S.cnt[C_STOP];
-  return s != 0 && S.step > s;
+  const int s = S.cnt[C_STOP], r = S.cnt[C_RETRYSTOP];
+  return (s != 0 && S.step > s) || (r != 0 && S.step > r);
+}
+// The other reason a batch pauses: the largest narrow-phase variant (sz_k_narrow<64, ..>) exists for items whose clip
+// outgrows the small working set (IT_RETRY) -- none in most fields, yet its launch costs ~4 us + a launch boundary in
+// every step.  sz_step therefore leaves it out (State::retry_stop) until such an item shows up: the small variant then
+// raises cnt[C_RETRYSTOP], the kernels that FOLLOW the narrow phase in that step (reduce, update) and all later steps return
+// at once, and the host enqueues the missing variant, the rest of the step and the remaining steps (the variant stays in
+// from then on).  Kernels after the narrow phase ask stopped_late().
+__device__ __forceinline__ bool stopped_late(const State& S) {
+  const int s = S.cnt[C_STOP], r = S.cnt[C_RETRYSTOP];
+  return (s != 0 && S.step > s) || (r != 0 && S.step >= r);
 }
 __device__ __forceinline__ void request_stop(const State& S) {
   if (S.step > 0 && S.stop_on_tags) S.cnt[C_STOP] = S.step;      // every requester of a step writes the same value
@@ -665,6 +675,7 @@ __global__ void sz_k_ghost_commit(State S) {
 // simulation.jl:138-144
 // drop_halo: tiled runs also forget the halo parents (N := owned)
 __global__ void sz_k_remove_ghosts(State S, int drop_halo) {
+  if (S.retry_stop && S.cnt[C_RETRYSTOP] != 0) return;       // the batch is paused inside a step: its ghosts are still needed
   int N = drop_halo ? S.cnt[C_NOWN] : S.cnt[C_N];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
     S.ngh[i] = 0;
@@ -1309,7 +1320,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       gsync();
       if (CLS < 2 && (m.ierr & CAPBITS)) {                // working set too small: let the largest variant redo the item
         nrows = 0; flags = IT_RETRY;
-        if (gl == 0) { atomicMax(&S.cnt[C_ITEMCLASS], 2); atomicAdd(&S.cnt[C_NRETRY], 1); }
+        if (gl == 0) { atomicMax(&S.cnt[C_ITEMCLASS], 2); atomicAdd(&S.cnt[C_NRETRY], 1); if (S.retry_stop && S.step > 0) S.cnt[C_RETRYSTOP] = S.step; }
       } else if (gl == 0 && m.ierr) m.err |= m.ierr;
       if (gl == 0) {
         S.it_info[it.info] = make_int2(nrows | (flags << 8), it.rows);
@@ -1453,7 +1464,7 @@ __device__ __forceinline__ int emit_rows(const State& S, int lane, int f, double
 }
 // mirror pass, ghost fold, torque and totals (collisions.jl:799-862)
 __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int n_init_arg) {
-  if (stopped(S)) return;
+  if (stopped_late(S)) return;
   const int M = S.cnt[C_M];
   const int nparents = S.cnt[C_NOWN];
   // the narrow phase has consumed the work list: heads and lengths of its segments start from zero for the next step
@@ -1519,7 +1530,7 @@ __global__ void sz_k_inter_compact(State S, double* dst) {
 // update_boundaries!, collisions.jl:565-571, boundaries.jl:526-568 (MovingBoundary only)
 __global__ void sz_k_update_boundaries(State S, int dt) {
   int e = threadIdx.x;
-  if (blockIdx.x != 0 || e >= 4 || S.ekind[e] != 3 || stopped(S)) return;
+  if (blockIdx.x != 0 || e >= 4 || S.ekind[e] != 3 || stopped_late(S)) return;
   double* rc = S.erect + e * 4;   // xmin, xmax, ymin, ymax
   if (e < 2) { double dy = S.ev[e] * dt; rc[2] += dy; rc[3] += dy; S.eval[e] += dy; }
   else { double dx = S.eu[e] * dt; rc[0] += dx; rc[1] += dx; S.eval[e] += dx; }
@@ -1879,7 +1890,7 @@ template <bool MOVE>
 // gl_fill (resident steps): the ghost-candidate list to append to (sz_k_ghost_list), -1: none
 __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Params P, int dt, int apply_frc, int bin, int nh, int gl_fill) {
   const GridGeo geo = grid_geo(S);
-  if (stopped(S)) return;
+  if (stopped_late(S)) return;
   const int N = nh >= 0 ? nh : S.cnt[C_NOWN];     // nh: see sz_k_ghost_flag_scan
   int wh = 0, wf = 0, wv = 0, wx = 0;
   const double wall[4] = { S.eval[0], S.eval[1], S.eval[2], S.eval[3] };
@@ -2031,7 +2042,7 @@ __global__ void __launch_bounds__(256) sz_k_move_strain(State S, int strain_only
   const GridGeo geo = grid_geo(S);
   constexpr int G = 16;
   __shared__ double t11[256 / G][64], t12[256 / G][64], t22[256 / G][64];
-  if (stopped(S)) return;
+  if (stopped_late(S)) return;
   int N = S.cnt[C_NOWN];
   int gl = threadIdx.x % G, gi = threadIdx.x / G, gpb = blockDim.x / G;
   for (int i = blockIdx.x * gpb + gi; i < N; i += gridDim.x * gpb) {

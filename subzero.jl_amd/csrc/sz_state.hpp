@@ -23,7 +23,9 @@ enum {
   C_NELEM_ROWS,
   C_NGCAND, C_NGCAND1,   // entries of the two ghost-candidate lists (State::gcand), used alternately step by step
   C_NFUSE,        // pair items that asked for a fuse in the last collision call (the host replays the fuse lists only then)
-  C_UNUSED3,      // (the guard counters live in State::warn: one word each serialised the chip)
+  C_RETRYSTOP,    // resident batches: 0, or 1 + the batch-relative step whose narrow phase met an item for the largest variant while that
+                  // variant was not enqueued (State::retry_stop): the batch pauses after that step's narrow launch and the host finishes it
+                  // (the guard counters live in State::warn: one word each serialised the chip)
   C_NG_NEW,       // ghosts created by the current pass
   C_NGHOSTS,
   C_NCELLS,
@@ -64,6 +66,7 @@ struct State {
   int tiled;                 // halo mode: order keys are global indices
   int step;                  // 1-based index of the step inside the running sz_step batch (0: process-mode call): kernels of
                              // steps after a stop request return at once (stopped(), sz_kernels.hpp)
+  int retry_stop;            // sz_step: the largest narrow variant is not enqueued; an item that needs it raises C_RETRYSTOP
   int stop_on_tags;          // sz_step: raise C_STOP when a parent is tagged (off with SZ_NO_STOP)
   int xcd_forcing;           // SZ_XCD_FORCING=1: XCD-contiguous floe ranges in the forcing kernels (A/B switch; default off: slower at 100 k)
   int xcd_neigh;             // SZ_XCD=1: XCD-contiguous floe ranges in the neighbour search too (A/B switch; default off)

@@ -439,6 +439,56 @@ def test_resident_batch_stops_when_a_floe_is_tagged(kind):
     assert hw.run(3, k + 1, 10, coupling_dt=10, coupling_on=False, stop_on_tags=False) == 3
 
 
+def _retry_scenario(w):
+    """two 8-spike stars drifting into each other: 6, then 8, then 16 crossings -- from the sixth step on the pair outgrows
+    the small narrow-phase working set (8 crossings) and is redone by the largest kernel variant"""
+    th = np.arange(16) * (2 * np.pi / 16)
+    rad = np.where(np.arange(16) % 2 == 0, 1.0e4, 0.55e4)
+    star = lambda rot, cx: np.stack([cx + rad * np.cos(-th + rot), 5e4 + rad * np.sin(-th + rot)], 1)
+    sq = lambda x0, y0, s=1e4: np.array([[x0, y0], [x0, y0 + s], [x0 + s, y0 + s], [x0 + s, y0], [x0, y0]])
+    w.set_consts(E=1e3); w.set_settings()
+    w.set_domain([1, 1, 1, 1], 0.0, 1e5, 0.0, 1e5)
+    w.set_grid_fields(10, 10, 0.0, 1e5, 0.0, 1e5, 0.0, 0.0, 0.0, 0.0, 0.0)
+    w.add_floe(cases.closed(star(0.0, 4.0e4)), 0.5)
+    w.add_floe(cases.closed(star(np.pi / 8, 4.5e4)), 0.5)
+    w.add_floe(sq(8.0e4, 1.0e4), 0.5); w.add_floe(sq(9.6e4, 6.0e4), 0.5)      # the last one has a ghost
+    w.set("u", np.array([0.0, -30.0, 0.0, 0.0]))
+    return w
+
+
+def test_resident_batch_pauses_for_the_largest_narrow_variant():
+    """sz_step leaves the largest narrow-phase variant out of its steps until an item needs it: the batch then pauses
+    inside that step, the host enqueues the variant, the rest of the step and the remaining steps.  The trajectory must
+    be the oracle's, and bit for bit the one of a run that enqueues the variant in every step."""
+    import os
+    from oracle import orc
+    ow = _retry_scenario(omk())
+    first = None
+    for k in range(10):
+        o, x, y = ow.rings()
+        if first is None and len(orc.intersection_points(np.stack([x[o[0]:o[1]], y[o[0]:o[1]]], 1), np.stack([x[o[1]:o[2]], y[o[1]:o[2]]], 1))) > 8:
+            first = k
+        ow.timestep_sim(k, 10, coupling_dt=10, coupling_on=False)
+    assert first is not None and 2 <= first < 8                 # the pause comes in the middle of the first batch
+    runs = []
+    for lean in ("1", "0"):
+        os.environ["SZ_LEAN_NARROW"] = lean
+        try:
+            hw = _retry_scenario(mk())
+        finally:
+            del os.environ["SZ_LEAN_NARROW"]
+        assert hw.run(8, 0, 10, coupling_dt=10, coupling_on=False, stop_on_tags=False) == 8
+        assert hw.stats()["n_retry"] >= 1
+        assert hw.run(2, 8, 10, coupling_dt=10, coupling_on=False, stop_on_tags=False) == 2      # the variant stays in
+        runs.append(hw)
+    parity.compare_worlds(runs[0], ow, rtol=1e-9, check_pairs=False)
+    for f in parity.SCALARS:
+        assert np.array_equal(runs[0].get(f), runs[1].get(f)), f
+    assert np.array_equal(runs[0].rings()[1], runs[1].rings()[1])
+    a, b = runs[0].interactions(), runs[1].interactions()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_field_reupload_keeps_the_temperatures():
     """sz_set_fields with an unchanged lattice shape keeps the ocean / atmosphere temperatures of sz_set_temps (the
     heat-flux factor of calc_two_way_coupling!, coupling.jl:1676, depends on them)."""
