@@ -246,8 +246,32 @@ def main():
         # the halo exchange runs inside the library (RCCL bound by libsubzero_hip.so: grouped send / receive with the
         # neighbouring tiles); SZ_TILES_BACKEND=torch: one torch.distributed all_to_all_single per step instead
         backend = os.environ.get("SZ_TILES_BACKEND", "library")
-        tw = tiles.TiledWorld(cfg, rank, world, local, dist, always_exchange=args.force_tiled, backend=backend)
-        tw.repartition_every = 10 ** 9        # floes drift metres per step against tiles of hundreds of km: no re-tiling inside a bench run
+        backend_note = None
+
+        def make_tiles(be):
+            t = tiles.TiledWorld(cfg, rank, world, local, dist, always_exchange=args.force_tiled, backend=be)
+            t.repartition_every = 10 ** 9     # floes drift metres per step against tiles of hundreds of km: no re-tiling inside a bench run
+            return t
+        # the library-side exchange binds RCCL at run time: if any rank cannot set it up (no librccl to bind, communicator refused),
+        # ALL ranks fall back to the torch.distributed exchange together -- a line with a note beats no line
+        err = None
+        try:
+            tw = make_tiles(backend)
+            tw.run(2, 0, cfg["dt"], coupling_dt=coupling_dt)           # first exchange (boxes, capacities, one send / receive)
+        except Exception as e:      # noqa: BLE001
+            err = str(e)[:300]
+        if dist is not None:
+            flag = torch.tensor([1 if err else 0], device="cuda", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            failed = bool(flag.item())
+        else:
+            failed = err is not None
+        if failed:
+            if backend != "library":
+                raise RuntimeError(err or "another rank failed to set up its tile")
+            backend_note = f"library exchange unavailable ({err or 'on another rank'}); torch.distributed all_to_all_single instead"
+            backend = "torch"
+            tw = make_tiles(backend)
         hw = tw.world
         runner = lambda n, t0: tw.run(n, t0, cfg["dt"], coupling_dt=coupling_dt)
 
@@ -361,6 +385,8 @@ def main():
                 out["speedup_vs_one_gpu_same_workload"] = one_gpu["ms_per_step"] / (1e3 * el / args.steps)
         if tiled:
             out["config"]["halo_exchange"] = backend if world > 1 or args.force_tiled else None
+            if backend_note:
+                out["config"]["halo_exchange_note"] = backend_note
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

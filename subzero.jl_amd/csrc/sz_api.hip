@@ -468,11 +468,12 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = 
   }
 }
 
-void stage_reduce(sz_ctx* c, int mirror, int n_init, int dt) {
+// m_hint: see sz_k_inter_fill (resident steps: the parents + the ghosts the last look at the device showed, and some)
+void stage_reduce(sz_ctx* c, int mirror, int n_init, int dt, int m_hint = 0) {
   State& S = c->S;
   Timed t(c, SZ_K_REDUCE);
   int gM = grid_for(S.capM, 256);
-  hipLaunchKernelGGL(sz_k_inter_fill, dim3(grid_for(S.capM, 128 / IF_G, 16384)), dim3(128), 0, c->stream, S, mirror, n_init);
+  hipLaunchKernelGGL(sz_k_inter_fill, dim3(grid_for(S.capM, 128 / IF_G, 16384)), dim3(128), 0, c->stream, S, mirror, n_init, m_hint);
   if (mirror && c->any_moving) hipLaunchKernelGGL(sz_k_update_boundaries, dim3(1), dim3(64), 0, c->stream, S, dt);
   t.end();
 }
@@ -484,7 +485,7 @@ void collisions_step(sz_ctx* c, int n_init, int dt, bool commit_ghosts, bool sta
     stage_elems(c, true);
   }
   stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, static_grid, fuse_forcing == 2 ? (c->precision == 1 ? 2 : 1) : 0, resume ? 2 : lean ? 1 : 0);
-  stage_reduce(c, 1, n_init, dt);
+  stage_reduce(c, 1, n_init, dt, c->S.tiled ? 0 : c->hostN + 3 * c->gl_est + c->hostN / 64 + 32);
 }
 // fuse_forcing: the step's forcings ride in another launch: 1 the neighbour search's, 2 the narrow phase's
 void collisions(sz_ctx* c, int n_init, int dt, bool commit_ghosts = false, bool static_grid = false, int fuse_forcing = 0) {
@@ -1640,6 +1641,7 @@ Rccl g_rccl;
 constexpr int NCCL_INT32 = 2, NCCL_FLOAT64 = 8, NCCL_SUM = 0;
 bool rccl_load(std::string& err) {
   if (g_rccl.h) return true;
+  if (getenv("SZ_RCCL_DISABLE")) { err = "RCCL binding switched off (SZ_RCCL_DISABLE)"; return false; }     // (to rehearse the callers' fallback)
   // an RCCL the process already holds comes first (a host framework's: two RCCL builds in one process each bring their own
   // runtime threads), then the system's
   const char* names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1" };
