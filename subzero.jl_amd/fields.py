@@ -25,6 +25,16 @@ def _points_in_ring(px, py, ring):
     return (np.sum(straddle & (X < xi), axis=1) % 2) == 1
 
 
+def _dist_outside_ring(px, py, ring):
+    """distance of the points to the polygon, 0 for points inside it"""
+    x1, y1 = ring[:-1, 0][None, :], ring[:-1, 1][None, :]
+    dx, dy = ring[1:, 0][None, :] - x1, ring[1:, 1][None, :] - y1
+    X, Y = px[:, None], py[:, None]
+    t = np.clip(((X - x1) * dx + (Y - y1) * dy) / (dx * dx + dy * dy), 0.0, 1.0)
+    d = np.sqrt(np.min((X - (x1 + t * dx)) ** 2 + (Y - (y1 + t * dy)) ** 2, axis=1))
+    return np.where(_points_in_ring(px, py, ring), 0.0, d)
+
+
 def subgrid_points(ring, cx, cy, dg):
     """generate_subfloe_points(::SubGridPointsGenerator, ...), coupling.jl:232-321 (centred ring)."""
     r = ring - np.array([cx, cy])
@@ -62,16 +72,42 @@ def make_config(n_floes=10000, seed=12345, concentration=0.8, spacing=2.0e4, wal
                 ocean="uniform", dt=20, hmean=0.25, subgrid_per_floe=10.0):
     """Returns a plain dict describing one synthetic scenario (polygons, state, domain, fields)."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    n_side = int(np.ceil(np.sqrt(n_floes)))
-    L = n_side * spacing
     # mean star area = pi r^2 E[(0.6+0.4U)^2] ~ 0.6533 pi r^2  -> r from the target concentration
     r0 = spacing * np.sqrt(concentration / (0.6533 * np.pi))
-    cells = rng.permutation(n_side * n_side)[:n_floes]
-    cells.sort()
-    gx, gy = (cells % n_side).astype(float), (cells // n_side).astype(float)
     jit = 0.1 * spacing
-    ccx = (gx + 0.5) * spacing + rng.uniform(-jit, jit, n_floes)
-    ccy = (gy + 0.5) * spacing + rng.uniform(-jit, jit, n_floes)
+    topo = []
+    if not topography:
+        n_side = int(np.ceil(np.sqrt(n_floes)))
+        L = n_side * spacing
+        cells = rng.permutation(n_side * n_side)[:n_floes]
+        cells.sort()
+        gx, gy = (cells % n_side).astype(float), (cells // n_side).astype(float)
+        ccx = (gx + 0.5) * spacing + rng.uniform(-jit, jit, n_floes)
+        ccy = (gy + 0.5) * spacing + rng.uniform(-jit, jit, n_floes)
+    else:
+        # the strait of examples/simple_strait.jl:24-28, scaled to the box: a coast-like wedge on the west and on the east side
+        # and an island in the channel between them; floes only in the water -- the ones next to a coast reach a little into it,
+        # so the floe-topography clip path has work from the first step on.  The lattice is sized so that n_floes cells are wet.
+        strait = lambda s: [np.array([[6e4, 4e4], [6e4, 4.5e4], [6.5e4, 4.5e4], [6.5e4, 4e4], [6e4, 4e4]]) * s,
+                            np.array([[0, 0.0], [0, 1e5], [2e4, 1e5], [3e4, 5e4], [2e4, 0], [0.0, 0.0]]) * s,
+                            np.array([[8e4, 0], [7e4, 5e4], [8e4, 1e5], [1e5, 1e5], [1e5, 0], [8e4, 0]]) * s]
+        n_side = int(np.ceil(np.sqrt(n_floes / 0.45)))
+        while True:
+            L = n_side * spacing
+            topo = strait(L / 1e5)
+            ax = (np.arange(n_side * n_side) % n_side + 0.5) * spacing; ay = (np.arange(n_side * n_side) // n_side + 0.5) * spacing
+            wet = np.ones(n_side * n_side, bool)
+            for t in topo:
+                wet &= _dist_outside_ring(ax, ay, t) > 0.3 * r0 + jit
+            if wet.sum() >= n_floes:
+                break
+            n_side += 1
+        cells = np.nonzero(wet)[0]
+        cells = cells[rng.permutation(len(cells))[:n_floes]]
+        cells.sort()
+        gx, gy = (cells % n_side).astype(float), (cells // n_side).astype(float)
+        ccx = (gx + 0.5) * spacing + rng.uniform(-jit, jit, n_floes)
+        ccy = (gy + 0.5) * spacing + rng.uniform(-jit, jit, n_floes)
     nv = rng.integers(8, 17, n_floes)
     off = np.zeros(n_floes + 1, np.int32); off[1:] = np.cumsum(nv + 1)
     vx = np.zeros(off[-1]); vy = np.zeros(off[-1])
@@ -102,10 +138,6 @@ def make_config(n_floes=10000, seed=12345, concentration=0.8, spacing=2.0e4, wal
         uo = np.repeat(prof[:, None], Ny + 1, 1); vo = np.zeros((Nx + 1, Ny + 1))
     else:
         raise ValueError(ocean)
-    topo = []
-    if topography:                           # two coast-like wedges and an island, simple_strait.jl:24-28 scaled
-        s = L / 1e5
-        topo = [np.array([[6e4, 4e4], [6e4, 4.5e4], [6.5e4, 4.5e4], [6.5e4, 4e4], [6e4, 4e4]]) * s]
     cfg = dict(n_floes=n_floes, seed=seed, L=L, kinds=kinds, vert_off=off, vx=vx, vy=vy,
                height=np.full(n_floes, hmean), u=u, v=v, xi=xi, dt=dt, Nx=Nx, Ny=Ny,
                uo=uo, vo=vo, hf=np.zeros((Nx + 1, Ny + 1)), ua=np.zeros((Nx + 1, Ny + 1)), va=np.zeros((Nx + 1, Ny + 1)),

@@ -420,3 +420,14 @@ def run_conservation(mk, C, case, stepper):
     last = conservation_metrics(w)
     assert np.all(w.ids()[2] == ACTIVE)                    # nothing for simplify_floes! to do: the run is the reference's
     return 100.0 * (last - first) / first
+
+
+def floe_onto_island(cfg, i=0):
+    """moves floe i of a strait field (fields.make_config(topography=True)) onto the island, so that the topography removes it
+    (collisions.jl:525); the derived columns are recomputed"""
+    from subzero_jl_amd import floe as floe_mod
+    o0, o1 = cfg["vert_off"][i], cfg["vert_off"][i + 1]
+    c = cfg["topography"][0][:-1].mean(0)
+    cfg["vx"][o0:o1] += c[0] - cfg["derived"]["cx"][i]; cfg["vy"][o0:o1] += c[1] - cfg["derived"]["cy"][i]
+    cfg["derived"] = floe_mod.derive(cfg["vert_off"], cfg["vx"], cfg["vy"], cfg["height"])
+    return cfg

@@ -145,14 +145,18 @@ def test_collisions_random_periodic(n, seed):
 
 
 def test_collisions_walls_topography():
-    """config-4 style: four collision walls + topography (floe-boundary clip path)."""
+    """config-4 style: four collision walls + the strait of examples/simple_strait.jl (two coast wedges and an island):
+    the floe-boundary and floe-topography clip paths.  One floe is put on the island: it is tagged for removal
+    (collisions.jl:525)."""
     from subzero_jl_amd import fields
     cfg = fields.make_config(n_floes=900, seed=3, walls=True, topography=True, ocean="strait")
+    assert len(cfg["topography"]) == 3
+    cases.floe_onto_island(cfg)
     hw, ow = _pair(cfg)
     hw.timestep_collisions(900, cfg["dt"]); ow.timestep_collisions(900, cfg["dt"])
     parity.compare_worlds(hw, ow, rtol=1e-10, fields=["coll_fx", "coll_fy", "coll_trq", "overarea"])
     rows = ow.interactions()[1]
-    assert np.any(rows[:, 0] < 0)      # boundary / topography contacts exist
+    assert np.sum((rows[:, 0] < 0) & (rows[:, 0] >= -4)) > 10 and np.sum(rows[:, 0] < -4) > 10      # wall and topography contacts
     # the tag counts a host uses to skip simplify_floes! when nothing was removed or fused
     st = hw.stats(); tags = hw.ids()[2]
     assert st["n_status_remove"] == int((tags == cases.REMOVE).sum()) and st["n_status_fuse"] == int((tags == cases.FUSE).sum())

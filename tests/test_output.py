@@ -142,7 +142,7 @@ def test_eulerian_random(walls, topo, dims):
 @pytest.mark.gpu
 def test_simplify_check():
     from subzero_jl_amd import fields
-    cfg = fields.make_config(n_floes=900, seed=3, walls=True, topography=True, ocean="strait")
+    cfg = cases.floe_onto_island(fields.make_config(n_floes=900, seed=3, walls=True, topography=True, ocean="strait"))
     hw, ow = fields.build_world(mk(), cfg), fields.build_world(omk(), cfg)
     hw.timestep_collisions(900, cfg["dt"]); ow.timestep_collisions(900, cfg["dt"])
     area = ow.get("area")
