@@ -109,7 +109,7 @@ def reference_cpu(cfg, cores, budget_s=60.0):
         return None
 
 
-def cpu_baseline(cfg, budget_s=20.0):
+def cpu_baseline(cfg, budget_s=20.0, relax_steps=0):
     """The oracle (kind: port) on a bounded sample of the same workload: the same 10k-floe field,
     as many whole timesteps as fit the budget (at least 2), all host cores of this process."""
     from oracle import orc
@@ -126,20 +126,25 @@ def cpu_baseline(cfg, budget_s=20.0):
         return ref
     w = fields.build_world(orc.World(), cfg)
     w.set_threads(cores)
-    w.timestep_sim(0, cfg["dt"], coupling_dt=1)        # warm-up step (page-in, allocator)
+    # the same relaxation as the measured run (untimed; it also pages everything in), so that both time the same kind of step
+    tr = time.perf_counter()
+    for k in range(max(relax_steps, 1)):
+        w.timestep_sim(k, cfg["dt"], coupling_dt=1)
+    tr = time.perf_counter() - tr
+    base = max(relax_steps, 1)
     t0 = time.perf_counter(); steps = 0
     while steps < 2 or (time.perf_counter() - t0 < 0.75 * budget_s and steps < 300):
-        w.timestep_sim(1 + steps, cfg["dt"], coupling_dt=1); steps += 1
+        w.timestep_sim(base + steps, cfg["dt"], coupling_dt=1); steps += 1
     el = time.perf_counter() - t0
     # the same on one core (the reference's default when Julia is started without -t)
     w.set_threads(1)
     t1 = time.perf_counter(); s1 = 0
     while s1 < 2 or (time.perf_counter() - t1 < 0.25 * budget_s and s1 < 100):
-        w.timestep_sim(1 + steps + s1, cfg["dt"], coupling_dt=1); s1 += 1
+        w.timestep_sim(base + steps + s1, cfg["dt"], coupling_dt=1); s1 += 1
     el1 = time.perf_counter() - t1
     return {"value": cfg["n_floes"] * steps / el, "unit": "floe-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} timesteps of the same {cfg['n_floes']}-floe field ({el:.1f} s), OpenMP over floes "
-                      f"like the reference's Threads.@threads loops; then {s1} steps on one core ({el1:.1f} s)",
+            "sample": f"{steps} timesteps of the same {cfg['n_floes']}-floe field ({el:.1f} s) after {base} untimed relaxation steps ({tr:.1f} s), "
+                      f"OpenMP over floes like the reference's Threads.@threads loops; then {s1} steps on one core ({el1:.1f} s)",
             "value_1core": cfg["n_floes"] * s1 / el1}
 
 
@@ -186,6 +191,8 @@ def main():
     ap.add_argument("--precision", default="f64", choices=["f64", "mixed"],
                     help="mixed: per-point forcing arithmetic in fp32 (BASELINE configs[4]); the metric's config is f64")
     ap.add_argument("--coupling-dt", type=int, default=1, help="couple every k-th step (reference default: 10)")
+    ap.add_argument("--relax-steps", type=int, default=50, help="untimed steps before the warm-up: the fields are generated on a jittered lattice "
+                    "with overlapping neighbours and then relaxed, as SURVEY.md §8(d) specifies for the synthetic configurations (50 steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-tiled", action="store_true", help="run the halo/RCCL path even with one rank")
     args = ap.parse_args()
@@ -281,12 +288,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    runner(args.warmup, 0)
+    if args.relax_steps > 0:
+        runner(args.relax_steps, 0)          # part of the workload's definition, not of the measurement
+    runner(args.warmup, args.relax_steps)
     # inside the timed region only the dominant kernel is bracketed by HIP events (one pair per step,
     # on the stream it is launched on): timing all seven classes costs ~20 % of a 0.25 ms step
     hw.profile(True, only="narrow")          # also clears the cumulative narrow-phase work counters
     blocks = []
-    tstep = args.warmup
+    tstep = args.relax_steps + args.warmup
     for _ in range(max(1, args.repeats)):
         barrier()
         t0 = time.perf_counter()
@@ -358,6 +367,7 @@ def main():
                                     if workload == "configs2" else
                                     f"configs[{int(workload[-1])}]-style field ({wl}): {cfg['n_floes']} floes, box {cfg['L'] / 1e3:.0f} km, boundaries {cfg['kinds'][0]}, "
                                     f"{len(cfg['topography'])} topography elements") +
+                                   f", {args.relax_steps} relaxation steps after generation" +
                                    f"; collisions + one-way coupling every {coupling_dt} step(s) + rigid-body update, dt={cfg['dt']} s" +
                                    (f"; {world} spatial tiles, one-deep ghost-floe halo per step" if tiled else ""),
                        "n_floes": cfg["n_floes"], "seed": cfg["seed"], "coupling_dt": coupling_dt, "two_way_coupling": bool(args.two_way),
@@ -388,7 +398,7 @@ def main():
             if backend_note:
                 out["config"]["halo_exchange_note"] = backend_note
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"] = cpu_baseline(cfg, relax_steps=args.relax_steps)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
