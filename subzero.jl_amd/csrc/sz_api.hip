@@ -89,6 +89,12 @@ struct sz_ctx {
   bool two_way = false; int tw_dt = 10; int tw_capM = 0; size_t tw_ncell = 0; bool temps_set = false;
   Pool tw_allocs, tw_field_allocs;
   // static broad-phase grid of the resident steps (fixed by the host: no bounds reduction per step)
+  // inline ghosts (sz_kernels.hpp ghost_inline_make): the resident steps make a step's ghosts in the kernel that places their parents,
+  // in allocation order; the reference's ghost numbers are recovered from the order keys of the last step that ran
+  bool ghost_inline = true;         // SZ_GHOST_INLINE=0: the candidate-list launch instead
+  bool gi_valid = false;            // the interaction rows / pair lists on the device carry order keys of inline ghosts
+  std::vector<long long> gi_keys;   // order key of the ghost at storage offset k (floe N + k) in the last step that ran
+  std::vector<int> gi_ref;          // ... and its number among the ghosts in the reference's order (ghost N + gi_ref[k])
   bool retry_seen = false;          // an item has needed the largest narrow variant: sz_step enqueues it in every step from now on
   bool no_lean_narrow = false;      // SZ_LEAN_NARROW=0: always enqueue it
   int forcing_where = -1;           // sz_forcing_launch
@@ -590,7 +596,7 @@ void stage_forcing(sz_ctx* c, int dt = -1) {      // in-order variant (process m
   t.end();
 }
 // gl_fill: ghost-candidate list the integrator appends to (resident steps on the list path), -1: none
-void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool bin = false, int gl_fill = -1) {
+void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool bin = false, int gl_fill = -1, int ginl = -1) {
   const int nh = bin && !c->S.tiled ? c->hostN : -1;     // resident single-context steps: the host knows the count
   // the guard counters describe the last timestep_floe_properties! call (inside a step the
   // ghost-removal kernel has already cleared them)
@@ -598,9 +604,9 @@ void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool 
   Timed t(c, SZ_K_INTEGRATE);
   // resident steps with small rings: one launch (thread per floe) integrates, moves the ring and bins the floe
   if (bin && c->max_ring <= MV_RING && c->fused_move) {
-    hipLaunchKernelGGL(sz_k_integrate<true>, dim3(grid_for(c->S.capM, 128)), dim3(128), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 1, nh, gl_fill);
+    hipLaunchKernelGGL(sz_k_integrate<true>, dim3(grid_for(c->S.capM, 128)), dim3(128), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 1, nh, gl_fill, ginl);
   } else {
-    hipLaunchKernelGGL(sz_k_integrate<false>, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 0, nh, gl_fill);
+    hipLaunchKernelGGL(sz_k_integrate<false>, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 0, nh, gl_fill, -1);
     hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 0, bin ? 1 : 0, gl_fill);
   }
   if (!bin) c->grid_live = false;          // floes moved without re-binning: the resident steps' cell lists are stale
@@ -624,14 +630,22 @@ int host_fuse_fixup(sz_ctx* c, const int* h, bool mirror, bool after_step = fals
   HIPCHK(c, hipMemcpy(info.data(), S.it_info, (size_t)M * MAXNB * sizeof(int2), hipMemcpyDeviceToHost));
   std::vector<int> tag(M);
   HIPCHK(c, hipMemcpy(tag.data(), c->S.tagA, (size_t)M * sizeof(int), hipMemcpyDeviceToHost));
-  for (int i = 0; i < M; i++)
+  // inline ghosts lie in allocation order: the replay walks the floes in the reference's order and the lists hold its numbers
+  // (ref[storage index] / sto[reference number]; the identity otherwise)
+  const int Np = h[C_N];
+  const bool renum = after_step && c->gi_valid && (int)c->gi_ref.size() == M - Np;
+  std::vector<int> ref(M), sto(M);
+  for (int i = 0; i < M; i++) { ref[i] = i < Np || !renum ? i : Np + c->gi_ref[i - Np]; sto[ref[i]] = i; }
+  for (int ii = 0; ii < M; ii++) {
+    const int i = sto[ii];
     for (int r = 0; r < nout[i]; r++)
-      if ((info[(size_t)i * MAXNB + r].x >> 8) & IT_FUSE) c->fuse_lists[i].push_back(nbo[(size_t)i * MAXNB + r]);
+      if ((info[(size_t)i * MAXNB + r].x >> 8) & IT_FUSE) c->fuse_lists[ii].push_back(ref[nbo[(size_t)i * MAXNB + r]]);
+  }
   if (mirror) {
-    for (int i = 0; i < M; i++) {
-      if (tag[i] != SZ_FUSE) continue;
-      size_t n = c->fuse_lists[i].size();
-      for (size_t k = 0; k < n; k++) { int idx = c->fuse_lists[i][k]; tag[idx] = SZ_FUSE; c->fuse_lists[idx].push_back(i); }
+    for (int ii = 0; ii < M; ii++) {
+      if (tag[sto[ii]] != SZ_FUSE) continue;
+      size_t n = c->fuse_lists[ii].size();
+      for (size_t k = 0; k < n; k++) { int idx = c->fuse_lists[ii][k]; tag[sto[idx]] = SZ_FUSE; c->fuse_lists[idx].push_back(ii); }
     }
   }
   if (after_step && coupled) {
@@ -662,6 +676,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_FUSED_MOVE")) c->fused_move = atoi(e) != 0;
   if (const char* e = getenv("SZ_TW_GENERAL_CLIP")) c->tw_general_clip = atoi(e) != 0;
   if (const char* e = getenv("SZ_LEAN_NARROW")) c->no_lean_narrow = atoi(e) == 0;
+  if (const char* e = getenv("SZ_GHOST_INLINE")) c->ghost_inline = atoi(e) != 0;
   if (const char* e = getenv("SZ_FUSE_FORCING")) { c->fuse_forcing = atoi(e) != 0; if (atoi(e) > 0) c->fuse_forcing_mode = atoi(e) >= 2 ? 2 : 1; }
   if (const char* e = getenv("SZ_STATIC_GRID")) c->no_static_grid = atoi(e) == 0;
   if (const char* e = getenv("SZ_BODY_RINGS")) c->no_body_rings = atoi(e) == 0;
@@ -827,7 +842,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   if (f->sub_off) for (int i = 0; i < N; i++) c->max_sub = std::max(c->max_sub, f->sub_off[i + 1] - f->sub_off[i]);
   DA(gplan, S.capM + 1); DA(gscan4, S.capM + 1); DA(gtot4, 4);
   DA(lb_agg, S.capM / SCAN_B + 8); DA(lb_inc, S.capM / SCAN_B + 8); DA(lb_flag, S.capM / SCAN_B + 8); c->scan_epoch = 0;
-  DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2); DA(gcand, (size_t)2 * S.capM);
+  DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2); DA(gcand, (size_t)2 * S.capM); DA(galloc, 32); DA(gkeys, (size_t)2 * S.capM);
   DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1); DA(cell_ovf, S.capCells + 1); DA(cell_slots, (size_t)S.capCells * CELL_K + 8);
   DA(cell_items, S.capM);
   DA(nb_out, (size_t)S.capM * MAXNB); DA(nb_in, (size_t)S.capM * MAXNB); DA(n_out, S.capM + 1); DA(n_in, S.capM + 1);
@@ -958,6 +973,19 @@ int sz_download_interactions(sz_ctx* c, int32_t* off, double* rows) {
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(tmp);
     if (e != hipSuccess) { c->err = hipGetErrorString(e); return SZ_E_HIP; }
+    if (c->gi_valid) {            // partners that were inline ghosts: order key -> the reference's floe number
+      std::vector<long long> sorted(c->gi_keys);
+      std::sort(sorted.begin(), sorted.end());
+      const double lim = (double)((long long)1 << 40);
+      for (int r = 0; r < total; r++) {
+        const double idx = rows[(size_t)r * 7];
+        if (idx <= lim) continue;
+        const long long key = (long long)idx - 1;
+        const auto it = std::lower_bound(sorted.begin(), sorted.end(), key);
+        if (it == sorted.end() || *it != key) { c->err = "interaction row names a ghost that is not among the last step's"; return SZ_E_STATE; }
+        rows[(size_t)r * 7] = (double)(c->hostN + (int)(it - sorted.begin()) + 1);
+      }
+    }
   }
   return SZ_OK;
 }
@@ -980,6 +1008,14 @@ int sz_download_pairs(sz_ctx* c, int32_t* pi, int32_t* pj) {
   if (h[C_NPAIRS] > 0) {
     HIPCHK(c, hipMemcpy(pi, c->S.pair_i, (size_t)h[C_NPAIRS] * sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(pj, c->S.pair_j, (size_t)h[C_NPAIRS] * sizeof(int), hipMemcpyDeviceToHost));
+    if (c->gi_valid && (int)c->gi_ref.size() == mlast - h[C_N]) {       // inline ghosts: storage index -> the reference's number, then its serial order
+      const int Np = h[C_N], np = h[C_NPAIRS];
+      std::vector<std::pair<int, int>> ps(np);
+      for (int k = 0; k < np; k++)
+        ps[k] = { pi[k] < Np ? pi[k] : Np + c->gi_ref[pi[k] - Np], pj[k] < Np ? pj[k] : Np + c->gi_ref[pj[k] - Np] };
+      std::sort(ps.begin(), ps.end());
+      for (int k = 0; k < np; k++) { pi[k] = ps[k].first; pj[k] = ps[k].second; }
+    }
   }
   return SZ_OK;
 }
@@ -1037,6 +1073,7 @@ int sz_debug_match_vertices(sz_ctx* c, int32_t npts, const double* px, const dou
 int sz_add_ghosts(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
+  c->gi_valid = false;         // (what follows numbers its ghosts by storage position)
   leave_resident(c);            // a process-mode call: the resident steps' ghost-candidate list is stale, the world rings must be current
   int oldM = c->hostM;
   stage_ghosts(c);
@@ -1066,6 +1103,7 @@ int sz_remove_ghosts(sz_ctx* c) {
 int sz_timestep_collisions(sz_ctx* c, int64_t n_init, int32_t dt) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
+  c->gi_valid = false;         // (what follows numbers its ghosts by storage position)
   leave_resident(c);            // a process-mode call: the resident steps' ghost-candidate list is stale, the world rings must be current
   collisions(c, (int)n_init, dt);
   c->inter_any = true; c->inter_lost = false;
@@ -1078,6 +1116,7 @@ int sz_timestep_collisions(sz_ctx* c, int64_t n_init, int32_t dt) {
 int sz_collide_pairs(sz_ctx* c, int64_t np, const int32_t* pi, const int32_t* pj, int32_t dt, double max_overlap) {
   if (!c || !c->have_floes || np < 0 || (np > 0 && (!pi || !pj))) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
+  c->gi_valid = false;         // (what follows numbers its ghosts by storage position)
   leave_resident(c);
   State& S = c->S;
   if (np > S.capPairs) { c->err = "too many explicit pairs"; return SZ_E_CAPACITY; }
@@ -1105,6 +1144,7 @@ int sz_collide_pairs(sz_ctx* c, int64_t np, const int32_t* pi, const int32_t* pj
 int sz_collide_domain(sz_ctx* c, int32_t dt, double max_overlap) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
+  c->gi_valid = false;         // (what follows numbers its ghosts by storage position)
   leave_resident(c);            // a process-mode call: the resident steps' ghost-candidate list is stale, the world rings must be current
   State& S = c->S;
   hipLaunchKernelGGL(sz_k_pairs_explicit, dim3(grid_for(S.capM + 1, 256)), dim3(256), 0, c->stream, S, 0);
@@ -1252,8 +1292,11 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   const bool gl = ghost_list_wanted(c, sg);
   // (ghosts a process-mode sz_add_ghosts left attached are dropped first: the list pass only visits the parents that get new ones)
   if (gl && periodic && c->hostM != c->hostN) hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
-  if (gl) use_ghost_list(c); else c->gl_valid = false;
+  // inline ghosts: no ghost launch in the steps at all (the integrator makes the next step's ghosts; needs the one-launch integrator)
+  const bool gi = gl && c->ghost_inline && !c->S.tiled && c->fused_move && c->max_ring <= MV_RING;
+  if (gl && !gi) use_ghost_list(c); else c->gl_valid = false;
   const int gl0 = c->gl_cur;
+  c->S.ginline = gi ? 1 : 0;
   const bool mixed = c->precision == 1 && !c->two_way;
   if (mixed) { int rc = ensure_mixed(c); if (rc) return rc; }
   // mixed precision: the steps run on body-frame rings (the integrator moves poses, not rings) when nothing else in the batch
@@ -1261,6 +1304,10 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   const bool body = mixed && coll && sg && (gl || !periodic) && !c->S.tiled && c->fused_move && c->max_ring <= MV_RING && !c->no_body_rings;
   if (!body) world_rings(c);
   c->S.body_rings = body ? 1 : 0;
+  if (gi) {               // the ghosts of the first step, from the parents as they lie (after the rings are in the batch's form)
+    HIPCHK(c, hipMemsetAsync(c->S.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0, c->hostN);
+  }
   // the largest narrow variant only takes items the small one hands on (none in most fields): it is left out of the steps until one
   // shows up -- the batch then pauses inside that step (stopped_late()) and is finished below
   bool lean = coll && !c->retry_seen && !c->no_lean_narrow && !c->S.tiled && !larger_rings(c);
@@ -1285,36 +1332,50 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
       const int fmode = !fuse ? 0 : c->fuse_forcing_mode ? c->fuse_forcing_mode : (c->hostN <= 30000 ? 2 : 1);
       if (!resume) {          // (a paused step has all of this behind it)
         if (coupling && !overlap && !fuse) stage_forcing(c, dt);
-        if (coll) stage_ghosts(c, true, sg, gl);
+        if (coll && !gi) stage_ghosts(c, true, sg, gl);
         if (overlap) stage_forcing_fork(c);
         if (coupling) c->forcing_where = fmode;
       }
+      c->S.gslot = s & 1;
       if (coll) collisions_step(c, c->hostN, dt, periodic && !sg, sg, resume ? 0 : fmode, lean, resume);
       if (overlap && !resume) stage_forcing_join(c);
-      stage_integrate(c, dt, !coll, coupling, sg, gl ? 1 - c->gl_cur : -1);
-      if (gl) c->gl_cur ^= 1;
+      stage_integrate(c, dt, !coll, coupling, sg, gl && !gi ? 1 - c->gl_cur : -1, gi ? 1 - (s & 1) : -1);
+      if (gl && !gi) c->gl_cur ^= 1;
     }
     c->S.step = 0;
     if (coll && periodic) hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
     int rc = sync_and_check(c, h);
-    if (rc) { c->S.retry_stop = 0; c->S.body_rings = 0; return rc; }
+    if (rc) { c->S.retry_stop = 0; c->S.body_rings = 0; c->S.ginline = 0; return rc; }
     if (!lean || h[C_RETRYSTOP] == 0) break;
     // paused after the narrow launch of step h[C_RETRYSTOP]: that variant is in from now on
     c->retry_seen = true; lean = false;
     s0 = h[C_RETRYSTOP] - 1; mid = 1;
-    if (gl) c->gl_cur = (gl0 + s0) & 1;
+    if (gl && !gi) c->gl_cur = (gl0 + s0) & 1;
     (void)hipMemsetAsync(c->S.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream);
   }
   c->S.retry_stop = 0;
+  c->S.ginline = 0;
   if (body && nsteps > 0) c->rings_stale = true;
   c->S.body_rings = 0;
   if (coll) { c->inter_any = true; c->inter_lost = false; }
   int rc = SZ_OK;
   const int done = h[C_STOP] > 0 ? h[C_STOP] : nsteps;
   if (steps_done) *steps_done = done;
-  if (gl) {               // the list the last step that RAN has filled, and how long it is
+  if (gl && !gi) {        // the list the last step that RAN has filled, and how long it is
     c->gl_cur = (gl0 + done) & 1;
     c->gl_est = h[C_NGCAND + c->gl_cur];
+  }
+  if (gi) {               // the order keys of the last step's ghosts: what the host needs to number them as the reference does
+    const int G = done > 0 ? h[C_NGHOSTS] : 0;
+    c->gi_keys.assign(G, 0);
+    if (G > 0) HIPCHK(c, hipMemcpy(c->gi_keys.data(), c->S.gkeys + (size_t)((done - 1) & 1) * c->S.capM, (size_t)G * sizeof(long long), hipMemcpyDeviceToHost));
+    std::vector<int> ord(G);
+    for (int k = 0; k < G; k++) ord[k] = k;
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return c->gi_keys[a] < c->gi_keys[b]; });
+    c->gi_ref.assign(G, 0);
+    for (int r = 0; r < G; r++) c->gi_ref[ord[r]] = r;
+    c->gi_valid = coll && done > 0;
+    c->gl_est = std::max(c->gl_est, G);        // (sizes the list pass should the next batch use it)
   }
   // status.fuse_idx of the step that ended the batch: the reference's serial propagation, replayed on the host as
   // sz_timestep_collisions does (only that step can have produced fuse pairs: the batch stops on the first tag)

@@ -633,6 +633,169 @@ __global__ void __launch_bounds__(256) sz_k_ghost_list(State S, int list, int bi
     ghost_fill_parent<false>(S, geo, lane, mine.x, mine.y, ex, T, N, NV0, bin, mine.w, mine.z, wall);
   }
 }
+// ---------------------------------------------------------------- "inline" ghosts: no ghost launch in the resident steps
+// Which ghosts a parent gets, and where they lie, depends on that parent alone; only their PLACE in the reference's order (all
+// E/W ghosts by parent, then all N/S ghosts by parent) needs the other parents.  The order matters in two ways: the serial order
+// of the pair loop / Dict rule -- carried by the order keys (okey), which need not be storage positions: (pass << 40) + 4 *
+// parent key + k orders the ghosts exactly as the reference does, as in the tiled runs -- and the numbers the host sees
+// (partner column of the rows, pair list, fuse lists), which are translated on download from the keys of the step's ghosts
+// (sz_api.hip ghost_ref_index).  So the thread that places a parent (the integrator at the end of step t, a seeding launch at
+// the start of a batch) makes the parent's ghosts for step t + 1 itself: rows and ring points from ONE packed atomic
+// {ghosts, points} -- rings stay packed back to back in allocation order -- copies of the parent's stored row translated by the
+// reference's own sequence of additions (ghosts_on_bounds!, collisions.jl:881-1000: ghost = copy + (+-L, 0) / (0, +-L); a parent
+// whose centroid has left the domain swaps with its new ghost).  The next neighbour search commits the counts.  The ghost
+// launch (11.5 us + a launch boundary at 10 k floes for ~230 ghosts) is gone from the step.
+constexpr int MV_RING = 20;      // ring points the one-launch integrator (sz_k_integrate<true>) holds in registers
+// up to three translations applied one after the other; an unused place holds (-0.0, -0.0), which changes no bit of any double
+struct Shift { double dx0, dy0, dx1, dy1, dx2, dy2; };
+__device__ __forceinline__ Shift shift_none() { Shift c; c.dx0 = c.dy0 = c.dx1 = c.dy1 = c.dx2 = c.dy2 = -0.0; return c; }
+__device__ __forceinline__ void shift_apply(const Shift& c, double& x, double& y) {
+  x += c.dx0; y += c.dy0; x += c.dx1; y += c.dy1; x += c.dx2; y += c.dy2;
+}
+// the parent's row as the ghosts copy it (deepcopy of the parent, collisions.jl:893): from the registers of the kernel that has just
+// placed it, or read back (ghost_row_load) -- every load before the first store, so that a thread pays one round trip, not one per point
+struct GhostRow {
+  double cx, cy, b0, b1, b2, b3, rmax, area, h, mass, mom, al, u, v, xi, over, tc, ts;
+  long long id, oki; int st; signed char os;
+  double rx[MV_RING], ry[MV_RING];          // the ring in world coordinates (unused on body-frame rings)
+};
+__device__ __forceinline__ void ghost_row_load(const State& S, int i, int n, int vo, GhostRow& r) {
+  r.cx = S.cx[i]; r.cy = S.cy[i]; r.b0 = S.bbx0[i]; r.b1 = S.bbx1[i]; r.b2 = S.bby0[i]; r.b3 = S.bby1[i];
+  r.rmax = S.rmax[i]; r.area = S.area[i]; r.h = S.height[i]; r.mass = S.mass[i]; r.mom = S.moment[i]; r.al = S.alpha[i];
+  r.u = S.u[i]; r.v = S.v[i]; r.xi = S.xi[i]; r.over = S.overarea[i];
+  r.id = S.id[i]; r.oki = S.okey[i]; r.st = S.status[i]; r.os = S.osign[i];
+  const bool body = S.body_rings != 0;
+  r.tc = body ? S.trig[2 * i] : 0.0; r.ts = body ? S.trig[2 * i + 1] : 0.0;
+#pragma unroll
+  for (int k = 0; k < MV_RING; k++) { r.rx[k] = !body && k < n ? S.vx[vo + k] : 0.0; r.ry[k] = !body && k < n ? S.vy[vo + k] : 0.0; }
+}
+// parent i with row R, flags fl != 5, ring (vo, n <= MV_RING); N parents, ring points of the parents NV0; slot: the allocator
+__device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, const double* wall, int N, int NV0, int slot, int i, int fl, int n, int vo,
+                                                  const GhostRow& R) {
+  const int dir0 = (fl & 3) - 1, dir1 = ((fl >> 2) & 3) - 1;
+  const int ng = dir0 != 0 && dir1 != 0 ? 3 : 1;
+  const bool body = S.body_rings != 0;
+  const int npts = body ? 0 : ng * n;                      // (ghosts on body-frame rings share the parent's ring)
+  // one allocation per wavefront for all its parents that make ghosts (the callers are thread-per-parent kernels; same-address atomics
+  // are worked off one at a time for the whole chip), handed on by a prefix over the lanes
+  const unsigned long long mine = ((unsigned long long)ng << 32) | (unsigned)npts;
+  const unsigned long long act = __ballot(1);
+  const int lane = threadIdx.x & 63, first = __ffsll((long long)act) - 1;
+  unsigned long long pre = 0, tot = 0;          // (a walk over the active lanes: the others hold nothing to shuffle from)
+  for (unsigned long long m = act; m; m &= m - 1) {
+    const int l = __ffsll((long long)m) - 1;
+    const unsigned long long v = __shfl(mine, l);
+    if (l < lane) pre += v;
+    tot += v;
+  }
+  unsigned long long base = 0;
+  if (lane == first) base = atomicAdd(&S.galloc[slot * 16], tot);
+  base = __shfl(base, first);
+  const unsigned long long old = base + pre;
+  const int og = (int)(old >> 32), ov = (int)(old & 0xffffffffull);
+  if (N + og + ng > S.capM) { atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
+  if (NV0 + ov + npts > S.capV) { atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); return; }
+  const double pcx = R.cx, pcy = R.cy, pb0 = R.b0, pb1 = R.b1, pb2 = R.b2, pb3 = R.b3;
+  const double c_rmax = R.rmax, c_area = R.area, c_h = R.h, c_mass = R.mass, c_mom = R.mom, c_al = R.al;
+  const double c_u = R.u, c_v = R.v, c_xi = R.xi, c_over = R.over, tc = R.tc, ts = R.ts;
+  const long long idv = R.id, oki = R.oki; const int stv = R.st; const signed char osv = R.os;
+  // ---- the two passes as sequences of translations (each applied to centroid, box and ring in turn: the reference's arithmetic)
+  // cp: the parent (swaps), c0: the E/W ghost -- or the N/S ghost of a parent without one --, c1: the N/S ghost of the E/W ghost,
+  // c2: the parent's own N/S ghost (corner parents)
+  Shift cp = shift_none(), c0 = shift_none(), c1 = shift_none(), c2 = shift_none();
+  long long k0 = 0, k1 = 0, k2 = 0;
+  bool moved = false;
+  if (dir0 != 0) {
+    const double maxv = wall[2], minv = wall[3], L = maxv - minv, t = dir0 > 0 ? L : -L;
+    c0.dx0 = t; c0.dy0 = 0.0;
+    double sp = 0.0;
+    if (pcx < minv) sp = L; else if (maxv < pcx) sp = -L;
+    if (sp != 0.0) { cp.dx0 = sp; cp.dy0 = 0.0; c0.dx1 = -sp; c0.dy1 = -0.0; moved = true; }
+    k0 = ((long long)1 << 40) + oki * 4;
+  }
+  if (dir1 != 0) {
+    const double maxv = wall[0], minv = wall[1], L = maxv - minv, t = dir1 > 0 ? L : -L;
+    double sp = 0.0;
+    if (pcy < minv) sp = L; else if (maxv < pcy) sp = -L;       // (the first pass does not move the parent in y)
+    if (dir0 != 0) {
+      c1 = c0; c1.dx2 = 0.0; c1.dy2 = t;                      // the ghost of the E/W ghost
+      c2.dx0 = cp.dx0; c2.dy0 = cp.dy0; c2.dx1 = 0.0; c2.dy1 = t;       // the parent's own (the parent as the first pass left it)
+      if (sp != 0.0) { cp.dx1 = 0.0; cp.dy1 = sp; c2.dx2 = -0.0; c2.dy2 = -sp; moved = true; }
+      k1 = ((long long)2 << 40) + oki * 4; k2 = ((long long)2 << 40) + oki * 4 + 1;
+    } else {
+      c0.dx0 = 0.0; c0.dy0 = t;
+      if (sp != 0.0) { cp.dx1 = 0.0; cp.dy1 = sp; c0.dx1 = -0.0; c0.dy1 = -sp; moved = true; }
+      k0 = ((long long)2 << 40) + oki * 4;
+    }
+  }
+  // ---- stores
+  auto put = [&](const Shift& c, int w, long long key) -> int {
+    const int g = N + og + w, vb = NV0 + ov + w * n;
+    double gx = pcx, gy = pcy, x0 = pb0, y0 = pb2, x1 = pb1, y1 = pb3;
+    shift_apply(c, gx, gy); shift_apply(c, x0, y0); shift_apply(c, x1, y1);
+    S.rmax[g] = c_rmax; S.area[g] = c_area; S.height[g] = c_h; S.mass[g] = c_mass; S.moment[g] = c_mom; S.alpha[g] = c_al;
+    S.u[g] = c_u; S.v[g] = c_v; S.xi[g] = c_xi; S.overarea[g] = c_over;
+    S.id[g] = idv; S.ghost_id[g] = (long long)(w + 1); S.okey[g] = key;
+    S.status[g] = stv; S.parent[g] = i; S.ngh[g] = 0; S.osign[g] = osv;
+    S.cfx[g] = 0.0; S.cfy[g] = 0.0; S.ctrq[g] = 0.0;
+    S.cx[g] = gx; S.cy[g] = gy; S.bbx0[g] = x0; S.bbx1[g] = x1; S.bby0[g] = y0; S.bby1[g] = y1;
+    if (body) { S.rb_off[g] = vo; S.rb_n[g] = n; S.trig[2 * g] = tc; S.trig[2 * g + 1] = ts; }
+    else {
+      S.voff[g] = vb; S.voff[g + 1] = vb + n;                // (the next allocation writes the same value: rings are packed back to back)
+#pragma unroll
+      for (int k = 0; k < MV_RING; k++) if (k < n) { double x = R.rx[k], y = R.ry[k]; shift_apply(c, x, y); S.vx[vb + k] = x; S.vy[vb + k] = y; }
+    }
+    if (S.rec32) rec32_store(S, g, gx, gy, c_rmax, x0, x1, y0, y1);
+    for (int q = 0; q < MAX_GHOSTS; q++) S.gh[g * MAX_GHOSTS + q] = -1;
+    S.gkeys[(size_t)slot * S.capM + og + w] = key;
+    int ix, iy; cell_of(geo, gx, gy, ix, iy);
+    return iy * geo.ncx + ix;
+  };
+  // (the cell entries last, their counter atomics back to back: one round trip for the three ghosts, not one each)
+  const int cl0 = put(c0, 0, k0);
+  int cl1 = -1, cl2 = -1;
+  if (ng == 3) { cl1 = put(c1, 1, k1); cl2 = put(c2, 2, k2); }
+  {
+    const int s0 = atomicAdd(&S.cell_cnt[cl0], 1);
+    const int s1 = cl1 >= 0 ? atomicAdd(&S.cell_cnt[cl1], 1) : 0, s2 = cl2 >= 0 ? atomicAdd(&S.cell_cnt[cl2], 1) : 0;
+    auto place = [&](int cl, int sl, int g) {            // as cell_insert()
+      if (sl < CELL_K) S.cell_slots[(size_t)cl * CELL_K + sl] = g;
+      else S.cell_items[g] = atomicExch(&S.cell_ovf[cl], g + 1) - 1;
+    };
+    place(cl0, s0, N + og);
+    if (cl1 >= 0) { place(cl1, s1, N + og + 1); place(cl2, s2, N + og + 2); }
+  }
+  if (moved) {                                               // the parent swapped with its ghost(s)
+    double px = pcx, py = pcy, x0 = pb0, y0 = pb2, x1 = pb1, y1 = pb3;
+    shift_apply(cp, px, py); shift_apply(cp, x0, y0); shift_apply(cp, x1, y1);
+    S.cx[i] = px; S.cy[i] = py; S.bbx0[i] = x0; S.bbx1[i] = x1; S.bby0[i] = y0; S.bby1[i] = y1;
+    if (!body) {
+#pragma unroll
+      for (int k = 0; k < MV_RING; k++) if (k < n) { double x = R.rx[k], y = R.ry[k]; shift_apply(cp, x, y); S.vx[vo + k] = x; S.vy[vo + k] = y; }
+    }
+    if (S.rec32) rec32_store(S, i, px, py, c_rmax, x0, x1, y0, y1);
+  }
+  for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = q < ng ? N + og + q : -1;
+  S.ngh[i] = ng;
+}
+// start of a resident batch: the ghosts of its first step, from the parents as they lie (thread per parent)
+__global__ void __launch_bounds__(256) sz_k_ghost_inline_seed(State S, int slot, int nh) {
+  const GridGeo geo = grid_geo(S);
+  const int N = nh >= 0 ? nh : S.cnt[C_N];
+  const int NV0 = S.voff[N];
+  const double wall[4] = { S.eval[0], S.eval[1], S.eval[2], S.eval[3] };
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    const int fl = ghost_flag_of(wall, S.any_periodic_ew, S.any_periodic_ns, S.cx[i], S.cy[i], S.rmax[i], S.bbx0[i], S.bbx1[i], S.bby0[i], S.bby1[i],
+                                 S.status[i] == SZ_ACTIVE && S.ghost_id[i] == 0);
+    if (fl != 5) {
+      const int n = ring_n(S, i), vo = ring_off(S, i);
+      if (n > MV_RING) { atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); continue; }
+      GhostRow R; ghost_row_load(S, i, n, vo, R);
+      ghost_inline_make(S, geo, wall, N, NV0, slot, i, fl, n, vo, R);
+    }
+  }
+}
+
 // mixed precision: the rings of the parents into their body frame (offsets from the centroid at alpha = 0, fp32) ...
 __global__ void sz_k_body_rings(State S) {
   const int N = S.cnt[C_N];
@@ -894,6 +1057,12 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   const int gl = threadIdx.x % NB_G, gi = threadIdx.x / NB_G;
   const StopRegs stop = stop_load(S);
   int M = S.cnt[C_M];
+  if (S.ginline) {            // inline ghosts: the step's ghosts were made by the kernel that placed their parents; the counts are committed here
+    const unsigned long long a = S.galloc[S.gslot * 16];
+    const int N = S.cnt[C_N], G = (int)(a >> 32), V = (int)(a & 0xffffffffull);
+    M = N + G;
+    if (bid == 0 && threadIdx.x == 0 && !stop_test(S, stop)) { S.cnt[C_M] = M; S.cnt[C_NV] = S.voff[N] + V; S.cnt[C_NGHOSTS] = G; }
+  }
   const GridGeo g = grid_geo(S);
   const int ncx = g.ncx, ncy = g.ncy;
   const int seg = bid % NSEG, segcap = seg_cap(S);
@@ -1162,6 +1331,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     const int ncells = (int)S.bounds[4] * (int)S.bounds[5];
     for (int q = blockIdx.x * TPB + threadIdx.x; q <= ncells; q += nblk * TPB) { S.cell_cnt[q] = 0; S.cell_ovf[q] = 0; }
     if (blockIdx.x == 0) for (int q = threadIdx.x; q < WARN_SLOTS * 4; q += TPB) S.warn[(q >> 2) * 32 + (q & 3)] = 0;
+    if (S.ginline && blockIdx.x == 0 && threadIdx.x == 0) S.galloc[(1 - S.gslot) * 16] = 0ull;      // the allocator this step's integrator makes the next ghosts in
   }
   STAMP(st, 21);
   // The one-item-per-wavefront variant mostly looks for the few items meant for it: its lanes test 64
@@ -1932,19 +2102,21 @@ __global__ void sz_k_calc_stress(State S, Params P) {
 // box, evaluates the strain and bins the floe -- what sz_k_move_strain does with 16 lanes per floe in a
 // second launch.  The ring is read into registers in one go (one memory round trip), the per-edge strain terms
 // are the same expressions summed in the same order.
-constexpr int MV_RING = 20;
 template <bool MOVE>
 // gl_fill (resident steps): the ghost-candidate list to append to (sz_k_ghost_list), -1: none
-__global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Params P, int dt, int apply_frc, int bin, int nh, int gl_fill) {
+// ginl: the allocator to make the next step's ghosts in (inline ghosts), -1: none
+__global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Params P, int dt, int apply_frc, int bin, int nh, int gl_fill, int ginl) {
   const GridGeo geo = grid_geo(S);
   const StopRegs stop = stop_load(S);
   const int N = nh >= 0 ? nh : S.cnt[C_NOWN];     // nh: see sz_k_ghost_flag_scan
+  const int nv0 = MOVE && ginl >= 0 ? S.voff[N] : 0;       // ring points of the parents (inline ghosts are laid out behind them)
   int wh = 0, wf = 0, wv = 0, wx = 0;
   const double wall[4] = { S.eval[0], S.eval[1], S.eval[2], S.eval[3] };
   bool tested = false;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-    const int st0 = gl_fill >= 0 ? S.status[i] : SZ_ACTIVE, ngh0 = gl_fill >= 0 ? S.ngh[i] : 0;
-    const double rmx = MOVE && (gl_fill >= 0 || S.rec32) ? S.rmax[i] : 0.0;
+    const bool gl_any = gl_fill >= 0 || ginl >= 0;
+    const int st0 = gl_any ? S.status[i] : SZ_ACTIVE, ngh0 = gl_any ? S.ngh[i] : 0;
+    const double rmx = MOVE && (gl_any || S.rec32) ? S.rmax[i] : 0.0;
     // Memory order is the whole cost of this kernel (a store in between keeps the compiler from hoisting the
     // loads behind it, and every batch of loads is one HBM round trip): everything is read first -- the
     // columns, then what their values address (contact rows, ring) -- then computed, then stored.
@@ -2067,9 +2239,24 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
       S.cx[i] = ncx; S.cy[i] = ncy;
       if (S.rec32) rec32_store(S, i, ncx, ncy, rmx, bx0, bx1, by0, by1);
       if (bin) cell_insert(S, geo, i, ncx, ncy);
-      if (gl_fill >= 0) {
+      if (gl_any) {
         const int gf = ghost_flag_of(wall, S.any_periodic_ew, S.any_periodic_ns, ncx, ncy, rmx, bx0, bx1, by0, by1, (frc_rm ? SZ_REMOVE : st0) == SZ_ACTIVE);
-        ghost_candidate_wave(S, gl_fill, gf != 5, i, gf, n, o);
+        if (ginl >= 0) {
+          if (gf != 5) {             // the next step's ghosts of this parent, from what has just been computed (a few per cent of the threads)
+            GhostRow R;
+            R.cx = ncx; R.cy = ncy; R.b0 = bx0; R.b1 = bx1; R.b2 = by0; R.b3 = by1;
+            R.rmax = rmx; R.area = area; R.h = h; R.mass = mass; R.mom = moment; R.al = al; R.u = nu; R.v = nv; R.xi = nxi;
+            R.over = S.overarea[i]; R.id = S.id[i]; R.oki = S.okey[i]; R.os = S.osign[i]; R.st = SZ_ACTIVE; R.tc = cal; R.ts = sal;
+#pragma unroll
+            for (int k = 0; k < MV_RING; k++) {        // the moved ring again (the expressions of the stores above: the same bits)
+              const double x = body ? 0.0 : px[k] + (-cx), y = body ? 0.0 : py[k] + (-cy);
+              const double xr = cda * x - sda * y, yr = sda * x + cda * y;
+              R.rx[k] = xr + (cx + dx); R.ry[k] = yr + (cy + dy);
+            }
+            ghost_inline_make(S, geo, wall, N, nv0, ginl, i, gf, n, o, R);
+          }
+        }
+        else ghost_candidate_wave(S, gl_fill, gf != 5, i, gf, n, o);
       }
     }
   }

@@ -114,6 +114,11 @@ struct State {
   // ---- ghosts workspace
   int *gflag, *gvscan;        // gvscan: ring offsets of the halo records being unpacked
   int4 *gplan, *gscan4, *gtot4;
+  // ghosts made by the kernel that places the parent (resident steps, "inline" ghosts: sz_kernels.hpp ghost_inline_make): two
+  // allocators {ghosts << 32 | ring points} a cache line apart (galloc[0], galloc[16]), used alternately step by step, and per
+  // allocator the order key of the ghost at every storage offset (gkeys[slot * capM + offset])
+  unsigned long long* galloc; long long* gkeys;
+  int ginline, gslot;         // inline ghosts on; the allocator holding the ghosts of the step being launched
   int4* gcand;                // two lists of capM entries {parent, ghost flags, ring points, -}: the parents that get ghosts in the next
                               // step, appended by whoever places a floe (integrator, halo unpack) -- see sz_k_ghost_list
   int4 *lb_agg, *lb_inc; unsigned* lb_flag;   // decoupled look-back scan: per workgroup aggregate, inclusive prefix, (epoch << 2 | status)
