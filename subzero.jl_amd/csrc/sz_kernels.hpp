@@ -689,12 +689,7 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
     tot += v;
   }
   unsigned long long base = 0;
-  if (lane == first) base = atomicAdd(&S.galloc[slot * 16], tot);
-  base = __shfl(base, first);
-  const unsigned long long old = base + pre;
-  const int og = (int)(old >> 32), ov = (int)(old & 0xffffffffull);
-  if (N + og + ng > S.capM) { atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
-  if (NV0 + ov + npts > S.capV) { atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); return; }
+  if (lane == first) base = atomicAdd(&S.galloc[slot * 16], tot);      // (its answer is looked at below, after the cell counters have gone out too)
   const double pcx = R.cx, pcy = R.cy, pb0 = R.b0, pb1 = R.b1, pb2 = R.b2, pb3 = R.b3;
   const double c_rmax = R.rmax, c_area = R.area, c_h = R.h, c_mass = R.mass, c_mom = R.mom, c_al = R.al;
   const double c_u = R.u, c_v = R.v, c_xi = R.xi, c_over = R.over, tc = R.tc, ts = R.ts;
@@ -728,8 +723,18 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
       k0 = ((long long)2 << 40) + oki * 4;
     }
   }
+  // ---- the counters of the cells the ghosts fall into are drawn now, beside the allocation: one round trip for both
+  auto cellof = [&](const Shift& c) { double x = pcx, y = pcy; shift_apply(c, x, y); int ix, iy; cell_of(geo, x, y, ix, iy); return iy * geo.ncx + ix; };
+  const int cl0 = cellof(c0), cl1 = ng == 3 ? cellof(c1) : -1, cl2 = ng == 3 ? cellof(c2) : -1;
+  const int s0 = atomicAdd(&S.cell_cnt[cl0], 1);
+  const int s1 = cl1 >= 0 ? atomicAdd(&S.cell_cnt[cl1], 1) : 0, s2 = cl2 >= 0 ? atomicAdd(&S.cell_cnt[cl2], 1) : 0;
+  base = __shfl(base, first);
+  const unsigned long long old = base + pre;
+  const int og = (int)(old >> 32), ov = (int)(old & 0xffffffffull);
+  if (N + og + ng > S.capM) { atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
+  if (NV0 + ov + npts > S.capV) { atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); return; }
   // ---- stores
-  auto put = [&](const Shift& c, int w, long long key) -> int {
+  auto put = [&](const Shift& c, int w, long long key) {
     const int g = N + og + w, vb = NV0 + ov + w * n;
     double gx = pcx, gy = pcy, x0 = pb0, y0 = pb2, x1 = pb1, y1 = pb3;
     shift_apply(c, gx, gy); shift_apply(c, x0, y0); shift_apply(c, x1, y1);
@@ -748,16 +753,10 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
     if (S.rec32) rec32_store(S, g, gx, gy, c_rmax, x0, x1, y0, y1);
     for (int q = 0; q < MAX_GHOSTS; q++) S.gh[g * MAX_GHOSTS + q] = -1;
     S.gkeys[(size_t)slot * S.capM + og + w] = key;
-    int ix, iy; cell_of(geo, gx, gy, ix, iy);
-    return iy * geo.ncx + ix;
   };
-  // (the cell entries last, their counter atomics back to back: one round trip for the three ghosts, not one each)
-  const int cl0 = put(c0, 0, k0);
-  int cl1 = -1, cl2 = -1;
-  if (ng == 3) { cl1 = put(c1, 1, k1); cl2 = put(c2, 2, k2); }
+  put(c0, 0, k0);
+  if (ng == 3) { put(c1, 1, k1); put(c2, 2, k2); }
   {
-    const int s0 = atomicAdd(&S.cell_cnt[cl0], 1);
-    const int s1 = cl1 >= 0 ? atomicAdd(&S.cell_cnt[cl1], 1) : 0, s2 = cl2 >= 0 ? atomicAdd(&S.cell_cnt[cl2], 1) : 0;
     auto place = [&](int cl, int sl, int g) {            // as cell_insert()
       if (sl < CELL_K) S.cell_slots[(size_t)cl * CELL_K + sl] = g;
       else S.cell_items[g] = atomicExch(&S.cell_ovf[cl], g + 1) - 1;
