@@ -2147,6 +2147,12 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
         for (int k = 0; k < MV_RING; k++) { px[k] = k < n ? S.vx[o + k] : 0.0; py[k] = k < n ? S.vy[o + k] : 0.0; }
       }
     }
+    // where the centroid goes depends on the old velocities alone (AB2): the counter of the cell it lands in is drawn now, and its
+    // answer -- a round trip -- is used with the last stores instead of being waited for there
+    const double dx = 1.5 * dt * u - 0.5 * dt * p_dxdt;
+    const double dy = 1.5 * dt * v - 0.5 * dt * p_dydt;
+    int cell_c = 0, cell_s = 0;
+    if (MOVE && bin) { int ix, iy; cell_of(geo, cx + dx, cy + dy, ix, iy); cell_c = iy * geo.ncx + ix; cell_s = atomicAdd(&S.cell_cnt[cell_c], 1); }
     // calc_stress! (update_floe.jl:392-414): as floe_stress(), on the values read above
     double s11 = 0, s12 = 0, s21 = 0, s22 = 0;
     if (rn > 0) {
@@ -2169,8 +2175,6 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
     double dh = hflx / h;
     double hfrac = (h + dh) / h;
     mass *= hfrac; double moment = moment0 * hfrac; h -= dh;
-    double dx = 1.5 * dt * u - 0.5 * dt * p_dxdt;
-    double dy = 1.5 * dt * v - 0.5 * dt * p_dydt;
     double da = 1.5 * dt * xi - 0.5 * dt * p_dalphadt;
     const double al = alpha0 + da;
     double cal, sal, cda, sda;                              // cos / sin alpha for the forcing kernel (32 lanes per floe: not the place for it)
@@ -2237,7 +2241,10 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
       S.strain[i * 4 + 0] = e11 / d; S.strain[i * 4 + 1] = e12 / d; S.strain[i * 4 + 2] = e12 / d; S.strain[i * 4 + 3] = e22 / d;
       S.cx[i] = ncx; S.cy[i] = ncy;
       if (S.rec32) rec32_store(S, i, ncx, ncy, rmx, bx0, bx1, by0, by1);
-      if (bin) cell_insert(S, geo, i, ncx, ncy);
+      if (bin) {                     // as cell_insert(), with the counter drawn above
+        if (cell_s < CELL_K) S.cell_slots[(size_t)cell_c * CELL_K + cell_s] = i;
+        else S.cell_items[i] = atomicExch(&S.cell_ovf[cell_c], i + 1) - 1;
+      }
       if (gl_any) {
         const int gf = ghost_flag_of(wall, S.any_periodic_ew, S.any_periodic_ns, ncx, ncy, rmx, bx0, bx1, by0, by1, (frc_rm ? SZ_REMOVE : st0) == SZ_ACTIVE);
         if (ginl >= 0) {
