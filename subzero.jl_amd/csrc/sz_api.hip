@@ -1339,7 +1339,8 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
       c->S.gslot = s & 1;
       if (coll) collisions_step(c, c->hostN, dt, periodic && !sg, sg, resume ? 0 : fmode, lean, resume);
       if (overlap && !resume) stage_forcing_join(c);
-      stage_integrate(c, dt, !coll, coupling, sg, gl && !gi ? 1 - c->gl_cur : -1, gi ? 1 - (s & 1) : -1);
+      // (inline ghosts: the last step of the batch makes none -- there is no step to make them for, and the cell lists stay the parents')
+      stage_integrate(c, dt, !coll, coupling, sg, gl && !gi ? 1 - c->gl_cur : -1, gi && s + 1 < nsteps ? 1 - (s & 1) : -1);
       if (gl && !gi) c->gl_cur ^= 1;
     }
     c->S.step = 0;
@@ -1375,6 +1376,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     c->gi_ref.assign(G, 0);
     for (int r = 0; r < G; r++) c->gi_ref[ord[r]] = r;
     c->gi_valid = coll && done > 0;
+    if (done < nsteps) c->grid_live = false;       // stopped early: the step that ended the batch has binned ghosts for a step that did not come
     c->gl_est = std::max(c->gl_est, G);        // (sizes the list pass should the next batch use it)
   }
   // status.fuse_idx of the step that ended the batch: the reference's serial propagation, replayed on the host as

@@ -493,6 +493,22 @@ def test_resident_batch_pauses_for_the_largest_narrow_variant():
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def test_one_step_batches_match_the_oracle():
+    """timestep_sim! called step by step (batches of one resident step each, nothing in between): what a batch leaves
+    behind -- cell lists, ghost bookkeeping of its last integrator -- must not leak into the next one"""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=400, seed=7)
+    hw, ow = _pair(cfg)
+    for t in range(4):
+        hw.timestep_sim(t, cfg["dt"], coupling_dt=1); ow.timestep_sim(t, cfg["dt"], coupling_dt=1)
+    parity.compare_worlds(hw, ow, rtol=1e-9)
+    hw.run(3, 4, cfg["dt"], coupling_dt=1, stop_on_tags=False)
+    for t in range(4, 7):
+        ow.timestep_sim(t, cfg["dt"], coupling_dt=1)
+    hw.timestep_sim(7, cfg["dt"], coupling_dt=1); ow.timestep_sim(7, cfg["dt"], coupling_dt=1)
+    parity.compare_worlds(hw, ow, rtol=1e-9)
+
+
 def test_field_reupload_keeps_the_temperatures():
     """sz_set_fields with an unchanged lattice shape keeps the ocean / atmosphere temperatures of sz_set_temps (the
     heat-flux factor of calc_two_way_coupling!, coupling.jl:1676, depends on them)."""
