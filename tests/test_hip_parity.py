@@ -509,6 +509,17 @@ def test_one_step_batches_match_the_oracle():
     parity.compare_worlds(hw, ow, rtol=1e-9)
 
 
+def test_random_call_sequences_match_the_oracle():
+    """tools/fuzz_sequences.py, a few seeds of it: random sequences of resident batches, timestep_sim! step by step, the process-mode
+    sequence, host edits and downloads on small periodic fields with fast floes (parents cross the walls), against the oracle at
+    every checkpoint -- nothing a call leaves behind may leak into the next (300 seeds x 15 calls were run when this was written:
+    all agree to the round-off of 30-step runs)"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_sequences", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_sequences.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    assert mod.run(nseeds=10, nops=10, rtol=1e-8, verbose=False) == 0
+
+
 def test_field_reupload_keeps_the_temperatures():
     """sz_set_fields with an unchanged lattice shape keeps the ocean / atmosphere temperatures of sz_set_temps (the
     heat-flux factor of calc_two_way_coupling!, coupling.jl:1676, depends on them)."""
