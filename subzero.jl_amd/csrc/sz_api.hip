@@ -1297,6 +1297,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   if (gl && !gi) use_ghost_list(c); else c->gl_valid = false;
   const int gl0 = c->gl_cur;
   c->S.ginline = gi ? 1 : 0;
+  if (coll) c->gi_valid = false;    // (this batch's rows replace the old ones; set again below if they carry order keys of inline ghosts)
   const bool mixed = c->precision == 1 && !c->two_way;
   if (mixed) { int rc = ensure_mixed(c); if (rc) return rc; }
   // mixed precision: the steps run on body-frame rings (the integrator moves poses, not rings) when nothing else in the batch
@@ -1375,7 +1376,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     std::sort(ord.begin(), ord.end(), [&](int a, int b) { return c->gi_keys[a] < c->gi_keys[b]; });
     c->gi_ref.assign(G, 0);
     for (int r = 0; r < G; r++) c->gi_ref[ord[r]] = r;
-    c->gi_valid = coll && done > 0;
+    if (coll) c->gi_valid = done > 0;
     if (done < nsteps) c->grid_live = false;       // stopped early: the step that ended the batch has binned ghosts for a step that did not come
     c->gl_est = std::max(c->gl_est, G);        // (sizes the list pass should the next batch use it)
   }
