@@ -646,6 +646,14 @@ __global__ void __launch_bounds__(256) sz_k_ghost_list(State S, int list, int bi
 // whose centroid has left the domain swaps with its new ghost).  The next neighbour search commits the counts.  The ghost
 // launch (11.5 us + a launch boundary at 10 k floes for ~230 ghosts) is gone from the step.
 constexpr int MV_RING = 20;      // ring points the one-launch integrator (sz_k_integrate<true>) holds in registers
+#ifdef SZ_STAMPS
+#ifndef SZ_ISTAMP_FLOE
+#define SZ_ISTAMP_FLOE 99
+#endif
+#define GSTAMP(k) do { if (i == SZ_ISTAMP_FLOE) S.stamps[900 + (k)] = clock64(); } while (0)
+#else
+#define GSTAMP(k) do {} while (0)
+#endif
 // up to three translations applied one after the other; an unused place holds (-0.0, -0.0), which changes no bit of any double
 struct Shift { double dx0, dy0, dx1, dy1, dx2, dy2; };
 __device__ __forceinline__ Shift shift_none() { Shift c; c.dx0 = c.dy0 = c.dx1 = c.dy1 = c.dx2 = c.dy2 = -0.0; return c; }
@@ -726,9 +734,12 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
   // ---- the counters of the cells the ghosts fall into are drawn now, beside the allocation: one round trip for both
   auto cellof = [&](const Shift& c) { double x = pcx, y = pcy; shift_apply(c, x, y); int ix, iy; cell_of(geo, x, y, ix, iy); return iy * geo.ncx + ix; };
   const int cl0 = cellof(c0), cl1 = ng == 3 ? cellof(c1) : -1, cl2 = ng == 3 ? cellof(c2) : -1;
+  GSTAMP(10);
   const int s0 = atomicAdd(&S.cell_cnt[cl0], 1);
   const int s1 = cl1 >= 0 ? atomicAdd(&S.cell_cnt[cl1], 1) : 0, s2 = cl2 >= 0 ? atomicAdd(&S.cell_cnt[cl2], 1) : 0;
+  GSTAMP(11);
   base = __shfl(base, first);
+  GSTAMP(12);
   const unsigned long long old = base + pre;
   const int og = (int)(old >> 32), ov = (int)(old & 0xffffffffull);
   if (N + og + ng > S.capM) { atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
@@ -744,19 +755,22 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
     S.status[g] = stv; S.parent[g] = i; S.ngh[g] = 0; S.osign[g] = osv;
     S.cfx[g] = 0.0; S.cfy[g] = 0.0; S.ctrq[g] = 0.0;
     S.cx[g] = gx; S.cy[g] = gy; S.bbx0[g] = x0; S.bbx1[g] = x1; S.bby0[g] = y0; S.bby1[g] = y1;
+    GSTAMP(16);
     if (body) { S.rb_off[g] = vo; S.rb_n[g] = n; S.trig[2 * g] = tc; S.trig[2 * g + 1] = ts; }
     else {
       S.voff[g] = vb; S.voff[g + 1] = vb + n;                // (the next allocation writes the same value: rings are packed back to back)
 #pragma unroll
       for (int k = 0; k < MV_RING; k++) if (k < n) { double x = R.rx[k], y = R.ry[k]; shift_apply(c, x, y); S.vx[vb + k] = x; S.vy[vb + k] = y; }
     }
+    GSTAMP(17);
     if (S.rec32) rec32_store(S, g, gx, gy, c_rmax, x0, x1, y0, y1);
     for (int q = 0; q < MAX_GHOSTS; q++) S.gh[g * MAX_GHOSTS + q] = -1;
     S.gkeys[(size_t)slot * S.capM + og + w] = key;
   };
-  put(c0, 0, k0);
-  if (ng == 3) { put(c1, 1, k1); put(c2, 2, k2); }
+  GSTAMP(13);
   {
+    // the cell entries BEFORE the copies: both need answers (allocation, counters), and a wait for an answer after the ~70 stores of
+    // a copy would be a wait for all of them
     auto place = [&](int cl, int sl, int g) {            // as cell_insert()
       if (sl < CELL_K) S.cell_slots[(size_t)cl * CELL_K + sl] = g;
       else S.cell_items[g] = atomicExch(&S.cell_ovf[cl], g + 1) - 1;
@@ -764,6 +778,10 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
     place(cl0, s0, N + og);
     if (cl1 >= 0) { place(cl1, s1, N + og + 1); place(cl2, s2, N + og + 2); }
   }
+  GSTAMP(14);
+  put(c0, 0, k0);
+  if (ng == 3) { put(c1, 1, k1); put(c2, 2, k2); }
+  GSTAMP(15);
   if (moved) {                                               // the parent swapped with its ghost(s)
     double px = pcx, py = pcy, x0 = pb0, y0 = pb2, x1 = pb1, y1 = pb3;
     shift_apply(cp, px, py); shift_apply(cp, x0, y0); shift_apply(cp, x1, y1);
@@ -2104,6 +2122,16 @@ __global__ void sz_k_calc_stress(State S, Params P) {
 template <bool MOVE>
 // gl_fill (resident steps): the ghost-candidate list to append to (sz_k_ghost_list), -1: none
 // ginl: the allocator to make the next step's ghosts in (inline ghosts), -1: none
+#ifdef SZ_STAMPS
+// diagnostic build: clock of the thread that updates floe SZ_ISTAMP_FLOE at a few points of the integrator (stamps[900 + k]);
+// tools/integrate_stamps.py prints them
+#ifndef SZ_ISTAMP_FLOE
+#define SZ_ISTAMP_FLOE 99
+#endif
+#define ISTAMP(k) do { if (MOVE && i == SZ_ISTAMP_FLOE) S.stamps[900 + (k)] = clock64(); } while (0)
+#else
+#define ISTAMP(k) do {} while (0)
+#endif
 __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Params P, int dt, int apply_frc, int bin, int nh, int gl_fill, int ginl) {
   const GridGeo geo = grid_geo(S);
   const StopRegs stop = stop_load(S);
@@ -2113,6 +2141,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
   const double wall[4] = { S.eval[0], S.eval[1], S.eval[2], S.eval[3] };
   bool tested = false;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    ISTAMP(0);
     const bool gl_any = gl_fill >= 0 || ginl >= 0;
     const int st0 = gl_any ? S.status[i] : SZ_ACTIVE, ngh0 = gl_any ? S.ngh[i] : 0;
     const double rmx = MOVE && (gl_any || S.rec32) ? S.rmax[i] : 0.0;
@@ -2128,14 +2157,15 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
     const double p_dxdt = S.p_dxdt[i], p_dydt = S.p_dydt[i], p_dalphadt = S.p_dalphadt[i];
     const double p_dudt = S.p_dudt[i], p_dvdt = S.p_dvdt[i], p_dxidt = S.p_dxidt[i];
     const double fxOA = S.fxOA[i], fyOA = S.fyOA[i], trqOA = S.trqOA[i];
-    double sa0[4];
-    for (int k = 0; k < 4; k++) sa0[k] = S.sa[i * 4 + k];
+    const double4 sa4 = *(const double4*)(S.sa + (size_t)i * 4);
+    const double sa0[4] = { sa4.x, sa4.y, sa4.z, sa4.w };
     const int o = MOVE ? ring_off(S, i) : 0, n = MOVE ? ring_n(S, i) : 0;
     if (!tested) {             // (the stop test after the first batch of loads has gone out, before anything is stored)
       loads_issued();
       if (stop_test_late(S, stop)) break;
       tested = true;
     }
+    ISTAMP(1);
     const bool body = MOVE && S.body_rings;           // the ring in its body frame (fp32), pose in fp64: nothing to rewrite
     double px[MOVE ? MV_RING : 1], py[MOVE ? MV_RING : 1];
     if (MOVE) {
@@ -2167,6 +2197,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
       s11 *= sc; s12 *= sc; s21 *= sc; s22 *= sc;
     }
     const double l = P.lambda, sv[4] = { s11, s12, s21, s22 };
+    ISTAMP(2);
     double hh = height0;
     if (hh > P.max_h) { hh = P.max_h; wh++; }
     double mass = mass0;
@@ -2193,16 +2224,25 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
     dxidt = frac * dxidt;
     double nxi = xi + 1.5 * dt * dxidt - 0.5 * dt * p_dxidt;
     if (fabs(nxi) > P.max_xi) { nxi = sgn(nxi) * P.max_xi; wx++; }
-    // ---- stores
+    ISTAMP(3);
+    // ---- stores.  First the floe's cell entry: its counter was drawn long ago, and a wait for an answer AFTER the stores below would
+    // be a wait for every one of them (loads and stores return in order only among their own kind: the counter says "all done")
+    if (MOVE && bin) {               // as cell_insert()
+      if (cell_s < CELL_K) S.cell_slots[(size_t)cell_c * CELL_K + cell_s] = i;
+      else S.cell_items[i] = atomicExch(&S.cell_ovf[cell_c], i + 1) - 1;
+    }
     if (frc_rm) { S.status[i] = SZ_REMOVE; request_stop(S); }
     // the ghosts of this step are detached here (nothing after the reduce looks at them): the next step's ghost pass
     // then only visits the parents that get new ones
     if (ngh0 != 0) { S.ngh[i] = 0; for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = -1; }
-    for (int k = 0; k < 4; k++) { S.sa[i * 4 + k] = (1 - l) * sa0[k] + l * sv[k]; S.si[i * 4 + k] = sv[k]; }
+    // (a wavefront holds at most 63 memory operations in flight, and this thread issues ~70 stores: the four-component columns go out
+    //  as one 32-byte store each)
+    *(double4*)(S.sa + (size_t)i * 4) = make_double4((1 - l) * sa0[0] + l * sv[0], (1 - l) * sa0[1] + l * sv[1], (1 - l) * sa0[2] + l * sv[2], (1 - l) * sa0[3] + l * sv[3]);
+    *(double4*)(S.si + (size_t)i * 4) = make_double4(sv[0], sv[1], sv[2], sv[3]);
     S.mass[i] = mass; S.moment[i] = moment; S.height[i] = h;
     S.alpha[i] = al;
-    S.trig[2 * i] = cal; S.trig[2 * i + 1] = sal;
-    if (!MOVE) { S.mot[i * 4 + 0] = dx; S.mot[i * 4 + 1] = dy; S.mot[i * 4 + 2] = cda; S.mot[i * 4 + 3] = sda; }
+    *(double2*)(S.trig + (size_t)i * 2) = make_double2(cal, sal);
+    if (!MOVE) *(double4*)(S.mot + (size_t)i * 4) = make_double4(dx, dy, cda, sda);
     S.p_dxdt[i] = u; S.p_dydt[i] = v; S.p_dalphadt[i] = xi;
     S.u[i] = nu; S.v[i] = nv;
     S.p_dudt[i] = dudt; S.p_dvdt[i] = dvdt;
@@ -2238,13 +2278,10 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
       S.bbx0[i] = bx0; S.bbx1[i] = bx1; S.bby0[i] = by0; S.bby1[i] = by1;
       e12 *= 0.5;
       const double d = 2 * area;
-      S.strain[i * 4 + 0] = e11 / d; S.strain[i * 4 + 1] = e12 / d; S.strain[i * 4 + 2] = e12 / d; S.strain[i * 4 + 3] = e22 / d;
+      *(double4*)(S.strain + (size_t)i * 4) = make_double4(e11 / d, e12 / d, e12 / d, e22 / d);
       S.cx[i] = ncx; S.cy[i] = ncy;
       if (S.rec32) rec32_store(S, i, ncx, ncy, rmx, bx0, bx1, by0, by1);
-      if (bin) {                     // as cell_insert(), with the counter drawn above
-        if (cell_s < CELL_K) S.cell_slots[(size_t)cell_c * CELL_K + cell_s] = i;
-        else S.cell_items[i] = atomicExch(&S.cell_ovf[cell_c], i + 1) - 1;
-      }
+      ISTAMP(4);
       if (gl_any) {
         const int gf = ghost_flag_of(wall, S.any_periodic_ew, S.any_periodic_ns, ncx, ncy, rmx, bx0, bx1, by0, by1, (frc_rm ? SZ_REMOVE : st0) == SZ_ACTIVE);
         if (ginl >= 0) {
@@ -2259,7 +2296,9 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
               const double xr = cda * x - sda * y, yr = sda * x + cda * y;
               R.rx[k] = xr + (cx + dx); R.ry[k] = yr + (cy + dy);
             }
+            ISTAMP(5);
             ghost_inline_make(S, geo, wall, N, nv0, ginl, i, gf, n, o, R);
+            ISTAMP(6);
           }
         }
         else ghost_candidate_wave(S, gl_fill, gf != 5, i, gf, n, o);

@@ -19,7 +19,7 @@ for blk in range(0, 40):
     os.environ["SZ_DEBUG"] = str((blk << 8) | int(os.environ.get("SZ_STAMPS_TWICE", "0")) * 16)
     w = fields.build_world(subzero_jl_amd.World(0), cfg)
     w.run(3, 0, cfg["dt"], coupling_dt=1)
-    out = np.zeros(512, np.int64)
+    out = np.zeros(512 + 8 * 8000, np.int64)
     w._chk(w.L.sz_debug_stamps(w.h, capi.ptr(out, capi._lp)))
     w.run(1, 3, cfg["dt"], coupling_dt=1)
     w._chk(w.L.sz_debug_stamps(w.h, capi.ptr(out, capi._lp)))
@@ -36,7 +36,7 @@ for blk in range(0, 40):
 w = fields.build_world(subzero_jl_amd.World(0), cfg)
 os.environ["SZ_DEBUG"] = str(1 << 30)
 w.run(3, 0, cfg["dt"], coupling_dt=1)
-out = np.zeros(512, np.int64)
+out = np.zeros(512 + 8 * 8000, np.int64)
 w._chk(w.L.sz_debug_stamps(w.h, capi.ptr(out, capi._lp)))
 w.run(1, 3, cfg["dt"], coupling_dt=1)
 w._chk(w.L.sz_debug_stamps(w.h, capi.ptr(out, capi._lp)))
