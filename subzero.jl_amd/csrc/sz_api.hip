@@ -94,6 +94,7 @@ struct sz_ctx {
   bool ghost_inline = true;         // SZ_GHOST_INLINE=0: the candidate-list launch instead
   bool gi_valid = false;            // the interaction rows / pair lists on the device carry order keys of inline ghosts
   std::vector<long long> gi_keys;   // order key of the ghost at storage offset k (floe N + k) in the last step that ran
+  bool gi_pending = false; int gi_pending_n = 0, gi_pending_slot = 0;      // ... still to be fetched from the device (gi_fetch)
   std::vector<int> gi_ref;          // ... and its number among the ghosts in the reference's order (ghost N + gi_ref[k])
   bool retry_seen = false;          // an item has needed the largest narrow variant: sz_step enqueues it in every step from now on
   bool no_lean_narrow = false;      // SZ_LEAN_NARROW=0: always enqueue it
@@ -613,6 +614,20 @@ void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool 
   t.end();
 }
 
+// inline ghosts: the keys of the last step's ghosts from the device, and each ghost's number in the reference's order
+int gi_fetch(sz_ctx* c) {
+  if (!c->gi_pending) return SZ_OK;
+  const int G = c->gi_pending_n;
+  c->gi_keys.assign(G, 0);
+  if (G > 0) HIPCHK(c, hipMemcpy(c->gi_keys.data(), c->S.gkeys + (size_t)c->gi_pending_slot * c->S.capM, (size_t)G * sizeof(long long), hipMemcpyDeviceToHost));
+  std::vector<int> ord(G);
+  for (int k = 0; k < G; k++) ord[k] = k;
+  std::sort(ord.begin(), ord.end(), [&](int a, int b) { return c->gi_keys[a] < c->gi_keys[b]; });
+  c->gi_ref.assign(G, 0);
+  for (int r = 0; r < G; r++) c->gi_ref[ord[r]] = r;
+  c->gi_pending = false;
+  return SZ_OK;
+}
 // exact host replay of the fuse bookkeeping (collisions.jl:367-368 and :801-806) for the rare
 // steps in which a pair exceeded max_overlap
 // after_step (sz_step): the ghosts of the step have already been detached (C_M == N; their rows and the pair arrays are
@@ -633,6 +648,7 @@ int host_fuse_fixup(sz_ctx* c, const int* h, bool mirror, bool after_step = fals
   // inline ghosts lie in allocation order: the replay walks the floes in the reference's order and the lists hold its numbers
   // (ref[storage index] / sto[reference number]; the identity otherwise)
   const int Np = h[C_N];
+  if (after_step && c->gi_valid) { int rc = gi_fetch(c); if (rc) return rc; }
   const bool renum = after_step && c->gi_valid && (int)c->gi_ref.size() == M - Np;
   std::vector<int> ref(M), sto(M);
   for (int i = 0; i < M; i++) { ref[i] = i < Np || !renum ? i : Np + c->gi_ref[i - Np]; sto[ref[i]] = i; }
@@ -789,6 +805,8 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   if (M64 > N64 && (!f->ghost_off || !f->ghost_idx || !f->ghost_id)) { c->err = "M > N needs ghost_off/ghost_idx/ghost_id"; return SZ_E_ARG; }
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->gi_pending && c->gi_valid) { int rc0 = gi_fetch(c); if (rc0) return rc0; }      // (the key tables go with the pool; the rows may stay)
+  c->gi_pending = false;
   reset_pool(c->allocs);       // the chunks of the previous upload are carved again (a shim uploads before every replaced call)
   State& S = c->S;
   const int M = (int)M64, N = (int)N64;
@@ -973,6 +991,7 @@ int sz_download_interactions(sz_ctx* c, int32_t* off, double* rows) {
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(tmp);
     if (e != hipSuccess) { c->err = hipGetErrorString(e); return SZ_E_HIP; }
+    if (c->gi_valid) { int rc2 = gi_fetch(c); if (rc2) return rc2; }
     if (c->gi_valid) {            // partners that were inline ghosts: order key -> the reference's floe number
       std::vector<long long> sorted(c->gi_keys);
       std::sort(sorted.begin(), sorted.end());
@@ -1008,6 +1027,7 @@ int sz_download_pairs(sz_ctx* c, int32_t* pi, int32_t* pj) {
   if (h[C_NPAIRS] > 0) {
     HIPCHK(c, hipMemcpy(pi, c->S.pair_i, (size_t)h[C_NPAIRS] * sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(pj, c->S.pair_j, (size_t)h[C_NPAIRS] * sizeof(int), hipMemcpyDeviceToHost));
+    if (c->gi_valid) { int rc2 = gi_fetch(c); if (rc2) return rc2; }
     if (c->gi_valid && (int)c->gi_ref.size() == mlast - h[C_N]) {       // inline ghosts: storage index -> the reference's number, then its serial order
       const int Np = h[C_N], np = h[C_NPAIRS];
       std::vector<std::pair<int, int>> ps(np);
@@ -1297,6 +1317,8 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   if (gl && !gi) use_ghost_list(c); else c->gl_valid = false;
   const int gl0 = c->gl_cur;
   c->S.ginline = gi ? 1 : 0;
+  if (c->gi_pending && c->gi_valid && !coll) { int rc = gi_fetch(c); if (rc) return rc; }      // (the key tables are about to be reused)
+  c->gi_pending = false;
   if (coll) c->gi_valid = false;    // (this batch's rows replace the old ones; set again below if they carry order keys of inline ghosts)
   const bool mixed = c->precision == 1 && !c->two_way;
   if (mixed) { int rc = ensure_mixed(c); if (rc) return rc; }
@@ -1367,18 +1389,12 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     c->gl_cur = (gl0 + done) & 1;
     c->gl_est = h[C_NGCAND + c->gl_cur];
   }
-  if (gi) {               // the order keys of the last step's ghosts: what the host needs to number them as the reference does
-    const int G = done > 0 ? h[C_NGHOSTS] : 0;
-    c->gi_keys.assign(G, 0);
-    if (G > 0) HIPCHK(c, hipMemcpy(c->gi_keys.data(), c->S.gkeys + (size_t)((done - 1) & 1) * c->S.capM, (size_t)G * sizeof(long long), hipMemcpyDeviceToHost));
-    std::vector<int> ord(G);
-    for (int k = 0; k < G; k++) ord[k] = k;
-    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return c->gi_keys[a] < c->gi_keys[b]; });
-    c->gi_ref.assign(G, 0);
-    for (int r = 0; r < G; r++) c->gi_ref[ord[r]] = r;
+  if (gi) {               // the order keys of the last step's ghosts are what the host needs to number them as the reference does:
+    // they are fetched when somebody asks for numbers (gi_fetch: downloads, the fuse replay) -- most batches end without
+    c->gi_pending_n = done > 0 ? h[C_NGHOSTS] : 0; c->gi_pending_slot = (done - 1) & 1; c->gi_pending = true;
     if (coll) c->gi_valid = done > 0;
     if (done < nsteps) c->grid_live = false;       // stopped early: the step that ended the batch has binned ghosts for a step that did not come
-    c->gl_est = std::max(c->gl_est, G);        // (sizes the list pass should the next batch use it)
+    c->gl_est = std::max(c->gl_est, c->gi_pending_n);        // (sizes the list pass should the next batch use it)
   }
   // status.fuse_idx of the step that ended the batch: the reference's serial propagation, replayed on the host as
   // sz_timestep_collisions does (only that step can have produced fuse pairs: the batch stops on the first tag)
