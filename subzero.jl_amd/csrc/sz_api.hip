@@ -1345,17 +1345,18 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
       const bool overlap = coupling && !c->two_way && (c->overlap_forcing != 0);
       // with collisions on, the ghosts of step s are detached by the ghost kernels of step s+1 (nothing
       // in between looks past the parents) and committed by the bounds kernel: two launches less
-      // The forcings only need the floes as the previous step left them, so they go first (the tiled step runs them
-      // beside the halo exchange, and both paths keep the same order: a parent that the ghost pass wraps around the
-      // domain is sampled at the periodic image it had before -- the same lattice values).  With the forcings on a
-      // second stream the fork comes after the ghost pass instead, so that nothing they read is being rewritten.
+      // The forcings only read the floes' state at the start of the step (after the ghost pass has wrapped the parents that left the
+      // domain) and write columns nothing reads before the update: they can run beside the collision kernels (second stream, fork
+      // after the ghost pass) or inside one of their launches.
       // (riding in the neighbour launch pays while both kernels leave the chip idle: measured better up to 40 k floes,
       // neutral at 100 k dense, worse at 100 k sparse -- there the forcings get their own launch)
       const bool fuse = coupling && !overlap && coll && !c->two_way && !(c->pmask >> SZ_K_FORCING & 1u) && c->fuse_forcing && c->hostN <= 65536;
       const int fmode = !fuse ? 0 : c->fuse_forcing_mode ? c->fuse_forcing_mode : (c->hostN <= 30000 ? 2 : 1);
       if (!resume) {          // (a paused step has all of this behind it)
-        if (coupling && !overlap && !fuse) stage_forcing(c, dt);
         if (coll && !gi) stage_ghosts(c, true, sg, gl);
+        // (after the ghost pass, like the reference's timestep_coupling!: a parent that has just swapped with its ghost is sampled where it
+        //  now lies -- the same lattice values as at its image, but the interpolation weights come from other coordinates)
+        if (coupling && !overlap && !fuse) stage_forcing(c, dt);
         if (overlap) stage_forcing_fork(c);
         if (coupling) c->forcing_where = fmode;
       }
