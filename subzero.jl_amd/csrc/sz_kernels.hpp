@@ -1825,6 +1825,14 @@ __global__ void sz_k_apply_frc(State S) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
     if (S.frc_remove[i]) S.status[i] = SZ_REMOVE;
 }
+// Tiled steps evaluate the forcings beside the halo exchange, BEFORE the step's ghost pass; the reference couples after it, i.e. a
+// parent whose centroid has left the domain through a periodic wall has swapped with its ghost by then.  The forcing kernels of a tiled
+// context therefore apply the swap's translation themselves (the ghost pass's own test and addition: same bits as the row it will store).
+__device__ __forceinline__ void forcing_wrap(const State& S, int i, double& cx, double& cy) {
+  if (!S.tiled || S.status[i] != SZ_ACTIVE) return;
+  if (S.any_periodic_ew) { const double maxv = S.eval[2], minv = S.eval[3], L = maxv - minv; if (cx < minv) cx = cx + L; else if (maxv < cx) cx = cx + (-L); }
+  if (S.any_periodic_ns) { const double maxv = S.eval[0], minv = S.eval[1], L = maxv - minv; if (cy < minv) cy = cy + L; else if (maxv < cy) cy = cy + (-L); }
+}
 constexpr int FRC_G = 32;      // lanes per floe of the two-way variant
 #ifndef FRC_PLAIN_LANES
 #define FRC_PLAIN_LANES 32
@@ -1863,6 +1871,7 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
   const int vb0 = S.xcd_forcing ? xcd_contiguous_from(first + bid, first, nblk, (N + wpb - 1) / wpb) : bid;
   for (int i = vb0 < 0 ? N : vb0 * wpb + wid; i < N; i += nblk * wpb) {
     double cxf = S.cx[i], cyf = S.cy[i], u = S.u[i], v = S.v[i], xi = S.xi[i];
+    forcing_wrap(S, i, cxf, cyf);
     double ca = S.trig[2 * i], sa = S.trig[2 * i + 1];   // cos(alpha), sin(alpha)
     double ma_ratio = S.mass[i] / S.area[i];
     int o = S.soff[i], ns = S.soff[i + 1] - o;
@@ -2025,7 +2034,8 @@ __device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, in
   const float ka = (float)(P.rho_a * P.Cd_ia), ko = (float)(P.rho_o * P.Cd_io);
   const int vb0 = S.xcd_forcing ? xcd_contiguous_from(first + bid, first, nblk, (N + wpb - 1) / wpb) : bid;
   for (int i = vb0 < 0 ? N : vb0 * wpb + wid; i < N; i += nblk * wpb) {
-    const double cxf = S.cx[i], cyf = S.cy[i], u = S.u[i], v = S.v[i];
+    double cxf = S.cx[i], cyf = S.cy[i]; const double u = S.u[i], v = S.v[i];
+    forcing_wrap(S, i, cxf, cyf);
     const float uf = (float)u, vf = (float)v, xif = (float)S.xi[i];
     const float ca = (float)S.trig[2 * i], sa = (float)S.trig[2 * i + 1];
     const double ma_ratio = S.mass[i] / S.area[i];

@@ -39,14 +39,27 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n, seed, steps, q, repartition=False):
+def _field(n, seed, fast=False):
+    from subzero_jl_amd import fields
+    from subzero_jl_amd import floe as floe_mod
+    cfg = fields.make_config(n_floes=n, seed=seed)
+    if fast:
+        # fast floes on a field shifted so that parents straddle the walls: some start outside the domain, others leave it during the
+        # run -- they swap with their ghosts (collisions.jl:942-950), and the forcings of a tiled step are evaluated BEFORE its ghost pass
+        cfg["u"] = np.abs(cfg["u"]) * 60.0 + 2.0; cfg["v"] = cfg["v"] * 60.0 + 1.0
+        cfg["vx"] = cfg["vx"] + 9800.0; cfg["vy"] = cfg["vy"] + 9900.0
+        cfg["derived"] = floe_mod.derive(cfg["vert_off"], cfg["vx"], cfg["vy"], cfg["height"])
+    return cfg
+
+
+def _worker(rank, world, port, n, seed, steps, q, repartition=False, fast=False):
     import torch
     import torch.distributed as dist
     from subzero_jl_amd import fields, tiles
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
-        cfg = fields.make_config(n_floes=n, seed=seed)
+        cfg = _field(n, seed, fast)
         tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True)
         if repartition:
             # half way through, hand every floe to the other kind of tiling (split along y instead of x): most
@@ -74,17 +87,19 @@ def _run_worker_two_way(*a):
     _guard(_worker_two_way)(*a)
 
 
-@pytest.mark.parametrize("world,n,seed,steps,repartition", [(2, 600, 31, 4, False), (2, 600, 33, 6, True), (4, 1000, 35, 4, False)])
-def test_ranks_equal_single(world, n, seed, steps, repartition):
+@pytest.mark.parametrize("world,n,seed,steps,repartition,fast", [(2, 600, 31, 4, False, False), (2, 600, 33, 6, True, False), (4, 1000, 35, 4, False, False),
+                                                                 (2, 500, 77, 30, False, True)])
+def test_ranks_equal_single(world, n, seed, steps, repartition, fast):
     """2 ranks (two tiles side by side) and 4 ranks (2 x 2 tiles: corner halos, both periodic directions across
-    tile boundaries) against the single-context run: bit-equal columns for every owned floe"""
+    tile boundaries) against the single-context run: bit-equal columns for every owned floe; `fast`: parents cross the
+    periodic walls and swap with their ghosts during the run"""
     import torch.multiprocessing as mp
     import subzero_jl_amd
     from subzero_jl_amd import fields
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_worker, args=(r, world, port, n, seed, steps, q, repartition)) for r in range(world)]
+    procs = [ctx.Process(target=_run_worker, args=(r, world, port, n, seed, steps, q, repartition, fast)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -96,9 +111,12 @@ def test_ranks_equal_single(world, n, seed, steps, repartition):
         for p in procs:                      # a rank left waiting in a collective by a failed peer
             if p.is_alive():
                 p.terminate()
-    cfg = fields.make_config(n_floes=n, seed=seed)
+    cfg = _field(n, seed, fast)
     hw = fields.build_world(subzero_jl_amd.World(0), cfg)
-    hw.run(steps, 0, cfg["dt"], coupling_dt=1)
+    hw.run(steps, 0, cfg["dt"], coupling_dt=1, stop_on_tags=False)
+    if fast:
+        wrapped = np.abs(hw.get("cx") - cfg["derived"]["cx"]) > 0.5 * cfg["L"]
+        assert wrapped.sum() >= 3                  # parents went through a wall and came back on the other side
     seen = np.zeros(n, bool)
     for rank, gidx, out, nhalo, vx in res:
         assert nhalo > 0
