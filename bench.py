@@ -182,7 +182,7 @@ def main():
     ap.add_argument("--floes", type=int, default=0, help="floes per GPU (weak scaling of the configs[1] field); default: 10000 on one "
                                                          "GPU, and for N > 1 the metric's strong-scaling workload instead")
     ap.add_argument("--total-floes", type=int, default=0, help="fix the job size (strong scaling)")
-    ap.add_argument("--workload", default=None, choices=["configs1", "configs2", "configs3", "configs4"],
+    ap.add_argument("--workload", default=None, choices=["configs1", "configs2", "configs3", "configs4", "walls"],
                     help="BASELINE.json configs[k]: 1 = periodic box + uniform flow (the metric's 1-GPU config, default for N = 1); 2 = "
                          "100k floes converge/diverge flow (the metric's multi-GPU config, default for N > 1); 3 = four collision "
                          "walls + topography, strait flow; 4 = 25 %% concentration")
@@ -236,7 +236,7 @@ def main():
     workload = args.workload or ("configs2" if (world > 1 and args.floes == 0) else "configs1")
     wl = {"configs1": dict(seed=12345), "configs2": dict(seed=12346, ocean="converge_diverge"),
           "configs3": dict(seed=12345, walls=True, topography=True, ocean="strait"),
-          "configs4": dict(seed=12347, concentration=0.25)}[workload]
+          "configs4": dict(seed=12347, concentration=0.25), "walls": dict(seed=12345, walls=True)}[workload]
     cfg = fields.make_config(n_floes=n_total, **wl)
     coupling_dt = args.coupling_dt
     tiled = not (world == 1 and not args.force_tiled)

@@ -860,7 +860,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   if (f->sub_off) for (int i = 0; i < N; i++) c->max_sub = std::max(c->max_sub, f->sub_off[i + 1] - f->sub_off[i]);
   DA(gplan, S.capM + 1); DA(gscan4, S.capM + 1); DA(gtot4, 4);
   DA(lb_agg, S.capM / SCAN_B + 8); DA(lb_inc, S.capM / SCAN_B + 8); DA(lb_flag, S.capM / SCAN_B + 8); c->scan_epoch = 0;
-  DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2); DA(gcand, (size_t)2 * S.capM); DA(galloc, 32); DA(gkeys, (size_t)2 * S.capM);
+  DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2); DA(gcand, (size_t)2 * S.capM); DA(galloc, 32); DA(gkeys, (size_t)2 * S.capM); DA(fam, S.capM);
   DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1); DA(cell_ovf, S.capCells + 1); DA(cell_slots, (size_t)S.capCells * CELL_K + 8);
   DA(cell_items, S.capM);
   DA(nb_out, (size_t)S.capM * MAXNB); DA(nb_in, (size_t)S.capM * MAXNB); DA(n_out, S.capM + 1); DA(n_in, S.capM + 1);

@@ -794,6 +794,18 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
   }
   for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = q < ng ? N + og + q : -1;
   S.ngh[i] = ng;
+  {
+    // the family record of this id for the Dict rule (pair_allowed_fam): the parent as it now lies, then its ghosts -- the values of the rows
+    State::Fam* F = S.fam + i;
+    double x = pcx, y = pcy; shift_apply(cp, x, y);
+    F->key[0] = oki; F->gid[0] = 0; F->cx[0] = x; F->cy[0] = y;
+    x = pcx; y = pcy; shift_apply(c0, x, y); F->key[1] = k0; F->gid[1] = 1; F->cx[1] = x; F->cy[1] = y;
+    if (ng == 3) {
+      x = pcx; y = pcy; shift_apply(c1, x, y); F->key[2] = k1; F->gid[2] = 2; F->cx[2] = x; F->cy[2] = y;
+      x = pcx; y = pcy; shift_apply(c2, x, y); F->key[3] = k2; F->gid[3] = 3; F->cx[3] = x; F->cy[3] = y;
+    }
+    F->r = c_rmax; F->n = ng + 1;
+  }
 }
 // start of a resident batch: the ghosts of its first step, from the parents as they lie (thread per parent)
 __global__ void __launch_bounds__(256) sz_k_ghost_inline_seed(State S, int slot, int nh) {
@@ -988,6 +1000,44 @@ __device__ bool pair_allowed(const State& S, int i, int j) {   // i < j, ids dif
   return (A && B) || (A != B);
 }
 
+// The same rule from the family records the inline ghost maker leaves (State::Fam): a side without ghosts is the floe itself (the
+// caller has its row), a side with ghosts is ONE contiguous record -- one round trip instead of the chain parent -> links -> rows
+// of every instance.  i before j in the serial order; (ki, gi, xi, yi, ri): key, ghost id, centroid, rmax of i, likewise j;
+// pi / pj: their parents; fi / fj: the side has ghosts.
+__device__ __forceinline__ bool pair_allowed_fam(const State& S, int pi, int pj, bool fi, bool fj,
+                                                 long long ki, long long gi, double xi, double yi, double ri,
+                                                 long long kj, long long gj, double xj, double yj, double rj) {
+  long long kx[4] = { ki, 0, 0, 0 }, gx[4] = { gi, 0, 0, 0 }, ky[4] = { kj, 0, 0, 0 }, gy[4] = { gj, 0, 0, 0 };
+  double ax[4] = { xi, 0, 0, 0 }, ay[4] = { yi, 0, 0, 0 }, bx[4] = { xj, 0, 0, 0 }, by[4] = { yj, 0, 0, 0 };
+  double ar = ri, br = rj; int nx = 1, ny = 1;
+  const State::Fam* FI = S.fam + pi; const State::Fam* FJ = S.fam + pj;
+  if (fi) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { kx[q] = FI->key[q]; gx[q] = FI->gid[q]; ax[q] = FI->cx[q]; ay[q] = FI->cy[q]; }
+    ar = FI->r; nx = FI->n;
+  }
+  if (fj) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { ky[q] = FJ->key[q]; gy[q] = FJ->gid[q]; bx[q] = FJ->cx[q]; by[q] = FJ->cy[q]; }
+    br = FJ->r; ny = FJ->n;
+  }
+  long long bka = 0, bkb = 0, gbx = 0, gby = 0; bool have = false;
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+      if (x >= nx || y >= ny) continue;
+      const bool lt = kx[x] < ky[y];
+      const long long ka = lt ? kx[x] : ky[y], kb = lt ? ky[y] : kx[x];
+      if (have && (ka > bka || (ka == bka && kb >= bkb))) continue;
+      // circles_touch(first, second): differences are squared and the sum of the radii commutes -- the same bits either way round
+      const double dx = lt ? ax[x] - bx[y] : bx[y] - ax[x], dy = lt ? ay[x] - by[y] : by[y] - ay[x], rr = lt ? ar + br : br + ar;
+      if ((dx * dx + dy * dy) < rr * rr) { have = true; bka = ka; bkb = kb; gbx = gx[x]; gby = gy[y]; }
+    }
+  }
+  return gi == gbx || gj == gby;
+}
+
 // Workgroups are dealt round robin over the 8 XCDs (blocks b and b + 8 share one, MI355X_MICROARCH.md), each XCD has its own
 // L2, and every launch starts with cold L2s: a floe's columns and ring are fetched once per XCD that touches them.  Kernels in
 // which a floe is read on behalf of its neighbours (neighbour search, narrow phase, reduce) therefore give the workgroups of one
@@ -1092,13 +1142,13 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   for (int kb = vb0 < 0 ? S.capM : vb0 * GPB; kb < S.capM; kb += nblk * GPB) {
     const int k = kb + gi;
     double ckx = 0, cky = 0, rk = 0, kx0 = 0, kx1 = 0, ky0 = 0, ky1 = 0;
-    long long idk = 0, okk = 0; bool kplain = true; int ix = 0, iy = 0, vok = 0, nvk = 0;
+    long long idk = 0, okk = 0, kgid = 0; bool kplain = true; int ix = 0, iy = 0, vok = 0, nvk = 0, kpar = 0;
     if (k < S.capM) {
       vok = ring_off(S, k); nvk = ring_n(S, k);
       ckx = S.cx[k]; cky = S.cy[k]; rk = S.rmax[k];
       kx0 = S.bbx0[k]; kx1 = S.bbx1[k]; ky0 = S.bby0[k]; ky1 = S.bby1[k];
       idk = S.id[k]; okk = S.okey[k];
-      kplain = S.parent[k] == k && S.ngh[k] == 0;
+      kpar = S.parent[k]; kplain = kpar == k && S.ngh[k] == 0; kgid = S.ghost_id[k];
     }
     loads_issued();
     if (stop_test(S, stop) || kb >= M) break;
@@ -1156,7 +1206,8 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
       const double ocx = S.cx[o], ocy = S.cy[o], orm = S.rmax[o];
       const double ox0 = S.bbx0[o], ox1 = S.bbx1[o], oy0 = S.bby0[o], oy1 = S.bby1[o];
       const long long oid = S.id[o], ko = S.okey[o];
-      const bool oplain = S.parent[o] == o && S.ngh[o] == 0;     // a parent without ghosts
+      const int opar = S.parent[o];
+      const bool oplain = opar == o && S.ngh[o] == 0;     // a parent without ghosts
       const int voo = ring_off(S, o), nvo = ring_n(S, o);
       // potential_interaction (collisions.jl:705-710), symmetric in its arguments
       double ddx = ckx - ocx, ddy = cky - ocy, rr = rk + orm;
@@ -1164,7 +1215,16 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
       if (oid == idk) continue;
       bool after = ko > okk;                   // o comes after k in the serial order
       // the Dict rule only bites when one of the two floes has periodic images
-      if (!(kplain && oplain) && !pair_allowed(S, after ? k : o, after ? o : k)) continue;
+      if (!(kplain && oplain)) {
+        bool ok;
+        if (S.ginline) {           // (inline ghosts leave a record per family: a floe that is a ghost, or has ghosts, has one at its parent)
+          const int kp = kpar, op = opar;
+          const long long gk = kgid, go = S.ghost_id[o];
+          ok = after ? pair_allowed_fam(S, kp, op, !kplain, !oplain, okk, gk, ckx, cky, rk, ko, go, ocx, ocy, orm)
+                     : pair_allowed_fam(S, op, kp, !oplain, !kplain, ko, go, ocx, ocy, orm, okk, gk, ckx, cky, rk);
+        } else ok = pair_allowed(S, after ? k : o, after ? o : k);
+        if (!ok) continue;
+      }
       int w = after ? 0 : 1;
       int slot = atomicAdd(&cnts[gi][w], 1);
       // AABB cull of the pairs this floe owns: rings whose boxes are disjoint cannot overlap, the item would

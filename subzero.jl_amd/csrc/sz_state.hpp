@@ -117,6 +117,10 @@ struct State {
   // ghosts made by the kernel that places the parent (resident steps, "inline" ghosts: sz_kernels.hpp ghost_inline_make): two
   // allocators {ghosts << 32 | ring points} a cache line apart (galloc[0], galloc[16]), used alternately step by step, and per
   // allocator the order key of the ghost at every storage offset (gkeys[slot * capM + offset])
+  // ... and, per parent that has ghosts, a record of all instances of its id (itself + its ghosts): what the Dict rule of the pair
+  // loop needs about a floe's "family", in one contiguous read instead of a chain through parent -> ghost links -> rows
+  struct Fam { long long key[4], gid[4]; double cx[4], cy[4], r; int n, pad; };
+  Fam* fam;
   unsigned long long* galloc; long long* gkeys;
   int ginline, gslot;         // inline ghosts on; the allocator holding the ghosts of the step being launched
   int4* gcand;                // two lists of capM entries {parent, ghost flags, ring points, -}: the parents that get ghosts in the next
