@@ -699,7 +699,7 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
   unsigned long long base = 0;
   if (lane == first) base = atomicAdd(&S.galloc[slot * 16], tot);      // (its answer is looked at below, after the cell counters have gone out too)
   const double pcx = R.cx, pcy = R.cy, pb0 = R.b0, pb1 = R.b1, pb2 = R.b2, pb3 = R.b3;
-  const double c_rmax = R.rmax, c_area = R.area, c_h = R.h, c_mass = R.mass, c_mom = R.mom, c_al = R.al;
+  const double c_rmax = R.rmax, c_area = R.area, c_h = R.h;
   const double c_u = R.u, c_v = R.v, c_xi = R.xi, c_over = R.over, tc = R.tc, ts = R.ts;
   const long long idv = R.id, oki = R.oki; const int stv = R.st; const signed char osv = R.os;
   // ---- the two passes as sequences of translations (each applied to centroid, box and ring in turn: the reference's arithmetic)
@@ -749,11 +749,13 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
     const int g = N + og + w, vb = NV0 + ov + w * n;
     double gx = pcx, gy = pcy, x0 = pb0, y0 = pb2, x1 = pb1, y1 = pb3;
     shift_apply(c, gx, gy); shift_apply(c, x0, y0); shift_apply(c, x1, y1);
-    S.rmax[g] = c_rmax; S.area[g] = c_area; S.height[g] = c_h; S.mass[g] = c_mass; S.moment[g] = c_mom; S.alpha[g] = c_al;
+    // (only what the collision kernels read of a ghost: these rows live for one resident step and are never handed to the host -- mass,
+    //  moment, alpha, the collision totals and the ghost's own ghost links are not among it; every store less is a slot of the 63 memory
+    //  operations the wavefront can have in flight)
+    S.rmax[g] = c_rmax; S.area[g] = c_area; S.height[g] = c_h;
     S.u[g] = c_u; S.v[g] = c_v; S.xi[g] = c_xi; S.overarea[g] = c_over;
     S.id[g] = idv; S.ghost_id[g] = (long long)(w + 1); S.okey[g] = key;
-    S.status[g] = stv; S.parent[g] = i; S.ngh[g] = 0; S.osign[g] = osv;
-    S.cfx[g] = 0.0; S.cfy[g] = 0.0; S.ctrq[g] = 0.0;
+    S.status[g] = stv; S.parent[g] = i; S.osign[g] = osv;
     S.cx[g] = gx; S.cy[g] = gy; S.bbx0[g] = x0; S.bbx1[g] = x1; S.bby0[g] = y0; S.bby1[g] = y1;
     GSTAMP(16);
     if (body) { S.rb_off[g] = vo; S.rb_n[g] = n; S.trig[2 * g] = tc; S.trig[2 * g + 1] = ts; }
@@ -764,7 +766,6 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
     }
     GSTAMP(17);
     if (S.rec32) rec32_store(S, g, gx, gy, c_rmax, x0, x1, y0, y1);
-    for (int q = 0; q < MAX_GHOSTS; q++) S.gh[g * MAX_GHOSTS + q] = -1;
     S.gkeys[(size_t)slot * S.capM + og + w] = key;
   };
   GSTAMP(13);
