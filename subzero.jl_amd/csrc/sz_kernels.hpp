@@ -1739,6 +1739,75 @@ __device__ __forceinline__ int emit_rows(const State& S, int lane, int f, double
   }
   return c;
 }
+// The rows of parent f and, behind them, the rows of its ng ghosts shifted into the parent's frame (the ghost fold of
+// collisions.jl:830-850) in ONE pass: the sources of all of them form one list that the lanes work off together, so the chains of
+// dependent loads behind a source (mirrored rows: neighbour list -> partner's list -> item -> rows) run side by side for the parent and
+// its ghosts instead of one emit_rows() after the other (a parent next to a periodic wall used to take 1 + ng times as long as the
+// others, and set the launch's duration).  Same rows at the same positions.  pre0: {n_out, el_off[f], el_off[f + 1], n_in} of f.
+__device__ __forceinline__ int emit_rows_fold(const State& S, int lane, int f, double* dst, int cap, int mirror, bool& ovf, int* st, int* tagA,
+                                              const int4& pre0, int ng, const int* gf, double cx, double cy) {
+  int sf[MAX_GHOSTS + 1], so[MAX_GHOSTS + 1], se[MAX_GHOSTS + 1], sn[MAX_GHOSTS + 1], si[MAX_GHOSTS + 1], sT[MAX_GHOSTS + 2];
+  double ssx[MAX_GHOSTS + 1], ssy[MAX_GHOSTS + 1];
+  sf[0] = f; so[0] = pre0.x; se[0] = pre0.y; sn[0] = pre0.z - pre0.y; si[0] = mirror ? pre0.w : 0; ssx[0] = 0.0; ssy[0] = 0.0;
+#pragma unroll
+  for (int q = 1; q <= MAX_GHOSTS; q++) {
+    const bool on = q <= ng; const int g = on ? gf[q - 1] : f;
+    const int e0 = S.el_off[g];
+    sf[q] = g; so[q] = on ? S.n_out[g] : 0; se[q] = e0; sn[q] = on ? S.el_off[g + 1] - e0 : 0; si[q] = on && mirror ? S.n_in[g] : 0;
+    ssx[q] = on ? S.cx[g] - cx : 0.0; ssy[q] = on ? S.cy[g] - cy : 0.0;
+  }
+  sT[0] = 0;
+#pragma unroll
+  for (int q = 0; q <= MAX_GHOSTS; q++) sT[q + 1] = sT[q] + so[q] + sn[q] + si[q];
+  const int T = sT[MAX_GHOSTS + 1];
+  const int gshift = (int)(threadIdx.x & 63) / IF_G * IF_G;
+  unsigned fuse_own = 0, rem_el = 0, fuse_in = 0;
+  int c = 0;
+  for (int base = 0; base < T; base += IF_G) {
+    const int s = base + lane;
+    int q = 0;
+#pragma unroll
+    for (int t = 1; t <= MAX_GHOSTS; t++) q += s >= sT[t] ? 1 : 0;
+    int fq = sf[0], nown = so[0], e0 = se[0], nel = sn[0], s0 = sT[0]; double sx = ssx[0], sy = ssy[0];
+#pragma unroll
+    for (int t = 1; t <= MAX_GHOSTS; t++) if (q == t) { fq = sf[t]; nown = so[t]; e0 = se[t]; nel = sn[t]; s0 = sT[t]; sx = ssx[t]; sy = ssy[t]; }
+    const int ls = s - s0;
+    int info = -1, n = 0, kind = -1; double idx = 0.0, sign = 1.0;
+    if (s < T) {
+      if (ls < nown) { info = fq * MAXNB + ls; idx = (double)(S.okey[S.nb_out[info]] + 1); kind = 0; }
+      else if (ls < nown + nel) { int qq = e0 + (ls - nown); info = S.capM * MAXNB + qq; idx = -(double)(S.el_elem[qq] + 1); kind = 1; }
+      else {
+        const int i = S.nb_in[(size_t)fq * MAXNB + (ls - nown - nel)];
+        const int ni = S.n_out[i];
+        for (int qq = 0; qq < ni; qq++) if (S.nb_out[(size_t)i * MAXNB + qq] == fq) info = i * MAXNB + qq;     // pair (i, fq); absent if the Dict rule dropped it
+        idx = (double)(S.okey[i] + 1); sign = -1.0; kind = 2;
+      }
+    }
+    int fl = 0; int2 iv = make_int2(0, 0);
+    if (info >= 0) { iv = S.it_info[info]; n = iv.x & 0xff; fl = iv.x >> 8; }
+    // (the tags are the parent's own: its ghosts' items do not tag it here)
+    fuse_own |= (unsigned)(__ballot(q == 0 && kind == 0 && (fl & IT_FUSE)) >> gshift) & 0xffu;
+    rem_el |= (unsigned)(__ballot(q == 0 && kind == 1 && (fl & IT_REMOVE)) >> gshift) & 0xffu;
+    fuse_in |= (unsigned)(__ballot(q == 0 && kind == 2 && (fl & IT_FUSE)) >> gshift) & 0xffu;
+    int inc = n;
+    for (int d = 1; d < IF_G; d <<= 1) { int t = __shfl_up(inc, d, IF_G); if (lane >= d) inc += t; }
+    const int tot = __shfl(inc, IF_G - 1, IF_G), off = inc - n;
+    const double* src = S.it_rows + (size_t)(n > 0 ? iv.y : 0) * ROWS_PER_ITEM * 5;
+    for (int r = 0; r < n; r++) {
+      const int pos = c + off + r;
+      if (pos < cap) {
+        double* d = dst + (size_t)pos * 7; const double* qr = src + r * 5;
+        d[0] = idx; d[1] = qr[0] * sign; d[2] = qr[1] * sign; d[3] = qr[2] - sx; d[4] = qr[3] - sy; d[5] = 0.0; d[6] = qr[4];
+      } else ovf = true;
+    }
+    c = c + tot < cap ? c + tot : cap;
+  }
+  if (fuse_own) *st = SZ_FUSE;
+  if (rem_el) *st = SZ_REMOVE;
+  *tagA = *st;
+  if (fuse_in) *st = SZ_FUSE;
+  return c;
+}
 // mirror pass, ghost fold, torque and totals (collisions.jl:799-862)
 // m_hint (resident steps; 0: none): about how many floes there are, from the host -- the floe a group starts with then does not
 // depend on the device's count, and its first loads go out together with the counter block (one round trip less in the launch's
@@ -1772,15 +1841,16 @@ __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int 
     if (mirror && is_ghost && par < n_init) { sx = cx - S.cx[par]; sy = cy - S.cy[par]; }
     bool ovf = false;
     int st = pr ? pr->st : S.status[k], tagA = st;
-    int c = emit_rows(S, lane, k, dst, 0, ROWCAP, sx, sy, mirror, ovf, &st, &tagA, pr ? &pr->cnts : nullptr);
     const bool totals = mirror && k < n_init;
-    if (totals) {                      // ghost fold (collisions.jl:830-850)
+    int c;
+    if (totals) {                      // own rows + ghost fold (collisions.jl:830-850), one pass
       const int ng = pr ? pr->ng : S.ngh[k];
-      for (int g = 0; g < ng; g++) {
-        const int gf = S.gh[k * MAX_GHOSTS + g];
-        c = emit_rows(S, lane, gf, dst, c, ROWCAP, S.cx[gf] - cx, S.cy[gf] - cy, mirror, ovf, nullptr, nullptr);
-      }
-    }
+      int gf[MAX_GHOSTS];
+#pragma unroll
+      for (int g = 0; g < MAX_GHOSTS; g++) gf[g] = S.gh[k * MAX_GHOSTS + g];
+      const int4 cn = pr ? pr->cnts : make_int4(S.n_out[k], S.el_off[k], S.el_off[k + 1], S.n_in[k]);
+      c = emit_rows_fold(S, lane, k, dst, ROWCAP, mirror, ovf, &st, &tagA, cn, ng, gf, cx, cy);
+    } else c = emit_rows(S, lane, k, dst, 0, ROWCAP, sx, sy, mirror, ovf, &st, &tagA, pr ? &pr->cnts : nullptr);
     if (ovf) atomicOr(&S.cnt[C_ERR], ERR_CAP_INTER);
     __threadfence_block();             // the rows were written by other lanes of this wavefront
     // torque per row over the lanes; totals (collisions.jl:747-749, 852-861) and the overlap sum in row
