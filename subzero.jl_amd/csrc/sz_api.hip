@@ -401,7 +401,8 @@ void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false
     if (c->precision == 1) hipLaunchKernelGGL(sz_k_neighbors_forcing<2>, dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn);
     else hipLaunchKernelGGL(sz_k_neighbors_forcing<1>, dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn);
   } else
-    hipLaunchKernelGGL(sz_k_neighbors, dim3(grid_for(S.capM, NB_TPB / NB_G, 8192)), dim3(NB_TPB), 0, c->stream, S);
+    if (c->hostN <= 40000) hipLaunchKernelGGL(sz_k_neighbors<true>, dim3(grid_for(S.capM, NB_TPB / NB_G, 8192)), dim3(NB_TPB), 0, c->stream, S);
+    else hipLaunchKernelGGL(sz_k_neighbors<false>, dim3(grid_for(S.capM, NB_TPB / NB_G, 8192)), dim3(NB_TPB), 0, c->stream, S);
   t.end();
 }
 

@@ -1111,7 +1111,9 @@ __device__ __forceinline__ Item item_of(const State& S, const Seg& g, int t) {
 // owned pairs whose ring boxes overlap are appended to the narrow phase's work list here (one tail atomic per workgroup);
 // the others get their (empty) result at once.
 constexpr int NB_G = 16, NB_TPB = 128, NB_POOL = 96;
-template <int TPB>
+// FAM: the Dict rule may read family records (inline ghosts; State::Fam) -- its arrays cost ~50 registers, a wavefront per SIMD that a
+// large field (throughput-bound search) misses: the host picks the instantiation by size
+template <int TPB, bool FAM = true>
 __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   constexpr int GPB = TPB / NB_G;
   __shared__ int cand[GPB][2][MAXNB];
@@ -1218,7 +1220,7 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
       // the Dict rule only bites when one of the two floes has periodic images
       if (!(kplain && oplain)) {
         bool ok;
-        if (S.ginline) {           // (inline ghosts leave a record per family: a floe that is a ghost, or has ghosts, has one at its parent)
+        if (FAM && S.ginline) {           // (inline ghosts leave a record per family: a floe that is a ghost, or has ghosts, has one at its parent)
           const int kp = kpar, op = opar;
           const long long gk = kgid, go = S.ghost_id[o];
           ok = after ? pair_allowed_fam(S, kp, op, !kplain, !oplain, okk, gk, ckx, cky, rk, ko, go, ocx, ocy, orm)
@@ -1276,7 +1278,8 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
     }
   }
 }
-__global__ void __launch_bounds__(NB_TPB) sz_k_neighbors(State S) { neighbors_body<NB_TPB>(S, blockIdx.x, gridDim.x); }
+template <bool FAM>
+__global__ void __launch_bounds__(NB_TPB) sz_k_neighbors(State S) { neighbors_body<NB_TPB, FAM>(S, blockIdx.x, gridDim.x); }
 
 // The compact pair list in the reference's serial order (i asc, j asc) -- out_off, pair_i, pair_j -- is only made when
 // the host asks for it (sz_download_pairs): fill after a scan of n_out.
@@ -2223,7 +2226,7 @@ __global__ void __launch_bounds__(256) sz_k_forcing_mixed(State S, Params P) { f
 // the rest evaluate the forcings (FRC 1: fp64, 2: mixed precision).  Measured at 10 k floes: 0.180 -> 0.168 ms/step.
 template <int FRC>
 __global__ void __launch_bounds__(256) sz_k_neighbors_forcing(State S, Params P, int nb_neigh) {
-  if ((int)blockIdx.x < nb_neigh) neighbors_body<256>(S, blockIdx.x, nb_neigh);
+  if ((int)blockIdx.x < nb_neigh) neighbors_body<256, false>(S, blockIdx.x, nb_neigh);      // (fields of 30 k floes and more: the lean instantiation)
   else if (FRC == 1) forcing_body<false>(S, P, (int)blockIdx.x - nb_neigh, (int)gridDim.x - nb_neigh, 0, nb_neigh);
   else forcing_mixed_body(S, P, (int)blockIdx.x - nb_neigh, (int)gridDim.x - nb_neigh, nb_neigh);
 }
