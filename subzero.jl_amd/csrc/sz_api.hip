@@ -74,7 +74,8 @@ struct sz_ctx {
   long long* d_stats = nullptr;
   int last_dt = 0;
   bool any_moving = false;
-  int overlap_forcing = 0;        // SZ_OVERLAP=1: forcings on a second stream beside the broad / narrow / reduce kernels.  The fork/join
+  int overlap_forcing = -1;       // -1: by size (fp64 fields above 65 536 floes, where the forcings have a launch of their own: 0.585 -> 0.567 ms/step at 100 k; not
+                                  // in mixed precision: 0.181 -> 0.187 on configs[4]); SZ_OVERLAP=0|1 forces it.  SZ_OVERLAP=1: forcings on a second stream beside the broad / narrow / reduce kernels.  The fork/join
                                   // costs ~10 us; riding in the neighbour launch (fuse_forcing) is as good or better at every size
   int max_sub = 0;                  // most sub-floe points of one floe (sizes the LDS of the two-way forcing kernel)
   int max_ring = 0, max_elem_ring = 5, max_ring_tiled = 0;   // largest ring sizes (host knowledge: which narrow variants can be needed)
@@ -1343,7 +1344,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
       c->S.step = s + 1;
       const bool resume = mid && s == s0;
       const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
-      const bool overlap = coupling && !c->two_way && (c->overlap_forcing != 0);
+      const bool overlap = coupling && !c->two_way && (c->overlap_forcing >= 0 ? c->overlap_forcing != 0 : (c->hostN > 65536 && c->precision == 0 && coll));
       // with collisions on, the ghosts of step s are detached by the ghost kernels of step s+1 (nothing
       // in between looks past the parents) and committed by the bounds kernel: two launches less
       // The forcings only read the floes' state at the start of the step (after the ghost pass has wrapped the parents that left the
