@@ -2218,7 +2218,7 @@ __device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, in
   }
 }
 
-__global__ void __launch_bounds__(256) sz_k_forcing_mixed(State S, Params P) { forcing_mixed_body(S, P, blockIdx.x, gridDim.x, 0); }
+__global__ void __launch_bounds__(256, 6) sz_k_forcing_mixed(State S, Params P) { forcing_mixed_body(S, P, blockIdx.x, gridDim.x, 0); }
 
 // Horizontal fusion: the neighbour search and the forcings are independent of each other (the forcings only need
 // the state the previous step left) and both are latency-bound per-floe kernels of ~20 us that leave most of the
