@@ -194,6 +194,9 @@ def main():
     ap.add_argument("--relax-steps", type=int, default=50, help="untimed steps before the warm-up: the fields are generated on a jittered lattice "
                     "with overlapping neighbours and then relaxed, as SURVEY.md §8(d) specifies for the synthetic configurations (50 steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true", help="N > 1 ranks that all use GPU 0, with gloo between them and the library's exchange "
+                    "over the host channel (sz_comm_init_host): runs the whole multi-rank flow of this script on a one-GPU box; the "
+                    "line it prints says so and is NOT a measurement")
     ap.add_argument("--force-tiled", action="store_true", help="run the halo/RCCL path even with one rank")
     args = ap.parse_args()
 
@@ -214,13 +217,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    if args.rehearse_shared_gpu:
+        local = 0
+    cdev = "cpu" if args.rehearse_shared_gpu else "cuda"          # where the script's own small collectives live
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or args.force_tiled:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29533"
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.rehearse_shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     # BASELINE.json: "floe-steps/sec at 10k/100k floes, 1/2/4/8 MI355X" -- one GPU: configs[1] (10 000 floes, uniform flow);
     # several GPUs: the strong-scaling workload, configs[2] (100 000 floes, converge/diverge flow) cut into spatial tiles.
@@ -252,11 +261,11 @@ def main():
         from subzero_jl_amd import tiles
         # the halo exchange runs inside the library (RCCL bound by libsubzero_hip.so: grouped send / receive with the
         # neighbouring tiles); SZ_TILES_BACKEND=torch: one torch.distributed all_to_all_single per step instead
-        backend = os.environ.get("SZ_TILES_BACKEND", "library")
+        backend = os.environ.get("SZ_TILES_BACKEND", "library-host" if args.rehearse_shared_gpu else "library")
         backend_note = None
 
         def make_tiles(be):
-            t = tiles.TiledWorld(cfg, rank, world, local, dist, always_exchange=args.force_tiled, backend=be)
+            t = tiles.TiledWorld(cfg, rank, world, local, dist, always_exchange=args.force_tiled, backend=be, host_staging=args.rehearse_shared_gpu)
             t.repartition_every = 10 ** 9     # floes drift metres per step against tiles of hundreds of km: no re-tiling inside a bench run
             return t
         # the library-side exchange binds RCCL at run time: if any rank cannot set it up (no librccl to bind, communicator refused),
@@ -268,7 +277,7 @@ def main():
         except Exception as e:      # noqa: BLE001
             err = str(e)[:300]
         if dist is not None:
-            flag = torch.tensor([1 if err else 0], device="cuda", dtype=torch.int32)
+            flag = torch.tensor([1 if err else 0], device=cdev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             failed = bool(flag.item())
         else:
@@ -313,7 +322,7 @@ def main():
         el = time.perf_counter() - t0
         tstep += args.steps
         if dist is not None:
-            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            t = torch.tensor([el], device=cdev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         blocks.append(el)
@@ -407,6 +416,8 @@ def main():
             out["config"]["halo_exchange"] = backend if world > 1 or args.force_tiled else None
             if backend_note:
                 out["config"]["halo_exchange_note"] = backend_note
+        if args.rehearse_shared_gpu:
+            out["data"] = "REHEARSAL: all ranks share GPU 0, transfers over gloo through the host -- not a measurement"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, relax_steps=args.relax_steps)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

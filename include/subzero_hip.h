@@ -277,6 +277,24 @@ int sz_set_stream(sz_ctx *ctx, void *hip_stream);
      sz_comm_allreduce   sum of n doubles in device memory over the ranks, in place (sz_eulerian_partial / sz_two_way_partial) */
 int sz_comm_unique_id(void *id128);
 int sz_comm_init(sz_ctx *ctx, int32_t nranks, int32_t rank, const void *id128);
+/* The same tiled run over the HOST's own channel between its ranks, for hosts whose ranks cannot open an RCCL communicator
+   (an MPI.jl build that is not device-aware, several ranks sharing one GPU -- RCCL refuses that, so this is also how the
+   library's multi-rank exchange is rehearsed on a one-GPU box): sz_comm_init_host instead of sz_comm_init, everything else
+   as above.  The library stages the regions through host memory and calls the three collectives below with HOST pointers;
+   they block, return 0 on success, and are called by every rank in the same order.
+     allgather          `bytes` from every rank into recv (nranks x bytes, in rank order)
+     sendrecv           npeers point-to-point transfers in each direction, all of them in flight together:
+                        send[k] / send_bytes[k] to rank peer[k], recv[k] / recv_bytes[k] from rank peer[k]
+                        (a peer's send_bytes to this rank equals this rank's recv_bytes for it; either may be 0)
+     allreduce_sum_f64  element-wise sum of n doubles over the ranks, in place */
+typedef struct sz_host_transport {
+  void *user;
+  int (*allgather)(void *user, const void *send, void *recv, int64_t bytes);
+  int (*sendrecv)(void *user, int32_t npeers, const int32_t *peer, const void *const *send, const int64_t *send_bytes,
+                  void *const *recv, const int64_t *recv_bytes);
+  int (*allreduce_sum_f64)(void *user, double *buf, int64_t n);
+} sz_host_transport;
+int sz_comm_init_host(sz_ctx *ctx, int32_t nranks, int32_t rank, const sz_host_transport *transport);
 int sz_comm_destroy(sz_ctx *ctx);
 /* one-rank self test of the RCCL binding (run-time loading, communicator of one rank, all-gather, all-reduce, grouped
    send / receive to self with the stream hand-shake of sz_tile_run): what of the exchange can run on a one-GPU box */

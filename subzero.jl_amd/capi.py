@@ -49,6 +49,16 @@ class SzStats(C.Structure):
                  "acc_narrow_launches", "acc_pair_items", "acc_pair_ring_points", "acc_pair_rows", "acc_elem_items", "acc_elem_rows")]
 
 
+_AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+_SR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, _ip, C.POINTER(C.c_void_p), _lp, C.POINTER(C.c_void_p), _lp)
+_AR = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int64)
+
+
+class SzHostTransport(C.Structure):
+    """sz_host_transport of include/subzero_hip.h: the host's own collectives for sz_comm_init_host"""
+    _fields_ = [("user", C.c_void_p), ("allgather", _AG), ("sendrecv", _SR), ("allreduce_sum_f64", _AR)]
+
+
 EXPORTS = [
     "sz_create", "sz_destroy", "sz_last_error", "sz_version", "sz_set_params", "sz_set_domain",
     "sz_set_topography", "sz_set_fields", "sz_upload_floes", "sz_get_stats", "sz_download_floes",
@@ -61,7 +71,7 @@ EXPORTS = [
     "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms", "sz_forcing_launch",
     "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_forcing", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps",
     "sz_get_boundary_rects", "sz_debug_match_vertices",
-    "sz_comm_unique_id", "sz_comm_init", "sz_comm_destroy", "sz_comm_selftest", "sz_comm_allreduce", "sz_tile_setup", "sz_tile_run",
+    "sz_comm_unique_id", "sz_comm_init", "sz_comm_init_host", "sz_comm_destroy", "sz_comm_selftest", "sz_comm_allreduce", "sz_tile_setup", "sz_tile_run",
 ]
 
 EUL_PARTIAL = 17      # SZ_EUL_PARTIAL: per-cell partial fields of sz_eulerian_partial
@@ -141,6 +151,7 @@ def load(build_if_missing=True):
     L.sz_debug_stamps.argtypes = [C.c_void_p, _lp]
     L.sz_comm_unique_id.argtypes = [C.c_void_p]
     L.sz_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    L.sz_comm_init_host.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SzHostTransport)]
     L.sz_comm_destroy.argtypes = [C.c_void_p]
     L.sz_comm_selftest.argtypes = [C.c_void_p]
     L.sz_comm_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]

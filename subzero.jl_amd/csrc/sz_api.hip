@@ -115,10 +115,12 @@ struct sz_ctx {
   // tiled runs with the exchange inside the library (sz_comm_init / sz_tile_setup / sz_tile_run): the RCCL communicator, a second
   // stream for the sends / receives (the forcings of the owned floes run beside them), the exchange buffers and their layout
   void* comm = nullptr; int comm_n = 0, comm_rank = 0;
+  sz_host_transport host_tr = { nullptr, nullptr, nullptr, nullptr }; bool host_transport = false;   // sz_comm_init_host: the collectives are the host's, staged through h_send / h_recv
+  std::vector<double> h_send, h_recv;
   hipStream_t comm_stream = nullptr; hipEvent_t ev_packed = nullptr, ev_recv = nullptr;
   Pool comm_allocs; double *d_send = nullptr, *d_recv = nullptr, *d_ref = nullptr, *d_gather = nullptr; int* d_dcap = nullptr;
   int halo_cap = 0; std::vector<int> cap_send, cap_recv;      // slots per peer region (stride) and what is really sent to / received from each peer
-  double tile_Lx = 0, tile_Ly = 0, tile_margin = 0; int tile_per_x = 0, tile_per_y = 0, tile_rebox_every = 50, tile_since_box = -1;
+  double tile_Lx = 0, tile_Ly = 0, tile_margin = 0; int tile_per_x = 0, tile_per_y = 0, tile_rebox_every = 50, tile_since_box = -1, tile_rebox_cur = 8;    // rebox_cur: the gather interval in use (<= rebox_every, from the measured drift)
   Pool tw_part_allocs; double* d_tw_partial = nullptr;
   int tile_forcing_tstep = -1;      // timestep whose forcings sz_tile_forcing has already enqueued
   bool tile_dirty = false;      // ghosts / halo floes of the last sz_tile_step still appended
@@ -1744,6 +1746,26 @@ bool rccl_load(std::string& err) {
     if (r_ != 0) { (ctx)->err = std::string(#call) + ": " + g_rccl.GetErrorString(r_); return SZ_E_HIP; } \
   } while (0)
 
+#define HOSTCHK(ctx, call, what)                                                                        \
+  do {                                                                                                 \
+    int r_ = (call);                                                                                   \
+    if (r_ != 0) { (ctx)->err = std::string("host transport: ") + what + " returned " + std::to_string(r_); return SZ_E_HIP; } \
+  } while (0)
+
+// all-gather of `bytes` per rank between device buffers on the context's stream (host transport: through the host, synchronous)
+int comm_allgather(sz_ctx* c, const void* d_src, void* d_dst, size_t count, int nccl_type, size_t elem) {
+  const int n = c->comm_n;
+  if (n == 1) { HIPCHK(c, hipMemcpyAsync(d_dst, d_src, count * elem, hipMemcpyDeviceToDevice, c->stream)); return SZ_OK; }
+  if (!c->host_transport) { NCCLCHK(c, g_rccl.AllGather(d_src, d_dst, count, nccl_type, c->comm, c->stream)); return SZ_OK; }
+  std::vector<char> hs(count * elem), hr(count * elem * n);
+  HIPCHK(c, hipMemcpyAsync(hs.data(), d_src, hs.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HOSTCHK(c, c->host_tr.allgather(c->host_tr.user, hs.data(), hr.data(), (int64_t)hs.size()), "allgather");
+  HIPCHK(c, hipMemcpyAsync(d_dst, hr.data(), hr.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SZ_OK;
+}
+
 // do the expanded box of rank d and the (margin-expanded) owned box of rank s meet, periodic images included?
 bool tiles_adjacent(const double* owned_s, const double* expanded_d, double margin, double Lx, double Ly, int per_x, int per_y) {
   for (int kx = (per_x ? -1 : 0); kx <= (per_x ? 1 : 0); kx++)
@@ -1762,25 +1784,27 @@ int tile_rebox(sz_ctx* c) {
   const int n = c->comm_n, me = c->comm_rank;
   int rc = sync_and_check(c); if (rc) return rc;
   hipLaunchKernelGGL(sz_k_owned_box, dim3(1), dim3(1024), 0, c->stream, S, c->d_gather);
-  std::vector<double> all((size_t)5 * n);
-  if (n > 1) NCCLCHK(c, g_rccl.AllGather(c->d_gather, c->d_gather + 8, 5, NCCL_FLOAT64, c->comm, c->stream));
-  else HIPCHK(c, hipMemcpyAsync(c->d_gather + 8, c->d_gather, 5 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  std::vector<double> all((size_t)6 * n);
+  if ((rc = comm_allgather(c, c->d_gather, c->d_gather + 8, 6, NCCL_FLOAT64, sizeof(double)))) return rc;
   HIPCHK(c, hipMemcpyAsync(all.data(), c->d_gather + 8, all.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  double rmax = 0.0;
-  for (int r = 0; r < n; r++) rmax = std::max(rmax, all[5 * r + 4]);
+  double rmax = 0.0, drift = 0.0;
+  for (int r = 0; r < n; r++) { rmax = std::max(rmax, all[6 * r + 4]); drift = std::max(drift, all[6 * r + 5]); }
+  // the gather interval follows the measured speed (every rank computes the same number): the floes may use 30 % of the margin
+  // before the next gather, half of it is the error threshold; a new setup starts with a short interval
+  if (c->tile_since_box > 0)
+    c->tile_rebox_cur = drift > 0.0 ? (int)std::max(1.0, std::min((double)c->tile_rebox_every, 0.3 * c->tile_margin / (drift / c->tile_since_box))) : c->tile_rebox_every;
   const double reach = 2.0 * rmax + c->tile_margin;
   std::vector<double> boxes((size_t)4 * n);
-  for (int r = 0; r < n; r++) { boxes[4 * r] = all[5 * r] - reach; boxes[4 * r + 1] = all[5 * r + 1] + reach; boxes[4 * r + 2] = all[5 * r + 2] - reach; boxes[4 * r + 3] = all[5 * r + 3] + reach; }
+  for (int r = 0; r < n; r++) { boxes[4 * r] = all[6 * r] - reach; boxes[4 * r + 1] = all[6 * r + 1] + reach; boxes[4 * r + 2] = all[6 * r + 2] - reach; boxes[4 * r + 3] = all[6 * r + 3] + reach; }
   HIPCHK(c, hipMemcpyAsync(S.bounds + 16, boxes.data(), boxes.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
   // counting pass, then the count matrix of all ranks (row s: what s sends to every d)
   int* dcnt = S.cnt + C_COUNT;
   hipLaunchKernelGGL(sz_k_halo_pack, dim3(1), dim3(1024), 0, c->stream, S, n, me, S.bounds + 16, c->tile_Lx, c->tile_Ly, c->tile_per_x,
                      c->tile_per_y, (double*)nullptr, 1, dcnt, (const int*)nullptr, (const double*)nullptr, 0.0);
-  int* d_mat = (int*)(c->d_gather + 8 + 5 * 64);
+  int* d_mat = (int*)(c->d_gather + 8 + 6 * 64);
   std::vector<int> mat((size_t)n * n);
-  if (n > 1) NCCLCHK(c, g_rccl.AllGather(dcnt, d_mat, (size_t)n, NCCL_INT32, c->comm, c->stream));
-  else HIPCHK(c, hipMemcpyAsync(d_mat, dcnt, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+  if ((rc = comm_allgather(c, dcnt, d_mat, (size_t)n, NCCL_INT32, sizeof(int)))) return rc;
   HIPCHK(c, hipMemcpyAsync(mat.data(), d_mat, mat.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   // slots per ordered pair: neighbours get 1.5 x the present count + 32, the others nothing (every rank computes the same table)
@@ -1789,7 +1813,7 @@ int tile_rebox(sz_ctx* c) {
   for (int s = 0; s < n; s++)
     for (int d = 0; d < n; d++) {
       if (s == d) continue;
-      const bool adj = tiles_adjacent(&all[5 * s], &boxes[4 * d], c->tile_margin, c->tile_Lx, c->tile_Ly, c->tile_per_x, c->tile_per_y);
+      const bool adj = tiles_adjacent(&all[6 * s], &boxes[4 * d], c->tile_margin, c->tile_Lx, c->tile_Ly, c->tile_per_x, c->tile_per_y);
       const int k = adj || mat[(size_t)s * n + d] > 0 ? mat[(size_t)s * n + d] * 3 / 2 + 32 : 0;
       if (s == me) c->cap_send[d] = k;
       if (d == me) c->cap_recv[s] = k;
@@ -1827,6 +1851,19 @@ int sz_comm_init(sz_ctx* c, int32_t nranks, int32_t rank, const void* id128) {
     UId id; memcpy(&id, id128, sizeof(id));
     NCCLCHK(c, g_rccl.CommInitRank(&c->comm, nranks, id, rank));
   }
+  c->comm_n = nranks; c->comm_rank = rank;
+  HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_recv, hipEventDisableTiming));
+  return SZ_OK;
+}
+// the host's own channel instead of RCCL (include/subzero_hip.h: sz_host_transport)
+int sz_comm_init_host(sz_ctx* c, int32_t nranks, int32_t rank, const sz_host_transport* t) {
+  if (!c || nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks) return SZ_E_ARG;
+  if (nranks > 1 && (!t || !t->allgather || !t->sendrecv || !t->allreduce_sum_f64)) { c->err = "sz_comm_init_host: the transport needs all three collectives"; return SZ_E_ARG; }
+  (void)hipSetDevice(c->device);
+  (void)sz_comm_destroy(c);
+  if (nranks > 1) { c->host_tr = *t; c->host_transport = true; }
   c->comm_n = nranks; c->comm_rank = rank;
   HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
@@ -1879,6 +1916,7 @@ int sz_comm_destroy(sz_ctx* c) {
   if (c->comm_stream) { (void)hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
   if (c->ev_packed) { (void)hipEventDestroy(c->ev_packed); c->ev_packed = nullptr; }
   if (c->ev_recv) { (void)hipEventDestroy(c->ev_recv); c->ev_recv = nullptr; }
+  c->host_transport = false; c->host_tr = sz_host_transport{ nullptr, nullptr, nullptr, nullptr };
   c->comm_n = 0; c->d_send = c->d_recv = c->d_ref = nullptr; c->d_dcap = nullptr; c->halo_cap = 0; c->tile_since_box = -1;
   if (c->d_gather) { (void)hipFree(c->d_gather); c->d_gather = nullptr; }
   free_pool(c->comm_allocs);
@@ -1889,7 +1927,14 @@ int sz_comm_destroy(sz_ctx* c) {
 int sz_comm_allreduce(sz_ctx* c, void* d_buf, int64_t n) {
   if (!c || !d_buf || n < 0 || c->comm_n < 1) return SZ_E_STATE;
   (void)hipSetDevice(c->device);
-  if (c->comm_n > 1) NCCLCHK(c, g_rccl.AllReduce(d_buf, d_buf, (size_t)n, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream));
+  if (c->comm_n > 1 && c->host_transport) {
+    std::vector<double> h((size_t)n);
+    HIPCHK(c, hipMemcpyAsync(h.data(), d_buf, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HOSTCHK(c, c->host_tr.allreduce_sum_f64(c->host_tr.user, h.data(), n), "allreduce_sum_f64");
+    HIPCHK(c, hipMemcpyAsync(d_buf, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  } else if (c->comm_n > 1) NCCLCHK(c, g_rccl.AllReduce(d_buf, d_buf, (size_t)n, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream));
   return SZ_OK;
 }
 int sz_tile_setup(sz_ctx* c, double Lx, double Ly, int32_t per_x, int32_t per_y, double drift_margin, int32_t rebox_every) {
@@ -1899,10 +1944,10 @@ int sz_tile_setup(sz_ctx* c, double Lx, double Ly, int32_t per_x, int32_t per_y,
   }
   (void)hipSetDevice(c->device);
   c->tile_Lx = Lx; c->tile_Ly = Ly; c->tile_per_x = per_x; c->tile_per_y = per_y; c->tile_margin = drift_margin; c->tile_rebox_every = rebox_every;
-  c->tile_since_box = -1; c->halo_cap = 0; c->d_send = nullptr;
+  c->tile_since_box = -1; c->halo_cap = 0; c->d_send = nullptr; c->tile_rebox_cur = std::min(rebox_every, 8);
   free_pool(c->comm_allocs);
   if (!c->d_gather) {          // own box | all boxes | count matrix (ints): lives as long as the communicator
-    HIPCHK(c, hipMalloc((void**)&c->d_gather, (8 + 5 * 64 + 64 * 64 / 2 + 64) * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&c->d_gather, (8 + 6 * 64 + 64 * 64 / 2 + 64) * sizeof(double)));
   }
   return SZ_OK;
 }
@@ -1914,14 +1959,34 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   const int n = c->comm_n, me = c->comm_rank;
   for (int s = 0; s < nsteps; s++) {
     const int tstep = tstep0 + s;
-    if (c->tile_since_box < 0 || c->tile_since_box >= c->tile_rebox_every) { int rc = tile_rebox(c); if (rc) return rc; }
+    if (c->tile_since_box < 0 || c->tile_since_box >= c->tile_rebox_cur) { int rc = tile_rebox(c); if (rc) return rc; }
     c->tile_since_box++;
     const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
     const size_t stride = (size_t)(c->halo_cap + 1) * HALO_REC;
     int* dcnt = S.cnt + C_COUNT;
     hipLaunchKernelGGL(sz_k_halo_pack, dim3(1), dim3(1024), 0, c->stream, S, n, me, S.bounds + 16, c->tile_Lx, c->tile_Ly, c->tile_per_x,
                        c->tile_per_y, c->d_send, c->halo_cap, dcnt, (const int*)c->d_dcap, (const double*)c->d_ref, c->tile_margin);
-    if (n > 1) {
+    if (n > 1 && c->host_transport) {
+      // the host's channel: the forcings go to the device first and run while the host trades the regions
+      HIPCHK(c, hipEventRecord(c->ev_packed, c->stream));
+      if (coupling) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return rc; }
+      HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
+      c->h_send.resize((size_t)n * stride); c->h_recv.resize((size_t)n * stride);
+      std::vector<int32_t> peer; std::vector<const void*> sp; std::vector<void*> rp; std::vector<int64_t> sb, rb;
+      for (int d = 0; d < n; d++) {
+        if (d == me || (c->cap_send[d] <= 0 && c->cap_recv[d] <= 0)) continue;
+        const size_t ns = c->cap_send[d] > 0 ? (size_t)(c->cap_send[d] + 1) * HALO_REC : 0, nr = c->cap_recv[d] > 0 ? (size_t)(c->cap_recv[d] + 1) * HALO_REC : 0;
+        if (ns) HIPCHK(c, hipMemcpyAsync(c->h_send.data() + d * stride, c->d_send + d * stride, ns * sizeof(double), hipMemcpyDeviceToHost, c->comm_stream));
+        peer.push_back(d); sp.push_back(c->h_send.data() + d * stride); sb.push_back((int64_t)(ns * sizeof(double)));
+        rp.push_back(c->h_recv.data() + d * stride); rb.push_back((int64_t)(nr * sizeof(double)));
+      }
+      HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+      HOSTCHK(c, c->host_tr.sendrecv(c->host_tr.user, (int32_t)peer.size(), peer.data(), sp.data(), sb.data(), rp.data(), rb.data()), "sendrecv");
+      for (size_t k = 0; k < peer.size(); k++)
+        if (rb[k]) HIPCHK(c, hipMemcpyAsync(c->d_recv + peer[k] * stride, rp[k], (size_t)rb[k], hipMemcpyHostToDevice, c->comm_stream));
+      HIPCHK(c, hipStreamSynchronize(c->comm_stream));       // (h_recv is reused by the next step)
+      HIPCHK(c, hipEventRecord(c->ev_recv, c->comm_stream));
+    } else if (n > 1) {
       HIPCHK(c, hipEventRecord(c->ev_packed, c->stream));
       HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
       NCCLCHK(c, g_rccl.GroupStart());
@@ -1934,7 +1999,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
       HIPCHK(c, hipEventRecord(c->ev_recv, c->comm_stream));
     }
     // the forcings of the owned floes need nothing from the halo: they run beside the exchange
-    if (coupling) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return rc; }
+    if (coupling && !(n > 1 && c->host_transport)) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return rc; }
     if (n > 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_recv, 0));
     int rc = sz_tile_step(c, c->d_recv, n, c->halo_cap, tstep, dt, coupling_dt, flags);
     if (rc) return rc;

@@ -2553,9 +2553,12 @@ __global__ void __launch_bounds__(1024) sz_k_halo_pack(State S, int nranks, int 
                                                        int per_x, int per_y, double* send, int cap, int* counts,
                                                        const int* dcap, const double* ref, double margin) {
   __shared__ int lc[64];
+  __shared__ int ldrift;
   if (threadIdx.x < 64) lc[threadIdx.x] = 0;
+  if (threadIdx.x == 0) ldrift = 0;
   __syncthreads();
   int n = S.cnt[C_NOWN];
+  double dmax = 0.0;
   for (int q = threadIdx.x; q < n; q += blockDim.x) {
     double cx = S.cx[q], cy = S.cy[q];
     if (ref) {
@@ -2563,6 +2566,7 @@ __global__ void __launch_bounds__(1024) sz_k_halo_pack(State S, int nranks, int 
       if (per_x && ddx > 0.5 * Lx) ddx = fabs(ddx - Lx);          // a parent the ghost pass wrapped around the domain
       if (per_y && ddy > 0.5 * Ly) ddy = fabs(ddy - Ly);
       if (2.0 * fmax(ddx, ddy) > margin) atomicOr(&S.cnt[C_ERR], ERR_HALO_DRIFT);
+      dmax = fmax(dmax, fmax(ddx, ddy));
     }
     int o = S.voff[q], nv = S.voff[q + 1] - o;
     for (int d = 0; d < nranks; d++) {
@@ -2584,7 +2588,9 @@ __global__ void __launch_bounds__(1024) sz_k_halo_pack(State S, int nranks, int 
       for (int k = 0; k < nv; k++) { r[12 + k] = S.vx[o + k]; r[12 + HALO_RING + k] = S.vy[o + k]; }
     }
   }
+  if (ref && dmax > 0.0) atomicMax(&ldrift, __float_as_int((float)dmax * 1.0001f));      // (non-negative floats order like their bits)
   __syncthreads();
+  if (ref && threadIdx.x == 0) S.cnt[C_DRIFT] = ldrift;          // what the host sizes the next gather interval with
   if ((int)threadIdx.x < nranks) {
     int d = threadIdx.x;
     counts[d] = lc[d];
@@ -2659,7 +2665,8 @@ __global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* 
     if (nrec == 0) S.voff[nown] = vbase;
   }
 }
-// bounding box of the owned centroids and the largest rmax: out[0..4] = xmin, xmax, ymin, ymax, rmax
+// bounding box of the owned centroids and the largest rmax: out[0..4] = xmin, xmax, ymin, ymax, rmax; out[5] = the largest
+// displacement since the last box gather as the last pack kernel measured it (C_DRIFT)
 __global__ void __launch_bounds__(1024) sz_k_owned_box(State S, double* out) {
   __shared__ double sh[5][16];
   int n = S.cnt[C_NOWN];
@@ -2678,7 +2685,7 @@ __global__ void __launch_bounds__(1024) sz_k_owned_box(State S, double* out) {
     for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
       x0 = fmin(x0, sh[0][w]); y0 = fmin(y0, sh[1][w]); x1 = fmax(x1, sh[2][w]); y1 = fmax(y1, sh[3][w]); rm = fmax(rm, sh[4][w]);
     }
-    out[0] = x0; out[1] = x1; out[2] = y0; out[3] = y1; out[4] = rm;
+    out[0] = x0; out[1] = x1; out[2] = y0; out[3] = y1; out[4] = rm; out[5] = (double)__int_as_float(S.cnt[C_DRIFT]);
   }
 }
 

@@ -39,6 +39,7 @@ enum {
   C_NENT,         // two-way coupling: (floe, centre cell) entries of the current coupling step
   C_STOP,         // resident batches (sz_step): 0, or 1 + the batch-relative step after which the batch stops -- a floe was tagged
                   // remove / fuse (or fell under the dissolve thresholds), so the host's simplify_floes! (simulation.jl:205-214) has work
+  C_DRIFT,        // tiled runs: largest displacement of an owned floe since the last box gather, metres as float bits (pack kernel)
   C_COUNT = 32
 };
 

@@ -76,15 +76,62 @@ def subset_config(cfg, idx):
     return cols, soff, cfg["sx"][ssel], cfg["sy"][ssel]
 
 
+def host_transport(dist, rank, world):
+    """sz_host_transport over torch.distributed collectives on HOST tensors (gloo, or any backend that takes CPU tensors):
+    the three collectives the library calls when the tiled run was set up with sz_comm_init_host."""
+    import torch
+
+    def view(p, nbytes):
+        return torch.frombuffer((C.c_char * nbytes).from_address(p), dtype=torch.uint8) if nbytes else torch.zeros(0, dtype=torch.uint8)
+
+    def allgather(user, send, recv, nbytes):
+        try:
+            out = view(recv, nbytes * world)
+            dist.all_gather(list(out.split(nbytes)), view(send, nbytes).clone())
+            return 0
+        except Exception:                      # noqa: BLE001  (an exception must not cross the C frames)
+            import traceback; traceback.print_exc()
+            return 1
+
+    def sendrecv(user, npeers, peer, send, send_bytes, recv, recv_bytes):
+        try:
+            ops = []
+            for k in range(npeers):
+                if recv_bytes[k]:
+                    ops.append(dist.P2POp(dist.irecv, view(recv[k], recv_bytes[k]), int(peer[k])))
+                if send_bytes[k]:
+                    ops.append(dist.P2POp(dist.isend, view(send[k], send_bytes[k]), int(peer[k])))
+            for r in (dist.batch_isend_irecv(ops) if ops else []):
+                r.wait()
+            return 0
+        except Exception:                      # noqa: BLE001
+            import traceback; traceback.print_exc()
+            return 1
+
+    def allreduce(user, buf, n):
+        try:
+            dist.all_reduce(torch.frombuffer((C.c_double * n).from_address(C.addressof(buf.contents)), dtype=torch.float64))
+            return 0
+        except Exception:                      # noqa: BLE001
+            import traceback; traceback.print_exc()
+            return 1
+
+    t = capi.SzHostTransport(None, capi._AG(allgather), capi._SR(sendrecv), capi._AR(allreduce))
+    t._keep = (allgather, sendrecv, allreduce)
+    return t
+
+
 class TiledWorld:
     """One rank of a tiled run.  `dist` is torch.distributed (initialised) or None for world == 1."""
 
-    def __init__(self, cfg, rank, world, device, dist, drift_margin=2000.0, rebox_every=50, host_staging=False,
+    def __init__(self, cfg, rank, world, device, dist, drift_margin=None, rebox_every=50, host_staging=False,
                  always_exchange=False, backend="torch"):
         """backend: "library" -- the exchange runs inside libsubzero_hip.so (sz_comm_init / sz_tile_setup / sz_tile_run: RCCL
         bound by the library, grouped send / receive with the neighbouring tiles only; `dist` is then only used to hand the
         communicator id to the ranks); "torch" -- one torch.distributed all_to_all_single per step on buffers the library
-        packs and unpacks (and, with host_staging, through the host: the gloo tests)."""
+        packs and unpacks (and, with host_staging, through the host: the gloo tests); "library-host" -- sz_tile_run as
+        with "library", but over the host's channel (sz_comm_init_host: `dist` collectives on host buffers, e.g. gloo) --
+        the library's multi-rank exchange without an RCCL communicator, which ranks sharing one GPU cannot open."""
         import torch
         self.torch = torch
         self.cfg, self.rank, self.nranks, self.dist = cfg, rank, world, dist
@@ -109,6 +156,10 @@ class TiledWorld:
         max_ring = float(np.diff(cfg["vert_off"]).max())        # over ALL floes: halo floes arrive unseen
         max_rmax = float(cfg["derived"]["rmax"].max())          # over ALL floes, like max_ring
         self._max_ring, self._max_rmax = max_ring, max_rmax
+        if drift_margin is None:
+            # metres an owned floe may move between two box gathers (half of it, strictly): a quarter of the largest floe radius keeps
+            # the extra halo small against the 2 x rmax interaction range and the gathers tens of steps apart at metres per step
+            drift_margin = max(2000.0, 0.25 * max_rmax)
         w._chk(w.L.sz_tile_enable(w.h, capi.ptr(g, capi._lp), max_ring, max_rmax))
         self.world = w
         self.REC = w.L.sz_halo_record_doubles()
@@ -124,6 +175,10 @@ class TiledWorld:
                 dist.broadcast_object_list(box, src=0)          # any host channel does: the id is 128 opaque bytes
                 uid = (C.c_char * 128).from_buffer_copy(box[0])
             w._chk(w.L.sz_comm_init(w.h, world, rank, C.cast(uid, C.c_void_p)))
+        elif backend == "library-host":
+            self._transport = host_transport(dist, rank, world)          # (kept alive: the library calls into it)
+            w._chk(w.L.sz_comm_init_host(w.h, world, rank, C.byref(self._transport)))
+        if backend in ("library", "library-host"):
             w._chk(w.L.sz_tile_setup(w.h, self.L, self.L, int(self.per_x), int(self.per_y), float(drift_margin), int(rebox_every)))
         elif not host_staging:
             # kernels and RCCL collectives are ordered by ONE stream: no host sync inside a step
@@ -346,7 +401,7 @@ class TiledWorld:
         w._push()
         g = np.ascontiguousarray(self.gidx, np.int64)
         w._chk(w.L.sz_tile_enable(w.h, capi.ptr(g, capi._lp), self._max_ring, self._max_rmax))
-        if self.backend == "library":
+        if self.backend in ("library", "library-host"):
             w._chk(w.L.sz_tile_setup(w.h, self.L, self.L, int(self.per_x), int(self.per_y), float(self.margin), int(self.rebox_every_max)))
         self.boxes = None                      # owned boxes and halo capacity are re-established at the next exchange
         self._ref = None
@@ -372,7 +427,7 @@ class TiledWorld:
         done = 0
         while done < nsteps:
             k = min(nsteps - done, self.repartition_every - self._since_check) if self.nranks > 1 else nsteps - done
-            if self.backend == "library":
+            if self.backend in ("library", "library-host"):
                 w = self.world
                 flags = (capi.COLLISIONS_ON if collisions_on else 0) | (capi.COUPLING_ON if coupling_on else 0)
                 w._chk(w.L.sz_tile_run(w.h, int(k), int(tstep0 + done), int(dt), int(coupling_dt), flags))

@@ -16,7 +16,7 @@ FIELDS = ["cx", "cy", "u", "v", "xi", "alpha", "coll_fx", "coll_fy", "coll_trq",
 def _guard(fn):
     """run a worker body; an exception goes to the parent through the queue instead of leaving it waiting"""
     def run(rank, world, port, *args):
-        q = args[-1] if not isinstance(args[-1], bool) else args[-2]
+        q = next(a for a in args if hasattr(a, "put"))
         try:
             fn(rank, world, port, *args)
         except BaseException as e:          # noqa: BLE001
@@ -52,7 +52,7 @@ def _field(n, seed, fast=False):
     return cfg
 
 
-def _worker(rank, world, port, n, seed, steps, q, repartition=False, fast=False):
+def _worker(rank, world, port, n, seed, steps, q, repartition=False, fast=False, backend="torch"):
     import torch
     import torch.distributed as dist
     from subzero_jl_amd import fields, tiles
@@ -60,7 +60,7 @@ def _worker(rank, world, port, n, seed, steps, q, repartition=False, fast=False)
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         cfg = _field(n, seed, fast)
-        tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True)
+        tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True, backend=backend, rebox_every=3 if backend != "torch" else 50)
         if repartition:
             # half way through, hand every floe to the other kind of tiling (split along y instead of x): most
             # floes change owner with their complete state, and the run must go on as if nothing had happened
@@ -87,19 +87,26 @@ def _run_worker_two_way(*a):
     _guard(_worker_two_way)(*a)
 
 
-@pytest.mark.parametrize("world,n,seed,steps,repartition,fast", [(2, 600, 31, 4, False, False), (2, 600, 33, 6, True, False), (4, 1000, 35, 4, False, False),
-                                                                 (2, 500, 77, 30, False, True)])
-def test_ranks_equal_single(world, n, seed, steps, repartition, fast):
+@pytest.mark.parametrize("world,n,seed,steps,repartition,fast,backend", [
+    (2, 600, 31, 4, False, False, "torch"), (2, 600, 33, 6, True, False, "torch"), (4, 1000, 35, 4, False, False, "torch"),
+    (2, 500, 77, 30, False, True, "torch"),
+    (2, 600, 31, 8, False, False, "library-host"), (2, 600, 33, 8, True, False, "library-host"), (4, 1000, 35, 8, False, False, "library-host"),
+    (2, 500, 77, 30, False, True, "library-host")])
+def test_ranks_equal_single(world, n, seed, steps, repartition, fast, backend):
     """2 ranks (two tiles side by side) and 4 ranks (2 x 2 tiles: corner halos, both periodic directions across
     tile boundaries) against the single-context run: bit-equal columns for every owned floe; `fast`: parents cross the
-    periodic walls and swap with their ghosts during the run"""
+    periodic walls and swap with their ghosts during the run.  backend "torch": the exchange is one torch.distributed
+    collective per step on buffers the library packs; "library-host": the exchange INSIDE the library (sz_tile_run: box and
+    count-matrix gathers, per-pair regions with real counts, neighbours only, drift reference, several gather intervals) with
+    the ranks' transfers made by the host channel (sz_comm_init_host over gloo) -- every line of the multi-rank path except the
+    RCCL calls themselves, which ranks sharing one GPU cannot make."""
     import torch.multiprocessing as mp
     import subzero_jl_amd
     from subzero_jl_amd import fields
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_worker, args=(r, world, port, n, seed, steps, q, repartition, fast)) for r in range(world)]
+    procs = [ctx.Process(target=_run_worker, args=(r, world, port, n, seed, steps, q, repartition, fast, backend)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -127,14 +134,14 @@ def test_ranks_equal_single(world, n, seed, steps, repartition, fast):
     assert seen.all()
 
 
-def _worker_two_way(rank, world, port, n, seed, steps, q):
+def _worker_two_way(rank, world, port, n, seed, steps, q, backend="torch"):
     import torch.distributed as dist
     from subzero_jl_amd import fields, tiles
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         cfg = fields.make_config(n_floes=n, seed=seed, ocean="shear")
-        tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True)
+        tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True, backend=backend)
         tw.set_two_way(0.5, -8.0, cfg["dt"])
         tw.run(steps, 0, cfg["dt"], coupling_dt=2)
         tw.sync()
@@ -145,7 +152,8 @@ def _worker_two_way(rank, world, port, n, seed, steps, q):
         dist.destroy_process_group()
 
 
-def test_two_way_coupling_across_tiles():
+@pytest.mark.parametrize("backend", ["torch", "library-host"])
+def test_two_way_coupling_across_tiles(backend):
     """Two ranks, two-way coupling on: the per-cell sums of both ranks added up give the single-context ocean
     fields (to round-off: the cross-rank sum order differs), and the run -- which feeds on the heat-flux factor
     the coupling writes -- follows the single-context trajectory."""
@@ -155,7 +163,7 @@ def test_two_way_coupling_across_tiles():
     n, seed, steps, world = 500, 41, 6, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue(); port = _free_port()
-    procs = [ctx.Process(target=_run_worker_two_way, args=(r, world, port, n, seed, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run_worker_two_way, args=(r, world, port, n, seed, steps, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     try:
