@@ -76,7 +76,7 @@ def _worker(rank, world, port, n, seed, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,seed", [(2, 300, 21), (4, 600, 22)])
+@pytest.mark.parametrize("world,n,seed", [(2, 300, 21), (4, 600, 22), (8, 1000, 23)])
 def test_halo_protocol_gloo(world, n, seed):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
