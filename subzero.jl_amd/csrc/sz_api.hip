@@ -822,7 +822,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   S.capRows = S.capPairs * 3 + S.capElem * 2; S.capCells = 4 * S.capM + 64; S.capS = NS;
   int rc;
 #define DA(field, n) if ((rc = dalloc(c, &S.field, (size_t)(n), c->allocs))) return rc
-  DA(cnt, C_COUNT + 64); DA(warn, WARN_SLOTS * 32);
+  DA(cnt, C_COUNT + 64 + 72); DA(warn, WARN_SLOTS * 32);      // counters | 64 per-rank counts of the pack kernel | its 66 scratch words
   double** dcols[] = { &S.cx, &S.cy, &S.rmax, &S.area, &S.height, &S.mass, &S.moment, &S.alpha, &S.u, &S.v, &S.xi,
                        &S.p_dxdt, &S.p_dydt, &S.p_dalphadt, &S.p_dudt, &S.p_dvdt, &S.p_dxidt, &S.fxOA, &S.fyOA, &S.trqOA,
                        &S.hflx, &S.overarea, &S.cfx, &S.cfy, &S.ctrq };
@@ -887,10 +887,10 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(tagA, S.capM + 1);
   DA(stamps, 512 + 8 * 8000);
   trim_pool(c->allocs);
-  int h[C_COUNT] = { 0 };
+  int h[C_COUNT + 64 + 72] = { 0 };
   h[C_M] = M; h[C_N] = N; h[C_NV] = V; h[C_NGHOSTS] = M - N; h[C_NOWN] = N;
   S.tiled = 0;
-  H2D(S.cnt, h, C_COUNT, int);
+  H2D(S.cnt, h, C_COUNT + 64 + 72, int);
   hipLaunchKernelGGL(sz_k_osign, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->hostM = M; c->hostN = N; c->have_floes = true; c->tile_dirty = false; c->mixed_pts_ok = false;
@@ -1499,7 +1499,7 @@ int sz_halo_pack(sz_ctx* c, int32_t nranks, int32_t me, double Lx, double Ly, in
   (void)hipSetDevice(c->device);
   State& S = c->S;
   int* dcnt = S.cnt + C_COUNT;                  // 64 ints reserved behind the counter block
-  hipLaunchKernelGGL(sz_k_halo_pack, dim3(1), dim3(1024), 0, c->stream, S, nranks, me, S.bounds + 16, Lx, Ly,
+  hipLaunchKernelGGL(sz_k_halo_pack, dim3(grid_for(std::max(c->hostN, 1), PACK_TPB)), dim3(PACK_TPB), 0, c->stream, S, nranks, me, S.bounds + 16, Lx, Ly,
                      per_x, per_y, (double*)d_send, cap, dcnt, (const int*)nullptr, (const double*)nullptr, 0.0);
   return SZ_OK;
 }
@@ -1800,7 +1800,7 @@ int tile_rebox(sz_ctx* c) {
   HIPCHK(c, hipMemcpyAsync(S.bounds + 16, boxes.data(), boxes.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
   // counting pass, then the count matrix of all ranks (row s: what s sends to every d)
   int* dcnt = S.cnt + C_COUNT;
-  hipLaunchKernelGGL(sz_k_halo_pack, dim3(1), dim3(1024), 0, c->stream, S, n, me, S.bounds + 16, c->tile_Lx, c->tile_Ly, c->tile_per_x,
+  hipLaunchKernelGGL(sz_k_halo_pack, dim3(grid_for(std::max(c->hostN, 1), PACK_TPB)), dim3(PACK_TPB), 0, c->stream, S, n, me, S.bounds + 16, c->tile_Lx, c->tile_Ly, c->tile_per_x,
                      c->tile_per_y, (double*)nullptr, 1, dcnt, (const int*)nullptr, (const double*)nullptr, 0.0);
   int* d_mat = (int*)(c->d_gather + 8 + 6 * 64);
   std::vector<int> mat((size_t)n * n);
@@ -1964,7 +1964,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
     const size_t stride = (size_t)(c->halo_cap + 1) * HALO_REC;
     int* dcnt = S.cnt + C_COUNT;
-    hipLaunchKernelGGL(sz_k_halo_pack, dim3(1), dim3(1024), 0, c->stream, S, n, me, S.bounds + 16, c->tile_Lx, c->tile_Ly, c->tile_per_x,
+    hipLaunchKernelGGL(sz_k_halo_pack, dim3(grid_for(std::max(c->hostN, 1), PACK_TPB)), dim3(PACK_TPB), 0, c->stream, S, n, me, S.bounds + 16, c->tile_Lx, c->tile_Ly, c->tile_per_x,
                        c->tile_per_y, c->d_send, c->halo_cap, dcnt, (const int*)c->d_dcap, (const double*)c->d_ref, c->tile_margin);
     if (n > 1 && c->host_transport) {
       // the host's channel: the forcings go to the device first and run while the host trades the regions

@@ -2549,26 +2549,23 @@ constexpr int HALO_REC = 12 + 2 * HALO_RING;   // doubles
 // further than half the drift margin built into the boxes -- beyond that a neighbour across a tile edge could be missed
 // silently, so it is an error (ERR_HALO_DRIFT), raised one step early enough.
 constexpr int ERR_HALO_DRIFT = 16384;
-__global__ void __launch_bounds__(1024) sz_k_halo_pack(State S, int nranks, int me, const double* boxes, double Lx, double Ly,
-                                                       int per_x, int per_y, double* send, int cap, int* counts,
-                                                       const int* dcap, const double* ref, double margin) {
-  __shared__ int lc[64];
-  __shared__ int ldrift;
-  if (threadIdx.x < 64) lc[threadIdx.x] = 0;
+constexpr int PACK_TPB = 256;
+// Workgroups of 256 owned floes: a workgroup counts its records per destination in LDS, reserves that many slots of every region
+// with one atomic per destination (counts[64 + d]: running totals), then writes its records; the workgroup that finishes last
+// (ticket in counts[128]) writes the header records and the totals and leaves the scratch words zero for the next launch.  (The
+// order of the records inside a region is arbitrary, as it was with one workgroup: order-dependent rules use the global index.)
+__global__ void __launch_bounds__(PACK_TPB) sz_k_halo_pack(State S, int nranks, int me, const double* boxes, double Lx, double Ly,
+                                                           int per_x, int per_y, double* send, int cap, int* counts,
+                                                           const int* dcap, const double* ref, double margin) {
+  __shared__ int lc[64], lc2[64], base[64];
+  __shared__ int ldrift, last;
+  int* run = counts + 64;
+  if (threadIdx.x < 64) { lc[threadIdx.x] = 0; lc2[threadIdx.x] = 0; }
   if (threadIdx.x == 0) ldrift = 0;
   __syncthreads();
-  int n = S.cnt[C_NOWN];
-  double dmax = 0.0;
-  for (int q = threadIdx.x; q < n; q += blockDim.x) {
-    double cx = S.cx[q], cy = S.cy[q];
-    if (ref) {
-      double ddx = fabs(cx - ref[q]), ddy = fabs(cy - ref[S.capM + q]);
-      if (per_x && ddx > 0.5 * Lx) ddx = fabs(ddx - Lx);          // a parent the ghost pass wrapped around the domain
-      if (per_y && ddy > 0.5 * Ly) ddy = fabs(ddy - Ly);
-      if (2.0 * fmax(ddx, ddy) > margin) atomicOr(&S.cnt[C_ERR], ERR_HALO_DRIFT);
-      dmax = fmax(dmax, fmax(ddx, ddy));
-    }
-    int o = S.voff[q], nv = S.voff[q + 1] - o;
+  const int n = S.cnt[C_NOWN];
+  auto hits_of = [&](double cx, double cy) {
+    unsigned long long hits = 0;
     for (int d = 0; d < nranks; d++) {
       if (d == me) continue;
       const double* b = boxes + 4 * d;
@@ -2578,24 +2575,61 @@ __global__ void __launch_bounds__(1024) sz_k_halo_pack(State S, int nranks, int 
           double x = cx + kx * Lx, y = cy + ky * Ly;
           hit = (b[0] <= x && x <= b[1] && b[2] <= y && y <= b[3]);
         }
-      if (!hit) continue;
-      int slot = atomicAdd(&lc[d], 1);
-      if (send == nullptr) continue;                 // counting pass (sizing of the exchange buffers)
-      if (slot >= (dcap ? dcap[d] : cap) || nv > HALO_RING) { atomicOr(&S.cnt[C_ERR], nv > HALO_RING ? ERR_CAP_RING : ERR_CAP_FLOES); continue; }
-      double* r = send + ((size_t)d * (cap + 1) + 1 + slot) * HALO_REC;
-      r[0] = (double)S.okey[q]; r[1] = (double)S.status[q]; r[2] = (double)nv; r[3] = cx; r[4] = cy; r[5] = S.rmax[q];
-      r[6] = S.area[q]; r[7] = S.height[q]; r[8] = S.u[q]; r[9] = S.v[q]; r[10] = S.xi[q]; r[11] = (double)S.id[q];
-      for (int k = 0; k < nv; k++) { r[12 + k] = S.vx[o + k]; r[12 + HALO_RING + k] = S.vy[o + k]; }
+      if (hit) hits |= 1ull << d;
     }
+    return hits;
+  };
+  double dmax = 0.0;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+    double cx = S.cx[q], cy = S.cy[q];
+    if (ref) {
+      double ddx = fabs(cx - ref[q]), ddy = fabs(cy - ref[S.capM + q]);
+      if (per_x && ddx > 0.5 * Lx) ddx = fabs(ddx - Lx);          // a parent the ghost pass wrapped around the domain
+      if (per_y && ddy > 0.5 * Ly) ddy = fabs(ddy - Ly);
+      if (2.0 * fmax(ddx, ddy) > margin) atomicOr(&S.cnt[C_ERR], ERR_HALO_DRIFT);
+      dmax = fmax(dmax, fmax(ddx, ddy));
+    }
+    unsigned long long hits = hits_of(cx, cy);
+    while (hits) { int d = __ffsll((long long)hits) - 1; hits &= hits - 1; atomicAdd(&lc[d], 1); }
   }
   if (ref && dmax > 0.0) atomicMax(&ldrift, __float_as_int((float)dmax * 1.0001f));      // (non-negative floats order like their bits)
   __syncthreads();
-  if (ref && threadIdx.x == 0) S.cnt[C_DRIFT] = ldrift;          // what the host sizes the next gather interval with
+  if ((int)threadIdx.x < nranks) base[threadIdx.x] = lc[threadIdx.x] ? atomicAdd(&run[threadIdx.x], lc[threadIdx.x]) : 0;
+  __syncthreads();
+  if (send)
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+      double cx = S.cx[q], cy = S.cy[q];
+      unsigned long long hits = hits_of(cx, cy);
+      int o = S.voff[q], nv = S.voff[q + 1] - o;
+      while (hits) {
+        int d = __ffsll((long long)hits) - 1; hits &= hits - 1;
+        int slot = base[d] + atomicAdd(&lc2[d], 1);
+        if (slot >= (dcap ? dcap[d] : cap) || nv > HALO_RING) { atomicOr(&S.cnt[C_ERR], nv > HALO_RING ? ERR_CAP_RING : ERR_CAP_FLOES); continue; }
+        double* r = send + ((size_t)d * (cap + 1) + 1 + slot) * HALO_REC;
+        r[0] = (double)S.okey[q]; r[1] = (double)S.status[q]; r[2] = (double)nv; r[3] = cx; r[4] = cy; r[5] = S.rmax[q];
+        r[6] = S.area[q]; r[7] = S.height[q]; r[8] = S.u[q]; r[9] = S.v[q]; r[10] = S.xi[q]; r[11] = (double)S.id[q];
+        for (int k = 0; k < nv; k++) { r[12 + k] = S.vx[o + k]; r[12 + HALO_RING + k] = S.vy[o + k]; }
+      }
+    }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (ref && ldrift) atomicMax(&run[65], ldrift);
+    __threadfence();
+    last = atomicAdd(&run[64], 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
   if ((int)threadIdx.x < nranks) {
     int d = threadIdx.x;
-    counts[d] = lc[d];
+    const int tot = atomicAdd(&run[d], 0);
+    run[d] = 0;
+    counts[d] = tot;
     const int room = dcap ? dcap[d] : cap;
-    if (send) send[(size_t)d * (cap + 1) * HALO_REC] = (double)(lc[d] < room ? lc[d] : room);
+    if (send) send[(size_t)d * (cap + 1) * HALO_REC] = (double)(tot < room ? tot : room);
+  }
+  if (threadIdx.x == 0) {
+    if (ref) S.cnt[C_DRIFT] = atomicAdd(&run[65], 0);          // what the host sizes the next gather interval with
+    run[65] = 0; run[64] = 0;
   }
 }
 // ---- fixed-layout exchange buffers: region of peer r = 1 header record (count in [0]) followed by
