@@ -265,7 +265,7 @@ def main():
         backend_note = None
 
         def make_tiles(be):
-            t = tiles.TiledWorld(cfg, rank, world, local, dist, always_exchange=args.force_tiled, backend=be, host_staging=args.rehearse_shared_gpu)
+            t = tiles.TiledWorld(cfg, rank, world, local, dist, always_exchange=args.force_tiled, backend=be, host_staging=args.rehearse_shared_gpu, rebox_every=150)
             t.repartition_every = 10 ** 9     # floes drift metres per step against tiles of hundreds of km: no re-tiling inside a bench run
             return t
         # the library-side exchange binds RCCL at run time: if any rank cannot set it up (no librccl to bind, communicator refused),

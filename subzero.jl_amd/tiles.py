@@ -157,9 +157,10 @@ class TiledWorld:
         max_rmax = float(cfg["derived"]["rmax"].max())          # over ALL floes, like max_ring
         self._max_ring, self._max_rmax = max_ring, max_rmax
         if drift_margin is None:
-            # metres an owned floe may move between two box gathers (half of it, strictly): a quarter of the largest floe radius keeps
-            # the extra halo small against the 2 x rmax interaction range and the gathers tens of steps apart at metres per step
-            drift_margin = max(2000.0, 0.25 * max_rmax)
+            # metres an owned floe may move between two box gathers (half of it, strictly): half the largest floe radius keeps the
+            # extra halo small against the 2 x rmax interaction range (+ 25 % of a strip that holds ~6 % of a tile's floes at 8 tiles
+            # of the 100 k field) and the gathers -- a handful of host synchronisations each -- a hundred steps apart at metres per step
+            drift_margin = max(2000.0, 0.5 * max_rmax)
         w._chk(w.L.sz_tile_enable(w.h, capi.ptr(g, capi._lp), max_ring, max_rmax))
         self.world = w
         self.REC = w.L.sz_halo_record_doubles()
