@@ -268,7 +268,10 @@ int sz_set_stream(sz_ctx *ctx, void *hip_stream);
                          (MPI broadcast, a file, ...)
      sz_comm_init        on every rank, collectively: the communicator of this context (nranks == 1: no RCCL needed)
      sz_tile_setup       after sz_upload_floes + sz_tile_enable: domain lengths and periodicity, the drift margin (metres a
-                         floe may move between two box gathers, on top of the interaction range) and the gather interval
+                         floe may move between two box gathers, on top of the interaction range) and the LONGEST gather
+                         interval: the library starts with 8 steps and sizes every following interval from the displacement
+                         it measured and the largest velocity now (30 % of the margin), at most doubling it.  rebox_every < 0:
+                         exactly every |rebox_every| steps, no adaptation (tests of the drift error)
      sz_tile_run         nsteps x timestep_sim! of the tiled run, collectively, same arguments on every rank.  Per step:
                          pack kernel, grouped ncclSend / ncclRecv with the neighbouring tiles only (real counts in the header
                          records, slots per pair sized at the last gather), forcings of the owned floes beside the exchange,

@@ -120,7 +120,7 @@ struct sz_ctx {
   hipStream_t comm_stream = nullptr; hipEvent_t ev_packed = nullptr, ev_recv = nullptr;
   Pool comm_allocs; double *d_send = nullptr, *d_recv = nullptr, *d_ref = nullptr, *d_gather = nullptr; int* d_dcap = nullptr;
   int halo_cap = 0; std::vector<int> cap_send, cap_recv;      // slots per peer region (stride) and what is really sent to / received from each peer
-  double tile_Lx = 0, tile_Ly = 0, tile_margin = 0; int tile_per_x = 0, tile_per_y = 0, tile_rebox_every = 50, tile_since_box = -1, tile_rebox_cur = 8;    // rebox_cur: the gather interval in use (<= rebox_every, from the measured drift)
+  double tile_Lx = 0, tile_Ly = 0, tile_margin = 0; int tile_per_x = 0, tile_per_y = 0, tile_rebox_every = 50, tile_since_box = -1, tile_rebox_cur = 8, tile_dt = 0; bool tile_rebox_fixed = false;    // rebox_cur: the gather interval in use (<= rebox_every, from the measured drift)
   Pool tw_part_allocs; double* d_tw_partial = nullptr;
   int tile_forcing_tstep = -1;      // timestep whose forcings sz_tile_forcing has already enqueued
   bool tile_dirty = false;      // ghosts / halo floes of the last sz_tile_step still appended
@@ -347,7 +347,7 @@ void world_rings(sz_ctx* c) {
   c->rings_stale = false;
 }
 // every call outside the resident steps: the candidate list they keep goes stale, the world rings must be current
-void leave_resident(sz_ctx* c) { c->gl_valid = false; world_rings(c); }
+void leave_resident(sz_ctx* c) { c->gl_valid = false; c->S.famrec = 0; world_rings(c); }
 
 // the candidate list of the coming step, seeded from the parents as they lie
 void use_ghost_list(sz_ctx* c) {
@@ -373,6 +373,7 @@ void stage_ghosts(sz_ctx* c, bool in_step = false, bool commit = false, bool use
   // the parents' count is the host's in resident single-context steps (nothing creates or removes floes there)
   const int nh = in_step && !S.tiled ? c->hostN : -1;
   if (!S.any_periodic_ew && !S.any_periodic_ns) return;
+  S.famrec = in_step ? 1 : 0;          // (process mode: ghosts the host uploaded may be present, which have no records)
   Timed t(c, SZ_K_GHOSTS);
   if (use_list) {
     const int waves = std::min(std::max(2 * c->gl_est + 64, 256), 8192);
@@ -889,7 +890,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   trim_pool(c->allocs);
   int h[C_COUNT + 64 + 72] = { 0 };
   h[C_M] = M; h[C_N] = N; h[C_NV] = V; h[C_NGHOSTS] = M - N; h[C_NOWN] = N;
-  S.tiled = 0;
+  S.tiled = 0; S.famrec = 0;
   H2D(S.cnt, h, C_COUNT + 64 + 72, int);
   hipLaunchKernelGGL(sz_k_osign, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0);
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1321,6 +1322,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   if (gl && !gi) use_ghost_list(c); else c->gl_valid = false;
   const int gl0 = c->gl_cur;
   c->S.ginline = gi ? 1 : 0;
+  if (gi) c->S.famrec = 1;
   if (c->gi_pending && c->gi_valid && !coll) { int rc = gi_fetch(c); if (rc) return rc; }      // (the key tables are about to be reused)
   c->gi_pending = false;
   if (coll) c->gi_valid = false;    // (this batch's rows replace the old ones; set again below if they carry order keys of inline ghosts)
@@ -1374,7 +1376,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     c->S.step = 0;
     if (coll && periodic) hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
     int rc = sync_and_check(c, h);
-    if (rc) { c->S.retry_stop = 0; c->S.body_rings = 0; c->S.ginline = 0; return rc; }
+    if (rc) { c->S.retry_stop = 0; c->S.body_rings = 0; c->S.ginline = 0; c->S.famrec = 0; return rc; }
     if (!lean || h[C_RETRYSTOP] == 0) break;
     // paused after the narrow launch of step h[C_RETRYSTOP]: that variant is in from now on
     c->retry_seen = true; lean = false;
@@ -1383,7 +1385,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     (void)hipMemsetAsync(c->S.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream);
   }
   c->S.retry_stop = 0;
-  c->S.ginline = 0;
+  c->S.ginline = 0; c->S.famrec = 0;
   if (body && nsteps > 0) c->rings_stale = true;
   c->S.body_rings = 0;
   if (coll) { c->inter_any = true; c->inter_lost = false; }
@@ -1784,25 +1786,33 @@ int tile_rebox(sz_ctx* c) {
   const int n = c->comm_n, me = c->comm_rank;
   int rc = sync_and_check(c); if (rc) return rc;
   hipLaunchKernelGGL(sz_k_owned_box, dim3(1), dim3(1024), 0, c->stream, S, c->d_gather);
-  std::vector<double> all((size_t)6 * n);
-  if ((rc = comm_allgather(c, c->d_gather, c->d_gather + 8, 6, NCCL_FLOAT64, sizeof(double)))) return rc;
+  constexpr int GB = 8;      // doubles per rank in the gather: box, rmax, drift, speed, (spare)
+  std::vector<double> all((size_t)GB * n);
+  if ((rc = comm_allgather(c, c->d_gather, c->d_gather + 8, GB, NCCL_FLOAT64, sizeof(double)))) return rc;
   HIPCHK(c, hipMemcpyAsync(all.data(), c->d_gather + 8, all.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  double rmax = 0.0, drift = 0.0;
-  for (int r = 0; r < n; r++) { rmax = std::max(rmax, all[6 * r + 4]); drift = std::max(drift, all[6 * r + 5]); }
-  // the gather interval follows the measured speed (every rank computes the same number): the floes may use 30 % of the margin
-  // before the next gather, half of it is the error threshold; a new setup starts with a short interval
-  if (c->tile_since_box > 0)
-    c->tile_rebox_cur = drift > 0.0 ? (int)std::max(1.0, std::min((double)c->tile_rebox_every, 0.3 * c->tile_margin / (drift / c->tile_since_box))) : c->tile_rebox_every;
+  double rmax = 0.0, drift = 0.0, speed = 0.0;
+  for (int r = 0; r < n; r++) { rmax = std::max(rmax, all[GB * r + 4]); drift = std::max(drift, all[GB * r + 5]); speed = std::max(speed, all[GB * r + 6]); }
+  // the gather interval follows the floes (every rank computes the same number): at the faster of the measured displacement per step since
+  // the last gather and the largest velocity component now, they may use 30 % of the margin before the next gather (half of it is the
+  // error threshold); the interval at most doubles from one gather to the next, and a new setup starts with a short one -- floes that
+  // start from rest are slower in their first steps than later
+  {
+    const double per_step = std::max(c->tile_since_box > 0 ? drift / c->tile_since_box : 0.0, speed * std::fabs((double)c->tile_dt));
+    int want = per_step > 0.0 ? (int)std::max(1.0, std::min((double)c->tile_rebox_every, 0.3 * c->tile_margin / per_step)) : c->tile_rebox_every;
+    if (c->tile_since_box > 0) want = std::min(want, 2 * c->tile_rebox_cur);
+    else want = std::min(want, c->tile_rebox_cur);
+    c->tile_rebox_cur = c->tile_rebox_fixed ? c->tile_rebox_every : std::max(1, want);
+  }
   const double reach = 2.0 * rmax + c->tile_margin;
   std::vector<double> boxes((size_t)4 * n);
-  for (int r = 0; r < n; r++) { boxes[4 * r] = all[6 * r] - reach; boxes[4 * r + 1] = all[6 * r + 1] + reach; boxes[4 * r + 2] = all[6 * r + 2] - reach; boxes[4 * r + 3] = all[6 * r + 3] + reach; }
+  for (int r = 0; r < n; r++) { boxes[4 * r] = all[GB * r] - reach; boxes[4 * r + 1] = all[GB * r + 1] + reach; boxes[4 * r + 2] = all[GB * r + 2] - reach; boxes[4 * r + 3] = all[GB * r + 3] + reach; }
   HIPCHK(c, hipMemcpyAsync(S.bounds + 16, boxes.data(), boxes.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
   // counting pass, then the count matrix of all ranks (row s: what s sends to every d)
   int* dcnt = S.cnt + C_COUNT;
   hipLaunchKernelGGL(sz_k_halo_pack, dim3(grid_for(std::max(c->hostN, 1), PACK_TPB)), dim3(PACK_TPB), 0, c->stream, S, n, me, S.bounds + 16, c->tile_Lx, c->tile_Ly, c->tile_per_x,
                      c->tile_per_y, (double*)nullptr, 1, dcnt, (const int*)nullptr, (const double*)nullptr, 0.0);
-  int* d_mat = (int*)(c->d_gather + 8 + 6 * 64);
+  int* d_mat = (int*)(c->d_gather + 8 + GB * 64);
   std::vector<int> mat((size_t)n * n);
   if ((rc = comm_allgather(c, dcnt, d_mat, (size_t)n, NCCL_INT32, sizeof(int)))) return rc;
   HIPCHK(c, hipMemcpyAsync(mat.data(), d_mat, mat.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1813,7 +1823,7 @@ int tile_rebox(sz_ctx* c) {
   for (int s = 0; s < n; s++)
     for (int d = 0; d < n; d++) {
       if (s == d) continue;
-      const bool adj = tiles_adjacent(&all[6 * s], &boxes[4 * d], c->tile_margin, c->tile_Lx, c->tile_Ly, c->tile_per_x, c->tile_per_y);
+      const bool adj = tiles_adjacent(&all[GB * s], &boxes[4 * d], c->tile_margin, c->tile_Lx, c->tile_Ly, c->tile_per_x, c->tile_per_y);
       const int k = adj || mat[(size_t)s * n + d] > 0 ? mat[(size_t)s * n + d] * 3 / 2 + 32 : 0;
       if (s == me) c->cap_send[d] = k;
       if (d == me) c->cap_recv[s] = k;
@@ -1938,16 +1948,16 @@ int sz_comm_allreduce(sz_ctx* c, void* d_buf, int64_t n) {
   return SZ_OK;
 }
 int sz_tile_setup(sz_ctx* c, double Lx, double Ly, int32_t per_x, int32_t per_y, double drift_margin, int32_t rebox_every) {
-  if (!c || !c->have_floes || !c->S.tiled || c->comm_n < 1 || !(drift_margin > 0) || rebox_every < 1) {
+  if (!c || !c->have_floes || !c->S.tiled || c->comm_n < 1 || !(drift_margin > 0) || rebox_every == 0) {
     if (c) c->err = "sz_tile_setup needs sz_upload_floes, sz_tile_enable and sz_comm_init first, a positive drift margin and rebox interval";
     return SZ_E_STATE;
   }
   (void)hipSetDevice(c->device);
-  c->tile_Lx = Lx; c->tile_Ly = Ly; c->tile_per_x = per_x; c->tile_per_y = per_y; c->tile_margin = drift_margin; c->tile_rebox_every = rebox_every;
-  c->tile_since_box = -1; c->halo_cap = 0; c->d_send = nullptr; c->tile_rebox_cur = std::min(rebox_every, 8);
+  c->tile_Lx = Lx; c->tile_Ly = Ly; c->tile_per_x = per_x; c->tile_per_y = per_y; c->tile_margin = drift_margin; c->tile_rebox_every = std::abs(rebox_every); c->tile_rebox_fixed = rebox_every < 0;
+  c->tile_since_box = -1; c->halo_cap = 0; c->d_send = nullptr; c->tile_rebox_cur = rebox_every < 0 ? -rebox_every : std::min(rebox_every, 8);
   free_pool(c->comm_allocs);
   if (!c->d_gather) {          // own box | all boxes | count matrix (ints): lives as long as the communicator
-    HIPCHK(c, hipMalloc((void**)&c->d_gather, (8 + 6 * 64 + 64 * 64 / 2 + 64) * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&c->d_gather, (8 + 8 * 64 + 64 * 64 / 2 + 64) * sizeof(double)));
   }
   return SZ_OK;
 }
@@ -1959,6 +1969,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   const int n = c->comm_n, me = c->comm_rank;
   for (int s = 0; s < nsteps; s++) {
     const int tstep = tstep0 + s;
+    c->tile_dt = dt;
     if (c->tile_since_box < 0 || c->tile_since_box >= c->tile_rebox_cur) { int rc = tile_rebox(c); if (rc) return rc; }
     c->tile_since_box++;
     const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;

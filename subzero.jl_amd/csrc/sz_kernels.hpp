@@ -438,7 +438,9 @@ __device__ __forceinline__ void ghost_fill_parent(State& S, const GridGeo& geo, 
                        lane == 5 ? S.alpha : lane == 6 ? S.u : lane == 7 ? S.v : lane == 8 ? S.xi : S.overarea;
   const double dval = lane < 10 ? dcol[i] : 0.0;
   const long long idv = S.id[i]; const int stv = S.status[i]; const signed char osv = S.osign[i];
-  const long long oki = S.tiled ? S.okey[i] : 0;
+  const long long okp = S.okey[i];
+  const long long oki = S.tiled ? okp : 0;
+  State::Fam* const F = S.fam + i;            // the family record of the Dict rule (pair_allowed_fam), as the inline ghost maker leaves it
   if (ngh_old != 0) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_GHOSTS_PER_PARENT); return; }
   if (n > (WIDE ? 128 : 64)) { if (lane == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); return; }
   // ---- the two passes, in registers; a ghost is stored as soon as nothing is derived from it any more (at most two
@@ -459,6 +461,7 @@ __device__ __forceinline__ void ghost_fill_parent(State& S, const GridGeo& geo, 
       if (lane == 15) rec32_store(S, g, gcx, gcy, rmx, g0, g1, g2, g3);
     }
     if (bin && lane == 14) cell_insert(S, geo, g, gcx, gcy);
+    if (lane == 16) { F->key[gid] = key; F->gid[gid] = (long long)gid; F->cx[gid] = gcx; F->cy[gid] = gcy; }
     if (lane < MAX_GHOSTS) S.gh[g * MAX_GHOSTS + lane] = -1;
   };
   int s0 = 0, s1 = 0, s2 = 0;
@@ -506,6 +509,10 @@ __device__ __forceinline__ void ghost_fill_parent(State& S, const GridGeo& geo, 
   }
   if (lane < MAX_GHOSTS) S.gh[i * MAX_GHOSTS + lane] = lane < ng ? (lane == 0 ? s0 : lane == 1 ? s1 : s2) : -1;
   if (lane == 0) S.ngh[i] = ng;
+  {
+    const double pcx = __shfl(P.pv, 0), pcy = __shfl(P.pv, 1);      // the parent where it now lies
+    if (lane == 16) { F->key[0] = okp; F->gid[0] = 0; F->cx[0] = pcx; F->cy[0] = pcy; F->r = S.rmax[i]; F->n = ng + 1; }
+  }
 }
 
 // gscan4 holds the exclusive int4 scan of gplan, gtot4[0] the totals
@@ -1220,7 +1227,7 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
       // the Dict rule only bites when one of the two floes has periodic images
       if (!(kplain && oplain)) {
         bool ok;
-        if (FAM && S.ginline) {           // (inline ghosts leave a record per family: a floe that is a ghost, or has ghosts, has one at its parent)
+        if (FAM && S.famrec) {           // (inline ghosts leave a record per family: a floe that is a ghost, or has ghosts, has one at its parent)
           const int kp = kpar, op = opar;
           const long long gk = kgid, go = S.ghost_id[o];
           ok = after ? pair_allowed_fam(S, kp, op, !kplain, !oplain, okk, gk, ckx, cky, rk, ko, go, ocx, ocy, orm)
@@ -2700,26 +2707,27 @@ __global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* 
   }
 }
 // bounding box of the owned centroids and the largest rmax: out[0..4] = xmin, xmax, ymin, ymax, rmax; out[5] = the largest
-// displacement since the last box gather as the last pack kernel measured it (C_DRIFT)
+// displacement since the last box gather as the last pack kernel measured it (C_DRIFT); out[6] = the largest |u|, |v| now
 __global__ void __launch_bounds__(1024) sz_k_owned_box(State S, double* out) {
-  __shared__ double sh[5][16];
+  __shared__ double sh[6][16];
   int n = S.cnt[C_NOWN];
-  double x0 = __builtin_inf(), y0 = __builtin_inf(), x1 = -__builtin_inf(), y1 = -__builtin_inf(), rm = 0.0;
+  double x0 = __builtin_inf(), y0 = __builtin_inf(), x1 = -__builtin_inf(), y1 = -__builtin_inf(), rm = 0.0, vm = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     x0 = fmin(x0, S.cx[i]); x1 = fmax(x1, S.cx[i]); y0 = fmin(y0, S.cy[i]); y1 = fmax(y1, S.cy[i]); rm = fmax(rm, S.rmax[i]);
+    vm = fmax(vm, fmax(fabs(S.u[i]), fabs(S.v[i])));
   }
   for (int d = 32; d >= 1; d >>= 1) {
     x0 = fmin(x0, __shfl_xor(x0, d)); y0 = fmin(y0, __shfl_xor(y0, d));
-    x1 = fmax(x1, __shfl_xor(x1, d)); y1 = fmax(y1, __shfl_xor(y1, d)); rm = fmax(rm, __shfl_xor(rm, d));
+    x1 = fmax(x1, __shfl_xor(x1, d)); y1 = fmax(y1, __shfl_xor(y1, d)); rm = fmax(rm, __shfl_xor(rm, d)); vm = fmax(vm, __shfl_xor(vm, d));
   }
   int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (lane == 0) { sh[0][wid] = x0; sh[1][wid] = y0; sh[2][wid] = x1; sh[3][wid] = y1; sh[4][wid] = rm; }
+  if (lane == 0) { sh[0][wid] = x0; sh[1][wid] = y0; sh[2][wid] = x1; sh[3][wid] = y1; sh[4][wid] = rm; sh[5][wid] = vm; }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
-      x0 = fmin(x0, sh[0][w]); y0 = fmin(y0, sh[1][w]); x1 = fmax(x1, sh[2][w]); y1 = fmax(y1, sh[3][w]); rm = fmax(rm, sh[4][w]);
+      x0 = fmin(x0, sh[0][w]); y0 = fmin(y0, sh[1][w]); x1 = fmax(x1, sh[2][w]); y1 = fmax(y1, sh[3][w]); rm = fmax(rm, sh[4][w]); vm = fmax(vm, sh[5][w]);
     }
-    out[0] = x0; out[1] = x1; out[2] = y0; out[3] = y1; out[4] = rm; out[5] = (double)__int_as_float(S.cnt[C_DRIFT]);
+    out[0] = x0; out[1] = x1; out[2] = y0; out[3] = y1; out[4] = rm; out[5] = (double)__int_as_float(S.cnt[C_DRIFT]); out[6] = vm;
   }
 }
 

@@ -124,6 +124,7 @@ struct State {
   Fam* fam;
   unsigned long long* galloc; long long* gkeys;
   int ginline, gslot;         // inline ghosts on; the allocator holding the ghosts of the step being launched
+  int famrec;                 // every ghost present was made inside a step by a maker that leaves the family records (State::Fam): the Dict rule reads them
   int4* gcand;                // two lists of capM entries {parent, ghost flags, ring points, -}: the parents that get ghosts in the next
                               // step, appended by whoever places a floe (integrator, halo unpack) -- see sz_k_ghost_list
   int4 *lb_agg, *lb_inc; unsigned* lb_flag;   // decoupled look-back scan: per workgroup aggregate, inclusive prefix, (epoch << 2 | status)

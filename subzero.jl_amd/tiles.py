@@ -184,8 +184,10 @@ class TiledWorld:
         elif not host_staging:
             # kernels and RCCL collectives are ordered by ONE stream: no host sync inside a step
             w._chk(w.L.sz_set_stream(w.h, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
-        self.margin, self.rebox_every = drift_margin, rebox_every
-        self.rebox_every_max = rebox_every
+        self.margin, self.rebox_every = drift_margin, min(abs(rebox_every), 8)
+        self._dt = 0
+        self.rebox_every_max = abs(rebox_every)
+        self._rebox_arg = rebox_every
         self._ref = None                                      # owned centroids at the last box gather (drift check)
         self.repartition_every = 500                          # steps between ownership checks (run())
         self.repartition_fraction = 0.1                       # ... re-tile when this share of the floes has left its tile
@@ -210,14 +212,19 @@ class TiledWorld:
             if self.per_x: dx = np.minimum(dx, np.abs(dx - self.L))       # a parent the ghost pass wrapped around
             if self.per_y: dy = np.minimum(dy, np.abs(dy - self.L))
             d = float(max(dx.max(), dy.max()))
-        t = self.torch.tensor([d], dtype=self.torch.float64, device="cpu" if self.host_staging else self.dev)
+        vmax = float(max(np.abs(w.get("u")[:n]).max(), np.abs(w.get("v")[:n]).max())) if n else 0.0
+        t = self.torch.tensor([d, vmax], dtype=self.torch.float64, device="cpu" if self.host_staging else self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        d = float(t.item())
+        d, vmax = float(t[0].item()), float(t[1].item())
         if 2.0 * d > self.margin:
             raise capi.SzError(f"halo drift: a floe moved {d:.1f} m in {self.steps_since_box} steps, the margin is {self.margin:.1f} m "
                                f"(gather the boxes more often or widen the margin)")
-        if d > 0 and self.steps_since_box > 0:
-            self.rebox_every = int(max(1, min(self.rebox_every_max, 0.4 * self.margin / (d / self.steps_since_box))))
+        # the faster of the measured displacement per step and the largest velocity component now may use 30 % of the margin before the
+        # next gather; the interval at most doubles from one gather to the next (floes that start from rest speed up)
+        per_step = max(d / self.steps_since_box if self.steps_since_box > 0 else 0.0, vmax * abs(self._dt))
+        if per_step > 0:
+            self.rebox_every = int(max(1, min(self.rebox_every_max, 2 * self.rebox_every if self.steps_since_box > 0 else self.rebox_every,
+                                              0.3 * self.margin / per_step)))
         self._ref = (cx, cy)
 
     def _allgather_boxes(self):
@@ -276,6 +283,7 @@ class TiledWorld:
 
     def step(self, tstep, dt, coupling_dt=10, collisions_on=True, coupling_on=True):
         w = self.world
+        self._dt = dt
         flags = (capi.COLLISIONS_ON if collisions_on else 0) | (capi.COUPLING_ON if coupling_on else 0)
         peers = self.nranks > 1 or self.always_exchange
         if peers:
@@ -403,7 +411,7 @@ class TiledWorld:
         g = np.ascontiguousarray(self.gidx, np.int64)
         w._chk(w.L.sz_tile_enable(w.h, capi.ptr(g, capi._lp), self._max_ring, self._max_rmax))
         if self.backend in ("library", "library-host"):
-            w._chk(w.L.sz_tile_setup(w.h, self.L, self.L, int(self.per_x), int(self.per_y), float(self.margin), int(self.rebox_every_max)))
+            w._chk(w.L.sz_tile_setup(w.h, self.L, self.L, int(self.per_x), int(self.per_y), float(self.margin), int(self._rebox_arg)))
         self.boxes = None                      # owned boxes and halo capacity are re-established at the next exchange
         self._ref = None
         return len(mv)

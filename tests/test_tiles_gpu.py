@@ -217,13 +217,16 @@ def test_halo_drift_is_an_error_not_a_missed_contact():
     from subzero_jl_amd.capi import SzError
     cfg = fields.make_config(n_floes=400, seed=52)
     cfg["u"] = np.abs(cfg["u"]) * 40.0 + 4.0                     # 4 .. 8 m/s: 80 .. 160 m per step
-    tw = tiles.TiledWorld(cfg, 0, 1, 0, None, backend="library", drift_margin=1500.0, rebox_every=50)
+    tw = tiles.TiledWorld(cfg, 0, 1, 0, None, backend="library", drift_margin=1500.0, rebox_every=-50)     # (< 0: a FIXED interval)
     tw.run(4, 0, cfg["dt"], coupling_dt=1)                       # 4 steps: at most 640 m, 2 x 640 < 1500
     with pytest.raises(SzError, match="halo-drift"):
         tw.run(30, 4, cfg["dt"], coupling_dt=1)
     # a gather interval that fits the speed is fine
-    tw2 = tiles.TiledWorld(cfg, 0, 1, 0, None, backend="library", drift_margin=1500.0, rebox_every=3)
+    tw2 = tiles.TiledWorld(cfg, 0, 1, 0, None, backend="library", drift_margin=1500.0, rebox_every=-3)
     tw2.run(30, 0, cfg["dt"], coupling_dt=1)
+    # and left to itself the library finds one: the interval follows the measured displacement and the velocities
+    tw3 = tiles.TiledWorld(cfg, 0, 1, 0, None, backend="library", drift_margin=1500.0, rebox_every=50)
+    tw3.run(60, 0, cfg["dt"], coupling_dt=1)
 
 
 def test_rccl_binding_self_test():
