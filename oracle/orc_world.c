@@ -749,6 +749,18 @@ static void ghosts_on_bounds(orc_world *w, int elem, const bound_t *b, double tx
   orc_intersection(&w->f[elem].poly, &b->poly, &rg);
   int nonempty = rg.n > 0;
   orc_regions_free(&rg);
+  /* A floe that only TOUCHES the wall has no ghost: the reference's own case is the triangle whose edges lie on the west and
+     south walls (test_collisions.jl:282-283, "no ghosts").  The boundary polygon is the half plane beyond the wall as far as a
+     floe is concerned, so a region of positive area needs a vertex strictly beyond the wall; without that test the restated
+     clipper can return a sliver of round-off area for collinear edges at a wall coordinate like 1.5e5 (Voronoi cells cut at the
+     walls: tests/test_hip_parity.py::test_voronoi_field_touching_cells). */
+  if (nonempty) {
+    const orc_ring *r = &w->f[elem].poly;
+    int beyond = 0;
+    for (int k = 0; k < r->n && !beyond; k++)
+      beyond = tx > 0 ? r->p[k].x < b->val : tx < 0 ? r->p[k].x > b->val : ty > 0 ? r->p[k].y < b->val : r->p[k].y > b->val;
+    nonempty = beyond;
+  }
   if (!nonempty) return;
   int ng = w->f[elem].nghosts;
   for (int k = 0; k < ng; k++) {

@@ -56,7 +56,8 @@ struct sz_ctx {
   Pool allocs;        // per-upload allocations
   Pool inter_allocs;  // floe.interactions (inter_cnt, inter_rows): survive an upload of the same size -- a shim uploads between
                       // timestep_collisions! and timestep_floe_properties!, and calc_stress! reads the rows of the collisions
-  int inter_capM = 0; bool inter_any = false, inter_lost = false;
+  int inter_capM = 0, inter_rowcap = 0; bool inter_any = false, inter_lost = false;
+  int nb_count_max = 0;             // bounding-circle neighbours of the most crowded floe at upload (inflated circles): sizes State::maxnb
   Pool static_allocs; // domain element table
   Pool field_allocs;  // ocean / atmosphere lattices
   bool have_floes = false, have_domain = false, have_fields = false;
@@ -405,8 +406,17 @@ void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false
     if (c->precision == 1) hipLaunchKernelGGL(sz_k_neighbors_forcing<2>, dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn);
     else hipLaunchKernelGGL(sz_k_neighbors_forcing<1>, dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn);
   } else
-    if (c->hostN <= 40000) hipLaunchKernelGGL(sz_k_neighbors<true>, dim3(grid_for(S.capM, NB_TPB / NB_G, 8192)), dim3(NB_TPB), 0, c->stream, S);
-    else hipLaunchKernelGGL(sz_k_neighbors<false>, dim3(grid_for(S.capM, NB_TPB / NB_G, 8192)), dim3(NB_TPB), 0, c->stream, S);
+  {
+    const dim3 gr(grid_for(S.capM, NB_TPB / NB_G, 8192)), bl(NB_TPB);
+    const bool fam = c->hostN <= 40000;
+    if (S.maxnb <= MAXNB) {
+      if (fam) hipLaunchKernelGGL((sz_k_neighbors<true, MAXNB>), gr, bl, 0, c->stream, S);
+      else hipLaunchKernelGGL((sz_k_neighbors<false, MAXNB>), gr, bl, 0, c->stream, S);
+    } else {
+      if (fam) hipLaunchKernelGGL((sz_k_neighbors<true, 64>), gr, bl, 0, c->stream, S);
+      else hipLaunchKernelGGL((sz_k_neighbors<false, 64>), gr, bl, 0, c->stream, S);
+    }
+  }
   t.end();
 }
 
@@ -644,6 +654,7 @@ int host_fuse_fixup(sz_ctx* c, const int* h, bool mirror, bool after_step = fals
   if ((int)c->fuse_lists.size() < M) c->fuse_lists.resize(M);
   if (h[C_NFUSE] == 0 || M == 0) return SZ_OK;          // no pair asked for a fuse (the narrow phase counts them)
   // the pairs in the reference's serial order (i asc, j asc): per floe its sorted list of owned pairs
+  const int MAXNB = S.maxnb;
   std::vector<int> nout(M), nbo((size_t)M * MAXNB); std::vector<int2> info((size_t)M * MAXNB);
   HIPCHK(c, hipMemcpy(nout.data(), S.n_out, (size_t)M * sizeof(int), hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(nbo.data(), S.nb_out, (size_t)M * MAXNB * sizeof(int), hipMemcpyDeviceToHost));
@@ -804,6 +815,63 @@ int sz_set_fields(sz_ctx* c, int32_t Nx, int32_t Ny, double x0, double xf, doubl
   return SZ_OK;
 }
 
+namespace {
+// The largest number of bounding-circle neighbours a floe of the uploaded field has (periodic images included), with the circles
+// inflated by 25 % so that the count still holds after the field has compacted somewhat: the neighbour lists of the device are sized from
+// it (State::maxnb).  window_max: the most floes any 3 x 3 cell window holds (cells a little larger than the device's): the pool of the
+// neighbour search's fast variant holds 96.  Fields of like-sized floes stay below 24; a field with a size spectrum -- the reference's Voronoi fields: a large
+// cell among small ones -- does not, and the reference's own lists grow as needed (collisions.jl:290-296).  O(M) with a uniform grid.
+int host_max_neighbours(const sz_ctx* c, const sz_floe_columns* f, int M, int* window_max) {
+  *window_max = 0;
+  if (!f->rmax || M < 2) return 0;
+  double rm = 0.0;
+  for (int i = 0; i < M; i++) rm = std::max(rm, f->rmax[i]);
+  if (!(rm > 0.0)) return 0;
+  const bool px = c->h_kinds[SZ_EAST] == SZ_PERIODIC && c->h_kinds[SZ_WEST] == SZ_PERIODIC;
+  const bool py = c->h_kinds[SZ_NORTH] == SZ_PERIODIC && c->h_kinds[SZ_SOUTH] == SZ_PERIODIC;
+  double x0 = c->h_vals[3], xf = c->h_vals[2], y0 = c->h_vals[1], yf = c->h_vals[0];     // W, E, S, N
+  double bx0 = f->cx[0], bx1 = f->cx[0], by0 = f->cy[0], by1 = f->cy[0];
+  for (int i = 1; i < M; i++) { bx0 = std::min(bx0, f->cx[i]); bx1 = std::max(bx1, f->cx[i]); by0 = std::min(by0, f->cy[i]); by1 = std::max(by1, f->cy[i]); }
+  if (!px || !(xf > x0)) { x0 = bx0; xf = bx1 + 1e-9 * std::max(1.0, std::fabs(bx1)); }
+  if (!py || !(yf > y0)) { y0 = by0; yf = by1 + 1e-9 * std::max(1.0, std::fabs(by1)); }
+  const double Lx = std::max(xf - x0, 1e-300), Ly = std::max(yf - y0, 1e-300), cs = 2.5 * rm;
+  const int nx = (int)std::max(1.0, std::min(2048.0, std::floor(Lx / cs))), ny = (int)std::max(1.0, std::min(2048.0, std::floor(Ly / cs)));
+  auto wrap = [](double v, double lo, double L) { v = std::fmod(v - lo, L); return v < 0 ? v + L : v; };
+  auto cell1 = [&](double v, double lo, double L, int n, bool per) { const double t = per ? wrap(v, lo, L) : v - lo; return std::max(0, std::min(n - 1, (int)(t / L * n))); };
+  std::vector<int> head((size_t)nx * ny, -1), next(M), cxi(M), cyi(M);
+  for (int i = 0; i < M; i++) {
+    cxi[i] = cell1(f->cx[i], x0, Lx, nx, px); cyi[i] = cell1(f->cy[i], y0, Ly, ny, py);
+    const size_t cidx = (size_t)cyi[i] * nx + cxi[i]; next[i] = head[cidx]; head[cidx] = i;
+  }
+  int best = 0;
+  for (int i = 0; i < M; i++) {
+    int cnt = 0, seen[9], ns = 0, win = 0;
+    for (int oy = -1; oy <= 1; oy++)
+      for (int ox = -1; ox <= 1; ox++) {
+        int ax = cxi[i] + ox, ay = cyi[i] + oy;
+        if (px) ax = (ax % nx + nx) % nx; else if (ax < 0 || ax >= nx) continue;
+        if (py) ay = (ay % ny + ny) % ny; else if (ay < 0 || ay >= ny) continue;
+        const int cidx = ay * nx + ax;
+        bool dup = false;
+        for (int q = 0; q < ns; q++) dup |= seen[q] == cidx;
+        if (dup) continue;
+        seen[ns++] = cidx;
+        for (int j = head[cidx]; j >= 0; j = next[j]) {
+          win++;
+          if (j == i) continue;
+          double dx = f->cx[i] - f->cx[j], dy = f->cy[i] - f->cy[j];
+          if (px) dx -= Lx * std::nearbyint(dx / Lx);
+          if (py) dy -= Ly * std::nearbyint(dy / Ly);
+          const double rr = 1.25 * (f->rmax[i] + f->rmax[j]);
+          cnt += (dx * dx + dy * dy) < rr * rr;
+        }
+      }
+    best = std::max(best, cnt); *window_max = std::max(*window_max, win);
+  }
+  return best;
+}
+}  // namespace
+
 int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* f) {
   if (!c || !f || M64 < 0 || N64 < 0 || N64 > M64 || !f->vert_off || !f->vx || !f->vy || !f->cx || !f->cy) return SZ_E_ARG;
   if (!c->have_domain) { c->err = "sz_set_domain must be called before sz_upload_floes"; return SZ_E_STATE; }
@@ -819,7 +887,13 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   c->max_ring = 0;
   for (int i = 0; i < M; i++) c->max_ring = std::max(c->max_ring, f->vert_off[i + 1] - f->vert_off[i]);
   const int NS = f->sub_off ? f->sub_off[N] : 0;
-  S.capM = 2 * M + 64; S.capV = 2 * V + 4096; S.capPairs = S.capM * 8; S.capElem = S.capM * 4;
+  // neighbour and row capacities from the field itself: like-sized floes 24 / 32, a size spectrum 64 / 128 (SZ_MAXNB=24|64 overrides)
+  int window_max = 0;
+  c->nb_count_max = host_max_neighbours(c, f, M, &window_max);
+  S.maxnb = c->nb_count_max + 2 <= MAXNB && window_max <= 80 ? MAXNB : 64;
+  if (const char* e = getenv("SZ_MAXNB")) S.maxnb = atoi(e) > MAXNB ? 64 : MAXNB;
+  S.rowcap = S.maxnb <= MAXNB ? ROWCAP : 128;
+  S.capM = 2 * M + 64; S.capV = 2 * V + 4096; S.capPairs = S.capM * (S.maxnb <= MAXNB ? 8 : 16); S.capElem = S.capM * 4;
   S.capRows = S.capPairs * 3 + S.capElem * 2; S.capCells = 4 * S.capM + 64; S.capS = NS;
   int rc;
 #define DA(field, n) if ((rc = dalloc(c, &S.field, (size_t)(n), c->allocs))) return rc
@@ -868,21 +942,21 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2); DA(gcand, (size_t)2 * S.capM); DA(galloc, 32); DA(gkeys, (size_t)2 * S.capM); DA(fam, S.capM);
   DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1); DA(cell_ovf, S.capCells + 1); DA(cell_slots, (size_t)S.capCells * CELL_K + 8);
   DA(cell_items, S.capM);
-  DA(nb_out, (size_t)S.capM * MAXNB); DA(nb_in, (size_t)S.capM * MAXNB); DA(n_out, S.capM + 1); DA(n_in, S.capM + 1);
+  DA(nb_out, (size_t)S.capM * S.maxnb); DA(nb_in, (size_t)S.capM * S.maxnb); DA(n_out, S.capM + 1); DA(n_in, S.capM + 1);
   DA(out_off, S.capM + 2); DA(out_mask, S.capM + 1); DA(work, 2 * ((size_t)S.capPairs + NSEG)); DA(wq, NSEG * 32); DA(pair_i, S.capPairs); DA(pair_j, S.capPairs);
   DA(el_off, S.capM + 2); DA(el_floe, S.capElem); DA(el_elem, S.capElem);
   size_t items = (size_t)S.capPairs + S.capElem;
-  DA(it_rows, items * ROWS_PER_ITEM * 5); DA(it_info, (size_t)S.capM * MAXNB + S.capElem + 1);
+  DA(it_rows, items * ROWS_PER_ITEM * 5); DA(it_info, (size_t)S.capM * S.maxnb + S.capElem + 1);
   DA(inter_off, S.capM + 2);
   // floe.interactions is part of the floe state, but not of sz_floe_columns (it is ragged): the rows the last
   // collision call left stay valid across an upload of the same size; after an upload of another size they are
   // gone, and sz_timestep_floe_properties / sz_calc_stress refuse to run on nothing (SZ_E_STATE) until
   // sz_upload_interactions or a collision call provides them again
-  if (c->inter_capM != S.capM || c->inter_allocs.empty()) {
+  if (c->inter_capM != S.capM || c->inter_rowcap != S.rowcap || c->inter_allocs.empty()) {
     free_pool(c->inter_allocs);
     if ((rc = dalloc(c, &S.inter_cnt, (size_t)S.capM + 1, c->inter_allocs))) return rc;
-    if ((rc = dalloc(c, &S.inter_rows, (size_t)S.capM * ROWCAP * 7, c->inter_allocs))) return rc;
-    c->inter_capM = S.capM; c->inter_lost = c->inter_any; c->inter_any = false;
+    if ((rc = dalloc(c, &S.inter_rows, (size_t)S.capM * S.rowcap * 7, c->inter_allocs))) return rc;
+    c->inter_capM = S.capM; c->inter_rowcap = S.rowcap; c->inter_lost = c->inter_any; c->inter_any = false;
   }
   DA(blk, std::max(S.capCells, std::max(S.capM, 1024)) / SCAN_B + 1024);
   DA(tagA, S.capM + 1);
@@ -1264,6 +1338,7 @@ int sz_upload_interactions(sz_ctx* c, const int32_t* off, const double* rows) {
     return SZ_OK;
   }
   if (!rows) return SZ_E_ARG;
+  const int ROWCAP = S.rowcap;
   std::vector<int> cnt(M); std::vector<double> buf((size_t)M * ROWCAP * 7, 0.0);
   for (int i = 0; i < M; i++) {
     int k = off[i + 1] - off[i];
@@ -1357,7 +1432,8 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
       // (riding in the neighbour launch pays while both kernels leave the chip idle: measured better up to 40 k floes,
       // neutral at 100 k dense, worse at 100 k sparse -- there the forcings get their own launch)
       const bool fuse = coupling && !overlap && coll && !c->two_way && !(c->pmask >> SZ_K_FORCING & 1u) && c->fuse_forcing && c->hostN <= 65536;
-      const int fmode = !fuse ? 0 : c->fuse_forcing_mode ? c->fuse_forcing_mode : (c->hostN <= 30000 ? 2 : 1);
+      int fmode = !fuse ? 0 : c->fuse_forcing_mode ? c->fuse_forcing_mode : (c->hostN <= 30000 ? 2 : 1);
+      if (fmode == 1 && c->S.maxnb > MAXNB) fmode = 2;      // (the neighbour + forcing launch exists for the default neighbour capacity only)
       if (!resume) {          // (a paused step has all of this behind it)
         if (coll && !gi) stage_ghosts(c, true, sg, gl);
         // (after the ghost pass, like the reference's timestep_coupling!: a parent that has just swapped with its ghost is sampled where it

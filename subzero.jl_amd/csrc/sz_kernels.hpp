@@ -12,6 +12,7 @@
 //   tiles     sz_k_halo_pack / sz_k_halo_unpack                           ghost-floe halo of a tiled (multi-GPU) run
 // All of it is HBM/latency-bound integer + fp64 vector work: no MFMA anywhere.
 #pragma once
+#include <type_traits>
 #include "sz_geom.hpp"
 #include "sz_state.hpp"
 
@@ -1105,7 +1106,7 @@ __device__ __forceinline__ Item item_of(const State& S, const Seg& g, int t) {
     const int4 k = S.work[2 * (size_t)w], r = S.work[2 * (size_t)w + 1];
     it.info = k.x; it.i = k.y; it.j = k.z; it.e = -1; it.rows = w; it.ao = k.w; it.na = r.x; it.bo = r.y; it.nb = r.z;
   } else {
-    const int q = (t - g.np) * NSEG + g.s; it.i = S.el_floe[q]; it.e = S.el_elem[q]; it.j = -1; it.rows = S.capPairs + q; it.info = S.capM * MAXNB + q;
+    const int q = (t - g.np) * NSEG + g.s; it.i = S.el_floe[q]; it.e = S.el_elem[q]; it.j = -1; it.rows = S.capPairs + q; it.info = S.capM * S.maxnb + q;
     it.ao = ring_off(S, it.i); it.na = ring_n(S, it.i); it.bo = S.eoff[it.e]; it.nb = S.eoff[it.e + 1] - it.bo;
   }
   return it;
@@ -1117,20 +1118,25 @@ __device__ __forceinline__ Item item_of(const State& S, const Seg& g, int t) {
 // (outgoing), earlier ones the pairs mirrored onto it (incoming).  Candidates are rank-sorted by order key in LDS.  The
 // owned pairs whose ring boxes overlap are appended to the narrow phase's work list here (one tail atomic per workgroup);
 // the others get their (empty) result at once.
-constexpr int NB_G = 16, NB_TPB = 128, NB_POOL = 96;
+constexpr int NB_G = 16, NB_TPB = 128;
 // FAM: the Dict rule may read family records (inline ghosts; State::Fam) -- its arrays cost ~50 registers, a wavefront per SIMD that a
 // large field (throughput-bound search) misses: the host picks the instantiation by size
-template <int TPB, bool FAM = true>
+// NBC: neighbours a floe may have in either direction (= State::maxnb, the stride of the neighbour lists): 24 for fields of like-sized
+// floes, 64 where the host's count at upload finds a size spectrum (Voronoi fields: a large cell has dozens of small neighbours)
+template <int TPB, bool FAM = true, int NBC = MAXNB>
 __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   constexpr int GPB = TPB / NB_G;
-  __shared__ int cand[GPB][2][MAXNB];
-  __shared__ long long ckey[GPB][2][MAXNB];
+  constexpr int NB_POOL = NBC <= 24 ? 96 : 224;       // floes the 3 x 3 cells around a floe may hold
+  static_assert(NBC <= 64, "the box mask of the owned pairs is one 64-bit word");
+  __shared__ int cand[GPB][2][NBC];
+  __shared__ long long ckey[GPB][2][NBC];
   __shared__ int cnts[GPB][2];
-  __shared__ int wmask[GPB];
+  using mask_t = typename std::conditional<(NBC <= 32), unsigned, unsigned long long>::type;      // box mask of the owned pairs
+  __shared__ mask_t wmask[GPB];
   __shared__ int pool[GPB][NB_POOL];
   __shared__ int npool[GPB];
   __shared__ int wbase[GPB + 1];
-  __shared__ int cvo[GPB][MAXNB], cnv[GPB][MAXNB], svo[GPB][MAXNB], snv[GPB][MAXNB];    // ring offset / size of the owned pairs' partners (unsorted, sorted)
+  __shared__ int cvo[GPB][NBC], cnv[GPB][NBC], svo[GPB][NBC], snv[GPB][NBC];    // ring offset / size of the owned pairs' partners (unsorted, sorted)
   const int gl = threadIdx.x % NB_G, gi = threadIdx.x / NB_G;
   const StopRegs stop = stop_load(S);
   int M = S.cnt[C_M];
@@ -1165,100 +1171,160 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
     if (bid == 0 && threadIdx.x == 0 && kb == vb0 * GPB) { S.cnt[C_ITEMCLASS] = 0; S.cnt[C_NFUSE] = 0; }     // per-step counters the narrow phase raises
     const bool act = k < M;
     __syncthreads();
-    if (gl == 0) { cnts[gi][0] = 0; cnts[gi][1] = 0; wmask[gi] = 0; npool[gi] = 0; }
+    if (gl == 0) { cnts[gi][0] = 0; cnts[gi][1] = 0; wmask[gi] = (mask_t)0; npool[gi] = 0; }
     __syncthreads();
     if (act) cell_of(g, ckx, cky, ix, iy);
     bool ovf = false;
-    if (act && gl < 9) {
-      const int oy = gl / 3 - 1, ox = gl % 3 - 1;
-      int cy = iy + oy, cxi = ix + ox;
-      bool visit = true;
-      // a wrapped direction with fewer than three cells would meet the same cell twice
-      if (g.wrapx) { cxi = cell_fold(cxi, ncx, 1); if ((ncx == 1 && ox != 0) || (ncx == 2 && ox > 0)) visit = false; }
-      else if (cxi < 0 || cxi >= ncx) visit = false;
-      if (g.wrapy) { cy = cell_fold(cy, ncy, 1); if ((ncy == 1 && oy != 0) || (ncy == 2 && oy > 0)) visit = false; }
-      else if (cy < 0 || cy >= ncy) visit = false;
-      if (visit) {
-        const int c = cy * ncx + cxi;
-        const int n = S.cell_cnt[c];
-        const int4 s0 = *(const int4*)(S.cell_slots + (size_t)c * CELL_K), s1 = *(const int4*)(S.cell_slots + (size_t)c * CELL_K + 4);
-        const int sl[CELL_K] = { s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w };
-        const int nbk = n < CELL_K ? n : CELL_K;
-        int take = 0;
+    auto candidates = [&](int np) {
+      for (int e = gl; e < np; e += NB_G) {
+        const int o = pool[gi][e];
+        if (o == k) continue;      // (the chunked pool holds the floe itself; in the one-pass variant this test never fires, but taking it out
+                                   //  moves the register allocation of the FAM instantiation from 168 to 173 -- one wavefront per SIMD less, 17 -> 23 us)
+        if (S.rec32) {
+          // mixed precision: the candidate's fp32 record first -- two 16-byte loads instead of seven scattered doubles; a
+          // candidate that fails the bounding-circle test even with the margin that covers the fp32 roundings is gone, the
+          // others are confirmed by the exact fp64 predicate below, so the pair list is the fp64 one bit for bit
+          const float4 oc = S.rec32[2 * (size_t)o];
+          const float fdx = (float)ckx - oc.x, fdy = (float)cky - oc.y;
+          const float frr = (float)rk + oc.z + MIX_CIRCLE_MARGIN + 1e-6f * fmaxf(fabsf((float)ckx), fabsf((float)cky));    // (+ 1 m per 1000 km of coordinate: fp32 spacing)
+          if (!(fdx * fdx + fdy * fdy < frr * frr)) continue;
+        }
+        // everything the tests below may need about o is requested at once
+        const double ocx = S.cx[o], ocy = S.cy[o], orm = S.rmax[o];
+        const double ox0 = S.bbx0[o], ox1 = S.bbx1[o], oy0 = S.bby0[o], oy1 = S.bby1[o];
+        const long long oid = S.id[o], ko = S.okey[o];
+        const int opar = S.parent[o];
+        const bool oplain = opar == o && S.ngh[o] == 0;     // a parent without ghosts
+        const int voo = ring_off(S, o), nvo = ring_n(S, o);
+        // potential_interaction (collisions.jl:705-710), symmetric in its arguments
+        double ddx = ckx - ocx, ddy = cky - ocy, rr = rk + orm;
+        if (!((ddx * ddx + ddy * ddy) < rr * rr)) continue;
+        if (oid == idk) continue;
+        bool after = ko > okk;                   // o comes after k in the serial order
+        // the Dict rule only bites when one of the two floes has periodic images
+        if (!(kplain && oplain)) {
+          bool ok;
+          if (FAM && S.famrec) {           // (inline ghosts leave a record per family: a floe that is a ghost, or has ghosts, has one at its parent)
+            const int kp = kpar, op = opar;
+            const long long gk = kgid, go = S.ghost_id[o];
+            ok = after ? pair_allowed_fam(S, kp, op, !kplain, !oplain, okk, gk, ckx, cky, rk, ko, go, ocx, ocy, orm)
+                       : pair_allowed_fam(S, op, kp, !oplain, !kplain, ko, go, ocx, ocy, orm, okk, gk, ckx, cky, rk);
+          } else ok = pair_allowed(S, after ? k : o, after ? o : k);
+          if (!ok) continue;
+        }
+        int w = after ? 0 : 1;
+        int slot = atomicAdd(&cnts[gi][w], 1);
+        // AABB cull of the pairs this floe owns: rings whose boxes are disjoint cannot overlap, the item would
+        // end at the first test of the clip (sz_geom.hpp clip()) with no row and no flag -- it is not run at all
+        int boxes = 1;
+        if (after) boxes = !(kx1 < ox0 || ox1 < kx0 || ky1 < oy0 || oy1 < ky0);
+        if (slot < NBC) { cand[gi][w][slot] = o | (boxes << 30); ckey[gi][w][slot] = ko; if (after) { cvo[gi][slot] = voo; cnv[gi][slot] = nvo; } } else ovf = true;
+      }
+    };
+    // Two ways to pool the floes of the 3 x 3 cells.  Fields of like-sized floes (NBC = 24): one pass, offsets from an LDS atomic, a pool of 96 --
+    // more is an error, and the host's count at upload rules it out (it picks NBC = 64 otherwise).  Fields with a size spectrum (NBC = 64):
+    // the chunked pool below, which no crowding overflows; it costs ~15 % of this kernel's time, which is why the first way is kept.
+    if constexpr (NBC <= MAXNB) {
+      if (act && gl < 9) {
+        const int oy = gl / 3 - 1, ox = gl % 3 - 1;
+        int cy = iy + oy, cxi = ix + ox;
+        bool visit = true;
+        // a wrapped direction with fewer than three cells would meet the same cell twice
+        if (g.wrapx) { cxi = cell_fold(cxi, ncx, 1); if ((ncx == 1 && ox != 0) || (ncx == 2 && ox > 0)) visit = false; }
+        else if (cxi < 0 || cxi >= ncx) visit = false;
+        if (g.wrapy) { cy = cell_fold(cy, ncy, 1); if ((ncy == 1 && oy != 0) || (ncy == 2 && oy > 0)) visit = false; }
+        else if (cy < 0 || cy >= ncy) visit = false;
+        if (visit) {
+          const int c = cy * ncx + cxi;
+          const int n = S.cell_cnt[c];
+          const int4 s0 = *(const int4*)(S.cell_slots + (size_t)c * CELL_K), s1 = *(const int4*)(S.cell_slots + (size_t)c * CELL_K + 4);
+          const int sl[CELL_K] = { s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w };
+          const int nbk = n < CELL_K ? n : CELL_K;
+          int take = 0;
 #pragma unroll
-        for (int q = 0; q < CELL_K; q++) take += (q < nbk && sl[q] != k) ? 1 : 0;
-        int at = take ? atomicAdd(&npool[gi], take) : 0;
+          for (int q = 0; q < CELL_K; q++) take += (q < nbk && sl[q] != k) ? 1 : 0;
+          int at = take ? atomicAdd(&npool[gi], take) : 0;
 #pragma unroll
-        for (int q = 0; q < CELL_K; q++) if (q < nbk && sl[q] != k) { if (at < NB_POOL) pool[gi][at] = sl[q]; else ovf = true; at++; }
-        if (n > CELL_K) {            // a crowded cell: the floes beyond the bucket are on a chain
-          for (int o = S.cell_ovf[c] - 1; o >= 0; o = S.cell_items[o]) {
-            if (o == k) continue;
-            const int a2 = atomicAdd(&npool[gi], 1);
-            if (a2 < NB_POOL) pool[gi][a2] = o; else ovf = true;
+          for (int q = 0; q < CELL_K; q++) if (q < nbk && sl[q] != k) { if (at < NB_POOL) pool[gi][at] = sl[q]; else ovf = true; at++; }
+          if (n > CELL_K) {            // a crowded cell: the floes beyond the bucket are on a chain
+            for (int o = S.cell_ovf[c] - 1; o >= 0; o = S.cell_items[o]) {
+              if (o == k) continue;
+              const int a2 = atomicAdd(&npool[gi], 1);
+              if (a2 < NB_POOL) pool[gi][a2] = o; else ovf = true;
+            }
           }
         }
       }
-    }
-    gsync();
-    const int np = npool[gi] < NB_POOL ? npool[gi] : NB_POOL;
-    for (int e = gl; e < np; e += NB_G) {
-      const int o = pool[gi][e];
-      if (S.rec32) {
-        // mixed precision: the candidate's fp32 record first -- two 16-byte loads instead of seven scattered doubles; a
-        // candidate that fails the bounding-circle test even with the margin that covers the fp32 roundings is gone, the
-        // others are confirmed by the exact fp64 predicate below, so the pair list is the fp64 one bit for bit
-        const float4 oc = S.rec32[2 * (size_t)o];
-        const float fdx = (float)ckx - oc.x, fdy = (float)cky - oc.y;
-        const float frr = (float)rk + oc.z + MIX_CIRCLE_MARGIN + 1e-6f * fmaxf(fabsf((float)ckx), fabsf((float)cky));    // (+ 1 m per 1000 km of coordinate: fp32 spacing)
-        if (!(fdx * fdx + fdy * fdy < frr * frr)) continue;
+      gsync();
+      const int np = npool[gi] < NB_POOL ? npool[gi] : NB_POOL;
+      candidates(np);
+    } else {
+      // The floes of the 3 x 3 cells: lanes 0..8 hold one cell each (count, bucket, chain); the cells' floes are numbered cell after cell
+      // (prefix of the counts over the lanes), pooled and tested in chunks of NB_POOL -- one chunk unless the cells are crowded (a size
+      // spectrum: the cell side follows the LARGEST floe, so a cell holds many small ones; the floe itself is in the pool and skipped).
+      int cn = 0, ccell = -1;
+      int4 b0 = make_int4(0, 0, 0, 0), b1 = b0;
+      if (act && gl < 9) {
+        const int oy = gl / 3 - 1, ox = gl % 3 - 1;
+        int cy = iy + oy, cxi = ix + ox;
+        bool visit = true;
+        // a wrapped direction with fewer than three cells would meet the same cell twice
+        if (g.wrapx) { cxi = cell_fold(cxi, ncx, 1); if ((ncx == 1 && ox != 0) || (ncx == 2 && ox > 0)) visit = false; }
+        else if (cxi < 0 || cxi >= ncx) visit = false;
+        if (g.wrapy) { cy = cell_fold(cy, ncy, 1); if ((ncy == 1 && oy != 0) || (ncy == 2 && oy > 0)) visit = false; }
+        else if (cy < 0 || cy >= ncy) visit = false;
+        if (visit) {
+          ccell = cy * ncx + cxi;
+          cn = S.cell_cnt[ccell];
+          b0 = *(const int4*)(S.cell_slots + (size_t)ccell * CELL_K); b1 = *(const int4*)(S.cell_slots + (size_t)ccell * CELL_K + 4);     // (count and bucket in one round trip)
+        }
       }
-      // everything the tests below may need about o is requested at once
-      const double ocx = S.cx[o], ocy = S.cy[o], orm = S.rmax[o];
-      const double ox0 = S.bbx0[o], ox1 = S.bbx1[o], oy0 = S.bby0[o], oy1 = S.bby1[o];
-      const long long oid = S.id[o], ko = S.okey[o];
-      const int opar = S.parent[o];
-      const bool oplain = opar == o && S.ngh[o] == 0;     // a parent without ghosts
-      const int voo = ring_off(S, o), nvo = ring_n(S, o);
-      // potential_interaction (collisions.jl:705-710), symmetric in its arguments
-      double ddx = ckx - ocx, ddy = cky - ocy, rr = rk + orm;
-      if (!((ddx * ddx + ddy * ddy) < rr * rr)) continue;
-      if (oid == idk) continue;
-      bool after = ko > okk;                   // o comes after k in the serial order
-      // the Dict rule only bites when one of the two floes has periodic images
-      if (!(kplain && oplain)) {
-        bool ok;
-        if (FAM && S.famrec) {           // (inline ghosts leave a record per family: a floe that is a ghost, or has ghosts, has one at its parent)
-          const int kp = kpar, op = opar;
-          const long long gk = kgid, go = S.ghost_id[o];
-          ok = after ? pair_allowed_fam(S, kp, op, !kplain, !oplain, okk, gk, ckx, cky, rk, ko, go, ocx, ocy, orm)
-                     : pair_allowed_fam(S, op, kp, !oplain, !kplain, ko, go, ocx, ocy, orm, okk, gk, ckx, cky, rk);
-        } else ok = pair_allowed(S, after ? k : o, after ? o : k);
-        if (!ok) continue;
+      int coff = cn;
+#pragma unroll
+      for (int d = 1; d < NB_G; d <<= 1) { const int t = __shfl_up(coff, d, NB_G); if (gl >= d) coff += t; }
+      const int ntot = __shfl(coff, NB_G - 1, NB_G);
+      coff -= cn;
+      if (cn > 0 && coff < NB_POOL) {          // the buckets' part of the first chunk, from the registers
+        const int sl[CELL_K] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+#pragma unroll
+        for (int q = 0; q < CELL_K; q++) { const int idx = coff + q; if (q < cn && idx < NB_POOL) pool[gi][idx] = sl[q]; }
       }
-      int w = after ? 0 : 1;
-      int slot = atomicAdd(&cnts[gi][w], 1);
-      // AABB cull of the pairs this floe owns: rings whose boxes are disjoint cannot overlap, the item would
-      // end at the first test of the clip (sz_geom.hpp clip()) with no row and no flag -- it is not run at all
-      int boxes = 1;
-      if (after) boxes = !(kx1 < ox0 || ox1 < kx0 || ky1 < oy0 || oy1 < ky0);
-      if (slot < MAXNB) { cand[gi][w][slot] = o | (boxes << 30); ckey[gi][w][slot] = ko; if (after) { cvo[gi][slot] = voo; cnv[gi][slot] = nvo; } } else ovf = true;
+      for (int cb = 0; cb < ntot; cb += NB_POOL) {
+        if (cn > 0 && coff < cb + NB_POOL && coff + cn > cb) {
+          if (cb > 0) {          // (later chunks ask for the bucket again: holding it across the chunks would cost the kernel a wavefront per SIMD)
+            const int4 s0 = *(const int4*)(S.cell_slots + (size_t)ccell * CELL_K), s1 = *(const int4*)(S.cell_slots + (size_t)ccell * CELL_K + 4);
+            const int sl[CELL_K] = { s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w };
+#pragma unroll
+            for (int q = 0; q < CELL_K; q++) { const int idx = coff + q - cb; if (q < cn && idx >= 0 && idx < NB_POOL) pool[gi][idx] = sl[q]; }
+          }
+          if (cn > CELL_K) {            // a crowded cell: the floes beyond the bucket are on a chain
+            int idx = coff + CELL_K - cb;
+            for (int o = S.cell_ovf[ccell] - 1; o >= 0 && idx < NB_POOL; o = S.cell_items[o], idx++) if (idx >= 0) pool[gi][idx] = o;
+            for (const int end = coff + cn - cb < NB_POOL ? coff + cn - cb : NB_POOL; idx < end; idx++) if (idx >= 0) pool[gi][idx] = k;      // (never: count and chain agree)
+          }
+        }
+        gsync();
+        const int np = ntot - cb < NB_POOL ? ntot - cb : NB_POOL;
+        candidates(np);
+        gsync();          // (the next chunk overwrites the pool)
+      }
     }
     if (ovf) atomicOr(&S.cnt[C_ERR], ERR_CAP_NEIGH);
     gsync();
     for (int w = 0; w < 2; w++) {
-      int n = cnts[gi][w] < MAXNB ? cnts[gi][w] : MAXNB;
-      int* dst = (w == 0 ? S.nb_out : S.nb_in) + (size_t)k * MAXNB;
+      int n = cnts[gi][w] < NBC ? cnts[gi][w] : NBC;
+      int* dst = (w == 0 ? S.nb_out : S.nb_in) + (size_t)k * NBC;
       for (int e = gl; e < n; e += NB_G) {
         long long ke = ckey[gi][w][e]; int r = 0;
         for (int f = 0; f < n; f++) r += ckey[gi][w][f] < ke;
         const int cv = cand[gi][w][e];
         dst[r] = cv & 0x3fffffff;
         if (w == 0) { pool[gi][r] = cv & 0x3fffffff; svo[gi][r] = cvo[gi][e]; snv[gi][r] = cnv[gi][e]; }   // (the pool is free by now: the sorted owned list, for the work items below)
-        if (w == 0 && (cv >> 30)) atomicOr(&wmask[gi], 1 << r);
+        if (w == 0 && (cv >> 30)) atomicOr(&wmask[gi], (mask_t)1 << r);
       }
       gsync();
       if (gl == 0 && act) {
-        if (w == 0) { S.n_out[k] = n; S.out_mask[k] = wmask[gi]; }
+        if (w == 0) { S.n_out[k] = n; S.out_mask[k] = (unsigned long long)wmask[gi]; }
         else S.n_in[k] = n;
       }
     }
@@ -1266,27 +1332,27 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
     __syncthreads();
     if (threadIdx.x == 0) {
       int tot = 0;
-      for (int q = 0; q < GPB; q++) { wbase[q] = tot; tot += __popc(wmask[q]); }
+      for (int q = 0; q < GPB; q++) { wbase[q] = tot; tot += __popcll((unsigned long long)wmask[q]); }
       int base = tot ? atomicAdd(&S.wq[seg * 32 + 1], tot) : 0;
       if (base + tot > segcap) { atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS); base = -1; }
       wbase[GPB] = base;
     }
     __syncthreads();
     if (act) {
-      const int base = wbase[GPB], mask = wmask[gi], nk = cnts[gi][0] < MAXNB ? cnts[gi][0] : MAXNB;
+      const int base = wbase[GPB], nk = cnts[gi][0] < NBC ? cnts[gi][0] : NBC; const mask_t mask = wmask[gi];
       for (int r = gl; r < nk; r += NB_G) {
-        const int slot = k * MAXNB + r;
+        const int slot = k * NBC + r;
         if ((mask >> r & 1) && base >= 0) {
           const int j = pool[gi][r];
-          const size_t w2 = 2 * ((size_t)seg * segcap + base + wbase[gi] + __popc(mask & ((1 << r) - 1)));
+          const size_t w2 = 2 * ((size_t)seg * segcap + base + wbase[gi] + __popcll((unsigned long long)(mask & (((mask_t)1 << r) - (mask_t)1))));
           S.work[w2] = make_int4(slot, k, j, vok); S.work[w2 + 1] = make_int4(nvk, svo[gi][r], snv[gi][r], 0);
         } else S.it_info[slot] = make_int2(0, -1);      // boxes disjoint: no region, no row, no flag (the clip's own first test)
       }
     }
   }
 }
-template <bool FAM>
-__global__ void __launch_bounds__(NB_TPB) sz_k_neighbors(State S) { neighbors_body<NB_TPB, FAM>(S, blockIdx.x, gridDim.x); }
+template <bool FAM, int NBC = MAXNB>
+__global__ void __launch_bounds__(NB_TPB, (NBC > MAXNB ? (FAM ? 3 : 4) : 1)) sz_k_neighbors(State S) { neighbors_body<NB_TPB, FAM, NBC>(S, blockIdx.x, gridDim.x); }
 
 // The compact pair list in the reference's serial order (i asc, j asc) -- out_off, pair_i, pair_j -- is only made when
 // the host asks for it (sz_download_pairs): fill after a scan of n_out.
@@ -1294,7 +1360,7 @@ __global__ void sz_k_pairs_fill(State S, int M) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
     const int o = S.out_off[i], nk = S.n_out[i];
     if (o + nk > S.capPairs) { atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS); continue; }
-    for (int t = 0; t < nk; t++) { S.pair_i[o + t] = i; S.pair_j[o + t] = S.nb_out[(size_t)i * MAXNB + t]; }
+    for (int t = 0; t < nk; t++) { S.pair_i[o + t] = i; S.pair_j[o + t] = S.nb_out[(size_t)i * S.maxnb + t]; }
   }
 }
 // explicit pair list (sz_collide_pairs; sorted by (i, j) on the host): out lists from the given pairs, no incoming
@@ -1307,14 +1373,14 @@ __global__ void sz_k_pairs_explicit(State S, int np) {
     while (lo < hi) { int mid = (lo + hi) >> 1; if (S.pair_i[mid] < k) lo = mid + 1; else hi = mid; }
     int e = lo; while (e < np && S.pair_i[e] == k) e++;
     int nk = e - lo;
-    if (nk > MAXNB) { atomicOr(&S.cnt[C_ERR], ERR_CAP_NEIGH); nk = MAXNB; }
-    S.n_out[k] = nk; S.n_in[k] = 0; S.out_mask[k] = nk >= 32 ? -1 : (1 << nk) - 1;
+    if (nk > S.maxnb) { atomicOr(&S.cnt[C_ERR], ERR_CAP_NEIGH); nk = S.maxnb; }
+    S.n_out[k] = nk; S.n_in[k] = 0; S.out_mask[k] = nk >= 64 ? ~0ull : (1ull << nk) - 1ull;
     for (int r = 0; r < nk; r++) {
       const int p = lo + r, j = S.pair_j[p];
-      S.nb_out[(size_t)k * MAXNB + r] = j;
+      S.nb_out[(size_t)k * S.maxnb + r] = j;
       if (p / NSEG < segcap) {
         const size_t w2 = 2 * ((size_t)(p % NSEG) * segcap + p / NSEG);
-        S.work[w2] = make_int4(k * MAXNB + r, k, j, S.voff[k]); S.work[w2 + 1] = make_int4(S.voff[k + 1] - S.voff[k], S.voff[j], S.voff[j + 1] - S.voff[j], 0);
+        S.work[w2] = make_int4(k * S.maxnb + r, k, j, S.voff[k]); S.work[w2 + 1] = make_int4(S.voff[k + 1] - S.voff[k], S.voff[j], S.voff[j + 1] - S.voff[j], 0);
       } else atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS);
     }
   }
@@ -1693,7 +1759,7 @@ __global__ void sz_k_items_clear(State S) {
 // Interaction rows live at a fixed stride (ROWCAP rows per floe): no offsets, no scan in the step;
 // sz_download_interactions compacts them to CSR on demand.  A floe with more rows than ROWCAP
 // raises ERR_CAP_INTER.
-constexpr int ROWCAP = 32;
+constexpr int ROWCAP = 32;      // (the default of State::rowcap)
 
 // A group of IF_G lanes per floe.  Appends the rows of floe f -- own pairs (j asc), domain elements
 // (N,S,E,W, topography), rows mirrored from partners that come earlier in the serial order (i asc,
@@ -1715,12 +1781,12 @@ __device__ __forceinline__ int emit_rows(const State& S, int lane, int f, double
   for (int base = 0; base < T; base += IF_G) {
     const int s = base + lane;
     int info = -1, n = 0, kind = -1; double idx = 0.0, sign = 1.0;
-    if (s < nown) { info = f * MAXNB + s; idx = (double)(S.okey[S.nb_out[info]] + 1); kind = 0; }
-    else if (s < nown + nel) { int q = e0 + (s - nown); info = S.capM * MAXNB + q; idx = -(double)(S.el_elem[q] + 1); kind = 1; }
+    if (s < nown) { info = f * S.maxnb + s; idx = (double)(S.okey[S.nb_out[info]] + 1); kind = 0; }
+    else if (s < nown + nel) { int q = e0 + (s - nown); info = S.capM * S.maxnb + q; idx = -(double)(S.el_elem[q] + 1); kind = 1; }
     else if (s < T) {
-      const int i = S.nb_in[(size_t)f * MAXNB + (s - nown - nel)];
+      const int i = S.nb_in[(size_t)f * S.maxnb + (s - nown - nel)];
       const int ni = S.n_out[i];
-      for (int q = 0; q < ni; q++) if (S.nb_out[(size_t)i * MAXNB + q] == f) info = i * MAXNB + q;     // pair (i, f); absent if the Dict rule dropped it
+      for (int q = 0; q < ni; q++) if (S.nb_out[(size_t)i * S.maxnb + q] == f) info = i * S.maxnb + q;     // pair (i, f); absent if the Dict rule dropped it
       idx = (double)(S.okey[i] + 1); sign = -1.0; kind = 2;
     }
     int fl = 0; int2 iv = make_int2(0, 0);
@@ -1784,12 +1850,12 @@ __device__ __forceinline__ int emit_rows_fold(const State& S, int lane, int f, d
     const int ls = s - s0;
     int info = -1, n = 0, kind = -1; double idx = 0.0, sign = 1.0;
     if (s < T) {
-      if (ls < nown) { info = fq * MAXNB + ls; idx = (double)(S.okey[S.nb_out[info]] + 1); kind = 0; }
-      else if (ls < nown + nel) { int qq = e0 + (ls - nown); info = S.capM * MAXNB + qq; idx = -(double)(S.el_elem[qq] + 1); kind = 1; }
+      if (ls < nown) { info = fq * S.maxnb + ls; idx = (double)(S.okey[S.nb_out[info]] + 1); kind = 0; }
+      else if (ls < nown + nel) { int qq = e0 + (ls - nown); info = S.capM * S.maxnb + qq; idx = -(double)(S.el_elem[qq] + 1); kind = 1; }
       else {
-        const int i = S.nb_in[(size_t)fq * MAXNB + (ls - nown - nel)];
+        const int i = S.nb_in[(size_t)fq * S.maxnb + (ls - nown - nel)];
         const int ni = S.n_out[i];
-        for (int qq = 0; qq < ni; qq++) if (S.nb_out[(size_t)i * MAXNB + qq] == fq) info = i * MAXNB + qq;     // pair (i, fq); absent if the Dict rule dropped it
+        for (int qq = 0; qq < ni; qq++) if (S.nb_out[(size_t)i * S.maxnb + qq] == fq) info = i * S.maxnb + qq;     // pair (i, fq); absent if the Dict rule dropped it
         idx = (double)(S.okey[i] + 1); sign = -1.0; kind = 2;
       }
     }
@@ -1843,7 +1909,7 @@ __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int 
   // (a launch whose grid is smaller than NSEG * 2 ints would be odd: threads 0 .. 15 of workgroup 0 do it)
   if (blockIdx.x == 0 && threadIdx.x < 2 * NSEG) S.wq[(threadIdx.x >> 1) * 32 + (threadIdx.x & 1)] = 0;
   auto reduce = [&](int k, const Pre* pr) {
-    double* dst = S.inter_rows + (size_t)k * ROWCAP * 7;
+    double* dst = S.inter_rows + (size_t)k * S.rowcap * 7;
     const bool is_ghost = (pr ? pr->gid : S.ghost_id[k]) != 0;
     const double cx = pr ? pr->cx : S.cx[k], cy = pr ? pr->cy : S.cy[k];
     double sx = 0.0, sy = 0.0;
@@ -1859,8 +1925,8 @@ __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int 
 #pragma unroll
       for (int g = 0; g < MAX_GHOSTS; g++) gf[g] = S.gh[k * MAX_GHOSTS + g];
       const int4 cn = pr ? pr->cnts : make_int4(S.n_out[k], S.el_off[k], S.el_off[k + 1], S.n_in[k]);
-      c = emit_rows_fold(S, lane, k, dst, ROWCAP, mirror, ovf, &st, &tagA, cn, ng, gf, cx, cy);
-    } else c = emit_rows(S, lane, k, dst, 0, ROWCAP, sx, sy, mirror, ovf, &st, &tagA, pr ? &pr->cnts : nullptr);
+      c = emit_rows_fold(S, lane, k, dst, S.rowcap, mirror, ovf, &st, &tagA, cn, ng, gf, cx, cy);
+    } else c = emit_rows(S, lane, k, dst, 0, S.rowcap, sx, sy, mirror, ovf, &st, &tagA, pr ? &pr->cnts : nullptr);
     if (ovf) atomicOr(&S.cnt[C_ERR], ERR_CAP_INTER);
     __threadfence_block();             // the rows were written by other lanes of this wavefront
     // torque per row over the lanes; totals (collisions.jl:747-749, 852-861) and the overlap sum in row
@@ -1900,7 +1966,7 @@ __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int 
 __global__ void sz_k_inter_compact(State S, double* dst) {
   int M = S.cnt[C_M];
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < M; k += gridDim.x * blockDim.x) {
-    int n = S.inter_cnt[k]; const double* src = S.inter_rows + (size_t)k * ROWCAP * 7;
+    int n = S.inter_cnt[k]; const double* src = S.inter_rows + (size_t)k * S.rowcap * 7;
     double* d = dst + (size_t)S.inter_off[k] * 7;
     for (int q = 0; q < n * 7; q++) d[q] = src[q];
   }
@@ -2247,7 +2313,7 @@ __device__ __forceinline__ void floe_stress(State& S, const Params& P, int i, do
   int rn = S.inter_cnt[i];
   if (rn > 0) {
     for (int k = 0; k < rn; k++) {
-      const double* r = S.inter_rows + ((size_t)i * ROWCAP + k) * 7;
+      const double* r = S.inter_rows + ((size_t)i * S.rowcap + k) * 7;
       s11 += (r[3] - cx) * r[1];
       s12 += (r[4] - cy) * r[1] + (r[3] - cx) * r[2];
       s22 += (r[4] - cy) * r[2];
@@ -2338,7 +2404,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
     double s11 = 0, s12 = 0, s21 = 0, s22 = 0;
     if (rn > 0) {
       for (int k = 0; k < rn; k++) {
-        const double* r = S.inter_rows + ((size_t)i * ROWCAP + k) * 7;
+        const double* r = S.inter_rows + ((size_t)i * S.rowcap + k) * 7;
         s11 += (r[3] - cx) * r[1];
         s12 += (r[4] - cy) * r[1] + (r[3] - cx) * r[2];
         s22 += (r[4] - cy) * r[2];
@@ -2756,16 +2822,16 @@ __global__ void sz_k_stats(State S, long long* out) {
   // pairs of the last step: per floe its owned pairs (all / those with overlapping ring boxes = the items run)
   const int mlast = S.cnt[C_M] > S.cnt[C_N] ? S.cnt[C_M] : S.cnt[C_N] + S.cnt[C_NGHOSTS];      // the ghosts of the last step own pairs too
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < mlast; k += gridDim.x * blockDim.x) {
-    const int nk = S.n_out[k], mask = S.out_mask[k];
-    v[10] += nk; v[11] += __popc(mask);
+    const int nk = S.n_out[k]; const unsigned long long mask = S.out_mask[k];
+    v[10] += nk; v[11] += __popcll(mask);
     const int nvk = ring_n(S, k);
     for (int r = 0; r < nk; r++) if (mask >> r & 1) {
-      const int j = S.nb_out[(size_t)k * MAXNB + r];
+      const int j = S.nb_out[(size_t)k * S.maxnb + r];
       v[0] += nvk + ring_n(S, j);
-      v[1] += S.it_info[k * MAXNB + r].x & 0xff;
+      v[1] += S.it_info[k * S.maxnb + r].x & 0xff;
     }
   }
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nel; q += gridDim.x * blockDim.x) v[2] += S.it_info[S.capM * MAXNB + q].x & 0xff;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nel; q += gridDim.x * blockDim.x) v[2] += S.it_info[S.capM * S.maxnb + q].x & 0xff;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < S.cnt[C_M]; k += gridDim.x * blockDim.x) {
     v[3] += S.inter_cnt[k];
     int st = S.status[k];

@@ -43,7 +43,7 @@ enum {
   C_COUNT = 32
 };
 
-constexpr int MAXNB = 24;       // broad-phase neighbours kept per floe and direction
+constexpr int MAXNB = 24;       // broad-phase neighbours kept per floe and direction: the default of State::maxnb (fields with a size spectrum get 64)
 constexpr int CELL_K = 8;       // floes a broad-phase cell holds in its bucket (more: overflow chain)
 constexpr int NSEG = 8;         // segments of the narrow phase's work list (one tail counter and one queue head each, a cache line apart)
 constexpr int ROWS_PER_ITEM = 16; // contact rows kept per pair / element item (the 8-lane kernels hold 4 regions and hand larger items on)
@@ -135,7 +135,8 @@ struct State {
   int *cell_cnt, *cell_slots, *cell_ovf, *cell_items;
   // per floe k: the neighbours that come later in the serial order (nb_out: the pairs k owns, sorted by order key; pair SLOT
   // = k * MAXNB + rank) and earlier (nb_in: the pairs mirrored onto it); out_mask: which owned pairs have overlapping ring boxes
-  int *nb_out, *nb_in, *n_out, *n_in, *out_mask;
+  int *nb_out, *nb_in, *n_out, *n_in; unsigned long long* out_mask;
+  int maxnb, rowcap;          // neighbours kept per floe and direction (stride of nb_out / nb_in / the pair slots: 24 or 64, chosen at upload), interaction rows per floe
   int *out_off, *pair_i, *pair_j;      // the compact pair list in serial order: made on demand (sz_download_pairs) / given (sz_collide_pairs)
   // work list of the narrow phase: the pair items to run, two int4 each {slot, i, j, ring offset i} {ring size i, ring offset j, ring size j, -}, appended by the neighbour search in NSEG segments of
   // capPairs / NSEG items; wq[s * 32] = queue head of segment s (rounds after the first), wq[s * 32 + 1] = its length

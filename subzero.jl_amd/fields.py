@@ -68,9 +68,40 @@ def subgrid_points(ring, cx, cy, dg):
     return np.concatenate([np.array(xs), gx[inside]]), np.concatenate([np.array(ys), gy[inside]])
 
 
+def voronoi_cells(rng, n_cells, L):
+    """Voronoi cells of n_cells uniform random seed points, bounded by the box [0, L]^2 (the seeds are mirrored in the four
+    walls, so every cell of an original seed ends at the box) -- the tessellation the reference's initialize_floe_field draws
+    its floes from (floe_utils / floe.jl: generate_voronoi_coords; VoronoiCells.jl there, scipy's Qhull here).  Returns a list
+    of closed clockwise rings."""
+    from scipy.spatial import Voronoi
+    p = rng.uniform(0.0, L, (n_cells, 2))
+    pts = np.concatenate([p, p * [-1, 1], p * [-1, 1] + [2 * L, 0], p * [1, -1], p * [1, -1] + [0, 2 * L]])
+    vor = Voronoi(pts)
+    rings = []
+    for i in range(n_cells):
+        reg = vor.regions[vor.point_region[i]]
+        if -1 in reg or len(reg) < 3:
+            continue
+        v = vor.vertices[reg]
+        c = v.mean(0)
+        order = np.argsort(-np.arctan2(v[:, 1] - c[1], v[:, 0] - c[0]))          # descending angle: clockwise
+        v = np.clip(v[order], 0.0, L)                                             # (round-off of the mirror construction)
+        keep = np.ones(len(v), bool)
+        for k in range(len(v)):                                                   # Qhull may return coincident vertices
+            if np.hypot(*(v[k] - v[k - 1])) < 1e-9 * L:
+                keep[k] = False
+        v = v[keep]
+        if len(v) >= 3:
+            rings.append(np.concatenate([v, v[:1]]))
+    return rings
+
+
 def make_config(n_floes=10000, seed=12345, concentration=0.8, spacing=2.0e4, walls=False, topography=False,
-                ocean="uniform", dt=20, hmean=0.25, subgrid_per_floe=10.0):
-    """Returns a plain dict describing one synthetic scenario (polygons, state, domain, fields)."""
+                ocean="uniform", dt=20, hmean=0.25, subgrid_per_floe=10.0, shape="star"):
+    """Returns a plain dict describing one synthetic scenario (polygons, state, domain, fields).
+    shape "star": random star-shaped polygons of 8-16 vertices on a jittered lattice (BASELINE.json configs[1]: "random-polygon
+    floes (8-16 verts)"); "voronoi": n_floes cells drawn from a bounded Voronoi tessellation of n_floes / concentration seeds --
+    the reference's own field generator (configs[0]): convex cells that TOUCH along whole edges, i.e. every contact starts degenerate."""
     rng = np.random.Generator(np.random.PCG64(seed))
     # mean star area = pi r^2 E[(0.6+0.4U)^2] ~ 0.6533 pi r^2  -> r from the target concentration
     r0 = spacing * np.sqrt(concentration / (0.6533 * np.pi))
@@ -108,10 +139,20 @@ def make_config(n_floes=10000, seed=12345, concentration=0.8, spacing=2.0e4, wal
         gx, gy = (cells % n_side).astype(float), (cells // n_side).astype(float)
         ccx = (gx + 0.5) * spacing + rng.uniform(-jit, jit, n_floes)
         ccy = (gy + 0.5) * spacing + rng.uniform(-jit, jit, n_floes)
-    nv = rng.integers(8, 17, n_floes)
+    if shape == "voronoi":
+        assert not topography, "the Voronoi generator fills the open box"
+        rings = voronoi_cells(rng, int(np.ceil(n_floes / concentration)), L)
+        assert len(rings) >= n_floes
+        pick = np.sort(rng.permutation(len(rings))[:n_floes])
+        rings = [rings[k] for k in pick]
+        nv = np.array([len(r) - 1 for r in rings])
+    else:
+        nv = rng.integers(8, 17, n_floes)
     off = np.zeros(n_floes + 1, np.int32); off[1:] = np.cumsum(nv + 1)
     vx = np.zeros(off[-1]); vy = np.zeros(off[-1])
-    for i in range(n_floes):
+    if shape == "voronoi":
+        vx[:] = np.concatenate([r[:, 0] for r in rings]); vy[:] = np.concatenate([r[:, 1] for r in rings])
+    for i in range(n_floes if shape != "voronoi" else 0):
         n = nv[i]
         # jittered equally spaced angles: consecutive angles differ by < pi, so the ring is
         # star-shaped about its centre (hence simple); descending = clockwise

@@ -220,6 +220,37 @@ def test_trajectories(n, seed, steps):
     assert np.array_equal(hw.warn_counts(), ow.warn_counts())
 
 
+@pytest.mark.parametrize("n,seed,walls,conc,steps", [(150, 3, False, 0.7, 30), (400, 4, True, 0.85, 30), (1500, 5, False, 1.0, 12)])
+def test_voronoi_field_touching_cells(n, seed, walls, conc, steps):
+    """The reference draws its floe fields from a Voronoi tessellation (initialize_floe_field; BASELINE configs[0]): convex cells
+    with 3-9 vertices that TOUCH their neighbours along whole edges and the walls along whole sides -- every contact starts as a
+    degenerate one (collinear edges, shared vertices, zero overlap area) and becomes a sliver as the shear flow moves the cells.
+    First call: pair lists bit-exact, rows within 1e-10.  Then 30 resident steps (12 of the fully packed, jammed field): pair lists equal, guard counters equal, state columns
+    within 1e-6 -- not the 1e-9 of the star-polygon fields: the contact point of a sliver region is its centroid, conditioned like
+    coordinate^2 / area, and ONE such contact turns a last-bit difference of a rotation angle (the forcing sums of the two codes differ
+    in the order of their additions, as the tolerance allows) into 1e-9 of a torque in one step (step 2 of the fully packed case, step 16
+    of the walled one: `tools/voronoi_diverge.py` prints the history).  The reference's own trajectory is as sensitive to its last bits."""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=n, seed=seed, spacing=1.0e4, shape="voronoi", ocean="shear", concentration=conc, walls=walls)
+    assert 4 <= np.diff(cfg["vert_off"]).min() and np.diff(cfg["vert_off"]).max() <= 14
+    hw, ow = _pair(cfg)
+    for w in (hw, ow):
+        w.add_ghosts(); w.timestep_collisions(n, cfg["dt"])
+    assert hw.M == ow.M and hw.ghosts() == ow.ghosts()
+    parity.compare_pairs(hw, ow)
+    parity.compare_interactions(hw, ow, rtol=1e-10)
+    for w in (hw, ow):
+        w.remove_ghosts(n)
+    hw2, ow2 = _pair(cfg)
+    hw2.run(steps, 0, cfg["dt"], coupling_dt=5, stop_on_tags=False)
+    for t in range(steps):
+        ow2.timestep_sim(t, cfg["dt"], coupling_dt=5)
+    parity.compare_worlds(hw2, ow2, rtol=1e-6, check_inter=False)
+    parity.compare_pairs(hw2, ow2)
+    assert np.array_equal(hw2.warn_counts(), ow2.warn_counts())
+    assert np.count_nonzero(ow2.get("overarea")) > n // 4            # the cells did run into each other
+
+
 @pytest.mark.parametrize("walls", [False, True])
 def test_resident_and_process_mode_interleaved(walls):
     """Resident steps keep a fixed broad-phase grid and its cell lists across steps; process-mode calls fit their
@@ -669,10 +700,12 @@ def _size_spectrum(w, n_small, big_r):
 
 
 def test_size_spectrum_field_and_its_capacity_limit():
-    """A large floe among small ones (the reference's Voronoi fields have a size spectrum).  Within the neighbour
-    capacity (24 per floe and direction) the contact rows match the oracle -- crowded cells (bucket + overflow chain)
-    included; beyond it the step fails LOUDLY (SZ_E_CAPACITY, neighbours bit) instead of dropping contacts.  The
-    reference grows its lists (collisions.jl:290-296); the engine's capacities are fixed per upload."""
+    """A large floe among small ones (the reference's Voronoi fields have a size spectrum).  The library counts the
+    bounding-circle neighbours of the uploaded field and sizes its neighbour lists from that: 24 per floe and direction for
+    like-sized floes, 64 (and 128 interaction rows per floe, the chunked candidate pool) where a floe has more -- the contact
+    rows match the oracle either way, crowded cells (bucket + overflow chain) included.  Beyond 64 the step fails LOUDLY
+    (SZ_E_CAPACITY, neighbours bit) instead of dropping contacts: the reference grows its lists (collisions.jl:290-296),
+    the engine's capacities are fixed per upload."""
     from subzero_jl_amd.capi import SzError
     hw = _size_spectrum(mk(), 20, 3.0e4); ow = _size_spectrum(omk(), 20, 3.0e4)
     for w in (hw, ow):
@@ -683,9 +716,18 @@ def test_size_spectrum_field_and_its_capacity_limit():
     assert len(ow.inter(0)) >= 20                          # the large floe really carries all those contacts
     hw.run(5, 0, 10, coupling_on=False); [ow.timestep_sim(t, 10, coupling_dt=10, coupling_on=False) for t in range(5)]
     parity.compare_worlds(hw, ow, rtol=1e-9)
-    big = _size_spectrum(mk(), 40, 6.0e4)
+    # 40 small floes around the large one: more than the default lists hold -- the upload picks the larger capacities
+    hw, ow = _size_spectrum(mk(), 40, 6.0e4), _size_spectrum(omk(), 40, 6.0e4)
+    for w in (hw, ow):
+        w.timestep_collisions(41, 10)
+    assert parity.compare_pairs(hw, ow) >= 40
+    parity.compare_interactions(hw, ow, 1e-10)
+    assert len(ow.inter(0)) >= 40
+    hw.run(5, 0, 10, coupling_on=False); [ow.timestep_sim(t, 10, coupling_dt=10, coupling_on=False) for t in range(5)]
+    parity.compare_worlds(hw, ow, rtol=1e-9)
+    huge = _size_spectrum(mk(), 90, 1.4e5)
     with pytest.raises(SzError, match="neighbours"):
-        big.timestep_collisions(41, 10)
+        huge.timestep_collisions(91, 10)
 
 
 # ---------------------------------------------------------------- mixed precision (BASELINE configs[4])

@@ -167,3 +167,21 @@ def test_julia_shim_binds_existing_symbols():
     for need in ("sz_timestep_collisions", "sz_timestep_coupling", "sz_timestep_floe_properties", "sz_step", "sz_upload_interactions",
                  "sz_download_fuse", "sz_simplify_check", "sz_get_boundary_rects"):
         assert any(n == need for n, _ in calls), need
+
+
+def test_hot_kernels_keep_their_register_budgets():
+    """Occupancy is part of the measured performance and changes silently: the neighbour search with the family records sits
+    exactly at the 168 registers that three wavefronts per SIMD allow (one more costs a third of its throughput: 17 -> 23 us at
+    10 k floes), the lean one under the 128 of four, the narrow phase at 168 with 16 KB of LDS per wavefront (ten wavefronts per
+    CU), and none of them may spill.  Read from the code object's metadata -- no GPU needed."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec); spec.loader.exec_module(kr)
+    res = kr.resources()
+    budget = {"sz_k_neighbors<true, 24>": (168, 0), "sz_k_neighbors<false, 24>": (128, 0), "sz_k_neighbors<true, 64>": (168, 64),
+              "sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 0>": (168, 0), "sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 1>": (168, 0),
+              "sz_k_inter_fill": (128, 0), "sz_k_forcing<false>": (128, 0), "sz_k_forcing_mixed": (80, 16), "sz_k_halo_pack": (128, 0)}
+    for name, (vg, scratch) in budget.items():
+        assert name in res, (name, sorted(k for k in res if k.startswith(name.split("<")[0])))
+        assert res[name]["vgpr"] <= vg and res[name]["scratch"] <= scratch, (name, res[name])
+    assert res["sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 1>"]["lds"] <= 16384
