@@ -182,7 +182,7 @@ def main():
     ap.add_argument("--floes", type=int, default=0, help="floes per GPU (weak scaling of the configs[1] field); default: 10000 on one "
                                                          "GPU, and for N > 1 the metric's strong-scaling workload instead")
     ap.add_argument("--total-floes", type=int, default=0, help="fix the job size (strong scaling)")
-    ap.add_argument("--workload", default=None, choices=["configs1", "configs2", "configs3", "configs4", "walls"],
+    ap.add_argument("--workload", default=None, choices=["configs1", "configs2", "configs3", "configs4", "walls", "voronoi"],
                     help="BASELINE.json configs[k]: 1 = periodic box + uniform flow (the metric's 1-GPU config, default for N = 1); 2 = "
                          "100k floes converge/diverge flow (the metric's multi-GPU config, default for N > 1); 3 = four collision "
                          "walls + topography, strait flow; 4 = 25 %% concentration")
@@ -245,7 +245,9 @@ def main():
     workload = args.workload or ("configs2" if (world > 1 and args.floes == 0) else "configs1")
     wl = {"configs1": dict(seed=12345), "configs2": dict(seed=12346, ocean="converge_diverge"),
           "configs3": dict(seed=12345, walls=True, topography=True, ocean="strait"),
-          "configs4": dict(seed=12347, concentration=0.25), "walls": dict(seed=12345, walls=True)}[workload]
+          "configs4": dict(seed=12347, concentration=0.25), "walls": dict(seed=12345, walls=True),
+          # the reference's own kind of field (initialize_floe_field): touching Voronoi cells, a size spectrum -> the larger neighbour capacity
+          "voronoi": dict(seed=12345, shape="voronoi", ocean="shear")}[workload]
     cfg = fields.make_config(n_floes=n_total, **wl)
     coupling_dt = args.coupling_dt
     tiled = not (world == 1 and not args.force_tiled)
@@ -384,7 +386,7 @@ def main():
                                     f"uniform_flow ocean 0.1 m/s" if workload == "configs1" else
                                     f"configs[2]: {cfg['n_floes']} random-polygon floes, doubly periodic box {cfg['L'] / 1e3:.0f} km, converge_diverge_flow ocean"
                                     if workload == "configs2" else
-                                    f"configs[{int(workload[-1])}]-style field ({wl}): {cfg['n_floes']} floes, box {cfg['L'] / 1e3:.0f} km, boundaries {cfg['kinds'][0]}, "
+                                    f"{'configs[' + workload[-1] + ']-style' if workload[-1].isdigit() else workload} field ({wl}): {cfg['n_floes']} floes, box {cfg['L'] / 1e3:.0f} km, boundaries {cfg['kinds'][0]}, "
                                     f"{len(cfg['topography'])} topography elements") +
                                    f", {args.relax_steps} relaxation steps after generation" +
                                    f"; collisions + one-way coupling every {coupling_dt} step(s) + rigid-body update, dt={cfg['dt']} s" +

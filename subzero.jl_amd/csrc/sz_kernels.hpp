@@ -1134,6 +1134,7 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   using mask_t = typename std::conditional<(NBC <= 32), unsigned, unsigned long long>::type;      // box mask of the owned pairs
   __shared__ mask_t wmask[GPB];
   __shared__ int pool[GPB][NB_POOL];
+  __shared__ int pool2[GPB][NBC > MAXNB ? NB_POOL : 1];      // (NBC = 64: the candidates of a chunk that passed the bounding-circle test)
   __shared__ int npool[GPB];
   __shared__ int wbase[GPB + 1];
   __shared__ int cvo[GPB][NBC], cnv[GPB][NBC], svo[GPB][NBC], snv[GPB][NBC];    // ring offset / size of the owned pairs' partners (unsorted, sorted)
@@ -1177,7 +1178,8 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
     bool ovf = false;
     auto candidates = [&](int np) {
       for (int e = gl; e < np; e += NB_G) {
-        const int o = pool[gi][e];
+        int o;
+        if constexpr (NBC > MAXNB) o = pool2[gi][e]; else o = pool[gi][e];
         if (o == k) continue;      // (the chunked pool holds the floe itself; in the one-pass variant this test never fires, but taking it out
                                    //  moves the register allocation of the FAM instantiation from 168 to 173 -- one wavefront per SIMD less, 17 -> 23 us)
         if (S.rec32) {
@@ -1304,9 +1306,23 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
           }
         }
         gsync();
-        const int np = ntot - cb < NB_POOL ? ntot - cb : NB_POOL;
+        const int npc = ntot - cb < NB_POOL ? ntot - cb : NB_POOL;
+        // A window of such a field holds a hundred floes and more, a dozen of which are neighbours: the bounding-circle test runs first, on
+        // three columns, and only the floes that pass it get the full set of loads (the one-pass variant asks for everything at once:
+        // most of ITS candidates pass).  potential_interaction (collisions.jl:705-710), the same expression as below.
+        if (gl == 0) npool[gi] = 0;
+        gsync();
+        for (int e = gl; e < npc; e += NB_G) {
+          const int o = pool[gi][e];
+          if (o == k) continue;
+          const double ocx = S.cx[o], ocy = S.cy[o], orm = S.rmax[o];
+          const double ddx = ckx - ocx, ddy = cky - ocy, rr = rk + orm;
+          if ((ddx * ddx + ddy * ddy) < rr * rr) pool2[gi][atomicAdd(&npool[gi], 1)] = o;
+        }
+        gsync();
+        const int np = npool[gi];
         candidates(np);
-        gsync();          // (the next chunk overwrites the pool)
+        gsync();          // (the next chunk overwrites the pools)
       }
     }
     if (ovf) atomicOr(&S.cnt[C_ERR], ERR_CAP_NEIGH);
