@@ -559,6 +559,100 @@ function remove_ghosts!(floes)
     return
 end
 
+# ------------------------------------------------------------------------------------------------ tiles: one process per GPU
+# A tiled run (DESIGN.md §6): every rank owns the floes of one spatial tile and trades a one-deep halo of ghost-floe records
+# with the neighbouring tiles each step, inside the library.  Between the ranks the library uses either RCCL (it opens the
+# communicator itself from a 128-byte id the host hands round) or the host's OWN channel -- three blocking collectives on
+# host memory, e.g. MPI.jl calls -- for hosts without a device-aware MPI or with several ranks on one GPU.
+
+# include/subzero_hip.h: sz_host_transport
+struct SzHostTransport
+    user::Ptr{Cvoid}
+    allgather::Ptr{Cvoid}
+    sendrecv::Ptr{Cvoid}
+    allreduce_sum_f64::Ptr{Cvoid}
+end
+
+# the host program's collectives: (allgather!(recv::Vector{UInt8}, send::Vector{UInt8}),
+#                                  sendrecv!(peers::Vector{Int32}, send::Vector{Vector{UInt8}}, recv::Vector{Vector{UInt8}}),
+#                                  allreduce_sum!(buf::Vector{Float64})), e.g. with MPI.jl:
+#     allgather!(r, s)       = MPI.Allgather!(s, MPI.UBuffer(r, length(s)), comm)
+#     sendrecv!(p, s, r)     = MPI.Waitall(vcat([MPI.Irecv!(r[k], comm; source = p[k], tag = 7) for k in eachindex(p) if !isempty(r[k])],
+#                                                [MPI.Isend(s[k], comm; dest = p[k], tag = 7) for k in eachindex(p) if !isempty(s[k])]))
+#     allreduce_sum!(b)      = MPI.Allreduce!(b, +, comm)
+const TRANSPORT = Ref{Any}(nothing)
+const TRANSPORT_NRANKS = Ref{Int}(1)
+
+function _transport_allgather(user::Ptr{Cvoid}, send::Ptr{UInt8}, recv::Ptr{UInt8}, bytes::Int64)::Cint
+    try
+        TRANSPORT[][1](unsafe_wrap(Array, recv, bytes * TRANSPORT_NRANKS[]), unsafe_wrap(Array, send, bytes))
+        return Cint(0)
+    catch
+        return Cint(1)                               # (an exception must not unwind through the C frames)
+    end
+end
+function _transport_sendrecv(user::Ptr{Cvoid}, npeers::Int32, peer::Ptr{Int32}, send::Ptr{Ptr{UInt8}}, send_bytes::Ptr{Int64},
+                             recv::Ptr{Ptr{UInt8}}, recv_bytes::Ptr{Int64})::Cint
+    try
+        n = Int(npeers)
+        peers = unsafe_wrap(Array, peer, n); sb = unsafe_wrap(Array, send_bytes, n); rb = unsafe_wrap(Array, recv_bytes, n)
+        sp = unsafe_wrap(Array, send, n); rp = unsafe_wrap(Array, recv, n)
+        TRANSPORT[][2](copy(peers), [unsafe_wrap(Array, sp[k], sb[k]) for k in 1:n], [unsafe_wrap(Array, rp[k], rb[k]) for k in 1:n])
+        return Cint(0)
+    catch
+        return Cint(1)
+    end
+end
+function _transport_allreduce(user::Ptr{Cvoid}, buf::Ptr{Float64}, n::Int64)::Cint
+    try
+        TRANSPORT[][3](unsafe_wrap(Array, buf, n))
+        return Cint(0)
+    catch
+        return Cint(1)
+    end
+end
+
+"""
+    tiles!(eng, nranks, rank, owned_global_index, max_ring, max_rmax, Lx, Ly; id = nothing, transport = nothing,
+           periodic_x = true, periodic_y = true, drift_margin = max(2000.0, max_rmax / 2), rebox_every = 150)
+
+Collective, after `upload!` of the floes this rank owns (those whose centroid lies in its tile; `owned_global_index[i]` =
+the index floe `i` has in the whole field, `max_ring` / `max_rmax` over ALL floes: halo floes arrive unseen).  `id`: the 128
+bytes of `comm_unique_id()` from rank 0, handed round by the host (RCCL between the ranks); `transport` = the three
+collectives described above (the host's channel).  Then `tile_run!` replaces `sz_step`.
+"""
+function tiles!(eng::HIPEngine, nranks::Integer, rank::Integer, owned_global_index::Vector{Int64}, max_ring::Real, max_rmax::Real,
+                Lx::Real, Ly::Real; id = nothing, transport = nothing, periodic_x::Bool = true, periodic_y::Bool = true,
+                drift_margin::Real = max(2000.0, max_rmax / 2), rebox_every::Integer = 150)
+    if transport !== nothing
+        TRANSPORT[] = transport; TRANSPORT_NRANKS[] = nranks
+        t = Ref(SzHostTransport(C_NULL,
+            @cfunction(_transport_allgather, Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ptr{UInt8}, Int64)),
+            @cfunction(_transport_sendrecv, Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Ptr{UInt8}}, Ptr{Int64}, Ptr{Ptr{UInt8}}, Ptr{Int64})),
+            @cfunction(_transport_allreduce, Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64))))
+        check(eng, @ccall lib.sz_comm_init_host(eng.ctx::Ptr{Cvoid}, nranks::Int32, rank::Int32, t::Ptr{SzHostTransport})::Cint)
+    else
+        idp = id === nothing ? C_NULL : pointer(id)
+        GC.@preserve id check(eng, @ccall lib.sz_comm_init(eng.ctx::Ptr{Cvoid}, nranks::Int32, rank::Int32, idp::Ptr{Cvoid})::Cint)
+    end
+    check(eng, @ccall lib.sz_tile_enable(eng.ctx::Ptr{Cvoid}, owned_global_index::Ptr{Int64}, Float64(max_ring)::Float64,
+                                         Float64(max_rmax)::Float64)::Cint)
+    check(eng, @ccall lib.sz_tile_setup(eng.ctx::Ptr{Cvoid}, Float64(Lx)::Float64, Float64(Ly)::Float64, Int32(periodic_x)::Int32,
+                                        Int32(periodic_y)::Int32, Float64(drift_margin)::Float64, Int32(rebox_every)::Int32)::Cint)
+    return
+end
+
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    @ccall(lib.sz_comm_unique_id(id::Ptr{Cvoid})::Cint) == 0 || error("sz_comm_unique_id: RCCL could not be bound")
+    return id
+end
+
+# nsteps x timestep_sim! of the tiled run, collectively (same arguments on every rank)
+function tile_run!(eng::HIPEngine, nsteps::Integer, tstep::Integer, Δt::Integer, coupling_Δt::Integer, flags::Integer)
+    check(eng, @ccall lib.sz_tile_run(eng.ctx::Ptr{Cvoid}, nsteps::Int32, tstep::Int32, Δt::Int32, coupling_Δt::Int32, flags::Int32)::Cint)
+end
+
 writer_periods(w) = Int[x.Δtout for ws in (w.floewriters, w.gridwriters, w.checkpointwriters) for x in ws]
 output_due(w, tstep, start) = tstep == start || any(p -> mod(tstep, p) == 0, writer_periods(w))
 function steps_to_next_output(w, tstep, start)

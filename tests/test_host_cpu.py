@@ -109,6 +109,10 @@ def test_julia_struct_mirrors_match_the_header(tmp_path):
     C compiler lays out from include/subzero_hip.h (Julia lays out isbits / pointer fields like C does)."""
     import subprocess
     js = _julia_structs()
+    # (the transport of tiled runs is four pointers: user + three function pointers, checked on its own below)
+    tr = js.pop("SzHostTransport")
+    assert [f for f, _ in tr] == ["user", "allgather", "sendrecv", "allreduce_sum_f64"] and all(t == "Ptr{Cvoid}" for _, t in tr)
+    assert ctypes.sizeof(capi.SzHostTransport) == 32 and [f for f, _ in capi.SzHostTransport._fields_] == [f for f, _ in tr]
     cnames = {"SzParams": "sz_params", "SzFloeColumns": "sz_floe_columns", "SzStats": "sz_stats"}
     assert set(js) == set(cnames)
     size_of = {"Float64": 8, "Int64": 8, "Int32": 4}
@@ -178,7 +182,8 @@ def test_hot_kernels_keep_their_register_budgets():
     spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
     kr = importlib.util.module_from_spec(spec); spec.loader.exec_module(kr)
     res = kr.resources()
-    budget = {"sz_k_neighbors<true, 24>": (168, 0), "sz_k_neighbors<false, 24>": (128, 0), "sz_k_neighbors<true, 64>": (168, 64),
+    budget = {"sz_k_neighbors<true, 24>": (168, 0), "sz_k_neighbors<false, 24>": (128, 0), "sz_k_neighbors<true, 64>": (256, 0),      # (35 KB of LDS per two wavefronts: two per SIMD whatever the registers)
+              
               "sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 0>": (168, 0), "sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 1>": (168, 0),
               "sz_k_inter_fill": (128, 0), "sz_k_forcing<false>": (128, 0), "sz_k_forcing_mixed": (80, 16), "sz_k_halo_pack": (128, 0)}
     for name, (vg, scratch) in budget.items():
