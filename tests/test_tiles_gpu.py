@@ -39,10 +39,10 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _field(n, seed, fast=False):
+def _field(n, seed, fast=False, shape="star"):
     from subzero_jl_amd import fields
     from subzero_jl_amd import floe as floe_mod
-    cfg = fields.make_config(n_floes=n, seed=seed)
+    cfg = fields.make_config(n_floes=n, seed=seed, shape=shape, **({"spacing": 1.0e4, "ocean": "shear"} if shape == "voronoi" else {}))
     if fast:
         # fast floes on a field shifted so that parents straddle the walls: some start outside the domain, others leave it during the
         # run -- they swap with their ghosts (collisions.jl:942-950), and the forcings of a tiled step are evaluated BEFORE its ghost pass
@@ -52,14 +52,14 @@ def _field(n, seed, fast=False):
     return cfg
 
 
-def _worker(rank, world, port, n, seed, steps, q, repartition=False, fast=False, backend="torch"):
+def _worker(rank, world, port, n, seed, steps, q, repartition=False, fast=False, backend="torch", shape="star"):
     import torch
     import torch.distributed as dist
     from subzero_jl_amd import fields, tiles
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
-        cfg = _field(n, seed, fast)
+        cfg = _field(n, seed, fast, shape)
         tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True, backend=backend, rebox_every=3 if backend != "torch" else 50)
         if repartition:
             # half way through, hand every floe to the other kind of tiling (split along y instead of x): most
@@ -132,6 +132,40 @@ def test_ranks_equal_single(world, n, seed, steps, repartition, fast, backend):
             ref = hw.get(f)[gidx]
             assert np.array_equal(out[f], ref), (rank, f, np.max(np.abs(out[f] - ref)))
     assert seen.all()
+
+
+@pytest.mark.parametrize("world,backend", [(2, "torch"), (4, "library-host")])
+def test_voronoi_field_ranks_equal_single(world, backend):
+    """The reference's own kind of field -- touching Voronoi cells with a size spectrum (the larger neighbour capacity, the chunked
+    candidate pool, halo floes the upload-time count has not seen) -- in tiles: bit-equal to the single context."""
+    import torch.multiprocessing as mp
+    import subzero_jl_amd
+    from subzero_jl_amd import fields
+    n, seed, steps = (900 if world == 2 else 3600), 93, 10          # (a tile holds at most as many halo floes as owned ones: 4 tiles need the larger field)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_run_worker, args=(r, world, port, n, seed, steps, q, False, False, backend, "voronoi")) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = _collect(q, world)
+        for p in procs:
+            p.join(60)
+        assert all(p.exitcode == 0 for p in procs)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    cfg = _field(n, seed, False, "voronoi")
+    hw = fields.build_world(subzero_jl_amd.World(0), cfg)
+    hw.run(steps, 0, cfg["dt"], coupling_dt=1, stop_on_tags=False)
+    seen = np.zeros(n, bool)
+    for rank, gidx, out, nhalo, vx in res:
+        assert nhalo > 0
+        seen[gidx] = True
+        for f in FIELDS:
+            assert np.array_equal(out[f], hw.get(f)[gidx]), (rank, f, np.max(np.abs(out[f] - hw.get(f)[gidx])))
+    assert seen.all() and np.count_nonzero(hw.get("overarea")) > n // 4
 
 
 def _worker_two_way(rank, world, port, n, seed, steps, q, backend="torch"):
