@@ -99,6 +99,7 @@ struct sz_ctx {
   bool gi_pending = false; int gi_pending_n = 0, gi_pending_slot = 0;      // ... still to be fetched from the device (gi_fetch)
   std::vector<int> gi_ref;          // ... and its number among the ghosts in the reference's order (ghost N + gi_ref[k])
   bool retry_seen = false;          // an item has needed the largest narrow variant: sz_step enqueues it in every step from now on
+  bool no_elems_ride = false;       // SZ_ELEMS_RIDE=0: the element items always get their own launch
   bool no_lean_narrow = false;      // SZ_LEAN_NARROW=0: always enqueue it
   int forcing_where = -1;           // sz_forcing_launch
   int fuse_forcing_mode = 0;        // ... 1: in the neighbour launch, 2: in the narrow launch (its tail), 0: by size -- the narrow launch while the narrow phase is one
@@ -391,7 +392,7 @@ void stage_ghosts(sz_ctx* c, bool in_step = false, bool commit = false, bool use
 
 // static_grid: the geometry in S.bounds is the host's (use_static_grid), no bounds kernel; the pair kernel does
 // the housekeeping the bounds kernel would have done
-void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false, bool fuse_forcing = false) {
+void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false, bool fuse_forcing = false, bool with_elems = false) {
   State& S = c->S;
   Timed t(c, SZ_K_BROAD);
   int gM = grid_for(S.capM, 256);
@@ -409,7 +410,11 @@ void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false
   {
     const dim3 gr(grid_for(S.capM, NB_TPB / NB_G, 8192)), bl(NB_TPB);
     const bool fam = c->hostN <= 40000;
-    if (S.maxnb <= MAXNB) {
+    if (with_elems) {          // the element items in the launch's tail (elems_ride)
+      // (no periodic wall, no ghosts, no Dict rule: the search's lean instantiation)
+      const int nbn = (int)gr.x, nbe = grid_for(S.capM, NB_TPB, 1 << 20);
+      hipLaunchKernelGGL(sz_k_neighbors_elem<false>, dim3(nbn + nbe), bl, 0, c->stream, S, next_epoch(c), nbn);
+    } else if (S.maxnb <= MAXNB) {
       if (fam) hipLaunchKernelGGL((sz_k_neighbors<true, MAXNB>), gr, bl, 0, c->stream, S);
       else hipLaunchKernelGGL((sz_k_neighbors<false, MAXNB>), gr, bl, 0, c->stream, S);
     } else {
@@ -503,8 +508,11 @@ void stage_reduce(sz_ctx* c, int mirror, int n_init, int dt, int m_hint = 0) {
 // a step of sz_step: `resume` = the rest of a step that paused after its narrow launch (see stopped_late())
 void collisions_step(sz_ctx* c, int n_init, int dt, bool commit_ghosts, bool static_grid, int fuse_forcing, bool lean, bool resume) {
   if (!resume) {
-    stage_broad(c, commit_ghosts, static_grid, fuse_forcing == 1);
-    stage_elems(c, true);
+    // resident steps of a field between walls: the element items are made in the tail of the neighbour search's launch
+    const bool ride = static_grid && fuse_forcing != 1 && c->S.any_domain_work && !c->S.any_periodic_ew && !c->S.any_periodic_ns &&
+                      c->S.maxnb <= MAXNB && !c->no_elems_ride;
+    stage_broad(c, commit_ghosts, static_grid, fuse_forcing == 1, ride);
+    if (!ride) stage_elems(c, true);
   }
   stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, static_grid, fuse_forcing == 2 ? (c->precision == 1 ? 2 : 1) : 0, resume ? 2 : lean ? 1 : 0);
   stage_reduce(c, 1, n_init, dt, c->S.tiled ? 0 : c->hostN + 3 * c->gl_est + c->hostN / 64 + 32);
@@ -709,6 +717,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_TW_GENERAL_CLIP")) c->tw_general_clip = atoi(e) != 0;
   if (const char* e = getenv("SZ_LEAN_NARROW")) c->no_lean_narrow = atoi(e) == 0;
   if (const char* e = getenv("SZ_GHOST_INLINE")) c->ghost_inline = atoi(e) != 0;
+  if (const char* e = getenv("SZ_ELEMS_RIDE")) c->no_elems_ride = atoi(e) == 0;
   if (const char* e = getenv("SZ_FUSE_FORCING")) { c->fuse_forcing = atoi(e) != 0; if (atoi(e) > 0) c->fuse_forcing_mode = atoi(e) >= 2 ? 2 : 1; }
   if (const char* e = getenv("SZ_STATIC_GRID")) c->no_static_grid = atoi(e) == 0;
   if (const char* e = getenv("SZ_BODY_RINGS")) c->no_body_rings = atoi(e) == 0;
@@ -938,7 +947,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   c->max_sub = 0;
   if (f->sub_off) for (int i = 0; i < N; i++) c->max_sub = std::max(c->max_sub, f->sub_off[i + 1] - f->sub_off[i]);
   DA(gplan, S.capM + 1); DA(gscan4, S.capM + 1); DA(gtot4, 4);
-  DA(lb_agg, S.capM / SCAN_B + 8); DA(lb_inc, S.capM / SCAN_B + 8); DA(lb_flag, S.capM / SCAN_B + 8); c->scan_epoch = 0;
+  DA(lb_agg, S.capM / 128 + 8); DA(lb_inc, S.capM / 128 + 8); DA(lb_flag, S.capM / 128 + 8); c->scan_epoch = 0;      // (tiles of 128 .. SCAN_B elements)
   DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2); DA(gcand, (size_t)2 * S.capM); DA(galloc, 32); DA(gkeys, (size_t)2 * S.capM); DA(fam, S.capM);
   DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1); DA(cell_ovf, S.capCells + 1); DA(cell_slots, (size_t)S.capCells * CELL_K + 8);
   DA(cell_items, S.capM);

@@ -252,9 +252,9 @@ __device__ __forceinline__ void st4_agent(int4* p, int4 v) {
   __hip_atomic_store(q + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(q + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // called by every thread of the workgroup with the tile total; returns the sum of all earlier tiles
-__device__ __forceinline__ int4 lookback_prefix4(State& S, int4 tot, unsigned epoch) {
+__device__ __forceinline__ int4 lookback_prefix4(State& S, int4 tot, unsigned epoch, int tile = -1) {
   __shared__ int4 s_prefix;
-  const int b = blockIdx.x;
+  const int b = tile >= 0 ? tile : (int)blockIdx.x;      // (tile: the scan's workgroups are the tail of a larger launch)
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     if (b == 0) {
@@ -1419,18 +1419,18 @@ __device__ __forceinline__ void elem_candidates(const State& S, int k, F&& emit)
     if (dx * dx + dy * dy < rr * rr) emit(e);
   }
 }
-// count, scan (look-back) and fill of the floe-element items in one launch
-__global__ void __launch_bounds__(SCAN_B) sz_k_elem_scan_fill(State S, unsigned epoch) {
+// count, scan (look-back) and fill of the floe-element items in one launch; tile: this workgroup's number among the scan's workgroups
+__device__ __forceinline__ void elem_scan_fill_body(State& S, unsigned epoch, int tile) {
   __shared__ int4 tot;
   if (stopped(S)) return;
   const int M = S.cnt[C_M];
-  const int base = blockIdx.x * SCAN_B;
-  if (base >= M && blockIdx.x != 0) return;
+  const int base = tile * (int)blockDim.x;
+  if (base >= M && tile != 0) return;
   const int k = base + threadIdx.x;
   int c = 0;
   if (k < M) elem_candidates(S, k, [&](int) { c++; });
   const int4 ex = block_exclusive_scan4(make_int4(c, 0, 0, 0), &tot);
-  const int4 before = lookback_prefix4(S, tot, epoch);
+  const int4 before = lookback_prefix4(S, tot, epoch, tile);
   if (M == 0) { if (k == 0) { S.el_off[0] = 0; S.cnt[C_NELEM] = 0; } return; }
   if (k >= M) return;
   int o = ex.x + before.x;
@@ -1442,6 +1442,15 @@ __global__ void __launch_bounds__(SCAN_B) sz_k_elem_scan_fill(State S, unsigned 
   }
   if (o + c > S.capElem) return;
   elem_candidates(S, k, [&](int e) { S.el_floe[o] = k; S.el_elem[o] = e; o++; });
+}
+__global__ void __launch_bounds__(SCAN_B) sz_k_elem_scan_fill(State S, unsigned epoch) { elem_scan_fill_body(S, epoch, (int)blockIdx.x); }
+// The element items ride in the tail of the neighbour search's launch (fields between walls: nothing in that launch changes the floe
+// count the scan reads -- with periodic walls its first workgroup commits the step's ghosts): the scan's workgroups only wait for
+// one another, they are handed out in index order behind the search's, and its own launch (7 us + a launch boundary) is gone.
+template <bool FAM>
+__global__ void __launch_bounds__(NB_TPB) sz_k_neighbors_elem(State S, unsigned epoch, int nbn) {
+  if ((int)blockIdx.x < nbn) neighbors_body<NB_TPB, FAM, MAXNB>(S, blockIdx.x, nbn);
+  else elem_scan_fill_body(S, epoch, (int)blockIdx.x - nbn);
 }
 
 // ============================================================================ narrow phase (A4-A10)
