@@ -551,6 +551,7 @@ def test_random_call_sequences_match_the_oracle():
     spec = importlib.util.spec_from_file_location("fuzz_sequences", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_sequences.py"))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     assert mod.run(nseeds=10, nops=10, rtol=1e-8, verbose=False) == 0
+    assert mod.run(nseeds=8, nops=10, rtol=1e-8, verbose=False, walls=True) == 0          # ... and between collision walls with topography
 
 
 def test_field_reupload_keeps_the_temperatures():
