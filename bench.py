@@ -218,6 +218,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     if args.rehearse_shared_gpu:
+        if world > 5:
+            raise SystemExit("--rehearse-shared-gpu: at most 5 ranks (the build boxes allow 6 processes on a GPU, and the launcher is one of them)")
         local = 0
     cdev = "cpu" if args.rehearse_shared_gpu else "cuda"          # where the script's own small collectives live
     torch.cuda.set_device(local)
