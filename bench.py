@@ -164,6 +164,19 @@ def pmc_traffic(workload, n_floes, kernel):
     return float(ent["hbm_bytes_per_launch"]), ent.get("source", path)
 
 
+def step_traffic(workload, n_floes, narrow_kernel):
+    """counter traffic of the step's launches from the same committed PMC passes: {launch: bytes} and their sum (None without a pass)"""
+    try:
+        ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"{workload}:{n_floes}", {})
+    except Exception:
+        return None
+    pick = {}
+    for k, v in ent.items():
+        if k == narrow_kernel or k.startswith(("sz_k_neighbors", "sz_k_inter_fill", "sz_k_integrate<true", "sz_k_elem_scan_fill", "sz_k_ghost_list")):
+            pick[k] = float(v["hbm_bytes_per_launch"])
+    return {"per_launch_bytes": pick, "bytes": sum(pick.values())} if pick else None
+
+
 NARROW_KERNEL = "sz_k_narrow<8,18,8,16,4,64,0,0,3,%d>"     # last argument: 0 narrow phase alone, 1 / 2 the step's forcings ride in the launch (fp64 / mixed)
 
 
@@ -404,7 +417,8 @@ def main():
                          "algorithmic_bytes_narrow_only": b_narrow,
                          "counts_per_launch": win, "counts_note": "device counters accumulated over the launches the event time averages (the middle timed block)",
                          "step_algorithmic_bytes": step_bytes,
-                         "step_frac": step_bytes / (el / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         "step_frac": step_bytes / (el / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "step_traffic": step_traffic(workload, cfg["n_floes"], kernel_name) if not tiled else None},
             "kernel_ms_per_step": {k: (v[0] / nb) for k, v in kt_all.items()},
             "kernel_ms_per_step_note": f"separate untimed pass of {nb} steps with all kernel classes event-timed",
             "counts": {k: st[k] for k in ("M", "N", "n_ghosts", "n_pairs", "n_pairs_clipped", "n_pair_rows", "n_elem_rows",
