@@ -409,7 +409,7 @@ void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false
   } else
   {
     const dim3 gr(grid_for(S.capM, NB_TPB / NB_G, 8192)), bl(NB_TPB);
-    const bool fam = c->hostN <= 40000;
+    const bool fam = c->hostN <= 40000 && (S.any_periodic_ew || S.any_periodic_ns);      // (no periodic wall: no ghosts, no Dict rule)
     if (with_elems) {          // the element items in the launch's tail (elems_ride)
       // (no periodic wall, no ghosts, no Dict rule: the search's lean instantiation)
       const int nbn = (int)gr.x, nbe = grid_for(S.capM, NB_TPB, 1 << 20);
