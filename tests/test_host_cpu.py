@@ -179,6 +179,8 @@ def test_hot_kernels_keep_their_register_budgets():
     10 k floes), the lean one under the 128 of four, the narrow phase at 168 with 16 KB of LDS per wavefront (ten wavefronts per
     CU), and none of them may spill.  Read from the code object's metadata -- no GPU needed."""
     import importlib.util
+    from subzero_jl_amd import build as _b
+    _b.build()                                  # (no-op when the library is up to date)
     spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
     kr = importlib.util.module_from_spec(spec); spec.loader.exec_module(kr)
     res = kr.resources()
