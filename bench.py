@@ -29,6 +29,93 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH
 W = 8                        # fp64 bytes
 
 
+def log(msg):
+    """progress line on stderr: what the self-launching parent's watchdog (and a human) sees of a running rank"""
+    sys.stderr.write(f"[bench rank {os.environ.get('RANK', '0')}] {msg}\n"); sys.stderr.flush()
+
+
+def launch_ranks(n, child_cmd, watchdog_s=900.0, shared_gpu=False, extra_env=None, out=None, err=None, poll_s=0.2):
+    """`python3 bench.py --gpus N` without an external launcher: N fresh child processes, one per GPU, started BEFORE this
+    process has imported torch or touched HIP (it never does: the parent only waits).  Every child gets RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run would set them; rank 0's stdout (the ONE JSON line) is
+    passed through, every child's stderr is passed through with its rank in front.  Watchdog: when NO child has written
+    anything for `watchdog_s` seconds, or one has exited non-zero, the children still running are killed (their exact PIDs)
+    and the parent exits non-zero with the stderr tails.  Returns the exit code."""
+    import collections
+    import socket
+    import subprocess
+    import threading
+    out = out or sys.stdout; err = err or sys.stderr
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs, tails, threads = [], [], []
+    last = [time.monotonic()]
+    lines0 = []
+
+    def pump(stream, rank, is_out):
+        for raw in iter(stream.readline, b""):
+            last[0] = time.monotonic()
+            line = raw.decode(errors="replace")
+            if is_out:
+                lines0.append(line)
+            else:
+                tails[rank].append(line)
+                err.write(f"[rank {rank}] {line}"); err.flush()
+        stream.close()
+
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(0 if shared_gpu else r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(extra_env or {})
+        p = subprocess.Popen(list(child_cmd), env=env, stdin=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                             stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL)
+        procs.append(p); tails.append(collections.deque(maxlen=40))
+        t = threading.Thread(target=pump, args=(p.stderr, r, False), daemon=True); t.start(); threads.append(t)
+        if r == 0:
+            t = threading.Thread(target=pump, args=(p.stdout, 0, True), daemon=True); t.start(); threads.append(t)
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill(); p.wait()
+
+    rc, why = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc, why = 1, f"rank {bad[0][0]} exited with code {bad[0][1]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() - last[0] > watchdog_s:
+            rc, why = 3, f"no rank wrote anything for {watchdog_s:.0f} s"
+            break
+        time.sleep(poll_s)
+    if rc:
+        kill_all()
+    for t in threads:
+        t.join(timeout=5.0)
+    if rc:
+        err.write(f"[bench launcher] {why}; children killed.  stderr tails:\n")
+        for r, tl in enumerate(tails):
+            err.write(f"--- rank {r} ---\n" + "".join(tl))
+        err.flush()
+        return rc
+    js = [l for l in lines0 if l.lstrip().startswith("{")]
+    if len(js) != 1:
+        err.write(f"[bench launcher] rank 0 printed {len(js)} JSON lines, expected 1\n"); err.flush()
+        return 4
+    out.write(js[0]); out.flush()
+    return 0
+
+
 def narrow_algorithmic_bytes(st):
     """B_narrow of SURVEY.md §8(d): both rings of every pair executed (2 coordinates x w per point)
     plus 7 scalars of both floes, and every contact row written (floe-floe rows twice: i and mirrored
@@ -158,9 +245,14 @@ def pmc_traffic(workload, n_floes, kernel):
         table = json.load(open(path))
     except Exception:
         return None, "profiles/pmc_traffic.json not found"
-    ent = table.get(f"{workload}:{n_floes}", {}).get(kernel)
+    grp = table.get(f"{workload}:{n_floes}", {})
+    ent = grp.get(kernel)
     if ent is None:
-        return None, f"no committed PMC pass for {workload} at {n_floes} floes (tools/profile_round.sh makes one)"
+        return None, f"no committed PMC pass for {kernel} of {workload} at {n_floes} floes (tools/profile_round.sh makes one)"
+    sha = (grp.get("_meta") or {}).get("kernel_source_sha16")
+    if sha != kernel_source_sha16():
+        return None, (f"the committed PMC pass was made on other kernel sources (sha {sha}, now {kernel_source_sha16()}): "
+                      f"not quoted; tools/profile_round.sh makes a new one")
     return float(ent["hbm_bytes_per_launch"]), ent.get("source", path)
 
 
@@ -170,19 +262,88 @@ def step_traffic(workload, n_floes, narrow_kernel):
         ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"{workload}:{n_floes}", {})
     except Exception:
         return None
+    if (ent.get("_meta") or {}).get("kernel_source_sha16") != kernel_source_sha16():
+        return None          # (measured on other kernel sources: see roofline.traffic_source)
     pick = {}
     for k, v in ent.items():
+        if k == "_meta":
+            continue
         if k == narrow_kernel or k.startswith(("sz_k_neighbors", "sz_k_inter_fill", "sz_k_integrate<true", "sz_k_elem_scan_fill", "sz_k_ghost_list")):
             pick[k] = float(v["hbm_bytes_per_launch"])
     return {"per_launch_bytes": pick, "bytes": sum(pick.values())} if pick else None
 
 
-NARROW_KERNEL = "sz_k_narrow<8,18,8,16,4,64,0,0,3,%d>"     # last argument: 0 narrow phase alone, 1 / 2 the step's forcings ride in the launch (fp64 / mixed)
+def kernel_source_sha16():
+    """sha256 (first 16 hex digits) of the kernel sources: the committed PMC table is only quoted for the code it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "subzero.jl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hpp", ".hip")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def forcing_algorithmic_bytes(st):
     """B_force of SURVEY.md §8(d): two coordinates per sub-floe point, 8 columns read and 4 written per floe"""
     return 2 * W * st["n_sub_points"] + st["N"] * (8 * W + 4 * W)
+
+
+PARITY_COLS = ["cx", "cy", "alpha", "u", "v", "xi", "height", "mass", "moment", "p_dxdt", "p_dydt", "p_dalphadt", "p_dudt", "p_dvdt",
+               "p_dxidt", "fxOA", "fyOA", "trqOA", "overarea", "coll_fx", "coll_fy", "coll_trq", "stress_accum", "stress_instant", "strain"]
+
+
+def oracle_parity(cfg, device, steps=2, coupling_dt=1):
+    """Parity evidence for the very field the bench times (N = 1 line): add_ghosts! + timestep_collisions! of the HIP engine against the
+    CPU oracle -- pair list bit-exact?, worst interaction-row element relative to tests/parity.py's per-element tolerance (rtol 1e-10 +
+    the round-off floor of the reference's own shoelace sums) -- then `steps` resident timesteps against the oracle's timestep_sim!
+    (largest max-norm relative error over the state columns).  The oracle is the checker here, never the thing measured."""
+    import numpy as np
+    import subzero_jl_amd
+    from subzero_jl_amd import fields
+    from oracle import orc
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity
+    n = cfg["n_floes"]
+    out = {"steps": steps, "n_floes": n}
+    try:
+        hw = fields.build_world(subzero_jl_amd.World(device), cfg); ow = fields.build_world(orc.World(), cfg)
+        ow.set_threads(len(os.sched_getaffinity(0)))
+        hw.add_ghosts(); ow.add_ghosts()
+        out["ghosts_equal"] = bool(hw.M == ow.M and hw.ghosts() == ow.ghosts())
+        hw.timestep_collisions(n, cfg["dt"]); ow.timestep_collisions(n, cfg["dt"])
+        hi, hj = hw.pairs(); oi, oj = ow.pairs()
+        out["n_pairs"] = int(len(oi))
+        out["pairs_equal"] = bool(len(hi) == len(oi) and np.array_equal(hi, oi) and np.array_equal(hj, oj))
+        hoff, hrows = hw.interactions(); ooff, orows = ow.interactions()
+        out["n_rows"] = int(len(orows))
+        if np.array_equal(hoff, ooff) and np.array_equal(hrows[:, 0], orows[:, 0]):
+            fl = parity.force_floors(orows, float(np.max(ow.get("rmax"))))
+            worst = 0.0; rel = 0.0
+            for c, floor in ((1, fl["force"]), (2, fl["force"]), (5, fl["torque"]), (6, fl["area"]), (3, 1e-10 * fl["Lc"]), (4, 1e-10 * fl["Lc"])):
+                r, _ = parity.worst_element(hrows[:, c], orows[:, c], 1e-10, floor); worst = max(worst, r)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    e = np.abs(hrows[:, c] - orows[:, c]) / np.maximum(np.abs(orows[:, c]), floor if floor > 0 else 1e-300)
+                rel = max(rel, float(np.nanmax(e)) if len(e) else 0.0)
+            out["rows_equal_structure"] = True
+            out["max_rel_row_err"] = rel                      # |a - b| / max(|b|, floor) over all row elements
+            out["rows_within_1e-10"] = bool(worst <= 1.0)     # the suite's criterion: |a - b| <= 1e-10 |b| + floor
+        else:
+            out["rows_equal_structure"] = False
+        del hw, ow
+        hw = fields.build_world(subzero_jl_amd.World(device), cfg); ow = fields.build_world(orc.World(), cfg)
+        ow.set_threads(len(os.sched_getaffinity(0)))
+        hw.run(steps, 0, cfg["dt"], coupling_dt=coupling_dt)
+        for t in range(steps):
+            ow.timestep_sim(t, cfg["dt"], coupling_dt=coupling_dt)
+        errs = {f: parity.relerr(hw.get(f), ow.get(f)) for f in ("cx", "cy", "alpha", "u", "v", "xi", "coll_fx", "coll_fy", "coll_trq", "fxOA", "fyOA", "trqOA", "sa11", "sa22", "e11")}
+        out["max_rel_state_err_after_steps"] = max(errs.values())
+        out["state_within_1e-9"] = bool(max(errs.values()) <= 1e-9)
+        out["guards_equal"] = bool(np.array_equal(hw.warn_counts(), ow.warn_counts()))
+        out["ok"] = bool(out["ghosts_equal"] and out["pairs_equal"] and out.get("rows_within_1e-10", False) and out["state_within_1e-9"])
+    except Exception as e:      # noqa: BLE001  (a line with the reason beats no line)
+        out["ok"] = False; out["error"] = str(e)[:300]
+    return out
 
 
 def main():
@@ -206,12 +367,34 @@ def main():
     ap.add_argument("--coupling-dt", type=int, default=1, help="couple every k-th step (reference default: 10)")
     ap.add_argument("--relax-steps", type=int, default=50, help="untimed steps before the warm-up: the fields are generated on a jittered lattice "
                     "with overlapping neighbours and then relaxed, as SURVEY.md §8(d) specifies for the synthetic configurations (50 steps)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline and the oracle parity of the timed field)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true", help="N > 1 ranks that all use GPU 0, with gloo between them and the library's exchange "
                     "over the host channel (sz_comm_init_host): runs the whole multi-rank flow of this script on a one-GPU box; the "
                     "line it prints says so and is NOT a measurement")
     ap.add_argument("--force-tiled", action="store_true", help="run the halo/RCCL path even with one rank")
+    ap.add_argument("--watchdog", type=float, default=900.0, help="self-launched N > 1 runs: seconds without a line from ANY rank after which the "
+                    "parent kills the ranks and exits non-zero")
+    ap.add_argument("--no-strong-reference", action="store_true", help="N = 1: skip the extra leg that times the multi-GPU workload (configs[2], 100 000 floes) "
+                    "in one context on this GPU -- the denominator of the strong-scaling curve, which the N > 1 lines are measured on")
+    ap.add_argument("--parity-steps", type=int, default=3, help="tiled runs: steps after which the owned columns of all ranks are compared with a "
+                    "single-context run of the same field on rank 0 (tiled_parity in the line); 0: skip")
     args = ap.parse_args()
+
+    # `python3 bench.py --gpus N` with no launcher around it: this process becomes the launcher -- N fresh children, one per GPU, before
+    # torch is imported or HIP touched (the children see WORLD_SIZE and run the code below; `python -m torch.distributed.run ... bench.py`
+    # sets it too, so the wrapped form takes the same path)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        child = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+        rc = launch_ranks(args.gpus, child, watchdog_s=args.watchdog, shared_gpu=args.rehearse_shared_gpu)
+        if rc != 0 and "SZ_TILES_BACKEND" not in os.environ and not args.rehearse_shared_gpu:
+            # The library's own RCCL exchange with real peers could not be exercised on the one-GPU build boxes.  Should it fail or
+            # hang on the first multi-GPU run, ONE more attempt is made with fresh processes and the torch.distributed exchange
+            # (all_to_all_single on the buffers the library packs); the line then says so.
+            sys.stderr.write(f"[bench launcher] first attempt ended with code {rc}; one more with SZ_TILES_BACKEND=torch\n"); sys.stderr.flush()
+            rc = launch_ranks(args.gpus, child, watchdog_s=args.watchdog, shared_gpu=False,
+                              extra_env={"SZ_TILES_BACKEND": "torch", "SZ_BENCH_NOTE": f"the run with the library's RCCL exchange ended with launcher code {rc}; "
+                                                                                        "this line is the second attempt (torch.distributed all_to_all_single)"})
+        sys.exit(rc)
 
     # RCCL prints a version banner on stdout; the contract is ONE JSON line there.  Everything the
     # libraries write to fd 1 goes to stderr, the JSON line is written to the saved descriptor.
@@ -227,7 +410,7 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     if args.rehearse_shared_gpu:
@@ -238,13 +421,16 @@ def main():
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or args.force_tiled:
+        import datetime
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29533"
+        # every rank builds the 100 k-floe field on the host first (tens of seconds), rank 0 also runs the one-GPU reference: generous timeouts
         if args.rehearse_shared_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=datetime.timedelta(minutes=30))
+    log(f"start: world {world}, device {local}")
 
     # BASELINE.json: "floe-steps/sec at 10k/100k floes, 1/2/4/8 MI355X" -- one GPU: configs[1] (10 000 floes, uniform flow);
     # several GPUs: the strong-scaling workload, configs[2] (100 000 floes, converge/diverge flow) cut into spatial tiles.
@@ -256,7 +442,7 @@ def main():
     elif world > 1:
         n_total, scaling = 100000, "strong"
     else:
-        n_total, scaling = 10000, "weak"
+        n_total, scaling = 10000, "strong"          # (one GPU, one fixed job: the N = 1 point of either curve)
     workload = args.workload or ("configs2" if (world > 1 and args.floes == 0) else "configs1")
     wl = {"configs1": dict(seed=12345), "configs2": dict(seed=12346, ocean="converge_diverge"),
           "configs3": dict(seed=12345, walls=True, topography=True, ocean="strait"),
@@ -264,8 +450,13 @@ def main():
           # the reference's own kind of field (initialize_floe_field): touching Voronoi cells, a size spectrum -> the larger neighbour capacity
           "voronoi": dict(seed=12345, shape="voronoi", ocean="shear")}[workload]
     cfg = fields.make_config(n_floes=n_total, **wl)
+    log(f"field built: {workload}, {n_total} floes")
     coupling_dt = args.coupling_dt
     tiled = not (world == 1 and not args.force_tiled)
+    tiled_parity = None
+    ref = None                     # rank 0 of a tiled run: the same field in ONE context (parity check, then the one-GPU reference point)
+    ref_steps = 0                  # steps that context has behind it
+    steps_run = 0                  # steps every context has behind it when the warm-up starts
     if not tiled:
         hw = fields.build_world(subzero_jl_amd.World(local), cfg)
         if args.two_way:
@@ -285,28 +476,55 @@ def main():
             t = tiles.TiledWorld(cfg, rank, world, local, dist, always_exchange=args.force_tiled, backend=be, host_staging=args.rehearse_shared_gpu, rebox_every=150)
             t.repartition_every = 10 ** 9     # floes drift metres per step against tiles of hundreds of km: no re-tiling inside a bench run
             return t
-        # the library-side exchange binds RCCL at run time: if any rank cannot set it up (no librccl to bind, communicator refused),
-        # ALL ranks fall back to the torch.distributed exchange together -- a line with a note beats no line
-        err = None
+        # The library-side exchange binds RCCL at run time.  TiledWorld agrees on a failed SET-UP between the ranks before any
+        # mismatched collective (tiles.py: every rank raises TileSetupError together); then ALL ranks fall back to the
+        # torch.distributed exchange -- a line with a note beats no line.  (A failure inside a RUNNING exchange cannot be agreed
+        # on: sz_tile_run returns the same error code on every rank at the end of the batch, and that is fatal here.)
         try:
             tw = make_tiles(backend)
-            tw.run(2, 0, cfg["dt"], coupling_dt=coupling_dt)           # first exchange (boxes, capacities, one send / receive)
-        except Exception as e:      # noqa: BLE001
-            err = str(e)[:300]
-        if dist is not None:
-            flag = torch.tensor([1 if err else 0], device=cdev, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            failed = bool(flag.item())
-        else:
-            failed = err is not None
-        if failed:
+        except tiles.TileSetupError as e:
             if backend != "library":
-                raise RuntimeError(err or "another rank failed to set up its tile")
-            backend_note = f"library exchange unavailable ({err or 'on another rank'}); torch.distributed all_to_all_single instead"
+                raise
+            backend_note = f"library exchange unavailable ({str(e)[:200]}); torch.distributed all_to_all_single instead"
+            log(backend_note)
             backend = "torch"
             tw = make_tiles(backend)
         hw = tw.world
+        if args.precision == "mixed":
+            hw.set_precision("mixed")
         runner = lambda n, t0: tw.run(n, t0, cfg["dt"], coupling_dt=coupling_dt)
+        log(f"tile set up: {len(tw.gidx)} owned floes, exchange = {backend}")
+        # ---- tiled result against the single context, at config scale: k steps of the timed field, owned columns of every rank
+        # gathered on rank 0 and compared bit for bit with ONE context stepping the whole field there
+        k = max(0, min(args.parity_steps, args.relax_steps if args.relax_steps > 0 else args.parity_steps))
+        if k > 0 and dist is not None:
+            runner(k, 0); steps_run = k
+            mine = {"gidx": tw.gidx.copy()}
+            for f in PARITY_COLS:
+                mine[f] = hw.get(f)[:len(tw.gidx)]
+            parts = [None] * world if rank == 0 else None
+            dist.gather_object(mine, parts, dst=0)
+            if rank == 0:
+                tiled_parity = {"steps": k, "ranks": world, "columns": len(PARITY_COLS)}
+                try:
+                    ref = fields.build_world(subzero_jl_amd.World(local), cfg)
+                    ref.set_precision(args.precision)
+                    ref.run(k, 0, cfg["dt"], coupling_dt=coupling_dt, stop_on_tags=False); ref_steps = k
+                    g = np.concatenate([p_["gidx"] for p_ in parts])
+                    bad = {}
+                    worst = 0.0
+                    for f in PARITY_COLS:
+                        a = np.concatenate([p_[f] for p_ in parts]); b = ref.get(f)[g]
+                        if not np.array_equal(a, b):
+                            sc = max(float(np.max(np.abs(b))), 1e-300)
+                            bad[f] = float(np.max(np.abs(a - b)) / sc); worst = max(worst, bad[f])
+                    tiled_parity.update(floes_compared=int(len(g)), all_floes_covered=bool(len(g) == cfg["n_floes"] and len(np.unique(g)) == len(g)),
+                                        bit_equal=not bad, columns_differing=bad, max_rel_diff=worst,
+                                        ok=bool(not bad and len(g) == cfg["n_floes"]))
+                except Exception as e:      # noqa: BLE001
+                    tiled_parity.update(ok=False, error=str(e)[:300])
+                log(f"tiled parity after {k} steps: {tiled_parity}")
+            del mine, parts
 
     def barrier():
         torch.cuda.synchronize()
@@ -314,9 +532,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if args.relax_steps > 0:
-        runner(args.relax_steps, 0)          # part of the workload's definition, not of the measurement
-    runner(args.warmup, args.relax_steps)
+    # ---- the oracle's word on the very field this run times (N = 1): before the timing, on fresh contexts
+    parity_line = None
+    if not tiled and not args.no_cpu_baseline and rank == 0 and not args.two_way and args.precision == "f64":
+        parity_line = oracle_parity(cfg, local, steps=2, coupling_dt=coupling_dt)
+        log(f"oracle parity: {parity_line}")
+
+    if args.relax_steps > steps_run:
+        runner(args.relax_steps - steps_run, steps_run)          # part of the workload's definition, not of the measurement
+    t_relaxed = max(args.relax_steps, steps_run)
+    runner(args.warmup, t_relaxed)
+    log("relaxed and warm")
     # Inside the timed region the dominant kernel is bracketed by HIP events (one pair per step, on the stream it is launched on) --
     # in ONE of the timed blocks, the middle one (its launches are typical of the window: the narrow phase gets cheaper as the contact network
     # relaxes): an event pair makes the kernel before and the kernel after it wait ~6 us each (kernel
@@ -325,7 +551,7 @@ def main():
     nrep = max(1, args.repeats)
     kt = st_ev = forcing_where = None
     blocks = []
-    tstep = args.relax_steps + args.warmup
+    tstep = t_relaxed + args.warmup
     for rep in range(nrep):
         if rep == nrep // 2:
             hw.profile(True, only="narrow")          # also clears the cumulative narrow-phase work counters: they count the launches the events time
@@ -343,10 +569,12 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         blocks.append(el)
+        log(f"block {rep}: {1e3 * el / args.steps:.4f} ms/step")
     el = float(np.median(blocks))
     if kt is None:                            # (the event-timed block was the last one)
         kt = hw.kernel_times(); st_ev = hw.stats(); forcing_where = hw.forcing_launch()
     st = hw.stats()                           # counts of the last step (st_ev: the cumulative work counters of the event-timed block)
+    kernel_name = hw.narrow_kernel_name()
     ceiling = measured_hbm_ceiling(torch, torch.device("cuda", local)) if rank == 0 else 0.0
     # per-class breakdown from a second, untimed pass with every class event-timed
     nb = max(1, min(args.steps, 50))
@@ -355,23 +583,32 @@ def main():
     torch.cuda.synchronize()
     kt_all = hw.kernel_times()
     hw.profile(False)
-    # strong scaling: the same workload on ONE GPU (rank 0, a second context beside its tile), so that the line carries its
-    # own reference point; the other ranks wait at the barrier
+    # strong scaling: the same workload on ONE GPU (rank 0, the context of the parity check beside its tile) through the SAME regime --
+    # the same relaxation and warm-up, the same step window, blocks of the same length, median -- so that the line carries its own
+    # reference point; the other ranks wait at the barrier
     one_gpu = None
     if tiled and world > 1:
         if rank == 0:
             try:
-                ref = fields.build_world(subzero_jl_amd.World(local), cfg)
-                ref.set_precision(args.precision)
-                ref.run(10, 0, cfg["dt"], coupling_dt=coupling_dt, stop_on_tags=False)
-                torch.cuda.synchronize(); t1 = time.perf_counter()
-                k1 = max(10, min(args.steps, 50))
-                ref.run(k1, 10, cfg["dt"], coupling_dt=coupling_dt, stop_on_tags=False)
-                torch.cuda.synchronize()
-                one_gpu = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / k1, "steps": k1, "note": "same field, one context on rank 0's GPU, steps 10.. of the run"}
+                if ref is None:
+                    ref = fields.build_world(subzero_jl_amd.World(local), cfg); ref.set_precision(args.precision); ref_steps = 0
+                rr = lambda n, t0: ref.run(n, t0, cfg["dt"], coupling_dt=coupling_dt, stop_on_tags=False)
+                if t_relaxed > ref_steps:
+                    rr(t_relaxed - ref_steps, ref_steps)
+                rr(args.warmup, t_relaxed)
+                rb = []; ts = t_relaxed + args.warmup
+                for rep in range(nrep):
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    rr(args.steps, ts)
+                    torch.cuda.synchronize(); rb.append(time.perf_counter() - t1); ts += args.steps
+                one_gpu = {"ms_per_step": 1e3 * float(np.median(rb)) / args.steps, "ms_per_step_min": 1e3 * min(rb) / args.steps,
+                           "ms_per_step_max": 1e3 * max(rb) / args.steps, "steps": args.steps, "repeats": nrep,
+                           "note": f"same field in one context on rank 0's GPU, same {t_relaxed} relaxation + {args.warmup} warm-up steps, the same step window "
+                                   f"({t_relaxed + args.warmup}..{ts}), median of {nrep} blocks"}
                 del ref
             except Exception as e:      # noqa: BLE001
                 one_gpu = {"error": str(e)[:200]}
+            log(f"one-GPU reference: {one_gpu}")
         barrier()
 
     if rank == 0:
@@ -384,7 +621,6 @@ def main():
         b_narrow = narrow_algorithmic_bytes(win)
         # small fields: the step's forcings ride in the narrow launch (its tail) -- the launch the events bracket then does both
         rides = forcing_where == 2 and coupling_dt == 1
-        kernel_name = NARROW_KERNEL % ((2 if args.precision == "mixed" else 1) if rides else 0)
         b_launch = b_narrow + (forcing_algorithmic_bytes(st) if rides else 0)
         achieved = b_launch / (narrow_ms * 1e-3) / 1e9 if narrow_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic(workload, cfg["n_floes"], kernel_name) if not tiled else (None, "tiled run")
@@ -403,11 +639,11 @@ def main():
                                     if workload == "configs2" else
                                     f"{'configs[' + workload[-1] + ']-style' if workload[-1].isdigit() else workload} field ({wl}): {cfg['n_floes']} floes, box {cfg['L'] / 1e3:.0f} km, boundaries {cfg['kinds'][0]}, "
                                     f"{len(cfg['topography'])} topography elements") +
-                                   f", {args.relax_steps} relaxation steps after generation" +
+                                   f", {t_relaxed} relaxation steps after generation (since round 2; round 1 timed the unrelaxed field)" +
                                    f"; collisions + one-way coupling every {coupling_dt} step(s) + rigid-body update, dt={cfg['dt']} s" +
                                    (f"; {world} spatial tiles, one-deep ghost-floe halo per step" if tiled else ""),
                        "n_floes": cfg["n_floes"], "seed": cfg["seed"], "coupling_dt": coupling_dt, "two_way_coupling": bool(args.two_way),
-                       "tiles": world if tiled else 1},
+                       "tiles": world if tiled else 1, "timed_step_window": [t_relaxed + args.warmup, tstep]},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
                          "kernel_note": ("narrow phase + the step's forcings in one launch (the forcings run in the tail of the narrow phase's single round): "
                                          "algorithmic bytes = B_narrow + B_force") if rides else "narrow phase",
@@ -426,6 +662,10 @@ def main():
             "tags_at_end_of_timed_window": {"n_status_remove": st["n_status_remove"], "n_status_fuse": st["n_status_fuse"],
                                             "note": "floes the reference's simplify_floes! would have acted on during the run (0 = the timed steps are the reference's trajectory)"},
         }
+        if parity_line is not None:
+            out["parity"] = parity_line
+        if tiled_parity is not None:
+            out["tiled_parity"] = tiled_parity
         if one_gpu is not None:
             out["one_gpu_same_workload"] = one_gpu
             if "ms_per_step" in one_gpu:
@@ -434,14 +674,40 @@ def main():
             out["config"]["halo_exchange"] = backend if world > 1 or args.force_tiled else None
             if backend_note:
                 out["config"]["halo_exchange_note"] = backend_note
+        if os.environ.get("SZ_BENCH_NOTE"):
+            out["note"] = os.environ["SZ_BENCH_NOTE"]
         if args.rehearse_shared_gpu:
             out["data"] = "REHEARSAL: all ranks share GPU 0, transfers over gloo through the host -- not a measurement"
+        if world == 1 and not tiled and workload == "configs1" and args.floes == 0 and args.total_floes == 0 and not args.no_strong_reference:
+            # the N > 1 lines of this script time configs[2] (100 000 floes, strong scaling): the same field in ONE context on this GPU, through
+            # the same regime, is the N = 1 point of THAT curve (this line's `value` is the metric's one-GPU configuration, configs[1])
+            try:
+                log("strong-scaling reference: configs[2] on this GPU ...")
+                del hw
+                cfg2 = fields.make_config(n_floes=100000, seed=12346, ocean="converge_diverge")
+                w2 = fields.build_world(subzero_jl_amd.World(local), cfg2); w2.set_precision(args.precision)
+                r2 = lambda n, t0: w2.run(n, t0, cfg2["dt"], coupling_dt=coupling_dt, stop_on_tags=False)
+                r2(args.relax_steps, 0); r2(args.warmup, args.relax_steps)
+                b2 = []; ts = args.relax_steps + args.warmup
+                for rep in range(nrep):
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    r2(args.steps, ts)
+                    torch.cuda.synchronize(); b2.append(time.perf_counter() - t1); ts += args.steps
+                m2 = float(np.median(b2))
+                out["strong_scaling_workload_on_one_gpu"] = {
+                    "workload": f"configs[2]: 100000 random-polygon floes, doubly periodic box {cfg2['L'] / 1e3:.0f} km, converge_diverge_flow ocean (what --gpus N > 1 times, cut into tiles)",
+                    "value": 100000 * args.steps / m2, "unit": "floe-steps/s", "ms_per_step": 1e3 * m2 / args.steps,
+                    "ms_per_step_min": 1e3 * min(b2) / args.steps, "ms_per_step_max": 1e3 * max(b2) / args.steps, "steps": args.steps, "repeats": nrep,
+                    "note": "the denominator for strong scaling 1 -> N GPUs at 100k floes; not this line's `value`"}
+                del w2, cfg2
+            except Exception as e:      # noqa: BLE001
+                out["strong_scaling_workload_on_one_gpu"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
+            log("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(cfg, relax_steps=args.relax_steps)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
-
 
 if __name__ == "__main__":
     main()

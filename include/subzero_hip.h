@@ -223,6 +223,8 @@ int sz_kernel_time_ms(sz_ctx *ctx, int32_t kclass, double *ms, int64_t *launches
    1 the neighbour search's, 2 the narrow phase's first variant (class SZ_K_NARROW then times both: a small field's narrow
    phase is one round with a long tail, and the forcings run in that tail), -1 no coupling step yet */
 int sz_forcing_launch(sz_ctx *ctx, int32_t *where);
+/* name of the dominant kernel's instantiation as a kernel trace (rocprofv3) prints it, for the last batch: buf gets at most n bytes */
+int sz_narrow_kernel_name(sz_ctx *ctx, char *buf, int32_t n);
 
 /* ---- multi-GPU halo support (no counterpart in the single-process reference:
    its periodic ghost floes, collisions.jl:881-1047, are the same pattern inside one address
@@ -277,7 +279,11 @@ int sz_set_stream(sz_ctx *ctx, void *hip_stream);
                          records, slots per pair sized at the last gather), forcings of the owned floes beside the exchange,
                          unpack + step.  Two-way coupling partial sums are all-reduced.  A floe that moves further than half
                          the margin between two gathers is an error (halo-drift bit), never a silently missed contact.
+                         Device errors are per rank; the ranks agree on them at every box gather and at the end of the call,
+                         so that EVERY rank returns the same code at the same step (a rank leaving on its own would hang the
+                         others: RCCL has no timeout).  A new sz_upload_floes invalidates sz_tile_enable / sz_tile_setup.
      sz_comm_allreduce   sum of n doubles in device memory over the ranks, in place (sz_eulerian_partial / sz_two_way_partial) */
+int sz_comm_available(void);   /* SZ_OK when RCCL can be bound in this process; ask on every rank and agree before sz_comm_init (collective) */
 int sz_comm_unique_id(void *id128);
 int sz_comm_init(sz_ctx *ctx, int32_t nranks, int32_t rank, const void *id128);
 /* The same tiled run over the HOST's own channel between its ranks, for hosts whose ranks cannot open an RCCL communicator

@@ -500,6 +500,12 @@ class World:
         self._chk(self.L.sz_forcing_launch(self.h, w.ctypes.data_as(C.POINTER(C.c_int32))))
         return int(w[0])
 
+    def narrow_kernel_name(self):
+        """the dominant kernel's instantiation as a kernel trace names it, for the last batch"""
+        buf = C.create_string_buffer(128)
+        self._chk(self.L.sz_narrow_kernel_name(self.h, buf, 128))
+        return buf.value.decode()
+
     def kernel_times(self):
         out = {}
         for k, name in enumerate(capi.KERNEL_CLASS_NAMES):

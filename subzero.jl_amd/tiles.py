@@ -121,6 +121,11 @@ def host_transport(dist, rank, world):
     return t
 
 
+class TileSetupError(capi.SzError):
+    """the exchange could not be set up -- raised on EVERY rank together (the ranks agree on it before any collective that
+    one of them would miss), so that a caller may fall back to another backend on all ranks at once"""
+
+
 class TiledWorld:
     """One rank of a tiled run.  `dist` is torch.distributed (initialised) or None for world == 1."""
 
@@ -137,6 +142,7 @@ class TiledWorld:
         self.cfg, self.rank, self.nranks, self.dist = cfg, rank, world, dist
         self.backend = backend
         self.host_staging = host_staging          # gloo: exchange through CPU tensors
+        self.world_device = device
         self.always_exchange = always_exchange    # run the collectives even with one rank (tests)
         self.L = cfg["L"]
         self.per_x = cfg["kinds"][2] == "periodic"; self.per_y = cfg["kinds"][0] == "periodic"
@@ -168,14 +174,21 @@ class TiledWorld:
         self.cap = 0                                          # record slots per peer, sized from a counting pass
         self.send = self.recv = None
         if backend == "library":
+            # Every step below that can fail on ONE rank is agreed on before the next collective: a rank that raised while its
+            # peers waited in a broadcast or inside ncclCommInitRank would hang the job (no JSON line, no error message).
             uid = (C.c_char * 128)()
             if world > 1:
+                self._agree(w.L.sz_comm_available() == 0, "RCCL cannot be bound by libsubzero_hip.so on some rank (librccl missing, or SZ_RCCL_DISABLE)")
+                ok = True
                 if rank == 0:
-                    w._chk(w.L.sz_comm_unique_id(C.cast(uid, C.c_void_p)))
-                box = [bytes(uid)]
-                dist.broadcast_object_list(box, src=0)          # any host channel does: the id is 128 opaque bytes
+                    ok = w.L.sz_comm_unique_id(C.cast(uid, C.c_void_p)) == 0
+                box = [bytes(uid) if ok else None]
+                dist.broadcast_object_list(box, src=0)          # any host channel does: the id is 128 opaque bytes (None: rank 0 could not make one)
+                if box[0] is None:
+                    raise TileSetupError("ncclGetUniqueId failed on rank 0")
                 uid = (C.c_char * 128).from_buffer_copy(box[0])
-            w._chk(w.L.sz_comm_init(w.h, world, rank, C.cast(uid, C.c_void_p)))
+            rc = w.L.sz_comm_init(w.h, world, rank, C.cast(uid, C.c_void_p))
+            self._agree(rc == 0, f"sz_comm_init failed on some rank ({w.L.sz_last_error(w.h).decode() if rc else 'not this one'})")
         elif backend == "library-host":
             self._transport = host_transport(dist, rank, world)          # (kept alive: the library calls into it)
             w._chk(w.L.sz_comm_init_host(w.h, world, rank, C.byref(self._transport)))
@@ -195,6 +208,17 @@ class TiledWorld:
         self.boxes = None
         self.steps_since_box = 0
         self.tw_buf = None                                    # per-cell partial sums of the two-way coupling
+
+    def _agree(self, ok, what):
+        """collective: raise TileSetupError on every rank when `ok` is false on any of them"""
+        if self.dist is None or self.nranks == 1:
+            if not ok:
+                raise TileSetupError(what)
+            return
+        t = self.torch.tensor([0 if ok else 1], dtype=self.torch.int32, device="cpu" if self.host_staging else self.torch.device("cuda", self.world_device))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        if int(t.item()):
+            raise TileSetupError(what)
 
     # ---- collectives
     def _drift_since_last_gather(self):

@@ -350,7 +350,7 @@ def test_converge_diverge_100k_properties():
     forces cancel over the parents, no guard fires for the forcings, state stays finite over 5 steps."""
     from subzero_jl_amd import fields
     n = 100000
-    cfg = fields.make_config(n_floes=n, seed=12346, ocean="converge_diverge")
+    cfg = _bench_cfg("configs2")
     hw = fields.build_world(mk(), cfg)
     hw.run(5, 0, cfg["dt"], coupling_dt=1)
     st = hw.stats()
@@ -388,6 +388,74 @@ def test_full_size_properties():
     assert np.all(np.abs(tot) <= 1e-9 * fscale * len(rows)), tot     # internal forces cancel over the parents
     assert abs(hw.get("coll_fx")[:n].sum()) <= 1e-9 * fscale * len(rows)
     assert np.all(hw.get("coll_fx")[n:] == 0)
+
+
+# ---------------------------------------------------------------- the oracle at the sizes the metric is quoted on
+import functools
+import os
+
+
+@functools.lru_cache(maxsize=2)
+def _bench_cfg(workload):
+    """the very fields bench.py times (same generator arguments as its workload table)"""
+    from subzero_jl_amd import fields
+    wl = {"configs1": dict(n_floes=10000, seed=12345), "configs3": dict(n_floes=10000, seed=12345, walls=True, topography=True, ocean="strait"),
+          "configs2": dict(n_floes=100000, seed=12346, ocean="converge_diverge")}[workload]
+    return fields.make_config(**wl)
+
+
+def _cores():
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(quota) // int(period)))
+    except Exception:
+        pass
+    return n
+
+
+@pytest.mark.parametrize("workload", ["configs1", "configs3"])
+def test_full_size_oracle_parity(workload):
+    """BASELINE configs[1] (10 000 floes, periodic box, uniform flow) and configs[3] (10 000 floes between four collision walls +
+    the strait's topography) at the size the metric is quoted on, against the OpenMP oracle: ghosts and their order, pair list
+    bit-exact, interaction rows and totals to 1e-10 per element; then 3 resident timesteps: pair list equal, state to 1e-9,
+    guard counters equal."""
+    from subzero_jl_amd import fields
+    cfg = _bench_cfg(workload)
+    n = cfg["n_floes"]
+    hw, ow = _pair(cfg); ow.set_threads(_cores())
+    hw.add_ghosts(); ow.add_ghosts()
+    assert hw.M == ow.M and hw.ghosts() == ow.ghosts()
+    if workload == "configs1":
+        assert hw.M > n           # periodic: there are ghosts
+    hw.timestep_collisions(n, cfg["dt"]); ow.timestep_collisions(n, cfg["dt"])
+    res = parity.compare_worlds(hw, ow, rtol=1e-10, fields=["coll_fx", "coll_fy", "coll_trq", "overarea"])
+    assert res["n_pairs"] > n and ow.interactions()[0][-1] > n
+    if workload == "configs3":
+        rows = ow.interactions()[1]
+        assert np.sum((rows[:, 0] < 0) & (rows[:, 0] >= -4)) > 50 and np.sum(rows[:, 0] < -4) > 20      # wall and topography contacts
+    del hw, ow
+    hw, ow = _pair(cfg); ow.set_threads(_cores())
+    steps = 3
+    assert hw.run(steps, 0, cfg["dt"], coupling_dt=1) == steps
+    for t in range(steps):
+        ow.timestep_sim(t, cfg["dt"], coupling_dt=1)
+    parity.compare_worlds(hw, ow, rtol=1e-9)
+    assert np.array_equal(hw.warn_counts(), ow.warn_counts())
+
+
+def test_collision_call_100k_pairs_bit_exact():
+    """BASELINE configs[2] size on one GPU: add_ghosts! + timestep_collisions! of 100 000 floes (converge/diverge field) against the
+    oracle's O(M^2) pair loop -- ghost lists equal, overlap-pair indices bit-exact, rows and totals to 1e-10 per element."""
+    cfg = _bench_cfg("configs2")
+    n = cfg["n_floes"]
+    hw, ow = _pair(cfg); ow.set_threads(_cores())
+    hw.add_ghosts(); ow.add_ghosts()
+    assert hw.M == ow.M and hw.ghosts() == ow.ghosts()
+    hw.timestep_collisions(n, cfg["dt"]); ow.timestep_collisions(n, cfg["dt"])
+    res = parity.compare_worlds(hw, ow, rtol=1e-10, fields=["coll_fx", "coll_fy", "coll_trq", "overarea"])
+    assert res["n_pairs"] > n
 
 
 def test_reupload_into_the_same_context():

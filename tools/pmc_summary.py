@@ -44,6 +44,14 @@ if kb:
                       "hbm_bytes_per_launch": (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0,
                       "source": f"profiles/{tag}_pmc_fetch_size.csv, profiles/{tag}_pmc_write_size.csv (2 x FETCH_SIZE + WRITE_SIZE)"}
                   for k, v in kb.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+    # the sources the passes were made on: bench.py only quotes the table for the same kernel code
+    import hashlib
+    h = hashlib.sha256()
+    cs = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "subzero.jl_amd", "csrc")
+    for f in sorted(os.listdir(cs)):
+        if f.endswith((".hpp", ".hip")):
+            h.update(open(os.path.join(cs, f), "rb").read())
+    table[key]["_meta"] = {"kernel_source_sha16": h.hexdigest()[:16], "tag": tag}
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)
     print(path)
 f = glob.glob(os.path.join(root, "prof_kt", "**", "*kernel_stats.csv"), recursive=True)
