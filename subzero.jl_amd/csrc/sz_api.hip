@@ -491,7 +491,7 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = 
     if (larger)
       hipLaunchKernelGGL((sz_k_narrow<16, NARROW_CAP1, 16, 80, 6, 64, NARROW_CAP0, 1>), dim3(grid_for(capItems, 4, 2048)), dim3(64), 0,
                          c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0);
-    hipLaunchKernelGGL((sz_k_narrow<64, NARROW_CAP2, 64, 320, 16, 64, NARROW_CAP1, 2>), dim3(grid_for(capItems, 1, larger ? 2048 : 256)), dim3(64), 0,
+    hipLaunchKernelGGL((sz_k_narrow<64, NARROW_CAP2, NARROW_KC2, NARROW_RC2, 16, 64, NARROW_CAP1, 2>), dim3(grid_for(capItems, 1, larger ? 2048 : 256)), dim3(64), 0,
                        c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0);
     t.end();
   }
@@ -1166,7 +1166,7 @@ int sz_get_boundary_rects(sz_ctx* c, double* rects16) {
 // which_vertices_match_points on given points and a given region ring (the reference's test vectors for it)
 int sz_debug_match_vertices(sz_ctx* c, int32_t npts, const double* px, const double* py, int32_t nr, const double* rx, const double* ry,
                             int32_t* idx, int32_t* n_out) {
-  if (!c || npts < 0 || npts > 64 || nr < 1 || nr > 320 || !idx || !n_out) return SZ_E_ARG;
+  if (!c || npts < 0 || npts > NARROW_KC2 || nr < 1 || nr > NARROW_RC2 || !idx || !n_out) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
   PoolGuard pool;
   double *dpx, *dpy, *drx, *dry; int* dout;

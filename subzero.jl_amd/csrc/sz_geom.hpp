@@ -66,7 +66,7 @@ struct GroupMem {
   double dlv[RM], dxv[RM], dyv[RM];          // per kept region: contact length and force direction
   double box[8];                             // ring boxes of the item: a x0 x1 y0 y1, b x0 x1 y0 y1 (a direction check of this item may be
   double ff;                                 // run by another lane group of the wavefront, which finds them here); force factor
-  uint32_t cinfo[KC];                        // per crossing: ia | ib<<7 | rankA<<14 | rankB<<20 | flags<<26
+  uint32_t cinfo[KC];                        // per crossing: ia | ib<<8 | rankA<<16 | rankB<<22 | flags<<28 (edges < 256, ranks < 64, two flag bits)
   int nraw, nx, nreg[2], flag, err, ierr, ntracefail, nea, neb;   // err: bits raised while this group's memory was the scratch; ierr: bits of ITS item
   unsigned acc[2];                           // work counters of the group: ring points of its pair items, pair rows
   uint16_t acc16[3];                         // ... pair items, element items, element rows (a group runs a few dozen items per launch)
@@ -257,6 +257,7 @@ SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, 
   constexpr int KC = sizeof(m.cta) / sizeof(double);
   constexpr int RC = sizeof(m.ecode);
   constexpr int RM = MEM::RMAXV;
+  static_assert(KC <= 64 && sizeof(m.ea) <= 255, "crossing ranks travel in 6 bits, edge indices and ring sizes in 8");
   const double* pax = ring.ax; const double* pay = ring.ay; const double* pbx = ring.bx; const double* pby = ring.by;
   double* rgx = m.reg[buf][0]; double* rgy = m.reg[buf][1];
   if (gl == 0) { m.nraw = 0; m.nreg[buf] = 0; m.roff[buf][0] = 0; m.nea = 0; m.neb = 0; }
@@ -373,7 +374,7 @@ SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, 
       rb += (jb < ib) || (jb == ib && (ub < tb || (ub == tb && ja < ia)));
     }
     m.ordA[ra] = (uint8_t)k; m.ordB[rb] = (uint8_t)k;
-    m.cinfo[k] = (uint32_t)ia | ((uint32_t)ib << 7) | ((uint32_t)ra << 14) | ((uint32_t)rb << 20) | ((uint32_t)m.cfl[k] << 26);
+    m.cinfo[k] = (uint32_t)ia | ((uint32_t)ib << 8) | ((uint32_t)ra << 16) | ((uint32_t)rb << 22) | ((uint32_t)(m.cfl[k] & 3) << 28);
   }
   gsync();
   STAMP(st, 6);
@@ -397,19 +398,19 @@ SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, 
     int cur = c0; bool on_a = true;
     uint32_t ci = m.cinfo[cur];
     do {
-      int fl = (int)(ci >> 26);
+      int fl = (int)(ci >> 28);
       bool fwd = on_a ? (fl & 1) : ((fl >> 1) & 1);
       int ne = on_a ? nea : neb;
       const double* vx = on_a ? pax : pbx; const double* vy = on_a ? pay : pby;
       double sx = on_a ? ox : 0.0, sy = on_a ? oy : 0.0;
-      int r = on_a ? (int)((ci >> 14) & 63) : (int)((ci >> 20) & 63);
-      int e0 = on_a ? (int)(ci & 127) : (int)((ci >> 7) & 127);
+      int r = on_a ? (int)((ci >> 16) & 63) : (int)((ci >> 22) & 63);
+      int e0 = on_a ? (int)(ci & 255) : (int)((ci >> 8) & 255);
       int rn, nxt, e1, nv;
       uint32_t cn;
       if (fwd) { rn = r + 1; if (rn == K) rn = 0; } else { rn = r - 1; if (rn < 0) rn = K - 1; }
       nxt = on_a ? m.ordA[rn] : m.ordB[rn];
       cn = m.cinfo[nxt];
-      e1 = on_a ? (int)(cn & 127) : (int)((cn >> 7) & 127);
+      e1 = on_a ? (int)(cn & 255) : (int)((cn >> 8) & 255);
       if (fwd) nv = (rn > r) ? (e1 - e0) : (ne - e0 + e1);
       else     nv = (rn < r) ? (e0 - e1) : (ne + e0 - e1);
       // the run of ring vertices between the two crossings: vertex t of the run is

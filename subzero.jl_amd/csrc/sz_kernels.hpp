@@ -1759,8 +1759,11 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
 #endif
 }
 
-constexpr int NARROW_CAP0 = 18, NARROW_CAP1 = 32, NARROW_CAP2 = 128;   // ring points per variant (18: rings of up to 17 vertices; the
-                                                                       // working set of the first variant is cut to fit 2 KB of LDS per item)
+constexpr int NARROW_CAP0 = 18, NARROW_CAP1 = 32, NARROW_CAP2 = 255;   // ring points per variant (18: rings of up to 17 vertices; the
+                                                                       // working set of the first variant is cut to fit 2 KB of LDS per item; 255: ring
+                                                                       // sizes and edge indices travel as bytes -- the reference's own test shapes,
+                                                                       // test/inputs/floe_shapes.jld2, have rings of up to 203 points)
+constexpr int NARROW_KC2 = 64, NARROW_RC2 = 640;                       // crossings / region points of the largest variant
 
 // items not touched by any narrow variant would keep stale row counts: clear them first
 __global__ void sz_k_items_clear(State S) {
@@ -2827,7 +2830,7 @@ __global__ void __launch_bounds__(1024) sz_k_owned_box(State S, double* out) {
 // One wavefront; out[0] = count, out[1..] = sorted 0-based vertex indices.
 __global__ void __launch_bounds__(64) sz_k_debug_match_vertices(int npts, const double* px, const double* py, int nr, const double* rx,
                                                                const double* ry, int* out) {
-  __shared__ GroupMem<NARROW_CAP2, 64, 320, 16> m;
+  __shared__ GroupMem<NARROW_CAP2, NARROW_KC2, NARROW_RC2, 16> m;
   const int gl = threadIdx.x;
   for (int k = gl; k < npts; k += 64) { m.cx[k] = px[k]; m.cy[k] = py[k]; m.uniq[k] = 1; }
   for (int k = gl; k < nr; k += 64) { m.reg[0][0][k] = rx[k]; m.reg[0][1][k] = ry[k]; }

@@ -12,7 +12,9 @@ data file.  No reference source text is copied.
                       (which_vertices_match_points), :173-192 (rotate_radians!)
   boundaries.json  <- test/test_simulation_components/domain_components/boundaries.jl:5-127 (boundary rectangles,
                       _update_boundary!)
-  conservation.json <- test/test_conservation.jl:58-146 (the three energy / momentum conservation runs with literal floes)
+  conservation.json <- test/test_conservation.jl:58-203 (the energy / momentum conservation runs: three with literal floes, two with
+                      the many-sided non-convex outlines floe_vertices[1, 3, 4, 5] of test/inputs/floe_shapes.jld2, decoded by
+                      following the JLD2 container's nested arrays of object references -- _H5 below)
   forcings.json    <- test/test_physical_processes/test_coupling.jl:464-639, with the sub-floe
                       points X, Y decoded from test/inputs/test_mc_points.jld2 (two contiguous
                       little-endian Float64 datasets of 241 values each inside the JLD2/HDF5
@@ -234,12 +236,122 @@ def boundaries():
     }
 
 
+class _H5:
+    """Just enough of HDF5 to follow JLD2's nested arrays of references (no HDF5 reader exists in the image): version-2 object
+    headers (OHDR, continuation blocks OCHK), the dataspace (0x01), datatype (0x03), data layout (0x08: compact or contiguous)
+    and filter pipeline (0x0B: none of the datasets read here has one -- asserted) messages.  Addresses are relative to the
+    superblock, which JLD2 puts behind a 512-byte user block."""
+
+    def __init__(self, path):
+        self.b = open(path, "rb").read(); self.base = 512
+        assert self.b[self.base:self.base + 8] == b"\x89HDF\r\n\x1a\n" and self.b[self.base + 8] == 2      # superblock version 2
+        self.root = struct.unpack_from("<Q", self.b, self.base + 12 + 24)[0]
+
+    def _msgs(self, p, end, fl, out):
+        b = self.b
+        while p + 4 <= end:
+            t = b[p]; sz = struct.unpack_from("<H", b, p + 1)[0]; p += 4
+            if fl & 0x04:
+                p += 2
+            if t == 0x10:             # continuation: (address, length) of an OCHK block
+                off, ln = struct.unpack_from("<QQ", b, p)
+                q = self.base + off
+                assert b[q:q + 4] == b"OCHK"
+                self._msgs(q + 4, q + ln - 4, fl, out)
+            elif t != 0:
+                out.append((t, p, sz))
+            p += sz
+
+    def messages(self, rel):
+        b = self.b; o = self.base + rel
+        assert b[o:o + 4] == b"OHDR" and b[o + 4] == 2, rel
+        fl = b[o + 5]; p = o + 6 + (16 if fl & 0x20 else 0) + (4 if fl & 0x10 else 0)
+        szb = 1 << (fl & 3)
+        size = int.from_bytes(b[p:p + szb], "little"); p += szb
+        out = []
+        self._msgs(p, p + size, fl, out)
+        return out
+
+    def links(self, rel):
+        """name -> object header address of a group's link messages (version 1, hard links, 1-byte name length)"""
+        out = {}
+        for t, p, sz in self.messages(rel):
+            if t == 0x06:
+                d = self.b[p:p + sz]
+                assert d[0] == 1 and d[1] == 0x10 and d[2] == 1, d[:4]
+                n = d[3]
+                out[d[4:4 + n].decode("utf8")] = struct.unpack_from("<Q", d, 4 + n)[0]
+        return out
+
+    def dataset(self, rel):
+        """(datatype class, element size, dims, raw bytes) of a dataset"""
+        cls = size = dims = raw = None
+        for t, p, sz in self.messages(rel):
+            d = self.b[p:p + sz]
+            if t == 0x01:
+                rank = d[1]; dims = struct.unpack_from("<%dQ" % rank, d, 4 if d[0] == 2 else 8)
+            elif t == 0x03:
+                cls = d[0] & 0xf; size = struct.unpack_from("<I", d, 4)[0]
+            elif t == 0x08:
+                if d[1] == 0:
+                    n = struct.unpack_from("<H", d, 2)[0]; raw = self.b[p + 4:p + 4 + n]
+                elif d[1] == 1:
+                    addr, n = struct.unpack_from("<QQ", d, 2); raw = self.b[self.base + addr:self.base + addr + n]
+                else:
+                    raise AssertionError("chunked dataset: not expected in these files")
+            elif t == 0x0B:
+                raise AssertionError("filtered (compressed) dataset: no codec in the image")
+        return cls, size, dims, raw
+
+
+def decode_floe_shapes(which):
+    """file["floe_vertices"][k] for the 1-based k in `which` out of test/inputs/floe_shapes.jld2: a 462 x 1 array of references,
+    each a PolyVec = Vector (rings) of Vector (points) of Vector{Float64}(2) -- every level an array of 8-byte references to the
+    next dataset (datatype class 7), the points little-endian Float64 pairs (class 1, size 8).  Returns {k: [ring, ..]}."""
+    h = _H5(os.path.join(REF, "test/inputs/floe_shapes.jld2"))
+    cls, size, dims, raw = h.dataset(h.links(h.root)["floe_vertices"])
+    assert cls == 7 and size == 8 and tuple(dims) == (1, 462), (cls, size, dims)
+    top = struct.unpack("<462Q", raw)
+    out = {}
+    for k in which:
+        cls, size, dims, raw = h.dataset(top[k - 1])
+        assert cls == 7 and size == 8
+        rings = []
+        for rr in struct.unpack("<%dQ" % (len(raw) // 8), raw):
+            cls2, size2, dims2, raw2 = h.dataset(rr)
+            assert cls2 == 7 and size2 == 8
+            pts = []
+            for pr in struct.unpack("<%dQ" % (len(raw2) // 8), raw2):
+                cls3, size3, dims3, raw3 = h.dataset(pr)
+                assert cls3 == 1 and size3 == 8 and tuple(dims3) == (2,), (cls3, size3, dims3)
+                pts.append(list(struct.unpack("<2d", raw3)))
+            rings.append(pts)
+        assert len(rings) == 1            # no holes
+        out[k] = rings
+    return out
+
+
+def _valid_ring(r):
+    """valid_ringvec! (floe_utils.jl:10-17): adjacent duplicates dropped, ring closed"""
+    r = [list(p) for p in r]
+    r = [p for i, p in enumerate(r) if i == len(r) - 1 or p != r[i + 1]]
+    if r[0] != r[-1]:
+        r.append(list(r[0]))
+    return r
+
+
 def conservation():
-    """test/test_conservation.jl:58-146: the three runs with literal floes (two blocks head on, offset, and with a
-    triangle between them).  dt = 1 s, 5000 steps, E = 1.5e3 (mean sqrt(area) + min sqrt(area)), mu = 0, coupling off,
-    open domain, hmean 0.25 (:1-56); pass = |change| of total kinetic energy, x momentum, y momentum and total angular
-    momentum (src/tools/conservation_em.jl:16-67) from the first to the last output below 1 %.  (The two runs with
-    shapes from test/inputs/floe_shapes.jld2 are not transcribed.)"""
+    """test/test_conservation.jl:58-203: the three runs with literal floes (two blocks head on, offset, and with a
+    triangle between them), the run with three many-sided non-convex floes (:156-182, criterion 2.1 %) and the run of one
+    non-convex floe next to a wall and a topography element (:184-203, energy only).  dt = 1 s, 5000 steps,
+    E = 1.5e3 (mean sqrt(area) + min sqrt(area)), mu = 0, coupling off, open domain, hmean 0.25 (:1-56); pass = |change| of
+    total kinetic energy, x momentum, y momentum and total angular momentum (src/tools/conservation_em.jl:16-67) from the
+    first to the last output below the criterion.  The complex shapes are floe_vertices[1, 3, 4, 5] of
+    test/inputs/floe_shapes.jld2 (decode_floe_shapes: rings of 35 / 50 / 146 / 203 points once closed), translated as the test
+    does (Subzero.translate); none of them overlaps another floe or the topography at the start (so the diff_polys of
+    initialize_floe_field, floe.jl:376-378, leaves them as they are)."""
+    shp = decode_floe_shapes([1, 3, 4, 5])
+    assert [len(_valid_ring(shp[k][0])) for k in (1, 3, 4, 5)] == [35, 50, 146, 203]
     floe1 = [[2e4, 2e4], [2e4, 5e4], [5e4, 5e4], [5e4, 2e4], [2e4, 2e4]]
     floe2 = [[6e4, 2e4], [6e4, 5e4], [9e4, 5e4], [9e4, 2e4], [6e4, 2e4]]
     floe3 = [[5.5e4, 2e4], [5.25e4, 4e4], [5.75e4, 4e4], [5.5e4, 2e4]]
@@ -252,6 +364,13 @@ def conservation():
             {"name": "offset", "floes": [floe1, translate(floe2, 0.0, 1e4)], "u": [0.11, -0.1], "v": [0.02, 0.02], "xi": [1e-7, 0.0]},
             {"name": "rotating", "floes": [floe1, floe2, floe3], "u": [0.11, -0.1, 0.0], "v": [0.001, 0.001, 0.001],
              "xi": [0.0, 0.0, 1e-5]},
+            {"name": "complex_shapes", "floes": [translate(_valid_ring(shp[3][0]), 0.0, 2e4), _valid_ring(shp[4][0]), _valid_ring(shp[5][0])],
+             "u": [0.1, 0.0, 0.0], "v": [0.0, -0.2, 0.2], "xi": [0.0, 0.0, 0.0], "max_percent_change": 2.1,
+             "_source": "test/test_conservation.jl:156-182"},
+            {"name": "wall_and_topography", "floes": [translate(_valid_ring(shp[1][0]), -1.75e4, -0.9e4)],
+             "u": [-0.09], "v": [-0.09], "xi": [0.0], "max_percent_change": 1.0, "only": [0],
+             "topography": [[[-1e4, 0.0], [-2e4, 1e4], [-1e4, 1e4], [-1e4, 0.0]]],
+             "_source": "test/test_conservation.jl:184-203 (energy only)"},
         ],
     }
 

@@ -166,15 +166,15 @@ def test_update_boundaries(golden):
     cases.check_update_boundaries(cases.run_update_boundaries(mk, U), U)
 
 
-@pytest.mark.parametrize("k", range(3))
+@pytest.mark.parametrize("k", range(5))
 def test_conservation(golden, k):
-    """test_conservation.jl:58-146: kinetic energy, linear and angular momentum change by less than 1 % over 5000 steps of
-    two / three colliding floes (this is the reference-held criterion that reaches the integrator body,
-    update_floe.jl:482-545)"""
+    """test_conservation.jl:58-203: kinetic energy, linear and angular momentum change by less than 1 % (2.1 % for the many-sided
+    non-convex floes of floe_shapes.jld2; energy only for the floe next to a wall and a topography element) over 5000 steps (this is
+    the reference-held criterion that reaches the integrator body, update_floe.jl:482-545)"""
     C = golden["conservation"]; case = C["cases"][k]
 
     def stepper(w, n, dt):
         for t in range(n):
             w.timestep_sim(t, dt, coupling_dt=10, coupling_on=False)
     change = cases.run_conservation(mk, C, case, stepper)
-    assert np.all(np.isfinite(change)) and np.all(np.abs(change) < C["max_percent_change"]), (case["name"], change)
+    assert cases.conservation_ok(C, case, change), (case["name"], change)
