@@ -279,6 +279,12 @@ int sz_set_stream(sz_ctx *ctx, void *hip_stream);
                          records, slots per pair sized at the last gather), forcings of the owned floes beside the exchange,
                          unpack + step.  Two-way coupling partial sums are all-reduced.  A floe that moves further than half
                          the margin between two gathers is an error (halo-drift bit), never a silently missed contact.
+                         As with sz_step the batch ends after the first step that leaves a floe tagged remove / fuse ON ANY RANK
+                         (simplify_floes!, simulation.jl:205-214, runs after every step and is the host's): every rank's header
+                         record carries its stop request to every other rank with the next exchange, whose unpack kernel ends the
+                         batch there before that step has touched anything.  *steps_done (may be NULL) is the same number on every
+                         rank; status.fuse_idx (sz_download_fuse) of a tiled context names partners by GLOBAL floe index.
+                         SZ_NO_STOP runs all steps.
                          Device errors are per rank; the ranks agree on them at every box gather and at the end of the call,
                          so that EVERY rank returns the same code at the same step (a rank leaving on its own would hang the
                          others: RCCL has no timeout).  A new sz_upload_floes invalidates sz_tile_enable / sz_tile_setup.
@@ -311,7 +317,7 @@ int sz_comm_selftest(sz_ctx *ctx);
 int sz_comm_allreduce(sz_ctx *ctx, void *d_buf, int64_t n);
 int sz_tile_setup(sz_ctx *ctx, double Lx, double Ly, int32_t periodic_x, int32_t periodic_y, double drift_margin,
                   int32_t rebox_every);
-int sz_tile_run(sz_ctx *ctx, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupling_dt, int32_t flags);
+int sz_tile_run(sz_ctx *ctx, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupling_dt, int32_t flags, int32_t *steps_done);
 
 /* ---- output path on the resident state
    sz_eulerian_data: calc_eulerian_data! (output.jl:793-914), the GridOutputWriter averages, over the rows the

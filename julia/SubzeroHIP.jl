@@ -648,9 +648,14 @@ function comm_unique_id()
     return id
 end
 
-# nsteps x timestep_sim! of the tiled run, collectively (same arguments on every rank)
+# nsteps x timestep_sim! of the tiled run, collectively (same arguments on every rank).  Returns the steps run: like sz_step the batch
+# ends after the first step that leaves a floe tagged remove / fuse on ANY rank (the same number on every rank), so that the host's
+# simplify_floes! runs at the step the reference runs it (simulation.jl:205-214)
 function tile_run!(eng::HIPEngine, nsteps::Integer, tstep::Integer, Δt::Integer, coupling_Δt::Integer, flags::Integer)
-    check(eng, @ccall lib.sz_tile_run(eng.ctx::Ptr{Cvoid}, nsteps::Int32, tstep::Int32, Δt::Int32, coupling_Δt::Int32, flags::Int32)::Cint)
+    done = Ref{Int32}(0)
+    check(eng, @ccall lib.sz_tile_run(eng.ctx::Ptr{Cvoid}, nsteps::Int32, tstep::Int32, Δt::Int32, coupling_Δt::Int32, flags::Int32,
+                                      done::Ptr{Int32})::Cint)
+    return Int(done[])
 end
 
 writer_periods(w) = Int[x.Δtout for ws in (w.floewriters, w.gridwriters, w.checkpointwriters) for x in ws]

@@ -158,7 +158,7 @@ def load(build_if_missing=True):
     L.sz_comm_selftest.argtypes = [C.c_void_p]
     L.sz_comm_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.sz_tile_setup.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double, C.c_int32]
-    L.sz_tile_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.sz_tile_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip]
     L.sz_get_boundary_rects.argtypes = [C.c_void_p, _dp]
     L.sz_debug_match_vertices.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, C.c_int32, _dp, _dp, _ip, _ip]
     for n in EXPORTS:

@@ -124,6 +124,8 @@ struct sz_ctx {
   int halo_cap = 0; std::vector<int> cap_send, cap_recv;      // slots per peer region (stride) and what is really sent to / received from each peer
   double tile_Lx = 0, tile_Ly = 0, tile_margin = 0; int tile_per_x = 0, tile_per_y = 0, tile_rebox_every = 50, tile_since_box = -1, tile_rebox_cur = 8, tile_dt = 0; bool tile_rebox_fixed = false;    // rebox_cur: the gather interval in use (<= rebox_every, from the measured drift)
   Pool tw_part_allocs; double* d_tw_partial = nullptr;
+  std::vector<long long> tile_gidx; // global index of every owned floe (sz_tile_enable): status.fuse_idx of a tiled context is reported in global numbers
+  bool tile_inline_off = false;     // SZ_TILE_INLINE=0: the tiled steps of sz_tile_run keep the list-based ghost pass, their own forcing launch and the one-workgroup unpack (A/B)
   int tile_forcing_tstep = -1;      // timestep whose forcings sz_tile_forcing has already enqueued
   bool tile_dirty = false;      // ghosts / halo floes of the last sz_tile_step still appended
   int last_err_bits = 0;   // device error bits the last sync_and_check found (tiled runs agree on them between the ranks)
@@ -658,9 +660,13 @@ int gi_fetch(sz_ctx* c) {
 // after_step (sz_step): the ghosts of the step have already been detached (C_M == N; their rows and the pair arrays are
 // still in place) and the integrator has run since: a floe the coupling marked for removal stays `remove`
 // (timestep_coupling! follows timestep_collisions! in timestep_sim!, simulation.jl:109-161)
-int host_fuse_fixup(sz_ctx* c, const int* h, bool mirror, bool after_step = false, bool coupled = false) {
+// tkeys (tiled contexts): the order key of every local row -- owned floes, then the step's halo floes and ghosts in allocation order; the
+// replay then walks the rows in the order of their keys (= the single context's floe order) and the lists come back indexed by STORAGE row
+// with partners named by storage row (tile_fuse_global turns those into global floe numbers)
+int host_fuse_fixup(sz_ctx* c, const int* h, bool mirror, bool after_step = false, bool coupled = false, const std::vector<long long>* tkeys = nullptr) {
   State& S = c->S;
   int M = after_step ? h[C_N] + h[C_NGHOSTS] : h[C_M];
+  if (tkeys) c->fuse_lists.assign(M, {});          // (they describe the step that ended this batch)
   if ((int)c->fuse_lists.size() < M) c->fuse_lists.resize(M);
   if (h[C_NFUSE] == 0 || M == 0) return SZ_OK;          // no pair asked for a fuse (the narrow phase counts them)
   // the pairs in the reference's serial order (i asc, j asc): per floe its sorted list of owned pairs
@@ -678,6 +684,11 @@ int host_fuse_fixup(sz_ctx* c, const int* h, bool mirror, bool after_step = fals
   const bool renum = after_step && c->gi_valid && (int)c->gi_ref.size() == M - Np;
   std::vector<int> ref(M), sto(M);
   for (int i = 0; i < M; i++) { ref[i] = i < Np || !renum ? i : Np + c->gi_ref[i - Np]; sto[ref[i]] = i; }
+  if (tkeys && (int)tkeys->size() == M) {
+    for (int i = 0; i < M; i++) sto[i] = i;
+    std::sort(sto.begin(), sto.end(), [&](int a, int b) { return (*tkeys)[a] < (*tkeys)[b]; });
+    for (int r = 0; r < M; r++) ref[sto[r]] = r;
+  }
   for (int ii = 0; ii < M; ii++) {
     const int i = sto[ii];
     for (int r = 0; r < nout[i]; r++)
@@ -696,6 +707,11 @@ int host_fuse_fixup(sz_ctx* c, const int* h, bool mirror, bool after_step = fals
     for (int i = 0; i < h[C_N]; i++) if (rm[i]) tag[i] = SZ_REMOVE;
   }
   HIPCHK(c, hipMemcpy(S.status, tag.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice));
+  if (tkeys && (int)tkeys->size() == M) {          // back to storage rows (index and values)
+    std::vector<std::vector<int>> byrow(M);
+    for (int r = 0; r < M; r++) { byrow[sto[r]] = c->fuse_lists[r]; for (int& v : byrow[sto[r]]) v = sto[v]; }
+    c->fuse_lists.swap(byrow);
+  }
   return SZ_OK;
 }
 
@@ -719,6 +735,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_TW_GENERAL_CLIP")) c->tw_general_clip = atoi(e) != 0;
   if (const char* e = getenv("SZ_LEAN_NARROW")) c->no_lean_narrow = atoi(e) == 0;
   if (const char* e = getenv("SZ_GHOST_INLINE")) c->ghost_inline = atoi(e) != 0;
+  if (const char* e = getenv("SZ_TILE_INLINE")) c->tile_inline_off = atoi(e) == 0;
   if (const char* e = getenv("SZ_ELEMS_RIDE")) c->no_elems_ride = atoi(e) == 0;
   if (const char* e = getenv("SZ_FUSE_FORCING")) { c->fuse_forcing = atoi(e) != 0; if (atoi(e) > 0) c->fuse_forcing_mode = atoi(e) >= 2 ? 2 : 1; }
   if (const char* e = getenv("SZ_STATIC_GRID")) c->no_static_grid = atoi(e) == 0;
@@ -1550,7 +1567,8 @@ int sz_tile_enable(sz_ctx* c, const int64_t* gidx, double halo_capacity_factor, 
   leave_resident(c);
   State& S = c->S;
   if (c->hostM != c->hostN) { c->err = "sz_tile_enable needs a ghost-free upload"; return SZ_E_STATE; }
-  std::vector<long long> ok(c->hostN);
+  std::vector<long long>& ok = c->tile_gidx;
+  ok.assign(c->hostN, 0);
   for (int i = 0; i < c->hostN; i++) ok[i] = gidx[i];
   H2D(S.okey, ok.data(), c->hostN, long long);
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2100,73 +2118,179 @@ int sz_tile_setup(sz_ctx* c, double Lx, double Ly, int32_t per_x, int32_t per_y,
   }
   return SZ_OK;
 }
+// The exchange of one step: the regions of d_send to the peers, theirs into d_recv, on the communication stream behind the pack kernel
+// (ev_packed) -- ev_recv is recorded when the halo is in.  all_ranks: every rank gets at least the header record (the stop agreement of the
+// inline steps reads the flags of ALL ranks); otherwise only the neighbouring tiles take part.
+namespace {
+int tile_exchange(sz_ctx* c, bool all_ranks) {
+  const int n = c->comm_n, me = c->comm_rank;
+  if (n <= 1) return SZ_OK;
+  const size_t stride = (size_t)(c->halo_cap + 1) * HALO_REC;
+  HIPCHK(c, hipEventRecord(c->ev_packed, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
+  if (c->host_transport) {
+    c->h_send.resize((size_t)n * stride); c->h_recv.resize((size_t)n * stride);
+    std::vector<int32_t> peer; std::vector<const void*> sp; std::vector<void*> rp; std::vector<int64_t> sb, rb;
+    for (int d = 0; d < n; d++) {
+      if (d == me || (!all_ranks && c->cap_send[d] <= 0 && c->cap_recv[d] <= 0)) continue;
+      const size_t ns = (all_ranks || c->cap_send[d] > 0) ? (size_t)(c->cap_send[d] + 1) * HALO_REC : 0;
+      const size_t nr = (all_ranks || c->cap_recv[d] > 0) ? (size_t)(c->cap_recv[d] + 1) * HALO_REC : 0;
+      if (ns) HIPCHK(c, hipMemcpyAsync(c->h_send.data() + d * stride, c->d_send + d * stride, ns * sizeof(double), hipMemcpyDeviceToHost, c->comm_stream));
+      peer.push_back(d); sp.push_back(c->h_send.data() + d * stride); sb.push_back((int64_t)(ns * sizeof(double)));
+      rp.push_back(c->h_recv.data() + d * stride); rb.push_back((int64_t)(nr * sizeof(double)));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+    HOSTCHK(c, c->host_tr.sendrecv(c->host_tr.user, (int32_t)peer.size(), peer.data(), sp.data(), sb.data(), rp.data(), rb.data()), "sendrecv");
+    for (size_t k = 0; k < peer.size(); k++)
+      if (rb[k]) HIPCHK(c, hipMemcpyAsync(c->d_recv + peer[k] * stride, rp[k], (size_t)rb[k], hipMemcpyHostToDevice, c->comm_stream));
+    HIPCHK(c, hipStreamSynchronize(c->comm_stream));       // (h_recv is reused by the next step)
+  } else {
+    NCCLCHK(c, g_rccl.GroupStart());
+    for (int d = 0; d < n; d++) {
+      if (d == me) continue;
+      if (all_ranks || c->cap_send[d] > 0) NCCLCHK(c, g_rccl.Send(c->d_send + d * stride, (size_t)(c->cap_send[d] + 1) * HALO_REC, NCCL_FLOAT64, d, c->comm, c->comm_stream));
+      if (all_ranks || c->cap_recv[d] > 0) NCCLCHK(c, g_rccl.Recv(c->d_recv + d * stride, (size_t)(c->cap_recv[d] + 1) * HALO_REC, NCCL_FLOAT64, d, c->comm, c->comm_stream));
+    }
+    NCCLCHK(c, g_rccl.GroupEnd());
+  }
+  HIPCHK(c, hipEventRecord(c->ev_recv, c->comm_stream));
+  return SZ_OK;
+}
+void tile_pack(sz_ctx* c) {
+  State& S = c->S;
+  hipLaunchKernelGGL(sz_k_halo_pack, dim3(grid_for(std::max(c->hostN, 1), PACK_TPB)), dim3(PACK_TPB), 0, c->stream, S, c->comm_n, c->comm_rank, S.bounds + 16,
+                     c->tile_Lx, c->tile_Ly, c->tile_per_x, c->tile_per_y, c->d_send, c->halo_cap, S.cnt + C_COUNT, (const int*)c->d_dcap, (const double*)c->d_ref, c->tile_margin);
+}
+// status.fuse_idx of a tiled context, in GLOBAL floe numbers: the order keys of the local rows of the step that ended the batch (owned
+// floes: their global index; halo floes and ghosts: the step's key table), the replay of host_fuse_fixup in key order, and the partners
+// renamed -- a ghost by its parent
+int tile_fuse_replay(sz_ctx* c, const int* h, bool last_coupled) {
+  int rc = gi_fetch(c); if (rc) return rc;
+  const int M = h[C_N] + h[C_NGHOSTS];
+  std::vector<long long> keys(M, 0);
+  for (int i = 0; i < M; i++) keys[i] = i < c->hostN ? c->tile_gidx[i] : (i - c->hostN < (int)c->gi_keys.size() ? c->gi_keys[i - c->hostN] : ((long long)3 << 40) + i);
+  rc = host_fuse_fixup(c, h, true, true, last_coupled, &keys);
+  if (rc) return rc;
+  const long long lim = (long long)1 << 40;
+  for (int i = 0; i < c->hostN && i < (int)c->fuse_lists.size(); i++)
+    for (int& v : c->fuse_lists[i]) { long long key = keys[v]; if (key >= lim) key = (key & (lim - 1)) >> 2; v = (int)key; }
+  return SZ_OK;
+}
+}  // namespace
+
 // nsteps x timestep_sim! of a tiled run, collectively on every rank (same arguments everywhere)
-int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupling_dt, int32_t flags) {
+int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupling_dt, int32_t flags, int32_t* steps_done) {
+  if (steps_done) *steps_done = 0;
   if (!c || !c->have_floes || !c->S.tiled || c->comm_n < 1 || c->tile_margin <= 0) {
     if (c) c->err = "sz_tile_run needs sz_tile_enable and sz_tile_setup after the last sz_upload_floes";
     return SZ_E_STATE;
   }
+  if (nsteps < 0) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
   State& S = c->S;
   const int n = c->comm_n, me = c->comm_rank;
+  const bool coll = (flags & SZ_COLLISIONS_ON) != 0;
+  // The steps of a tile are the single context's (sz_step): ghosts made by whoever places the parent (integrator: owned floes, unpack:
+  // halo floes), forcings in the tail of the narrow launch, no ghost launch -- plus the pack and unpack kernels and the exchange.
+  // Needs what the inline ghost maker needs (rings that fit the one-launch integrator, the static grid).  Otherwise (and with
+  // SZ_TILE_INLINE=0): the list-based steps of sz_tile_step.
+  const bool inl = coll && !c->tile_inline_off && c->ghost_inline && c->fused_move && c->grid_ok && !c->no_static_grid && !c->two_way &&
+                   std::max(c->max_ring, c->max_ring_tiled) <= MV_RING && ((flags & SZ_COUPLING_ON) == 0 || c->have_fields);
+  if (!inl) {
+    for (int s = 0; s < nsteps; s++) {
+      const int tstep = tstep0 + s;
+      c->tile_dt = dt;
+      if (c->tile_since_box < 0 || c->tile_since_box >= c->tile_rebox_cur) { int rc = tile_rebox(c); if (rc) return rc; }
+      c->tile_since_box++;
+      const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
+      tile_pack(c);
+      // (the host's channel blocks: the forcings go to the device first and run while the host trades the regions)
+      if (coupling && n > 1 && c->host_transport) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return rc; }
+      { int rc = tile_exchange(c, false); if (rc) return rc; }
+      // the forcings of the owned floes need nothing from the halo: they run beside the exchange
+      if (coupling && !(n > 1 && c->host_transport)) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return rc; }
+      if (n > 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_recv, 0));
+      int rc = sz_tile_step(c, c->d_recv, n, c->halo_cap, tstep, dt, coupling_dt, flags);
+      if (rc) return rc;
+      if (c->two_way && coupling) {       // ice-on-ocean stress: per-cell partial sums, summed over the ranks, finished on every rank
+        const size_t nc = 3 * c->tw_ncell;
+        if (!c->d_tw_partial) { int r2 = dalloc(c, &c->d_tw_partial, nc, c->tw_part_allocs); if (r2) return r2; }
+        if ((rc = sz_two_way_partial(c, c->d_tw_partial)) || (rc = sz_comm_allreduce(c, c->d_tw_partial, (int64_t)nc)) ||
+            (rc = sz_two_way_finish(c, c->d_tw_partial, dt))) return rc;
+      }
+    }
+    // (the ranks agree on the error word: a rank with a device error and a clean one return the same code)
+    const int rce = tile_sync_agree(c);
+    c->fuse_lists.resize(c->hostM);
+    if (steps_done) *steps_done = nsteps;
+    return rce;
+  }
+  // ---------------- inline steps
+  const bool periodic = S.any_periodic_ew || S.any_periodic_ns;
+  tile_cleanup(c);                                  // (the halo floes / ghosts a list-based call may have left attached)
+  if (c->gi_pending) c->gi_pending = false;
+  c->gi_valid = false;
+  c->gl_valid = false;
+  world_rings(c);
+  S.stop_on_tags = (flags & SZ_NO_STOP) ? 0 : 1;
+  HIPCHK(c, hipMemsetAsync(S.cnt + C_STOP, 0, sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(S.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream));
+  use_static_grid(c);
+  if (c->precision == 1) { int rc = ensure_mixed(c); if (rc) return rc; }
+  S.ginline = 1; S.famrec = 1; S.retry_stop = 0; S.body_rings = 0;
+  HIPCHK(c, hipMemsetAsync(S.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
+  // the periodic ghosts of the owned floes for the first step (and the swap of parents that lie outside the domain), BEFORE the first pack
+  if (periodic && nsteps > 0) hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0, c->hostN);
+  auto fail = [&](int rc) { S.ginline = 0; S.famrec = 0; S.step = 0; return rc; };
   for (int s = 0; s < nsteps; s++) {
     const int tstep = tstep0 + s;
+    S.step = s + 1; S.gslot = s & 1;
     c->tile_dt = dt;
-    if (c->tile_since_box < 0 || c->tile_since_box >= c->tile_rebox_cur) { int rc = tile_rebox(c); if (rc) return rc; }
+    if (c->tile_since_box < 0 || c->tile_since_box >= c->tile_rebox_cur) { int rc = tile_rebox(c); if (rc) return fail(rc); }
     c->tile_since_box++;
     const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
-    const size_t stride = (size_t)(c->halo_cap + 1) * HALO_REC;
-    int* dcnt = S.cnt + C_COUNT;
-    hipLaunchKernelGGL(sz_k_halo_pack, dim3(grid_for(std::max(c->hostN, 1), PACK_TPB)), dim3(PACK_TPB), 0, c->stream, S, n, me, S.bounds + 16, c->tile_Lx, c->tile_Ly, c->tile_per_x,
-                       c->tile_per_y, c->d_send, c->halo_cap, dcnt, (const int*)c->d_dcap, (const double*)c->d_ref, c->tile_margin);
-    if (n > 1 && c->host_transport) {
-      // the host's channel: the forcings go to the device first and run while the host trades the regions
-      HIPCHK(c, hipEventRecord(c->ev_packed, c->stream));
-      if (coupling) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return rc; }
-      HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
-      c->h_send.resize((size_t)n * stride); c->h_recv.resize((size_t)n * stride);
-      std::vector<int32_t> peer; std::vector<const void*> sp; std::vector<void*> rp; std::vector<int64_t> sb, rb;
-      for (int d = 0; d < n; d++) {
-        if (d == me || (c->cap_send[d] <= 0 && c->cap_recv[d] <= 0)) continue;
-        const size_t ns = c->cap_send[d] > 0 ? (size_t)(c->cap_send[d] + 1) * HALO_REC : 0, nr = c->cap_recv[d] > 0 ? (size_t)(c->cap_recv[d] + 1) * HALO_REC : 0;
-        if (ns) HIPCHK(c, hipMemcpyAsync(c->h_send.data() + d * stride, c->d_send + d * stride, ns * sizeof(double), hipMemcpyDeviceToHost, c->comm_stream));
-        peer.push_back(d); sp.push_back(c->h_send.data() + d * stride); sb.push_back((int64_t)(ns * sizeof(double)));
-        rp.push_back(c->h_recv.data() + d * stride); rb.push_back((int64_t)(nr * sizeof(double)));
-      }
-      HIPCHK(c, hipStreamSynchronize(c->comm_stream));
-      HOSTCHK(c, c->host_tr.sendrecv(c->host_tr.user, (int32_t)peer.size(), peer.data(), sp.data(), sb.data(), rp.data(), rb.data()), "sendrecv");
-      for (size_t k = 0; k < peer.size(); k++)
-        if (rb[k]) HIPCHK(c, hipMemcpyAsync(c->d_recv + peer[k] * stride, rp[k], (size_t)rb[k], hipMemcpyHostToDevice, c->comm_stream));
-      HIPCHK(c, hipStreamSynchronize(c->comm_stream));       // (h_recv is reused by the next step)
-      HIPCHK(c, hipEventRecord(c->ev_recv, c->comm_stream));
-    } else if (n > 1) {
-      HIPCHK(c, hipEventRecord(c->ev_packed, c->stream));
-      HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
-      NCCLCHK(c, g_rccl.GroupStart());
-      for (int d = 0; d < n; d++) {
-        if (d == me) continue;
-        if (c->cap_send[d] > 0) NCCLCHK(c, g_rccl.Send(c->d_send + d * stride, (size_t)(c->cap_send[d] + 1) * HALO_REC, NCCL_FLOAT64, d, c->comm, c->comm_stream));
-        if (c->cap_recv[d] > 0) NCCLCHK(c, g_rccl.Recv(c->d_recv + d * stride, (size_t)(c->cap_recv[d] + 1) * HALO_REC, NCCL_FLOAT64, d, c->comm, c->comm_stream));
-      }
-      NCCLCHK(c, g_rccl.GroupEnd());
-      HIPCHK(c, hipEventRecord(c->ev_recv, c->comm_stream));
+    tile_pack(c);
+    { int rc = tile_exchange(c, true); if (rc) return fail(rc); }
+    if (n > 1) {
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_recv, 0));
+      const long long slots = (long long)n * c->halo_cap;
+      hipLaunchKernelGGL(sz_k_halo_unpack_inline, dim3(grid_for(slots, UNPACK_TPB, 1 << 20)), dim3(UNPACK_TPB), 0, c->stream, S, (const double*)c->d_recv, n, me, c->halo_cap,
+                         S.gslot, c->hostN);
     }
-    // the forcings of the owned floes need nothing from the halo: they run beside the exchange
-    if (coupling && !(n > 1 && c->host_transport)) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return rc; }
-    if (n > 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_recv, 0));
-    int rc = sz_tile_step(c, c->d_recv, n, c->halo_cap, tstep, dt, coupling_dt, flags);
-    if (rc) return rc;
-    if (c->two_way && coupling) {       // ice-on-ocean stress: per-cell partial sums, summed over the ranks, finished on every rank
-      const size_t nc = 3 * c->tw_ncell;
-      if (!c->d_tw_partial) { int r2 = dalloc(c, &c->d_tw_partial, nc, c->tw_part_allocs); if (r2) return r2; }
-      if ((rc = sz_two_way_partial(c, c->d_tw_partial)) || (rc = sz_comm_allreduce(c, c->d_tw_partial, (int64_t)nc)) ||
-          (rc = sz_two_way_finish(c, c->d_tw_partial, dt))) return rc;
-    }
+    // the forcings: where sz_step puts them (the tail of the narrow launch for tiles of up to 30 k owned floes, the neighbour launch up to 65 k)
+    const bool fuse = coupling && !(c->pmask >> SZ_K_FORCING & 1u) && c->fuse_forcing && c->hostN <= 65536;
+    int fmode = !fuse ? 0 : c->fuse_forcing_mode ? c->fuse_forcing_mode : (c->hostN <= 30000 ? 2 : 1);
+    if (fmode == 1 && S.maxnb > MAXNB) fmode = 2;
+    if (coupling && !fuse) stage_forcing(c, dt);
+    if (coupling) c->forcing_where = fmode;
+    collisions_step(c, -1, dt, false, true, fmode, false, false);
+    stage_integrate(c, dt, false, coupling, true, -1, periodic && s + 1 < nsteps ? 1 - (s & 1) : -1);
   }
-  // (the ranks agree on the error word: a rank with a device error and a clean one return the same code)
-  const int rce = tile_sync_agree(c);
+  S.step = 0; S.ginline = 0; S.famrec = 0;
+  c->tile_dirty = nsteps > 0;
+  int h[C_COUNT];
+  int rc = sync_and_check(c, h);                     // (drops the halo floes and ghosts of the last step: tile_cleanup)
+  if (rc == SZ_E_HIP) return rc;
+  {
+    int all = 0;
+    const int rc2 = comm_agree_bits(c, rc ? (c->last_err_bits ? c->last_err_bits : 1) : 0, &all);
+    if (rc2) return rc2;
+    if (all) return SZ_E_CAPACITY;
+  }
+  const int done = h[C_STOP] > 0 ? std::min(h[C_STOP], (int)nsteps) : nsteps;
+  if (steps_done) *steps_done = done;
+  if (done < nsteps) c->grid_live = false;          // stopped early: cells hold floes of a step that did not come
+  c->inter_any = true; c->inter_lost = false;
+  // status.fuse_idx of the step that ended the batch (as sz_step: only that step can have produced fuse pairs)
+  if (done > 0 && (h[C_STOP] > 0 || (flags & SZ_NO_STOP))) {
+    const int tlast = tstep0 + done - 1;
+    const bool last_coupled = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tlast % coupling_dt) == 0;
+    c->gi_pending_n = h[C_NGHOSTS]; c->gi_pending_slot = (done - 1) & 1; c->gi_pending = true;
+    rc = tile_fuse_replay(c, h, last_coupled);
+    c->gi_pending = false;
+  }
   c->fuse_lists.resize(c->hostM);
-  return rce;
+  return rc;
 }
 
 // counts of the last sz_halo_pack per destination rank (synchronises); used to size the exchange buffers

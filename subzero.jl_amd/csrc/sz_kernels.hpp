@@ -686,8 +686,12 @@ __device__ __forceinline__ void ghost_row_load(const State& S, int i, int n, int
   for (int k = 0; k < MV_RING; k++) { r.rx[k] = !body && k < n ? S.vx[vo + k] : 0.0; r.ry[k] = !body && k < n ? S.vy[vo + k] : 0.0; }
 }
 // parent i with row R, flags fl != 5, ring (vo, n <= MV_RING); N parents, ring points of the parents NV0; slot: the allocator
+// how many ghosts the flags ask for
+__device__ __forceinline__ int ghost_count_of(int fl) { return fl == 5 ? 0 : ((fl & 3) != 1 && ((fl >> 2) & 3) != 1) ? 3 : 1; }
+// given: the caller has already drawn the rows and ring points of the ghosts from the allocator ({rows << 32 | points} before them) -- the halo
+// unpack of a tiled run allocates a received floe and its ghosts in one go
 __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, const double* wall, int N, int NV0, int slot, int i, int fl, int n, int vo,
-                                                  const GhostRow& R) {
+                                                  const GhostRow& R, const unsigned long long* given = nullptr) {
   const int dir0 = (fl & 3) - 1, dir1 = ((fl >> 2) & 3) - 1;
   const int ng = dir0 != 0 && dir1 != 0 ? 3 : 1;
   const bool body = S.body_rings != 0;
@@ -695,17 +699,21 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
   // one allocation per wavefront for all its parents that make ghosts (the callers are thread-per-parent kernels; same-address atomics
   // are worked off one at a time for the whole chip), handed on by a prefix over the lanes
   const unsigned long long mine = ((unsigned long long)ng << 32) | (unsigned)npts;
-  const unsigned long long act = __ballot(1);
-  const int lane = threadIdx.x & 63, first = __ffsll((long long)act) - 1;
+  const int lane = threadIdx.x & 63;
+  int first = 0;
   unsigned long long pre = 0, tot = 0;          // (a walk over the active lanes: the others hold nothing to shuffle from)
-  for (unsigned long long m = act; m; m &= m - 1) {
-    const int l = __ffsll((long long)m) - 1;
-    const unsigned long long v = __shfl(mine, l);
-    if (l < lane) pre += v;
-    tot += v;
-  }
   unsigned long long base = 0;
-  if (lane == first) base = atomicAdd(&S.galloc[slot * 16], tot);      // (its answer is looked at below, after the cell counters have gone out too)
+  if (!given) {
+    const unsigned long long act = __ballot(1);
+    first = __ffsll((long long)act) - 1;
+    for (unsigned long long m = act; m; m &= m - 1) {
+      const int l = __ffsll((long long)m) - 1;
+      const unsigned long long v = __shfl(mine, l);
+      if (l < lane) pre += v;
+      tot += v;
+    }
+    if (lane == first) base = atomicAdd(&S.galloc[slot * 16], tot);      // (its answer is looked at below, after the cell counters have gone out too)
+  }
   const double pcx = R.cx, pcy = R.cy, pb0 = R.b0, pb1 = R.b1, pb2 = R.b2, pb3 = R.b3;
   const double c_rmax = R.rmax, c_area = R.area, c_h = R.h;
   const double c_u = R.u, c_v = R.v, c_xi = R.xi, c_over = R.over, tc = R.tc, ts = R.ts;
@@ -746,9 +754,9 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
   const int s0 = atomicAdd(&S.cell_cnt[cl0], 1);
   const int s1 = cl1 >= 0 ? atomicAdd(&S.cell_cnt[cl1], 1) : 0, s2 = cl2 >= 0 ? atomicAdd(&S.cell_cnt[cl2], 1) : 0;
   GSTAMP(11);
-  base = __shfl(base, first);
+  if (!given) base = __shfl(base, first);
   GSTAMP(12);
-  const unsigned long long old = base + pre;
+  const unsigned long long old = given ? *given : base + pre;
   const int og = (int)(old >> 32), ov = (int)(old & 0xffffffffull);
   if (N + og + ng > S.capM) { atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
   if (NV0 + ov + npts > S.capV) { atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); return; }
@@ -2726,7 +2734,12 @@ __global__ void __launch_bounds__(PACK_TPB) sz_k_halo_pack(State S, int nranks, 
     run[d] = 0;
     counts[d] = tot;
     const int room = dcap ? dcap[d] : cap;
-    if (send) send[(size_t)d * (cap + 1) * HALO_REC] = (double)(tot < room ? tot : room);
+    if (send) {
+      // header record: [0] the count, [1] this rank's stop request (resident batches end after the first step that tags a floe,
+      // on EVERY rank: sz_k_halo_unpack_inline reads the flags of all ranks before the next step does anything)
+      double* hdr = send + (size_t)d * (cap + 1) * HALO_REC;
+      hdr[0] = (double)(tot < room ? tot : room); hdr[1] = (double)S.cnt[C_STOP];
+    }
   }
   if (threadIdx.x == 0) {
     if (ref) S.cnt[C_DRIFT] = atomicAdd(&run[65], 0);          // what the host sizes the next gather interval with
@@ -2798,6 +2811,106 @@ __global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* 
   if (threadIdx.x == 0) {
     S.cnt[C_M] = nown + nrec; S.cnt[C_N] = nown + nrec; S.cnt[C_NV] = vbase + totv; S.cnt[C_NHALO] = nrec;
     if (nrec == 0) S.voff[nown] = vbase;
+  }
+}
+// ---- the halo of a tiled step whose ghosts are made "inline" (sz_tile_run): THREAD per received record, as many workgroups as the
+// regions hold slots.  A received floe and the ghosts it needs on this rank are rows of the SAME bump allocator the owned parents'
+// ghosts come from (State::galloc: {rows << 32 | ring points} in one atomic per wavefront, rings packed back to back in allocation
+// order), behind the owned floes: [owned | ghosts of owned, halo floes, ghosts of halo floes in allocation order].  Nothing in a
+// step needs the parents to be contiguous -- order-dependent rules use the order keys (global indices), totals are only kept for
+// owned floes -- so the count of "parents" stays the owned count and no row offset has to be scanned.  The thread bins the floe,
+// makes its periodic ghosts from the record it holds (ghost_inline_make) and leaves its order key in the step's key table.
+// Stop agreement: the header record of every rank carries that rank's stop request (a floe was tagged in the step before:
+// simplify_floes!, simulation.jl:205-214, is the host's); any request ends the batch on THIS rank too, before this step has touched
+// anything -- all ranks return the state after the same step.
+constexpr int UNPACK_TPB = 256;
+__global__ void __launch_bounds__(UNPACK_TPB) sz_k_halo_unpack_inline(State S, const double* recv, int nranks, int me, int cap, int slot, int nown) {
+  if (stopped(S)) return;
+  {
+    int stop = 0;
+    for (int r = 0; r < nranks; r++) { if (r == me) continue; const int f = (int)recv[(size_t)r * (cap + 1) * HALO_REC + 1]; if (f > 0) stop = f; }
+    if (stop > 0 && S.stop_on_tags) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) S.cnt[C_STOP] = stop;      // (every requester of a batch names the same step)
+      return;
+    }
+  }
+  const GridGeo geo = grid_geo(S);
+  const int NV0 = S.voff[nown];
+  const double wall[4] = { S.eval[0], S.eval[1], S.eval[2], S.eval[3] };
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = (int)(t / cap), q = (int)(t % cap);
+  bool act = r < nranks && r != me;
+  if (act) {
+    int cnt_r = (int)recv[(size_t)r * (cap + 1) * HALO_REC];
+    if (cnt_r > cap) { if (q == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); cnt_r = cap; }
+    act = q < cnt_r;
+  }
+  if (t == 0) {          // (statistics only)
+    int tot = 0;
+    for (int rr = 0; rr < nranks; rr++) if (rr != me) { const int c0 = (int)recv[(size_t)rr * (cap + 1) * HALO_REC]; tot += c0 < cap ? c0 : cap; }
+    S.cnt[C_NHALO] = tot;
+  }
+  // ---- the record, all of it before the first store
+  const double* rec = recv + ((size_t)(act ? r : 0) * (cap + 1) + 1 + (act ? q : 0)) * HALO_REC;
+  GhostRow R;
+  int nv = 0;
+  if (act) {
+    nv = (int)rec[2];
+    if (nv > MV_RING) { atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); act = false; nv = 0; }
+  }
+  R.oki = act ? (long long)rec[0] : 0; R.st = act ? (int)rec[1] : SZ_ACTIVE; R.cx = act ? rec[3] : 0.0; R.cy = act ? rec[4] : 0.0;
+  R.rmax = act ? rec[5] : 0.0; R.area = act ? rec[6] : 0.0; R.h = act ? rec[7] : 0.0; R.u = act ? rec[8] : 0.0; R.v = act ? rec[9] : 0.0;
+  R.xi = act ? rec[10] : 0.0; R.id = act ? (long long)rec[11] : 0; R.mass = 0.0; R.mom = 0.0; R.al = 0.0; R.over = 0.0; R.tc = 1.0; R.ts = 0.0;
+#pragma unroll
+  for (int k = 0; k < MV_RING; k++) { R.rx[k] = k < nv ? rec[12 + k] : 0.0; R.ry[k] = k < nv ? rec[12 + HALO_RING + k] : 0.0; }
+  double x0 = __builtin_inf(), x1 = -__builtin_inf(), y0 = __builtin_inf(), y1 = -__builtin_inf();
+#pragma unroll
+  for (int k = 0; k < MV_RING; k++) if (k < nv) { x0 = fmin(x0, R.rx[k]); x1 = fmax(x1, R.rx[k]); y0 = fmin(y0, R.ry[k]); y1 = fmax(y1, R.ry[k]); }
+  R.b0 = x0; R.b1 = x1; R.b2 = y0; R.b3 = y1;
+  double sarea = 0.0;          // ring_signed_area() on the registers: the same sums in the same order
+  if (nv > 0) {
+    double p1x = R.rx[0], p1y = R.ry[0];
+#pragma unroll
+    for (int k = 1; k < MV_RING; k++) if (k < nv) { const double p2x = R.rx[k], p2y = R.ry[k]; sarea += p1x * p2y - p1y * p2x; p1x = p2x; p1y = p2y; }
+    sarea += p1x * R.ry[0] - p1y * R.rx[0];
+    sarea = sarea / 2.0;
+  }
+  R.os = sarea >= 0.0 ? 1 : -1;
+  const int gf = act ? ghost_flag_of(wall, S.any_periodic_ew, S.any_periodic_ns, R.cx, R.cy, R.rmax, x0, x1, y0, y1, R.st == SZ_ACTIVE) : 5;
+  const int ng = ghost_count_of(gf);
+  // ---- rows and ring points of the floe and its ghosts: one allocation per wavefront
+  const unsigned long long mine = act ? (((unsigned long long)(1 + ng) << 32) | (unsigned)(nv * (1 + ng))) : 0ull;
+  unsigned long long inc = mine;
+  const int lane = threadIdx.x & 63;
+  for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+  const unsigned long long tot = __shfl(inc, 63);
+  unsigned long long base = 0;
+  if (lane == 0 && tot) base = atomicAdd(&S.galloc[slot * 16], tot);
+  base = __shfl(base, 0);
+  if (!act) return;
+  const unsigned long long old = base + inc - mine;
+  const int og = (int)(old >> 32), ov = (int)(old & 0xffffffffull);
+  if (nown + og + 1 + ng > S.capM) { atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
+  if (NV0 + ov + nv * (1 + ng) > S.capV) { atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); return; }
+  const int g = nown + og, vb = NV0 + ov;
+  int cix, ciy; cell_of(geo, R.cx, R.cy, cix, ciy);
+  const int cell_c = ciy * geo.ncx + cix, cell_s = atomicAdd(&S.cell_cnt[cell_c], 1);
+  if (cell_s < CELL_K) S.cell_slots[(size_t)cell_c * CELL_K + cell_s] = g;
+  else S.cell_items[g] = atomicExch(&S.cell_ovf[cell_c], g + 1) - 1;
+  S.okey[g] = R.oki; S.status[g] = R.st; S.cx[g] = R.cx; S.cy[g] = R.cy; S.rmax[g] = R.rmax;
+  S.area[g] = R.area; S.height[g] = R.h; S.u[g] = R.u; S.v[g] = R.v; S.xi[g] = R.xi; S.id[g] = R.id;
+  S.ghost_id[g] = 0; S.parent[g] = g; S.ngh[g] = 0; S.overarea[g] = 0.0;
+  for (int k = 0; k < MAX_GHOSTS; k++) S.gh[g * MAX_GHOSTS + k] = -1;
+  S.voff[g] = vb; S.voff[g + 1] = vb + nv;
+#pragma unroll
+  for (int k = 0; k < MV_RING; k++) if (k < nv) { S.vx[vb + k] = R.rx[k]; S.vy[vb + k] = R.ry[k]; }
+  S.osign[g] = R.os;
+  S.bbx0[g] = x0; S.bbx1[g] = x1; S.bby0[g] = y0; S.bby1[g] = y1;
+  if (S.rec32) rec32_store(S, g, R.cx, R.cy, R.rmax, x0, x1, y0, y1);
+  S.gkeys[(size_t)slot * S.capM + og] = R.oki;
+  if (gf != 5) {
+    const unsigned long long given = ((unsigned long long)(og + 1) << 32) | (unsigned)(ov + nv);
+    ghost_inline_make(S, geo, wall, nown, NV0, slot, g, gf, nv, vb, R, &given);
   }
 }
 // bounding box of the owned centroids and the largest rmax: out[0..4] = xmin, xmax, ymin, ymax, rmax; out[5] = the largest

@@ -456,15 +456,21 @@ class TiledWorld:
             return 0
         return self.repartition()
 
-    def run(self, nsteps, tstep0, dt, coupling_dt=10, collisions_on=True, coupling_on=True):
+    def run(self, nsteps, tstep0, dt, coupling_dt=10, collisions_on=True, coupling_on=True, stop_on_tags=False):
+        """nsteps x timestep_sim! of the tiled run (collective).  Returns the steps run.  stop_on_tags (library backends): the batch ends
+        after the first step that leaves a floe tagged remove / fuse on ANY rank -- the same step on every rank -- as World.run does
+        for the single context (the reference runs simplify_floes! after every step, simulation.jl:205-214)."""
         done = 0
         while done < nsteps:
             k = min(nsteps - done, self.repartition_every - self._since_check) if self.nranks > 1 else nsteps - done
             if self.backend in ("library", "library-host"):
                 w = self.world
-                flags = (capi.COLLISIONS_ON if collisions_on else 0) | (capi.COUPLING_ON if coupling_on else 0)
-                w._chk(w.L.sz_tile_run(w.h, int(k), int(tstep0 + done), int(dt), int(coupling_dt), flags))
+                flags = (capi.COLLISIONS_ON if collisions_on else 0) | (capi.COUPLING_ON if coupling_on else 0) | (0 if stop_on_tags else capi.NO_STOP)
+                ran = C.c_int32(0)
+                w._chk(w.L.sz_tile_run(w.h, int(k), int(tstep0 + done), int(dt), int(coupling_dt), flags, C.byref(ran)))
                 w._host_stale = True
+                if ran.value < k:
+                    return done + int(ran.value)
             else:
                 for s in range(k):
                     self.step(tstep0 + done + s, dt, coupling_dt, collisions_on, coupling_on)
@@ -473,6 +479,7 @@ class TiledWorld:
             if self.nranks > 1 and self._since_check >= self.repartition_every:
                 self._since_check = 0
                 self.maybe_repartition()
+        return done
 
     def sync(self):
         self.world._chk(self.world.L.sz_sync(self.world.h))

@@ -274,3 +274,93 @@ def test_rccl_binding_self_test():
     for pre in ("", "import torch, torch.distributed\n"):
         out = subprocess.run([sys.executable, "-c", code % (root, pre)], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
+
+
+# ---------------------------------------------------------------- batches of a tiled run end where the reference runs simplify_floes!
+def _tag_cfg(kind):
+    """the scenarios of test_hip_parity.py::test_resident_batch_stops_when_a_floe_is_tagged, laid across the edge between two tiles
+    (x = 5e4): `fuse` -- two floes owned by DIFFERENT ranks close in until their overlap passes floe_floe_max_overlap; `open` -- a
+    floe of rank 1 drifts into an open boundary while rank 0 knows nothing of it"""
+    from subzero_jl_amd import floe as floe_mod
+    sq = lambda x0, y0, s=1e4: np.array([[x0, y0], [x0, y0 + s], [x0 + s, y0 + s], [x0 + s, y0], [x0, y0]])
+    if kind == "fuse":
+        kinds = ["periodic"] * 4
+        rings = [sq(4.2e4, 4.5e4), sq(4.61e4, 4.6e4), sq(8.0e4, 1.0e4), sq(9.6e4, 6.0e4), sq(1.0e4, 1.0e4)]      # 0 | 1, 2, 3 (has a ghost) | 0
+        u = [3.0, -3.0, 0.0, 0.0, 0.0]
+    else:
+        kinds = ["open"] * 4
+        rings = [sq(2.0e4, 4.5e4), sq(8.9e4 + 380.0, 2.0e4), sq(5.2e4, 7.0e4), sq(3.0e4, 1.0e4)]
+        u = [0.0, 20.0, 0.0, 0.0]
+    n = len(rings)
+    off = np.zeros(n + 1, np.int32); off[1:] = np.cumsum([len(r) for r in rings])
+    vx = np.concatenate([r[:, 0] for r in rings]); vy = np.concatenate([r[:, 1] for r in rings])
+    h = np.full(n, 0.5)
+    z = np.zeros((11, 11))
+    return dict(n_floes=n, L=1e5, kinds=kinds, vert_off=off, vx=vx, vy=vy, height=h, u=np.array(u), v=np.zeros(n), xi=np.zeros(n), dt=10,
+                Nx=10, Ny=10, uo=z, vo=z, hf=z, ua=z, va=z, topography=[], E=1e3, derived=floe_mod.derive(off, vx, vy, h),
+                sub_off=np.zeros(n + 1, np.int32), sx=np.zeros(0), sy=np.zeros(0), seed=0)
+
+
+def _worker_tags(rank, world, port, kind, q):
+    import torch.distributed as dist
+    from subzero_jl_amd import tiles
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        cfg = _tag_cfg(kind)
+        tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True, backend="library-host", rebox_every=3, drift_margin=3000.0)
+        done = tw.run(12, 0, 10, coupling_dt=10, coupling_on=False, stop_on_tags=True)
+        out = {f: tw.owned(f) for f in FIELDS}
+        st = tw.world.ids()[2][:len(tw.gidx)]
+        fuse = [list(map(int, f)) for f in tw.world.fuse()][:len(tw.gidx)]
+        again = tw.run(5, done, 10, coupling_dt=10, coupling_on=False, stop_on_tags=True)       # tagged at entry: one step
+        q.put((rank, tw.gidx, out, done, st, fuse, again))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_worker_tags(*a):
+    _guard(_worker_tags)(*a)
+
+
+@pytest.mark.parametrize("kind", ["fuse", "open"])
+def test_tiled_batch_ends_on_every_rank_where_a_floe_is_tagged(kind):
+    """The reference runs simplify_floes! after EVERY step (simulation.jl:205-214).  A tiled batch ends after the step in which ANY
+    rank tags a floe -- the stop request rides in the header records of the next exchange to every rank, whose unpack kernel ends the
+    batch before that step has touched anything -- so both ranks report the same number of steps, and their state, status tags and
+    status.fuse_idx (in global floe numbers) are the single context's after that step."""
+    import torch.multiprocessing as mp
+    import subzero_jl_amd
+    from subzero_jl_amd import fields
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_run_worker_tags, args=(r, 2, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = _collect(q, 2)
+        for p in procs:
+            p.join(60)
+        assert all(p.exitcode == 0 for p in procs)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    cfg = _tag_cfg(kind)
+    hw = fields.build_world(subzero_jl_amd.World(0), cfg)
+    k = hw.run(12, 0, 10, coupling_dt=10, coupling_on=False)
+    assert 2 <= k < 12                                     # the tag comes in the middle of the batch
+    tags = hw.ids()[2]; ref_fuse = [list(map(int, f)) for f in hw.fuse()]
+    assert np.any(tags[:cfg["n_floes"]] != 1)
+    owners = set()
+    for rank, gidx, out, done, st, fuse, again in res:
+        assert done == k and again == 1, (rank, done, k, again)
+        assert np.array_equal(st, tags[gidx]), (rank, st, tags[gidx])
+        for f in FIELDS:
+            assert np.array_equal(out[f], hw.get(f)[gidx]), (rank, f)
+        for i, g in enumerate(gidx):
+            assert sorted(fuse[i]) == sorted(ref_fuse[g]), (rank, g, fuse[i], ref_fuse[g])       # (parents only in these scenarios: global = the single context's numbers)
+        if np.any(st != 1):
+            owners.add(rank)
+    if kind == "fuse":
+        assert owners == {0, 1}            # the fused pair straddles the tile edge

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_ks
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ks -o ks -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_ks.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ks -o ks -- python3 $R/bench.py --no-cpu-baseline --no-strong-reference > /dev/null 2> $R/gpurun_out/prof_ks.err
 python3 - <<PY
 import csv, glob
 f = glob.glob("$R/gpurun_out/prof_ks/**/*kernel_stats.csv", recursive=True)[0]

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_ksa
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ksa -o ks -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/prof_ksa.json 2> $R/gpurun_out/prof_ksa.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ksa -o ks -- python3 $R/bench.py --no-cpu-baseline --no-strong-reference "$@" > $R/gpurun_out/prof_ksa.json 2> $R/gpurun_out/prof_ksa.err
 cut -c1-160 $R/gpurun_out/prof_ksa.json
 python3 - <<PY
 import csv, glob
