@@ -618,6 +618,8 @@ def main():
         nl = max(st_ev["acc_narrow_launches"], 1)
         win = {"n_pair_ring_points": st_ev["acc_pair_ring_points"] / nl, "n_pairs_clipped": st_ev["acc_pair_items"] / nl,
                "n_pair_rows": st_ev["acc_pair_rows"] / nl, "n_elem_rows": st_ev["acc_elem_rows"] / nl}
+        dirchk = {"per_launch": st_ev["acc_dir_checks"] / nl, "certified_fraction": st_ev["acc_dir_checks_certified"] / max(st_ev["acc_dir_checks"], 1),
+                  "note": "direction checks of calc_normal_force (collisions.jl:58-68); certified = settled from the crossing detection of the translated polygon alone, no second clip"}
         b_narrow = narrow_algorithmic_bytes(win)
         # small fields: the step's forcings ride in the narrow launch (its tail) -- the launch the events bracket then does both
         rides = forcing_where == 2 and coupling_dt == 1
@@ -651,7 +653,7 @@ def main():
                          "measured_copy_ceiling": ceiling, "frac_of_measured_ceiling": achieved / ceiling if ceiling > 0 else None,
                          "kernel_ms": narrow_ms, "kernel_launches_timed": n_launch, "algorithmic_bytes_per_launch": b_launch,
                          "algorithmic_bytes_narrow_only": b_narrow,
-                         "counts_per_launch": win, "counts_note": "device counters accumulated over the launches the event time averages (the middle timed block)",
+                         "counts_per_launch": win, "direction_checks": dirchk, "counts_note": "device counters accumulated over the launches the event time averages (the middle timed block)",
                          "step_algorithmic_bytes": step_bytes,
                          "step_frac": step_bytes / (el / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "step_traffic": step_traffic(workload, cfg["n_floes"], kernel_name) if not tiled else None},

@@ -107,6 +107,8 @@ typedef struct {
   int64_t acc_pair_rows;        /* floe-floe contact rows before mirroring                                       */
   int64_t acc_elem_items;       /* floe-boundary / floe-topography items run                                     */
   int64_t acc_elem_rows;
+  int64_t acc_dir_checks;       /* direction checks of calc_normal_force (collisions.jl:58-68) run ...                          */
+  int64_t acc_dir_checks_certified; /* ... of which settled from the crossing detection of the translated polygon alone (no second clip) */
 } sz_stats;
 
 /* kernel classes for sz_kernel_time_ms */

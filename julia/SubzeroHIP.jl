@@ -134,6 +134,8 @@ struct SzStats
     acc_pair_rows::Int64
     acc_elem_items::Int64
     acc_elem_rows::Int64
+    acc_dir_checks::Int64
+    acc_dir_checks_certified::Int64
 end
 
 const SZ_COLLISIONS_ON = Int32(1)

@@ -46,7 +46,7 @@ class SzStats(C.Structure):
                 ("M", "N", "n_ring_points", "n_sub_points", "n_pairs", "n_pair_ring_points", "n_pair_rows",
                  "n_elem_items", "n_elem_rows", "n_inter_rows", "n_ghosts",
                  "warn_height", "warn_force", "warn_vel", "warn_xi", "n_trace_fail", "n_halo", "n_pairs_clipped", "n_status_remove", "n_status_fuse", "n_retry",
-                 "acc_narrow_launches", "acc_pair_items", "acc_pair_ring_points", "acc_pair_rows", "acc_elem_items", "acc_elem_rows")]
+                 "acc_narrow_launches", "acc_pair_items", "acc_pair_ring_points", "acc_pair_rows", "acc_elem_items", "acc_elem_rows", "acc_dir_checks", "acc_dir_checks_certified")]
 
 
 _AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)

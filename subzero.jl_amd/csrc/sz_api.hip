@@ -602,7 +602,16 @@ void stage_forcing(sz_ctx* c, int dt = -1) {      // in-order variant (process m
   if (!c->two_way && c->precision == 1) {
     hipLaunchKernelGGL(sz_k_forcing_mixed, dim3(grid_for(c->S.capM, 256 / FRC_PLAIN, 8192)), dim3(256), 0, c->stream, c->S, c->P);
   } else if (!c->two_way) {
-    hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_PLAIN, 8192)), dim3(256), 0, c->stream, c->S, c->P, 0);
+    const int x = getenv("SZ_FRC_X") ? atoi(getenv("SZ_FRC_X")) : 0;        // experiments (tools/forcing_ab.py)
+    const dim3 g32(grid_for(c->S.capM, 256 / 32, 8192)), g16(grid_for(c->S.capM, 256 / 16, 8192)), b(256);
+    if (x == 1) hipLaunchKernelGGL((sz_k_forcing_x<32, true, false, 1>), g32, b, 0, c->stream, c->S, c->P);
+    else if (x == 2) hipLaunchKernelGGL((sz_k_forcing_x<32, false, true, 1>), g32, b, 0, c->stream, c->S, c->P);
+    else if (x == 3) hipLaunchKernelGGL((sz_k_forcing_x<32, true, true, 1>), g32, b, 0, c->stream, c->S, c->P);
+    else if (x == 4) hipLaunchKernelGGL((sz_k_forcing_x<16, true, true, 1>), g16, b, 0, c->stream, c->S, c->P);
+    else if (x == 5) hipLaunchKernelGGL((sz_k_forcing_x<32, true, true, 5>), g32, b, 0, c->stream, c->S, c->P);
+    else if (x == 6) hipLaunchKernelGGL((sz_k_forcing_x<16, false, true, 5>), g16, b, 0, c->stream, c->S, c->P);
+    else if (x == 7) hipLaunchKernelGGL((sz_k_forcing_x<32, false, false, 1>), g32, b, 0, c->stream, c->S, c->P);
+    else hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_PLAIN, 8192)), dim3(256), 0, c->stream, c->S, c->P, 0);
   } else {
     // timestep_coupling! with two_way_coupling_on (coupling.jl:1705-1738): one-way forcings + per-floe cell slots,
     // then calc_two_way_coupling! (:1617-1680) as a counting sort by cell, one clip per (floe, cell) entry, a reduction
@@ -755,7 +764,7 @@ sz_ctx* sz_create(int device_id) {
   P.fcor = 1.4e-4; P.turn = 15.0 * 3.14159265358979323846 / 180.0; P.ff_max_overlap = 0.55; P.fd_max_overlap = 0.75;
   P.rho_i = 920.0; P.max_h = 10.0; P.max_xi = 1e-5; P.lambda = 0.2; P.dd = 1;
   P.Cd_ao = 1.25e-3; P.k_ice = 2.14; P.L_ice = 2.93e5;
-  if (hipMalloc((void**)&c->d_stats, 18 * sizeof(long long)) != hipSuccess) { delete c; return nullptr; }
+  if (hipMalloc((void**)&c->d_stats, 20 * sizeof(long long)) != hipSuccess) { delete c; return nullptr; }
   if (hipMalloc((void**)&c->S.acc, (size_t)ACC_SLOTS * 8 * sizeof(unsigned long long)) != hipSuccess) { delete c; return nullptr; }
   (void)hipMemset(c->S.acc, 0, (size_t)ACC_SLOTS * 8 * sizeof(unsigned long long));
   return c;
@@ -1024,9 +1033,9 @@ int sz_get_stats(sz_ctx* c, sz_stats* out) {
   (void)hipSetDevice(c->device);
   tile_cleanup(c);
   State& S = c->S;
-  HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 18 * sizeof(long long), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 20 * sizeof(long long), c->stream));
   hipLaunchKernelGGL(sz_k_stats, dim3(grid_for((long long)S.capPairs + S.capElem, 256, 1024)), dim3(256), 0, c->stream, S, c->d_stats);
-  int h[C_COUNT]; long long st[18];
+  int h[C_COUNT]; long long st[20];
   HIPCHK(c, hipMemcpyAsync(st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(h, S.cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1043,6 +1052,7 @@ int sz_get_stats(sz_ctx* c, sz_stats* out) {
   out->n_retry = h[C_NRETRY];
   out->acc_narrow_launches = st[10]; out->acc_pair_items = st[11]; out->acc_pair_ring_points = st[12];
   out->acc_pair_rows = st[13]; out->acc_elem_items = st[14]; out->acc_elem_rows = st[15];
+  out->acc_dir_checks = st[18]; out->acc_dir_checks_certified = st[19];
   return SZ_OK;
 }
 

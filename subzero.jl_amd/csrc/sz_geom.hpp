@@ -24,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace szg {
 
@@ -54,6 +55,7 @@ struct GroupMem {
   static constexpr int RMAXV = RM;
   // (members ordered by alignment -- doubles, 4-byte, 2-byte, bytes -- so that the struct has no padding: eight of
   //  them must stay within 16 KB for ten workgroups per CU)
+  using roff_t = typename std::conditional<(RC < 256), uint8_t, int16_t>::type;     // a position in a region buffer
   double ax[CAP], ay[CAP], bx[CAP], by[CAP];
   double cta[KC], ctb[KC], cx[KC], cy[KC];   // crossings in canonical (ia, ib) order
   double reg[2][2][RC];                      // region rings [clip][x|y][point]; reg[1] doubles as the
@@ -67,20 +69,27 @@ struct GroupMem {
   double box[8];                             // ring boxes of the item: a x0 x1 y0 y1, b x0 x1 y0 y1 (a direction check of this item may be
   double ff;                                 // run by another lane group of the wavefront, which finds them here); force factor
   uint32_t cinfo[KC];                        // per crossing: ia | ib<<8 | rankA<<16 | rankB<<22 | flags<<28 (edges < 256, ranks < 64, two flag bits)
-  int nraw, nx, nreg[2], flag, err, ierr, ntracefail, nea, neb;   // err: bits raised while this group's memory was the scratch; ierr: bits of ITS item
+  int nraw, err, ierr, nea, neb;             // err: bits raised while this group's memory was the scratch; ierr: bits of ITS item (LDS atomics: 32-bit)
   unsigned acc[2];                           // work counters of the group: ring points of its pair items, pair rows
-  uint16_t acc16[3];                         // ... pair items, element items, element rows (a group runs a few dozen items per launch)
-  int16_t cia[KC], cib[KC], ria[KC], rib[KC];   // (ria doubles as the scratch of match_vertices: the raw slots are dead after the clip)
-  int16_t midx[KC];                          // matched region-vertex index per ipoint
-  int16_t roff[2][RM + 2];
+  uint16_t acc16[5];                         // ... pair items, element items, element rows, direction checks, of which certified (a group runs a few dozen items per launch)
+  int16_t nx, nreg[2], flag, ntracefail;
+  int16_t ria[KC];                           // raw crossing slots: a-edge (doubles as the scratch of match_vertices: the raw slots are dead after the clip)
+  roff_t midx[KC];                           // matched region-vertex index per ipoint
+  roff_t roff[2][RM + 2];
+  roff_t cpos[KC];                           // contact clip: where crossing k sits in its region's ring (position in the region buffer) ...
+  uint8_t creg[KC];                          // ... and which region that is (0xff: none) -- kept for the certified direction check
+  uint8_t sga[KC], sgb[KC], sgf[KC];         // the contact clip's crossing set: a-edge, b-edge, flags (a copy no later clip in this memory overwrites)
+  uint8_t cia[KC], cib[KC], rib[KC];
   uint8_t ordA[KC], ordB[KC];                // crossing id at rank r along a / b
   uint8_t cfl[KC], rfl[KC], uniq[KC];
   int8_t ecode[RC];                          // many-intersect per-edge class
   uint8_t ea[CAP], eb[CAP];                  // edges of a / b that reach into the overlap box
   int8_t keep[RM];
   int8_t chk[RM];                            // the kept regions (positions in keep) that need the direction check
+  uint8_t chkc[RM];                          // ... 1: the region is a lens (two crossings): its check may be certified without a second clip
   uint8_t rna, rnb; int8_t roa, rob;         // ring sizes and orientation signs of the item
   int8_t nchk, nkeep;
+  uint8_t nsig;                              // crossings of the contact clip (entries of sga / sgb / sgf)
 };
 static_assert(sizeof(GroupMem<18, 8, 16, 4>) <= 2048, "eight groups of the first narrow variant must fit 16 KB");
 
@@ -251,21 +260,24 @@ SZ_DEV double gmax(double v) { for (int d = G / 2; d >= 1; d >>= 1) v = fmax(v, 
 // `ring` holds the two rings, `m` is the working set the clip writes (crossings, regions of buffer `buf`): the same
 // GroupMem for an item's own clips; the direction check of an item may be run by ANOTHER lane group of the wavefront,
 // which then reads the rings from the owner's memory and works in its own (narrow phase, sz_kernels.hpp).
+// detect_only: stop after the crossing detection (m.nraw raw crossings in m.ria / m.rib / m.rfl, unordered) -- what the certified
+// direction check needs of the translated polygon; nothing but the raw slots and the candidate-edge lists of `m` is written
 template <int G, class MEM>
 SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, int oa, int nb, int ob, int buf, const Box& ba, const Box& bb,
-                 Stamps& st) {
+                 Stamps& st, bool detect_only = false) {
+  using roff_t = typename MEM::roff_t;
   constexpr int KC = sizeof(m.cta) / sizeof(double);
   constexpr int RC = sizeof(m.ecode);
   constexpr int RM = MEM::RMAXV;
   static_assert(KC <= 64 && sizeof(m.ea) <= 255, "crossing ranks travel in 6 bits, edge indices and ring sizes in 8");
   const double* pax = ring.ax; const double* pay = ring.ay; const double* pbx = ring.bx; const double* pby = ring.by;
   double* rgx = m.reg[buf][0]; double* rgy = m.reg[buf][1];
-  if (gl == 0) { m.nraw = 0; m.nreg[buf] = 0; m.roff[buf][0] = 0; m.nea = 0; m.neb = 0; }
-  if (na < 4 || nb < 4) { if (gl == 0) m.nx = 0; gsync(); return; }
+  if (gl == 0) { m.nraw = 0; m.nea = 0; m.neb = 0; if (!detect_only) { m.nreg[buf] = 0; m.roff[buf][0] = 0; } }
+  if (na < 4 || nb < 4) { if (gl == 0 && !detect_only) m.nx = 0; gsync(); return; }
   // bounding boxes are kept per floe (min/max commute with the rounding of `+ ox`, so the box of
   // the translated ring is the translated box, bit for bit)
   const double ax0 = ba.x0 + ox, ax1 = ba.x1 + ox, ay0 = ba.y0 + oy, ay1 = ba.y1 + oy;
-  if (ax1 < bb.x0 || bb.x1 < ax0 || ay1 < bb.y0 || bb.y1 < ay0) { if (gl == 0) m.nx = 0; gsync(); return; }
+  if (ax1 < bb.x0 || bb.x1 < ax0 || ay1 < bb.y0 || bb.y1 < ay0) { if (gl == 0 && !detect_only) m.nx = 0; gsync(); return; }
   // overlap box: a crossing point lies in both rings' boxes, so only edges that reach into it can cross
   const double qx0 = fmax(ax0, bb.x0), qx1 = fmin(ax1, bb.x1), qy0 = fmax(ay0, bb.y0), qy1 = fmin(ay1, bb.y1);
   gsync();
@@ -296,7 +308,7 @@ SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, 
         if (sr != ss) {
           int slot = atomicAdd(&m.nraw, 1);
           if (slot < KC) {
-            m.ria[slot] = (int16_t)ia; m.rib[slot] = (int16_t)ib;
+            m.ria[slot] = (int16_t)ia; m.rib[slot] = (uint8_t)ib;
             m.rfl[slot] = (uint8_t)((((sp * ob) < 0) ? 1 : 0) | (((sr * oa) < 0) ? 2 : 0));
           }
         }
@@ -304,6 +316,7 @@ SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, 
     }
   }
   gsync();
+  if (detect_only) return;
   int K = m.nraw;
   if (K > KC) { if (gl == 0) { m.err |= ERR_CAP_XING; m.nx = 0; } gsync(); return; }
   // ---- phase 2: parameters and point of every crossing (one lane per crossing)
@@ -327,10 +340,11 @@ SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, 
   for (int s = gl; s < K; s += G) {
     int key = (int)m.ria[s] * 65536 + (int)m.rib[s], r = 0;
     for (int t = 0; t < K; t++) r += ((int)m.ria[t] * 65536 + (int)m.rib[t]) < key;
-    m.cia[r] = m.ria[s]; m.cib[r] = m.rib[s]; m.cta[r] = raw[s]; m.ctb[r] = raw[KC + s];
+    m.cia[r] = (uint8_t)m.ria[s]; m.cib[r] = m.rib[s]; m.cta[r] = raw[s]; m.ctb[r] = raw[KC + s];
     m.cx[r] = raw[2 * KC + s]; m.cy[r] = raw[3 * KC + s]; m.cfl[r] = m.rfl[s];
+    if (buf == 0) { m.sga[r] = (uint8_t)m.ria[s]; m.sgb[r] = m.rib[s]; m.sgf[r] = m.rfl[s] & 3; m.creg[r] = 0xff; }      // (the contact clip's crossing set, kept)
   }
-  if (gl == 0) m.nx = K;
+  if (gl == 0) { m.nx = K; if (buf == 0) m.nsig = (uint8_t)K; }
   gsync();
   STAMP(st, 4);
   if (K == 0) {
@@ -355,7 +369,7 @@ SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, 
         }
         gsync();
         ring_area_centroid(rgx, rgy, n, sa, ccx, ccy);
-        if (gl == 0) { m.nreg[buf] = 1; m.roff[buf][1] = (int16_t)n; m.rarea[buf][0] = fabs(sa); }
+        if (gl == 0) { m.nreg[buf] = 1; m.roff[buf][1] = (roff_t)n; m.rarea[buf][0] = fabs(sa); }
       }
     }
     gsync();
@@ -393,6 +407,8 @@ SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, 
       if (off + cnt < RC) { if (gl == 0) { rgx[off + cnt] = x; rgy[off + cnt] = y; } }
       cnt++;
     };
+    const uint64_t visited0 = visited;
+    if (buf == 0 && gl == 0) { m.cpos[c0] = (roff_t)(off + cnt); m.creg[c0] = (uint8_t)nreg; }
     emit1(m.cx[c0], m.cy[c0]);
     visited |= (1ull << c0);
     int cur = c0; bool on_a = true;
@@ -422,6 +438,7 @@ SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, 
         if (off + cnt + t < RC) { rgx[off + cnt + t] = vx[v] + sx; rgy[off + cnt + t] = vy[v] + sy; }
       }
       cnt += nv;
+      if (buf == 0 && gl == 0 && nxt != c0) { m.cpos[nxt] = (roff_t)(off + cnt); m.creg[nxt] = (uint8_t)nreg; }
       emit1(m.cx[nxt], m.cy[nxt]);
       guard += nv + 1;
       if (guard > guard_max) { failed = true; break; }
@@ -431,7 +448,9 @@ SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, 
     } while (cur != c0);
     // a trace abandoned by the guard (inconsistent crossing flags: self-intersecting input or
     // round-off) yields no region; tracing goes on with the next unvisited crossing
-    if (failed) { nfail++; gsync(); continue; }
+    // (a trace that yields no region: its crossings belong to none)
+    auto disown = [&]() { if (buf == 0 && gl == 0) for (uint64_t q = visited ^ visited0; q; q &= q - 1) m.creg[__ffsll((long long)q) - 1] = 0xff; };
+    if (failed) { nfail++; disown(); gsync(); continue; }
     if (off + cnt > RC) { if (gl == 0) m.err |= ERR_CAP_REGION; break; }
     gsync();
     double sa = 0.0, ccx = 0.0, ccy = 0.0;
@@ -439,12 +458,12 @@ SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, 
     if (cnt >= 4 && sa != 0.0) {
       if (nreg < RM) {
         if (gl == 0) {
-          m.rarea[buf][nreg] = fabs(sa); m.roff[buf][nreg + 1] = (int16_t)(off + cnt);
+          m.rarea[buf][nreg] = fabs(sa); m.roff[buf][nreg + 1] = (roff_t)(off + cnt);
           if (buf == 0) { m.rcx[nreg] = ccx; m.rcy[nreg] = ccy; }
         }
         nreg++; off += cnt;
       } else { if (gl == 0) m.err |= ERR_CAP_REGION; break; }
-    }
+    } else disown();
     gsync();
   }
   if (nfail && gl == 0) m.ntracefail += nfail;
@@ -455,7 +474,7 @@ SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, 
 
 template <int G, class MEM>
 SZ_DEV void clip(MEM& m, int gl, double ox, double oy, int na, int oa, int nb, int ob, int buf, const Box& ba, const Box& bb, Stamps& st) {
-  clip<G>(m, m, gl, ox, oy, na, oa, nb, ob, buf, ba, bb, st);
+  clip<G>(m, m, gl, ox, oy, na, oa, nb, ob, buf, ba, bb, st, false);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -494,7 +513,7 @@ SZ_DEV int match_vertices(MEM& m, int gl, int nuniq, const double* rx, const dou
       if (v < 0) continue;
       int u = c - 1;
       while (u >= 0 && m.midx[u] > v) { m.midx[u + 1] = m.midx[u]; u--; }
-      m.midx[u + 1] = (int16_t)v; c++;
+      m.midx[u + 1] = (typename MEM::roff_t)v; c++;
     }
   }
   gsync();
@@ -639,14 +658,21 @@ SZ_DEV void contact_post(MEM& m, int gl, int na, int nb, const ItemCtx& cx_, int
     STAMP(st, 12);
     // unique crossing points (GO.intersection_points): first occurrences in canonical order
     const int K = m.nx;
-    for (int k = gl; k < K; k += G) {
-      bool dup = false;
-      for (int l = 0; l < k; l++) if (m.cx[l] == m.cx[k] && m.cy[l] == m.cy[k]) { dup = true; break; }
-      m.uniq[k] = dup ? 0 : 1;
-    }
-    gsync();
     int nip = 0;
-    for (int k = 0; k < K; k++) nip += m.uniq[k];
+    // The common contact -- two crossings, one lens-shaped region -- needs none of the general matching: both crossing points are vertices
+    // of the region (at distance 0, so which_vertices_match_points, floe_utils.jl:331-352, matches each to the FIRST region vertex with
+    // exactly its coordinates), two matches is the m == 2 branch of calc_normal_force.  Same indices, same expressions, same bits.
+    const bool two = K == 2 && nreg == 1 && m.creg[0] == 0 && m.creg[1] == 0;
+    if (two) nip = (m.cx[0] == m.cx[1] && m.cy[0] == m.cy[1]) ? 1 : 2;
+    else {
+      for (int k = gl; k < K; k += G) {
+        bool dup = false;
+        for (int l = 0; l < k; l++) if (m.cx[l] == m.cx[k] && m.cy[l] == m.cy[k]) { dup = true; break; }
+        m.uniq[k] = dup ? 0 : 1;
+      }
+      gsync();
+      for (int k = 0; k < K; k++) nip += m.uniq[k];
+    }
     // min-area filter (collisions.jl:158-170)
     if (nip >= 2) {
       int n1 = na - 1, n2 = nb - 1;
@@ -662,26 +688,145 @@ SZ_DEV void contact_post(MEM& m, int gl, int na, int nb, const ItemCtx& cx_, int
       int nr = m.roff[0][rr + 1] - m.roff[0][rr];
       double ddx = 0.0, ddy = 0.0, ddl = 0.0;
       if (m.rarea[0][rr] != 0) {
-        int mc = match_vertices<G>(m, gl, nip, rx, ry, nr);
-        if (mc == 2) {
-          int i1 = m.midx[0], i2 = m.midx[1];
+        if (two) {
+          // first region vertex with the coordinates of crossing 0 / 1 (the crossing's own position unless an earlier vertex coincides with it)
+          int f0 = nr, f1 = nr;
+          const double c0x = m.cx[0], c0y = m.cy[0], c1x = m.cx[1], c1y = m.cy[1];
+          for (int j = gl; j < nr; j += G) {
+            if (rx[j] == c0x && ry[j] == c0y && j < f0) f0 = j;
+            if (rx[j] == c1x && ry[j] == c1y && j < f1) f1 = j;
+          }
+          for (int d = G / 2; d >= 1; d >>= 1) { const int o0 = __shfl_xor(f0, d, G), o1 = __shfl_xor(f1, d, G); f0 = o0 < f0 ? o0 : f0; f1 = o1 < f1 ? o1 : f1; }
+          const int i1 = f0 < f1 ? f0 : f1, i2 = f0 < f1 ? f1 : f0;
           double ex = rx[i2] - rx[i1], ey = ry[i2] - ry[i1];
           ddl = sqrt(ex * ex + ey * ey);
           if (ddl > 0.1) { ddx = -ey / ddl; ddy = ex / ddl; }
-        } else if (mc != 0) {
-          ddl = many_intersect<G>(m, gl, rx, ry, nr, na, force_factor, ddx, ddy);
+        } else {
+          int mc = match_vertices<G>(m, gl, nip, rx, ry, nr);
+          if (mc == 2) {
+            int i1 = m.midx[0], i2 = m.midx[1];
+            double ex = rx[i2] - rx[i1], ey = ry[i2] - ry[i1];
+            ddl = sqrt(ex * ex + ey * ey);
+            if (ddl > 0.1) { ddx = -ey / ddl; ddy = ex / ddl; }
+          } else if (mc != 0) {
+            ddl = many_intersect<G>(m, gl, rx, ry, nr, na, force_factor, ddx, ddy);
+          }
+          gsync();
         }
-        gsync();
       }
       // the direction check runs for a region with area and a contact length (collisions.jl:58)
       const bool check = m.rarea[0][rr] != 0 && ddl > 0.1 && !(cx_.dbg & 2);
-      if (gl == 0) { m.dlv[w] = ddl; m.dxv[w] = ddx; m.dyv[w] = ddy; if (check) m.chk[nchk] = (int8_t)w; }
+      // a region with exactly two crossings on its boundary is a lens: its check can be certified from the crossing detection of the
+      // translated polygon alone (certified_check below)
+      int ncr = 0;
+      for (int k = 0; k < K; k++) ncr += m.creg[k] == rr;
+      if (gl == 0) { m.dlv[w] = ddl; m.dxv[w] = ddx; m.dyv[w] = ddy; if (check) { m.chk[nchk] = (int8_t)w; m.chkc[nchk] = (ncr == 2 && !(cx_.dbg & 64)) ? 1 : 0; } }
       if (check) nchk++;
     }
     STAMP(st, 8);
   } while (false);
   if (gl == 0) { m.nkeep = (int8_t)nkeep; m.nchk = (int8_t)nchk; m.ff = force_factor; m.ierr = m.err & CAPBITS; m.err &= ~CAPBITS; }
   gsync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// The direction check of calc_normal_force (collisions.jl:58-68) WITHOUT the second clip, for a contact region that is a lens
+// (two crossings c_in, c_out: p1's ring enters p2 at c_in and leaves it at c_out).  The reference translates p1 by d (the unit
+// normal), clips again and flips the sign for every new region that intersects the old one and is larger.  If the translated p1
+// crosses p2 on exactly the same edge pairs with the same entry / exit flags as before -- checked here against the crossing
+// detection of the translated polygon, run by clip(.., detect_only) into `scr` -- the new clip has the same regions with the same
+// vertex sequences, only the crossing points have slid along their (straight) edges, LINEARLY in the translation.  The area of
+// the lens then changes by EXACTLY
+//     dA = oa * [ d x (c_out - c_in) + 1/2 d x (w_out - w_in) ],      w = slide of a crossing = e_b * (d x e_a) / (e_b x e_a)
+// (the flux of d through the part of the lens boundary that belongs to p1, integrated over the translation; oa = orientation sign
+// of p1; e_a, e_b = the crossing's edge vectors), and "new region larger" is dA > 0.  The decision is taken only when |dA| is far
+// above the round-off of the reference's own area sums (shoelace over absolute coordinates: ~ n eps Lc^2), when the new lens
+// certainly still intersects the old one (they share a vertex of p2, or their intervals on the one p2 edge overlap), and when no
+// OTHER region of the item can come within reach of this one (bounding boxes more than the translation + slides apart).  Otherwise:
+// false, and the caller runs the full check.  Returns true when the sign has been settled (and flipped if need be).
+template <int G, class MEM>
+SZ_DEV bool certified_check(MEM& own, const MEM& scr, int gl, int q) {
+  const int K = own.nsig, K1 = scr.nraw;
+  bool ok = K1 == K && K >= 2;
+  // every crossing of the translated polygon is one of the contact clip's (same edges, same flags); K1 == K and distinct pairs: a bijection
+  if (ok) {
+    bool mine = true;
+    for (int s2 = gl; s2 < K1; s2 += G) {
+      const int ia = scr.ria[s2], ib = scr.rib[s2], fl = scr.rfl[s2] & 3;
+      bool found = false;
+      for (int k = 0; k < K; k++) found |= own.sga[k] == ia && own.sgb[k] == ib && own.sgf[k] == fl;
+      mine &= found;
+    }
+    const int gshift = (int)(threadIdx.x & 63) / G * G;
+    const unsigned long long bad = (__ballot(!mine) >> gshift) & (G >= 64 ? ~0ull : ((1ull << G) - 1ull));
+    ok = bad == 0;
+  }
+  if (!ok) return false;
+  const int r = own.keep[q];
+  int kin = -1, kout = -1, ncr = 0;
+  for (int k = 0; k < K; k++) if (own.creg[k] == r) { ncr++; if (own.sgf[k] & 1) kin = k; else kout = k; }
+  if (ncr != 2 || kin < 0 || kout < 0) return false;
+  const double dx = own.dxv[q], dy = own.dyv[q];
+  const double* rgx = own.reg[0][0]; const double* rgy = own.reg[0][1];
+  const double cix = rgx[own.cpos[kin]], ciy = rgy[own.cpos[kin]], cox = rgx[own.cpos[kout]], coy = rgy[own.cpos[kout]];
+  // slides of the two crossings along their b-edges for the unit translation d
+  double wx[2], wy[2], tbs[2]; bool good = true;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int k = h == 0 ? kin : kout;
+    const int ia = own.sga[k], ib = own.sgb[k];
+    const double eax = own.ax[ia + 1] - own.ax[ia], eay = own.ay[ia + 1] - own.ay[ia];
+    const double ebx = own.bx[ib + 1] - own.bx[ib], eby = own.by[ib + 1] - own.by[ib];
+    const double den = ebx * eay - eby * eax;                 // e_b x e_a
+    const double num = dx * eay - dy * eax;                   // d x e_a
+    if (den == 0.0) good = false;
+    const double t = num / den;
+    tbs[h] = t; wx[h] = t * ebx; wy[h] = t * eby;
+  }
+  if (!good) return false;
+  const double oa = (double)own.roa;
+  const double dA = oa * ((dx * (coy - ciy) - dy * (cox - cix)) + 0.5 * (dx * (wy[1] - wy[0]) - dy * (wx[1] - wx[0])));
+  // round-off floor of the reference's two area sums and of the crossing points: n eps Lc^2 with a wide margin
+  const int nr = own.roff[0][r + 1] - own.roff[0][r];
+  const double Lc = fmax(fmax(fabs(cix), fabs(ciy)), fmax(fabs(cox), fabs(coy)));
+  const double tol = 256.0 * (double)(nr + 8) * 2.220446049250313e-16 * Lc * Lc + 1e-9 * own.rarea[0][r];
+  if (!(fabs(dA) > tol)) return false;
+  // the new lens intersects the old one: a p2 vertex lies on both boundaries unless both crossings sit on ONE edge of p2 -- then the
+  // old and the new interval of that edge must overlap (parameters along the edge, the slides are tbs)
+  if (own.sgb[kin] == own.sgb[kout]) {
+    const int ib = own.sgb[kin];
+    const double ebx = own.bx[ib + 1] - own.bx[ib], eby = own.by[ib + 1] - own.by[ib], e2 = ebx * ebx + eby * eby;
+    const double t0 = ((cix - own.bx[ib]) * ebx + (ciy - own.by[ib]) * eby) / e2, t1 = ((cox - own.bx[ib]) * ebx + (coy - own.by[ib]) * eby) / e2;
+    const double lo = fmin(t0, t1), hi = fmax(t0, t1), lo1 = fmin(t0 + tbs[0], t1 + tbs[1]), hi1 = fmax(t0 + tbs[0], t1 + tbs[1]);
+    if (!(fmax(lo, lo1) < fmin(hi, hi1))) return false;
+  }
+  // other regions of the item: theirs stay within (1 + their slides) of where they were; keep it simple and rigorous -- boxes of the
+  // old regions, grown by a reach that covers any slide that keeps a crossing on its edge (an edge is no longer than the ring box)
+  const int nreg = own.nreg[0];
+  if (nreg > 1) {
+    double bx0 = __builtin_inf(), bx1 = -__builtin_inf(), by0 = __builtin_inf(), by1 = -__builtin_inf();
+    for (int j = own.roff[0][r]; j < own.roff[0][r + 1]; j++) { bx0 = fmin(bx0, rgx[j]); bx1 = fmax(bx1, rgx[j]); by0 = fmin(by0, rgy[j]); by1 = fmax(by1, rgy[j]); }
+    for (int t = 0; t < nreg; t++) {
+      if (t == r) continue;
+      // the crossings of region t slide by at most smax_t
+      double smax = 0.0;
+      for (int k = 0; k < K; k++) if (own.creg[k] == t) {
+        const int ia = own.sga[k], ib = own.sgb[k];
+        const double eax = own.ax[ia + 1] - own.ax[ia], eay = own.ay[ia + 1] - own.ay[ia];
+        const double ebx = own.bx[ib + 1] - own.bx[ib], eby = own.by[ib + 1] - own.by[ib];
+        const double den = ebx * eay - eby * eax;
+        if (den == 0.0) return false;
+        const double tt = (dx * eay - dy * eax) / den;
+        smax = fmax(smax, fabs(tt) * sqrt(ebx * ebx + eby * eby));
+      }
+      const double reach = 1.0 + smax + 1e-6 * Lc * 2.220446049250313e-16 * 1e6 + 1e-3;
+      double tx0 = __builtin_inf(), tx1 = -__builtin_inf(), ty0 = __builtin_inf(), ty1 = -__builtin_inf();
+      for (int j = own.roff[0][t]; j < own.roff[0][t + 1]; j++) { tx0 = fmin(tx0, rgx[j]); tx1 = fmax(tx1, rgx[j]); ty0 = fmin(ty0, rgy[j]); ty1 = fmax(ty1, rgy[j]); }
+      if (!(tx1 + reach < bx0 || bx1 < tx0 - reach || ty1 + reach < by0 || by1 < ty0 - reach)) return false;
+    }
+  }
+  if (gl == 0 && dA > 0.0) { own.dxv[q] = dx * -1; own.dyv[q] = dy * -1; }
+  return true;
 }
 
 // The direction check of calc_normal_force (collisions.jl:58-68) for kept region q of the item whose rings and contact

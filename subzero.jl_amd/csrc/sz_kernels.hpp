@@ -1511,7 +1511,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
   // (narrow kernel 374 -> 242 us at 100 k floes; one head for the whole chip costs ~20 ns per ticket, serialised across the
   // XCDs: measured slower than the static split).  The results do not depend on who runs an item.
   const int nitems = sg.n;
-  if (gl == 0) { m.err = 0; m.ierr = 0; m.ntracefail = 0; m.nchk = 0; m.nkeep = 0; m.acc[0] = m.acc[1] = 0; m.acc16[0] = m.acc16[1] = m.acc16[2] = 0; }   // acc: work done by this group (in LDS: no register held across the rounds)
+  if (gl == 0) { m.err = 0; m.ierr = 0; m.ntracefail = 0; m.nchk = 0; m.nkeep = 0; m.acc[0] = m.acc[1] = 0; m.acc16[0] = m.acc16[1] = m.acc16[2] = m.acc16[3] = m.acc16[4] = 0; }   // acc: work done by this group (in LDS: no register held across the rounds)
   if (CLS == 0) {
     // housekeeping of the step (the neighbour search has consumed the cells; the integrator fills them again): cell counts
     // and overflow heads cleared, the guard counters of the coming update reset
@@ -1657,7 +1657,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       long long tA0 = clock64(); (void)tA0;
 #endif
       for (int pass = 0; pass == 0 || (pass - 1) * GPB < total; pass++) {
-        bool run = false; int g = gi, q = 0, buf = 0; double ox = 0.0, oy = 0.0;
+        bool run = false, cert = false; int g = gi, q = 0, buf = 0; double ox = 0.0, oy = 0.0;
         if (pass == 0) run = have && !(dbg & 4);
         else {
           const int idx = (pass - 1) * GPB + gi;
@@ -1666,6 +1666,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
             while (pre + mem[g].nchk <= idx) { pre += mem[g].nchk; g++; }
             q = (int)mem[g].chk[idx - pre];
             const auto& o = mem[g];
+            cert = o.chkc[idx - pre] != 0;
             run = true; buf = 1; ox = o.dxv[q]; oy = o.dyv[q];
             pna = o.rna; pnb = o.rnb; poa = o.roa; pob = o.rob;
             pba = Box{ o.box[0], o.box[1], o.box[2], o.box[3] }; pbb = Box{ o.box[4], o.box[5], o.box[6], o.box[7] };
@@ -1674,7 +1675,17 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
 #ifdef SZ_STAMPS
         long long tc0 = clock64();
 #endif
-        if (run) clip<G>(mem[g], m, gl, ox, oy, pna, poa, pnb, pob, buf, pba, pbb, st);
+        // A check of a lens-shaped region first tries to do without the second clip: only the crossing detection of the translated polygon
+        // (clip(.., detect_only)), then certified_check(); the full clip + check_post follow when that cannot settle the sign.  One call
+        // site of clip() for all of it (the turns of one loop: the routine exists once in the instruction stream).
+        bool settled = false;
+        for (int att = 0;; att++) {
+          const bool detect = run && cert && att == 0;
+          if (run) clip<G>(mem[g], m, gl, ox, oy, pna, poa, pnb, pob, buf, pba, pbb, st, detect);
+          if (detect) settled = certified_check<G>(mem[g], m, gl, q);
+          if (!detect || settled) break;
+        }
+        if (pass > 0 && run && gl == 0) { m.acc16[3]++; if (settled) m.acc16[4]++; }
 #ifdef SZ_STAMPS
         if (pass == 0) st.cA2 += clock64() - tc0;
 #endif
@@ -1687,7 +1698,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
           { long long now = clock64(); st.cA += now - st.tmark; st.tmark = now; st.ntask += total; int nl = 0; for (int k = 0; k < GPB; k++) nl += mem[k].nx > 0 && mem[k].nkeep > 0; st.nlive += nl; }
 #endif
         } else {
-          if (run) check_post<G>(mem[g], m, gl, q, st);
+          if (run && !settled) check_post<G>(mem[g], m, gl, q, st);
           gsync();
 #ifdef SZ_STAMPS
           st.npass++;
@@ -1736,11 +1747,11 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
   if (gl == 0 && m.ntracefail) atomicAdd(&S.cnt[C_TRACE_FAIL], m.ntracefail);
   {
     // one set of atomics per wavefront, spread over ACC_SLOTS lines (same-address atomics serialise chip-wide)
-    unsigned v[5];
-    for (int k = 0; k < 5; k++) { v[k] = gl != 0 ? 0u : k == 0 ? m.acc16[0] : k == 1 ? m.acc[0] : k == 2 ? m.acc[1] : k == 3 ? m.acc16[1] : m.acc16[2]; for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d); }
+    unsigned v[7];
+    for (int k = 0; k < 7; k++) { v[k] = gl != 0 ? 0u : k == 0 ? m.acc16[0] : k == 1 ? m.acc[0] : k == 2 ? m.acc[1] : k == 3 ? m.acc16[1] : k == 4 ? m.acc16[2] : k == 5 ? m.acc16[3] : m.acc16[4]; for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d); }
     if ((threadIdx.x & 63) == 0) {
       unsigned long long* a = S.acc + (size_t)((blockIdx.x * (TPB / 64) + (threadIdx.x >> 6)) % ACC_SLOTS) * 8;
-      for (int k = 0; k < 5; k++) if (v[k]) atomicAdd(a + 1 + k, (unsigned long long)v[k]);
+      for (int k = 0; k < 7; k++) if (v[k]) atomicAdd(a + 1 + k, (unsigned long long)v[k]);
       if (CLS == 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a, 1ull);
     }
   }
@@ -2245,6 +2256,120 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
 
 template <bool TW>
 __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P, int pmax) { forcing_body<TW>(S, P, blockIdx.x, gridDim.x, pmax, 0); }
+
+// ---- experimental variants of the one-way forcing loop (SZ_FRC_X, tools/forcing_ab.py)
+// sqrt by one reciprocal-square-root estimate and two coupled Newton steps (Goldschmidt): ~1 ulp, no scaling for denormals (the
+// arguments are squared relative velocities: 0 or far above the denormal range); 0 -> 0
+__device__ __forceinline__ double sqrt_fast(double s) {
+  const double y = __builtin_amdgcn_rsq(s);
+  double g = s * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  const double d = fma(-g, g, s);
+  g = fma(d, h, g);
+  return s > 0.0 ? g : 0.0;
+}
+template <int FG, bool PREF, bool LEAN>
+__device__ __forceinline__ void forcing_plain_x(State& S, const Params& P, int bid, int nblk) {
+  const int lane = threadIdx.x % FG, wpb = blockDim.x / FG, wid = threadIdx.x / FG;
+  if (stopped(S)) return;
+  const int N = S.cnt[C_NOWN];
+  const int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
+  const double cturn = cos(P.turn), sturn = sin(P.turn);
+  const double ka = P.rho_a * P.Cd_ia, ko = P.rho_o * P.Cd_io;
+  for (int i = bid * wpb + wid; i < N; i += nblk * wpb) {
+    double cxf = S.cx[i], cyf = S.cy[i]; const double u = S.u[i], v = S.v[i], xi = S.xi[i];
+    forcing_wrap(S, i, cxf, cyf);
+    const double ca = S.trig[2 * i], sa = S.trig[2 * i + 1];
+    const double ma_ratio = S.mass[i] / S.area[i];
+    const double mf = ma_ratio * P.fcor;
+    const int o = S.soff[i], ns = S.soff[i + 1] - o;
+    double tx = 0, ty = 0, ttrq = 0, th = 0; int np = 0;
+    double nsx = lane < ns ? S.sx[o + lane] : 0.0, nsy = lane < ns ? S.sy[o + lane] : 0.0;
+    for (int k = lane; k < ns; k += FG) {
+      double sxk, syk;
+      if constexpr (PREF) {
+        sxk = nsx; syk = nsy;
+        const int kn = k + FG;
+        nsx = kn < ns ? S.sx[o + kn] : 0.0; nsy = kn < ns ? S.sy[o + kn] : 0.0;
+      } else { sxk = S.sx[o + k]; syk = S.sy[o + k]; }
+      double x, y, xc, yc;
+      if constexpr (LEAN) {
+        xc = fma(ca, sxk, -(sa * syk)); yc = fma(sa, sxk, ca * syk);
+        x = xc + cxf; y = yc + cyf;
+      } else {
+        x = (ca * sxk - sa * syk) + cxf; y = (sa * sxk + ca * syk) + cyf;
+        xc = x - cxf; yc = y - cyf;
+      }
+      const bool inb = (per_x || (S.gx0 <= x && x <= S.gxf)) && (per_y || (S.gy0 <= y && y <= S.gyf));
+      if (!inb) continue;
+      np++;
+      const double up = u - xi * yc, vp = v + xi * xc;
+      const LatticeCell lc = lattice_cell(S, x, y, per_x, per_y);
+      double n4[4][5];
+      {
+        const int oo[4] = { lc.o00, lc.o01, lc.o10, lc.o11 };
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const double4 a = *(const double4*)(S.nodes + (size_t)oo[q] * 8);
+          n4[q][0] = a.x; n4[q][1] = a.y; n4[q][2] = a.z; n4[q][3] = a.w; n4[q][4] = S.nodes[(size_t)oo[q] * 8 + 4];
+        }
+      }
+      double uatm, vatm, uocn, vocn, hfl;
+      if constexpr (LEAN) {
+        // four weights once, then a field is one product and three fused multiply-adds
+        const double omty = 1.0 - lc.ty, omtx = 1.0 - lc.tx;
+        const double w00 = omtx * omty, w01 = omtx * lc.ty, w10 = lc.tx * omty, w11 = lc.tx * lc.ty;
+        auto sample = [&](int f) { return fma(w11, n4[3][f], fma(w10, n4[2][f], fma(w01, n4[1][f], w00 * n4[0][f]))); };
+        uatm = sample(3); vatm = sample(4); uocn = sample(0); vocn = sample(1); hfl = sample(2);
+      } else {
+        const double omty = 1.0 - lc.ty, omtx = 1.0 - lc.tx;
+        auto sample = [&](int f) {
+          double c0 = fma(lc.ty, n4[1][f], omty * n4[0][f]);
+          double c1 = fma(lc.ty, n4[3][f], omty * n4[2][f]);
+          return fma(lc.tx, c1, omtx * c0);
+        };
+        uatm = sample(3); vatm = sample(4); uocn = sample(0); vocn = sample(1); hfl = sample(2);
+      }
+      const double du = uatm - up, dv = vatm - vp;
+      const double duo = uocn - up, dvo = vocn - vp;
+      double fx, fy;
+      if constexpr (LEAN) {
+        const double nrm = sqrt_fast(fma(du, du, dv * dv)), nrmo = sqrt_fast(fma(duo, duo, dvo * dvo));
+        const double qa = ka * nrm, qo = ko * nrmo;
+        fx = fma(qa, du, fma(qo, fma(cturn, duo, -(sturn * dvo)), -(mf * vocn)));
+        fy = fma(qa, dv, fma(qo, fma(sturn, duo, cturn * dvo), mf * uocn));
+      } else {
+        const double nrm = sqrt(du * du + dv * dv);
+        const double tax = P.rho_a * P.Cd_ia * nrm * du, tay = P.rho_a * P.Cd_ia * nrm * dv;
+        const double nrmo = sqrt(duo * duo + dvo * dvo);
+        const double tox = P.rho_o * P.Cd_io * nrmo * (cturn * duo - sturn * dvo);
+        const double toy = P.rho_o * P.Cd_io * nrmo * (sturn * duo + cturn * dvo);
+        const double tpx = -ma_ratio * P.fcor * vocn, tpy = ma_ratio * P.fcor * uocn;
+        fx = tax + tpx + tox; fy = tay + tpy + toy;
+      }
+      tx += fx; ty += fy; th += hfl;
+      if constexpr (LEAN) ttrq += fma(fy, xc, -(fx * yc)); else ttrq += (-fx * yc + fy * xc);
+    }
+    for (int d = FG / 2; d >= 1; d >>= 1) {
+      tx += __shfl_xor(tx, d, FG); ty += __shfl_xor(ty, d, FG); ttrq += __shfl_xor(ttrq, d, FG); th += __shfl_xor(th, d, FG);
+    }
+    int npt = np;
+    for (int d = FG / 2; d >= 1; d >>= 1) npt += __shfl_xor(npt, d, FG);
+    if (lane == 0) {
+      S.frc_remove[i] = npt == 0 ? 1 : 0;
+      if (npt != 0) {
+        const double xcor = ma_ratio * P.fcor * v, ycor = ma_ratio * P.fcor * u;
+        const double totx = npt * xcor + tx, toty = -npt * ycor + ty;
+        const double area = S.area[i];
+        S.fxOA[i] = totx / npt * area; S.fyOA[i] = toty / npt * area;
+        S.trqOA[i] = ttrq / npt * area; S.hflx[i] = th / npt;
+      }
+    }
+  }
+}
+template <int FG, bool PREF, bool LEAN, int WPE>
+__global__ void __launch_bounds__(256, WPE) sz_k_forcing_x(State S, Params P) { forcing_plain_x<FG, PREF, LEAN>(S, P, blockIdx.x, gridDim.x); }
 // dynamic LDS of sz_k_forcing<true> for pmax points per floe
 inline size_t tw_forcing_lds(int pmax) { return (size_t)TW_FPB * ((size_t)2 * pmax * sizeof(double) + (size_t)(pmax + FC_CAP) * (sizeof(int) + 1)); }
 
@@ -2984,11 +3109,11 @@ __global__ void sz_k_stats(State S, long long* out) {
     for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
     if ((threadIdx.x & 63) == 0 && x) atomicAdd((unsigned long long*)&out[k < 10 ? k : k + 6], (unsigned long long)x);     // pairs, pairs run: out[16], out[17]
   }
-  // out[10..15]: the cumulative narrow-phase work counters (sum over the slots)
-  if (blockIdx.x == 0 && threadIdx.x < 6) {
+  // out[10..15], out[18..19]: the cumulative narrow-phase work counters (sum over the slots)
+  if (blockIdx.x == 0 && threadIdx.x < 8) {
     unsigned long long t = 0;
     for (int q = 0; q < ACC_SLOTS; q++) t += S.acc[(size_t)q * 8 + threadIdx.x];
-    out[10 + threadIdx.x] = (long long)t;
+    out[threadIdx.x < 6 ? 10 + threadIdx.x : 12 + threadIdx.x] = (long long)t;
   }
 }
 

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 N=${1:-100000}; K=${2:-60}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_ksn
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ksn -o ks -- python3 $R/bench.py --no-cpu-baseline --floes $N --steps $K --warmup 10 > $R/gpurun_out/prof_ksn.json 2> $R/gpurun_out/prof_ksn.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ksn -o ks -- python3 $R/bench.py --no-cpu-baseline --no-strong-reference --floes $N --steps $K --warmup 10 > $R/gpurun_out/prof_ksn.json 2> $R/gpurun_out/prof_ksn.err
 cut -c1-160 $R/gpurun_out/prof_ksn.json
 python3 - <<PY
 import csv, glob
