@@ -602,16 +602,7 @@ void stage_forcing(sz_ctx* c, int dt = -1) {      // in-order variant (process m
   if (!c->two_way && c->precision == 1) {
     hipLaunchKernelGGL(sz_k_forcing_mixed, dim3(grid_for(c->S.capM, 256 / FRC_PLAIN, 8192)), dim3(256), 0, c->stream, c->S, c->P);
   } else if (!c->two_way) {
-    const int x = getenv("SZ_FRC_X") ? atoi(getenv("SZ_FRC_X")) : 0;        // experiments (tools/forcing_ab.py)
-    const dim3 g32(grid_for(c->S.capM, 256 / 32, 8192)), g16(grid_for(c->S.capM, 256 / 16, 8192)), b(256);
-    if (x == 1) hipLaunchKernelGGL((sz_k_forcing_x<32, true, false, 1>), g32, b, 0, c->stream, c->S, c->P);
-    else if (x == 2) hipLaunchKernelGGL((sz_k_forcing_x<32, false, true, 1>), g32, b, 0, c->stream, c->S, c->P);
-    else if (x == 3) hipLaunchKernelGGL((sz_k_forcing_x<32, true, true, 1>), g32, b, 0, c->stream, c->S, c->P);
-    else if (x == 4) hipLaunchKernelGGL((sz_k_forcing_x<16, true, true, 1>), g16, b, 0, c->stream, c->S, c->P);
-    else if (x == 5) hipLaunchKernelGGL((sz_k_forcing_x<32, true, true, 5>), g32, b, 0, c->stream, c->S, c->P);
-    else if (x == 6) hipLaunchKernelGGL((sz_k_forcing_x<16, false, true, 5>), g16, b, 0, c->stream, c->S, c->P);
-    else if (x == 7) hipLaunchKernelGGL((sz_k_forcing_x<32, false, false, 1>), g32, b, 0, c->stream, c->S, c->P);
-    else hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_PLAIN, 8192)), dim3(256), 0, c->stream, c->S, c->P, 0);
+    hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_PLAIN, 8192)), dim3(256), 0, c->stream, c->S, c->P, 0);
   } else {
     // timestep_coupling! with two_way_coupling_on (coupling.jl:1705-1738): one-way forcings + per-floe cell slots,
     // then calc_two_way_coupling! (:1617-1680) as a counting sort by cell, one clip per (floe, cell) entry, a reduction

@@ -747,9 +747,9 @@ SZ_DEV void contact_post(MEM& m, int gl, int na, int nb, const ItemCtx& cx_, int
 template <int G, class MEM>
 SZ_DEV bool certified_check(MEM& own, const MEM& scr, int gl, int q) {
   const int K = own.nsig, K1 = scr.nraw;
-  bool ok = K1 == K && K >= 2;
+  if (K1 != K || K < 2) return false;
   // every crossing of the translated polygon is one of the contact clip's (same edges, same flags); K1 == K and distinct pairs: a bijection
-  if (ok) {
+  {
     bool mine = true;
     for (int s2 = gl; s2 < K1; s2 += G) {
       const int ia = scr.ria[s2], ib = scr.rib[s2], fl = scr.rfl[s2] & 3;
@@ -759,71 +759,61 @@ SZ_DEV bool certified_check(MEM& own, const MEM& scr, int gl, int q) {
     }
     const int gshift = (int)(threadIdx.x & 63) / G * G;
     const unsigned long long bad = (__ballot(!mine) >> gshift) & (G >= 64 ? ~0ull : ((1ull << G) - 1ull));
-    ok = bad == 0;
+    if (bad) return false;
   }
-  if (!ok) return false;
   const int r = own.keep[q];
   int kin = -1, kout = -1, ncr = 0;
-  for (int k = 0; k < K; k++) if (own.creg[k] == r) { ncr++; if (own.sgf[k] & 1) kin = k; else kout = k; }
+  for (int k = 0; k < K; k++) {
+    const int cr = own.creg[k];
+    if (cr == 0xff) return false;            // a crossing of no region (a sliver of zero area): the translation may give it one
+    if (cr == r) { ncr++; if (own.sgf[k] & 1) kin = k; else kout = k; }
+  }
   if (ncr != 2 || kin < 0 || kout < 0) return false;
   const double dx = own.dxv[q], dy = own.dyv[q];
   const double* rgx = own.reg[0][0]; const double* rgy = own.reg[0][1];
-  const double cix = rgx[own.cpos[kin]], ciy = rgy[own.cpos[kin]], cox = rgx[own.cpos[kout]], coy = rgy[own.cpos[kout]];
-  // slides of the two crossings along their b-edges for the unit translation d
-  double wx[2], wy[2], tbs[2]; bool good = true;
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    const int k = h == 0 ? kin : kout;
+  // slide of crossing k along its b-edge for the unit translation d, as a parameter step of that edge: t = (d x e_a) / (e_b x e_a)
+  auto slide = [&](int k, double& ebx, double& eby) {
     const int ia = own.sga[k], ib = own.sgb[k];
     const double eax = own.ax[ia + 1] - own.ax[ia], eay = own.ay[ia + 1] - own.ay[ia];
-    const double ebx = own.bx[ib + 1] - own.bx[ib], eby = own.by[ib + 1] - own.by[ib];
-    const double den = ebx * eay - eby * eax;                 // e_b x e_a
-    const double num = dx * eay - dy * eax;                   // d x e_a
-    if (den == 0.0) good = false;
-    const double t = num / den;
-    tbs[h] = t; wx[h] = t * ebx; wy[h] = t * eby;
-  }
-  if (!good) return false;
-  const double oa = (double)own.roa;
-  const double dA = oa * ((dx * (coy - ciy) - dy * (cox - cix)) + 0.5 * (dx * (wy[1] - wy[0]) - dy * (wx[1] - wx[0])));
-  // round-off floor of the reference's two area sums and of the crossing points: n eps Lc^2 with a wide margin
-  const int nr = own.roff[0][r + 1] - own.roff[0][r];
-  const double Lc = fmax(fmax(fabs(cix), fabs(ciy)), fmax(fabs(cox), fabs(coy)));
-  const double tol = 256.0 * (double)(nr + 8) * 2.220446049250313e-16 * Lc * Lc + 1e-9 * own.rarea[0][r];
-  if (!(fabs(dA) > tol)) return false;
-  // the new lens intersects the old one: a p2 vertex lies on both boundaries unless both crossings sit on ONE edge of p2 -- then the
-  // old and the new interval of that edge must overlap (parameters along the edge, the slides are tbs)
-  if (own.sgb[kin] == own.sgb[kout]) {
-    const int ib = own.sgb[kin];
-    const double ebx = own.bx[ib + 1] - own.bx[ib], eby = own.by[ib + 1] - own.by[ib], e2 = ebx * ebx + eby * eby;
-    const double t0 = ((cix - own.bx[ib]) * ebx + (ciy - own.by[ib]) * eby) / e2, t1 = ((cox - own.bx[ib]) * ebx + (coy - own.by[ib]) * eby) / e2;
-    const double lo = fmin(t0, t1), hi = fmax(t0, t1), lo1 = fmin(t0 + tbs[0], t1 + tbs[1]), hi1 = fmax(t0 + tbs[0], t1 + tbs[1]);
-    if (!(fmax(lo, lo1) < fmin(hi, hi1))) return false;
-  }
-  // other regions of the item: theirs stay within (1 + their slides) of where they were; keep it simple and rigorous -- boxes of the
-  // old regions, grown by a reach that covers any slide that keeps a crossing on its edge (an edge is no longer than the ring box)
+    ebx = own.bx[ib + 1] - own.bx[ib]; eby = own.by[ib + 1] - own.by[ib];
+    return (dx * eay - dy * eax) / (ebx * eay - eby * eax);          // (den == 0: inf / nan, refused by the tolerance test below)
+  };
+  // other regions of the item stay within (1 m + their slides) of where they were: their boxes, grown by that reach, must miss this one's
   const int nreg = own.nreg[0];
   if (nreg > 1) {
     double bx0 = __builtin_inf(), bx1 = -__builtin_inf(), by0 = __builtin_inf(), by1 = -__builtin_inf();
     for (int j = own.roff[0][r]; j < own.roff[0][r + 1]; j++) { bx0 = fmin(bx0, rgx[j]); bx1 = fmax(bx1, rgx[j]); by0 = fmin(by0, rgy[j]); by1 = fmax(by1, rgy[j]); }
     for (int t = 0; t < nreg; t++) {
       if (t == r) continue;
-      // the crossings of region t slide by at most smax_t
-      double smax = 0.0;
-      for (int k = 0; k < K; k++) if (own.creg[k] == t) {
-        const int ia = own.sga[k], ib = own.sgb[k];
-        const double eax = own.ax[ia + 1] - own.ax[ia], eay = own.ay[ia + 1] - own.ay[ia];
-        const double ebx = own.bx[ib + 1] - own.bx[ib], eby = own.by[ib + 1] - own.by[ib];
-        const double den = ebx * eay - eby * eax;
-        if (den == 0.0) return false;
-        const double tt = (dx * eay - dy * eax) / den;
-        smax = fmax(smax, fabs(tt) * sqrt(ebx * ebx + eby * eby));
-      }
-      const double reach = 1.0 + smax + 1e-6 * Lc * 2.220446049250313e-16 * 1e6 + 1e-3;
-      double tx0 = __builtin_inf(), tx1 = -__builtin_inf(), ty0 = __builtin_inf(), ty1 = -__builtin_inf();
-      for (int j = own.roff[0][t]; j < own.roff[0][t + 1]; j++) { tx0 = fmin(tx0, rgx[j]); tx1 = fmax(tx1, rgx[j]); ty0 = fmin(ty0, rgy[j]); ty1 = fmax(ty1, rgy[j]); }
-      if (!(tx1 + reach < bx0 || bx1 < tx0 - reach || ty1 + reach < by0 || by1 < ty0 - reach)) return false;
+      double reach = 0.0;
+      for (int k = 0; k < K; k++) if (own.creg[k] == t) { double ebx, eby; const double tt = slide(k, ebx, eby); reach = fmax(reach, fabs(tt) * sqrt(ebx * ebx + eby * eby)); }
+      reach += 1.001;
+      bool apart = false;
+      { double lo = __builtin_inf(), hi = -__builtin_inf(); for (int j = own.roff[0][t]; j < own.roff[0][t + 1]; j++) { lo = fmin(lo, rgx[j]); hi = fmax(hi, rgx[j]); } apart |= hi + reach < bx0 || bx1 < lo - reach; }
+      { double lo = __builtin_inf(), hi = -__builtin_inf(); for (int j = own.roff[0][t]; j < own.roff[0][t + 1]; j++) { lo = fmin(lo, rgy[j]); hi = fmax(hi, rgy[j]); } apart |= hi + reach < by0 || by1 < lo - reach; }
+      if (!apart) return false;            // (reach = nan compares false everywhere: refused)
     }
+  }
+  const double cix = rgx[own.cpos[kin]], ciy = rgy[own.cpos[kin]], cox = rgx[own.cpos[kout]], coy = rgy[own.cpos[kout]];
+  double ebx, eby;
+  const double tin = slide(kin, ebx, eby);
+  double second = -(dx * (tin * eby) - dy * (tin * ebx));
+  const double tout = slide(kout, ebx, eby);
+  second += dx * (tout * eby) - dy * (tout * ebx);
+  const double dA = (double)own.roa * ((dx * (coy - ciy) - dy * (cox - cix)) + 0.5 * second);
+  // round-off floor of the reference's two area sums and of the crossing points: n eps Lc^2 with a wide margin
+  const int nr = own.roff[0][r + 1] - own.roff[0][r];
+  const double Lc = fmax(fmax(fabs(cix), fabs(ciy)), fmax(fabs(cox), fabs(coy)));
+  const double tol = 256.0 * (double)(nr + 8) * 2.220446049250313e-16 * Lc * Lc + 1e-9 * own.rarea[0][r];
+  if (!(fabs(dA) > tol)) return false;
+  // the new lens intersects the old one: a p2 vertex lies on both boundaries unless both crossings sit on ONE edge of p2 -- then the
+  // old and the new interval of that edge must overlap (parameters along the edge; (ebx, eby) is that edge's vector after the call above)
+  if (own.sgb[kin] == own.sgb[kout]) {
+    const int ib = own.sgb[kin];
+    const double e2 = ebx * ebx + eby * eby;
+    const double t0 = ((cix - own.bx[ib]) * ebx + (ciy - own.by[ib]) * eby) / e2, t1 = ((cox - own.bx[ib]) * ebx + (coy - own.by[ib]) * eby) / e2;
+    const double lo = fmin(t0, t1), hi = fmax(t0, t1), lo1 = fmin(t0 + tin, t1 + tout), hi1 = fmax(t0 + tin, t1 + tout);
+    if (!(fmax(lo, lo1) < fmin(hi, hi1))) return false;
   }
   if (gl == 0 && dA > 0.0) { own.dxv[q] = dx * -1; own.dyv[q] = dy * -1; }
   return true;

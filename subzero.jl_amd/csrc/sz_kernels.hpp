@@ -2257,119 +2257,6 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
 template <bool TW>
 __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P, int pmax) { forcing_body<TW>(S, P, blockIdx.x, gridDim.x, pmax, 0); }
 
-// ---- experimental variants of the one-way forcing loop (SZ_FRC_X, tools/forcing_ab.py)
-// sqrt by one reciprocal-square-root estimate and two coupled Newton steps (Goldschmidt): ~1 ulp, no scaling for denormals (the
-// arguments are squared relative velocities: 0 or far above the denormal range); 0 -> 0
-__device__ __forceinline__ double sqrt_fast(double s) {
-  const double y = __builtin_amdgcn_rsq(s);
-  double g = s * y, h = 0.5 * y;
-  double r = fma(-h, g, 0.5);
-  g = fma(g, r, g); h = fma(h, r, h);
-  const double d = fma(-g, g, s);
-  g = fma(d, h, g);
-  return s > 0.0 ? g : 0.0;
-}
-template <int FG, bool PREF, bool LEAN>
-__device__ __forceinline__ void forcing_plain_x(State& S, const Params& P, int bid, int nblk) {
-  const int lane = threadIdx.x % FG, wpb = blockDim.x / FG, wid = threadIdx.x / FG;
-  if (stopped(S)) return;
-  const int N = S.cnt[C_NOWN];
-  const int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
-  const double cturn = cos(P.turn), sturn = sin(P.turn);
-  const double ka = P.rho_a * P.Cd_ia, ko = P.rho_o * P.Cd_io;
-  for (int i = bid * wpb + wid; i < N; i += nblk * wpb) {
-    double cxf = S.cx[i], cyf = S.cy[i]; const double u = S.u[i], v = S.v[i], xi = S.xi[i];
-    forcing_wrap(S, i, cxf, cyf);
-    const double ca = S.trig[2 * i], sa = S.trig[2 * i + 1];
-    const double ma_ratio = S.mass[i] / S.area[i];
-    const double mf = ma_ratio * P.fcor;
-    const int o = S.soff[i], ns = S.soff[i + 1] - o;
-    double tx = 0, ty = 0, ttrq = 0, th = 0; int np = 0;
-    double nsx = lane < ns ? S.sx[o + lane] : 0.0, nsy = lane < ns ? S.sy[o + lane] : 0.0;
-    for (int k = lane; k < ns; k += FG) {
-      double sxk, syk;
-      if constexpr (PREF) {
-        sxk = nsx; syk = nsy;
-        const int kn = k + FG;
-        nsx = kn < ns ? S.sx[o + kn] : 0.0; nsy = kn < ns ? S.sy[o + kn] : 0.0;
-      } else { sxk = S.sx[o + k]; syk = S.sy[o + k]; }
-      double x, y, xc, yc;
-      if constexpr (LEAN) {
-        xc = fma(ca, sxk, -(sa * syk)); yc = fma(sa, sxk, ca * syk);
-        x = xc + cxf; y = yc + cyf;
-      } else {
-        x = (ca * sxk - sa * syk) + cxf; y = (sa * sxk + ca * syk) + cyf;
-        xc = x - cxf; yc = y - cyf;
-      }
-      const bool inb = (per_x || (S.gx0 <= x && x <= S.gxf)) && (per_y || (S.gy0 <= y && y <= S.gyf));
-      if (!inb) continue;
-      np++;
-      const double up = u - xi * yc, vp = v + xi * xc;
-      const LatticeCell lc = lattice_cell(S, x, y, per_x, per_y);
-      double n4[4][5];
-      {
-        const int oo[4] = { lc.o00, lc.o01, lc.o10, lc.o11 };
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const double4 a = *(const double4*)(S.nodes + (size_t)oo[q] * 8);
-          n4[q][0] = a.x; n4[q][1] = a.y; n4[q][2] = a.z; n4[q][3] = a.w; n4[q][4] = S.nodes[(size_t)oo[q] * 8 + 4];
-        }
-      }
-      double uatm, vatm, uocn, vocn, hfl;
-      if constexpr (LEAN) {
-        // four weights once, then a field is one product and three fused multiply-adds
-        const double omty = 1.0 - lc.ty, omtx = 1.0 - lc.tx;
-        const double w00 = omtx * omty, w01 = omtx * lc.ty, w10 = lc.tx * omty, w11 = lc.tx * lc.ty;
-        auto sample = [&](int f) { return fma(w11, n4[3][f], fma(w10, n4[2][f], fma(w01, n4[1][f], w00 * n4[0][f]))); };
-        uatm = sample(3); vatm = sample(4); uocn = sample(0); vocn = sample(1); hfl = sample(2);
-      } else {
-        const double omty = 1.0 - lc.ty, omtx = 1.0 - lc.tx;
-        auto sample = [&](int f) {
-          double c0 = fma(lc.ty, n4[1][f], omty * n4[0][f]);
-          double c1 = fma(lc.ty, n4[3][f], omty * n4[2][f]);
-          return fma(lc.tx, c1, omtx * c0);
-        };
-        uatm = sample(3); vatm = sample(4); uocn = sample(0); vocn = sample(1); hfl = sample(2);
-      }
-      const double du = uatm - up, dv = vatm - vp;
-      const double duo = uocn - up, dvo = vocn - vp;
-      double fx, fy;
-      if constexpr (LEAN) {
-        const double nrm = sqrt_fast(fma(du, du, dv * dv)), nrmo = sqrt_fast(fma(duo, duo, dvo * dvo));
-        const double qa = ka * nrm, qo = ko * nrmo;
-        fx = fma(qa, du, fma(qo, fma(cturn, duo, -(sturn * dvo)), -(mf * vocn)));
-        fy = fma(qa, dv, fma(qo, fma(sturn, duo, cturn * dvo), mf * uocn));
-      } else {
-        const double nrm = sqrt(du * du + dv * dv);
-        const double tax = P.rho_a * P.Cd_ia * nrm * du, tay = P.rho_a * P.Cd_ia * nrm * dv;
-        const double nrmo = sqrt(duo * duo + dvo * dvo);
-        const double tox = P.rho_o * P.Cd_io * nrmo * (cturn * duo - sturn * dvo);
-        const double toy = P.rho_o * P.Cd_io * nrmo * (sturn * duo + cturn * dvo);
-        const double tpx = -ma_ratio * P.fcor * vocn, tpy = ma_ratio * P.fcor * uocn;
-        fx = tax + tpx + tox; fy = tay + tpy + toy;
-      }
-      tx += fx; ty += fy; th += hfl;
-      if constexpr (LEAN) ttrq += fma(fy, xc, -(fx * yc)); else ttrq += (-fx * yc + fy * xc);
-    }
-    for (int d = FG / 2; d >= 1; d >>= 1) {
-      tx += __shfl_xor(tx, d, FG); ty += __shfl_xor(ty, d, FG); ttrq += __shfl_xor(ttrq, d, FG); th += __shfl_xor(th, d, FG);
-    }
-    int npt = np;
-    for (int d = FG / 2; d >= 1; d >>= 1) npt += __shfl_xor(npt, d, FG);
-    if (lane == 0) {
-      S.frc_remove[i] = npt == 0 ? 1 : 0;
-      if (npt != 0) {
-        const double xcor = ma_ratio * P.fcor * v, ycor = ma_ratio * P.fcor * u;
-        const double totx = npt * xcor + tx, toty = -npt * ycor + ty;
-        const double area = S.area[i];
-        S.fxOA[i] = totx / npt * area; S.fyOA[i] = toty / npt * area;
-        S.trqOA[i] = ttrq / npt * area; S.hflx[i] = th / npt;
-      }
-    }
-  }
-}
-template <int FG, bool PREF, bool LEAN, int WPE>
-__global__ void __launch_bounds__(256, WPE) sz_k_forcing_x(State S, Params P) { forcing_plain_x<FG, PREF, LEAN>(S, P, blockIdx.x, gridDim.x); }
 // dynamic LDS of sz_k_forcing<true> for pmax points per floe
 inline size_t tw_forcing_lds(int pmax) { return (size_t)TW_FPB * ((size_t)2 * pmax * sizeof(double) + (size_t)(pmax + FC_CAP) * (sizeof(int) + 1)); }
 
