@@ -54,6 +54,8 @@ struct sz_ctx {
   Params P{};
   std::string err;
   Pool allocs;        // per-upload allocations
+  Pool list_allocs;   // the lists whose capacity follows the field and GROWS on demand (grow_lists): neighbour lists, pair items, item rows
+  int callid = 0;     // collision calls so far (State::callid: a call run again after its lists grew adds its overlap to floe.overarea once)
   Pool inter_allocs;  // floe.interactions (inter_cnt, inter_rows): survive an upload of the same size -- a shim uploads between
                       // timestep_collisions! and timestep_floe_properties!, and calc_stress! reads the rows of the collisions
   int inter_capM = 0, inter_rowcap = 0; bool inter_any = false, inter_lost = false;
@@ -247,6 +249,61 @@ int sync_and_check(sz_ctx* c, int* cnt_out = nullptr) {
   return SZ_OK;
 }
 
+// ---------------------------------------------------------------- lists that follow the field
+// floe.interactions (rows at a stride of State::rowcap per floe): kept across an upload of the same size (see sz_upload_floes)
+int carve_interactions(sz_ctx* c) {
+  State& S = c->S;
+  if (c->inter_capM != S.capM || c->inter_rowcap != S.rowcap || c->inter_allocs.empty()) {
+    free_pool(c->inter_allocs);
+    int rc;
+    if ((rc = dalloc(c, &S.inter_cnt, (size_t)S.capM + 1, c->inter_allocs))) return rc;
+    if ((rc = dalloc(c, &S.inter_rows, (size_t)S.capM * S.rowcap * 7, c->inter_allocs))) return rc;
+    c->inter_capM = S.capM; c->inter_rowcap = S.rowcap; c->inter_lost = c->inter_any; c->inter_any = false;
+  }
+  return SZ_OK;
+}
+// neighbour lists (stride State::maxnb), the narrow phase's work list and the rows of its items (State::capPairs)
+int carve_lists(sz_ctx* c) {
+  State& S = c->S;
+  reset_pool(c->list_allocs);
+  int rc;
+#define DL(field, n) if ((rc = dalloc(c, &S.field, (size_t)(n), c->list_allocs))) return rc
+  DL(nb_out, (size_t)S.capM * S.maxnb); DL(nb_in, (size_t)S.capM * S.maxnb);
+  DL(work, 2 * ((size_t)S.capPairs + NSEG)); DL(wq, NSEG * 32); DL(pair_i, S.capPairs); DL(pair_j, S.capPairs);
+  DL(it_rows, ((size_t)S.capPairs + S.capElem) * ROWS_PER_ITEM * 5); DL(it_info, (size_t)S.capM * S.maxnb + S.capElem + 1);
+#undef DL
+  trim_pool(c->list_allocs);
+  HIPCHK(c, hipMemsetAsync(S.wq, 0, NSEG * 32 * sizeof(int), c->stream));
+  return SZ_OK;
+}
+// The reference's lists grow as needed (collisions.jl:290-296: vcat; the Dict of the pair loop).  A call / step that outgrew a list has
+// raised the matching error bit (and, inside a resident batch, paused the batch before anything of the floes' state changed): the lists
+// are carved again with the next capacity and the caller runs the call / step again.  growable: nothing but list capacities overflowed.
+constexpr int GROW_BITS = ERR_CAP_NEIGH | ERR_CAP_PAIRS | ERR_CAP_INTER;
+bool growable(int bits) { return bits != 0 && (bits & ~GROW_BITS) == 0; }
+int grow_lists(sz_ctx* c, int bits) {
+  State& S = c->S;
+  int maxnb = S.maxnb, rowcap = S.rowcap; long long capPairs = S.capPairs;
+  if (bits & ERR_CAP_NEIGH) {
+    if (maxnb >= 256) { c->err = "a floe has more than 256 bounding-circle neighbours in one direction: beyond the engine's largest neighbour capacity"; return SZ_E_CAPACITY; }
+    maxnb = maxnb <= MAXNB ? 64 : 256;
+    rowcap = std::max(rowcap, maxnb <= 64 ? 128 : 512);
+    capPairs = std::max(capPairs, (long long)S.capM * 16);
+  }
+  if (bits & ERR_CAP_INTER) rowcap *= 4;
+  if (bits & ERR_CAP_PAIRS) capPairs *= 2;
+  const double bytes = (double)S.capM * maxnb * 16.0 + (double)capPairs * (16.0 + 8.0 + ROWS_PER_ITEM * 40.0) + (double)S.capM * rowcap * 56.0;
+  if (rowcap > 8192 || capPairs > (1LL << 30) || bytes > 64e9) { c->err = "the lists a step needs have outgrown 64 GB (neighbours / pair items / interaction rows per floe)"; return SZ_E_CAPACITY; }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (getenv("SZ_VERBOSE")) fprintf(stderr, "[subzero-hip] lists grow (bits 0x%x): neighbours %d -> %d, rows per floe %d -> %d, pair items %d -> %lld\n", bits, S.maxnb, maxnb, S.rowcap, rowcap, S.capPairs, capPairs);
+  S.maxnb = maxnb; S.rowcap = rowcap; S.capPairs = (int)capPairs;
+  int rc = carve_lists(c);
+  if (!rc) rc = carve_interactions(c);
+  if (!rc) HIPCHK(c, hipMemsetAsync(S.inter_cnt, 0, ((size_t)S.capM + 1) * sizeof(int), c->stream));
+  c->inter_lost = false;             // (the call that is run again provides the rows)
+  return rc;
+}
+
 // ---------------------------------------------------------------- element table upload
 int upload_elements(sz_ctx* c) {
   free_pool(c->static_allocs);
@@ -421,9 +478,11 @@ void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false
     } else if (S.maxnb <= MAXNB) {
       if (fam) hipLaunchKernelGGL((sz_k_neighbors<true, MAXNB>), gr, bl, 0, c->stream, S);
       else hipLaunchKernelGGL((sz_k_neighbors<false, MAXNB>), gr, bl, 0, c->stream, S);
-    } else {
+    } else if (S.maxnb <= 64) {
       if (fam) hipLaunchKernelGGL((sz_k_neighbors<true, 64>), gr, bl, 0, c->stream, S);
       else hipLaunchKernelGGL((sz_k_neighbors<false, 64>), gr, bl, 0, c->stream, S);
+    } else {          // (a floe with more than 64 neighbours: the capacity that keeps such a field running)
+      hipLaunchKernelGGL((sz_k_neighbors<false, 256>), dim3(grid_for(S.capM, 64 / NB_G, 16384)), dim3(64), 0, c->stream, S);
     }
   }
   t.end();
@@ -765,7 +824,7 @@ void sz_destroy(sz_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  free_pool(c->allocs); free_pool(c->inter_allocs); free_pool(c->static_allocs); free_pool(c->field_allocs); free_pool(c->tw_allocs); free_pool(c->tw_field_allocs);
+  free_pool(c->allocs); free_pool(c->list_allocs); free_pool(c->inter_allocs); free_pool(c->static_allocs); free_pool(c->field_allocs); free_pool(c->tw_allocs); free_pool(c->tw_field_allocs);
   free_pool(c->mixed_pt_allocs); free_pool(c->mixed_node_allocs); free_pool(c->mixed_geom_allocs); free_pool(c->comm_allocs); free_pool(c->tw_part_allocs);
   (void)sz_comm_destroy(c);
   for (auto& e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -918,9 +977,10 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   // neighbour and row capacities from the field itself: like-sized floes 24 / 32, a size spectrum 64 / 128 (SZ_MAXNB=24|64 overrides)
   int window_max = 0;
   c->nb_count_max = host_max_neighbours(c, f, M, &window_max);
-  S.maxnb = c->nb_count_max + 2 <= MAXNB && window_max <= 80 ? MAXNB : 64;
-  if (const char* e = getenv("SZ_MAXNB")) S.maxnb = atoi(e) > MAXNB ? 64 : MAXNB;
-  S.rowcap = S.maxnb <= MAXNB ? ROWCAP : 128;
+  S.maxnb = c->nb_count_max + 2 <= MAXNB && window_max <= 80 ? MAXNB : c->nb_count_max + 2 <= 64 ? 64 : 256;
+  if (const char* e = getenv("SZ_MAXNB")) S.maxnb = atoi(e) > 64 ? 256 : atoi(e) > MAXNB ? 64 : MAXNB;
+  S.rowcap = S.maxnb <= MAXNB ? ROWCAP : S.maxnb <= 64 ? 128 : 512;
+  if (const char* e = getenv("SZ_ROWCAP")) S.rowcap = std::max(1, atoi(e));          // (tests of the growth path)
   S.capM = 2 * M + 64; S.capV = 2 * V + 4096; S.capPairs = S.capM * (S.maxnb <= MAXNB ? 8 : 16); S.capElem = S.capM * 4;
   S.capRows = S.capPairs * 3 + S.capElem * 2; S.capCells = 4 * S.capM + 64; S.capS = NS;
   int rc;
@@ -970,22 +1030,18 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2); DA(gcand, (size_t)2 * S.capM); DA(galloc, 32); DA(gkeys, (size_t)2 * S.capM); DA(fam, S.capM);
   DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1); DA(cell_ovf, S.capCells + 1); DA(cell_slots, (size_t)S.capCells * CELL_K + 8);
   DA(cell_items, S.capM);
-  DA(nb_out, (size_t)S.capM * S.maxnb); DA(nb_in, (size_t)S.capM * S.maxnb); DA(n_out, S.capM + 1); DA(n_in, S.capM + 1);
-  DA(out_off, S.capM + 2); DA(out_mask, S.capM + 1); DA(work, 2 * ((size_t)S.capPairs + NSEG)); DA(wq, NSEG * 32); DA(pair_i, S.capPairs); DA(pair_j, S.capPairs);
+  DA(n_out, S.capM + 1); DA(n_in, S.capM + 1); DA(over_stamp, S.capM + 1); DA(over_base, S.capM + 1);
+  DA(out_off, S.capM + 2);
   DA(el_off, S.capM + 2); DA(el_floe, S.capElem); DA(el_elem, S.capElem);
-  size_t items = (size_t)S.capPairs + S.capElem;
-  DA(it_rows, items * ROWS_PER_ITEM * 5); DA(it_info, (size_t)S.capM * S.maxnb + S.capElem + 1);
   DA(inter_off, S.capM + 2);
+  HIPCHK(c, hipMemsetAsync(S.over_stamp, 0, ((size_t)S.capM + 1) * sizeof(int), c->stream));
+  // neighbour lists, pair items and their rows: in a pool of their own, carved again (larger) when a step outgrows them
+  if ((rc = carve_lists(c))) return rc;
   // floe.interactions is part of the floe state, but not of sz_floe_columns (it is ragged): the rows the last
   // collision call left stay valid across an upload of the same size; after an upload of another size they are
   // gone, and sz_timestep_floe_properties / sz_calc_stress refuse to run on nothing (SZ_E_STATE) until
   // sz_upload_interactions or a collision call provides them again
-  if (c->inter_capM != S.capM || c->inter_rowcap != S.rowcap || c->inter_allocs.empty()) {
-    free_pool(c->inter_allocs);
-    if ((rc = dalloc(c, &S.inter_cnt, (size_t)S.capM + 1, c->inter_allocs))) return rc;
-    if ((rc = dalloc(c, &S.inter_rows, (size_t)S.capM * S.rowcap * 7, c->inter_allocs))) return rc;
-    c->inter_capM = S.capM; c->inter_rowcap = S.rowcap; c->inter_lost = c->inter_any; c->inter_any = false;
-  }
+  if ((rc = carve_interactions(c))) return rc;
   DA(blk, std::max(S.capCells, std::max(S.capM, 1024)) / SCAN_B + 1024);
   DA(tagA, S.capM + 1);
   DA(stamps, 512 + 8 * 8000);
@@ -1237,11 +1293,17 @@ int sz_timestep_collisions(sz_ctx* c, int64_t n_init, int32_t dt) {
   (void)hipSetDevice(c->device);
   c->gi_valid = false;         // (what follows numbers its ghosts by storage position)
   leave_resident(c);            // a process-mode call: the resident steps' ghost-candidate list is stale, the world rings must be current
-  collisions(c, (int)n_init, dt);
-  c->inter_any = true; c->inter_lost = false;
+  c->S.callid = ++c->callid;
   int h[C_COUNT];
-  int rc = sync_and_check(c, h);
-  if (rc) return rc;
+  for (;;) {
+    collisions(c, (int)n_init, dt);
+    c->inter_any = true; c->inter_lost = false;
+    int rc = sync_and_check(c, h);
+    // a list outgrown (neighbours per floe, pair items, rows per floe): larger lists, the call again -- the reference's lists grow (collisions.jl:290-296)
+    if (rc == SZ_E_CAPACITY && growable(c->last_err_bits)) { if ((rc = grow_lists(c, c->last_err_bits))) return rc; continue; }
+    if (rc) return rc;
+    break;
+  }
   return host_fuse_fixup(c, h, true);
 }
 
@@ -1262,6 +1324,7 @@ int sz_collide_pairs(sz_ctx* c, int64_t np, const int32_t* pi, const int32_t* pj
   for (int64_t k = 0; k < np; k++) { hi[k] = ps[k].first; hj[k] = ps[k].second; }
   if (np) { H2D(S.pair_i, hi.data(), np, int); H2D(S.pair_j, hj.data(), np, int); }
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  S.callid = ++c->callid;
   hipLaunchKernelGGL(sz_k_pairs_explicit, dim3(grid_for(S.capM + 1, 256)), dim3(256), 0, c->stream, S, (int)np);
   stage_elems(c, false);
   stage_narrow(c, dt, max_overlap, c->P.fd_max_overlap);
@@ -1279,6 +1342,7 @@ int sz_collide_domain(sz_ctx* c, int32_t dt, double max_overlap) {
   c->gi_valid = false;         // (what follows numbers its ghosts by storage position)
   leave_resident(c);            // a process-mode call: the resident steps' ghost-candidate list is stale, the world rings must be current
   State& S = c->S;
+  S.callid = ++c->callid;
   hipLaunchKernelGGL(sz_k_pairs_explicit, dim3(grid_for(S.capM + 1, 256)), dim3(256), 0, c->stream, S, 0);
   stage_elems(c, true);
   stage_narrow(c, dt, c->P.ff_max_overlap, max_overlap);
@@ -1449,11 +1513,12 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   // shows up -- the batch then pauses inside that step (stopped_late()) and is finished below
   bool lean = coll && !c->retry_seen && !c->no_lean_narrow && !c->S.tiled && !larger_rings(c);
   int h[C_COUNT];
+  const int callid0 = c->callid; c->callid += nsteps;          // (step s of this batch is collision call callid0 + s + 1, also when it is run again)
   for (int s0 = 0, mid = 0;;) {
     c->S.retry_stop = lean ? 1 : 0;
     for (int s = s0; s < nsteps; s++) {
       int tstep = tstep0 + s;
-      c->S.step = s + 1;
+      c->S.step = s + 1; c->S.callid = callid0 + s + 1;
       const bool resume = mid && s == s0;
       const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
       const bool overlap = coupling && !c->two_way && (c->overlap_forcing >= 0 ? c->overlap_forcing != 0 : (c->hostN > 65536 && c->precision == 0 && coll));
@@ -1485,6 +1550,22 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     c->S.step = 0;
     if (coll && periodic) hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
     int rc = sync_and_check(c, h);
+    if (rc == SZ_E_CAPACITY && growable(c->last_err_bits) && h[C_RETRYSTOP] > 0 && coll) {
+      // A list outgrown inside step h[C_RETRYSTOP] (neighbours per floe, pair items, rows per floe): the batch paused there before anything
+      // of the floes' state changed (capacity_stop()).  Larger lists, then that step and the rest of the batch again, from the parents as
+      // they lie -- exactly as a batch that starts at that step would (cells, the step's ghosts): the reference's lists grow (collisions.jl:290-296).
+      if ((rc = grow_lists(c, c->last_err_bits))) { c->S.retry_stop = 0; c->S.body_rings = 0; c->S.ginline = 0; c->S.famrec = 0; c->S.step = 0; return rc; }
+      s0 = h[C_RETRYSTOP] - 1; mid = 0;
+      (void)hipMemsetAsync(c->S.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream);
+      (void)hipMemsetAsync(c->S.cnt + C_STOP, 0, sizeof(int), c->stream);
+      c->grid_live = false; use_static_grid(c);
+      if (gi) {
+        (void)hipMemsetAsync(c->S.galloc, 0, 32 * sizeof(unsigned long long), c->stream);
+        c->S.gslot = s0 & 1;
+        hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, s0 & 1, c->hostN);
+      } else if (gl) { c->gl_valid = false; use_ghost_list(c); }
+      continue;
+    }
     if (rc) { c->S.retry_stop = 0; c->S.body_rings = 0; c->S.ginline = 0; c->S.famrec = 0; return rc; }
     if (!lean || h[C_RETRYSTOP] == 0) break;
     // paused after the narrow launch of step h[C_RETRYSTOP]: that variant is in from now on
@@ -1661,6 +1742,7 @@ int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int
   // between two steps looks past the owned floes, so no clean-up launch is needed per step: the ghosts and halo
   // floes of the LAST step are dropped when the host next looks at the state (tile_cleanup).
   // n_init = every local parent (owned + halo): totals of halo floes are computed and then ignored
+  S.callid = ++c->callid;
   if (coll) stage_ghosts(c, true, sg, gl);
   if (coll) collisions(c, -1, dt, periodic && !sg, sg);
   stage_integrate(c, dt, false, coupling, sg, gl ? 1 - c->gl_cur : -1);
@@ -2264,6 +2346,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     if (fmode == 1 && S.maxnb > MAXNB) fmode = 2;
     if (coupling && !fuse) stage_forcing(c, dt);
     if (coupling) c->forcing_where = fmode;
+    S.callid = ++c->callid;
     collisions_step(c, -1, dt, false, true, fmode, false, false);
     stage_integrate(c, dt, false, coupling, true, -1, periodic && s + 1 < nsteps ? 1 - (s & 1) : -1);
   }

@@ -53,6 +53,13 @@ __device__ __forceinline__ void loads_issued() { asm volatile("" ::: "memory"); 
 __device__ __forceinline__ void request_stop(const State& S) {
   if (S.step > 0 && S.stop_on_tags) S.cnt[C_STOP] = S.step;      // every requester of a step writes the same value
 }
+// A list of this step has outgrown its capacity (neighbours per floe, pair items, interaction rows per floe): the reference's lists
+// grow as needed (collisions.jl:290-296), the engine's are carved per upload.  Besides the sticky error bit the step is paused like
+// the step that needs the largest narrow variant (C_RETRYSTOP): the kernels that follow in it and all later steps return at once,
+// nothing of the floes' state has changed, and the host carves larger lists and runs the step again (sz_api.hip: grow_lists).
+__device__ __forceinline__ void capacity_stop(const State& S) {
+  if (S.step > 0) S.cnt[C_RETRYSTOP] = S.step;
+}
 
 // ring offset / size of floe i: into vx, vy (CSR offsets voff) or, on body-frame rings (mixed precision), into ring32
 __device__ __forceinline__ int ring_off(const State& S, int i) { return S.body_rings ? S.rb_off[i] : S.voff[i]; }
@@ -1134,13 +1141,15 @@ constexpr int NB_G = 16, NB_TPB = 128;
 template <int TPB, bool FAM = true, int NBC = MAXNB>
 __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   constexpr int GPB = TPB / NB_G;
-  constexpr int NB_POOL = NBC <= 24 ? 96 : 224;       // floes the 3 x 3 cells around a floe may hold
-  static_assert(NBC <= 64, "the box mask of the owned pairs is one 64-bit word");
+  constexpr int NB_POOL = NBC <= 24 ? 96 : (NBC <= 64 ? 224 : 256);       // floes the 3 x 3 cells around a floe may hold (chunked pool: per chunk)
+  constexpr int MW = (NBC + 63) / 64;                  // 64-bit words of the box mask of the owned pairs
+  static_assert(NB_POOL >= NBC, "the pool is reused for the sorted list of the owned pairs");
   __shared__ int cand[GPB][2][NBC];
   __shared__ long long ckey[GPB][2][NBC];
   __shared__ int cnts[GPB][2];
-  using mask_t = typename std::conditional<(NBC <= 32), unsigned, unsigned long long>::type;      // box mask of the owned pairs
-  __shared__ mask_t wmask[GPB];
+  using mask_t = typename std::conditional<(NBC <= 32), unsigned, unsigned long long>::type;      // box mask of the owned pairs (NBC > 64: MW words)
+  __shared__ mask_t wmask[MW > 1 ? 1 : GPB];
+  __shared__ unsigned long long wmaskw[MW > 1 ? GPB : 1][MW];
   __shared__ int pool[GPB][NB_POOL];
   __shared__ int pool2[GPB][NBC > MAXNB ? NB_POOL : 1];      // (NBC = 64: the candidates of a chunk that passed the bounding-circle test)
   __shared__ int npool[GPB];
@@ -1180,7 +1189,8 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
     if (bid == 0 && threadIdx.x == 0 && kb == vb0 * GPB) { S.cnt[C_ITEMCLASS] = 0; S.cnt[C_NFUSE] = 0; }     // per-step counters the narrow phase raises
     const bool act = k < M;
     __syncthreads();
-    if (gl == 0) { cnts[gi][0] = 0; cnts[gi][1] = 0; wmask[gi] = (mask_t)0; npool[gi] = 0; }
+    if (gl == 0) { cnts[gi][0] = 0; cnts[gi][1] = 0; npool[gi] = 0; if constexpr (MW == 1) wmask[gi] = (mask_t)0; }
+    if constexpr (MW > 1) { if (gl < MW) wmaskw[gi][gl] = 0ull; }
     __syncthreads();
     if (act) cell_of(g, ckx, cky, ix, iy);
     bool ovf = false;
@@ -1333,7 +1343,7 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
         gsync();          // (the next chunk overwrites the pools)
       }
     }
-    if (ovf) atomicOr(&S.cnt[C_ERR], ERR_CAP_NEIGH);
+    if (ovf) { atomicOr(&S.cnt[C_ERR], ERR_CAP_NEIGH); }
     gsync();
     for (int w = 0; w < 2; w++) {
       int n = cnts[gi][w] < NBC ? cnts[gi][w] : NBC;
@@ -1344,11 +1354,11 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
         const int cv = cand[gi][w][e];
         dst[r] = cv & 0x3fffffff;
         if (w == 0) { pool[gi][r] = cv & 0x3fffffff; svo[gi][r] = cvo[gi][e]; snv[gi][r] = cnv[gi][e]; }   // (the pool is free by now: the sorted owned list, for the work items below)
-        if (w == 0 && (cv >> 30)) atomicOr(&wmask[gi], (mask_t)1 << r);
+        if (w == 0 && (cv >> 30)) { if constexpr (MW == 1) atomicOr(&wmask[gi], (mask_t)1 << r); else atomicOr(&wmaskw[gi][r >> 6], 1ull << (r & 63)); }
       }
       gsync();
       if (gl == 0 && act) {
-        if (w == 0) { S.n_out[k] = n; S.out_mask[k] = (unsigned long long)wmask[gi]; }
+        if (w == 0) S.n_out[k] = n;
         else S.n_in[k] = n;
       }
     }
@@ -1356,27 +1366,42 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
     __syncthreads();
     if (threadIdx.x == 0) {
       int tot = 0;
-      for (int q = 0; q < GPB; q++) { wbase[q] = tot; tot += __popcll((unsigned long long)wmask[q]); }
+      for (int q = 0; q < GPB; q++) {
+        wbase[q] = tot;
+        if constexpr (MW == 1) tot += __popcll((unsigned long long)wmask[q]); else for (int w8 = 0; w8 < MW; w8++) tot += __popcll(wmaskw[q][w8]);
+      }
       int base = tot ? atomicAdd(&S.wq[seg * 32 + 1], tot) : 0;
       if (base + tot > segcap) { atomicOr(&S.cnt[C_ERR], ERR_CAP_PAIRS); base = -1; }
       wbase[GPB] = base;
     }
     __syncthreads();
     if (act) {
-      const int base = wbase[GPB], nk = cnts[gi][0] < NBC ? cnts[gi][0] : NBC; const mask_t mask = wmask[gi];
+      const int base = wbase[GPB], nk = cnts[gi][0] < NBC ? cnts[gi][0] : NBC;
+      mask_t mask = (mask_t)0;
+      if constexpr (MW == 1) mask = wmask[gi];
       for (int r = gl; r < nk; r += NB_G) {
         const int slot = k * NBC + r;
-        if ((mask >> r & 1) && base >= 0) {
+        bool on; int before;
+        if constexpr (MW == 1) { on = (mask >> r & 1) != 0; before = __popcll((unsigned long long)(mask & (((mask_t)1 << r) - (mask_t)1))); }
+        else {
+          const unsigned long long mword = wmaskw[gi][r >> 6];
+          on = (mword >> (r & 63) & 1) != 0; before = __popcll(mword & ((1ull << (r & 63)) - 1ull));
+          for (int w8 = 0; w8 < (r >> 6); w8++) before += __popcll(wmaskw[gi][w8]);
+        }
+        if (on && base >= 0) {
           const int j = pool[gi][r];
-          const size_t w2 = 2 * ((size_t)seg * segcap + base + wbase[gi] + __popcll((unsigned long long)(mask & (((mask_t)1 << r) - (mask_t)1))));
+          const size_t w2 = 2 * ((size_t)seg * segcap + base + wbase[gi] + before);
           S.work[w2] = make_int4(slot, k, j, vok); S.work[w2 + 1] = make_int4(nvk, svo[gi][r], snv[gi][r], 0);
         } else S.it_info[slot] = make_int2(0, -1);      // boxes disjoint: no region, no row, no flag (the clip's own first test)
       }
     }
   }
 }
+// NBC = 256 (a floe with more than 64 neighbours in one direction: a large floe among many small ones): a quarter of the lane groups per
+// workgroup (48 KB of LDS for four floes) -- the capacity that keeps such a field running, not a fast path
+template <int NBC> constexpr int nb_tpb() { return NBC > 64 ? 64 : NB_TPB; }
 template <bool FAM, int NBC = MAXNB>
-__global__ void __launch_bounds__(NB_TPB, (NBC > MAXNB ? (FAM ? 3 : 4) : 1)) sz_k_neighbors(State S) { neighbors_body<NB_TPB, FAM, NBC>(S, blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(nb_tpb<NBC>(), (NBC > 64 ? 1 : NBC > MAXNB ? (FAM ? 3 : 4) : 1)) sz_k_neighbors(State S) { neighbors_body<nb_tpb<NBC>(), FAM, NBC>(S, blockIdx.x, gridDim.x); }
 
 // The compact pair list in the reference's serial order (i asc, j asc) -- out_off, pair_i, pair_j -- is only made when
 // the host asks for it (sz_download_pairs): fill after a scan of n_out.
@@ -1398,7 +1423,7 @@ __global__ void sz_k_pairs_explicit(State S, int np) {
     int e = lo; while (e < np && S.pair_i[e] == k) e++;
     int nk = e - lo;
     if (nk > S.maxnb) { atomicOr(&S.cnt[C_ERR], ERR_CAP_NEIGH); nk = S.maxnb; }
-    S.n_out[k] = nk; S.n_in[k] = 0; S.out_mask[k] = nk >= 64 ? ~0ull : (1ull << nk) - 1ull;
+    S.n_out[k] = nk; S.n_in[k] = 0;
     for (int r = 0; r < nk; r++) {
       const int p = lo + r, j = S.pair_j[p];
       S.nb_out[(size_t)k * S.maxnb + r] = j;
@@ -1519,6 +1544,9 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     for (int q = blockIdx.x * TPB + threadIdx.x; q <= ncells; q += nblk * TPB) { S.cell_cnt[q] = 0; S.cell_ovf[q] = 0; }
     if (blockIdx.x == 0) for (int q = threadIdx.x; q < WARN_SLOTS * 4; q += TPB) S.warn[(q >> 2) * 32 + (q & 3)] = 0;
     if (S.ginline && blockIdx.x == 0 && threadIdx.x == 0) S.galloc[(1 - S.gslot) * 16] = 0ull;      // the allocator this step's integrator makes the next ghosts in
+    // a list the neighbour search outgrew (its error bits): the batch pauses in this step -- raised here, where the counter block is
+    // at hand anyway, rather than in the search (which sits exactly on its register budget)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (S.cnt[C_ERR] & (ERR_CAP_NEIGH | ERR_CAP_PAIRS))) capacity_stop(S);
   }
   STAMP(st, 21);
   // The one-item-per-wavefront variant mostly looks for the few items meant for it: its lanes test 64
@@ -1974,7 +2002,7 @@ __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int 
       const int4 cn = pr ? pr->cnts : make_int4(S.n_out[k], S.el_off[k], S.el_off[k + 1], S.n_in[k]);
       c = emit_rows_fold(S, lane, k, dst, S.rowcap, mirror, ovf, &st, &tagA, cn, ng, gf, cx, cy);
     } else c = emit_rows(S, lane, k, dst, 0, S.rowcap, sx, sy, mirror, ovf, &st, &tagA, pr ? &pr->cnts : nullptr);
-    if (ovf) atomicOr(&S.cnt[C_ERR], ERR_CAP_INTER);
+    if (ovf) { atomicOr(&S.cnt[C_ERR], ERR_CAP_INTER); capacity_stop(S); }
     __threadfence_block();             // the rows were written by other lanes of this wavefront
     // torque per row over the lanes; totals (collisions.jl:747-749, 852-861) and the overlap sum in row
     // order; ghosts keep zero totals.  Without the mirror pass (floe_floe_interaction! /
@@ -1998,7 +2026,11 @@ __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int 
       if (st != SZ_ACTIVE && k < nparents) request_stop(S);        // simplify_floes! has work after this step
       S.inter_cnt[k] = c;
       S.cfx[k] = totals ? fx : 0.0; S.cfy[k] = totals ? fy : 0.0; S.ctrq[k] = totals ? tq : 0.0;
-      S.overarea[k] += over;
+      // floe.overarea accumulates (collisions.jl:304).  A call that is run AGAIN after its lists were carved larger (grow_lists) must
+      // add its overlap once, and the complete one: the column's value from before the call is kept beside the number of the call
+      double base = S.overarea[k];
+      if (S.over_stamp[k] != S.callid) { S.over_base[k] = base; S.over_stamp[k] = S.callid; } else base = S.over_base[k];
+      S.overarea[k] = base + over;
     }
   };
   if (hinted) {
@@ -2975,13 +3007,16 @@ __global__ void sz_k_stats(State S, long long* out) {
   // pairs of the last step: per floe its owned pairs (all / those with overlapping ring boxes = the items run)
   const int mlast = S.cnt[C_M] > S.cnt[C_N] ? S.cnt[C_M] : S.cnt[C_N] + S.cnt[C_NGHOSTS];      // the ghosts of the last step own pairs too
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < mlast; k += gridDim.x * blockDim.x) {
-    const int nk = S.n_out[k]; const unsigned long long mask = S.out_mask[k];
-    v[10] += nk; v[11] += __popcll(mask);
+    const int nk = S.n_out[k];
+    v[10] += nk;
     const int nvk = ring_n(S, k);
-    for (int r = 0; r < nk; r++) if (mask >> r & 1) {
+    for (int r = 0; r < nk; r++) {
+      const int2 info = S.it_info[(size_t)k * S.maxnb + r];
+      if (info.y < 0) continue;          // ring boxes disjoint: the pair was not an item of the narrow phase (it_info = {0, -1})
+      v[11]++;
       const int j = S.nb_out[(size_t)k * S.maxnb + r];
       v[0] += nvk + ring_n(S, j);
-      v[1] += S.it_info[k * S.maxnb + r].x & 0xff;
+      v[1] += info.x & 0xff;
     }
   }
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nel; q += gridDim.x * blockDim.x) v[2] += S.it_info[S.capM * S.maxnb + q].x & 0xff;

@@ -134,9 +134,10 @@ struct State {
   // walking a list node by node), floes beyond that on an overflow chain (cell_ovf: head + 1, cell_items: next links)
   int *cell_cnt, *cell_slots, *cell_ovf, *cell_items;
   // per floe k: the neighbours that come later in the serial order (nb_out: the pairs k owns, sorted by order key; pair SLOT
-  // = k * MAXNB + rank) and earlier (nb_in: the pairs mirrored onto it); out_mask: which owned pairs have overlapping ring boxes
-  int *nb_out, *nb_in, *n_out, *n_in; unsigned long long* out_mask;
-  int maxnb, rowcap;          // neighbours kept per floe and direction (stride of nb_out / nb_in / the pair slots: 24 or 64, chosen at upload), interaction rows per floe
+  // = k * MAXNB + rank) and earlier (nb_in: the pairs mirrored onto it)
+  int *nb_out, *nb_in, *n_out, *n_in;
+  double* over_base; int* over_stamp; int callid;       // floe.overarea before the collision call `over_stamp` (sz_k_inter_fill); collision call that last added its overlap to floe.overarea (sz_k_inter_fill): a call run again after its lists grew adds nothing twice
+  int maxnb, rowcap;          // neighbours kept per floe and direction (stride of nb_out / nb_in / the pair slots: 24, 64 or 256 -- chosen at upload, grown on demand), interaction rows per floe
   int *out_off, *pair_i, *pair_j;      // the compact pair list in serial order: made on demand (sz_download_pairs) / given (sz_collide_pairs)
   // work list of the narrow phase: the pair items to run, two int4 each {slot, i, j, ring offset i} {ring size i, ring offset j, ring size j, -}, appended by the neighbour search in NSEG segments of
   // capPairs / NSEG items; wq[s * 32] = queue head of segment s (rounds after the first), wq[s * 32 + 1] = its length

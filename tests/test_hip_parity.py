@@ -784,9 +784,9 @@ def test_size_spectrum_field_and_its_capacity_limit():
     """A large floe among small ones (the reference's Voronoi fields have a size spectrum).  The library counts the
     bounding-circle neighbours of the uploaded field and sizes its neighbour lists from that: 24 per floe and direction for
     like-sized floes, 64 (and 128 interaction rows per floe, the chunked candidate pool) where a floe has more -- the contact
-    rows match the oracle either way, crowded cells (bucket + overflow chain) included.  Beyond 64 the step fails LOUDLY
-    (SZ_E_CAPACITY, neighbours bit) instead of dropping contacts: the reference grows its lists (collisions.jl:290-296),
-    the engine's capacities are fixed per upload."""
+    rows match the oracle either way, crowded cells (bucket + overflow chain) included.  Beyond 64: the third capacity, 256
+    (a quarter of the lane groups per workgroup: the capacity that keeps such a field running, not a fast path); beyond that the
+    step fails LOUDLY (SZ_E_CAPACITY, neighbours bit) instead of dropping contacts."""
     from subzero_jl_amd.capi import SzError
     hw = _size_spectrum(mk(), 20, 3.0e4); ow = _size_spectrum(omk(), 20, 3.0e4)
     for w in (hw, ow):
@@ -806,9 +806,43 @@ def test_size_spectrum_field_and_its_capacity_limit():
     assert len(ow.inter(0)) >= 40
     hw.run(5, 0, 10, coupling_on=False); [ow.timestep_sim(t, 10, coupling_dt=10, coupling_on=False) for t in range(5)]
     parity.compare_worlds(hw, ow, rtol=1e-9)
-    huge = _size_spectrum(mk(), 90, 1.4e5)
-    with pytest.raises(SzError, match="neighbours"):
-        huge.timestep_collisions(91, 10)
+    # 90 small floes: beyond 64 neighbours -- the third capacity (256 per floe and direction)
+    hw, ow = _size_spectrum(mk(), 90, 1.4e5), _size_spectrum(omk(), 90, 1.4e5)
+    for w in (hw, ow):
+        w.timestep_collisions(91, 10)
+    assert parity.compare_pairs(hw, ow) >= 90
+    parity.compare_interactions(hw, ow, 1e-10)
+    assert len(ow.inter(0)) >= 90
+    hw.run(5, 0, 10, coupling_on=False); [ow.timestep_sim(t, 10, coupling_dt=10, coupling_on=False) for t in range(5)]
+    parity.compare_worlds(hw, ow, rtol=1e-9)
+
+
+@pytest.mark.parametrize("n_small,start,rowcap", [(40, "24", None), (90, "24", None), (20, "24", "8"), (40, "64", "16")])
+def test_lists_grow_when_a_step_outgrows_them(monkeypatch, n_small, start, rowcap):
+    """The reference's lists grow as needed (collisions.jl:290-296: interactions by vcat; the Dict of the pair loop).  The engine's
+    neighbour lists, pair items and interaction rows are carved per upload from a count of the field -- and when a call or a step
+    outgrows them all the same (here: the upload is TOLD to start too small, SZ_MAXNB / SZ_ROWCAP), the library carves larger ones
+    and runs the call / the step again: process-mode timestep_collisions! and resident batches (the batch pauses in the step that
+    overflowed, before anything of the floes' state has changed) both match the oracle, floe.overarea is not added twice."""
+    monkeypatch.setenv("SZ_MAXNB", start)
+    if rowcap:
+        monkeypatch.setenv("SZ_ROWCAP", rowcap)
+    big_r = {20: 3.0e4, 40: 6.0e4, 90: 1.4e5}[n_small]
+    hw, ow = _size_spectrum(mk(), n_small, big_r), _size_spectrum(omk(), n_small, big_r)
+    for w in (hw, ow):
+        w.timestep_collisions(n_small + 1, 10)
+    assert parity.compare_pairs(hw, ow) >= n_small
+    parity.compare_interactions(hw, ow, 1e-10)
+    parity.compare_worlds(hw, ow, rtol=1e-10, fields=["coll_fx", "coll_fy", "coll_trq", "overarea"])
+    # a second call on the grown lists, then a resident batch on a FRESH context that has to grow inside its first step
+    for w in (hw, ow):
+        w.timestep_collisions(n_small + 1, 10)
+    parity.compare_worlds(hw, ow, rtol=1e-10, fields=["coll_fx", "coll_fy", "coll_trq", "overarea"])
+    hw, ow = _size_spectrum(mk(), n_small, big_r), _size_spectrum(omk(), n_small, big_r)
+    assert hw.run(5, 0, 10, coupling_on=False) == 5
+    [ow.timestep_sim(t, 10, coupling_dt=10, coupling_on=False) for t in range(5)]
+    parity.compare_worlds(hw, ow, rtol=1e-9)
+    assert np.array_equal(hw.warn_counts(), ow.warn_counts())
 
 
 # ---------------------------------------------------------------- mixed precision (BASELINE configs[4])
