@@ -219,20 +219,27 @@ def cpu_baseline(cfg, budget_s=20.0, relax_steps=0):
         w.timestep_sim(k, cfg["dt"], coupling_dt=1)
     tr = time.perf_counter() - tr
     base = max(relax_steps, 1)
+    w.phase_times()
     t0 = time.perf_counter(); steps = 0
     while steps < 2 or (time.perf_counter() - t0 < 0.75 * budget_s and steps < 300):
         w.timestep_sim(base + steps, cfg["dt"], coupling_dt=1); steps += 1
     el = time.perf_counter() - t0
+    ph = w.phase_times()
     # the same on one core (the reference's default when Julia is started without -t)
     w.set_threads(1)
     t1 = time.perf_counter(); s1 = 0
     while s1 < 2 or (time.perf_counter() - t1 < 0.25 * budget_s and s1 < 100):
         w.timestep_sim(base + steps + s1, cfg["dt"], coupling_dt=1); s1 += 1
     el1 = time.perf_counter() - t1
+    ph1 = w.phase_times()
     return {"value": cfg["n_floes"] * steps / el, "unit": "floe-steps/s", "cores": cores, "kind": "port",
             "sample": f"{steps} timesteps of the same {cfg['n_floes']}-floe field ({el:.1f} s) after {base} untimed relaxation steps ({tr:.1f} s), "
                       f"OpenMP over floes like the reference's Threads.@threads loops; then {s1} steps on one core ({el1:.1f} s)",
-            "value_1core": cfg["n_floes"] * s1 / el1}
+            "value_1core": cfg["n_floes"] * s1 / el1,
+            # where the port spends its time (ms per step): the phases the reference runs serially (Dict pass, mirror / ghost fold,
+            # the forcing loop: collisions.jl:799-862, coupling.jl:1498) are why more cores buy little
+            "ms_per_step_by_phase": {k: 1e3 * v / steps for k, v in ph.items()},
+            "ms_per_step_by_phase_1core": {k: 1e3 * v / s1 for k, v in ph1.items()}}
 
 
 def pmc_traffic(workload, n_floes, kernel):

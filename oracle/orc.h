@@ -182,6 +182,10 @@ void orc_get_pairs(const orc_world *w, int32_t *pi, int32_t *pj);
    down-scalings, velocity fracs, xi clamps (update_floe.jl:482-491,516-531,540-543) */
 void orc_get_warn_counts(const orc_world *w, int64_t *out4);
 void orc_set_threads(orc_world *w, int nthreads);
+/* wall seconds per phase of the steps run since the last reset (8 doubles: add_ghosts!, pair loop, Dict pass, interactions,
+   mirror + ghost fold + totals, timestep_coupling!, timestep_floe_properties!, -): where the CPU path spends its time */
+void orc_get_phase_times(const orc_world *w, double *out8);
+void orc_reset_phase_times(orc_world *w);
 
 #ifdef __cplusplus
 }

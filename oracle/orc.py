@@ -281,6 +281,17 @@ class World:
     def set_threads(self, n):
         self.L.orc_set_threads(self.h, int(n))
 
+    PHASES = ["add_ghosts", "pair_loop_all_pairs_circles", "dict_pass_serial", "floe_floe_and_domain_interactions",
+              "mirror_ghost_fold_totals_serial", "timestep_coupling_serial", "timestep_floe_properties"]
+
+    def phase_times(self, reset=True):
+        """wall seconds per phase of the steps run since the last reset (where the CPU path spends its time)"""
+        out = np.zeros(8)
+        self.L.orc_get_phase_times(self.h, _p(out))
+        if reset:
+            self.L.orc_reset_phase_times(self.h)
+        return {n: float(out[k]) for k, n in enumerate(self.PHASES)}
+
     # ---- the reference's process API
     def eulerian_data(self, xg, yg):
         """calc_eulerian_data! (output.jl:793-914): array [len(EUL_OUTPUTS), nx, ny]."""

@@ -7,6 +7,7 @@
  * -(4+k) topography k, collisions.jl:608-660).  Everything else in the C API is 0-based.
  */
 #define _GNU_SOURCE
+#define _POSIX_C_SOURCE 200809L
 #include "orc.h"
 #include <math.h>
 #include <stdlib.h>
@@ -65,7 +66,16 @@ struct orc_world {
   int32_t *pi, *pj; int npairs, cappairs;
   int64_t warn[4];
   int nthreads;
+  /* wall seconds per phase since the last orc_reset_phase_times (bench.py prints where the CPU path spends its time):
+     0 add_ghosts!, 1 pair loop (all-pairs bounding circles, threaded over i), 2 Dict pass (serial), 3 floe-floe / floe-domain
+     interactions (threaded over i), 4 mirror + ghost fold + totals (serial, as in the reference), 5 timestep_coupling! (serial
+     loop over floes, as in the reference), 6 timestep_floe_properties! (threaded) */
+  double tphase[8];
 };
+#include <time.h>
+static double wall_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+void orc_get_phase_times(const orc_world *w, double *out8) { for (int k = 0; k < 8; k++) out8[k] = w->tphase[k]; }
+void orc_reset_phase_times(orc_world *w) { for (int k = 0; k < 8; k++) w->tphase[k] = 0.0; }
 
 /* ------------------------------------------------------------------ helpers */
 static void floe_init(floe_t *f) { memset(f, 0, sizeof(*f)); orc_ring_init(&f->poly); f->status = ORC_ACTIVE; }
@@ -637,6 +647,7 @@ static dent_t *dict_get_or_insert(dict_t *d, int64_t k1, int64_t k2, int64_t g1,
 void orc_timestep_collisions(orc_world *w, int n_init, int dt) {
   int M = w->M;
   floe_t *F = w->f;
+  double t0 = wall_now(), t1;
   int **cand = (int **)calloc((size_t)(M > 0 ? M : 1), sizeof(int *));
   int *ncand = (int *)calloc((size_t)(M > 0 ? M : 1), sizeof(int));
 #ifdef _OPENMP
@@ -656,6 +667,7 @@ void orc_timestep_collisions(orc_world *w, int n_init, int dt) {
     }
     cand[i] = c; ncand[i] = n;
   }
+  t1 = wall_now(); w->tphase[1] += t1 - t0; t0 = t1;
   /* serial Dict pass, collisions.jl:751-775 */
   dict_t d; dict_init(&d, 1024);
   w->npairs = 0;
@@ -681,6 +693,7 @@ void orc_timestep_collisions(orc_world *w, int n_init, int dt) {
     ncand[i] = keep;
   }
   free(d.e);
+  t1 = wall_now(); w->tphase[2] += t1 - t0; t0 = t1;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 16) num_threads(w->nthreads)
 #endif
@@ -690,6 +703,7 @@ void orc_timestep_collisions(orc_world *w, int n_init, int dt) {
     free(cand[i]);
   }
   free(cand); free(ncand);
+  t1 = wall_now(); w->tphase[3] += t1 - t0; t0 = t1;
   update_boundaries(w, dt);
   /* mirror pass, collisions.jl:799-828 */
   for (int i = 0; i < M; i++) {
@@ -739,6 +753,7 @@ void orc_timestep_collisions(orc_world *w, int n_init, int dt) {
     }
     F[i].cfx += sfx; F[i].cfy += sfy; F[i].ctrq += st;
   }
+  w->tphase[4] += wall_now() - t0;
 }
 
 /* ------------------------------------------------------------------ ghosts */
@@ -1213,9 +1228,15 @@ void orc_timestep_floe_properties(orc_world *w, int dt) {
 void orc_timestep_sim(orc_world *w, int tstep, int dt, int coupling_dt, int collisions_on, int coupling_on) {
   if (w->M == 0) return;
   int n_init = w->M;
+  double t0 = wall_now(), t1;
   orc_add_ghosts(w);
+  t1 = wall_now(); w->tphase[0] += t1 - t0; t0 = t1;
   if (collisions_on) orc_timestep_collisions(w, n_init, dt);
+  t0 = wall_now();
   orc_remove_ghosts(w, n_init);
+  t1 = wall_now(); w->tphase[0] += t1 - t0; t0 = t1;
   if (coupling_on && coupling_dt > 0 && (tstep % coupling_dt) == 0) orc_timestep_coupling(w);
+  t1 = wall_now(); w->tphase[5] += t1 - t0; t0 = t1;
   orc_timestep_floe_properties(w, dt);
+  w->tphase[6] += wall_now() - t0;
 }
