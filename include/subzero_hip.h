@@ -319,7 +319,21 @@ int sz_comm_selftest(sz_ctx *ctx);
 int sz_comm_allreduce(sz_ctx *ctx, void *d_buf, int64_t n);
 int sz_tile_setup(sz_ctx *ctx, double Lx, double Ly, int32_t periodic_x, int32_t periodic_y, double drift_margin,
                   int32_t rebox_every);
+/* optional, after sz_tile_setup: the centre of this rank's tile.  The bounding box of the owned floes -- what the peers select this rank's
+   halo with -- takes every centroid at its periodic image nearest to that point at the first gather (later gathers use the centre of the
+   box before), so that a parent the ghost pass has wrapped to the far side of the domain does not stretch the box across the domain */
+int sz_tile_set_center(sz_ctx *ctx, double x, double y);
 int sz_tile_run(sz_ctx *ctx, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupling_dt, int32_t flags, int32_t *steps_done);
+/* Migration (collective, between two sz_tile_run calls): every owned floe is re-assigned to the tile that holds its centroid -- px x py
+   tiles over the domain of sz_set_domain, tile (ix, iy) = rank iy * px + ix; owner_override (may be NULL; one entry per owned floe, in
+   the order of the last upload) names the new owner rank instead.  Floes that change tile travel with their complete state (all columns,
+   tensors, status, ring, sub-floe points) over the library's channel (RCCL or the host transport); the context is then rebuilt from the
+   kept and the received floes, ordered by global index, exactly as an upload + sz_tile_enable + sz_tile_setup (same parameters) would --
+   host-staged inside the library: a rare operation.  *n_sent = floes this rank gave away, *n_owned = floes it owns now (the `id`
+   column of sz_download_floes names them: the host's own copies of the columns are stale).  floe.interactions do not travel.
+   sz_download_subpoints: the sub-floe points of the floes the context holds (off: N + 1 entries; sx == NULL: offsets only). */
+int sz_tile_migrate(sz_ctx *ctx, int32_t px, int32_t py, const int32_t *owner_override, int64_t *n_sent, int64_t *n_owned);
+int sz_download_subpoints(sz_ctx *ctx, int32_t *off, double *sx, double *sy);
 
 /* ---- output path on the resident state
    sz_eulerian_data: calc_eulerian_data! (output.jl:793-914), the GridOutputWriter averages, over the rows the

@@ -625,7 +625,7 @@ collectives described above (the host's channel).  Then `tile_run!` replaces `sz
 """
 function tiles!(eng::HIPEngine, nranks::Integer, rank::Integer, owned_global_index::Vector{Int64}, max_ring::Real, max_rmax::Real,
                 Lx::Real, Ly::Real; id = nothing, transport = nothing, periodic_x::Bool = true, periodic_y::Bool = true,
-                drift_margin::Real = max(2000.0, max_rmax / 2), rebox_every::Integer = 150)
+                drift_margin::Real = max(2000.0, max_rmax / 2), rebox_every::Integer = 150, tile_center = nothing)
     if transport !== nothing
         TRANSPORT[] = transport; TRANSPORT_NRANKS[] = nranks
         t = Ref(SzHostTransport(C_NULL,
@@ -641,6 +641,9 @@ function tiles!(eng::HIPEngine, nranks::Integer, rank::Integer, owned_global_ind
                                          Float64(max_rmax)::Float64)::Cint)
     check(eng, @ccall lib.sz_tile_setup(eng.ctx::Ptr{Cvoid}, Float64(Lx)::Float64, Float64(Ly)::Float64, Int32(periodic_x)::Int32,
                                         Int32(periodic_y)::Int32, Float64(drift_margin)::Float64, Int32(rebox_every)::Int32)::Cint)
+    if tile_center !== nothing           # (x, y) of this rank's tile centre: see sz_tile_set_center
+        check(eng, @ccall lib.sz_tile_set_center(eng.ctx::Ptr{Cvoid}, Float64(tile_center[1])::Float64, Float64(tile_center[2])::Float64)::Cint)
+    end
     return
 end
 
@@ -658,6 +661,14 @@ function tile_run!(eng::HIPEngine, nsteps::Integer, tstep::Integer, Δt::Integer
     check(eng, @ccall lib.sz_tile_run(eng.ctx::Ptr{Cvoid}, nsteps::Int32, tstep::Int32, Δt::Int32, coupling_Δt::Int32, flags::Int32,
                                       done::Ptr{Int32})::Cint)
     return Int(done[])
+end
+
+# floes that left their tile go to the rank that owns the tile their centroid lies in now (px x py tiles over the domain), with their
+# complete state, over the library's channel; collective, between two tile_run! calls.  Returns (floes given away, floes owned now).
+function tile_migrate!(eng::HIPEngine, px::Integer, py::Integer)
+    sent = Ref{Int64}(0); owned = Ref{Int64}(0)
+    check(eng, @ccall lib.sz_tile_migrate(eng.ctx::Ptr{Cvoid}, px::Int32, py::Int32, C_NULL::Ptr{Int32}, sent::Ptr{Int64}, owned::Ptr{Int64})::Cint)
+    return Int(sent[]), Int(owned[])
 end
 
 writer_periods(w) = Int[x.Δtout for ws in (w.floewriters, w.gridwriters, w.checkpointwriters) for x in ws]

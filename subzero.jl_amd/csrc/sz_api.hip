@@ -128,6 +128,7 @@ struct sz_ctx {
   Pool tw_part_allocs; double* d_tw_partial = nullptr;
   std::vector<long long> tile_gidx; // global index of every owned floe (sz_tile_enable): status.fuse_idx of a tiled context is reported in global numbers
   bool tile_inline_off = false;     // SZ_TILE_INLINE=0: the tiled steps of sz_tile_run keep the list-based ghost pass, their own forcing launch and the one-workgroup unpack (A/B)
+  double tile_box_ctr[2] = { 0, 0 }; bool tile_box_valid = false;   // centre of this rank's owned box at the last gather (sz_k_owned_box: periodic images)
   int tile_forcing_tstep = -1;      // timestep whose forcings sz_tile_forcing has already enqueued
   bool tile_dirty = false;      // ghosts / halo floes of the last sz_tile_step still appended
   int last_err_bits = 0;   // device error bits the last sync_and_check found (tiled runs agree on them between the ranks)
@@ -258,6 +259,7 @@ int carve_interactions(sz_ctx* c) {
     int rc;
     if ((rc = dalloc(c, &S.inter_cnt, (size_t)S.capM + 1, c->inter_allocs))) return rc;
     if ((rc = dalloc(c, &S.inter_rows, (size_t)S.capM * S.rowcap * 7, c->inter_allocs))) return rc;
+    HIPCHK(c, hipMemsetAsync(S.inter_cnt, 0, ((size_t)S.capM + 1) * sizeof(int), c->stream));
     c->inter_capM = S.capM; c->inter_rowcap = S.rowcap; c->inter_lost = c->inter_any; c->inter_any = false;
   }
   return SZ_OK;
@@ -1035,6 +1037,14 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(el_off, S.capM + 2); DA(el_floe, S.capElem); DA(el_elem, S.capElem);
   DA(inter_off, S.capM + 2);
   HIPCHK(c, hipMemsetAsync(S.over_stamp, 0, ((size_t)S.capM + 1) * sizeof(int), c->stream));
+  // (a re-upload carves the chunks of the previous one again: per-floe COUNTS that a kernel may read before a collision call has written them
+  //  -- sz_k_stats walks n_out -- must not hold what some other array left there)
+  HIPCHK(c, hipMemsetAsync(S.n_out, 0, ((size_t)S.capM + 1) * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(S.n_in, 0, ((size_t)S.capM + 1) * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(S.el_off, 0, ((size_t)S.capM + 2) * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(S.warn, 0, (size_t)WARN_SLOTS * 32 * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(S.lb_flag, 0, ((size_t)S.capM / 128 + 8) * sizeof(unsigned), c->stream));      // (the look-back scans' epochs start over with scan_epoch = 0)
+  if (!f->sub_off) HIPCHK(c, hipMemsetAsync(S.soff, 0, ((size_t)S.capM + 1) * sizeof(int), c->stream));
   // neighbour lists, pair items and their rows: in a pool of their own, carved again (larger) when a step outgrows them
   if ((rc = carve_lists(c))) return rc;
   // floe.interactions is part of the floe state, but not of sz_floe_columns (it is ragged): the rows the last
@@ -1667,7 +1677,7 @@ int sz_tile_enable(sz_ctx* c, const int64_t* gidx, double halo_capacity_factor, 
 int sz_owned_box(sz_ctx* c, double* out5) {
   if (!c || !c->have_floes || !out5) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
-  hipLaunchKernelGGL(sz_k_owned_box, dim3(1), dim3(1024), 0, c->stream, c->S, c->S.bounds + 8);
+  hipLaunchKernelGGL(sz_k_owned_box, dim3(1), dim3(1024), 0, c->stream, c->S, c->S.bounds + 8, (const double*)nullptr, 0.0, 0.0, 0, 0);
   HIPCHK(c, hipMemcpyAsync(out5, c->S.bounds + 8, 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return SZ_OK;
@@ -2019,12 +2029,20 @@ int tile_rebox(sz_ctx* c) {
   State& S = c->S;
   const int n = c->comm_n, me = c->comm_rank;
   int rc = tile_sync_agree(c); if (rc) return rc;
-  hipLaunchKernelGGL(sz_k_owned_box, dim3(1), dim3(1024), 0, c->stream, S, c->d_gather);
+  // (every gather after the first: centroids at their periodic image nearest to the centre of the last box -- d_gather[8 + 8 me ..] still holds it)
+  double* d_ctr = c->d_gather + 8 + 8 * 64 + 64 * 64 / 2 + 48;          // two of the spare doubles
+  if (c->tile_box_valid) {
+    const double ctr[2] = { c->tile_box_ctr[0], c->tile_box_ctr[1] };
+    HIPCHK(c, hipMemcpyAsync(d_ctr, ctr, sizeof(ctr), hipMemcpyHostToDevice, c->stream));
+  }
+  hipLaunchKernelGGL(sz_k_owned_box, dim3(1), dim3(1024), 0, c->stream, S, c->d_gather, c->tile_box_valid ? (const double*)d_ctr : (const double*)nullptr,
+                     c->tile_Lx, c->tile_Ly, c->tile_per_x, c->tile_per_y);
   constexpr int GB = 8;      // doubles per rank in the gather: box, rmax, drift, speed, (spare)
   std::vector<double> all((size_t)GB * n);
   if ((rc = comm_allgather(c, c->d_gather, c->d_gather + 8, GB, NCCL_FLOAT64, sizeof(double)))) return rc;
   HIPCHK(c, hipMemcpyAsync(all.data(), c->d_gather + 8, all.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->tile_box_ctr[0] = 0.5 * (all[GB * me] + all[GB * me + 1]); c->tile_box_ctr[1] = 0.5 * (all[GB * me + 2] + all[GB * me + 3]); c->tile_box_valid = true;
   double rmax = 0.0, drift = 0.0, speed = 0.0;
   for (int r = 0; r < n; r++) { rmax = std::max(rmax, all[GB * r + 4]); drift = std::max(drift, all[GB * r + 5]); speed = std::max(speed, all[GB * r + 6]); }
   // the gather interval follows the floes (every rank computes the same number): at the faster of the measured displacement per step since
@@ -2195,12 +2213,214 @@ int sz_tile_setup(sz_ctx* c, double Lx, double Ly, int32_t per_x, int32_t per_y,
   (void)hipSetDevice(c->device);
   c->tile_Lx = Lx; c->tile_Ly = Ly; c->tile_per_x = per_x; c->tile_per_y = per_y; c->tile_margin = drift_margin; c->tile_rebox_every = std::abs(rebox_every); c->tile_rebox_fixed = rebox_every < 0;
   c->tile_since_box = -1; c->halo_cap = 0; c->d_send = nullptr; c->tile_rebox_cur = rebox_every < 0 ? -rebox_every : std::min(rebox_every, 8);
+  c->tile_box_valid = false;
   free_pool(c->comm_allocs);
   if (!c->d_gather) {          // own box | all boxes | count matrix (ints): lives as long as the communicator
     HIPCHK(c, hipMalloc((void**)&c->d_gather, (8 + 8 * 64 + 64 * 64 / 2 + 64) * sizeof(double)));
   }
   return SZ_OK;
 }
+// ---------------------------------------------------------------- migration
+// Floes drift; ownership follows the tile that holds the centroid.  sz_tile_migrate re-assigns every owned floe (collective): the floes
+// that changed tile travel with their COMPLETE state -- every column incl. the previous-step tendencies and the stress / strain tensors,
+// status, ring, sub-floe points -- over the library's own channel (RCCL send / receive between device buffers, or the host's transport),
+// and every rank's context is rebuilt from the floes it keeps and the ones it received, ordered by global index, through the same path an
+// upload takes (capacities, neighbour counts, grid, ghost-candidate estimate are all re-derived).  The re-assignment is host-staged inside
+// the library -- a rare operation (floes move metres per step against tiles of hundreds of km) whose cost is a download and an upload of
+// the tile; the in-reference analogue is the parent / ghost swap of collisions.jl:942-950.  floe.interactions of the last collision call do
+// not travel (the next step's collision call rebuilds them before anything reads them).
+namespace {
+// variable-size all-to-all of doubles between the ranks: sendv[d] to rank d, recvv[s] (sized here) from rank s
+int comm_alltoallv(sz_ctx* c, const std::vector<std::vector<double>>& sendv, std::vector<std::vector<double>>& recvv) {
+  const int n = c->comm_n, me = c->comm_rank;
+  recvv.assign(n, {});
+  if (n == 1) return SZ_OK;
+  // sizes first: every rank's row of the size matrix
+  std::vector<int> mine(n), all((size_t)n * n);
+  for (int d = 0; d < n; d++) mine[d] = (int)sendv[d].size();
+  int* d_row = (int*)(c->d_gather + 8 + 8 * 64);          // (the count-matrix area of the box gather: free between gathers)
+  HIPCHK(c, hipMemcpyAsync(d_row, mine.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  int* d_all = d_row + 64;
+  int rc = comm_allgather(c, d_row, d_all, (size_t)n, NCCL_INT32, sizeof(int));
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int s2 = 0; s2 < n; s2++) if (s2 != me) recvv[s2].assign((size_t)all[(size_t)s2 * n + me], 0.0);
+  if (c->host_transport) {
+    std::vector<int32_t> peer; std::vector<const void*> sp; std::vector<void*> rp; std::vector<int64_t> sb, rb;
+    for (int d = 0; d < n; d++) {
+      if (d == me) continue;
+      peer.push_back(d); sp.push_back(sendv[d].data()); sb.push_back((int64_t)(sendv[d].size() * sizeof(double)));
+      rp.push_back(recvv[d].data()); rb.push_back((int64_t)(recvv[d].size() * sizeof(double)));
+    }
+    HOSTCHK(c, c->host_tr.sendrecv(c->host_tr.user, (int32_t)peer.size(), peer.data(), sp.data(), sb.data(), rp.data(), rb.data()), "sendrecv");
+    return SZ_OK;
+  }
+  // RCCL: device staging buffers, one grouped send / receive
+  size_t ts = 0, tr = 0;
+  for (int d = 0; d < n; d++) { if (d == me) continue; ts += sendv[d].size(); tr += recvv[d].size(); }
+  PoolGuard pool; double *ds = nullptr, *dr = nullptr;
+  if ((rc = dalloc(c, &ds, ts, pool.v)) || (rc = dalloc(c, &dr, tr, pool.v))) return rc;
+  size_t os = 0;
+  for (int d = 0; d < n; d++) { if (d == me || sendv[d].empty()) continue; HIPCHK(c, hipMemcpyAsync(ds + os, sendv[d].data(), sendv[d].size() * sizeof(double), hipMemcpyHostToDevice, c->stream)); os += sendv[d].size(); }
+  NCCLCHK(c, g_rccl.GroupStart());
+  os = 0; size_t orr = 0;
+  for (int d = 0; d < n; d++) {
+    if (d == me) continue;
+    if (!sendv[d].empty()) { NCCLCHK(c, g_rccl.Send(ds + os, sendv[d].size(), NCCL_FLOAT64, d, c->comm, c->stream)); os += sendv[d].size(); }
+    if (!recvv[d].empty()) { NCCLCHK(c, g_rccl.Recv(dr + orr, recvv[d].size(), NCCL_FLOAT64, d, c->comm, c->stream)); orr += recvv[d].size(); }
+  }
+  NCCLCHK(c, g_rccl.GroupEnd());
+  orr = 0;
+  for (int d = 0; d < n; d++) { if (d == me || recvv[d].empty()) continue; HIPCHK(c, hipMemcpyAsync(recvv[d].data(), dr + orr, recvv[d].size() * sizeof(double), hipMemcpyDeviceToHost, c->stream)); orr += recvv[d].size(); }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SZ_OK;
+}
+constexpr int MIG_NCOL = 25 + 12 + 5;      // the 25 scalar columns, three 2 x 2 tensors, id, status, global index, ring points, sub-floe points
+}  // namespace
+
+int sz_tile_migrate(sz_ctx* c, int32_t px, int32_t py, const int32_t* owner_override, int64_t* n_sent, int64_t* n_owned) {
+  if (n_sent) *n_sent = 0;
+  if (!c || !c->have_floes || !c->S.tiled || c->comm_n < 1 || c->tile_margin <= 0 || px < 1 || py < 1 || (!owner_override && px * py != c->comm_n)) {
+    if (c) c->err = "sz_tile_migrate needs a tiled context after sz_tile_setup, and px * py == the number of ranks";
+    return SZ_E_STATE;
+  }
+  (void)hipSetDevice(c->device);
+  State& S = c->S;
+  const int n = c->comm_n, me = c->comm_rank;
+  int rc = tile_sync_agree(c); if (rc) return rc;             // (ghosts and halo floes of the last step are dropped: the state is the owned floes)
+  world_rings(c);
+  const int N = c->hostN;
+  // ---- the tile's state on the host
+  double* const dcol[25] = { S.cx, S.cy, S.rmax, S.area, S.height, S.mass, S.moment, S.alpha, S.u, S.v, S.xi, S.p_dxdt, S.p_dydt, S.p_dalphadt, S.p_dudt, S.p_dvdt, S.p_dxidt,
+                             S.fxOA, S.fyOA, S.trqOA, S.hflx, S.overarea, S.cfx, S.cfy, S.ctrq };
+  std::vector<std::vector<double>> col(25, std::vector<double>((size_t)N));
+  std::vector<double> ten[3] = { std::vector<double>((size_t)4 * N), std::vector<double>((size_t)4 * N), std::vector<double>((size_t)4 * N) };
+  std::vector<long long> id((size_t)N); std::vector<int> status((size_t)N), voff((size_t)N + 1), soff((size_t)N + 1);
+  for (int k = 0; k < 25; k++) if (N) HIPCHK(c, hipMemcpy(col[k].data(), dcol[k], (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+  double* const dten[3] = { S.sa, S.si, S.strain };
+  for (int k = 0; k < 3; k++) if (N) HIPCHK(c, hipMemcpy(ten[k].data(), dten[k], (size_t)4 * N * sizeof(double), hipMemcpyDeviceToHost));
+  if (N) { HIPCHK(c, hipMemcpy(id.data(), S.id, (size_t)N * sizeof(long long), hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(status.data(), S.status, (size_t)N * sizeof(int), hipMemcpyDeviceToHost)); }
+  HIPCHK(c, hipMemcpy(voff.data(), S.voff, ((size_t)N + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(soff.data(), S.soff, ((size_t)N + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  const int V = voff[N], NS = soff[N];
+  std::vector<double> vx((size_t)std::max(V, 1)), vy((size_t)std::max(V, 1)), sx((size_t)std::max(NS, 1)), sy((size_t)std::max(NS, 1));
+  if (V) { HIPCHK(c, hipMemcpy(vx.data(), S.vx, (size_t)V * sizeof(double), hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(vy.data(), S.vy, (size_t)V * sizeof(double), hipMemcpyDeviceToHost)); }
+  if (NS) { HIPCHK(c, hipMemcpy(sx.data(), S.sx, (size_t)NS * sizeof(double), hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(sy.data(), S.sy, (size_t)NS * sizeof(double), hipMemcpyDeviceToHost)); }
+  // ---- who owns what now: the tile that holds the centroid (periodic: of its image inside the domain), px x py tiles over the domain
+  const double x0 = c->h_vals[3], y0 = c->h_vals[1], Lx = c->h_vals[2] - c->h_vals[3], Ly = c->h_vals[0] - c->h_vals[1];
+  std::vector<int> owner((size_t)N);
+  for (int i = 0; i < N; i++) {
+    if (owner_override) { owner[i] = owner_override[i]; if (owner[i] < 0 || owner[i] >= n) { c->err = "sz_tile_migrate: owner out of range"; return SZ_E_ARG; } continue; }
+    double x = col[0][i] - x0, y = col[1][i] - y0;
+    if (c->tile_per_x) { x = std::fmod(x, Lx); if (x < 0) x += Lx; }
+    if (c->tile_per_y) { y = std::fmod(y, Ly); if (y < 0) y += Ly; }
+    const int ix = std::max(0, std::min(px - 1, (int)(x / Lx * px))), iy = std::max(0, std::min(py - 1, (int)(y / Ly * py)));
+    owner[i] = iy * px + ix;
+  }
+  // ---- movers, one stream of doubles per destination: MIG_NCOL scalars, then ring x / y, then sub-floe points x / y of every floe
+  std::vector<std::vector<double>> sendv(n), recvv;
+  int nmove = 0;
+  for (int i = 0; i < N; i++) {
+    if (owner[i] == me) continue;
+    nmove++;
+    std::vector<double>& b = sendv[owner[i]];
+    for (int k = 0; k < 25; k++) b.push_back(col[k][i]);
+    for (int k = 0; k < 3; k++) for (int q = 0; q < 4; q++) b.push_back(ten[k][(size_t)4 * i + q]);
+    const int nv = voff[i + 1] - voff[i], ns = soff[i + 1] - soff[i];
+    b.push_back((double)id[i]); b.push_back((double)status[i]); b.push_back((double)c->tile_gidx[i]); b.push_back((double)nv); b.push_back((double)ns);
+    b.insert(b.end(), vx.begin() + voff[i], vx.begin() + voff[i + 1]); b.insert(b.end(), vy.begin() + voff[i], vy.begin() + voff[i + 1]);
+    b.insert(b.end(), sx.begin() + soff[i], sx.begin() + soff[i + 1]); b.insert(b.end(), sy.begin() + soff[i], sy.begin() + soff[i + 1]);
+  }
+  if ((rc = comm_alltoallv(c, sendv, recvv))) return rc;
+  // did anything move anywhere?  (every rank must take the same branch: the rebuild below ends in collective set-up calls)
+  int moved_all = 0;
+  if ((rc = comm_agree_bits(c, nmove > 0 ? 1 : 0, &moved_all))) return rc;
+  if (n_sent) *n_sent = nmove;
+  if (!moved_all) { if (n_owned) *n_owned = N; return SZ_OK; }
+  // ---- the new tile: kept floes + received ones, ordered by global index
+  struct Src { long long g; int from; size_t at; };          // from < 0: local row `at`; else stream `from`, offset `at`
+  std::vector<Src> src;
+  for (int i = 0; i < N; i++) if (owner[i] == me) src.push_back({ c->tile_gidx[i], -1, (size_t)i });
+  for (int s2 = 0; s2 < n; s2++) {
+    const std::vector<double>& b = recvv[s2];
+    for (size_t at = 0; at < b.size();) {
+      if (at + MIG_NCOL > b.size()) { c->err = "sz_tile_migrate: truncated record"; return SZ_E_STATE; }
+      const int nv = (int)b[at + 40], ns = (int)b[at + 41];
+      src.push_back({ (long long)b[at + 39], s2, at });
+      at += (size_t)MIG_NCOL + 2 * (size_t)nv + 2 * (size_t)ns;
+    }
+  }
+  std::sort(src.begin(), src.end(), [](const Src& a, const Src& b2) { return a.g < b2.g; });
+  const int Nn = (int)src.size();
+  if (Nn == 0) { c->err = "sz_tile_migrate: a tile without floes (every rank must own at least one)"; return SZ_E_STATE; }
+  std::vector<std::vector<double>> ncol(25, std::vector<double>((size_t)Nn));
+  std::vector<double> nten[3] = { std::vector<double>((size_t)4 * Nn), std::vector<double>((size_t)4 * Nn), std::vector<double>((size_t)4 * Nn) };
+  std::vector<long long> nid((size_t)Nn), ngid((size_t)Nn); std::vector<int> nstatus((size_t)Nn), nvoff((size_t)Nn + 1, 0), nsoff((size_t)Nn + 1, 0);
+  std::vector<double> nvx, nvy, nsx, nsy;
+  for (int r = 0; r < Nn; r++) {
+    const Src& q = src[r];
+    ngid[r] = q.g;
+    if (q.from < 0) {
+      const size_t i = q.at;
+      for (int k = 0; k < 25; k++) ncol[k][r] = col[k][i];
+      for (int k = 0; k < 3; k++) for (int t = 0; t < 4; t++) nten[k][(size_t)4 * r + t] = ten[k][4 * i + t];
+      nid[r] = id[i]; nstatus[r] = status[i];
+      nvx.insert(nvx.end(), vx.begin() + voff[i], vx.begin() + voff[i + 1]); nvy.insert(nvy.end(), vy.begin() + voff[i], vy.begin() + voff[i + 1]);
+      nsx.insert(nsx.end(), sx.begin() + soff[i], sx.begin() + soff[i + 1]); nsy.insert(nsy.end(), sy.begin() + soff[i], sy.begin() + soff[i + 1]);
+    } else {
+      const double* b = recvv[q.from].data() + q.at;
+      for (int k = 0; k < 25; k++) ncol[k][r] = b[k];
+      for (int k = 0; k < 3; k++) for (int t = 0; t < 4; t++) nten[k][(size_t)4 * r + t] = b[25 + 4 * k + t];
+      nid[r] = (long long)b[37]; nstatus[r] = (int)b[38];
+      const int nv = (int)b[40], ns = (int)b[41];
+      const double* p = b + MIG_NCOL;
+      nvx.insert(nvx.end(), p, p + nv); nvy.insert(nvy.end(), p + nv, p + 2 * nv);
+      p += 2 * (size_t)nv;
+      nsx.insert(nsx.end(), p, p + ns); nsy.insert(nsy.end(), p + ns, p + 2 * ns);
+    }
+    nvoff[r + 1] = (int)nvx.size(); nsoff[r + 1] = (int)nsx.size();
+  }
+  if (nvx.empty()) { nvx.push_back(0.0); nvy.push_back(0.0); }
+  if (nsx.empty()) { nsx.push_back(0.0); nsy.push_back(0.0); }
+  // ---- rebuild through the upload path, then the tile set-up again (collective, same parameters as before)
+  const double Lx0 = c->tile_Lx, Ly0 = c->tile_Ly, margin = c->tile_margin; const int perx = c->tile_per_x, pery = c->tile_per_y;
+  const int rebox = c->tile_rebox_fixed ? -c->tile_rebox_every : c->tile_rebox_every;
+  const double ring_hint = (double)c->max_ring_tiled, rmax_hint = c->rmax_hint;
+  sz_floe_columns f; memset(&f, 0, sizeof(f));
+  f.cx = ncol[0].data(); f.cy = ncol[1].data(); f.rmax = ncol[2].data(); f.area = ncol[3].data(); f.height = ncol[4].data(); f.mass = ncol[5].data(); f.moment = ncol[6].data();
+  f.alpha = ncol[7].data(); f.u = ncol[8].data(); f.v = ncol[9].data(); f.xi = ncol[10].data(); f.p_dxdt = ncol[11].data(); f.p_dydt = ncol[12].data(); f.p_dalphadt = ncol[13].data();
+  f.p_dudt = ncol[14].data(); f.p_dvdt = ncol[15].data(); f.p_dxidt = ncol[16].data(); f.fxOA = ncol[17].data(); f.fyOA = ncol[18].data(); f.trqOA = ncol[19].data();
+  f.hflx_factor = ncol[20].data(); f.overarea = ncol[21].data(); f.coll_fx = ncol[22].data(); f.coll_fy = ncol[23].data(); f.coll_trq = ncol[24].data();
+  f.stress_accum = nten[0].data(); f.stress_instant = nten[1].data(); f.strain = nten[2].data();
+  f.id = (int64_t*)nid.data(); f.status = nstatus.data(); f.vert_off = nvoff.data(); f.vx = nvx.data(); f.vy = nvy.data(); f.sub_off = nsoff.data(); f.sx = nsx.data(); f.sy = nsy.data();
+  const int prec = c->precision;
+  if ((rc = sz_upload_floes(c, Nn, Nn, &f))) return rc;
+  c->inter_lost = false; c->inter_any = true;
+  HIPCHK(c, hipMemsetAsync(S.inter_cnt, 0, ((size_t)S.capM + 1) * sizeof(int), c->stream));          // (no rows until the next collision call)
+  if ((rc = sz_tile_enable(c, (const int64_t*)ngid.data(), ring_hint, rmax_hint))) return rc;
+  if ((rc = sz_tile_setup(c, Lx0, Ly0, perx, pery, margin, rebox))) return rc;
+  if (!owner_override) (void)sz_tile_set_center(c, x0 + ((me % px) + 0.5) * Lx / px, y0 + ((me / px) + 0.5) * Ly / py);
+  c->precision = prec;
+  if (n_owned) *n_owned = Nn;
+  return SZ_OK;
+}
+// sub-floe points of the floes the context holds (CSR: off has N + 1 entries; call with sx == NULL for the offsets alone): after a
+// migration the host's copy of these is the library's
+int sz_download_subpoints(sz_ctx* c, int32_t* off, double* sx, double* sy) {
+  if (!c || !c->have_floes || !off) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  tile_cleanup(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int N = c->hostN;
+  HIPCHK(c, hipMemcpy(off, c->S.soff, ((size_t)N + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  if (sx && sy && off[N] > 0) {
+    HIPCHK(c, hipMemcpy(sx, c->S.sx, (size_t)off[N] * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(sy, c->S.sy, (size_t)off[N] * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return SZ_OK;
+}
+
 // The exchange of one step: the regions of d_send to the peers, theirs into d_recv, on the communication stream behind the pack kernel
 // (ev_packed) -- ev_recv is recorded when the halo is in.  all_ranks: every rank gets at least the header record (the stop agreement of the
 // inline steps reads the flags of ALL ranks); otherwise only the neighbouring tiles take part.
@@ -2261,6 +2481,13 @@ int tile_fuse_replay(sz_ctx* c, const int* h, bool last_coupled) {
 }
 }  // namespace
 
+// the centre of this rank's tile (optional, after sz_tile_setup): in a periodic direction the owned box of the FIRST gather then takes every
+// centroid at its image nearest to it, as the later gathers do with the centre of the box before (sz_k_owned_box)
+int sz_tile_set_center(sz_ctx* c, double x, double y) {
+  if (!c || !c->S.tiled || c->tile_margin <= 0) { if (c) c->err = "sz_tile_set_center needs sz_tile_setup"; return SZ_E_STATE; }
+  c->tile_box_ctr[0] = x; c->tile_box_ctr[1] = y; c->tile_box_valid = true;
+  return SZ_OK;
+}
 // nsteps x timestep_sim! of a tiled run, collectively on every rank (same arguments everywhere)
 int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupling_dt, int32_t flags, int32_t* steps_done) {
   if (steps_done) *steps_done = 0;
@@ -2325,6 +2552,16 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   // the periodic ghosts of the owned floes for the first step (and the swap of parents that lie outside the domain), BEFORE the first pack
   if (periodic && nsteps > 0) hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0, c->hostN);
   auto fail = [&](int rc) { S.ginline = 0; S.famrec = 0; S.step = 0; return rc; };
+  // SZ_SYNC_DEBUG=1 (diagnosis of a faulting kernel): wait after every stage of every step and say so on stderr -- the last line names the stage
+  const bool dbgsync = getenv("SZ_SYNC_DEBUG") != nullptr;
+  auto stage_done = [&](int s, const char* what) {
+    if (!dbgsync) return;
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    int h4[C_COUNT]; (void)hipMemcpy(h4, S.cnt, sizeof(h4), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[sz rank %d] step %d: %s done (%s) M=%d N=%d own=%d halo=%d ghosts=%d err=0x%x\n", me, s, what, hipGetErrorString(e), h4[C_M], h4[C_N], h4[C_NOWN], h4[C_NHALO], h4[C_NGHOSTS], h4[C_ERR]);
+    fflush(stderr);
+  };
+  stage_done(-1, "seed");
   for (int s = 0; s < nsteps; s++) {
     const int tstep = tstep0 + s;
     S.step = s + 1; S.gslot = s & 1;
@@ -2332,7 +2569,9 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     if (c->tile_since_box < 0 || c->tile_since_box >= c->tile_rebox_cur) { int rc = tile_rebox(c); if (rc) return fail(rc); }
     c->tile_since_box++;
     const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
+    stage_done(s, "rebox");
     tile_pack(c);
+    stage_done(s, "pack");
     { int rc = tile_exchange(c, true); if (rc) return fail(rc); }
     if (n > 1) {
       HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_recv, 0));
@@ -2340,6 +2579,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
       hipLaunchKernelGGL(sz_k_halo_unpack_inline, dim3(grid_for(slots, UNPACK_TPB, 1 << 20)), dim3(UNPACK_TPB), 0, c->stream, S, (const double*)c->d_recv, n, me, c->halo_cap,
                          S.gslot, c->hostN);
     }
+    stage_done(s, "exchange + unpack");
     // the forcings: where sz_step puts them (the tail of the narrow launch for tiles of up to 30 k owned floes, the neighbour launch up to 65 k)
     const bool fuse = coupling && !(c->pmask >> SZ_K_FORCING & 1u) && c->fuse_forcing && c->hostN <= 65536;
     int fmode = !fuse ? 0 : c->fuse_forcing_mode ? c->fuse_forcing_mode : (c->hostN <= 30000 ? 2 : 1);
@@ -2347,8 +2587,14 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     if (coupling && !fuse) stage_forcing(c, dt);
     if (coupling) c->forcing_where = fmode;
     S.callid = ++c->callid;
-    collisions_step(c, -1, dt, false, true, fmode, false, false);
+    if (dbgsync) {          // (the stages of collisions_step one by one)
+      stage_broad(c, false, true, fmode == 1, false); stage_done(s, "neighbour search");
+      stage_elems(c, true); stage_done(s, "element items");
+      stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, true, fmode == 2 ? (c->precision == 1 ? 2 : 1) : 0, 0); stage_done(s, "narrow phase");
+      stage_reduce(c, 1, -1, dt, 0); stage_done(s, "reduce");
+    } else collisions_step(c, -1, dt, false, true, fmode, false, false);
     stage_integrate(c, dt, false, coupling, true, -1, periodic && s + 1 < nsteps ? 1 - (s & 1) : -1);
+    stage_done(s, "integrate");
   }
   S.step = 0; S.ginline = 0; S.famrec = 0;
   c->tile_dirty = nsteps > 0;

@@ -765,8 +765,11 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
   GSTAMP(12);
   const unsigned long long old = given ? *given : base + pre;
   const int og = (int)(old >> 32), ov = (int)(old & 0xffffffffull);
-  if (N + og + ng > S.capM) { atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
-  if (NV0 + ov + npts > S.capV) { atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); return; }
+  // (out of rows or ring points: the error bit, and the allocator is marked POISONED in the word beside it -- its count then says nothing
+  //  about how many rows were really written, and the neighbour search that commits it runs the step on the parents alone instead of
+  //  walking rows nobody made.  The count itself is left alone: later allocations must keep seeing a plain, ever larger offset.)
+  if (N + og + ng > S.capM) { atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); atomicOr(&S.galloc[slot * 16 + 1], 1ull); return; }
+  if (NV0 + ov + npts > S.capV) { atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); atomicOr(&S.galloc[slot * 16 + 1], 1ull); return; }
   // ---- stores
   auto put = [&](const Shift& c, int w, long long key) {
     const int g = N + og + w, vb = NV0 + ov + w * n;
@@ -1159,8 +1162,9 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   const StopRegs stop = stop_load(S);
   int M = S.cnt[C_M];
   if (S.ginline) {            // inline ghosts: the step's ghosts were made by the kernel that placed their parents; the counts are committed here
-    const unsigned long long a = S.galloc[S.gslot * 16];
-    const int N = S.cnt[C_N], G = (int)(a >> 32), V = (int)(a & 0xffffffffull);
+    const unsigned long long a = S.galloc[S.gslot * 16], poisoned = S.galloc[S.gslot * 16 + 1];
+    const int N = S.cnt[C_N]; int G = (int)(a >> 32), V = (int)(a & 0xffffffffull);
+    if (poisoned || N + G > S.capM) { G = 0; V = 0; }          // a poisoned allocator (see ghost_inline_make): the parents alone, the error bit is up
     M = N + G;
     if (bid == 0 && threadIdx.x == 0 && !stop_test(S, stop)) { S.cnt[C_M] = M; S.cnt[C_NV] = S.voff[N] + V; S.cnt[C_NGHOSTS] = G; }
   }
@@ -1543,7 +1547,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     const int ncells = (int)S.bounds[4] * (int)S.bounds[5];
     for (int q = blockIdx.x * TPB + threadIdx.x; q <= ncells; q += nblk * TPB) { S.cell_cnt[q] = 0; S.cell_ovf[q] = 0; }
     if (blockIdx.x == 0) for (int q = threadIdx.x; q < WARN_SLOTS * 4; q += TPB) S.warn[(q >> 2) * 32 + (q & 3)] = 0;
-    if (S.ginline && blockIdx.x == 0 && threadIdx.x == 0) S.galloc[(1 - S.gslot) * 16] = 0ull;      // the allocator this step's integrator makes the next ghosts in
+    if (S.ginline && blockIdx.x == 0 && threadIdx.x == 0) { S.galloc[(1 - S.gslot) * 16] = 0ull; S.galloc[(1 - S.gslot) * 16 + 1] = 0ull; }      // the allocator (and its poison mark) this step's integrator makes the next ghosts in
     // a list the neighbour search outgrew (its error bits): the batch pauses in this step -- raised here, where the counter block is
     // at hand anyway, rather than in the search (which sits exactly on its register budget)
     if (blockIdx.x == 0 && threadIdx.x == 0 && (S.cnt[C_ERR] & (ERR_CAP_NEIGH | ERR_CAP_PAIRS))) capacity_stop(S);
@@ -2934,8 +2938,8 @@ __global__ void __launch_bounds__(UNPACK_TPB) sz_k_halo_unpack_inline(State S, c
   if (!act) return;
   const unsigned long long old = base + inc - mine;
   const int og = (int)(old >> 32), ov = (int)(old & 0xffffffffull);
-  if (nown + og + 1 + ng > S.capM) { atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); return; }
-  if (NV0 + ov + nv * (1 + ng) > S.capV) { atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); return; }
+  if (nown + og + 1 + ng > S.capM) { atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); atomicOr(&S.galloc[slot * 16 + 1], 1ull); return; }
+  if (NV0 + ov + nv * (1 + ng) > S.capV) { atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); atomicOr(&S.galloc[slot * 16 + 1], 1ull); return; }
   const int g = nown + og, vb = NV0 + ov;
   int cix, ciy; cell_of(geo, R.cx, R.cy, cix, ciy);
   const int cell_c = ciy * geo.ncx + cix, cell_s = atomicAdd(&S.cell_cnt[cell_c], 1);
@@ -2959,12 +2963,19 @@ __global__ void __launch_bounds__(UNPACK_TPB) sz_k_halo_unpack_inline(State S, c
 }
 // bounding box of the owned centroids and the largest rmax: out[0..4] = xmin, xmax, ymin, ymax, rmax; out[5] = the largest
 // displacement since the last box gather as the last pack kernel measured it (C_DRIFT); out[6] = the largest |u|, |v| now
-__global__ void __launch_bounds__(1024) sz_k_owned_box(State S, double* out) {
+// ctr (may be null): the centre of the box at the last gather -- in a periodic direction every centroid is taken at its image nearest to
+// that centre, so that a parent the ghost pass has wrapped to the other side of the domain does not stretch its owner's box (and with it
+// the owner's halo) across the whole domain; the box may then reach beyond the walls, which the senders' image test handles
+__global__ void __launch_bounds__(1024) sz_k_owned_box(State S, double* out, const double* ctr, double Lx, double Ly, int per_x, int per_y) {
   __shared__ double sh[6][16];
   int n = S.cnt[C_NOWN];
   double x0 = __builtin_inf(), y0 = __builtin_inf(), x1 = -__builtin_inf(), y1 = -__builtin_inf(), rm = 0.0, vm = 0.0;
+  const double ccx = ctr ? ctr[0] : 0.0, ccy = ctr ? ctr[1] : 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    x0 = fmin(x0, S.cx[i]); x1 = fmax(x1, S.cx[i]); y0 = fmin(y0, S.cy[i]); y1 = fmax(y1, S.cy[i]); rm = fmax(rm, S.rmax[i]);
+    double xi = S.cx[i], yi = S.cy[i];
+    if (ctr && per_x) { if (xi - ccx > 0.5 * Lx) xi -= Lx; else if (ccx - xi > 0.5 * Lx) xi += Lx; }
+    if (ctr && per_y) { if (yi - ccy > 0.5 * Ly) yi -= Ly; else if (ccy - yi > 0.5 * Ly) yi += Ly; }
+    x0 = fmin(x0, xi); x1 = fmax(x1, xi); y0 = fmin(y0, yi); y1 = fmax(y1, yi); rm = fmax(rm, S.rmax[i]);
     vm = fmax(vm, fmax(fabs(S.u[i]), fabs(S.v[i])));
   }
   for (int d = 32; d >= 1; d >>= 1) {

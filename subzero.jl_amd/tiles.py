@@ -194,6 +194,8 @@ class TiledWorld:
             w._chk(w.L.sz_comm_init_host(w.h, world, rank, C.byref(self._transport)))
         if backend in ("library", "library-host"):
             w._chk(w.L.sz_tile_setup(w.h, self.L, self.L, int(self.per_x), int(self.per_y), float(drift_margin), int(rebox_every)))
+            px, py = tile_grid(world)          # (the tile rule of assign_tiles: rank = iy * px + ix)
+            w._chk(w.L.sz_tile_set_center(w.h, (rank % px + 0.5) * self.L / px, (rank // px + 0.5) * self.L / py))
         elif not host_staging:
             # kernels and RCCL collectives are ordered by ONE stream: no host sync inside a step
             w._chk(w.L.sz_set_stream(w.h, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
@@ -440,6 +442,36 @@ class TiledWorld:
         self._ref = None
         return len(mv)
 
+    def migrate(self, owner_fn=None):
+        """Migration inside the library (sz_tile_migrate: library backends): every owned floe goes to the tile that holds its centroid now
+        (or to owner_fn(cx, cy)), with its complete state, over the library's own channel (RCCL / the host transport); the context is
+        rebuilt from the kept and received floes ordered by global index.  Collective.  Returns the number of floes this rank gave away."""
+        w = self.world
+        self.sync()
+        ov = None
+        if owner_fn is not None:
+            w._host_stale = True
+            n = len(self.gidx)
+            cx, cy = w.get("cx")[:n].copy(), w.get("cy")[:n].copy()
+            if self.per_x: cx %= self.L
+            if self.per_y: cy %= self.L
+            ov = np.ascontiguousarray(owner_fn(cx, cy), np.int32)
+        px, py = tile_grid(self.nranks)
+        sent = C.c_int64(0); owned = C.c_int64(0)
+        w._chk(w.L.sz_tile_migrate(w.h, int(px), int(py), capi.ptr(ov, capi._ip) if ov is not None else None, C.byref(sent), C.byref(owned)))
+        # the host's copies of the columns are the library's now
+        n = int(owned.value)
+        w.N = n; w._M = n; w._dirty = False; w._host_stale = True; w._sub = {}
+        off = np.zeros(n + 1, np.int32)
+        w._chk(w.L.sz_download_subpoints(w.h, capi.ptr(off, capi._ip), None, None))
+        sx = np.zeros(max(int(off[n]), 1)); sy = np.zeros(max(int(off[n]), 1))
+        w._chk(w.L.sz_download_subpoints(w.h, capi.ptr(off, capi._ip), capi.ptr(sx), capi.ptr(sy)))
+        w.col["sub_off"], w.col["sx"], w.col["sy"] = off, sx[:off[n]], sy[:off[n]]
+        w._pull()
+        self.gidx = (w.col["id"][:n] - 1).astype(np.int64)
+        self.boxes = None; self._ref = None
+        return int(sent.value)
+
     def maybe_repartition(self):
         """Ownership is static between calls of repartition(); floes drift.  Collective: re-tile when more than
         `repartition_fraction` of all floes has left the tile that owns it (cheap test: the owned centroids against the
@@ -454,7 +486,7 @@ class TiledWorld:
         self.dist.all_reduce(t)
         if int(t[0]) <= self.repartition_fraction * max(int(t[1]), 1):
             return 0
-        return self.repartition()
+        return self.migrate() if self.backend in ("library", "library-host") else self.repartition()
 
     def run(self, nsteps, tstep0, dt, coupling_dt=10, collisions_on=True, coupling_on=True, stop_on_tags=False):
         """nsteps x timestep_sim! of the tiled run (collective).  Returns the steps run.  stop_on_tags (library backends): the batch ends

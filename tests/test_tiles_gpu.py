@@ -67,7 +67,8 @@ def _worker(rank, world, port, n, seed, steps, q, repartition=False, fast=False,
             half = steps // 2
             tw.run(half, 0, cfg["dt"], coupling_dt=1)
             L = cfg["L"]
-            moved = tw.repartition(owner_fn=lambda cx, cy: (cy > 0.5 * L).astype(int))
+            other = lambda cx, cy: (cy > 0.5 * L).astype(int)
+            moved = tw.migrate(owner_fn=other) if repartition == "migrate" else tw.repartition(owner_fn=other)
             assert moved > 0 and len(tw.gidx) > 0
             tw.run(steps - half, half, cfg["dt"], coupling_dt=1)
         else:
@@ -90,7 +91,8 @@ def _run_worker_two_way(*a):
 @pytest.mark.parametrize("world,n,seed,steps,repartition,fast,backend", [
     (2, 600, 31, 4, False, False, "torch"), (2, 600, 33, 6, True, False, "torch"), (4, 1000, 35, 4, False, False, "torch"),
     (2, 500, 77, 30, False, True, "torch"),
-    (2, 600, 31, 8, False, False, "library-host"), (2, 600, 33, 8, True, False, "library-host"), (4, 1000, 35, 8, False, False, "library-host"),
+    (2, 600, 31, 8, False, False, "library-host"), (2, 600, 33, 8, True, False, "library-host"), (2, 600, 33, 8, "migrate", False, "library-host"),
+    (4, 1000, 35, 8, False, False, "library-host"),
     (2, 500, 77, 30, False, True, "library-host")])
 def test_ranks_equal_single(world, n, seed, steps, repartition, fast, backend):
     """2 ranks (two tiles side by side) and 4 ranks (2 x 2 tiles: corner halos, both periodic directions across
@@ -364,3 +366,111 @@ def test_tiled_batch_ends_on_every_rank_where_a_floe_is_tagged(kind):
             owners.add(rank)
     if kind == "fuse":
         assert owners == {0, 1}            # the fused pair straddles the tile edge
+
+
+# ---------------------------------------------------------------- migration inside the library
+def _worker_migrate(rank, world, port, n, seed, steps, every, q):
+    import time
+    import torch.distributed as dist
+    from subzero_jl_amd import tiles
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        cfg = _field(n, seed, fast=True)
+        tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True, backend="library-host", rebox_every=5)
+        moved, cost = 0, []
+        for t0 in range(0, steps, every):
+            tw.run(min(every, steps - t0), t0, cfg["dt"], coupling_dt=1)
+            if t0 + every < steps:
+                t = time.perf_counter(); moved += tw.migrate(); cost.append(time.perf_counter() - t)
+        out = {f: tw.owned(f) for f in FIELDS}
+        q.put((rank, tw.gidx, out, moved, cost))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_worker_migrate(*a):
+    _guard(_worker_migrate)(*a)
+
+
+@pytest.mark.parametrize("world,n", [(2, 500), (4, 1000)])
+def test_migration_every_20_steps(world, n):
+    """sz_tile_migrate: fast floes (2 - 8 m/s: 40 - 160 m per step on tiles a few hundred km wide, parents
+    crossing the periodic walls) with a re-tile every 20 steps -- floes that left their tile go to their new owner with their complete
+    state over the library's channel, the contexts are rebuilt -- and after 60 steps every owned column is bit-equal to the single
+    context's.  The cost per re-tile is printed (host-staged inside the library: a download and an upload of the tile)."""
+    import torch.multiprocessing as mp
+    import subzero_jl_amd
+    from subzero_jl_amd import fields
+    steps, every, seed = 60, 20, 78
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_run_worker_migrate, args=(r, world, port, n, seed, steps, every, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = _collect(q, world)
+        for p in procs:
+            p.join(60)
+        assert all(p.exitcode == 0 for p in procs)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    cfg = _field(n, seed, fast=True)
+    hw = fields.build_world(subzero_jl_amd.World(0), cfg)
+    hw.run(steps, 0, cfg["dt"], coupling_dt=1, stop_on_tags=False)
+    seen = np.zeros(n, bool); moved = 0
+    for rank, gidx, out, mv, cost in res:
+        assert not seen[gidx].any()
+        seen[gidx] = True; moved += mv
+        print(f"rank {rank}: {len(gidx)} floes owned at the end, {mv} given away, re-tile cost {['%.1f ms' % (1e3 * c) for c in cost]}")
+        for f in FIELDS:
+            assert np.array_equal(out[f], hw.get(f)[gidx]), (rank, f, np.max(np.abs(out[f] - hw.get(f)[gidx])))
+    assert seen.all() and moved > 0
+
+
+def _worker_overflow(rank, world, port, q):
+    import torch.distributed as dist
+    from subzero_jl_amd import tiles
+    from subzero_jl_amd.capi import SzError
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        cfg = _field(1000, 35)
+        # a drift margin as wide as the domain: every floe of every other rank is in this rank's halo -- three times what the tile's rows hold
+        tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True, backend="library-host", rebox_every=5, drift_margin=float(cfg["L"]))
+        try:
+            tw.run(4, 0, cfg["dt"], coupling_dt=1)
+            q.put((rank, "no error"))
+        except SzError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_worker_overflow(*a):
+    _guard(_worker_overflow)(*a)
+
+
+def test_a_halo_that_outgrows_the_tile_is_an_error_on_every_rank():
+    """More halo floes than the tile has rows for: the unpack kernel refuses the rows it has no room for, marks the step's allocator
+    poisoned (the neighbour search then runs on the owned floes alone instead of walking rows nobody wrote) and raises the capacity
+    bit -- which all ranks agree on at the end of the batch: every rank raises, none hangs, nothing is written out of bounds."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_run_worker_overflow, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    try:
+        res = _collect(q, 4)
+        for p in procs:
+            p.join(60)
+        assert all(p.exitcode == 0 for p in procs)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    for rank, msg in res:
+        assert "error bits" in msg and msg != "no error", (rank, msg)
