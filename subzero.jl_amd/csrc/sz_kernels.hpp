@@ -1714,7 +1714,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
         for (int att = 0;; att++) {
           const bool detect = run && cert && att == 0;
           if (run) clip<G>(mem[g], m, gl, ox, oy, pna, poa, pnb, pob, buf, pba, pbb, st, detect);
-          if (detect) settled = certified_check<G>(mem[g], m, gl, q);
+          if (detect) { settled = certified_check<G>(mem[g], m, gl, q); STAMP(st, 14); }
           if (!detect || settled) break;
         }
         if (pass > 0 && run && gl == 0) { m.acc16[3]++; if (settled) m.acc16[4]++; }

@@ -13,7 +13,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 cfg = fields.make_config(n_floes=n, seed=12345)
 names = {0: "rings staged", 1: "candidate edges done", 2: "detect signs done", 3: "detect params done", 4: "canonical done",
          5: "containment done", 6: "rank done", 7: "trace+area done", 8: "match/many done", 10: "intersects done",
-         11: "item done", 12: "overlap tests done", 13: "direction settled",
+         11: "item done", 12: "overlap tests done", 13: "direction settled", 14: "certified check done (detect-only clip + exact area change)",
          20: "stop flag read", 21: "segment + housekeeping", 22: "work item read", 23: "ring offsets read", 24: "ring loads back", 25: "scalar loads back", 26: "sign + box loads back"}
 for blk in range(0, 40):
     os.environ["SZ_DEBUG"] = str((blk << 8) | int(os.environ.get("SZ_STAMPS_TWICE", "0")) * 16)
