@@ -80,7 +80,8 @@ _LIB = None
 
 
 def lib_path():
-    return _build.LIB
+    # (SZ_LIB_PATH: another build of the same library -- A/B experiments on compile-time choices, tools/ only)
+    return os.environ.get("SZ_LIB_PATH") or _build.LIB
 
 
 def load(build_if_missing=True):

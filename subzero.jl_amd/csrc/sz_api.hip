@@ -103,6 +103,8 @@ struct sz_ctx {
   bool retry_seen = false;          // an item has needed the largest narrow variant: sz_step enqueues it in every step from now on
   bool no_elems_ride = false;       // SZ_ELEMS_RIDE=0: the element items always get their own launch
   bool no_lean_narrow = false;      // SZ_LEAN_NARROW=0: always enqueue it
+  bool no_crec = false;             // SZ_CREC=0: no collision records (State::crec) in the resident steps
+  double2* crec_buf = nullptr;      // the records' memory (State::crec points at it only inside the batches that keep it current)
   int forcing_where = -1;           // sz_forcing_launch
   int fuse_forcing_mode = 0;        // ... 1: in the neighbour launch, 2: in the narrow launch (its tail), 0: by size -- the narrow launch while the narrow phase is one
                                     // round with a long tail (measured better up to 20 k floes, even at 40 k, worse at 65 k); SZ_FUSE_FORCING=1|2 forces one
@@ -465,10 +467,11 @@ void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false
     c->grid_live = false;
   }
   // the neighbour search appends the pair items to the narrow phase's work list itself: no scan, no pair-list launch
+  const bool rec = S.crec != nullptr;      // collision records are current in this batch: the instantiations that read them
   if (fuse_forcing) {          // the step's forcings ride in the neighbour launch (sz_k_neighbors_forcing)
     const int nbn = grid_for(S.capM, 256 / NB_G, 8192), nbf = grid_for(S.capM, 256 / FRC_PLAIN, 8192);
-    if (c->precision == 1) hipLaunchKernelGGL(sz_k_neighbors_forcing<2>, dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn);
-    else hipLaunchKernelGGL(sz_k_neighbors_forcing<1>, dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn);
+    if (c->precision == 1) { if (rec) hipLaunchKernelGGL((sz_k_neighbors_forcing<2, true>), dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn); else hipLaunchKernelGGL((sz_k_neighbors_forcing<2, false>), dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn); }
+    else { if (rec) hipLaunchKernelGGL((sz_k_neighbors_forcing<1, true>), dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn); else hipLaunchKernelGGL((sz_k_neighbors_forcing<1, false>), dim3(nbn + nbf), dim3(256), 0, c->stream, S, c->P, nbn); }
   } else
   {
     const dim3 gr(grid_for(S.capM, NB_TPB / NB_G, 8192)), bl(NB_TPB);
@@ -476,10 +479,11 @@ void stage_broad(sz_ctx* c, bool commit_ghosts = false, bool static_grid = false
     if (with_elems) {          // the element items in the launch's tail (elems_ride)
       // (no periodic wall, no ghosts, no Dict rule: the search's lean instantiation)
       const int nbn = (int)gr.x, nbe = grid_for(S.capM, NB_TPB, 1 << 20);
-      hipLaunchKernelGGL(sz_k_neighbors_elem<false>, dim3(nbn + nbe), bl, 0, c->stream, S, next_epoch(c), nbn);
+      if (rec) hipLaunchKernelGGL((sz_k_neighbors_elem<false, true>), dim3(nbn + nbe), bl, 0, c->stream, S, next_epoch(c), nbn);
+      else hipLaunchKernelGGL((sz_k_neighbors_elem<false, false>), dim3(nbn + nbe), bl, 0, c->stream, S, next_epoch(c), nbn);
     } else if (S.maxnb <= MAXNB) {
-      if (fam) hipLaunchKernelGGL((sz_k_neighbors<true, MAXNB>), gr, bl, 0, c->stream, S);
-      else hipLaunchKernelGGL((sz_k_neighbors<false, MAXNB>), gr, bl, 0, c->stream, S);
+      if (fam) { if (rec) hipLaunchKernelGGL((sz_k_neighbors<true, MAXNB, true>), gr, bl, 0, c->stream, S); else hipLaunchKernelGGL((sz_k_neighbors<true, MAXNB>), gr, bl, 0, c->stream, S); }
+      else { if (rec) hipLaunchKernelGGL((sz_k_neighbors<false, MAXNB, true>), gr, bl, 0, c->stream, S); else hipLaunchKernelGGL((sz_k_neighbors<false, MAXNB>), gr, bl, 0, c->stream, S); }
     } else if (S.maxnb <= 64) {
       if (fam) hipLaunchKernelGGL((sz_k_neighbors<true, 64>), gr, bl, 0, c->stream, S);
       else hipLaunchKernelGGL((sz_k_neighbors<false, 64>), gr, bl, 0, c->stream, S);
@@ -795,6 +799,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_FUSED_MOVE")) c->fused_move = atoi(e) != 0;
   if (const char* e = getenv("SZ_TW_GENERAL_CLIP")) c->tw_general_clip = atoi(e) != 0;
   if (const char* e = getenv("SZ_LEAN_NARROW")) c->no_lean_narrow = atoi(e) == 0;
+  if (const char* e = getenv("SZ_CREC")) c->no_crec = atoi(e) == 0;
   if (const char* e = getenv("SZ_GHOST_INLINE")) c->ghost_inline = atoi(e) != 0;
   if (const char* e = getenv("SZ_TILE_INLINE")) c->tile_inline_off = atoi(e) == 0;
   if (const char* e = getenv("SZ_ELEMS_RIDE")) c->no_elems_ride = atoi(e) == 0;
@@ -1030,6 +1035,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(gplan, S.capM + 1); DA(gscan4, S.capM + 1); DA(gtot4, 4);
   DA(lb_agg, S.capM / 128 + 8); DA(lb_inc, S.capM / 128 + 8); DA(lb_flag, S.capM / 128 + 8); c->scan_epoch = 0;      // (tiles of 128 .. SCAN_B elements)
   DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2); DA(gcand, (size_t)2 * S.capM); DA(galloc, 32); DA(gkeys, (size_t)2 * S.capM); DA(fam, S.capM);
+  DA(crec, (size_t)8 * S.capM); c->crec_buf = S.crec; S.crec = nullptr;
   DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1); DA(cell_ovf, S.capCells + 1); DA(cell_slots, (size_t)S.capCells * CELL_K + 8);
   DA(cell_items, S.capM);
   DA(n_out, S.capM + 1); DA(n_in, S.capM + 1); DA(over_stamp, S.capM + 1); DA(over_base, S.capM + 1);
@@ -1515,6 +1521,11 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   const bool body = mixed && coll && sg && (gl || !periodic) && !c->S.tiled && c->fused_move && c->max_ring <= MV_RING && !c->no_body_rings;
   if (!body) world_rings(c);
   c->S.body_rings = body ? 1 : 0;
+  // collision records (State::crec): in batches whose kernels keep them current -- the one-launch integrator, and for periodic walls the
+  // inline ghost maker; seeded here from the columns (before the ghost seed: the maker updates the records of the parents it visits)
+  const bool cr = coll && sg && !c->no_crec && c->crec_buf && c->fused_move && c->max_ring <= MV_RING && (gi || !periodic) && nsteps > 0;
+  c->S.crec = cr ? c->crec_buf : nullptr;
+  if (cr) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, c->S, c->hostN);
   if (gi) {               // the ghosts of the first step, from the parents as they lie (after the rings are in the batch's form)
     HIPCHK(c, hipMemsetAsync(c->S.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0, c->hostN);
@@ -1564,11 +1575,12 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
       // A list outgrown inside step h[C_RETRYSTOP] (neighbours per floe, pair items, rows per floe): the batch paused there before anything
       // of the floes' state changed (capacity_stop()).  Larger lists, then that step and the rest of the batch again, from the parents as
       // they lie -- exactly as a batch that starts at that step would (cells, the step's ghosts): the reference's lists grow (collisions.jl:290-296).
-      if ((rc = grow_lists(c, c->last_err_bits))) { c->S.retry_stop = 0; c->S.body_rings = 0; c->S.ginline = 0; c->S.famrec = 0; c->S.step = 0; return rc; }
+      if ((rc = grow_lists(c, c->last_err_bits))) { c->S.retry_stop = 0; c->S.body_rings = 0; c->S.ginline = 0; c->S.famrec = 0; c->S.step = 0; c->S.crec = nullptr; return rc; }
       s0 = h[C_RETRYSTOP] - 1; mid = 0;
       (void)hipMemsetAsync(c->S.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream);
       (void)hipMemsetAsync(c->S.cnt + C_STOP, 0, sizeof(int), c->stream);
       c->grid_live = false; use_static_grid(c);
+      if (cr) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, c->S, c->hostN);
       if (gi) {
         (void)hipMemsetAsync(c->S.galloc, 0, 32 * sizeof(unsigned long long), c->stream);
         c->S.gslot = s0 & 1;
@@ -1576,7 +1588,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
       } else if (gl) { c->gl_valid = false; use_ghost_list(c); }
       continue;
     }
-    if (rc) { c->S.retry_stop = 0; c->S.body_rings = 0; c->S.ginline = 0; c->S.famrec = 0; return rc; }
+    if (rc) { c->S.retry_stop = 0; c->S.body_rings = 0; c->S.ginline = 0; c->S.famrec = 0; c->S.crec = nullptr; return rc; }
     if (!lean || h[C_RETRYSTOP] == 0) break;
     // paused after the narrow launch of step h[C_RETRYSTOP]: that variant is in from now on
     c->retry_seen = true; lean = false;
@@ -1585,7 +1597,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     (void)hipMemsetAsync(c->S.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream);
   }
   c->S.retry_stop = 0;
-  c->S.ginline = 0; c->S.famrec = 0;
+  c->S.ginline = 0; c->S.famrec = 0; c->S.crec = nullptr;
   if (body && nsteps > 0) c->rings_stale = true;
   c->S.body_rings = 0;
   if (coll) { c->inter_any = true; c->inter_lost = false; }
@@ -2504,6 +2516,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   // halo floes), forcings in the tail of the narrow launch, no ghost launch -- plus the pack and unpack kernels and the exchange.
   // Needs what the inline ghost maker needs (rings that fit the one-launch integrator, the static grid).  Otherwise (and with
   // SZ_TILE_INLINE=0): the list-based steps of sz_tile_step.
+  S.crec = nullptr;
   const bool inl = coll && !c->tile_inline_off && c->ghost_inline && c->fused_move && c->grid_ok && !c->no_static_grid && !c->two_way &&
                    std::max(c->max_ring, c->max_ring_tiled) <= MV_RING && ((flags & SZ_COUPLING_ON) == 0 || c->have_fields);
   if (!inl) {
@@ -2550,8 +2563,11 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   S.ginline = 1; S.famrec = 1; S.retry_stop = 0; S.body_rings = 0;
   HIPCHK(c, hipMemsetAsync(S.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
   // the periodic ghosts of the owned floes for the first step (and the swap of parents that lie outside the domain), BEFORE the first pack
+  // collision records of the owned floes (the halo floes get theirs from the unpack kernel, ghosts from their maker; see sz_step)
+  S.crec = (!c->no_crec && c->crec_buf && nsteps > 0) ? c->crec_buf : nullptr;
+  if (S.crec) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, S, c->hostN);
   if (periodic && nsteps > 0) hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0, c->hostN);
-  auto fail = [&](int rc) { S.ginline = 0; S.famrec = 0; S.step = 0; return rc; };
+  auto fail = [&](int rc) { S.ginline = 0; S.famrec = 0; S.step = 0; S.crec = nullptr; return rc; };
   // SZ_SYNC_DEBUG=1 (diagnosis of a faulting kernel): wait after every stage of every step and say so on stderr -- the last line names the stage
   const bool dbgsync = getenv("SZ_SYNC_DEBUG") != nullptr;
   auto stage_done = [&](int s, const char* what) {
@@ -2596,7 +2612,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     stage_integrate(c, dt, false, coupling, true, -1, periodic && s + 1 < nsteps ? 1 - (s & 1) : -1);
     stage_done(s, "integrate");
   }
-  S.step = 0; S.ginline = 0; S.famrec = 0;
+  S.step = 0; S.ginline = 0; S.famrec = 0; S.crec = nullptr;
   c->tile_dirty = nsteps > 0;
   int h[C_COUNT];
   int rc = sync_and_check(c, h);                     // (drops the halo floes and ghosts of the last step: tile_cleanup)

@@ -64,7 +64,7 @@ struct GroupMem {
   double rcx[RM], rcy[RM];                   // centroids of the regions of clip 0
   // per-item scalars live here rather than in registers across the clips (the kernel's register
   // budget decides how many items the chip holds in flight):
-  double kin[14];                            // i: cx cy u v xi, j: cx cy u v xi, area_i h_i area_j h_j
+  double kin[14];                            // i: cx cy u v xi area h, j: the same (the order of the collision record's quads {cx, cy} {u, v} {xi, area} {h, -})
   double dlv[RM], dxv[RM], dyv[RM];          // per kept region: contact length and force direction
   double box[8];                             // ring boxes of the item: a x0 x1 y0 y1, b x0 x1 y0 y1 (a direction check of this item may be
   double ff;                                 // run by another lane group of the wavefront, which finds them here); force factor
@@ -593,7 +593,7 @@ struct Body {          // kinematics of one side of a contact
 enum { ITEM_PAIR = 0, ITEM_OPEN = 1, ITEM_SOLID = 2 };
 enum { IT_FUSE = 1, IT_REMOVE = 2, IT_RETRY = 4 };
 
-enum { KIN_I = 0, KIN_J = 5, KIN_AREA_I = 10, KIN_H_I = 11, KIN_AREA_J = 12, KIN_H_J = 13 };   // GroupMem::kin
+enum { KIN_I = 0, KIN_J = 7, KIN_AREA_I = 5, KIN_H_I = 6, KIN_AREA_J = 12, KIN_H_J = 13 };   // GroupMem::kin
 
 struct ItemCtx {
   int mode;            // ITEM_PAIR: floe-floe; ITEM_OPEN: open boundary; ITEM_SOLID: collision/moving boundary, topography

@@ -72,6 +72,29 @@ __device__ __forceinline__ void rec32_store(const State& S, int i, double cx, do
   S.rec32[2 * (size_t)i + 1] = make_float4((float)x0, (float)x1, (float)y0, (float)y1);
 }
 
+// ---- collision records (State::crec): packing of the two integer quads, and the stores of whoever places a floe
+constexpr long long CREC_KEYMASK = (1ll << 48) - 1;          // order keys stay below 2^48: (pass << 40) + 4 * (global index) + k
+__device__ __forceinline__ double crec_okf(long long okey, int nv, int osign) {
+  return __longlong_as_double(okey | ((long long)(nv & 255) << 48) | ((long long)(osign < 0 ? 1 : 0) << 56));
+}
+__device__ __forceinline__ double crec_vp(int voff, int parent, int ngh) {
+  return __longlong_as_double((long long)(unsigned)voff | ((long long)parent << 32) | ((long long)ngh << 60));
+}
+__device__ __forceinline__ void crec_store_all(const State& S, int row, double cx, double cy, double rmax, long long id, long long okey, int nv, int osign,
+                                               int voff, int parent, int ngh, double x0, double x1, double y0, double y1, double u, double v, double xi,
+                                               double area, double h, long long ghost_id) {
+  double2* r = S.crec + (size_t)row * 8;
+  r[0] = make_double2(cx, cy); r[1] = make_double2(rmax, __longlong_as_double(id));
+  r[2] = make_double2(crec_okf(okey, nv, osign), crec_vp(voff, parent, ngh));
+  r[3] = make_double2(x0, x1); r[4] = make_double2(y0, y1); r[5] = make_double2(u, v); r[6] = make_double2(xi, area);
+  r[7] = make_double2(h, __longlong_as_double(ghost_id));
+}
+// a floe that has only been translated (a parent that swapped with its ghost)
+__device__ __forceinline__ void crec_store_place(const State& S, int row, double cx, double cy, double x0, double x1, double y0, double y1) {
+  double2* r = S.crec + (size_t)row * 8;
+  r[0] = make_double2(cx, cy); r[3] = make_double2(x0, x1); r[4] = make_double2(y0, y1);
+}
+
 // ============================================================================ scan (exclusive, int)
 constexpr int SCAN_B = 1024;
 
@@ -792,6 +815,7 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
     }
     GSTAMP(17);
     if (S.rec32) rec32_store(S, g, gx, gy, c_rmax, x0, x1, y0, y1);
+    if (S.crec) crec_store_all(S, g, gx, gy, c_rmax, idv, key, n, osv, body ? vo : vb, i, 0, x0, x1, y0, y1, c_u, c_v, c_xi, c_area, c_h, (long long)(w + 1));
     S.gkeys[(size_t)slot * S.capM + og + w] = key;
   };
   GSTAMP(13);
@@ -818,9 +842,11 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
       for (int k = 0; k < MV_RING; k++) if (k < n) { double x = R.rx[k], y = R.ry[k]; shift_apply(cp, x, y); S.vx[vo + k] = x; S.vy[vo + k] = y; }
     }
     if (S.rec32) rec32_store(S, i, px, py, c_rmax, x0, x1, y0, y1);
+    if (S.crec) crec_store_place(S, i, px, py, x0, x1, y0, y1);
   }
   for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = q < ng ? N + og + q : -1;
   S.ngh[i] = ng;
+  if (S.crec) S.crec[(size_t)i * 8 + 2].y = crec_vp(vo, i, ng);
   {
     // the family record of this id for the Dict rule (pair_allowed_fam): the parent as it now lies, then its ghosts -- the values of the rows
     State::Fam* F = S.fam + i;
@@ -882,6 +908,12 @@ __global__ void sz_k_rec32_seed(State S) {
   const int M = S.cnt[C_M];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x)
     rec32_store(S, i, S.cx[i], S.cy[i], S.rmax[i], S.bbx0[i], S.bbx1[i], S.bby0[i], S.bby1[i]);
+}
+// the collision records of the rows [0, n) as the columns hold them (start of a resident batch; the kernels of the batch keep them current)
+__global__ void __launch_bounds__(256) sz_k_crec_seed(State S, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    crec_store_all(S, i, S.cx[i], S.cy[i], S.rmax[i], S.id[i], S.okey[i], ring_n(S, i), S.osign[i], ring_off(S, i), S.parent[i], S.ngh[i],
+                   S.bbx0[i], S.bbx1[i], S.bby0[i], S.bby1[i], S.u[i], S.v[i], S.xi[i], S.area[i], S.height[i], S.ghost_id[i]);
 }
 // seeds candidate list `list` from the parents as they lie (after an upload / a process-mode call), thread per parent
 __global__ void sz_k_ghost_seed(State S, int list) {
@@ -1141,7 +1173,9 @@ constexpr int NB_G = 16, NB_TPB = 128;
 // large field (throughput-bound search) misses: the host picks the instantiation by size
 // NBC: neighbours a floe may have in either direction (= State::maxnb, the stride of the neighbour lists): 24 for fields of like-sized
 // floes, 64 where the host's count at upload finds a size spectrum (Voronoi fields: a large cell has dozens of small neighbours)
-template <int TPB, bool FAM = true, int NBC = MAXNB>
+// REC: the floe's own row and every candidate come from the collision records (State::crec: five 16-byte loads from ONE line instead of
+// thirteen scattered columns -- the kernel is bound by the number of lines its loads touch)
+template <int TPB, bool FAM = true, int NBC = MAXNB, bool REC = false>
 __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   constexpr int GPB = TPB / NB_G;
   constexpr int NB_POOL = NBC <= 24 ? 96 : (NBC <= 64 ? 224 : 256);       // floes the 3 x 3 cells around a floe may hold (chunked pool: per chunk)
@@ -1158,6 +1192,7 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   __shared__ int npool[GPB];
   __shared__ int wbase[GPB + 1];
   __shared__ int cvo[GPB][NBC], cnv[GPB][NBC], svo[GPB][NBC], snv[GPB][NBC];    // ring offset / size of the owned pairs' partners (unsorted, sorted)
+  __shared__ double kbox[REC ? GPB : 1][4];      // (records: the floe's own ring box waits here for the AABB cull instead of in eight registers through the Dict rule)
   const int gl = threadIdx.x % NB_G, gi = threadIdx.x / NB_G;
   const StopRegs stop = stop_load(S);
   int M = S.cnt[C_M];
@@ -1182,11 +1217,21 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
     double ckx = 0, cky = 0, rk = 0, kx0 = 0, kx1 = 0, ky0 = 0, ky1 = 0;
     long long idk = 0, okk = 0, kgid = 0; bool kplain = true; int ix = 0, iy = 0, vok = 0, nvk = 0, kpar = 0;
     if (k < S.capM) {
-      vok = ring_off(S, k); nvk = ring_n(S, k);
-      ckx = S.cx[k]; cky = S.cy[k]; rk = S.rmax[k];
-      kx0 = S.bbx0[k]; kx1 = S.bbx1[k]; ky0 = S.bby0[k]; ky1 = S.bby1[k];
-      idk = S.id[k]; okk = S.okey[k];
-      kpar = S.parent[k]; kplain = kpar == k && S.ngh[k] == 0; kgid = S.ghost_id[k];
+      if constexpr (REC) {
+        const double2* rr = S.crec + (size_t)k * 8;
+        const double2 q0 = rr[0], q1 = rr[1], q2 = rr[2], q3 = rr[3], q4 = rr[4];
+        const long long okf = __double_as_longlong(q2.x), vp = __double_as_longlong(q2.y);
+        ckx = q0.x; cky = q0.y; rk = q1.x; idk = __double_as_longlong(q1.y);
+        okk = okf & CREC_KEYMASK; nvk = (int)(okf >> 48) & 255; vok = (int)(unsigned)vp;
+        kpar = (int)(vp >> 32) & 0x0fffffff; kplain = kpar == k && (vp >> 60) == 0;
+        if (gl == 0) { kbox[gi][0] = q3.x; kbox[gi][1] = q3.y; kbox[gi][2] = q4.x; kbox[gi][3] = q4.y; }      // (before the barriers below; rewritten only after the loop's last one)
+      } else {
+        vok = ring_off(S, k); nvk = ring_n(S, k);
+        ckx = S.cx[k]; cky = S.cy[k]; rk = S.rmax[k];
+        kx0 = S.bbx0[k]; kx1 = S.bbx1[k]; ky0 = S.bby0[k]; ky1 = S.bby1[k];
+        idk = S.id[k]; okk = S.okey[k];
+        kpar = S.parent[k]; kplain = kpar == k && S.ngh[k] == 0; kgid = S.ghost_id[k];
+      }
     }
     loads_issued();
     if (stop_test(S, stop) || kb >= M) break;
@@ -1214,12 +1259,23 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
           if (!(fdx * fdx + fdy * fdy < frr * frr)) continue;
         }
         // everything the tests below may need about o is requested at once
-        const double ocx = S.cx[o], ocy = S.cy[o], orm = S.rmax[o];
-        const double ox0 = S.bbx0[o], ox1 = S.bbx1[o], oy0 = S.bby0[o], oy1 = S.bby1[o];
-        const long long oid = S.id[o], ko = S.okey[o];
-        const int opar = S.parent[o];
-        const bool oplain = opar == o && S.ngh[o] == 0;     // a parent without ghosts
-        const int voo = ring_off(S, o), nvo = ring_n(S, o);
+        double ocx, ocy, orm, ox0, ox1, oy0, oy1; long long oid, ko; int opar, voo, nvo; bool oplain;
+        if constexpr (REC) {
+          const double2* ro = S.crec + (size_t)o * 8;
+          const double2 q0 = ro[0], q1 = ro[1], q2 = ro[2], q3 = ro[3], q4 = ro[4];
+          const long long okf = __double_as_longlong(q2.x), vp = __double_as_longlong(q2.y);
+          ocx = q0.x; ocy = q0.y; orm = q1.x; oid = __double_as_longlong(q1.y);
+          ko = okf & CREC_KEYMASK; nvo = (int)(okf >> 48) & 255; voo = (int)(unsigned)vp;
+          opar = (int)(vp >> 32) & 0x0fffffff; oplain = opar == o && (vp >> 60) == 0;
+          ox0 = q3.x; ox1 = q3.y; oy0 = q4.x; oy1 = q4.y;
+        } else {
+          ocx = S.cx[o]; ocy = S.cy[o]; orm = S.rmax[o];
+          ox0 = S.bbx0[o]; ox1 = S.bbx1[o]; oy0 = S.bby0[o]; oy1 = S.bby1[o];
+          oid = S.id[o]; ko = S.okey[o];
+          opar = S.parent[o];
+          oplain = opar == o && S.ngh[o] == 0;     // a parent without ghosts
+          voo = ring_off(S, o); nvo = ring_n(S, o);
+        }
         // potential_interaction (collisions.jl:705-710), symmetric in its arguments
         double ddx = ckx - ocx, ddy = cky - ocy, rr = rk + orm;
         if (!((ddx * ddx + ddy * ddy) < rr * rr)) continue;
@@ -1230,7 +1286,8 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
           bool ok;
           if (FAM && S.famrec) {           // (inline ghosts leave a record per family: a floe that is a ghost, or has ghosts, has one at its parent)
             const int kp = kpar, op = opar;
-            const long long gk = kgid, go = S.ghost_id[o];
+            // (on records the floe's own ghost number is asked for here, in the rare branch that needs it, instead of being held through the loop)
+            const long long gk = REC ? __double_as_longlong(S.crec[(size_t)k * 8 + 7].y) : kgid, go = REC ? __double_as_longlong(S.crec[(size_t)o * 8 + 7].y) : S.ghost_id[o];
             ok = after ? pair_allowed_fam(S, kp, op, !kplain, !oplain, okk, gk, ckx, cky, rk, ko, go, ocx, ocy, orm)
                        : pair_allowed_fam(S, op, kp, !oplain, !kplain, ko, go, ocx, ocy, orm, okk, gk, ckx, cky, rk);
           } else ok = pair_allowed(S, after ? k : o, after ? o : k);
@@ -1241,7 +1298,10 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
         // AABB cull of the pairs this floe owns: rings whose boxes are disjoint cannot overlap, the item would
         // end at the first test of the clip (sz_geom.hpp clip()) with no row and no flag -- it is not run at all
         int boxes = 1;
-        if (after) boxes = !(kx1 < ox0 || ox1 < kx0 || ky1 < oy0 || oy1 < ky0);
+        if (after) {
+          if constexpr (REC) boxes = !(kbox[gi][1] < ox0 || ox1 < kbox[gi][0] || kbox[gi][3] < oy0 || oy1 < kbox[gi][2]);
+          else boxes = !(kx1 < ox0 || ox1 < kx0 || ky1 < oy0 || oy1 < ky0);
+        }
         if (slot < NBC) { cand[gi][w][slot] = o | (boxes << 30); ckey[gi][w][slot] = ko; if (after) { cvo[gi][slot] = voo; cnv[gi][slot] = nvo; } } else ovf = true;
       }
     };
@@ -1404,8 +1464,12 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
 // NBC = 256 (a floe with more than 64 neighbours in one direction: a large floe among many small ones): a quarter of the lane groups per
 // workgroup (48 KB of LDS for four floes) -- the capacity that keeps such a field running, not a fast path
 template <int NBC> constexpr int nb_tpb() { return NBC > 64 ? 64 : NB_TPB; }
-template <bool FAM, int NBC = MAXNB>
-__global__ void __launch_bounds__(nb_tpb<NBC>(), (NBC > 64 ? 1 : NBC > MAXNB ? (FAM ? 3 : 4) : 1)) sz_k_neighbors(State S) { neighbors_body<nb_tpb<NBC>(), FAM, NBC>(S, blockIdx.x, gridDim.x); }
+#ifndef SZ_NB_LEAN_WPE
+#define SZ_NB_LEAN_WPE 1      // (measured: the lean instantiation on records compiled for five wavefronts per SIMD -- 96 registers, 32 B of scratch -- is slower,
+                              //  79.2 -> 84.8 us at 100 k floes, even at 40 k: profiles/r03_runs/r3_h_*)
+#endif
+template <bool FAM, int NBC = MAXNB, bool REC = false>
+__global__ void __launch_bounds__(nb_tpb<NBC>(), (NBC > 64 ? 1 : NBC > MAXNB ? (FAM ? 3 : 4) : (REC && !FAM ? SZ_NB_LEAN_WPE : 1))) sz_k_neighbors(State S) { neighbors_body<nb_tpb<NBC>(), FAM, NBC, REC>(S, blockIdx.x, gridDim.x); }
 
 // The compact pair list in the reference's serial order (i asc, j asc) -- out_off, pair_i, pair_j -- is only made when
 // the host asks for it (sz_download_pairs): fill after a scan of n_out.
@@ -1484,9 +1548,9 @@ __global__ void __launch_bounds__(SCAN_B) sz_k_elem_scan_fill(State S, unsigned 
 // The element items ride in the tail of the neighbour search's launch (fields between walls: nothing in that launch changes the floe
 // count the scan reads -- with periodic walls its first workgroup commits the step's ghosts): the scan's workgroups only wait for
 // one another, they are handed out in index order behind the search's, and its own launch (7 us + a launch boundary) is gone.
-template <bool FAM>
+template <bool FAM, bool REC = false>
 __global__ void __launch_bounds__(NB_TPB) sz_k_neighbors_elem(State S, unsigned epoch, int nbn) {
-  if ((int)blockIdx.x < nbn) neighbors_body<NB_TPB, FAM, MAXNB>(S, blockIdx.x, nbn);
+  if ((int)blockIdx.x < nbn) neighbors_body<NB_TPB, FAM, MAXNB, REC>(S, blockIdx.x, nbn);
   else elem_scan_fill_body(S, epoch, (int)blockIdx.x - nbn);
 }
 
@@ -1618,27 +1682,53 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       constexpr int NIT = (CAP + G - 1) / G, NKI = (14 + G - 1) / G;
       double rax[NIT], ray[NIT], rbx[NIT], rby[NIT], kv[NKI];
       const int ekind = is_pair ? 0 : S.ekind[e];
+      // The item's scalars, ring signs and ring boxes reach the lanes through LDS: every lane asks for a few values, stores them into the
+      // item's memory (kin, box, roa / rob) and all lanes read what they need after the group barrier -- four doubles per lane are held
+      // across the wait instead of two boxes and two signs in every lane.
+      //  * a pair item on collision records (State::crec): two 16-byte loads per lane from the two floes' record lines instead of
+      //    loads from 22 scattered column lines -- lanes 0..3 take quads {0, 5, 6, 7} of floe i and then the box quads of i and j,
+      //    lanes 4..7 the same quads of floe j and then the two sign quads;
+      //  * otherwise the columns: scalar q = lane (+ G), box value = lane (< 8), sign = lane (< 2).
+      const bool urec = G == 8 && S.crec != nullptr && is_pair;
+      double bv0 = 0.0, bv1 = 0.0; int osv = 1;
+      // (which column / quad a lane asks for depends on the lane alone: the compiler would compute those pointers once, before the loop over
+      //  the items, hold them in registers through the whole kernel and -- at this kernel's budget -- spill them; the lane number is
+      //  therefore made opaque here, a handful of selects per item instead of scratch reloads)
+      int glv = gl; asm volatile("" : "+v"(glv));
 #pragma unroll
-      for (int r = 0; r < NKI; r++) {             // the item's scalars, one lane each
-        const int q = gl + r * G;
-        const int c = q < 10 ? q % 5 : 5 + (q & 1);                  // cx cy u v xi | area height
-        const bool side_j = q < 10 ? q >= 5 : q >= 12;
-        const double* col = c == 0 ? S.cx : c == 1 ? S.cy : c == 2 ? S.u : c == 3 ? S.v : c == 4 ? S.xi : c == 5 ? S.area : S.height;
-        double val = 0.0;
-        if (q < 14) {
-          if (!side_j) val = col[i];
-          else if (is_pair) val = col[j];
-          else val = (ekind == 3 && c == 2) ? S.eu[e] : (ekind == 3 && c == 3) ? S.ev[e] : 0.0;   // a wall / topography: rigid (u, v)
+      for (int r = 0; r < NKI; r++) kv[r] = 0.0;
+      if (urec) {
+        const double2* ri = S.crec + (size_t)i * 8; const double2* rj = S.crec + (size_t)j * 8;
+        const int qsel = (glv & 3) == 0 ? 0 : 4 + (glv & 3);
+        const double2 qa = (glv < 4 ? ri : rj)[qsel];
+        const double2 qb = glv < 2 ? ri[3 + glv] : glv < 4 ? rj[1 + glv] : glv == 4 ? ri[2] : rj[2];
+        kv[0] = qa.x; kv[NKI - 1] = qa.y; bv0 = qb.x; bv1 = qb.y;
+      } else {
+#pragma unroll
+        for (int r = 0; r < NKI; r++) {             // the item's scalars, one lane each
+          const int q = glv + r * G;
+          const int c = q < 10 ? q % 5 : 5 + (q & 1);                  // cx cy u v xi | area height
+          const bool side_j = q < 10 ? q >= 5 : q >= 12;
+          const double* col = c == 0 ? S.cx : c == 1 ? S.cy : c == 2 ? S.u : c == 3 ? S.v : c == 4 ? S.xi : c == 5 ? S.area : S.height;
+          double val = 0.0;
+          if (q < 14) {
+            if (!side_j) val = col[i];
+            else if (is_pair) val = col[j];
+            else val = (ekind == 3 && c == 2) ? S.eu[e] : (ekind == 3 && c == 3) ? S.ev[e] : 0.0;   // a wall / topography: rigid (u, v)
+          }
+          kv[r] = val;
         }
-        kv[r] = val;
+        if (glv < 8) {
+          const int w = glv & 3;
+          const double* bc = w == 0 ? S.bbx0 : w == 1 ? S.bbx1 : w == 2 ? S.bby0 : S.bby1;
+          bv0 = glv < 4 ? bc[i] : is_pair ? bc[j] : S.ebb[4 * e + w];
+        }
+        if (glv < 2) osv = glv == 0 ? S.osign[i] : is_pair ? S.osign[j] : S.eosign[e];
       }
-      const int oa = S.osign[i], ob = is_pair ? S.osign[j] : S.eosign[e];
       if (!is_pair) {
         ic.mode = ekind == 0 ? ITEM_OPEN : ITEM_SOLID; ic.max_overlap = fd_max_overlap;
         ic.elem_dir = e < 4 ? e : -1; ic.elem_val = S.eval[e]; ic.rigid_j = 1;
       }
-      const Box ba{ S.bbx0[i], S.bbx1[i], S.bby0[i], S.bby1[i] };
-      const Box bb = is_pair ? Box{ S.bbx0[j], S.bbx1[j], S.bby0[j], S.bby1[j] } : Box{ S.ebb[4 * e], S.ebb[4 * e + 1], S.ebb[4 * e + 2], S.ebb[4 * e + 3] };
       if (S.body_rings) {
         // mixed precision: rings live once, in the body frame, as fp32; the world coordinates the predicates work on are
         // rebuilt here in fp64 from the fp64 pose -- the same expression the integrator's box and sz_k_world_rings use
@@ -1669,9 +1759,25 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
         if (q < na) { m.ax[q] = rax[r]; m.ay[q] = ray[r]; }
         if (q < nb) { m.bx[q] = rbx[r]; m.by[q] = rby[r]; }
       }
+      if (urec) {
+        // kin: i: cx cy u v xi area h, j: the same -- the quads as they come;  box: a x0 x1 y0 y1, b x0 x1 y0 y1
+        const int w = gl & 3, at = (gl < 4 ? 0 : 7) + 2 * w;
+        m.kin[at] = kv[0];
+        if (w != 3) m.kin[at + 1] = kv[NKI - 1];
+        if (gl < 4) { m.box[2 * gl] = bv0; m.box[2 * gl + 1] = bv1; }
+        else if (gl < 6) (&m.roa)[gl - 4] = (__double_as_longlong(bv0) >> 56) & 1 ? -1 : 1;
+      } else {
 #pragma unroll
-      for (int r = 0; r < NKI; r++) { const int q = gl + r * G; if (q < 14) m.kin[q] = kv[r]; }
+        for (int r = 0; r < NKI; r++) {
+          const int q = gl + r * G;
+          if (q < 14) m.kin[q < 10 ? (q >= 5 ? 7 : 0) + q % 5 : (q >= 12 ? 7 : 0) + 5 + (q & 1)] = kv[r];
+        }
+        if (gl < 8) m.box[gl] = bv0;
+        if (gl < 2) (&m.roa)[gl] = (int8_t)osv;
+      }
       gsync();
+      const int oa = m.roa, ob = m.rob;
+      const Box ba{ m.box[0], m.box[1], m.box[2], m.box[3] }, bb{ m.box[4], m.box[5], m.box[6], m.box[7] };
       STAMP(st, 0);
 #ifdef SZ_STAMPS
       { long long now = clock64(); st.cA1 += now - st.tmark; }
@@ -2381,9 +2487,9 @@ __global__ void __launch_bounds__(256, 6) sz_k_forcing_mixed(State S, Params P) 
 // the state the previous step left) and both are latency-bound per-floe kernels of ~20 us that leave most of the
 // chip idle; a second stream would cost ~10 us of fork/join.  One launch: workgroups [0, nb_neigh) search neighbours,
 // the rest evaluate the forcings (FRC 1: fp64, 2: mixed precision).  Measured at 10 k floes: 0.180 -> 0.168 ms/step.
-template <int FRC>
+template <int FRC, bool REC = false>
 __global__ void __launch_bounds__(256) sz_k_neighbors_forcing(State S, Params P, int nb_neigh) {
-  if ((int)blockIdx.x < nb_neigh) neighbors_body<256, false>(S, blockIdx.x, nb_neigh);      // (fields of 30 k floes and more: the lean instantiation)
+  if ((int)blockIdx.x < nb_neigh) neighbors_body<256, false, MAXNB, REC>(S, blockIdx.x, nb_neigh);      // (fields of 30 k floes and more: the lean instantiation)
   else if (FRC == 1) forcing_body<false>(S, P, (int)blockIdx.x - nb_neigh, (int)gridDim.x - nb_neigh, 0, nb_neigh);
   else forcing_mixed_body(S, P, (int)blockIdx.x - nb_neigh, (int)gridDim.x - nb_neigh, nb_neigh);
 }
@@ -2582,6 +2688,11 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
       *(double4*)(S.strain + (size_t)i * 4) = make_double4(e11 / d, e12 / d, e12 / d, e22 / d);
       S.cx[i] = ncx; S.cy[i] = ncy;
       if (S.rec32) rec32_store(S, i, ncx, ncy, rmx, bx0, bx1, by0, by1);
+      if (S.crec) {            // what has changed of the floe's collision record (rmax, id, order key, ring size and sign stay)
+        double2* r = S.crec + (size_t)i * 8;
+        r[0] = make_double2(ncx, ncy); r[2].y = crec_vp(o, i, 0); r[3] = make_double2(bx0, bx1); r[4] = make_double2(by0, by1);
+        r[5] = make_double2(nu, nv); r[6] = make_double2(nxi, area); r[7].x = h;
+      }
       ISTAMP(4);
       if (gl_any) {
         const int gf = ghost_flag_of(wall, S.any_periodic_ew, S.any_periodic_ns, ncx, ncy, rmx, bx0, bx1, by0, by1, (frc_rm ? SZ_REMOVE : st0) == SZ_ACTIVE);
@@ -2955,6 +3066,7 @@ __global__ void __launch_bounds__(UNPACK_TPB) sz_k_halo_unpack_inline(State S, c
   S.osign[g] = R.os;
   S.bbx0[g] = x0; S.bbx1[g] = x1; S.bby0[g] = y0; S.bby1[g] = y1;
   if (S.rec32) rec32_store(S, g, R.cx, R.cy, R.rmax, x0, x1, y0, y1);
+  if (S.crec) crec_store_all(S, g, R.cx, R.cy, R.rmax, R.id, R.oki, nv, R.os, vb, g, 0, x0, x1, y0, y1, R.u, R.v, R.xi, R.area, R.h, 0ll);
   S.gkeys[(size_t)slot * S.capM + og] = R.oki;
   if (gf != 5) {
     const unsigned long long given = ((unsigned long long)(og + 1) << 32) | (unsigned)(ov + nv);

@@ -107,6 +107,15 @@ struct State {
   // fp32 broad-phase record per floe {cx, cy, rmax, -} {box x0, x1, y0, y1}: the neighbour search of mixed mode tests candidates
   // on it with a conservative margin and confirms the survivors with the exact fp64 predicate (the pair list stays bit-exact)
   float4* rec32;
+  // ---- collision record (round 3): what the neighbour search needs of a CANDIDATE and the narrow phase's staging of an item's two floes,
+  // in ONE 128-byte line per row instead of ~13 scattered 8-byte columns (the texture path works off one line per lane and load
+  // instruction: the candidate loads were half of the neighbour search's time).  Eight 16-byte quads:
+  //   0 {cx, cy}  1 {rmax, id}  2 {order key | ring points << 48 | (ring orientation < 0) << 56,  ring offset | parent << 32 | ghosts << 60}
+  //   3 {box x0, x1}  4 {box y0, y1}  5 {u, v}  6 {xi, area}  7 {height, ghost_id}
+  // A CACHE of the columns, not their replacement: non-null only in the launches of resident batches whose kernels keep it current
+  // (a seeding launch at the start of the batch, then whoever places a floe: the one-launch integrator, the inline ghost maker, the
+  // inline halo unpack); everything else reads and writes the columns as before.
+  double2* crec;
   // ---- two-way coupling (allocated by sz_set_two_way): per floe the centre cells its sub-floe points fall into
   // (FC_CAP slots per floe: cell id, shift code, sum of -tau_ocn, points), per cell the entries sorted by floe
   int *fc_key, *fc_n, *fc_cnt; signed char* fc_code; double *fc_tx, *fc_ty, *fc_area;

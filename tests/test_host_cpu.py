@@ -184,11 +184,12 @@ def test_hot_kernels_keep_their_register_budgets():
     spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
     kr = importlib.util.module_from_spec(spec); spec.loader.exec_module(kr)
     res = kr.resources()
-    budget = {"sz_k_neighbors<true, 24>": (168, 0), "sz_k_neighbors<false, 24>": (128, 0), "sz_k_neighbors<true, 64>": (256, 0),      # (35 KB of LDS per two wavefronts: two per SIMD whatever the registers)
-              
-              # (the narrow phase parks three loop-invariant words -- the prefetched first work item -- in scratch once per launch since the certified
-              #  direction check joined the kernel: 12 bytes, stored before the first round and read back once per round)
-              "sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 0>": (168, 16), "sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 1>": (168, 16),
+    budget = {"sz_k_neighbors<true, 24, false>": (168, 0), "sz_k_neighbors<false, 24, false>": (128, 0), "sz_k_neighbors<true, 64, false>": (256, 0),      # (35 KB of LDS per two wavefronts: two per SIMD whatever the registers)
+              # (the instantiations on collision records, State::crec -- what the resident steps run)
+              "sz_k_neighbors<true, 24, true>": (168, 0), "sz_k_neighbors<false, 24, true>": (128, 0),
+              # (the narrow phase parks the prefetched first work item -- four loop-invariant words -- in scratch once per launch: 16 bytes + one
+              #  word, stored before the first round and read back by the round that uses it)
+              "sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 0>": (168, 20), "sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 1>": (168, 20),
               "sz_k_inter_fill": (128, 0), "sz_k_forcing<false>": (128, 0), "sz_k_forcing_mixed": (80, 16), "sz_k_halo_pack": (128, 0)}
     for name, (vg, scratch) in budget.items():
         assert name in res, (name, sorted(k for k in res if k.startswith(name.split("<")[0])))
