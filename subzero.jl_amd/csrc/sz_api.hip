@@ -104,6 +104,8 @@ struct sz_ctx {
   bool no_elems_ride = false;       // SZ_ELEMS_RIDE=0: the element items always get their own launch
   bool no_lean_narrow = false;      // SZ_LEAN_NARROW=0: always enqueue it
   bool no_crec = false;             // SZ_CREC=0: no collision records (State::crec) in the resident steps
+  double* frc_alt[4] = { nullptr, nullptr, nullptr, nullptr };      // second set of the forcing outputs fxOA, fyOA, trqOA, hflx (tiled steps with peers, see sz_tile_run)
+  bool tile_forcing_in_tail = false;      // SZ_TILE_FORCING_TAIL=1: tiled steps with peers keep the forcings in the narrow launch's tail (A/B switch)
   double2* crec_buf = nullptr;      // the records' memory (State::crec points at it only inside the batches that keep it current)
   int forcing_where = -1;           // sz_forcing_launch
   int fuse_forcing_mode = 0;        // ... 1: in the neighbour launch, 2: in the narrow launch (its tail), 0: by size -- the narrow launch while the narrow phase is one
@@ -800,6 +802,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_TW_GENERAL_CLIP")) c->tw_general_clip = atoi(e) != 0;
   if (const char* e = getenv("SZ_LEAN_NARROW")) c->no_lean_narrow = atoi(e) == 0;
   if (const char* e = getenv("SZ_CREC")) c->no_crec = atoi(e) == 0;
+  if (const char* e = getenv("SZ_TILE_FORCING_TAIL")) c->tile_forcing_in_tail = atoi(e) != 0;
   if (const char* e = getenv("SZ_GHOST_INLINE")) c->ghost_inline = atoi(e) != 0;
   if (const char* e = getenv("SZ_TILE_INLINE")) c->tile_inline_off = atoi(e) == 0;
   if (const char* e = getenv("SZ_ELEMS_RIDE")) c->no_elems_ride = atoi(e) == 0;
@@ -1036,6 +1039,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(lb_agg, S.capM / 128 + 8); DA(lb_inc, S.capM / 128 + 8); DA(lb_flag, S.capM / 128 + 8); c->scan_epoch = 0;      // (tiles of 128 .. SCAN_B elements)
   DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2); DA(gcand, (size_t)2 * S.capM); DA(galloc, 32); DA(gkeys, (size_t)2 * S.capM); DA(fam, S.capM);
   DA(crec, (size_t)8 * S.capM); c->crec_buf = S.crec; S.crec = nullptr;
+  for (int k = 0; k < 4; k++) if ((rc = dalloc(c, &c->frc_alt[k], (size_t)S.capM, c->allocs))) return rc;
   DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1); DA(cell_ovf, S.capCells + 1); DA(cell_slots, (size_t)S.capCells * CELL_K + 8);
   DA(cell_items, S.capM);
   DA(n_out, S.capM + 1); DA(n_in, S.capM + 1); DA(over_stamp, S.capM + 1); DA(over_base, S.capM + 1);
@@ -2578,6 +2582,9 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     fflush(stderr);
   };
   stage_done(-1, "seed");
+  std::vector<signed char> fset((size_t)std::max(nsteps, 1), (signed char)-1);      // the output set the forcings of step s wrote (-1: none of this kind)
+  int cur_set = 0;
+  auto swap_frc = [&]() { std::swap(S.fxOA, c->frc_alt[0]); std::swap(S.fyOA, c->frc_alt[1]); std::swap(S.trqOA, c->frc_alt[2]); std::swap(S.hflx, c->frc_alt[3]); cur_set ^= 1; };
   for (int s = 0; s < nsteps; s++) {
     const int tstep = tstep0 + s;
     S.step = s + 1; S.gslot = s & 1;
@@ -2588,7 +2595,18 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     stage_done(s, "rebox");
     tile_pack(c);
     stage_done(s, "pack");
+    // With peers the forcings of the owned floes (they need nothing from the halo) run BESIDE the exchange -- on the main stream while the
+    // communication stream trades the regions, before the host's channel blocks -- and the narrow launch carries no forcing tail; without
+    // peers there is nothing to hide them behind and they ride in the narrow launch's tail as in sz_step.
+    const bool beside = coupling && n > 1 && !(c->pmask >> SZ_K_FORCING & 1u) && !c->tile_forcing_in_tail;
+    // (these forcings run before this rank knows whether a peer has asked for the batch to end at the previous step -- the unpack kernel
+    //  below finds out.  They therefore write a SECOND set of the four output columns, alternating step by step, and the set the last
+    //  step that really ran has written is made the context's at the end of the call: a batch that ends early leaves fxOA .. hflx of the
+    //  step it ended with, as sz_step does.)
+    if (beside) { swap_frc(); fset[s] = (signed char)cur_set; }
+    if (beside && c->host_transport) stage_forcing(c, dt);
     { int rc = tile_exchange(c, true); if (rc) return fail(rc); }
+    if (beside && !c->host_transport) stage_forcing(c, dt);
     if (n > 1) {
       HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_recv, 0));
       const long long slots = (long long)n * c->halo_cap;
@@ -2597,10 +2615,10 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     }
     stage_done(s, "exchange + unpack");
     // the forcings: where sz_step puts them (the tail of the narrow launch for tiles of up to 30 k owned floes, the neighbour launch up to 65 k)
-    const bool fuse = coupling && !(c->pmask >> SZ_K_FORCING & 1u) && c->fuse_forcing && c->hostN <= 65536;
+    const bool fuse = coupling && !beside && !(c->pmask >> SZ_K_FORCING & 1u) && c->fuse_forcing && c->hostN <= 65536;
     int fmode = !fuse ? 0 : c->fuse_forcing_mode ? c->fuse_forcing_mode : (c->hostN <= 30000 ? 2 : 1);
     if (fmode == 1 && S.maxnb > MAXNB) fmode = 2;
-    if (coupling && !fuse) stage_forcing(c, dt);
+    if (coupling && !fuse && !beside) stage_forcing(c, dt);
     if (coupling) c->forcing_where = fmode;
     S.callid = ++c->callid;
     if (dbgsync) {          // (the stages of collisions_step one by one)
@@ -2625,6 +2643,11 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   }
   const int done = h[C_STOP] > 0 ? std::min(h[C_STOP], (int)nsteps) : nsteps;
   if (steps_done) *steps_done = done;
+  {          // the forcing outputs of the last step that ran (see `beside` above)
+    int want = 0;                                                        // (set 0: the columns as they were at entry)
+    for (int s2 = 0; s2 < done; s2++) if (fset[s2] >= 0) want = fset[s2];
+    if (want != cur_set) swap_frc();
+  }
   if (done < nsteps) c->grid_live = false;          // stopped early: cells hold floes of a step that did not come
   c->inter_any = true; c->inter_lost = false;
   // status.fuse_idx of the step that ended the batch (as sz_step: only that step can have produced fuse pairs)

@@ -2552,6 +2552,12 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
     const bool gl_any = gl_fill >= 0 || ginl >= 0;
     const int st0 = gl_any ? S.status[i] : SZ_ACTIVE, ngh0 = gl_any ? S.ngh[i] : 0;
     const double rmx = MOVE && (gl_any || S.rec32) ? S.rmax[i] : 0.0;
+    // what a ghost copies of its parent beyond the update's own operands (inline ghosts): asked for HERE, with the first batch -- inside the
+    // ghost branch these four loads were a dependent round trip behind the thread's ~60 stores (6.7 k cycles of the 21 k the ghost cost)
+    const bool ghost_ops = MOVE && ginl >= 0;
+    const long long g_id = ghost_ops ? S.id[i] : 0, g_oki = ghost_ops ? S.okey[i] : 0;
+    const double g_over = ghost_ops ? S.overarea[i] : 0.0;
+    const signed char g_os = ghost_ops ? S.osign[i] : (signed char)1;
     // Memory order is the whole cost of this kernel (a store in between keeps the compiler from hoisting the
     // loads behind it, and every batch of loads is one HBM round trip): everything is read first -- the
     // columns, then what their values address (contact rows, ring) -- then computed, then stored.
@@ -2701,7 +2707,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
             GhostRow R;
             R.cx = ncx; R.cy = ncy; R.b0 = bx0; R.b1 = bx1; R.b2 = by0; R.b3 = by1;
             R.rmax = rmx; R.area = area; R.h = h; R.mass = mass; R.mom = moment; R.al = al; R.u = nu; R.v = nv; R.xi = nxi;
-            R.over = S.overarea[i]; R.id = S.id[i]; R.oki = S.okey[i]; R.os = S.osign[i]; R.st = SZ_ACTIVE; R.tc = cal; R.ts = sal;
+            R.over = g_over; R.id = g_id; R.oki = g_oki; R.os = g_os; R.st = SZ_ACTIVE; R.tc = cal; R.ts = sal;
 #pragma unroll
             for (int k = 0; k < MV_RING; k++) {        // the moved ring again (the expressions of the stores above: the same bits)
               const double x = body ? 0.0 : px[k] + (-cx), y = body ? 0.0 : py[k] + (-cy);

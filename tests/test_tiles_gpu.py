@@ -279,7 +279,7 @@ def test_rccl_binding_self_test():
 
 
 # ---------------------------------------------------------------- batches of a tiled run end where the reference runs simplify_floes!
-def _tag_cfg(kind):
+def _tag_cfg(kind, coupled=False):
     """the scenarios of test_hip_parity.py::test_resident_batch_stops_when_a_floe_is_tagged, laid across the edge between two tiles
     (x = 5e4): `fuse` -- two floes owned by DIFFERENT ranks close in until their overlap passes floe_floe_max_overlap; `open` -- a
     floe of rank 1 drifts into an open boundary while rank 0 knows nothing of it"""
@@ -298,24 +298,36 @@ def _tag_cfg(kind):
     vx = np.concatenate([r[:, 0] for r in rings]); vy = np.concatenate([r[:, 1] for r in rings])
     h = np.full(n, 0.5)
     z = np.zeros((11, 11))
-    return dict(n_floes=n, L=1e5, kinds=kinds, vert_off=off, vx=vx, vy=vy, height=h, u=np.array(u), v=np.zeros(n), xi=np.zeros(n), dt=10,
-                Nx=10, Ny=10, uo=z, vo=z, hf=z, ua=z, va=z, topography=[], E=1e3, derived=floe_mod.derive(off, vx, vy, h),
-                sub_off=np.zeros(n + 1, np.int32), sx=np.zeros(0), sy=np.zeros(0), seed=0)
+    cfg = dict(n_floes=n, L=1e5, kinds=kinds, vert_off=off, vx=vx, vy=vy, height=h, u=np.array(u), v=np.zeros(n), xi=np.zeros(n), dt=10,
+               Nx=10, Ny=10, uo=z, vo=z, hf=z, ua=z, va=z, topography=[], E=1e3, derived=floe_mod.derive(off, vx, vy, h),
+               sub_off=np.zeros(n + 1, np.int32), sx=np.zeros(0), sy=np.zeros(0), seed=0)
+    if coupled:
+        # one-way coupling every step: sub-floe points and a weak ocean that varies in space, so that fxOA .. hflx change from step to step
+        # (too weak to move the tag to another step: 1e-3 m/s against closing speeds of 3 - 20 m/s)
+        from subzero_jl_amd import fields
+        xs = np.linspace(0.0, 1e5, 11)
+        cfg["uo"] = 1e-3 * np.sin(2 * np.pi * xs / 1e5)[:, None] * np.ones((1, 11)); cfg["vo"] = 1e-3 * np.ones((11, 1)) * np.cos(2 * np.pi * xs / 1e5)[None, :]
+        d = cfg["derived"]; so = np.zeros(n + 1, np.int32); sxs = []; sys_ = []
+        for i in range(n):
+            sx, sy = fields.subgrid_points(rings[i], d["cx"][i], d["cy"][i], 2.5e3)
+            so[i + 1] = so[i] + len(sx); sxs.append(sx); sys_.append(sy)
+        cfg["sub_off"] = so; cfg["sx"] = np.concatenate(sxs); cfg["sy"] = np.concatenate(sys_)
+    return cfg
 
 
-def _worker_tags(rank, world, port, kind, q):
+def _worker_tags(rank, world, port, kind, q, coupled=False):
     import torch.distributed as dist
     from subzero_jl_amd import tiles
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
-        cfg = _tag_cfg(kind)
+        cfg = _tag_cfg(kind, coupled)
         tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True, backend="library-host", rebox_every=3, drift_margin=3000.0)
-        done = tw.run(12, 0, 10, coupling_dt=10, coupling_on=False, stop_on_tags=True)
+        done = tw.run(12, 0, 10, coupling_dt=1 if coupled else 10, coupling_on=coupled, stop_on_tags=True)
         out = {f: tw.owned(f) for f in FIELDS}
         st = tw.world.ids()[2][:len(tw.gidx)]
         fuse = [list(map(int, f)) for f in tw.world.fuse()][:len(tw.gidx)]
-        again = tw.run(5, done, 10, coupling_dt=10, coupling_on=False, stop_on_tags=True)       # tagged at entry: one step
+        again = tw.run(5, done, 10, coupling_dt=1 if coupled else 10, coupling_on=coupled, stop_on_tags=True)       # tagged at entry: one step
         q.put((rank, tw.gidx, out, done, st, fuse, again))
     finally:
         dist.destroy_process_group()
@@ -325,18 +337,20 @@ def _run_worker_tags(*a):
     _guard(_worker_tags)(*a)
 
 
-@pytest.mark.parametrize("kind", ["fuse", "open"])
-def test_tiled_batch_ends_on_every_rank_where_a_floe_is_tagged(kind):
+@pytest.mark.parametrize("kind,coupled", [("fuse", False), ("open", False), ("fuse", True), ("open", True)])
+def test_tiled_batch_ends_on_every_rank_where_a_floe_is_tagged(kind, coupled):
     """The reference runs simplify_floes! after EVERY step (simulation.jl:205-214).  A tiled batch ends after the step in which ANY
     rank tags a floe -- the stop request rides in the header records of the next exchange to every rank, whose unpack kernel ends the
     batch before that step has touched anything -- so both ranks report the same number of steps, and their state, status tags and
-    status.fuse_idx (in global floe numbers) are the single context's after that step."""
+    status.fuse_idx (in global floe numbers) are the single context's after that step.  `coupled`: one-way coupling every step -- with peers
+    the forcings run beside the exchange, i.e. before a rank knows that the batch has ended, into a second set of output columns; the
+    ranks must come back with fxOA .. hflx of the step the batch ended with, not of the one that never ran."""
     import torch.multiprocessing as mp
     import subzero_jl_amd
     from subzero_jl_amd import fields
     ctx = mp.get_context("spawn")
     q = ctx.Queue(); port = _free_port()
-    procs = [ctx.Process(target=_run_worker_tags, args=(r, 2, port, kind, q)) for r in range(2)]
+    procs = [ctx.Process(target=_run_worker_tags, args=(r, 2, port, kind, q, coupled)) for r in range(2)]
     for p in procs:
         p.start()
     try:
@@ -348,9 +362,9 @@ def test_tiled_batch_ends_on_every_rank_where_a_floe_is_tagged(kind):
         for p in procs:
             if p.is_alive():
                 p.terminate()
-    cfg = _tag_cfg(kind)
+    cfg = _tag_cfg(kind, coupled)
     hw = fields.build_world(subzero_jl_amd.World(0), cfg)
-    k = hw.run(12, 0, 10, coupling_dt=10, coupling_on=False)
+    k = hw.run(12, 0, 10, coupling_dt=1 if coupled else 10, coupling_on=coupled)
     assert 2 <= k < 12                                     # the tag comes in the middle of the batch
     tags = hw.ids()[2]; ref_fuse = [list(map(int, f)) for f in hw.fuse()]
     assert np.any(tags[:cfg["n_floes"]] != 1)
