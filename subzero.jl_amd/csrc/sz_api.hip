@@ -1029,8 +1029,13 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
     H2D(S.parent, parent.data(), M, int); H2D(S.gh, gh.data(), (size_t)MAX_GHOSTS * M, int); H2D(S.ngh, ngh.data(), M, int);
     HIPCHK(c, hipStreamSynchronize(c->stream));   // host vectors go out of scope
   }
-  DA(voff, S.capM + 1); DA(vx, S.capV); DA(vy, S.capV);
-  H2D(S.voff, f->vert_off, M + 1, int); H2D(S.vx, f->vx, V, double); H2D(S.vy, f->vy, V, double);
+  DA(voff, S.capM + 1); DA(vxy, S.capV);
+  H2D(S.voff, f->vert_off, M + 1, int);
+  {          // the rings, interleaved {x, y} on the device (State::vxy)
+    std::vector<double> xy((size_t)2 * std::max(V, 1));
+    for (int k = 0; k < V; k++) { xy[(size_t)2 * k] = f->vx[k]; xy[(size_t)2 * k + 1] = f->vy[k]; }
+    H2D(S.vxy, xy.data(), (size_t)2 * V, double); HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   DA(soff, S.capM + 1); DA(sx, NS); DA(sy, NS);
   if (f->sub_off) { H2D(S.soff, f->sub_off, N + 1, int); H2D(S.sx, f->sx, NS, double); H2D(S.sy, f->sy, NS, double); }
   c->max_sub = 0;
@@ -1144,7 +1149,12 @@ int sz_download_floes(sz_ctx* c, sz_floe_columns* f) {
   D2H(f->coll_fx, S.cfx, M, double); D2H(f->coll_fy, S.cfy, M, double); D2H(f->coll_trq, S.ctrq, M, double);
   D2H(f->stress_accum, S.sa, 4 * M, double); D2H(f->stress_instant, S.si, 4 * M, double); D2H(f->strain, S.strain, 4 * M, double);
   D2H(f->id, S.id, M, long long); D2H(f->ghost_id, S.ghost_id, M, long long); D2H(f->status, S.status, M, int);
-  D2H(f->vert_off, S.voff, M + 1, int); D2H(f->vx, S.vx, V, double); D2H(f->vy, S.vy, V, double);
+  D2H(f->vert_off, S.voff, M + 1, int);
+  if ((f->vx || f->vy) && V > 0) {
+    std::vector<double> xy((size_t)2 * V);
+    HIPCHK(c, hipMemcpy(xy.data(), S.vxy, (size_t)2 * V * sizeof(double), hipMemcpyDeviceToHost));
+    for (int k = 0; k < V; k++) { if (f->vx) f->vx[k] = xy[(size_t)2 * k]; if (f->vy) f->vy[k] = xy[(size_t)2 * k + 1]; }
+  }
   if (f->ghost_off) {
     std::vector<int> gh((size_t)MAX_GHOSTS * M), ngh(M);
     HIPCHK(c, hipMemcpy(gh.data(), S.gh, gh.size() * sizeof(int), hipMemcpyDeviceToHost));
@@ -2321,7 +2331,11 @@ int sz_tile_migrate(sz_ctx* c, int32_t px, int32_t py, const int32_t* owner_over
   HIPCHK(c, hipMemcpy(soff.data(), S.soff, ((size_t)N + 1) * sizeof(int), hipMemcpyDeviceToHost));
   const int V = voff[N], NS = soff[N];
   std::vector<double> vx((size_t)std::max(V, 1)), vy((size_t)std::max(V, 1)), sx((size_t)std::max(NS, 1)), sy((size_t)std::max(NS, 1));
-  if (V) { HIPCHK(c, hipMemcpy(vx.data(), S.vx, (size_t)V * sizeof(double), hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(vy.data(), S.vy, (size_t)V * sizeof(double), hipMemcpyDeviceToHost)); }
+  if (V) {
+    std::vector<double> xy((size_t)2 * V);
+    HIPCHK(c, hipMemcpy(xy.data(), S.vxy, (size_t)2 * V * sizeof(double), hipMemcpyDeviceToHost));
+    for (int k = 0; k < V; k++) { vx[k] = xy[(size_t)2 * k]; vy[k] = xy[(size_t)2 * k + 1]; }
+  }
   if (NS) { HIPCHK(c, hipMemcpy(sx.data(), S.sx, (size_t)NS * sizeof(double), hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(sy.data(), S.sy, (size_t)NS * sizeof(double), hipMemcpyDeviceToHost)); }
   // ---- who owns what now: the tile that holds the centroid (periodic: of its image inside the domain), px x py tiles over the domain
   const double x0 = c->h_vals[3], y0 = c->h_vals[1], Lx = c->h_vals[2] - c->h_vals[3], Ly = c->h_vals[0] - c->h_vals[1];

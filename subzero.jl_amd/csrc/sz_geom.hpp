@@ -219,11 +219,12 @@ SZ_DEV void ring_area_centroid(const double* x, const double* y, int n, double& 
   sa = (a2 + (p1x * y[0] - p1y * x[0])) / 2.0;
 }
 // GO._signed_area on a closed ring
-SZ_DEV double ring_signed_area(const double* x, const double* y, int n) {
+// (st: stride of the coordinate arrays in doubles -- 2 for the interleaved floe rings)
+SZ_DEV double ring_signed_area(const double* x, const double* y, int n, int st = 1) {
   if (n == 0) return 0.0;
   double area = 0.0, p1x = x[0], p1y = y[0];
   for (int i = 1; i < n; i++) {
-    double p2x = x[i], p2y = y[i];
+    double p2x = x[(size_t)i * st], p2y = y[(size_t)i * st];
     area += p1x * p2y - p1y * p2x;
     p1x = p2x; p1y = p2y;
   }

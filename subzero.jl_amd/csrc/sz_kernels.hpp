@@ -183,10 +183,10 @@ __global__ void sz_k_osign(State S, int first) {
   int M = S.cnt[C_M];
   for (int i = first + blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
     int o = S.voff[i], n = S.voff[i + 1] - o;
-    double a = ring_signed_area(S.vx + o, S.vy + o, n);
+    double a = ring_signed_area((const double*)(S.vxy + o), (const double*)(S.vxy + o) + 1, n, 2);
     S.osign[i] = a >= 0.0 ? 1 : -1;
     double x0 = __builtin_inf(), x1 = -__builtin_inf(), y0 = __builtin_inf(), y1 = -__builtin_inf();
-    for (int q = 0; q < n; q++) { x0 = fmin(x0, S.vx[o + q]); x1 = fmax(x1, S.vx[o + q]); y0 = fmin(y0, S.vy[o + q]); y1 = fmax(y1, S.vy[o + q]); }
+    for (int q = 0; q < n; q++) { const double2 p = S.vxy[o + q]; x0 = fmin(x0, p.x); x1 = fmax(x1, p.x); y0 = fmin(y0, p.y); y1 = fmax(y1, p.y); }
     S.bbx0[i] = x0; S.bbx1[i] = x1; S.bby0[i] = y0; S.bby1[i] = y1;
     double al = S.alpha[i];
     S.trig[2 * i] = cos(al); S.trig[2 * i + 1] = sin(al);
@@ -439,8 +439,8 @@ template <bool WIDE>
 __device__ __forceinline__ void rig_store(State& S, int lane, int f, int vo, int n, const RigT<WIDE>& r) {
   if (lane < 6) rig_col(S, lane)[f] = r.pv;
   if (S.body_rings) return;                      // the ring is the parent's, in its body frame: only the pose moves
-  if (lane < n) { S.vx[vo + lane] = r.x0; S.vy[vo + lane] = r.y0; }
-  if constexpr (WIDE) { if (lane + 64 < n) { S.vx[vo + lane + 64] = r.x1; S.vy[vo + lane + 64] = r.y1; } }
+  if (lane < n) S.vxy[vo + lane] = make_double2(r.x0, r.y0);
+  if constexpr (WIDE) { if (lane + 64 < n) S.vxy[vo + lane + 64] = make_double2(r.x1, r.y1); }
 }
 
 // One flagged parent, by a whole wavefront: both passes of add_ghosts! for parent i.  fl: its flags (dx+1 | (dy+1)<<2),
@@ -460,8 +460,8 @@ __device__ __forceinline__ void ghost_fill_parent(State& S, const GridGeo& geo, 
   R P;
   P.pv = lane < 6 ? rig_col(S, lane)[i] : 0.0;
   const bool body = S.body_rings != 0;
-  P.x0 = !body && lane < n ? S.vx[vo + lane] : 0.0; P.y0 = !body && lane < n ? S.vy[vo + lane] : 0.0;
-  if constexpr (WIDE) { P.x1 = !body && lane + 64 < n ? S.vx[vo + lane + 64] : 0.0; P.y1 = !body && lane + 64 < n ? S.vy[vo + lane + 64] : 0.0; }
+  { const double2 p = !body && lane < n ? S.vxy[vo + lane] : make_double2(0.0, 0.0); P.x0 = p.x; P.y0 = p.y; }
+  if constexpr (WIDE) { const double2 p = !body && lane + 64 < n ? S.vxy[vo + lane + 64] : make_double2(0.0, 0.0); P.x1 = p.x; P.y1 = p.y; }
   const double tc = body ? S.trig[2 * i] : 0.0, ts = body ? S.trig[2 * i + 1] : 0.0;
   const double rmx = S.rec32 ? S.rmax[i] : 0.0;
   // the copied scalar columns (deepcopy of the parent, collisions.jl:893): lane q < 10 carries double column q
@@ -713,7 +713,7 @@ __device__ __forceinline__ void ghost_row_load(const State& S, int i, int n, int
   const bool body = S.body_rings != 0;
   r.tc = body ? S.trig[2 * i] : 0.0; r.ts = body ? S.trig[2 * i + 1] : 0.0;
 #pragma unroll
-  for (int k = 0; k < MV_RING; k++) { r.rx[k] = !body && k < n ? S.vx[vo + k] : 0.0; r.ry[k] = !body && k < n ? S.vy[vo + k] : 0.0; }
+  for (int k = 0; k < MV_RING; k++) { const double2 p = !body && k < n ? S.vxy[vo + k] : make_double2(0.0, 0.0); r.rx[k] = p.x; r.ry[k] = p.y; }
 }
 // parent i with row R, flags fl != 5, ring (vo, n <= MV_RING); N parents, ring points of the parents NV0; slot: the allocator
 // how many ghosts the flags ask for
@@ -811,7 +811,7 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
     else {
       S.voff[g] = vb; S.voff[g + 1] = vb + n;                // (the next allocation writes the same value: rings are packed back to back)
 #pragma unroll
-      for (int k = 0; k < MV_RING; k++) if (k < n) { double x = R.rx[k], y = R.ry[k]; shift_apply(c, x, y); S.vx[vb + k] = x; S.vy[vb + k] = y; }
+      for (int k = 0; k < MV_RING; k++) if (k < n) { double x = R.rx[k], y = R.ry[k]; shift_apply(c, x, y); S.vxy[vb + k] = make_double2(x, y); }
     }
     GSTAMP(17);
     if (S.rec32) rec32_store(S, g, gx, gy, c_rmax, x0, x1, y0, y1);
@@ -839,7 +839,7 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
     S.cx[i] = px; S.cy[i] = py; S.bbx0[i] = x0; S.bbx1[i] = x1; S.bby0[i] = y0; S.bby1[i] = y1;
     if (!body) {
 #pragma unroll
-      for (int k = 0; k < MV_RING; k++) if (k < n) { double x = R.rx[k], y = R.ry[k]; shift_apply(cp, x, y); S.vx[vo + k] = x; S.vy[vo + k] = y; }
+      for (int k = 0; k < MV_RING; k++) if (k < n) { double x = R.rx[k], y = R.ry[k]; shift_apply(cp, x, y); S.vxy[vo + k] = make_double2(x, y); }
     }
     if (S.rec32) rec32_store(S, i, px, py, c_rmax, x0, x1, y0, y1);
     if (S.crec) crec_store_place(S, i, px, py, x0, x1, y0, y1);
@@ -885,7 +885,8 @@ __global__ void sz_k_body_rings(State S) {
     const int o = S.voff[i], n = S.voff[i + 1] - o;
     const double cx = S.cx[i], cy = S.cy[i], ca = S.trig[2 * i], sa = S.trig[2 * i + 1];
     for (int k = 0; k < n; k++) {
-      const double dx = S.vx[o + k] - cx, dy = S.vy[o + k] - cy;
+      const double2 p = S.vxy[o + k];
+      const double dx = p.x - cx, dy = p.y - cy;
       S.ring32[o + k] = make_float2((float)(ca * dx + sa * dy), (float)(-sa * dx + ca * dy));
     }
     S.rb_off[i] = o; S.rb_n[i] = n;
@@ -899,7 +900,7 @@ __global__ void sz_k_world_rings(State S) {
     const double cx = S.cx[i], cy = S.cy[i], ca = S.trig[2 * i], sa = S.trig[2 * i + 1];
     for (int k = 0; k < n; k++) {
       const float2 b = S.ring32[o + k];
-      S.vx[o + k] = (ca * (double)b.x - sa * (double)b.y) + cx; S.vy[o + k] = (sa * (double)b.x + ca * (double)b.y) + cy;
+      S.vxy[o + k] = make_double2((ca * (double)b.x - sa * (double)b.y) + cx, (sa * (double)b.x + ca * (double)b.y) + cy);
     }
   }
 }
@@ -1678,7 +1679,6 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     if (have) {
       // Staging: every load of the item -- rings, scalars, signs, boxes -- is asked for BEFORE the first LDS store (a loop of
       // load -> store pairs waits for each load in turn: seven dependent round trips of ~2.5 k cycles instead of one).
-      const double* bxs = is_pair ? S.vx : S.ex; const double* bys = is_pair ? S.vy : S.ey;
       constexpr int NIT = (CAP + G - 1) / G, NKI = (14 + G - 1) / G;
       double rax[NIT], ray[NIT], rbx[NIT], rby[NIT], kv[NKI];
       const int ekind = is_pair ? 0 : S.ekind[e];
@@ -1743,14 +1743,16 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
           if (is_pair) {
             const float2 pb = q < nb ? S.ring32[bo + q] : make_float2(0.f, 0.f);
             rbx[r] = (caj * (double)pb.x - saj * (double)pb.y) + cxj; rby[r] = (saj * (double)pb.x + caj * (double)pb.y) + cyj;
-          } else { rbx[r] = q < nb ? bxs[bo + q] : 0.0; rby[r] = q < nb ? bys[bo + q] : 0.0; }
+          } else { rbx[r] = q < nb ? S.ex[bo + q] : 0.0; rby[r] = q < nb ? S.ey[bo + q] : 0.0; }
         }
       } else {
 #pragma unroll
         for (int r = 0; r < NIT; r++) {
           const int q = gl + r * G;
-          rax[r] = q < na ? S.vx[ao + q] : 0.0; ray[r] = q < na ? S.vy[ao + q] : 0.0;
-          rbx[r] = q < nb ? bxs[bo + q] : 0.0; rby[r] = q < nb ? bys[bo + q] : 0.0;
+          const double2 pa = q < na ? S.vxy[ao + q] : make_double2(0.0, 0.0);
+          rax[r] = pa.x; ray[r] = pa.y;
+          if (is_pair) { const double2 pb = q < nb ? S.vxy[bo + q] : make_double2(0.0, 0.0); rbx[r] = pb.x; rby[r] = pb.y; }
+          else { rbx[r] = q < nb ? S.ex[bo + q] : 0.0; rby[r] = q < nb ? S.ey[bo + q] : 0.0; }
         }
       }
 #pragma unroll
@@ -2587,7 +2589,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
         for (int k = 0; k < MV_RING; k++) { const float2 b = k < n ? S.ring32[o + k] : make_float2(0.f, 0.f); px[k] = (double)b.x; py[k] = (double)b.y; }
       } else {
 #pragma unroll
-        for (int k = 0; k < MV_RING; k++) { px[k] = k < n ? S.vx[o + k] : 0.0; py[k] = k < n ? S.vy[o + k] : 0.0; }
+        for (int k = 0; k < MV_RING; k++) { const double2 p = k < n ? S.vxy[o + k] : make_double2(0.0, 0.0); px[k] = p.x; py[k] = p.y; }
       }
     }
     // where the centroid goes depends on the old velocities alone (AB2): the counter of the cell it lands in is drawn now, and its
@@ -2683,7 +2685,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
             const double ud = u2 - u1, vd = v2 - v1;
             e11 += ud * yd; e12 += ud * xd + vd * yd; e22 += vd * xd;
           }
-          if (!body) { S.vx[o + k] = mx; S.vy[o + k] = my; }
+          if (!body) S.vxy[o + k] = make_double2(mx, my);
           bx0 = fmin(bx0, mx); bx1 = fmax(bx1, mx); by0 = fmin(by0, my); by1 = fmax(by1, my);
           ax = mx; ay = my;
         }
@@ -2756,8 +2758,9 @@ __global__ void __launch_bounds__(256) sz_k_move_strain(State S, int strain_only
     double ncx = cx + dx, ncy = cy + dy;
     double u = S.u[i], xi = S.xi[i];
     auto moved = [&](int k, double& mx, double& my) {
-      if (strain_only) { mx = S.vx[o + k]; my = S.vy[o + k]; return; }
-      double x = S.vx[o + k] + (-cx), y = S.vy[o + k] + (-cy);
+      const double2 p = S.vxy[o + k];
+      if (strain_only) { mx = p.x; my = p.y; return; }
+      double x = p.x + (-cx), y = p.y + (-cy);
       double xr = c * x - s * y, yr = s * x + c * y;
       mx = xr + (cx + dx); my = yr + (cy + dy);
     };
@@ -2785,7 +2788,7 @@ __global__ void __launch_bounds__(256) sz_k_move_strain(State S, int strain_only
     double bx0 = __builtin_inf(), bx1 = -__builtin_inf(), by0 = __builtin_inf(), by1 = -__builtin_inf();
     for (int k = gl; k < n && !strain_only; k += G) {
       double mx, my; moved(k, mx, my);
-      S.vx[o + k] = mx; S.vy[o + k] = my;
+      S.vxy[o + k] = make_double2(mx, my);
       bx0 = fmin(bx0, mx); bx1 = fmax(bx1, mx); by0 = fmin(by0, my); by1 = fmax(by1, my);
     }
     bx0 = gmin<G>(bx0); bx1 = gmax<G>(bx1); by0 = gmin<G>(by0); by1 = gmax<G>(by1);
@@ -2882,7 +2885,7 @@ __global__ void __launch_bounds__(PACK_TPB) sz_k_halo_pack(State S, int nranks, 
         double* r = send + ((size_t)d * (cap + 1) + 1 + slot) * HALO_REC;
         r[0] = (double)S.okey[q]; r[1] = (double)S.status[q]; r[2] = (double)nv; r[3] = cx; r[4] = cy; r[5] = S.rmax[q];
         r[6] = S.area[q]; r[7] = S.height[q]; r[8] = S.u[q]; r[9] = S.v[q]; r[10] = S.xi[q]; r[11] = (double)S.id[q];
-        for (int k = 0; k < nv; k++) { r[12 + k] = S.vx[o + k]; r[12 + HALO_RING + k] = S.vy[o + k]; }
+        for (int k = 0; k < nv; k++) { const double2 p = S.vxy[o + k]; r[12 + k] = p.x; r[12 + HALO_RING + k] = p.y; }
       }
     }
   __syncthreads();
@@ -2960,7 +2963,7 @@ __global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* 
     double x0 = __builtin_inf(), x1 = -__builtin_inf(), y0 = __builtin_inf(), y1 = -__builtin_inf();
     for (int k = 0; k < nv; k++) {
       double x = r[12 + k], y = r[12 + HALO_RING + k];
-      S.vx[vb + k] = x; S.vy[vb + k] = y;
+      S.vxy[vb + k] = make_double2(x, y);
       x0 = fmin(x0, x); x1 = fmax(x1, x); y0 = fmin(y0, y); y1 = fmax(y1, y);
     }
     S.osign[g] = ring_signed_area(r + 12, r + 12 + HALO_RING, nv) >= 0.0 ? 1 : -1;
@@ -3068,7 +3071,7 @@ __global__ void __launch_bounds__(UNPACK_TPB) sz_k_halo_unpack_inline(State S, c
   for (int k = 0; k < MAX_GHOSTS; k++) S.gh[g * MAX_GHOSTS + k] = -1;
   S.voff[g] = vb; S.voff[g + 1] = vb + nv;
 #pragma unroll
-  for (int k = 0; k < MV_RING; k++) if (k < nv) { S.vx[vb + k] = R.rx[k]; S.vy[vb + k] = R.ry[k]; }
+  for (int k = 0; k < MV_RING; k++) if (k < nv) S.vxy[vb + k] = make_double2(R.rx[k], R.ry[k]);
   S.osign[g] = R.os;
   S.bbx0[g] = x0; S.bbx1[g] = x1; S.bby0[g] = y0; S.bby1[g] = y1;
   if (S.rec32) rec32_store(S, g, R.cx, R.cy, R.rmax, x0, x1, y0, y1);

@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(64) sz_k_eul_area(State S, EulGrid E, int nent
     gsync();
     if (nb > EU_CAP) { cap_err = true; if (gl == 0) E.pic[t] = 0.0; continue; }
     eul_cell_ring(m, gl, xmin, xmax, ymin, ymax);
-    for (int k = gl; k < nb; k += EU_G) { m.bx[k] = S.vx[bo + k]; m.by[k] = S.vy[bo + k]; }
+    for (int k = gl; k < nb; k += EU_G) { const double2 p = S.vxy[bo + k]; m.bx[k] = p.x; m.by[k] = p.y; }
     gsync();
     const Box bc{ xmin, xmax, ymin, ymax };
     const Box bf{ S.bbx0[i], S.bbx1[i], S.bby0[i], S.bby1[i] };
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) sz_k_eul_area_rect(State S, EulGrid E, in
     rc.w = E.xg[ix + 1] - xmin; rc.h = E.yg[iy + 1] - ymin; rc.acc = 0.0; rc.hout = false;
     rc.ox0 = rc.oy0 = rc.oxp = rc.oyp = 0.0;
     for (int k = 0; k < 4; k++) { rc.have[k] = false; rc.fx[k] = rc.fy[k] = rc.px[k] = rc.py[k] = 0.0; }
-    for (int k = 0; k + 1 < nb; k++) rc.feed<0>(S.vx[bo + k] - xmin, S.vy[bo + k] - ymin);
+    for (int k = 0; k + 1 < nb; k++) { const double2 p = S.vxy[bo + k]; rc.feed<0>(p.x - xmin, p.y - ymin); }
     E.pic[t] = rc.finish();
   }
 }

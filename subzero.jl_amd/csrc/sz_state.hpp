@@ -84,7 +84,8 @@ struct State {
   int *status, *parent, *gh, *ngh, *frc_remove;   // gh: MAX_GHOSTS per floe
   signed char* osign;                // ring orientation sign
   double *bbx0, *bbx1, *bby0, *bby1; // ring bounding boxes (kept current by every kernel that moves a ring)
-  int* voff; double *vx, *vy;
+  int* voff; double2* vxy;           // rings, CSR: point k of floe i at vxy[voff[i] + k] = {x, y} (closed: the first point repeated) -- interleaved,
+                                     // so that whoever moves, copies or stages a ring issues one 16-byte access per point instead of two 8-byte ones
   int* soff; double *sx, *sy;
   // ---- domain elements: 0..3 = N,S,E,W boundaries, 4.. = topography
   int* eoff; double *ex, *ey;

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(64) sz_k_tw_area(State S) {
     if (nb > TW_CAP) { if (gl == 0) { atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); S.fc_area[ent] = 0.0; } continue; }
     // _make_bounding_box_polygon: (xmin,ymin) (xmin,ymax) (xmax,ymax) (xmax,ymin) (xmin,ymin)
     if (gl < 5) { m.ax[gl] = (gl == 2 || gl == 3) ? xmax : xmin; m.ay[gl] = (gl == 1 || gl == 2) ? ymax : ymin; }
-    for (int k = gl; k < nb; k += TW_G) { m.bx[k] = S.vx[bo + k] + dx; m.by[k] = S.vy[bo + k] + dy; }   // _translate_poly
+    for (int k = gl; k < nb; k += TW_G) { const double2 p = S.vxy[bo + k]; m.bx[k] = p.x + dx; m.by[k] = p.y + dy; }   // _translate_poly
     gsync();
     const Box ba{ xmin, xmax, ymin, ymax };
     const Box bb{ S.bbx0[i] + dx, S.bbx1[i] + dx, S.bby0[i] + dy, S.bby1[i] + dy };
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) sz_k_tw_area_rect(State S) {
     // the ring box decides the two cheap cases: no overlap, and (for a window inside the box nothing is known)
     const double b0 = S.bbx0[i] + dx, b1 = S.bbx1[i] + dx, b2 = S.bby0[i] + dy, b3 = S.bby1[i] + dy;
     if (!(b1 < xmin || xmax < b0 || b3 < ymin || ymax < b2) && rc.w > 0.0 && rc.h > 0.0) {
-      for (int k = 0; k + 1 < nb; k++) rc.feed<0>((S.vx[bo + k] + dx) - xmin, (S.vy[bo + k] + dy) - ymin);   // _translate_poly, then window coordinates
+      for (int k = 0; k + 1 < nb; k++) { const double2 p = S.vxy[bo + k]; rc.feed<0>((p.x + dx) - xmin, (p.y + dy) - ymin); }   // _translate_poly, then window coordinates
       a = rc.finish();
     }
     S.fc_area[ent] = a;
