@@ -21,7 +21,7 @@ w.run(1, 20, cfg["dt"], coupling_dt=1)
 w._chk(w.L.sz_debug_stamps(w.h, capi.ptr(out, capi._lp)))
 nrec = int(min(out[511], 8000))
 r = out[512:512 + 8 * nrec].reshape(nrec, 8)
-r = r[r[:, 4] + r[:, 5] > 0]                      # wavefronts that ran a round
+r = r[(r[:, 4] + r[:, 5] > 0) & (r[:, 1] > 0) & (r[:, 4] < (1 << 40))]      # wavefronts that ran a round (a record of a wavefront without items holds no phase times)
 a1 = ((r[:, 7] >> 8) & ((1 << 28) - 1)) << 8; a2 = (r[:, 7] >> 36) << 8; r[:, 7] &= 255
 print("phase A split, mean k cycles: staging %.1f  contact clip %.1f  after the clip (overlap tests, vertex matching, directions) %.1f" % (a1.mean() / 1e3, a2.mean() / 1e3, (r[:, 4] - a1 - a2).mean() / 1e3))
 heavy = r[:, 7] >= 2
