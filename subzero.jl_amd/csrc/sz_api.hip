@@ -2576,6 +2576,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   S.stop_on_tags = (flags & SZ_NO_STOP) ? 0 : 1;
   HIPCHK(c, hipMemsetAsync(S.cnt + C_STOP, 0, sizeof(int), c->stream));
   HIPCHK(c, hipMemsetAsync(S.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(S.cnt + C_PAUSED, 0, sizeof(int), c->stream));
   use_static_grid(c);
   if (c->precision == 1) { int rc = ensure_mixed(c); if (rc) return rc; }
   S.ginline = 1; S.famrec = 1; S.retry_stop = 0; S.body_rings = 0;
@@ -2585,7 +2586,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   S.crec = (!c->no_crec && c->crec_buf && nsteps > 0) ? c->crec_buf : nullptr;
   if (S.crec) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, S, c->hostN);
   if (periodic && nsteps > 0) hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0, c->hostN);
-  auto fail = [&](int rc) { S.ginline = 0; S.famrec = 0; S.step = 0; S.crec = nullptr; return rc; };
+  auto fail = [&](int rc) { S.ginline = 0; S.famrec = 0; S.step = 0; S.crec = nullptr; S.retry_stop = 0; return rc; };
   // SZ_SYNC_DEBUG=1 (diagnosis of a faulting kernel): wait after every stage of every step and say so on stderr -- the last line names the stage
   const bool dbgsync = getenv("SZ_SYNC_DEBUG") != nullptr;
   auto stage_done = [&](int s, const char* what) {
@@ -2599,7 +2600,17 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   std::vector<signed char> fset((size_t)std::max(nsteps, 1), (signed char)-1);      // the output set the forcings of step s wrote (-1: none of this kind)
   int cur_set = 0;
   auto swap_frc = [&]() { std::swap(S.fxOA, c->frc_alt[0]); std::swap(S.fyOA, c->frc_alt[1]); std::swap(S.trqOA, c->frc_alt[2]); std::swap(S.hflx, c->frc_alt[3]); cur_set ^= 1; };
-  for (int s = 0; s < nsteps; s++) {
+  // The largest narrow variant is left out of the steps until an item needs it, as in sz_step (-4 us and a launch boundary per step).  A
+  // rank whose narrow phase meets such an item pauses inside that step (C_RETRYSTOP); its pause rides in the header records of the next
+  // exchange (sz_k_halo_pack hdr[2]), whose unpack kernel stops every other rank before that step has touched anything.  After the sync
+  // all ranks know the step: the rank that paused finishes it (the variant, the reduce, the integrator), and everybody runs the rest of
+  // the batch again from the step after it, as a batch that starts there (cells, ghosts, records seeded anew) with the variant in.
+  bool lean = !c->retry_seen && !c->no_lean_narrow && !larger_rings(c) && !dbgsync;
+  std::vector<int> callid_of((size_t)std::max(nsteps, 1), 0);
+  int h[C_COUNT]; int rc = SZ_OK;
+  for (int s_begin = 0;;) {
+  S.retry_stop = lean ? 1 : 0;
+  for (int s = s_begin; s < nsteps; s++) {
     const int tstep = tstep0 + s;
     S.step = s + 1; S.gslot = s & 1;
     c->tile_dt = dt;
@@ -2634,21 +2645,62 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     if (fmode == 1 && S.maxnb > MAXNB) fmode = 2;
     if (coupling && !fuse && !beside) stage_forcing(c, dt);
     if (coupling) c->forcing_where = fmode;
-    S.callid = ++c->callid;
+    S.callid = ++c->callid; callid_of[s] = S.callid;
     if (dbgsync) {          // (the stages of collisions_step one by one)
       stage_broad(c, false, true, fmode == 1, false); stage_done(s, "neighbour search");
       stage_elems(c, true); stage_done(s, "element items");
       stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, true, fmode == 2 ? (c->precision == 1 ? 2 : 1) : 0, 0); stage_done(s, "narrow phase");
       stage_reduce(c, 1, -1, dt, 0); stage_done(s, "reduce");
-    } else collisions_step(c, -1, dt, false, true, fmode, false, false);
+    } else collisions_step(c, -1, dt, false, true, fmode, lean, false);
     stage_integrate(c, dt, false, coupling, true, -1, periodic && s + 1 < nsteps ? 1 - (s & 1) : -1);
     stage_done(s, "integrate");
   }
-  S.step = 0; S.ginline = 0; S.famrec = 0; S.crec = nullptr;
+  S.step = 0;
   c->tile_dirty = nsteps > 0;
-  int h[C_COUNT];
-  int rc = sync_and_check(c, h);                     // (drops the halo floes and ghosts of the last step: tile_cleanup)
-  if (rc == SZ_E_HIP) return rc;
+  rc = sync_and_check(c, h);                     // (drops the halo floes and ghosts of the last step: tile_cleanup -- unless a step is paused)
+  if (rc == SZ_E_HIP) return fail(rc);
+  {          // (the ranks agree on the error word BEFORE anybody decides to run steps again: a rank leaving on its own would hang the others)
+    int all = 0;
+    const int rc2 = comm_agree_bits(c, rc ? (c->last_err_bits ? c->last_err_bits : 1) : 0, &all);
+    if (rc2) return fail(rc2);
+    if (all) return fail(SZ_E_CAPACITY);
+  }
+  const int sp = h[C_RETRYSTOP];                 // 1-based step that was paused, here or on a peer (0: none)
+  if (!lean || sp <= 0 || (h[C_STOP] > 0 && h[C_STOP] < sp)) break;
+  // ---- a pause for the largest narrow variant in step sp
+  const int tsp = tstep0 + sp - 1;
+  const bool coupling_sp = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tsp % coupling_dt) == 0;
+  HIPCHK(c, hipMemsetAsync(S.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(S.cnt + C_PAUSED, 0, sizeof(int), c->stream));
+  S.retry_stop = 0; c->retry_seen = true; lean = false;
+  if (h[C_PAUSED] == sp) {          // this rank's step: the variant, then what the pause held back
+    S.step = sp; S.gslot = (sp - 1) & 1; S.callid = callid_of[sp - 1];
+    stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, true, 0, 2);
+    stage_reduce(c, 1, -1, dt, 0);
+    stage_integrate(c, dt, false, coupling_sp, true, -1, -1);
+    S.step = 0;
+  }
+  {          // the forcing outputs as of step sp (the steps after it are run again)
+    int want = 0;
+    for (int s2 = 0; s2 < sp; s2++) if (fset[s2] >= 0) want = fset[s2];
+    if (want != cur_set) swap_frc();
+    for (int s2 = sp; s2 < nsteps; s2++) fset[s2] = -1;
+  }
+  c->tile_dirty = true;
+  if (sp >= nsteps) {               // (the last step of the batch: no peer has heard of it, nothing is run again)
+    rc = sync_and_check(c, h);
+    if (rc == SZ_E_HIP) return fail(rc);
+    break;
+  }
+  // the rest of the batch again, from the floes as they lie after step sp (sz_step's capacity restart does the same)
+  tile_cleanup(c);
+  c->grid_live = false; use_static_grid(c);
+  HIPCHK(c, hipMemsetAsync(S.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
+  if (S.crec) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, S, c->hostN);
+  if (periodic) hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, sp & 1, c->hostN);
+  s_begin = sp;
+  }
+  S.step = 0; S.ginline = 0; S.famrec = 0; S.crec = nullptr; S.retry_stop = 0;
   {
     int all = 0;
     const int rc2 = comm_agree_bits(c, rc ? (c->last_err_bits ? c->last_err_bits : 1) : 0, &all);

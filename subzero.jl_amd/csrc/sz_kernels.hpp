@@ -1856,7 +1856,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       gsync();
       if (CLS < 2 && (m.ierr & CAPBITS)) {                // working set too small: let the largest variant redo the item
         nrows = 0; flags = IT_RETRY;
-        if (gl == 0) { atomicMax(&S.cnt[C_ITEMCLASS], 2); atomicAdd(&S.cnt[C_NRETRY], 1); if (S.retry_stop && S.step > 0) S.cnt[C_RETRYSTOP] = S.step; }
+        if (gl == 0) { atomicMax(&S.cnt[C_ITEMCLASS], 2); atomicAdd(&S.cnt[C_NRETRY], 1); if (S.retry_stop && S.step > 0) { S.cnt[C_RETRYSTOP] = S.step; S.cnt[C_PAUSED] = S.step; } }
       } else if (gl == 0 && m.ierr) m.err |= m.ierr;
       if (gl == 0) {
         S.it_info[it.info] = make_int2(nrows | (flags << 8), it.rows);
@@ -2907,6 +2907,7 @@ __global__ void __launch_bounds__(PACK_TPB) sz_k_halo_pack(State S, int nranks, 
       // on EVERY rank: sz_k_halo_unpack_inline reads the flags of all ranks before the next step does anything)
       double* hdr = send + (size_t)d * (cap + 1) * HALO_REC;
       hdr[0] = (double)(tot < room ? tot : room); hdr[1] = (double)S.cnt[C_STOP];
+      hdr[2] = (double)S.cnt[C_RETRYSTOP];      // ... and its pause (the step whose narrow phase met an item for the variant that was left out, or outgrew a list)
     }
   }
   if (threadIdx.x == 0) {
@@ -2995,12 +2996,19 @@ constexpr int UNPACK_TPB = 256;
 __global__ void __launch_bounds__(UNPACK_TPB) sz_k_halo_unpack_inline(State S, const double* recv, int nranks, int me, int cap, int slot, int nown) {
   if (stopped(S)) return;
   {
-    int stop = 0;
-    for (int r = 0; r < nranks; r++) { if (r == me) continue; const int f = (int)recv[(size_t)r * (cap + 1) * HALO_REC + 1]; if (f > 0) stop = f; }
-    if (stop > 0 && S.stop_on_tags) {
-      if (blockIdx.x == 0 && threadIdx.x == 0) S.cnt[C_STOP] = stop;      // (every requester of a batch names the same step)
-      return;
+    int stop = 0, pause = 0;
+    for (int r = 0; r < nranks; r++) {
+      if (r == me) continue;
+      const double* hdr = recv + (size_t)r * (cap + 1) * HALO_REC;
+      const int f = (int)hdr[1], pz = (int)hdr[2];
+      if (f > 0) stop = f;
+      if (pz > 0) pause = pz;
     }
+    // a peer paused inside the step before (its narrow phase needs the variant that is left out of the steps): this rank has finished that
+    // step and waits here -- nothing of this step has touched anything -- until the host has finished it over there and starts the rest again
+    if (pause > 0) { if (blockIdx.x == 0 && threadIdx.x == 0 && S.cnt[C_RETRYSTOP] == 0) S.cnt[C_RETRYSTOP] = pause; }
+    if (stop > 0 && S.stop_on_tags) { if (blockIdx.x == 0 && threadIdx.x == 0) S.cnt[C_STOP] = stop; }      // (every requester of a batch names the same step)
+    if (pause > 0 || (stop > 0 && S.stop_on_tags)) return;
   }
   const GridGeo geo = grid_geo(S);
   const int NV0 = S.voff[nown];

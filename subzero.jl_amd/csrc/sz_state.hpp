@@ -40,6 +40,8 @@ enum {
   C_STOP,         // resident batches (sz_step): 0, or 1 + the batch-relative step after which the batch stops -- a floe was tagged
                   // remove / fuse (or fell under the dissolve thresholds), so the host's simplify_floes! (simulation.jl:205-214) has work
   C_DRIFT,        // tiled runs: largest displacement of an owned floe since the last box gather, metres as float bits (pack kernel)
+  C_PAUSED,       // the step C_RETRYSTOP names was paused by THIS context's narrow phase (tiled runs: a peer's pause arrives in the halo headers
+                  // and sets C_RETRYSTOP alone)
   C_COUNT = 32
 };
 

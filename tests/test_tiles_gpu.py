@@ -382,6 +382,86 @@ def test_tiled_batch_ends_on_every_rank_where_a_floe_is_tagged(kind, coupled):
         assert owners == {0, 1}            # the fused pair straddles the tile edge
 
 
+# ---------------------------------------------------------------- the pause for the largest narrow variant, agreed between the ranks
+def _retry_cfg(x0):
+    """test_hip_parity.py::_retry_scenario as a tile configuration: two 8-spike stars drifting into each other (6, then 8, then 16 crossings: from
+    the sixth step on the pair outgrows the small narrow-phase working set), centres at x0 and x0 + 5 km; two squares on the other tile"""
+    from subzero_jl_amd import floe as floe_mod
+    th = np.arange(16) * (2 * np.pi / 16)
+    rad = np.where(np.arange(16) % 2 == 0, 1.0e4, 0.55e4)
+    def star(rot, cx):
+        r = np.stack([cx + rad * np.cos(-th + rot), 5e4 + rad * np.sin(-th + rot)], 1)
+        return np.concatenate([r, r[:1]])
+    sq = lambda x0_, y0, s=1e4: np.array([[x0_, y0], [x0_, y0 + s], [x0_ + s, y0 + s], [x0_ + s, y0], [x0_, y0]])
+    rings = [star(0.0, x0), star(np.pi / 8, x0 + 0.5e4), sq(8.0e4, 1.0e4), sq(9.6e4, 6.0e4)]      # the last one has a ghost
+    n = len(rings)
+    off = np.zeros(n + 1, np.int32); off[1:] = np.cumsum([len(r) for r in rings])
+    vx = np.concatenate([r[:, 0] for r in rings]); vy = np.concatenate([r[:, 1] for r in rings])
+    h = np.full(n, 0.5); z = np.zeros((11, 11))
+    return dict(n_floes=n, L=1e5, kinds=["periodic"] * 4, vert_off=off, vx=vx, vy=vy, height=h, u=np.array([0.0, -30.0, 0.0, 0.0]), v=np.zeros(n), xi=np.zeros(n),
+                dt=10, Nx=10, Ny=10, uo=z, vo=z, hf=z, ua=z, va=z, topography=[], E=1e3, derived=floe_mod.derive(off, vx, vy, h),
+                sub_off=np.zeros(n + 1, np.int32), sx=np.zeros(0), sy=np.zeros(0), seed=0)
+
+
+def _worker_retry(rank, world, port, x0, q):
+    import torch.distributed as dist
+    from subzero_jl_amd import tiles
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        cfg = _retry_cfg(x0)
+        tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True, backend="library-host", rebox_every=3, drift_margin=3000.0)
+        done = tw.run(8, 0, 10, coupling_dt=10, coupling_on=False)
+        nretry = int(tw.world.stats()["n_retry"])
+        done2 = tw.run(2, 8, 10, coupling_dt=10, coupling_on=False)
+        q.put((rank, tw.gidx, {f: tw.owned(f) for f in FIELDS}, done, done2, nretry))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_worker_retry(*a):
+    _guard(_worker_retry)(*a)
+
+
+@pytest.mark.parametrize("x0", [4.0e4, 4.7e4])
+def test_tiled_batch_pauses_for_the_largest_narrow_variant(x0):
+    """sz_tile_run leaves the largest narrow-phase variant out of its steps, as sz_step does.  When a pair outgrows the small working set in the
+    middle of a batch, the rank that holds it pauses inside that step; the pause reaches the other rank with the next exchange, which stops
+    before that step has touched anything; the first rank finishes its step and both run the rest of the batch again.  x0 = 40 km: both stars
+    on rank 0, far from rank 1's halo (only rank 0 pauses); x0 = 47 km: the pair straddles the tile edge and both ranks meet it.  Owned columns
+    bit-equal to the single context (which pauses the same way)."""
+    import torch.multiprocessing as mp
+    import subzero_jl_amd
+    from subzero_jl_amd import fields
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_run_worker_retry, args=(r, 2, port, x0, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = _collect(q, 2)
+        for p in procs:
+            p.join(60)
+        assert all(p.exitcode == 0 for p in procs)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    cfg = _retry_cfg(x0)
+    hw = fields.build_world(subzero_jl_amd.World(0), cfg)
+    assert hw.run(8, 0, 10, coupling_dt=10, coupling_on=False, stop_on_tags=False) == 8
+    assert hw.stats()["n_retry"] >= 1
+    assert hw.run(2, 8, 10, coupling_dt=10, coupling_on=False, stop_on_tags=False) == 2
+    paused = set()
+    for rank, gidx, out, done, done2, nretry in res:
+        assert done == 8 and done2 == 2, (rank, done, done2)
+        if nretry:
+            paused.add(rank)
+        for f in FIELDS:
+            assert np.array_equal(out[f], hw.get(f)[gidx]), (rank, f)
+    assert paused == ({0} if x0 < 4.5e4 else {0, 1}), paused
+
+
 # ---------------------------------------------------------------- migration inside the library
 def _worker_migrate(rank, world, port, n, seed, steps, every, q):
     import time
