@@ -369,6 +369,10 @@ int sz_debug_match_vertices(sz_ctx *ctx, int32_t npts, const double *px, const d
 /* diagnostic build (-DSZ_STAMPS) only: stamp log of one lane group of the narrow phase
    (out512[0] = entries, then (stage << 48) | cycles since the wave started) */
 int sz_debug_stamps(sz_ctx *ctx, long long *out512);
+/* test hook: parts of the collision records (the per-floe 128-byte cache of the columns the neighbour search and the narrow phase read;
+   DESIGN.md section 3.00) of the owned parents that differ from the columns after the last resident batch -- 0 expected; -1: that batch
+   did not run on records */
+int sz_debug_crec_mismatches(sz_ctx *ctx, int64_t *n_bad);
 
 #ifdef __cplusplus
 }

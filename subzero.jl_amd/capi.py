@@ -69,7 +69,7 @@ EXPORTS = [
     "sz_set_two_way", "sz_set_temps", "sz_download_ocean_stress", "sz_two_way_partial", "sz_two_way_finish", "sz_set_precision",
     "sz_eulerian_data", "sz_eulerian_partial", "sz_eulerian_finish", "sz_simplify_check",
     "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms", "sz_forcing_launch", "sz_narrow_kernel_name",
-    "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_forcing", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps",
+    "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_forcing", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps", "sz_debug_crec_mismatches",
     "sz_get_boundary_rects", "sz_debug_match_vertices",
     "sz_comm_available", "sz_comm_unique_id", "sz_comm_init", "sz_comm_init_host", "sz_comm_destroy", "sz_comm_selftest", "sz_comm_allreduce", "sz_tile_setup", "sz_tile_set_center", "sz_tile_run", "sz_tile_migrate", "sz_download_subpoints",
 ]
@@ -150,6 +150,7 @@ def load(build_if_missing=True):
     L.sz_sync.argtypes = [C.c_void_p]
     L.sz_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.sz_debug_stamps.argtypes = [C.c_void_p, _lp]
+    L.sz_debug_crec_mismatches.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.sz_comm_available.argtypes = []
     L.sz_narrow_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     L.sz_comm_unique_id.argtypes = [C.c_void_p]

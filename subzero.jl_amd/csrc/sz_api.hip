@@ -107,6 +107,7 @@ struct sz_ctx {
   double* frc_alt[4] = { nullptr, nullptr, nullptr, nullptr };      // second set of the forcing outputs fxOA, fyOA, trqOA, hflx (tiled steps with peers, see sz_tile_run)
   bool tile_forcing_in_tail = false;      // SZ_TILE_FORCING_TAIL=1: tiled steps with peers keep the forcings in the narrow launch's tail (A/B switch)
   double2* crec_buf = nullptr;      // the records' memory (State::crec points at it only inside the batches that keep it current)
+  bool crec_was_live = false;       // the last resident batch ran on records (sz_debug_crec_mismatches)
   int forcing_where = -1;           // sz_forcing_launch
   int fuse_forcing_mode = 0;        // ... 1: in the neighbour launch, 2: in the narrow launch (its tail), 0: by size -- the narrow launch while the narrow phase is one
                                     // round with a long tail (measured better up to 20 k floes, even at 40 k, worse at 65 k); SZ_FUSE_FORCING=1|2 forces one
@@ -1538,7 +1539,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   // collision records (State::crec): in batches whose kernels keep them current -- the one-launch integrator, and for periodic walls the
   // inline ghost maker; seeded here from the columns (before the ghost seed: the maker updates the records of the parents it visits)
   const bool cr = coll && sg && !c->no_crec && c->crec_buf && c->fused_move && c->max_ring <= MV_RING && (gi || !periodic) && nsteps > 0;
-  c->S.crec = cr ? c->crec_buf : nullptr;
+  c->S.crec = cr ? c->crec_buf : nullptr; c->crec_was_live = cr;
   if (cr) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, c->S, c->hostN);
   if (gi) {               // the ghosts of the first step, from the parents as they lie (after the rings are in the batch's form)
     HIPCHK(c, hipMemsetAsync(c->S.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
@@ -1712,6 +1713,23 @@ int sz_owned_box(sz_ctx* c, double* out5) {
 int sz_halo_record_doubles(void) { return HALO_REC; }
 
 // diagnostic build only: cycles per narrow-phase stage, summed over groups (zeros otherwise)
+// test hook: quads of the collision records (State::crec) of the owned parents that differ from the columns they cache; *n_bad = -1 when the last
+// resident batch did not run on records
+int sz_debug_crec_mismatches(sz_ctx* c, int64_t* n_bad) {
+  if (!c || !c->have_floes || !n_bad) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  if (!c->crec_buf || !c->crec_was_live) { *n_bad = -1; return SZ_OK; }
+  int h[C_COUNT];
+  int rc = sync_and_check(c, h); if (rc) return rc;
+  unsigned long long* d = (unsigned long long*)(c->S.cnt + C_COUNT + 64 + 68);      // (two spare words of the counter block)
+  HIPCHK(c, hipMemsetAsync(d, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(sz_k_crec_check, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, c->S, (const double2*)c->crec_buf, c->hostN, d);
+  unsigned long long v = 0;
+  HIPCHK(c, hipMemcpyAsync(&v, d, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_bad = (int64_t)v;
+  return SZ_OK;
+}
 int sz_debug_stamps(sz_ctx* c, long long* out16) {
   if (!c || !c->have_floes || !out16) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
@@ -2583,7 +2601,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   HIPCHK(c, hipMemsetAsync(S.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
   // the periodic ghosts of the owned floes for the first step (and the swap of parents that lie outside the domain), BEFORE the first pack
   // collision records of the owned floes (the halo floes get theirs from the unpack kernel, ghosts from their maker; see sz_step)
-  S.crec = (!c->no_crec && c->crec_buf && nsteps > 0) ? c->crec_buf : nullptr;
+  S.crec = (!c->no_crec && c->crec_buf && nsteps > 0) ? c->crec_buf : nullptr; c->crec_was_live = S.crec != nullptr;
   if (S.crec) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, S, c->hostN);
   if (periodic && nsteps > 0) hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0, c->hostN);
   auto fail = [&](int rc) { S.ginline = 0; S.famrec = 0; S.step = 0; S.crec = nullptr; S.retry_stop = 0; return rc; };

@@ -916,6 +916,22 @@ __global__ void __launch_bounds__(256) sz_k_crec_seed(State S, int n) {
     crec_store_all(S, i, S.cx[i], S.cy[i], S.rmax[i], S.id[i], S.okey[i], ring_n(S, i), S.osign[i], ring_off(S, i), S.parent[i], S.ngh[i],
                    S.bbx0[i], S.bbx1[i], S.bby0[i], S.bby1[i], S.u[i], S.v[i], S.xi[i], S.area[i], S.height[i], S.ghost_id[i]);
 }
+// test hook: how many of the rows [0, n) hold a collision record that differs from the columns it caches (bit for bit; the ghost count of
+// a parent is compared with its ngh column) -- 0 after any resident batch, whoever placed the floes in it
+__global__ void __launch_bounds__(256) sz_k_crec_check(State S, const double2* rec, int n, unsigned long long* bad) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double2* r = rec + (size_t)i * 8;
+    auto ne = [](double a, double b) { return __double_as_longlong(a) != __double_as_longlong(b); };
+    int m = 0;
+    m += ne(r[0].x, S.cx[i]) || ne(r[0].y, S.cy[i]);
+    m += ne(r[1].x, S.rmax[i]) || __double_as_longlong(r[1].y) != S.id[i];
+    m += ne(r[2].x, crec_okf(S.okey[i], ring_n(S, i), S.osign[i])) || ne(r[2].y, crec_vp(ring_off(S, i), S.parent[i], S.ngh[i]));
+    m += ne(r[3].x, S.bbx0[i]) || ne(r[3].y, S.bbx1[i]) || ne(r[4].x, S.bby0[i]) || ne(r[4].y, S.bby1[i]);
+    m += ne(r[5].x, S.u[i]) || ne(r[5].y, S.v[i]) || ne(r[6].x, S.xi[i]) || ne(r[6].y, S.area[i]);
+    m += ne(r[7].x, S.height[i]) || __double_as_longlong(r[7].y) != S.ghost_id[i];
+    if (m) atomicAdd(bad, (unsigned long long)m);
+  }
+}
 // seeds candidate list `list` from the parents as they lie (after an upload / a process-mode call), thread per parent
 __global__ void sz_k_ghost_seed(State S, int list) {
   const int N = S.cnt[C_N];

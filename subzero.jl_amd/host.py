@@ -237,6 +237,13 @@ class World:
             self._chk(self.L.sz_upload_interactions(self.h, capi.ptr(off, capi._ip), None))
             self._new_field = False
 
+    def crec_mismatches(self):
+        """test hook: parts of the collision records (the per-floe cache of the columns the neighbour search and the narrow phase read) that differ
+        from the columns after the last resident batch; -1: that batch did not run on records"""
+        n = C.c_int64(0)
+        self._chk(self.L.sz_debug_crec_mismatches(self.h, C.byref(n)))
+        return int(n.value)
+
     def stats(self):
         s = capi.SzStats()
         self._chk(self.L.sz_get_stats(self.h, C.byref(s)))

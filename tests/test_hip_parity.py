@@ -594,6 +594,33 @@ def test_resident_batch_pauses_for_the_largest_narrow_variant():
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+@pytest.mark.parametrize("kind", ["periodic", "walls", "fast", "mixed"])
+def test_collision_records_stay_current(kind):
+    """The collision records (State::crec: one 128-byte line per floe with what the neighbour search and the narrow phase's staging read of it) are
+    a CACHE of the columns, kept current inside a resident batch by whoever places a floe (integrator, inline ghost maker; seeded at the start
+    of the batch).  After batches of several kinds every record of every parent must equal the columns bit for bit -- also where nothing in
+    the results would show a stale one yet: a periodic field, walls + topography (no ghosts at all), fast floes that cross the periodic walls
+    (parents swap with their ghosts), mixed precision (body-frame rings)."""
+    from subzero_jl_amd import fields
+    if kind == "walls":
+        cfg = fields.make_config(n_floes=900, seed=5, walls=True, topography=True, ocean="strait")
+    else:
+        cfg = fields.make_config(n_floes=1200, seed=21, concentration=0.8)
+    hw = fields.build_world(mk(), cfg)
+    if kind == "fast":
+        rng = np.random.default_rng(3)
+        hw.set("u", rng.uniform(-40.0, 40.0, cfg["n_floes"])); hw.set("v", rng.uniform(-40.0, 40.0, cfg["n_floes"]))
+    if kind == "mixed":
+        hw.set_precision("mixed")
+    t = 0
+    for k in (1, 7, 3, 1, 12):
+        assert hw.run(k, t, cfg["dt"], coupling_dt=1, stop_on_tags=False) == k
+        t += k
+        assert hw.crec_mismatches() == 0, (kind, t)
+    if kind == "fast":
+        assert hw.stats()["n_ghosts"] > 0
+
+
 def test_one_step_batches_match_the_oracle():
     """timestep_sim! called step by step (batches of one resident step each, nothing in between): what a batch leaves
     behind -- cell lists, ghost bookkeeping of its last integrator -- must not leak into the next one"""

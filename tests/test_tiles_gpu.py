@@ -414,6 +414,7 @@ def _worker_retry(rank, world, port, x0, q):
         done = tw.run(8, 0, 10, coupling_dt=10, coupling_on=False)
         nretry = int(tw.world.stats()["n_retry"])
         done2 = tw.run(2, 8, 10, coupling_dt=10, coupling_on=False)
+        assert tw.world.crec_mismatches() == 0          # (the collision records of the owned floes are the columns', also after the restart)
         q.put((rank, tw.gidx, {f: tw.owned(f) for f in FIELDS}, done, done2, nretry))
     finally:
         dist.destroy_process_group()
