@@ -1706,7 +1706,9 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       //    lanes 4..7 the same quads of floe j and then the two sign quads;
       //  * otherwise the columns: scalar q = lane (+ G), box value = lane (< 8), sign = lane (< 2).
       const bool urec = G == 8 && S.crec != nullptr && is_pair;
-      double bv0 = 0.0, bv1 = 0.0; int osv = 1;
+      constexpr int NBV = (8 + G - 1) / G;          // box values a lane asks for on the column path (one for lane groups of 8 and more)
+      double bv0 = 0.0, bv1 = 0.0, bvx[NBV > 1 ? NBV : 1]; int osv = 1;
+      for (int r = 0; r < (NBV > 1 ? NBV : 1); r++) bvx[r] = 0.0;
       // (which column / quad a lane asks for depends on the lane alone: the compiler would compute those pointers once, before the loop over
       //  the items, hold them in registers through the whole kernel and -- at this kernel's budget -- spill them; the lane number is
       //  therefore made opaque here, a handful of selects per item instead of scratch reloads)
@@ -1734,10 +1736,15 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
           }
           kv[r] = val;
         }
-        if (glv < 8) {
-          const int w = glv & 3;
-          const double* bc = w == 0 ? S.bbx0 : w == 1 ? S.bbx1 : w == 2 ? S.bby0 : S.bby1;
-          bv0 = glv < 4 ? bc[i] : is_pair ? bc[j] : S.ebb[4 * e + w];
+#pragma unroll
+        for (int r = 0; r < NBV; r++) {
+          const int qb = glv + r * G;
+          if (qb < 8) {
+            const int w = qb & 3;
+            const double* bc = w == 0 ? S.bbx0 : w == 1 ? S.bbx1 : w == 2 ? S.bby0 : S.bby1;
+            const double bvv = qb < 4 ? bc[i] : is_pair ? bc[j] : S.ebb[4 * e + w];
+            if (NBV > 1) bvx[r] = bvv; else bv0 = bvv;
+          }
         }
         if (glv < 2) osv = glv == 0 ? S.osign[i] : is_pair ? S.osign[j] : S.eosign[e];
       }
@@ -1790,7 +1797,10 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
           const int q = gl + r * G;
           if (q < 14) m.kin[q < 10 ? (q >= 5 ? 7 : 0) + q % 5 : (q >= 12 ? 7 : 0) + 5 + (q & 1)] = kv[r];
         }
-        if (gl < 8) m.box[gl] = bv0;
+        if (NBV > 1) {
+#pragma unroll
+          for (int r = 0; r < NBV; r++) { const int qb = gl + r * G; if (qb < 8) m.box[qb] = bvx[r]; }
+        } else if (gl < 8) m.box[gl] = bv0;
         if (gl < 2) (&m.roa)[gl] = (int8_t)osv;
       }
       gsync();
