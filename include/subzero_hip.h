@@ -151,6 +151,28 @@ int sz_get_stats(sz_ctx *ctx, sz_stats *out);
 int sz_download_floes(sz_ctx *ctx, sz_floe_columns *cols);
 /* interactions of all M floes: off has M+1 entries, rows has n_inter_rows*7 doubles */
 int sz_download_interactions(sz_ctx *ctx, int32_t *off, double *rows);
+/* ---- the same boundary for hosts whose floes are Floe{Float32} (floe.jl:24: the struct is generic in its float type FT; SURVEY section 8b
+   "two instantiations: _f64, _f32").  documentation.md:25 supports and tests Float64 only, so there are no Float32 answers to reproduce: the
+   engine computes in double (or mixed precision, sz_set_precision) whatever the host's FT -- these entry points widen the columns on the
+   way in and round them on the way out (a run from Float32 columns therefore equals the run from the same values held as doubles, rounded
+   once at the end).  Integer columns and the CSR offsets are the same types as above. */
+typedef struct {
+  float *cx, *cy, *rmax, *area, *height, *mass, *moment, *alpha, *u, *v, *xi;
+  float *p_dxdt, *p_dydt, *p_dalphadt, *p_dudt, *p_dvdt, *p_dxidt;
+  float *fxOA, *fyOA, *trqOA, *hflx_factor, *overarea;
+  float *coll_fx, *coll_fy, *coll_trq;
+  float *stress_accum, *stress_instant, *strain;         /* 4 per floe */
+  int64_t *id, *ghost_id;
+  int32_t *status;
+  int32_t *vert_off;  float *vx, *vy;
+  int32_t *sub_off;   float *sx, *sy;
+  int32_t *ghost_off; int32_t *ghost_idx;
+} sz_floe_columns_f32;
+int sz_upload_floes_f32(sz_ctx *ctx, int64_t M, int64_t N, const sz_floe_columns_f32 *cols);
+int sz_download_floes_f32(sz_ctx *ctx, sz_floe_columns_f32 *cols);
+int sz_set_fields_f32(sz_ctx *ctx, int32_t Nx, int32_t Ny, double x0, double xf, double y0, double yf,
+                      const float *uocn, const float *vocn, const float *hflx_factor, const float *uatm, const float *vatm);
+int sz_download_interactions_f32(sz_ctx *ctx, int32_t *off, float *rows);
 /* the pairs that reached the narrow phase, in the reference's serial (i asc, j asc) order */
 int sz_download_pairs(sz_ctx *ctx, int32_t *pi, int32_t *pj);
 /* status.fuse_idx after the mirror pass (collisions.jl:801-806): off M+1, idx; call with

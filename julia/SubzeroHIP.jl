@@ -105,6 +105,51 @@ mutable struct SzFloeColumns
 end
 SzFloeColumns() = SzFloeColumns(ntuple(_ -> C_NULL, 39)...)
 
+# include/subzero_hip.h: sz_floe_columns_f32 -- the same columns of a Floe{Float32} host (the engine widens them on the way in and rounds
+# them on the way out; see the Float32 section at the end of this file)
+mutable struct SzFloeColumnsF32
+    cx::Ptr{Float32}
+    cy::Ptr{Float32}
+    rmax::Ptr{Float32}
+    area::Ptr{Float32}
+    height::Ptr{Float32}
+    mass::Ptr{Float32}
+    moment::Ptr{Float32}
+    alpha::Ptr{Float32}
+    u::Ptr{Float32}
+    v::Ptr{Float32}
+    xi::Ptr{Float32}
+    p_dxdt::Ptr{Float32}
+    p_dydt::Ptr{Float32}
+    p_dalphadt::Ptr{Float32}
+    p_dudt::Ptr{Float32}
+    p_dvdt::Ptr{Float32}
+    p_dxidt::Ptr{Float32}
+    fxOA::Ptr{Float32}
+    fyOA::Ptr{Float32}
+    trqOA::Ptr{Float32}
+    hflx_factor::Ptr{Float32}
+    overarea::Ptr{Float32}
+    coll_fx::Ptr{Float32}
+    coll_fy::Ptr{Float32}
+    coll_trq::Ptr{Float32}
+    stress_accum::Ptr{Float32}
+    stress_instant::Ptr{Float32}
+    strain::Ptr{Float32}
+    id::Ptr{Int64}
+    ghost_id::Ptr{Int64}
+    status::Ptr{Int32}
+    vert_off::Ptr{Int32}
+    vx::Ptr{Float32}
+    vy::Ptr{Float32}
+    sub_off::Ptr{Int32}
+    sx::Ptr{Float32}
+    sy::Ptr{Float32}
+    ghost_off::Ptr{Int32}
+    ghost_idx::Ptr{Int32}
+end
+SzFloeColumnsF32() = SzFloeColumnsF32(ntuple(_ -> C_NULL, 39)...)
+
 # include/subzero_hip.h: sz_stats
 struct SzStats
     M::Int64
@@ -677,6 +722,77 @@ function steps_to_next_output(w, tstep, start)
     ps = writer_periods(w)
     isempty(ps) && return typemax(Int32) ÷ 2
     return minimum(p - mod(tstep, p) for p in ps)
+end
+
+
+# ------------------------------------------------------------------------------------------------ Float32 hosts
+# Floe{FT} is generic (floe.jl:24) although only Float64 is tested and supported (documentation.md:25).  The library's `_f32` entry points
+# take the columns of a Floe{Float32} field as they lie, widen them on the way in, compute as for a Float64 host and round on the way out.
+# The column traffic of such a host: `upload32!` / `download32!` below (the process-mode boundary); the overloads of the three hot calls
+# above stay Float64 methods -- for a Float32 simulation they are the same bodies with these two in place of `upload!` / `download!`,
+# `sz_set_fields_f32` for the lattices and `sz_download_interactions_f32` for floe.interactions.
+struct Packed32
+    cols::SzFloeColumnsF32
+    keep::Vector{Any}                     # every flattened vector the pointers point into
+    status::Vector{Int32}
+end
+
+function pack32(floes::StructArray{<:Floe{Float32}}, n_parents::Integer)
+    M = length(floes)
+    cx = Float32[c[1] for c in floes.centroid]; cy = Float32[c[2] for c in floes.centroid]
+    coll_fx = Float32[f[1, 1] for f in floes.collision_force]; coll_fy = Float32[f[1, 2] for f in floes.collision_force]
+    sa = Vector{Float32}(undef, 4M); si = similar(sa); st = similar(sa)
+    for i in 1:M
+        sa[4i-3:4i] .= tensor4(floes.stress_accum[i]); si[4i-3:4i] .= tensor4(floes.stress_instant[i])
+        st[4i-3:4i] .= tensor4(floes.strain[i])
+    end
+    status = Int32[Int32(s.tag) for s in floes.status]
+    vert_off = Vector{Int32}(undef, M + 1); vert_off[1] = 0
+    vx = Float32[]; vy = Float32[]
+    for i in 1:M
+        for pt in GI.getpoint(GI.getexterior(floes.poly[i]))
+            push!(vx, GI.x(pt)); push!(vy, GI.y(pt))
+        end
+        vert_off[i+1] = length(vx)
+    end
+    sub_off = Vector{Int32}(undef, n_parents + 1); sub_off[1] = 0
+    sx = Float32[]; sy = Float32[]
+    for i in 1:n_parents
+        append!(sx, floes.x_subfloe_points[i]); append!(sy, floes.y_subfloe_points[i])
+        sub_off[i+1] = length(sx)
+    end
+    id = Vector{Int64}(floes.id); ghost_id = Vector{Int64}(floes.ghost_id)
+    c = SzFloeColumnsF32()
+    c.cx = pointer(cx); c.cy = pointer(cy)
+    c.rmax = pointer(floes.rmax); c.area = pointer(floes.area); c.height = pointer(floes.height)
+    c.mass = pointer(floes.mass); c.moment = pointer(floes.moment); c.alpha = pointer(floes.α)
+    c.u = pointer(floes.u); c.v = pointer(floes.v); c.xi = pointer(floes.ξ)
+    c.p_dxdt = pointer(floes.p_dxdt); c.p_dydt = pointer(floes.p_dydt); c.p_dalphadt = pointer(floes.p_dαdt)
+    c.p_dudt = pointer(floes.p_dudt); c.p_dvdt = pointer(floes.p_dvdt); c.p_dxidt = pointer(floes.p_dξdt)
+    c.fxOA = pointer(floes.fxOA); c.fyOA = pointer(floes.fyOA); c.trqOA = pointer(floes.trqOA)
+    c.hflx_factor = pointer(floes.hflx_factor); c.overarea = pointer(floes.overarea)
+    c.coll_fx = pointer(coll_fx); c.coll_fy = pointer(coll_fy); c.coll_trq = pointer(floes.collision_trq)
+    c.stress_accum = pointer(sa); c.stress_instant = pointer(si); c.strain = pointer(st)
+    c.id = pointer(id); c.ghost_id = pointer(ghost_id); c.status = pointer(status)
+    c.vert_off = pointer(vert_off); c.vx = pointer(vx); c.vy = pointer(vy)
+    c.sub_off = pointer(sub_off); c.sx = pointer(sx); c.sy = pointer(sy)
+    return Packed32(c, Any[cx, cy, coll_fx, coll_fy, sa, si, st, vert_off, vx, vy, sub_off, sx, sy, id, ghost_id], status)
+end
+
+function upload32!(eng::HIPEngine, floes::StructArray{<:Floe{Float32}}, n_parents)
+    P = pack32(floes, n_parents)
+    GC.@preserve P floes begin
+        check(eng, @ccall lib.sz_upload_floes_f32(eng.ctx::Ptr{Cvoid}, length(floes)::Int64, n_parents::Int64,
+                                                  P.cols::Ref{SzFloeColumnsF32})::Cint)
+    end
+    return P
+end
+
+function download32!(eng::HIPEngine, floes::StructArray{<:Floe{Float32}}, P::Packed32)
+    GC.@preserve P floes begin
+        check(eng, @ccall lib.sz_download_floes_f32(eng.ctx::Ptr{Cvoid}, P.cols::Ref{SzFloeColumnsF32})::Cint)
+    end
+    return
 end
 
 end # module

@@ -12,6 +12,7 @@ from . import build as _build
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 _lp = C.POINTER(C.c_int64)
+_fp = C.POINTER(C.c_float)
 
 OPEN, PERIODIC, COLLISION, MOVING = 0, 1, 2, 3
 NORTH, SOUTH, EAST, WEST = 0, 1, 2, 3
@@ -38,6 +39,15 @@ class SzFloeColumns(C.Structure):
                 [("id", _lp), ("ghost_id", _lp), ("status", _ip),
                  ("vert_off", _ip), ("vx", _dp), ("vy", _dp),
                  ("sub_off", _ip), ("sx", _dp), ("sy", _dp),
+                 ("ghost_off", _ip), ("ghost_idx", _ip)])
+
+
+class SzFloeColumnsF32(C.Structure):
+    """sz_floe_columns_f32: the columns of a Floe{Float32} host (the engine widens on the way in, rounds on the way out)"""
+    _fields_ = ([(n, _fp) for n in DCOLS] + [(n, _fp) for n in TCOLS] +
+                [("id", _lp), ("ghost_id", _lp), ("status", _ip),
+                 ("vert_off", _ip), ("vx", _fp), ("vy", _fp),
+                 ("sub_off", _ip), ("sx", _fp), ("sy", _fp),
                  ("ghost_off", _ip), ("ghost_idx", _ip)])
 
 
@@ -69,7 +79,7 @@ EXPORTS = [
     "sz_set_two_way", "sz_set_temps", "sz_download_ocean_stress", "sz_two_way_partial", "sz_two_way_finish", "sz_set_precision",
     "sz_eulerian_data", "sz_eulerian_partial", "sz_eulerian_finish", "sz_simplify_check",
     "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms", "sz_forcing_launch", "sz_narrow_kernel_name",
-    "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_forcing", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps", "sz_debug_crec_mismatches",
+    "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_forcing", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps", "sz_debug_crec_mismatches", "sz_upload_floes_f32", "sz_download_floes_f32", "sz_set_fields_f32", "sz_download_interactions_f32",
     "sz_get_boundary_rects", "sz_debug_match_vertices",
     "sz_comm_available", "sz_comm_unique_id", "sz_comm_init", "sz_comm_init_host", "sz_comm_destroy", "sz_comm_selftest", "sz_comm_allreduce", "sz_tile_setup", "sz_tile_set_center", "sz_tile_run", "sz_tile_migrate", "sz_download_subpoints",
 ]
@@ -110,6 +120,10 @@ def load(build_if_missing=True):
     L.sz_get_stats.argtypes = [C.c_void_p, C.POINTER(SzStats)]
     L.sz_download_floes.argtypes = [C.c_void_p, C.POINTER(SzFloeColumns)]
     L.sz_download_interactions.argtypes = [C.c_void_p, _ip, _dp]
+    L.sz_upload_floes_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(SzFloeColumnsF32)]
+    L.sz_download_floes_f32.argtypes = [C.c_void_p, C.POINTER(SzFloeColumnsF32)]
+    L.sz_set_fields_f32.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _fp, _fp, _fp, _fp, _fp]
+    L.sz_download_interactions_f32.argtypes = [C.c_void_p, _ip, _fp]
     L.sz_download_pairs.argtypes = [C.c_void_p, _ip, _ip]
     L.sz_download_fuse.argtypes = [C.c_void_p, _ip, _ip]
     L.sz_get_boundary_vals.argtypes = [C.c_void_p, _dp]

@@ -1170,6 +1170,80 @@ int sz_download_floes(sz_ctx* c, sz_floe_columns* f) {
   return SZ_OK;
 }
 
+// ---------------------------------------------------------------- Float32 hosts (include/subzero_hip.h: sz_floe_columns_f32)
+#define SZ_F32_SCALARS(X) X(cx) X(cy) X(rmax) X(area) X(height) X(mass) X(moment) X(alpha) X(u) X(v) X(xi) X(p_dxdt) X(p_dydt) X(p_dalphadt) \
+  X(p_dudt) X(p_dvdt) X(p_dxidt) X(fxOA) X(fyOA) X(trqOA) X(hflx_factor) X(overarea) X(coll_fx) X(coll_fy) X(coll_trq)
+#define SZ_F32_TENSORS(X) X(stress_accum) X(stress_instant) X(strain)
+int sz_upload_floes_f32(sz_ctx* c, int64_t M, int64_t N, const sz_floe_columns_f32* f) {
+  if (!c || !f || M < 0 || N < 0 || N > M) return SZ_E_ARG;
+  if (M > 0 && !f->vert_off) { c->err = "sz_upload_floes_f32: vert_off is required"; return SZ_E_ARG; }
+  const size_t V = M > 0 ? (size_t)f->vert_off[M] : 0, NS = (f->sub_off && N > 0) ? (size_t)f->sub_off[N] : 0;
+  std::vector<std::vector<double>> keep;
+  auto widen = [&](const float* src, size_t n) -> double* {
+    if (!src) return nullptr;
+    keep.emplace_back(n ? n : 1);
+    for (size_t k = 0; k < n; k++) keep.back()[k] = (double)src[k];
+    return keep.back().data();
+  };
+  sz_floe_columns d; memset(&d, 0, sizeof(d));
+#define X(name) d.name = widen(f->name, (size_t)M);
+  SZ_F32_SCALARS(X)
+#undef X
+#define X(name) d.name = widen(f->name, (size_t)4 * M);
+  SZ_F32_TENSORS(X)
+#undef X
+  d.id = f->id; d.ghost_id = f->ghost_id; d.status = f->status; d.vert_off = f->vert_off; d.sub_off = f->sub_off; d.ghost_off = f->ghost_off; d.ghost_idx = f->ghost_idx;
+  d.vx = widen(f->vx, V); d.vy = widen(f->vy, V); d.sx = widen(f->sx, NS); d.sy = widen(f->sy, NS);
+  return sz_upload_floes(c, M, N, &d);
+}
+int sz_download_floes_f32(sz_ctx* c, sz_floe_columns_f32* f) {
+  if (!c || !f) return SZ_E_ARG;
+  sz_stats st;
+  int rc = sz_get_stats(c, &st); if (rc) return rc;
+  const size_t M = (size_t)st.M, V = (size_t)st.n_ring_points, NS = (size_t)st.n_sub_points;
+  std::vector<std::vector<double>> keep;
+  struct Back { float* dst; double* src; size_t n; }; std::vector<Back> back;
+  auto room = [&](float* dst, size_t n) -> double* {
+    if (!dst) return nullptr;
+    keep.emplace_back(n ? n : 1);
+    back.push_back({ dst, keep.back().data(), n });
+    return keep.back().data();
+  };
+  sz_floe_columns d; memset(&d, 0, sizeof(d));
+#define X(name) d.name = room(f->name, M);
+  SZ_F32_SCALARS(X)
+#undef X
+#define X(name) d.name = room(f->name, 4 * M);
+  SZ_F32_TENSORS(X)
+#undef X
+  d.id = f->id; d.ghost_id = f->ghost_id; d.status = f->status; d.vert_off = f->vert_off; d.sub_off = f->sub_off; d.ghost_off = f->ghost_off; d.ghost_idx = f->ghost_idx;
+  d.vx = room(f->vx, V); d.vy = room(f->vy, V); d.sx = room(f->sx, NS); d.sy = room(f->sy, NS);
+  rc = sz_download_floes(c, &d); if (rc) return rc;
+  for (const Back& b : back) for (size_t k = 0; k < b.n; k++) b.dst[k] = (float)b.src[k];
+  return SZ_OK;
+}
+int sz_set_fields_f32(sz_ctx* c, int32_t Nx, int32_t Ny, double x0, double xf, double y0, double yf, const float* uocn, const float* vocn,
+                      const float* hflx, const float* uatm, const float* vatm) {
+  if (!c || Nx < 1 || Ny < 1) return SZ_E_ARG;
+  const size_t n = (size_t)(Nx + 1) * (Ny + 1);
+  std::vector<double> a[5]; const float* src[5] = { uocn, vocn, hflx, uatm, vatm };
+  for (int k = 0; k < 5; k++) if (src[k]) { a[k].resize(n); for (size_t q = 0; q < n; q++) a[k][q] = (double)src[k][q]; }
+  auto p = [&](int k) { return src[k] ? a[k].data() : (const double*)nullptr; };
+  return sz_set_fields(c, Nx, Ny, x0, xf, y0, yf, p(0), p(1), p(2), p(3), p(4));
+}
+int sz_download_interactions_f32(sz_ctx* c, int32_t* off, float* rows) {
+  if (!c || !off) return SZ_E_ARG;
+  sz_stats st;
+  int rc = sz_get_stats(c, &st); if (rc) return rc;
+  rc = sz_download_interactions(c, off, nullptr); if (rc) return rc;          // the offsets first: off[M] = rows in all
+  const size_t total = (size_t)off[st.M];
+  if (!rows || total == 0) return SZ_OK;
+  std::vector<double> r(total * 7);
+  rc = sz_download_interactions(c, off, r.data()); if (rc) return rc;
+  for (size_t k = 0; k < total * 7; k++) rows[k] = (float)r[k];
+  return SZ_OK;
+}
+
 int sz_download_interactions(sz_ctx* c, int32_t* off, double* rows) {
   if (!c || !off || !c->have_floes) return SZ_E_ARG;
   (void)hipSetDevice(c->device);

@@ -27,7 +27,11 @@ _I64 = np.int64
 
 
 class World:
-    def __init__(self, device=0):
+    def __init__(self, device=0, ftype=np.float64):
+        """ftype = numpy.float32: a Floe{Float32} host -- the columns cross the boundary as floats (sz_*_f32); the engine computes in double
+        all the same, and this class keeps its own copies as float64 holding the rounded values"""
+        self._ft = np.dtype(ftype)
+        assert self._ft in (np.dtype(np.float64), np.dtype(np.float32))
         self.L = capi.load()
         self.h = self.L.sz_create(int(device))
         if not self.h:
@@ -109,9 +113,10 @@ class World:
                                            capi.ptr(cx), capi.ptr(cy), capi.ptr(rm)))
 
     def set_grid_fields(self, Nx, Ny, x0, xf, y0, yf, uo, vo, hflx, ua, va):
-        arrs = [np.ascontiguousarray(np.broadcast_to(a, (Nx + 1, Ny + 1)), np.float64) for a in (uo, vo, hflx, ua, va)]
-        self._chk(self.L.sz_set_fields(self.h, int(Nx), int(Ny), float(x0), float(xf), float(y0), float(yf),
-                                       *(capi.ptr(a) for a in arrs)))
+        arrs = [np.ascontiguousarray(np.broadcast_to(a, (Nx + 1, Ny + 1)), self._ft) for a in (uo, vo, hflx, ua, va)]
+        f32 = self._ft == np.float32
+        fn = self.L.sz_set_fields_f32 if f32 else self.L.sz_set_fields
+        self._chk(fn(self.h, int(Nx), int(Ny), float(x0), float(xf), float(y0), float(yf), *(capi.ptr(a, capi._fp if f32 else capi._dp) for a in arrs)))
         self._grid = (int(Nx), int(Ny))
 
     def set_precision(self, mode):
@@ -190,15 +195,17 @@ class World:
 
     # ------------------------------------------------------------------ host <-> device
     def _columns_struct(self, col, keep):
-        f = capi.SzFloeColumns()
+        f32 = self._ft == np.float32
+        f = capi.SzFloeColumnsF32() if f32 else capi.SzFloeColumns()
+        pt = capi._fp if f32 else capi._dp
         for n in capi.DCOLS + ["vx", "vy", "sx", "sy"]:
             a = col.get(n)
             if a is not None:
-                a = np.ascontiguousarray(a, np.float64); keep.append(a); setattr(f, n, capi.ptr(a))
+                a = np.ascontiguousarray(a, self._ft); keep.append(a); setattr(f, n, capi.ptr(a, pt))
         for n in capi.TCOLS:
             a = col.get(n)
             if a is not None:
-                a = np.ascontiguousarray(a, np.float64).reshape(-1); keep.append(a); setattr(f, n, capi.ptr(a))
+                a = np.ascontiguousarray(a, self._ft).reshape(-1); keep.append(a); setattr(f, n, capi.ptr(a, pt))
         for n in ("id", "ghost_id"):
             a = col.get(n)
             if a is not None:
@@ -230,7 +237,7 @@ class World:
             self._sub = {}
         keep = []
         f = self._columns_struct(col, keep)
-        self._chk(self.L.sz_upload_floes(self.h, int(self._M), int(self.N), C.byref(f)))
+        self._chk((self.L.sz_upload_floes_f32 if self._ft == np.float32 else self.L.sz_upload_floes)(self.h, int(self._M), int(self.N), C.byref(f)))
         self._dirty = False; self._host_stale = False
         if getattr(self, "_new_field", False):
             off = np.zeros(self._M + 1, _I32)
@@ -254,15 +261,19 @@ class World:
             return
         st = self.stats()
         M, V = st["M"], st["n_ring_points"]
-        col = {n: np.zeros(M) for n in capi.DCOLS}
+        col = {n: np.zeros(M, self._ft) for n in capi.DCOLS}
         for n in capi.TCOLS:
-            col[n] = np.zeros((M, 4))
+            col[n] = np.zeros((M, 4), self._ft)
         col["id"] = np.zeros(M, _I64); col["ghost_id"] = np.zeros(M, _I64); col["status"] = np.zeros(M, _I32)
-        col["vert_off"] = np.zeros(M + 1, _I32); col["vx"] = np.zeros(V); col["vy"] = np.zeros(V)
+        col["vert_off"] = np.zeros(M + 1, _I32); col["vx"] = np.zeros(V, self._ft); col["vy"] = np.zeros(V, self._ft)
         col["ghost_off"] = np.zeros(M + 1, _I32); col["ghost_idx"] = np.zeros(max(3 * M, 1), _I32)
         keep = []
         f = self._columns_struct(col, keep)
-        self._chk(self.L.sz_download_floes(self.h, C.byref(f)))
+        self._chk((self.L.sz_download_floes_f32 if self._ft == np.float32 else self.L.sz_download_floes)(self.h, C.byref(f)))
+        if self._ft == np.float32:          # (this class keeps float64 copies: the rounded values)
+            for n in list(col):
+                if col[n].dtype == np.float32:
+                    col[n] = col[n].astype(np.float64)
         for n in ("sub_off", "sx", "sy"):
             if n in self.col:
                 col[n] = self.col[n]
@@ -317,8 +328,12 @@ class World:
     def interactions(self):
         self._push()
         st = self.stats()
-        off = np.zeros(st["M"] + 1, _I32); rows = np.zeros((max(st["n_inter_rows"], 1), 7))
-        self._chk(self.L.sz_download_interactions(self.h, capi.ptr(off, capi._ip), capi.ptr(rows)))
+        off = np.zeros(st["M"] + 1, _I32); rows = np.zeros((max(st["n_inter_rows"], 1), 7), self._ft)
+        if self._ft == np.float32:
+            self._chk(self.L.sz_download_interactions_f32(self.h, capi.ptr(off, capi._ip), capi.ptr(rows, capi._fp)))
+            rows = rows.astype(np.float64)
+        else:
+            self._chk(self.L.sz_download_interactions(self.h, capi.ptr(off, capi._ip), capi.ptr(rows)))
         return off, rows[:off[-1]]
 
     def inter(self, i):

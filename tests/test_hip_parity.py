@@ -621,6 +621,32 @@ def test_collision_records_stay_current(kind):
         assert hw.stats()["n_ghosts"] > 0
 
 
+def test_float32_host_boundary():
+    """The _f32 instantiation of the boundary (sz_upload_floes_f32, sz_download_floes_f32, sz_set_fields_f32, sz_download_interactions_f32:
+    SURVEY section 8b; Floe{FT} is generic, floe.jl:24).  documentation.md:25 supports Float64 only -- there are no Float32 answers -- so the
+    contract is: columns are widened on the way in, the engine computes as for a Float64 host, results are rounded on the way out.  A
+    Float32 host must therefore get exactly the Float64 host's results for the same (float-representable) inputs, rounded once."""
+    import subzero_jl_amd
+    from subzero_jl_amd import fields, capi
+    r32 = lambda a: np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
+    cfg = fields.make_config(n_floes=600, seed=31, concentration=0.8, ocean="converge_diverge")
+    for k in ("vx", "vy", "sx", "sy", "u", "v", "xi", "uo", "vo", "hf", "ua", "va"):
+        cfg[k] = r32(cfg[k])
+    cfg["derived"] = {k: (r32(v) if np.asarray(v).dtype == np.float64 else v) for k, v in cfg["derived"].items()}
+    w32 = fields.build_world(subzero_jl_amd.World(0, np.float32), cfg)
+    w64 = fields.build_world(subzero_jl_amd.World(0), cfg)
+    for w in (w32, w64):
+        assert w.run(6, 0, cfg["dt"], coupling_dt=1, stop_on_tags=False) == 6
+    for f in parity.SCALARS + ["fxOA", "fyOA", "trqOA", "coll_fx", "coll_fy", "coll_trq", "overarea"]:
+        a, b = w32.get(f), w64.get(f)
+        assert np.array_equal(a, r32(b)), f
+    assert not np.array_equal(w64.get("cx"), r32(w64.get("cx")))          # (the Float64 host's columns really carry more digits)
+    o32, x32, y32 = w32.rings(); o64, x64, y64 = w64.rings()
+    assert np.array_equal(o32, o64) and np.array_equal(x32, r32(x64)) and np.array_equal(y32, r32(y64))
+    i32, i64 = w32.interactions(), w64.interactions()
+    assert np.array_equal(i32[0], i64[0]) and i64[0][-1] > 100 and np.array_equal(i32[1], r32(i64[1]))
+
+
 def test_one_step_batches_match_the_oracle():
     """timestep_sim! called step by step (batches of one resident step each, nothing in between): what a batch leaves
     behind -- cell lists, ghost bookkeeping of its last integrator -- must not leak into the next one"""

@@ -113,7 +113,7 @@ def test_julia_struct_mirrors_match_the_header(tmp_path):
     tr = js.pop("SzHostTransport")
     assert [f for f, _ in tr] == ["user", "allgather", "sendrecv", "allreduce_sum_f64"] and all(t == "Ptr{Cvoid}" for _, t in tr)
     assert ctypes.sizeof(capi.SzHostTransport) == 32 and [f for f, _ in capi.SzHostTransport._fields_] == [f for f, _ in tr]
-    cnames = {"SzParams": "sz_params", "SzFloeColumns": "sz_floe_columns", "SzStats": "sz_stats"}
+    cnames = {"SzParams": "sz_params", "SzFloeColumns": "sz_floe_columns", "SzFloeColumnsF32": "sz_floe_columns_f32", "SzStats": "sz_stats"}
     assert set(js) == set(cnames)
     size_of = {"Float64": 8, "Int64": 8, "Int32": 4}
     hdr = open(os.path.join(ROOT, "include", "subzero_hip.h")).read()
@@ -143,7 +143,7 @@ def test_julia_struct_mirrors_match_the_header(tmp_path):
     assert [g for g in got if g] == expect
     # ... and the ctypes mirrors of the Python binding agree with the same C layout
     assert ctypes.sizeof(capi.SzParams) == int(expect[[e.split()[0] for e in expect].index("sz_params")].split()[1])
-    assert ctypes.sizeof(capi.SzFloeColumns) == 39 * 8 and ctypes.sizeof(capi.SzStats) == 29 * 8
+    assert ctypes.sizeof(capi.SzFloeColumns) == 39 * 8 and ctypes.sizeof(capi.SzFloeColumnsF32) == 39 * 8 and ctypes.sizeof(capi.SzStats) == 29 * 8
 
 
 def test_julia_shim_binds_existing_symbols():
