@@ -3,6 +3,9 @@
 // sz_kernels.hpp / sz_geom.hpp.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -734,7 +737,10 @@ int gi_fetch(sz_ctx* c) {
 int host_fuse_fixup(sz_ctx* c, const int* h, bool mirror, bool after_step = false, bool coupled = false, const std::vector<long long>* tkeys = nullptr) {
   State& S = c->S;
   int M = after_step ? h[C_N] + h[C_NGHOSTS] : h[C_M];
-  if (tkeys) c->fuse_lists.assign(M, {});          // (they describe the step that ended this batch)
+  // A resident batch's lists describe the step that ended it, and only that step: whatever earlier batches left in them is dropped.  (The
+  // reference's simplify_floes! consumes status.fuse_idx after every step; batches that run on past a fuse -- SZ_NO_STOP, measurement runs --
+  // would otherwise replay lists that name the ghost numbers of older steps.)
+  if (tkeys || after_step) c->fuse_lists.assign(M, {});
   if ((int)c->fuse_lists.size() < M) c->fuse_lists.resize(M);
   if (h[C_NFUSE] == 0 || M == 0) return SZ_OK;          // no pair asked for a fuse (the narrow phase counts them)
   // the pairs in the reference's serial order (i asc, j asc): per floe its sorted list of owned pairs
@@ -760,13 +766,17 @@ int host_fuse_fixup(sz_ctx* c, const int* h, bool mirror, bool after_step = fals
   for (int ii = 0; ii < M; ii++) {
     const int i = sto[ii];
     for (int r = 0; r < nout[i]; r++)
-      if ((info[(size_t)i * MAXNB + r].x >> 8) & IT_FUSE) c->fuse_lists[ii].push_back(ref[nbo[(size_t)i * MAXNB + r]]);
+      if ((info[(size_t)i * MAXNB + r].x >> 8) & IT_FUSE) { const int pj = nbo[(size_t)i * MAXNB + r]; if (pj >= 0 && pj < M) c->fuse_lists[ii].push_back(ref[pj]); }
   }
   if (mirror) {
     for (int ii = 0; ii < M; ii++) {
       if (tag[sto[ii]] != SZ_FUSE) continue;
       size_t n = c->fuse_lists[ii].size();
-      for (size_t k = 0; k < n; k++) { int idx = c->fuse_lists[ii][k]; tag[sto[idx]] = SZ_FUSE; c->fuse_lists[idx].push_back(ii); }
+      for (size_t k = 0; k < n; k++) {
+        const int idx = c->fuse_lists[ii][k];
+        if (idx < 0 || idx >= M) continue;          // (a partner number of a step whose ghosts are gone: process-mode lists accumulate like the reference's)
+        tag[sto[idx]] = SZ_FUSE; c->fuse_lists[idx].push_back(ii);
+      }
     }
   }
   if (after_step && coupled) {
@@ -777,7 +787,7 @@ int host_fuse_fixup(sz_ctx* c, const int* h, bool mirror, bool after_step = fals
   HIPCHK(c, hipMemcpy(S.status, tag.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice));
   if (tkeys && (int)tkeys->size() == M) {          // back to storage rows (index and values)
     std::vector<std::vector<int>> byrow(M);
-    for (int r = 0; r < M; r++) { byrow[sto[r]] = c->fuse_lists[r]; for (int& v : byrow[sto[r]]) v = sto[v]; }
+    for (int r = 0; r < M; r++) { byrow[sto[r]] = c->fuse_lists[r]; for (int& v : byrow[sto[r]]) v = v >= 0 && v < M ? sto[v] : v; }
     c->fuse_lists.swap(byrow);
   }
   return SZ_OK;
@@ -790,7 +800,19 @@ extern "C" {
 
 const char* sz_version(void) { return "subzero-hip 0.1 (gfx950)"; }
 
+// SZ_BACKTRACE=1 (diagnosis of a host-side crash on a box without a debugger): SIGSEGV / SIGABRT print the C frames (module + offset: resolve with
+// addr2line -e libsubzero_hip.so <offset>) before the process dies
+static void sz_crash_handler(int sig) {
+  signal(SIGALRM, SIG_DFL); alarm(2);          // (a handler that gets stuck -- the heap's lock may be held -- still ends the process)
+  void* fr[64];
+  const int n = backtrace(fr, 64);
+  const char msg[] = "[subzero-hip] fatal signal, C frames:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(fr, n, 2);
+  signal(sig, SIG_DFL); raise(sig);
+}
 sz_ctx* sz_create(int device_id) {
+  if (getenv("SZ_BACKTRACE")) { void* warm[4]; (void)backtrace(warm, 4); signal(SIGSEGV, sz_crash_handler); signal(SIGABRT, sz_crash_handler); }      // (the first backtrace() loads its library: not inside a handler)
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id >= n) return nullptr;
   if (hipSetDevice(device_id) != hipSuccess) return nullptr;
@@ -2598,7 +2620,7 @@ int tile_fuse_replay(sz_ctx* c, const int* h, bool last_coupled) {
   if (rc) return rc;
   const long long lim = (long long)1 << 40;
   for (int i = 0; i < c->hostN && i < (int)c->fuse_lists.size(); i++)
-    for (int& v : c->fuse_lists[i]) { long long key = keys[v]; if (key >= lim) key = (key & (lim - 1)) >> 2; v = (int)key; }
+    for (int& v : c->fuse_lists[i]) { if (v < 0 || v >= (int)keys.size()) continue; long long key = keys[v]; if (key >= lim) key = (key & (lim - 1)) >> 2; v = (int)key; }
   return SZ_OK;
 }
 }  // namespace
