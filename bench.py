@@ -379,7 +379,7 @@ def main():
                     "over the host channel (sz_comm_init_host): runs the whole multi-rank flow of this script on a one-GPU box; the "
                     "line it prints says so and is NOT a measurement")
     ap.add_argument("--force-tiled", action="store_true", help="run the halo/RCCL path even with one rank")
-    ap.add_argument("--watchdog", type=float, default=900.0, help="self-launched N > 1 runs: seconds without a line from ANY rank after which the "
+    ap.add_argument("--watchdog", type=float, default=300.0, help="self-launched N > 1 runs: seconds without a line from ANY rank after which the "
                     "parent kills the ranks and exits non-zero")
     ap.add_argument("--no-strong-reference", action="store_true", help="N = 1: skip the extra leg that times the multi-GPU workload (configs[2], 100 000 floes) "
                     "in one context on this GPU -- the denominator of the strong-scaling curve, which the N > 1 lines are measured on")
