@@ -90,6 +90,8 @@ struct GroupMem {
   uint8_t rna, rnb; int8_t roa, rob;         // ring sizes and orientation signs of the item
   int8_t nchk, nkeep;
   uint8_t nsig;                              // crossings of the contact clip (entries of sga / sgb / sgf)
+  uint8_t lists_ok, fullnow;                 // ea / eb / nea / neb are still the CONTACT clip's (no later clip in this memory has rebuilt them); this group
+                                             // runs a clip that rebuilds them in the current pass -- see clip(.., reuse) and the narrow kernel's pass loop
 };
 static_assert(sizeof(GroupMem<18, 8, 16, 4>) <= 2048, "eight groups of the first narrow variant must fit 16 KB");
 
@@ -264,8 +266,11 @@ SZ_DEV double gmax(double v) { for (int d = G / 2; d >= 1; d >>= 1) v = fmax(v, 
 // detect_only: stop after the crossing detection (m.nraw raw crossings in m.ria / m.rib / m.rfl, unordered) -- what the certified
 // direction check needs of the translated polygon; nothing but the raw slots and the candidate-edge lists of `m` is written
 template <int G, class MEM>
+// reuse (detect-only clips of a direction check): the candidate edges are the contact clip's, still standing in the OWNER's memory (`ring`) --
+// the contact clip selects them with the overlap box grown by 2 m, which covers every translation of ring a by a unit vector (the box
+// moves by at most 1 m, the edges of a by at most 1 m), and a superset of candidates changes no result: the crossing test is exact
 SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, int oa, int nb, int ob, int buf, const Box& ba, const Box& bb,
-                 Stamps& st, bool detect_only = false) {
+                 Stamps& st, bool detect_only = false, bool reuse = false) {
   using roff_t = typename MEM::roff_t;
   constexpr int KC = sizeof(m.cta) / sizeof(double);
   constexpr int RC = sizeof(m.ecode);
@@ -273,20 +278,21 @@ SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, 
   static_assert(KC <= 64 && sizeof(m.ea) <= 255, "crossing ranks travel in 6 bits, edge indices and ring sizes in 8");
   const double* pax = ring.ax; const double* pay = ring.ay; const double* pbx = ring.bx; const double* pby = ring.by;
   double* rgx = m.reg[buf][0]; double* rgy = m.reg[buf][1];
-  if (gl == 0) { m.nraw = 0; m.nea = 0; m.neb = 0; if (!detect_only) { m.nreg[buf] = 0; m.roff[buf][0] = 0; } }
+  if (gl == 0) { m.nraw = 0; if (!reuse) { m.nea = 0; m.neb = 0; } if (!detect_only) { m.nreg[buf] = 0; m.roff[buf][0] = 0; } }
   if (na < 4 || nb < 4) { if (gl == 0 && !detect_only) m.nx = 0; gsync(); return; }
   // bounding boxes are kept per floe (min/max commute with the rounding of `+ ox`, so the box of
   // the translated ring is the translated box, bit for bit)
   const double ax0 = ba.x0 + ox, ax1 = ba.x1 + ox, ay0 = ba.y0 + oy, ay1 = ba.y1 + oy;
   if (ax1 < bb.x0 || bb.x1 < ax0 || ay1 < bb.y0 || bb.y1 < ay0) { if (gl == 0 && !detect_only) m.nx = 0; gsync(); return; }
   // overlap box: a crossing point lies in both rings' boxes, so only edges that reach into it can cross
-  const double qx0 = fmax(ax0, bb.x0), qx1 = fmin(ax1, bb.x1), qy0 = fmax(ay0, bb.y0), qy1 = fmin(ay1, bb.y1);
+  const double grow = buf == 0 ? 2.0 : 0.0;          // (the contact clip's candidates also serve the direction checks: see `reuse`)
+  const double qx0 = fmax(ax0, bb.x0) - grow, qx1 = fmin(ax1, bb.x1) + grow, qy0 = fmax(ay0, bb.y0) - grow, qy1 = fmin(ay1, bb.y1) + grow;
   gsync();
-  for (int ia = gl; ia + 1 < na; ia += G) {
+  for (int ia = gl; ia + 1 < na && !reuse; ia += G) {
     double px = pax[ia] + ox, py = pay[ia] + oy, rx = pax[ia + 1] + ox, ry = pay[ia + 1] + oy;
     if (fmax(px, rx) >= qx0 && fmin(px, rx) <= qx1 && fmax(py, ry) >= qy0 && fmin(py, ry) <= qy1) m.ea[atomicAdd(&m.nea, 1)] = (uint8_t)ia;
   }
-  for (int ib = gl; ib + 1 < nb; ib += G) {
+  for (int ib = gl; ib + 1 < nb && !reuse; ib += G) {
     double px = pbx[ib], py = pby[ib], rx = pbx[ib + 1], ry = pby[ib + 1];
     if (fmax(px, rx) >= qx0 && fmin(px, rx) <= qx1 && fmax(py, ry) >= qy0 && fmin(py, ry) <= qy1) m.eb[atomicAdd(&m.neb, 1)] = (uint8_t)ib;
   }
@@ -297,10 +303,11 @@ SZ_DEV void clip(const MEM& ring, MEM& m, int gl, double ox, double oy, int na, 
   // afterwards, once per crossing (phase 2).
   double* raw = m.reg[1][0];
   {
-    const int ca = m.nea, cb = m.neb, tot = ca * cb;
+    const uint8_t* lea = reuse ? ring.ea : m.ea; const uint8_t* leb = reuse ? ring.eb : m.eb;
+    const int ca = reuse ? ring.nea : m.nea, cb = reuse ? ring.neb : m.neb, tot = ca * cb;
     for (int t = gl; t < tot; t += G) {
       int ua = t / cb, ub = t - ua * cb;
-      int ia = m.ea[ua], ib = m.eb[ub];
+      int ia = lea[ua], ib = leb[ub];
       double px = pax[ia] + ox, py = pay[ia] + oy, qx = pax[ia + 1] + ox, qy = pay[ia + 1] + oy;
       double rx = pbx[ib], ry = pby[ib], sx = pbx[ib + 1], sy = pby[ib + 1];
       int sp = side_a_vs_b(rx, ry, sx, sy, px, py), sq = side_a_vs_b(rx, ry, sx, sy, qx, qy);

@@ -1812,7 +1812,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
 #endif
       pna = na; pnb = nb; poa = oa; pob = ob; pba = ba; pbb = bb;
       contact_pre(m, gl, na, oa, nb, ob, ba, bb);
-    } else if (gl == 0) { m.nkeep = 0; m.nchk = 0; m.ierr = 0; }
+    } else if (gl == 0) { m.nkeep = 0; m.nchk = 0; m.ierr = 0; m.lists_ok = 0; }
     // ================= phases A (pass 0: the contact clip of the own item) and B (passes 1..: the direction checks of ALL
     // items of the wavefront, one per lane group and pass -- an item with two or three contact regions no longer works its
     // checks off one after the other while the other groups idle: 14 % of the wavefronts hold such an item, and they used
@@ -1844,12 +1844,25 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
         // A check of a lens-shaped region first tries to do without the second clip: only the crossing detection of the translated polygon
         // (clip(.., detect_only)), then certified_check(); the full clip + check_post follow when that cannot settle the sign.  One call
         // site of clip() for all of it (the turns of one loop: the routine exists once in the instruction stream).
+        // The certified attempt (detect-only clip + certified_check) takes its candidate edges from the contact clip's lists in the OWNER's
+        // memory, and is only made while they still stand there: no later clip has rebuilt them (lists_ok), and the owner group does not
+        // rebuild them at this very turn of the loop (fullnow: a check that is not certifiable is a full clip in the owner group's own memory
+        // at attempt 0, at the same instructions).  Everything else -- not certifiable, lists gone, attempt failed -- is the full clip, which
+        // rebuilds the lists of the memory it works in; for a certifiable check that happens at attempt 1, when every reader of attempt 0 is done.
+        bool try_cert = false;
+        if (pass > 0) {
+          if (gl == 0) m.fullnow = (run && !cert) ? 1 : 0;
+          gsync();
+          try_cert = run && cert && mem[g].lists_ok != 0 && mem[g].fullnow == 0;
+        }
         bool settled = false;
         for (int att = 0;; att++) {
-          const bool detect = run && cert && att == 0;
-          if (run) clip<G>(mem[g], m, gl, ox, oy, pna, poa, pnb, pob, buf, pba, pbb, st, detect);
+          const bool detect = try_cert && att == 0;
+          const bool full = run && !detect && (att == 1 || !cert);
+          if (detect || full) clip<G>(mem[g], m, gl, ox, oy, pna, poa, pnb, pob, buf, pba, pbb, st, detect, detect);
+          if (full && gl == 0) m.lists_ok = pass == 0 ? 1 : 0;      // (this clip has rebuilt the candidate lists of the memory it worked in)
           if (detect) { settled = certified_check<G>(mem[g], m, gl, q); STAMP(st, 14); }
-          if (!detect || settled) break;
+          if (att == 1 || !run || !cert || settled) break;
         }
         if (pass > 0 && run && gl == 0) { m.acc16[3]++; if (settled) m.acc16[4]++; }
 #ifdef SZ_STAMPS
@@ -1857,7 +1870,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
 #endif
         if (pass == 0) {
           if (run) contact_post<G>(m, gl, na, nb, ic, flags, st);
-          else if (have && gl == 0) { m.nkeep = 0; m.nchk = 0; m.ierr = 0; m.ff = 0.0; }
+          else if (have && gl == 0) { m.nkeep = 0; m.nchk = 0; m.ierr = 0; m.ff = 0.0; m.lists_ok = 0; }
           gsync();
           for (int k = 0; k < GPB; k++) total += mem[k].nchk;
 #ifdef SZ_STAMPS
