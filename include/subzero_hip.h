@@ -350,11 +350,18 @@ int sz_tile_run(sz_ctx *ctx, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t
    tiles over the domain of sz_set_domain, tile (ix, iy) = rank iy * px + ix; owner_override (may be NULL; one entry per owned floe, in
    the order of the last upload) names the new owner rank instead.  Floes that change tile travel with their complete state (all columns,
    tensors, status, ring, sub-floe points) over the library's channel (RCCL or the host transport); the context is then rebuilt from the
-   kept and the received floes, ordered by global index, exactly as an upload + sz_tile_enable + sz_tile_setup (same parameters) would --
-   host-staged inside the library: a rare operation.  *n_sent = floes this rank gave away, *n_owned = floes it owns now (the `id`
-   column of sz_download_floes names them: the host's own copies of the columns are stale).  floe.interactions do not travel.
+   kept and the received floes, ordered by global index, exactly as an upload + sz_tile_enable + sz_tile_setup (same parameters) would.
+   The movers are packed on the device, one stream per destination, travel device to device (RCCL grouped send / receive; a host
+   transport stages those streams only) and the rows are gathered into their new order on the device: the host sees the owner and
+   offset columns and a directory of what arrived, no floe data (csrc/sz_migrate.hpp).  The capacities of the last upload stay; a
+   tile that would crowd them (more than 1/8 above what that upload held, on any rank) is rebuilt through a download and an upload
+   instead -- the host-staged path, on every rank (SZ_MIGRATE_HOST=1 forces it; sz_debug_migrate_path: 1 device, 2 host-staged).
+   *n_sent = floes this rank gave away, *n_owned = floes it owns now (sz_tile_owned_gidx names them; the host's own copies of the
+   columns are stale).  floe.interactions do not travel.
    sz_download_subpoints: the sub-floe points of the floes the context holds (off: N + 1 entries; sx == NULL: offsets only). */
 int sz_tile_migrate(sz_ctx *ctx, int32_t px, int32_t py, const int32_t *owner_override, int64_t *n_sent, int64_t *n_owned);
+int sz_tile_owned_gidx(sz_ctx *ctx, int64_t *gidx, int64_t n_cap);
+int sz_debug_migrate_path(sz_ctx *ctx);
 int sz_download_subpoints(sz_ctx *ctx, int32_t *off, double *sx, double *sy);
 
 /* ---- output path on the resident state

@@ -16,6 +16,7 @@
 #include "sz_kernels.hpp"
 #include "sz_twoway.hpp"
 #include "sz_output.hpp"
+#include "sz_migrate.hpp"
 #include <rocprim/rocprim.hpp>      // device radix sort of the output-grid entries (sz_eulerian_data)
 
 using namespace sz;
@@ -134,6 +135,9 @@ struct sz_ctx {
   int halo_cap = 0; std::vector<int> cap_send, cap_recv;      // slots per peer region (stride) and what is really sent to / received from each peer
   double tile_Lx = 0, tile_Ly = 0, tile_margin = 0; int tile_per_x = 0, tile_per_y = 0, tile_rebox_every = 50, tile_since_box = -1, tile_rebox_cur = 8, tile_dt = 0; bool tile_rebox_fixed = false;    // rebox_cur: the gather interval in use (<= rebox_every, from the measured drift)
   Pool tw_part_allocs; double* d_tw_partial = nullptr;
+  Pool mig_allocs;                  // scratch of sz_tile_migrate (streams, directory, the gathered rows): kept between migrations
+  Pool sub_allocs;                  // sub-floe points of a tile that outgrew State::capS in a migration (sz_tile_migrate): until the next upload
+  int migrate_path = 0;             // how the last sz_tile_migrate ran: 1 packed on the device, 2 staged through the host (sz_debug_migrate_path)
   std::vector<long long> tile_gidx; // global index of every owned floe (sz_tile_enable): status.fuse_idx of a tiled context is reported in global numbers
   bool tile_inline_off = false;     // SZ_TILE_INLINE=0: the tiled steps of sz_tile_run keep the list-based ghost pass, their own forcing launch and the one-workgroup unpack (A/B)
   double tile_box_ctr[2] = { 0, 0 }; bool tile_box_valid = false;   // centre of this rank's owned box at the last gather (sz_k_owned_box: periodic images)
@@ -858,7 +862,7 @@ void sz_destroy(sz_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   free_pool(c->allocs); free_pool(c->list_allocs); free_pool(c->inter_allocs); free_pool(c->static_allocs); free_pool(c->field_allocs); free_pool(c->tw_allocs); free_pool(c->tw_field_allocs);
-  free_pool(c->mixed_pt_allocs); free_pool(c->mixed_node_allocs); free_pool(c->mixed_geom_allocs); free_pool(c->comm_allocs); free_pool(c->tw_part_allocs);
+  free_pool(c->mixed_pt_allocs); free_pool(c->mixed_node_allocs); free_pool(c->mixed_geom_allocs); free_pool(c->comm_allocs); free_pool(c->tw_part_allocs); free_pool(c->sub_allocs); free_pool(c->mig_allocs);
   (void)sz_comm_destroy(c);
   for (auto& e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   (void)hipFree(c->d_stats); (void)hipFree(c->S.acc);
@@ -1000,6 +1004,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->gi_pending && c->gi_valid) { int rc0 = gi_fetch(c); if (rc0) return rc0; }      // (the key tables go with the pool; the rows may stay)
   c->gi_pending = false;
+  free_pool(c->sub_allocs);
   reset_pool(c->allocs);       // the chunks of the previous upload are carved again (a shim uploads before every replaced call)
   State& S = c->S;
   const int M = (int)M64, N = (int)N64;
@@ -2222,11 +2227,12 @@ int tile_rebox(sz_ctx* c) {
       cap = std::max(cap, k);
     }
   if (cap > c->halo_cap || !c->d_send) {
-    free_pool(c->comm_allocs);
+    reset_pool(c->comm_allocs);          // (chunks that are large enough are carved again: a set-up after a migration allocates nothing)
     c->halo_cap = cap;
     const size_t nd = (size_t)n * (cap + 1) * HALO_REC;
     if ((rc = dalloc(c, &c->d_send, nd, c->comm_allocs)) || (rc = dalloc(c, &c->d_recv, nd, c->comm_allocs)) ||
         (rc = dalloc(c, &c->d_ref, (size_t)2 * S.capM, c->comm_allocs)) || (rc = dalloc(c, &c->d_dcap, 64, c->comm_allocs))) return rc;
+    trim_pool(c->comm_allocs);
   }
   // regions of ranks that send nothing keep a zero count in their header record
   HIPCHK(c, hipMemsetAsync(c->d_recv, 0, (size_t)n * (c->halo_cap + 1) * HALO_REC * sizeof(double), c->stream));
@@ -2354,7 +2360,6 @@ int sz_tile_setup(sz_ctx* c, double Lx, double Ly, int32_t per_x, int32_t per_y,
   c->tile_Lx = Lx; c->tile_Ly = Ly; c->tile_per_x = per_x; c->tile_per_y = per_y; c->tile_margin = drift_margin; c->tile_rebox_every = std::abs(rebox_every); c->tile_rebox_fixed = rebox_every < 0;
   c->tile_since_box = -1; c->halo_cap = 0; c->d_send = nullptr; c->tile_rebox_cur = rebox_every < 0 ? -rebox_every : std::min(rebox_every, 8);
   c->tile_box_valid = false;
-  free_pool(c->comm_allocs);
   if (!c->d_gather) {          // own box | all boxes | count matrix (ints): lives as long as the communicator
     HIPCHK(c, hipMalloc((void**)&c->d_gather, (8 + 8 * 64 + 64 * 64 / 2 + 64) * sizeof(double)));
   }
@@ -2416,7 +2421,213 @@ int comm_alltoallv(sz_ctx* c, const std::vector<std::vector<double>>& sendv, std
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return SZ_OK;
 }
-constexpr int MIG_NCOL = 25 + 12 + 5;      // the 25 scalar columns, three 2 x 2 tensors, id, status, global index, ring points, sub-floe points
+// sizes of a variable-size all-to-all: mine[d] doubles go to rank d; all[s * n + d] = what rank s sends to rank d
+int comm_sizes(sz_ctx* c, const std::vector<int>& mine, std::vector<int>& all) {
+  const int n = c->comm_n;
+  all.assign((size_t)n * n, 0);
+  if (n == 1) { all[0] = mine[0]; return SZ_OK; }
+  int* d_row = (int*)(c->d_gather + 8 + 8 * 64);          // (the count-matrix area of the box gather: free between gathers)
+  HIPCHK(c, hipMemcpyAsync(d_row, mine.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  int* d_all = d_row + 64;
+  int rc = comm_allgather(c, d_row, d_all, (size_t)n, NCCL_INT32, sizeof(int));
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SZ_OK;
+}
+
+// sz_tile_migrate with the movers packed on the device (sz_migrate.hpp): owners, pack, exchange device to device, merge of the directories, the
+// rows gathered into the new order, then what sz_upload_floes does behind its copies (counters, ring signs and boxes, cleared per-floe counts).
+// The capacities the context was carved with stay; *fell_back = 1 (and nothing has changed) when some rank's new tile would crowd them --
+// every rank then takes the host-staged path below, which carves anew.  The host reads the owner and offset columns (ints) and the merged
+// directory; no floe column, ring or sub-floe point crosses to the host (a host transport stages the movers' streams).
+int tile_migrate_device(sz_ctx* c, int px, int py, const int32_t* owner_override, int64_t* n_sent, int64_t* n_owned, int* fell_back) {
+  State& S = c->S;
+  const int n = c->comm_n, me = c->comm_rank, N = c->hostN;
+  *fell_back = 0;
+  int rc;
+  if (c->gi_pending && c->gi_valid) { if ((rc = gi_fetch(c))) return rc; }
+  c->gi_pending = false;
+  struct Scratch { Pool& v; } pool{ c->mig_allocs };      // (the scratch of the last migration is carved again: no allocation in the common case)
+  reset_pool(pool.v);
+  // ---- owners, and how much goes where
+  int *d_owner = nullptr, *d_override = nullptr, *d_bad = nullptr, *d_cntd = nullptr;
+  unsigned long long *d_tally = nullptr, *d_cur = nullptr; long long *d_base = nullptr, *d_rbase = nullptr, *d_rsize = nullptr; double** d_cols = nullptr;
+  if ((rc = dalloc(c, &d_owner, (size_t)N + 1, pool.v)) || (rc = dalloc(c, &d_tally, 128, pool.v)) || (rc = dalloc(c, &d_cur, 128, pool.v)) ||
+      (rc = dalloc(c, &d_base, 64, pool.v)) || (rc = dalloc(c, &d_rbase, 64, pool.v)) || (rc = dalloc(c, &d_rsize, 64, pool.v)) ||
+      (rc = dalloc(c, &d_cntd, 64, pool.v)) || (rc = dalloc(c, &d_bad, 1, pool.v)) || (rc = dalloc(c, &d_cols, 32, pool.v))) return rc;
+  if (owner_override) {
+    if ((rc = dalloc(c, &d_override, (size_t)N + 1, pool.v))) return rc;
+    if (N) HIPCHK(c, hipMemcpyAsync(d_override, owner_override, (size_t)N * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  }
+  const double x0 = c->h_vals[3], y0 = c->h_vals[1], Lx = c->h_vals[2] - c->h_vals[3], Ly = c->h_vals[0] - c->h_vals[1];
+  hipLaunchKernelGGL(sz_k_mig_owner, dim3(grid_for(std::max(N, 1), 256)), dim3(256), 0, c->stream, S, N, (const int*)d_override, x0, y0, Lx, Ly, px, py,
+                     c->tile_per_x, c->tile_per_y, me, n, d_owner, d_tally, d_bad);
+  unsigned long long tally[128]; int bad = 0;
+  std::vector<int> owner((size_t)N + 1), voff((size_t)N + 1), soff((size_t)N + 1);
+  HIPCHK(c, hipMemcpyAsync(tally, d_tally, sizeof(tally), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  if (N) HIPCHK(c, hipMemcpyAsync(owner.data(), d_owner, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(voff.data(), S.voff, ((size_t)N + 1) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(soff.data(), S.soff, ((size_t)N + 1) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int any_bad = 0;
+  if ((rc = comm_agree_bits(c, bad ? 1 : 0, &any_bad))) return rc;
+  if (any_bad) { c->err = "sz_tile_migrate: owner out of range"; return SZ_E_ARG; }
+  // ---- the movers' records, one stream per destination
+  std::vector<int> mine(n, 0), all, cntd(64, 0); std::vector<long long> base(64, 0);
+  size_t ts = 0; int nmove = 0; bool too_long = false;
+  for (int d = 0; d < n; d++) {
+    const unsigned long long cnt = tally[2 * d];
+    if (d == me || !cnt) continue;
+    const unsigned long long sz = 1 + (unsigned long long)MIG_DIR * cnt + tally[2 * d + 1];
+    if (sz > 0x7fffffffull) { too_long = true; break; }
+    mine[d] = (int)sz; base[d] = (long long)ts; ts += (size_t)sz; cntd[d] = (int)cnt; nmove += (int)cnt;
+  }
+  if (too_long) { for (int d = 0; d < n; d++) { mine[d] = 0; cntd[d] = 0; } ts = 0; }      // (says so in the agreement below; nothing is sent)
+  double* d_sendb = nullptr;
+  if ((rc = dalloc(c, &d_sendb, ts, pool.v))) return rc;
+  double* const hcols[MIG_NSC + 3] = { S.cx, S.cy, S.rmax, S.area, S.height, S.mass, S.moment, S.alpha, S.u, S.v, S.xi, S.p_dxdt, S.p_dydt, S.p_dalphadt,
+                                       S.p_dudt, S.p_dvdt, S.p_dxidt, S.fxOA, S.fyOA, S.trqOA, S.hflx, S.overarea, S.cfx, S.cfy, S.ctrq, S.sa, S.si, S.strain };
+  HIPCHK(c, hipMemcpyAsync(d_cols, hcols, sizeof(hcols), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_base, base.data(), 64 * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_cntd, cntd.data(), 64 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  if (ts) hipLaunchKernelGGL(sz_k_mig_pack, dim3(grid_for((long long)N * 64, 256, 2048)), dim3(256), 0, c->stream, S, N, (const int*)d_owner, me, d_sendb,
+                             (const long long*)d_base, (const int*)d_cntd, d_cur, (double* const*)d_cols);
+  // ---- sizes, then the streams: device to device (a host transport: staged, the movers only)
+  if ((rc = comm_sizes(c, mine, all))) return rc;
+  std::vector<long long> rbase(64, 0), rsize(64, 0);
+  size_t tr = 0;
+  for (int s2 = 0; s2 < n; s2++) { if (s2 == me) continue; rbase[s2] = (long long)tr; rsize[s2] = all[(size_t)s2 * n + me]; tr += (size_t)rsize[s2]; }
+  double* d_recvb = nullptr;
+  if ((rc = dalloc(c, &d_recvb, tr, pool.v))) return rc;
+  if (n > 1 && c->host_transport) {
+    std::vector<double> hs(std::max<size_t>(ts, 1)), hr(std::max<size_t>(tr, 1));
+    if (ts) HIPCHK(c, hipMemcpyAsync(hs.data(), d_sendb, ts * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<int32_t> peer; std::vector<const void*> sp; std::vector<void*> rp; std::vector<int64_t> sb, rb;
+    for (int d = 0; d < n; d++) {
+      if (d == me) continue;
+      peer.push_back(d); sp.push_back(hs.data() + base[d]); sb.push_back((int64_t)mine[d] * (int64_t)sizeof(double));
+      rp.push_back(hr.data() + rbase[d]); rb.push_back((int64_t)rsize[d] * (int64_t)sizeof(double));
+    }
+    HOSTCHK(c, c->host_tr.sendrecv(c->host_tr.user, (int32_t)peer.size(), peer.data(), sp.data(), sb.data(), rp.data(), rb.data()), "sendrecv");
+    if (tr) HIPCHK(c, hipMemcpyAsync(d_recvb, hr.data(), tr * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  } else if (n > 1) {
+    NCCLCHK(c, g_rccl.GroupStart());
+    for (int d = 0; d < n; d++) {
+      if (d == me) continue;
+      if (mine[d]) NCCLCHK(c, g_rccl.Send(d_sendb + base[d], (size_t)mine[d], NCCL_FLOAT64, d, c->comm, c->stream));
+      if (rsize[d]) NCCLCHK(c, g_rccl.Recv(d_recvb + rbase[d], (size_t)rsize[d], NCCL_FLOAT64, d, c->comm, c->stream));
+    }
+    NCCLCHK(c, g_rccl.GroupEnd());
+  }
+  // ---- what arrived: the merged directory is all the host reads of it
+  const int dcap = (int)(tr / (size_t)(MIG_DIR + MIG_NCOL)) + 1;
+  double* d_dirs = nullptr;
+  if ((rc = dalloc(c, &d_dirs, (size_t)MIG_DIR * (1 + (size_t)dcap), pool.v))) return rc;
+  HIPCHK(c, hipMemcpyAsync(d_rbase, rbase.data(), 64 * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_rsize, rsize.data(), 64 * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(sz_k_mig_dirs, dim3(1), dim3(256), 0, c->stream, (const double*)d_recvb, (const long long*)d_rbase, (const long long*)d_rsize, n, d_dirs, dcap);
+  std::vector<double> dirs((size_t)MIG_DIR * (1 + (size_t)dcap));
+  HIPCHK(c, hipMemcpyAsync(dirs.data(), d_dirs, dirs.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int R = (int)dirs[0];
+  // ---- the new tile: kept floes + received ones, ordered by global index
+  struct Src { long long g; int s; };
+  std::vector<Src> src;
+  for (int i = 0; i < N; i++) if (owner[i] == me) src.push_back({ c->tile_gidx[i], i });
+  for (int e = 0; e < R; e++) src.push_back({ (long long)dirs[(size_t)MIG_DIR * (1 + e)], -(e + 1) });
+  std::sort(src.begin(), src.end(), [](const Src& a, const Src& b2) { return a.g < b2.g; });
+  const int Nn = (int)src.size();
+  std::vector<int> hsrc((size_t)Nn + 1), nvoff((size_t)Nn + 1, 0), nsoff((size_t)Nn + 1, 0); std::vector<long long> ngid((size_t)Nn + 1);
+  int ring_in = 0, sub_in = 0; double rmax_in = 0.0;
+  for (int r = 0; r < Nn; r++) {
+    const int s2 = src[r].s;
+    int nv, ns;
+    if (s2 >= 0) { nv = voff[s2 + 1] - voff[s2]; ns = soff[s2 + 1] - soff[s2]; }
+    else {
+      const double* e = dirs.data() + (size_t)MIG_DIR * (size_t)(-s2);
+      nv = (int)e[1]; ns = (int)e[2]; ring_in = std::max(ring_in, nv); sub_in = std::max(sub_in, ns); rmax_in = std::max(rmax_in, e[4]);
+    }
+    hsrc[r] = s2; ngid[r] = src[r].g; nvoff[r + 1] = nvoff[r] + nv; nsoff[r + 1] = nsoff[r] + ns;
+  }
+  const int Vn = nvoff[Nn], NSn = nsoff[Nn];
+  // does it fit what the context was carved for (sz_upload_floes: capM = 2 M + 64 rows and capV = 2 V + 4096 ring points, for the owned floes, their
+  // ghosts and the halo)?  An eighth more than the upload held is let in.
+  const int M0 = (S.capM - 64) / 2, V0 = (S.capV - 4096) / 2;
+  const bool fits = Nn <= M0 + M0 / 8 && Vn <= V0 + V0 / 8 && !too_long;
+  int bits = (nmove > 0 ? 1 : 0) | (fits ? 0 : 2) | (Nn == 0 ? 4 : 0) | (R < 0 ? 8 : 0), allb = 0;
+  if ((rc = comm_agree_bits(c, bits, &allb))) return rc;
+  if (allb & 8) { c->err = "sz_tile_migrate: a stream of movers arrived inconsistent"; return SZ_E_STATE; }
+  if (n_sent) *n_sent = nmove;
+  if (!(allb & 1)) { c->err.clear(); if (n_owned) *n_owned = N; return SZ_OK; }
+  if (allb & 4) { c->err = "sz_tile_migrate: a tile without floes (every rank must own at least one)"; return SZ_E_STATE; }
+  if (allb & 2) { c->err.clear(); *fell_back = 1; return SZ_OK; }
+  c->err.clear();
+  // ---- the rows into their new order: gathered beside the old ones first (a row's source may lie on either side of it)
+  int *d_src = nullptr, *d_nvoff = nullptr, *d_nsoff = nullptr; double *d_tmp = nullptr, *d_tsx = nullptr, *d_tsy = nullptr; double2* d_tv = nullptr;
+  if ((rc = dalloc(c, &d_src, (size_t)Nn + 1, pool.v)) || (rc = dalloc(c, &d_nvoff, (size_t)Nn + 1, pool.v)) || (rc = dalloc(c, &d_nsoff, (size_t)Nn + 1, pool.v)) ||
+      (rc = dalloc(c, &d_tmp, (size_t)39 * Nn, pool.v)) || (rc = dalloc(c, &d_tv, (size_t)Vn, pool.v)) ||
+      (rc = dalloc(c, &d_tsx, (size_t)NSn, pool.v)) || (rc = dalloc(c, &d_tsy, (size_t)NSn, pool.v))) return rc;
+  HIPCHK(c, hipMemcpyAsync(d_src, hsrc.data(), (size_t)Nn * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_nvoff, nvoff.data(), ((size_t)Nn + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_nsoff, nsoff.data(), ((size_t)Nn + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(sz_k_mig_gather, dim3(grid_for(Nn, 256)), dim3(256), 0, c->stream, S, Nn, (const int*)d_src, (const double*)d_dirs, (const double*)d_recvb,
+                     (double* const*)d_cols, d_tmp);
+  hipLaunchKernelGGL(sz_k_mig_points, dim3(grid_for((long long)Nn * 64, 256, 4096)), dim3(256), 0, c->stream, S, Nn, (const int*)d_src, (const double*)d_dirs,
+                     (const double*)d_recvb, (const int*)d_nvoff, (const int*)d_nsoff, d_tv, d_tsx, d_tsy);
+  hipLaunchKernelGGL(sz_k_mig_scatter, dim3(grid_for(Nn, 256)), dim3(256), 0, c->stream, S, Nn, (double* const*)d_cols, (const double*)d_tmp);
+  if (Vn) HIPCHK(c, hipMemcpyAsync(S.vxy, d_tv, (size_t)Vn * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(S.voff, d_nvoff, ((size_t)Nn + 1) * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+  Pool old_sub;
+  if (NSn > S.capS) {          // the sub-floe points have no slack at upload (they are the largest array of a field): a tile that gained points gets a new pair
+    old_sub = c->sub_allocs; c->sub_allocs = Pool();
+    S.capS = NSn + NSn / 4;
+    if ((rc = dalloc(c, &S.sx, (size_t)S.capS, c->sub_allocs)) || (rc = dalloc(c, &S.sy, (size_t)S.capS, c->sub_allocs))) return rc;
+  }
+  if (NSn) {
+    HIPCHK(c, hipMemcpyAsync(S.sx, d_tsx, (size_t)NSn * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(S.sy, d_tsy, (size_t)NSn * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
+  HIPCHK(c, hipMemcpyAsync(S.soff, d_nsoff, ((size_t)Nn + 1) * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+  // ---- as behind the copies of sz_upload_floes: counters, per-floe counts a kernel may read before a collision call writes them, ring signs / boxes / trig
+  int h[C_COUNT + 64 + 72] = { 0 };
+  h[C_M] = Nn; h[C_N] = Nn; h[C_NV] = Vn; h[C_NGHOSTS] = 0; h[C_NOWN] = Nn;
+  HIPCHK(c, hipMemcpyAsync(S.cnt, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(S.over_stamp, 0, ((size_t)S.capM + 1) * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(S.n_out, 0, ((size_t)S.capM + 1) * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(S.n_in, 0, ((size_t)S.capM + 1) * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(S.el_off, 0, ((size_t)S.capM + 2) * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(S.warn, 0, (size_t)WARN_SLOTS * 32 * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(S.lb_flag, 0, ((size_t)S.capM / 128 + 8) * sizeof(unsigned), c->stream)); c->scan_epoch = 0;
+  HIPCHK(c, hipMemsetAsync(S.inter_cnt, 0, ((size_t)S.capM + 1) * sizeof(int), c->stream));          // (no rows until the next collision call)
+  hipLaunchKernelGGL(sz_k_osign, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_pool(old_sub);
+  const double Lx0 = c->tile_Lx, Ly0 = c->tile_Ly, margin = c->tile_margin; const int perx = c->tile_per_x, pery = c->tile_per_y;
+  const int rebox = c->tile_rebox_fixed ? -c->tile_rebox_every : c->tile_rebox_every;
+  const double ring_hint = (double)c->max_ring_tiled, rmax_hint = c->rmax_hint;
+  const int prec = c->precision;
+  S.tiled = 0; S.famrec = 0;
+  c->tile_margin = 0.0; c->tile_since_box = -1; c->halo_cap = 0; c->d_send = c->d_recv = c->d_ref = nullptr; c->d_dcap = nullptr;
+  c->hostM = Nn; c->hostN = Nn; c->tile_dirty = false; c->mixed_pts_ok = false;
+  c->gl_valid = false; c->gl_est = std::min(Nn, c->gl_est + R);          // (the ghost-candidate estimate is an upper bound)
+  c->mixed_geom_ok = false; c->rings_stale = false; S.rec32 = nullptr; S.ring32 = nullptr; S.body_rings = 0;
+  c->max_ring = std::max(c->max_ring, ring_in); c->max_sub = std::max(c->max_sub, sub_in); c->rmax_max = std::max(c->rmax_max, rmax_in);
+  setup_grid(c);
+  c->fuse_lists.assign(Nn, {});
+  c->inter_lost = false; c->inter_any = true;
+  if ((rc = sz_tile_enable(c, (const int64_t*)ngid.data(), ring_hint, rmax_hint))) return rc;
+  if ((rc = sz_tile_setup(c, Lx0, Ly0, perx, pery, margin, rebox))) return rc;
+  if (!owner_override) (void)sz_tile_set_center(c, x0 + ((me % px) + 0.5) * Lx / px, y0 + ((me / px) + 0.5) * Ly / py);
+  c->precision = prec;
+  trim_pool(pool.v);
+  if (n_owned) *n_owned = Nn;
+  return SZ_OK;
+}
+int tile_migrate_host(sz_ctx* c, int32_t px, int32_t py, const int32_t* owner_override, int64_t* n_sent, int64_t* n_owned);
 }  // namespace
 
 int sz_tile_migrate(sz_ctx* c, int32_t px, int32_t py, const int32_t* owner_override, int64_t* n_sent, int64_t* n_owned) {
@@ -2426,10 +2637,34 @@ int sz_tile_migrate(sz_ctx* c, int32_t px, int32_t py, const int32_t* owner_over
     return SZ_E_STATE;
   }
   (void)hipSetDevice(c->device);
-  State& S = c->S;
-  const int n = c->comm_n, me = c->comm_rank;
   int rc = tile_sync_agree(c); if (rc) return rc;             // (ghosts and halo floes of the last step are dropped: the state is the owned floes)
   world_rings(c);
+  c->migrate_path = 0;
+  const char* e = getenv("SZ_MIGRATE_HOST");                  // (A/B switch, the same on every rank: the host-staged path only)
+  if (!(e && atoi(e) != 0)) {
+    int fell_back = 0;
+    rc = tile_migrate_device(c, px, py, owner_override, n_sent, n_owned, &fell_back);
+    if (rc) return rc;
+    if (!fell_back) { c->migrate_path = 1; return SZ_OK; }
+  }
+  rc = tile_migrate_host(c, px, py, owner_override, n_sent, n_owned);
+  if (rc == SZ_OK) c->migrate_path = 2;
+  return rc;
+}
+// how the last sz_tile_migrate ran: 1 = movers packed on the device, 2 = staged through the host (0: it did not get that far)
+int sz_debug_migrate_path(sz_ctx* c) { return c ? c->migrate_path : 0; }
+// global indices of the owned floes (sz_tile_enable; after sz_tile_migrate: of the new tile), n_cap >= the number of owned floes
+int sz_tile_owned_gidx(sz_ctx* c, int64_t* out, int64_t n_cap) {
+  if (!c || !c->have_floes || !c->S.tiled || !out || n_cap < (int64_t)c->tile_gidx.size()) return SZ_E_ARG;
+  for (size_t i = 0; i < c->tile_gidx.size(); i++) out[i] = c->tile_gidx[i];
+  return SZ_OK;
+}
+
+namespace {
+int tile_migrate_host(sz_ctx* c, int32_t px, int32_t py, const int32_t* owner_override, int64_t* n_sent, int64_t* n_owned) {
+  State& S = c->S;
+  const int n = c->comm_n, me = c->comm_rank;
+  int rc;
   const int N = c->hostN;
   // ---- the tile's state on the host
   double* const dcol[25] = { S.cx, S.cy, S.rmax, S.area, S.height, S.mass, S.moment, S.alpha, S.u, S.v, S.xi, S.p_dxdt, S.p_dydt, S.p_dalphadt, S.p_dudt, S.p_dvdt, S.p_dxidt,
@@ -2549,6 +2784,7 @@ int sz_tile_migrate(sz_ctx* c, int32_t px, int32_t py, const int32_t* owner_over
   if (n_owned) *n_owned = Nn;
   return SZ_OK;
 }
+}  // namespace
 // sub-floe points of the floes the context holds (CSR: off has N + 1 entries; call with sx == NULL for the offsets alone): after a
 // migration the host's copy of these is the library's
 int sz_download_subpoints(sz_ctx* c, int32_t* off, double* sx, double* sy) {

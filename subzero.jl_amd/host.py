@@ -180,7 +180,7 @@ class World:
         self.col.setdefault("id", np.arange(1, M + 1, dtype=_I64))
         self.col.setdefault("ghost_id", np.zeros(M, _I64))
         self.col.setdefault("status", np.full(M, capi.ACTIVE, _I32))
-        self._sub = {}
+        self._sub = {}; self._sub_on_device = False
         self._dirty = True; self._host_stale = False
         self._new_field = True    # a different field: the interaction rows the device may still hold are not its rows
 
@@ -189,6 +189,7 @@ class World:
         self._dirty = True
 
     def set_subpoints_csr(self, sub_off, sx, sy):
+        self._sub_on_device = False
         self.col["sub_off"] = np.ascontiguousarray(sub_off, _I32)
         self.col["sx"] = np.ascontiguousarray(sx, np.float64); self.col["sy"] = np.ascontiguousarray(sy, np.float64)
         self._dirty = True
@@ -216,11 +217,24 @@ class World:
                 a = np.ascontiguousarray(a, _I32); keep.append(a); setattr(f, n, capi.ptr(a, capi._ip))
         return f
 
+    def _fetch_subpoints(self):
+        """after a migration of a tiled run (tiles.TiledWorld.migrate) the sub-floe points of the tile are the library's: fetched when needed"""
+        if not getattr(self, "_sub_on_device", False):
+            return
+        n = self.N
+        off = np.zeros(n + 1, _I32)
+        self._chk(self.L.sz_download_subpoints(self.h, capi.ptr(off, capi._ip), None, None))
+        sx = np.zeros(max(int(off[n]), 1)); sy = np.zeros(max(int(off[n]), 1))
+        self._chk(self.L.sz_download_subpoints(self.h, capi.ptr(off, capi._ip), capi.ptr(sx), capi.ptr(sy)))
+        self.col["sub_off"], self.col["sx"], self.col["sy"] = off, sx[:off[n]], sy[:off[n]]
+        self._sub_on_device = False
+
     def _push(self):
         if not self._dirty:
             return
         if not self._have_domain:
             raise SzError("set_domain must be called before the first process call")
+        self._fetch_subpoints()
         col = dict(self.col)
         if "sub_off" not in col or self._sub:
             off = np.zeros(self.N + 1, _I32); xs = []; ys = []
@@ -274,6 +288,7 @@ class World:
             for n in list(col):
                 if col[n].dtype == np.float32:
                     col[n] = col[n].astype(np.float64)
+        self._fetch_subpoints()
         for n in ("sub_off", "sx", "sy"):
             if n in self.col:
                 col[n] = self.col[n]

@@ -459,16 +459,14 @@ class TiledWorld:
         px, py = tile_grid(self.nranks)
         sent = C.c_int64(0); owned = C.c_int64(0)
         w._chk(w.L.sz_tile_migrate(w.h, int(px), int(py), capi.ptr(ov, capi._ip) if ov is not None else None, C.byref(sent), C.byref(owned)))
-        # the host's copies of the columns are the library's now
+        # the host's copies of the columns are stale now: the columns come back with the next get() (World._pull), the sub-floe points when
+        # something asks for them (World._fetch_subpoints) -- a migration itself moves no floe data to the host
         n = int(owned.value)
-        w.N = n; w._M = n; w._dirty = False; w._host_stale = True; w._sub = {}
-        off = np.zeros(n + 1, np.int32)
-        w._chk(w.L.sz_download_subpoints(w.h, capi.ptr(off, capi._ip), None, None))
-        sx = np.zeros(max(int(off[n]), 1)); sy = np.zeros(max(int(off[n]), 1))
-        w._chk(w.L.sz_download_subpoints(w.h, capi.ptr(off, capi._ip), capi.ptr(sx), capi.ptr(sy)))
-        w.col["sub_off"], w.col["sx"], w.col["sy"] = off, sx[:off[n]], sy[:off[n]]
-        w._pull()
-        self.gidx = (w.col["id"][:n] - 1).astype(np.int64)
+        w.N = n; w._M = n; w._dirty = False; w._host_stale = True; w._sub = {}; w._sub_on_device = True
+        g = np.zeros(max(n, 1), np.int64)
+        w._chk(w.L.sz_tile_owned_gidx(w.h, capi.ptr(g, capi._lp), int(g.size)))
+        self.gidx = g[:n].copy()
+        self.migrate_path = int(w.L.sz_debug_migrate_path(w.h))          # 1: packed on the device, 2: host-staged
         self.boxes = None; self._ref = None
         return int(sent.value)
 

@@ -68,8 +68,21 @@ def _worker(rank, world, port, n, seed, steps, q, repartition=False, fast=False,
             tw.run(half, 0, cfg["dt"], coupling_dt=1)
             L = cfg["L"]
             other = lambda cx, cy: (cy > 0.5 * L).astype(int)
-            moved = tw.migrate(owner_fn=other) if repartition == "migrate" else tw.repartition(owner_fn=other)
-            assert moved > 0 and len(tw.gidx) > 0
+            if repartition == "migrate-band":          # a band either side of the tile edge changes hands: the tiles keep their size
+                other = lambda cx, cy: ((cx > 0.5 * L) ^ (np.abs(cx - 0.5 * L) < 0.06 * L)).astype(int)
+            elif repartition == "migrate-lopsided":    # one tile grows by a sixth: more than its context was carved to take in
+                other = lambda cx, cy: (cx > 0.40 * L).astype(int)
+            if repartition == "migrate-host":
+                os.environ["SZ_MIGRATE_HOST"] = "1"
+            moved = tw.migrate(owner_fn=other) if str(repartition).startswith("migrate") else tw.repartition(owner_fn=other)
+            assert (moved > 0 or repartition == "migrate-lopsided") and len(tw.gidx) > 0          # (lopsided: one rank only receives)
+            if str(repartition).startswith("migrate"):
+                # packed on the device (1) unless a tile outgrows its context or the switch asks for the host-staged path (2): the same on every rank
+                want = {"migrate-band": (1,), "migrate-host": (2,), "migrate-lopsided": (2,)}.get(repartition, (1, 2))
+                assert tw.migrate_path in want, (repartition, tw.migrate_path)
+                paths = [None] * world
+                dist.all_gather_object(paths, tw.migrate_path)
+                assert len(set(paths)) == 1, paths
             tw.run(steps - half, half, cfg["dt"], coupling_dt=1)
         else:
             tw.run(steps, 0, cfg["dt"], coupling_dt=1)
@@ -92,6 +105,7 @@ def _run_worker_two_way(*a):
     (2, 600, 31, 4, False, False, "torch"), (2, 600, 33, 6, True, False, "torch"), (4, 1000, 35, 4, False, False, "torch"),
     (2, 500, 77, 30, False, True, "torch"),
     (2, 600, 31, 8, False, False, "library-host"), (2, 600, 33, 8, True, False, "library-host"), (2, 600, 33, 8, "migrate", False, "library-host"),
+    (2, 600, 33, 8, "migrate-band", False, "library-host"), (2, 600, 33, 8, "migrate-host", False, "library-host"), (2, 600, 33, 8, "migrate-lopsided", False, "library-host"),
     (4, 1000, 35, 8, False, False, "library-host"),
     (2, 500, 77, 30, False, True, "library-host")])
 def test_ranks_equal_single(world, n, seed, steps, repartition, fast, backend):
@@ -478,6 +492,7 @@ def _worker_migrate(rank, world, port, n, seed, steps, every, q):
             tw.run(min(every, steps - t0), t0, cfg["dt"], coupling_dt=1)
             if t0 + every < steps:
                 t = time.perf_counter(); moved += tw.migrate(); cost.append(time.perf_counter() - t)
+                assert tw.migrate_path == 1 or os.environ.get("SZ_PROBE_ANY_PATH"), tw.migrate_path          # floes that drifted over a tile edge: packed and placed on the device
         out = {f: tw.owned(f) for f in FIELDS}
         q.put((rank, tw.gidx, out, moved, cost))
     finally:
@@ -492,8 +507,8 @@ def _run_worker_migrate(*a):
 def test_migration_every_20_steps(world, n):
     """sz_tile_migrate: fast floes (2 - 8 m/s: 40 - 160 m per step on tiles a few hundred km wide, parents
     crossing the periodic walls) with a re-tile every 20 steps -- floes that left their tile go to their new owner with their complete
-    state over the library's channel, the contexts are rebuilt -- and after 60 steps every owned column is bit-equal to the single
-    context's.  The cost per re-tile is printed (host-staged inside the library: a download and an upload of the tile)."""
+    state over the library's channel, packed and placed on the device (csrc/sz_migrate.hpp) -- and after 60 steps every owned column is
+    bit-equal to the single context's.  The cost per re-tile is printed."""
     import torch.multiprocessing as mp
     import subzero_jl_amd
     from subzero_jl_amd import fields
