@@ -715,6 +715,12 @@ function tile_migrate!(eng::HIPEngine, px::Integer, py::Integer)
     check(eng, @ccall lib.sz_tile_migrate(eng.ctx::Ptr{Cvoid}, px::Int32, py::Int32, C_NULL::Ptr{Int32}, sent::Ptr{Int64}, owned::Ptr{Int64})::Cint)
     return Int(sent[]), Int(owned[])
 end
+# global indices (0-based positions in the undivided floe list) of the floes this rank owns, after tile_migrate! too
+function tile_owned(eng::HIPEngine, n_owned::Integer)
+    g = Vector{Int64}(undef, max(n_owned, 1))
+    check(eng, @ccall lib.sz_tile_owned_gidx(eng.ctx::Ptr{Cvoid}, g::Ptr{Int64}, length(g)::Int64)::Cint)
+    return g[1:n_owned]
+end
 
 writer_periods(w) = Int[x.Δtout for ws in (w.floewriters, w.gridwriters, w.checkpointwriters) for x in ws]
 output_due(w, tstep, start) = tstep == start || any(p -> mod(tstep, p) == 0, writer_periods(w))
