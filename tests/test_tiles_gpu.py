@@ -150,17 +150,19 @@ def test_ranks_equal_single(world, n, seed, steps, repartition, fast, backend):
     assert seen.all()
 
 
-@pytest.mark.parametrize("world,backend", [(2, "torch"), (4, "library-host")])
-def test_voronoi_field_ranks_equal_single(world, backend):
+@pytest.mark.parametrize("world,backend,repartition", [(2, "torch", False), (4, "library-host", False), (2, "library-host", "migrate-band")])
+def test_voronoi_field_ranks_equal_single(world, backend, repartition):
     """The reference's own kind of field -- touching Voronoi cells with a size spectrum (the larger neighbour capacity, the chunked
-    candidate pool, halo floes the upload-time count has not seen) -- in tiles: bit-equal to the single context."""
+    candidate pool, halo floes the upload-time count has not seen) -- in tiles: bit-equal to the single context.  "migrate-band": half way
+    through, the cells either side of the tile edge change owner through sz_tile_migrate's device path (records of many ring and
+    sub-floe point counts, rows of the larger capacities)."""
     import torch.multiprocessing as mp
     import subzero_jl_amd
     from subzero_jl_amd import fields
     n, seed, steps = (900 if world == 2 else 3600), 93, 10          # (a tile holds at most as many halo floes as owned ones: 4 tiles need the larger field)
     ctx = mp.get_context("spawn")
     q = ctx.Queue(); port = _free_port()
-    procs = [ctx.Process(target=_run_worker, args=(r, world, port, n, seed, steps, q, False, False, backend, "voronoi")) for r in range(world)]
+    procs = [ctx.Process(target=_run_worker, args=(r, world, port, n, seed, steps, q, repartition, False, backend, "voronoi")) for r in range(world)]
     for p in procs:
         p.start()
     try:
