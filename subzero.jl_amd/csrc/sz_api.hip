@@ -699,7 +699,7 @@ void stage_forcing(sz_ctx* c, int dt = -1) {      // in-order variant (process m
   t.end();
 }
 // gl_fill: ghost-candidate list the integrator appends to (resident steps on the list path), -1: none
-void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool bin = false, int gl_fill = -1, int ginl = -1) {
+void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool bin = false, int gl_fill = -1, int ginl = -1, const PackInl* pack = nullptr) {
   const int nh = bin && !c->S.tiled ? c->hostN : -1;     // resident single-context steps: the host knows the count
   // the guard counters describe the last timestep_floe_properties! call (inside a step the
   // ghost-removal kernel has already cleared them)
@@ -707,9 +707,11 @@ void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool 
   Timed t(c, SZ_K_INTEGRATE);
   // resident steps with small rings: one launch (thread per floe) integrates, moves the ring and bins the floe
   if (bin && c->max_ring <= MV_RING && c->fused_move) {
-    hipLaunchKernelGGL(sz_k_integrate<true>, dim3(grid_for(c->S.capM, 128)), dim3(128), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 1, nh, gl_fill, ginl);
+    // (tiled steps: the same thread also writes the floe's halo records for the next step -- sz_k_integrate<true, true>)
+    if (pack) hipLaunchKernelGGL((sz_k_integrate<true, true>), dim3(grid_for(c->S.capM, 128)), dim3(128), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 1, nh, gl_fill, ginl, *pack);
+    else hipLaunchKernelGGL(sz_k_integrate<true>, dim3(grid_for(c->S.capM, 128)), dim3(128), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 1, nh, gl_fill, ginl, PackInl{});
   } else {
-    hipLaunchKernelGGL(sz_k_integrate<false>, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 0, nh, gl_fill, -1);
+    hipLaunchKernelGGL(sz_k_integrate<false>, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 0, nh, gl_fill, -1, PackInl{});
     hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 0, bin ? 1 : 0, gl_fill);
   }
   if (!bin) c->grid_live = false;          // floes moved without re-binning: the resident steps' cell lists are stale
@@ -2839,6 +2841,15 @@ int tile_exchange(sz_ctx* c, bool all_ranks) {
   HIPCHK(c, hipEventRecord(c->ev_recv, c->comm_stream));
   return SZ_OK;
 }
+// what a pack is given (sz_k_halo_pack; the integrator of a tiled step that packs for the next one: sz_k_integrate<true, true>)
+PackInl tile_pack_args(sz_ctx* c) {
+  State& S = c->S;
+  PackInl a;
+  a.send = c->d_send; a.boxes = S.bounds + 16; a.dcap = c->d_dcap; a.ref = c->d_ref; a.counts = S.cnt + C_COUNT;
+  a.Lx = c->tile_Lx; a.Ly = c->tile_Ly; a.margin = c->tile_margin;
+  a.nranks = c->comm_n; a.me = c->comm_rank; a.cap = c->halo_cap; a.per_x = c->tile_per_x; a.per_y = c->tile_per_y;
+  return a;
+}
 void tile_pack(sz_ctx* c) {
   State& S = c->S;
   hipLaunchKernelGGL(sz_k_halo_pack, dim3(grid_for(std::max(c->hostN, 1), PACK_TPB)), dim3(PACK_TPB), 0, c->stream, S, c->comm_n, c->comm_rank, S.bounds + 16,
@@ -2958,8 +2969,13 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   bool lean = !c->retry_seen && !c->no_lean_narrow && !larger_rings(c) && !dbgsync;
   std::vector<int> callid_of((size_t)std::max(nsteps, 1), 0);
   int h[C_COUNT]; int rc = SZ_OK;
+  // The halo records of step s + 1 are written by the integrator of step s (the thread that has just placed the floe holds all a record
+  // carries; SZ_TILE_PACK_INLINE=0: by a pack launch at the start of every step, as the first step of a batch, the step after a box
+  // gather -- its boxes, slot counts and buffers are new -- and the step a batch is taken up again at always are).
+  static const bool pack_inline_on = !(getenv("SZ_TILE_PACK_INLINE") && atoi(getenv("SZ_TILE_PACK_INLINE")) == 0);
   for (int s_begin = 0;;) {
   S.retry_stop = lean ? 1 : 0;
+  bool packed = false;               // the records of the step about to run are in d_send already
   for (int s = s_begin; s < nsteps; s++) {
     const int tstep = tstep0 + s;
     S.step = s + 1; S.gslot = s & 1;
@@ -2968,7 +2984,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     c->tile_since_box++;
     const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
     stage_done(s, "rebox");
-    tile_pack(c);
+    if (!packed) tile_pack(c);
     stage_done(s, "pack");
     // With peers the forcings of the owned floes (they need nothing from the halo) run BESIDE the exchange -- on the main stream while the
     // communication stream trades the regions, before the host's channel blocks -- and the narrow launch carries no forcing tail; without
@@ -3002,7 +3018,10 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
       stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, true, fmode == 2 ? (c->precision == 1 ? 2 : 1) : 0, 0); stage_done(s, "narrow phase");
       stage_reduce(c, 1, -1, dt, 0); stage_done(s, "reduce");
     } else collisions_step(c, -1, dt, false, true, fmode, lean, false);
-    stage_integrate(c, dt, false, coupling, true, -1, periodic && s + 1 < nsteps ? 1 - (s & 1) : -1);
+    // (the next step gathers the boxes anew when tile_since_box has reached the interval: see the top of the loop)
+    packed = pack_inline_on && !dbgsync && s + 1 < nsteps && c->tile_since_box < c->tile_rebox_cur && c->d_send != nullptr;
+    const PackInl pk = tile_pack_args(c);
+    stage_integrate(c, dt, false, coupling, true, -1, periodic && s + 1 < nsteps ? 1 - (s & 1) : -1, packed ? &pk : nullptr);
     stage_done(s, "integrate");
   }
   S.step = 0;

@@ -720,8 +720,9 @@ __device__ __forceinline__ void ghost_row_load(const State& S, int i, int n, int
 __device__ __forceinline__ int ghost_count_of(int fl) { return fl == 5 ? 0 : ((fl & 3) != 1 && ((fl >> 2) & 3) != 1) ? 3 : 1; }
 // given: the caller has already drawn the rows and ring points of the ghosts from the allocator ({rows << 32 | points} before them) -- the halo
 // unpack of a tiled run allocates a received floe and its ghosts in one go
+// parent_shift (may be null): the translations a parent that swapped with its ghost was moved by (the caller goes on with the parent's new place)
 __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, const double* wall, int N, int NV0, int slot, int i, int fl, int n, int vo,
-                                                  const GhostRow& R, const unsigned long long* given = nullptr) {
+                                                  const GhostRow& R, const unsigned long long* given = nullptr, Shift* parent_shift = nullptr) {
   const int dir0 = (fl & 3) - 1, dir1 = ((fl >> 2) & 3) - 1;
   const int ng = dir0 != 0 && dir1 != 0 ? 3 : 1;
   const bool body = S.body_rings != 0;
@@ -834,6 +835,7 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
   if (ng == 3) { put(c1, 1, k1); put(c2, 2, k2); }
   GSTAMP(15);
   if (moved) {                                               // the parent swapped with its ghost(s)
+    if (parent_shift) *parent_shift = cp;
     double px = pcx, py = pcy, x0 = pb0, y0 = pb2, x1 = pb1, y1 = pb3;
     shift_apply(cp, px, py); shift_apply(cp, x0, y0); shift_apply(cp, x1, y1);
     S.cx[i] = px; S.cy[i] = py; S.bbx0[i] = x0; S.bbx1[i] = x1; S.bby0[i] = y0; S.bby1[i] = y1;
@@ -2562,14 +2564,68 @@ __global__ void sz_k_calc_stress(State S, Params P) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) floe_stress(S, P, i, S.cx[i], S.cy[i]);
 }
 
+// ---- halo records of tiled runs (multi-GPU; the exchange itself: "halo exchange" below).  One record per floe sent to another
+// rank: the columns the collision path reads + the ring.
+constexpr int HALO_RING = 32;
+constexpr int HALO_REC = 12 + 2 * HALO_RING;   // doubles
+constexpr int ERR_HALO_DRIFT = 16384;
+// the ranks whose (already expanded) box holds the centroid or one of its periodic images, as a bit set
+__device__ __forceinline__ unsigned long long halo_hits(const double* boxes, int nranks, int me, double Lx, double Ly, int per_x, int per_y, double cx, double cy) {
+  unsigned long long hits = 0;
+  for (int d = 0; d < nranks; d++) {
+    if (d == me) continue;
+    const double* b = boxes + 4 * d;
+    bool hit = false;
+    for (int kx = (per_x ? -1 : 0); kx <= (per_x ? 1 : 0) && !hit; kx++)
+      for (int ky = (per_y ? -1 : 0); ky <= (per_y ? 1 : 0) && !hit; ky++) {
+        double x = cx + kx * Lx, y = cy + ky * Ly;
+        hit = (b[0] <= x && x <= b[1] && b[2] <= y && y <= b[3]);
+      }
+    if (hit) hits |= 1ull << d;
+  }
+  return hits;
+}
+// the workgroup that finishes a pack last (threads 0 .. nranks - 1 and thread 0): the header record of every region, the totals, the scratch
+// words (counts[64 + d]: running totals, [128]: ticket, [129]: drift) zero again for the next pack
+__device__ __forceinline__ void halo_headers(const State& S, int nranks, double* send, int cap, int* counts, const int* dcap, bool drift) {
+  int* run = counts + 64;
+  if ((int)threadIdx.x < nranks) {
+    int d = threadIdx.x;
+    const int tot = atomicAdd(&run[d], 0);
+    run[d] = 0;
+    counts[d] = tot;
+    const int room = dcap ? dcap[d] : cap;
+    if (send) {
+      // header record: [0] the count, [1] this rank's stop request (resident batches end after the first step that tags a floe,
+      // on EVERY rank: sz_k_halo_unpack_inline reads the flags of all ranks before the next step does anything)
+      double* hdr = send + (size_t)d * (cap + 1) * HALO_REC;
+      hdr[0] = (double)(tot < room ? tot : room); hdr[1] = (double)S.cnt[C_STOP];
+      hdr[2] = (double)S.cnt[C_RETRYSTOP];      // ... and its pause (the step whose narrow phase met an item for the variant that was left out, or outgrew a list)
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (drift) S.cnt[C_DRIFT] = atomicAdd(&run[65], 0);          // what the host sizes the next gather interval with
+    run[65] = 0; run[64] = 0;
+  }
+}
+// what sz_k_halo_pack is given, as one kernel argument: the integrator of a tiled step writes the halo records of the NEXT step itself
+// (sz_k_integrate<true, true>) -- the thread that has just placed a floe holds everything a record carries
+struct PackInl {
+  double* send; const double* boxes; const int* dcap; const double* ref; int* counts;
+  double Lx, Ly, margin;
+  int nranks, me, cap, per_x, per_y;
+};
+
 // one thread per floe: stress, guards, thermodynamics, AB2 velocity update; stores the motion.
 // MOVE (resident steps, rings of at most MV_RING points): the same thread also moves the ring, refreshes its
 // box, evaluates the strain and bins the floe -- what sz_k_move_strain does with 16 lanes per floe in a
 // second launch.  The ring is read into registers in one go (one memory round trip), the per-edge strain terms
 // are the same expressions summed in the same order.
-template <bool MOVE>
+template <bool MOVE, bool PACK = false>
 // gl_fill (resident steps): the ghost-candidate list to append to (sz_k_ghost_list), -1: none
 // ginl: the allocator to make the next step's ghosts in (inline ghosts), -1: none
+// PACK (tiled steps, with MOVE): the thread also writes the floe's halo records for the next step (PK: what sz_k_halo_pack is given) -- the
+// pack launch of that step and its place in the chain of dependent launches go away
 #ifdef SZ_STAMPS
 // diagnostic build: clock of the thread that updates floe SZ_ISTAMP_FLOE at a few points of the integrator (stamps[900 + k]);
 // tools/integrate_stamps.py prints them
@@ -2580,7 +2636,7 @@ template <bool MOVE>
 #else
 #define ISTAMP(k) do {} while (0)
 #endif
-__global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Params P, int dt, int apply_frc, int bin, int nh, int gl_fill, int ginl) {
+__global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Params P, int dt, int apply_frc, int bin, int nh, int gl_fill, int ginl, PackInl PK) {
   const GridGeo geo = grid_geo(S);
   const StopRegs stop = stop_load(S);
   const int N = nh >= 0 ? nh : S.cnt[C_NOWN];     // nh: see sz_k_ghost_flag_scan
@@ -2588,14 +2644,16 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
   int wh = 0, wf = 0, wv = 0, wx = 0;
   const double wall[4] = { S.eval[0], S.eval[1], S.eval[2], S.eval[3] };
   bool tested = false;
+  double pk_drift = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
     ISTAMP(0);
     const bool gl_any = gl_fill >= 0 || ginl >= 0;
-    const int st0 = gl_any ? S.status[i] : SZ_ACTIVE, ngh0 = gl_any ? S.ngh[i] : 0;
-    const double rmx = MOVE && (gl_any || S.rec32) ? S.rmax[i] : 0.0;
+    const int st0 = gl_any || PACK ? S.status[i] : SZ_ACTIVE, ngh0 = gl_any ? S.ngh[i] : 0;
+    const double rmx = MOVE && (gl_any || S.rec32 || PACK) ? S.rmax[i] : 0.0;
+    const double pk_rx = PACK && PK.ref ? PK.ref[i] : 0.0, pk_ry = PACK && PK.ref ? PK.ref[S.capM + i] : 0.0;      // where the floe lay when the boxes were gathered
     // what a ghost copies of its parent beyond the update's own operands (inline ghosts): asked for HERE, with the first batch -- inside the
     // ghost branch these four loads were a dependent round trip behind the thread's ~60 stores (6.7 k cycles of the 21 k the ghost cost)
-    const bool ghost_ops = MOVE && ginl >= 0;
+    const bool ghost_ops = MOVE && (ginl >= 0 || PACK);
     const long long g_id = ghost_ops ? S.id[i] : 0, g_oki = ghost_ops ? S.okey[i] : 0;
     const double g_over = ghost_ops ? S.overarea[i] : 0.0;
     const signed char g_os = ghost_ops ? S.osign[i] : (signed char)1;
@@ -2741,6 +2799,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
         r[5] = make_double2(nu, nv); r[6] = make_double2(nxi, area); r[7].x = h;
       }
       ISTAMP(4);
+      Shift pshift = shift_none();          // a parent that swaps with its ghost below: where it goes
       if (gl_any) {
         const int gf = ghost_flag_of(wall, S.any_periodic_ew, S.any_periodic_ns, ncx, ncy, rmx, bx0, bx1, by0, by1, (frc_rm ? SZ_REMOVE : st0) == SZ_ACTIVE);
         if (ginl >= 0) {
@@ -2756,12 +2815,79 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
               R.rx[k] = xr + (cx + dx); R.ry[k] = yr + (cy + dy);
             }
             ISTAMP(5);
-            ghost_inline_make(S, geo, wall, N, nv0, ginl, i, gf, n, o, R);
+            ghost_inline_make(S, geo, wall, N, nv0, ginl, i, gf, n, o, R, nullptr, PACK ? &pshift : nullptr);
             ISTAMP(6);
           }
         }
         else ghost_candidate_wave(S, gl_fill, gf != 5, i, gf, n, o);
       }
+      if (PACK) {
+        // ---- the floe's halo records for the next step, as sz_k_halo_pack writes them from the columns this thread has just stored: the drift
+        // test against the positions the boxes were gathered at, the ranks whose box holds the centroid (or an image of it), a slot in each
+        // of their regions -- ONE atomic per wavefront and destination (same-address atomics are worked off one at a time for the whole
+        // chip), handed on by the lanes' rank among the wavefront's hits -- and the record
+        double fx = ncx, fy = ncy;
+        shift_apply(pshift, fx, fy);
+        if (PK.ref) {
+          double ddx = fabs(fx - pk_rx), ddy = fabs(fy - pk_ry);
+          if (PK.per_x && ddx > 0.5 * PK.Lx) ddx = fabs(ddx - PK.Lx);          // a parent the ghost pass wrapped around the domain
+          if (PK.per_y && ddy > 0.5 * PK.Ly) ddy = fabs(ddy - PK.Ly);
+          if (2.0 * fmax(ddx, ddy) > PK.margin) atomicOr(&S.cnt[C_ERR], ERR_HALO_DRIFT);
+          pk_drift = fmax(pk_drift, fmax(ddx, ddy));
+        }
+        const unsigned long long hits = halo_hits(PK.boxes, PK.nranks, PK.me, PK.Lx, PK.Ly, PK.per_x, PK.per_y, fx, fy);
+        const int lane = threadIdx.x & 63;
+        int* run = PK.counts + 64;
+        for (int d = 0; d < PK.nranks; d++) {
+          const bool mine = (hits >> d) & 1ull;
+          const unsigned long long m = __ballot(mine);
+          if (!m) continue;
+          const int leader = __ffsll((long long)m) - 1;
+          int base = 0;
+          if (lane == leader) base = atomicAdd(&run[d], __popcll(m));
+          base = __shfl(base, leader);
+          if (mine) {
+            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (slot >= (PK.dcap ? PK.dcap[d] : PK.cap) || n > HALO_RING) atomicOr(&S.cnt[C_ERR], n > HALO_RING ? ERR_CAP_RING : ERR_CAP_FLOES);
+            else {
+              double* r = PK.send + ((size_t)d * (PK.cap + 1) + 1 + slot) * HALO_REC;
+              r[0] = (double)g_oki; r[1] = (double)(frc_rm ? SZ_REMOVE : st0); r[2] = (double)n; r[3] = fx; r[4] = fy; r[5] = rmx;
+              r[6] = area; r[7] = h; r[8] = nu; r[9] = nv; r[10] = nxi; r[11] = (double)g_id;
+#pragma unroll
+              for (int k = 0; k < MV_RING; k++) {      // the moved ring once more (the expressions of the stores above, then the swap: the same bits)
+                if (k < n) {
+                  const double x = px[k] + (-cx), y = py[k] + (-cy);
+                  const double xr = cda * x - sda * y, yr = sda * x + cda * y;
+                  double mx = xr + (cx + dx), my = yr + (cy + dy);
+                  shift_apply(pshift, mx, my);
+                  r[12 + k] = mx; r[12 + HALO_RING + k] = my;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (PACK) {
+    // the largest displacement since the gather (one atomic per wavefront), then -- unless this launch belongs to a step the batch has
+    // stopped or paused before -- the workgroup that finishes last writes the header records (halo_headers)
+    __shared__ int pk_last;
+    float dm = (float)pk_drift * 1.0001f;
+    for (int d = 32; d >= 1; d >>= 1) dm = fmaxf(dm, __shfl_xor(dm, d));
+    if ((threadIdx.x & 63) == 0 && PK.ref && dm > 0.f) atomicMax(&PK.counts[64 + 65], __float_as_int(dm));      // (non-negative floats order like their bits)
+    if (stop_test_late(S, stop)) {
+      // nothing was integrated and nothing packed: the records of the last pack stay, but the peers must hear of the stop / the pause in the
+      // header words of the next exchange (the pack launch this replaces ran regardless)
+      if (blockIdx.x == 0 && (int)threadIdx.x < PK.nranks) {
+        double* hdr = PK.send + (size_t)threadIdx.x * (PK.cap + 1) * HALO_REC;
+        hdr[1] = (double)S.cnt[C_STOP]; hdr[2] = (double)S.cnt[C_RETRYSTOP];
+      }
+    } else {
+      __syncthreads();
+      if (threadIdx.x == 0) { __threadfence(); pk_last = atomicAdd(&PK.counts[64 + 64], 1) == (int)gridDim.x - 1; }
+      __syncthreads();
+      if (pk_last) halo_headers(S, PK.nranks, PK.send, PK.cap, PK.counts, PK.dcap, PK.ref != nullptr);
     }
   }
   // one atomic per wavefront and counter, spread over WARN_SLOTS lines: the guards fire for most floes of a stiff
@@ -2851,9 +2977,8 @@ __global__ void __launch_bounds__(256) sz_k_move_strain(State S, int strain_only
 }
 
 // ============================================================================ halo exchange (multi-GPU)
-// One record per floe sent to another rank: the columns the collision path reads + the ring.
-constexpr int HALO_RING = 32;
-constexpr int HALO_REC = 12 + 2 * HALO_RING;   // doubles
+// One record per floe sent to another rank: the columns the collision path reads + the ring (HALO_REC, defined before the integrator, which
+// writes the records of the next step itself in tiled runs).
 
 // Every owned floe whose centroid -- or one of its periodic images -- lies inside another rank's
 // (already expanded) box is written to that rank's region of the send buffer.  One block: the
@@ -2864,7 +2989,6 @@ constexpr int HALO_REC = 12 + 2 * HALO_RING;   // doubles
 // centroids when the boxes were gathered, 2 x capM doubles: the halo selection is only valid while no floe has moved
 // further than half the drift margin built into the boxes -- beyond that a neighbour across a tile edge could be missed
 // silently, so it is an error (ERR_HALO_DRIFT), raised one step early enough.
-constexpr int ERR_HALO_DRIFT = 16384;
 constexpr int PACK_TPB = 256;
 // Workgroups of 256 owned floes: a workgroup counts its records per destination in LDS, reserves that many slots of every region
 // with one atomic per destination (counts[64 + d]: running totals), then writes its records; the workgroup that finishes last
@@ -2880,21 +3004,7 @@ __global__ void __launch_bounds__(PACK_TPB) sz_k_halo_pack(State S, int nranks, 
   if (threadIdx.x == 0) ldrift = 0;
   __syncthreads();
   const int n = S.cnt[C_NOWN];
-  auto hits_of = [&](double cx, double cy) {
-    unsigned long long hits = 0;
-    for (int d = 0; d < nranks; d++) {
-      if (d == me) continue;
-      const double* b = boxes + 4 * d;
-      bool hit = false;
-      for (int kx = (per_x ? -1 : 0); kx <= (per_x ? 1 : 0) && !hit; kx++)
-        for (int ky = (per_y ? -1 : 0); ky <= (per_y ? 1 : 0) && !hit; ky++) {
-          double x = cx + kx * Lx, y = cy + ky * Ly;
-          hit = (b[0] <= x && x <= b[1] && b[2] <= y && y <= b[3]);
-        }
-      if (hit) hits |= 1ull << d;
-    }
-    return hits;
-  };
+  auto hits_of = [&](double cx, double cy) { return halo_hits(boxes, nranks, me, Lx, Ly, per_x, per_y, cx, cy); };
   double dmax = 0.0;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
     double cx = S.cx[q], cy = S.cy[q];
@@ -2935,24 +3045,7 @@ __global__ void __launch_bounds__(PACK_TPB) sz_k_halo_pack(State S, int nranks, 
   }
   __syncthreads();
   if (!last) return;
-  if ((int)threadIdx.x < nranks) {
-    int d = threadIdx.x;
-    const int tot = atomicAdd(&run[d], 0);
-    run[d] = 0;
-    counts[d] = tot;
-    const int room = dcap ? dcap[d] : cap;
-    if (send) {
-      // header record: [0] the count, [1] this rank's stop request (resident batches end after the first step that tags a floe,
-      // on EVERY rank: sz_k_halo_unpack_inline reads the flags of all ranks before the next step does anything)
-      double* hdr = send + (size_t)d * (cap + 1) * HALO_REC;
-      hdr[0] = (double)(tot < room ? tot : room); hdr[1] = (double)S.cnt[C_STOP];
-      hdr[2] = (double)S.cnt[C_RETRYSTOP];      // ... and its pause (the step whose narrow phase met an item for the variant that was left out, or outgrew a list)
-    }
-  }
-  if (threadIdx.x == 0) {
-    if (ref) S.cnt[C_DRIFT] = atomicAdd(&run[65], 0);          // what the host sizes the next gather interval with
-    run[65] = 0; run[64] = 0;
-  }
+  halo_headers(S, nranks, send, cap, counts, dcap, ref != nullptr);
 }
 // ---- fixed-layout exchange buffers: region of peer r = 1 header record (count in [0]) followed by
 // `cap` record slots.  The host never needs the counts, so a whole step is enqueued without a sync.
