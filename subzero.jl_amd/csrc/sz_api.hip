@@ -594,7 +594,11 @@ void collisions_step(sz_ctx* c, int n_init, int dt, bool commit_ghosts, bool sta
     if (!ride) stage_elems(c, true);
   }
   stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, static_grid, fuse_forcing == 2 ? (c->precision == 1 ? 2 : 1) : 0, resume ? 2 : lean ? 1 : 0);
-  stage_reduce(c, 1, n_init, dt, c->S.tiled ? 0 : c->hostN + 3 * c->gl_est + c->hostN / 64 + 32);
+  // (rows the step can hold at most, for the reduce's first batch of loads: a tile's halo floes are bounded by the slots of its receive regions,
+  //  and any of them may bring up to three ghosts)
+  int halo = 0;
+  if (c->S.tiled) for (size_t r = 0; r < c->cap_recv.size(); r++) halo += std::max(c->cap_recv[r], 0);
+  stage_reduce(c, 1, n_init, dt, c->hostN + halo + 3 * (c->gl_est + halo) + c->hostN / 64 + 32);
 }
 // fuse_forcing: the step's forcings ride in another launch: 1 the neighbour search's, 2 the narrow phase's
 void collisions(sz_ctx* c, int n_init, int dt, bool commit_ghosts = false, bool static_grid = false, int fuse_forcing = 0) {

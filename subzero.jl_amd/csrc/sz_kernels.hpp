@@ -2598,8 +2598,10 @@ __device__ __forceinline__ void halo_headers(const State& S, int nranks, double*
     if (send) {
       // header record: [0] the count, [1] this rank's stop request (resident batches end after the first step that tags a floe,
       // on EVERY rank: sz_k_halo_unpack_inline reads the flags of all ranks before the next step does anything)
+      // (the stop word may have been raised inside the launch that packs -- the integrator, on another XCD: read where it was written, past
+      //  this XCD's L2)
       double* hdr = send + (size_t)d * (cap + 1) * HALO_REC;
-      hdr[0] = (double)(tot < room ? tot : room); hdr[1] = (double)S.cnt[C_STOP];
+      hdr[0] = (double)(tot < room ? tot : room); hdr[1] = (double)__hip_atomic_load(&S.cnt[C_STOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       hdr[2] = (double)S.cnt[C_RETRYSTOP];      // ... and its pause (the step whose narrow phase met an item for the variant that was left out, or outgrew a list)
     }
   }
@@ -2743,7 +2745,12 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
       if (cell_s < CELL_K) S.cell_slots[(size_t)cell_c * CELL_K + cell_s] = i;
       else S.cell_items[i] = atomicExch(&S.cell_ovf[cell_c], i + 1) - 1;
     }
-    if (frc_rm) { S.status[i] = SZ_REMOVE; request_stop(S); }
+    if (frc_rm) {
+      S.status[i] = SZ_REMOVE;
+      if (PACK) {            // the workgroup that writes the halo headers at the end of THIS launch must see the request: performed at memory and waited for
+        if (S.step > 0 && S.stop_on_tags) { const int was = atomicMax(&S.cnt[C_STOP], S.step); asm volatile("" :: "v"(was)); }
+      } else request_stop(S);
+    }
     // the ghosts of this step are detached here (nothing after the reduce looks at them): the next step's ghost pass
     // then only visits the parents that get new ones
     if (ngh0 != 0) { S.ngh[i] = 0; for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = -1; }
@@ -2875,7 +2882,9 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
     __shared__ int pk_last;
     float dm = (float)pk_drift * 1.0001f;
     for (int d = 32; d >= 1; d >>= 1) dm = fmaxf(dm, __shfl_xor(dm, d));
-    if ((threadIdx.x & 63) == 0 && PK.ref && dm > 0.f) atomicMax(&PK.counts[64 + 65], __float_as_int(dm));      // (non-negative floats order like their bits)
+    if ((threadIdx.x & 63) == 0 && PK.ref && dm > 0.f) {      // (non-negative floats order like their bits; waited for: the ticket below follows it)
+      const int was = atomicMax(&PK.counts[64 + 65], __float_as_int(dm)); asm volatile("" :: "v"(was));
+    }
     if (stop_test_late(S, stop)) {
       // nothing was integrated and nothing packed: the records of the last pack stay, but the peers must hear of the stop / the pause in the
       // header words of the next exchange (the pack launch this replaces ran regardless)
@@ -2884,8 +2893,10 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
         hdr[1] = (double)S.cnt[C_STOP]; hdr[2] = (double)S.cnt[C_RETRYSTOP];
       }
     } else {
+      // (no fence before the ticket: what the last workgroup reads of the others -- slot totals, drift, the stop word -- was written by
+      //  atomics that have returned; the records themselves are read after the launch)
       __syncthreads();
-      if (threadIdx.x == 0) { __threadfence(); pk_last = atomicAdd(&PK.counts[64 + 64], 1) == (int)gridDim.x - 1; }
+      if (threadIdx.x == 0) pk_last = atomicAdd(&PK.counts[64 + 64], 1) == (int)gridDim.x - 1;
       __syncthreads();
       if (pk_last) halo_headers(S, PK.nranks, PK.send, PK.cap, PK.counts, PK.dcap, PK.ref != nullptr);
     }
