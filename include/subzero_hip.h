@@ -362,6 +362,12 @@ int sz_tile_run(sz_ctx *ctx, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t
 int sz_tile_migrate(sz_ctx *ctx, int32_t px, int32_t py, const int32_t *owner_override, int64_t *n_sent, int64_t *n_owned);
 int sz_tile_owned_gidx(sz_ctx *ctx, int64_t *gidx, int64_t n_cap);
 int sz_debug_migrate_path(sz_ctx *ctx);
+/* diagnosis: the ghost / halo row that carried order key `key` in the last resident step that used ghost allocator `slot` (0-based step & 1), as the
+   collision kernels saw it -- out56: row (-1: none), cx, cy, u, v, xi, rmax, area, height, box x0 x1 y0 y1, ring points, parent, status, ring x[20], y[20] */
+int sz_debug_find_key(sz_ctx *ctx, int32_t slot, int64_t key, double *out56);
+/* diagnosis: pair items of the last resident step between the instances (parent, ghosts) of two floe ids -- out61: entries, then {owner key, partner
+   key, contact rows, owner row, partner row} for up to 12 of them */
+int sz_debug_pairs_of_ids(sz_ctx *ctx, int32_t slot, int64_t id_a, int64_t id_b, double *out61);
 int sz_download_subpoints(sz_ctx *ctx, int32_t *off, double *sx, double *sy);
 
 /* ---- output path on the resident state

@@ -81,7 +81,7 @@ EXPORTS = [
     "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms", "sz_forcing_launch", "sz_narrow_kernel_name",
     "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_forcing", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps", "sz_debug_crec_mismatches", "sz_upload_floes_f32", "sz_download_floes_f32", "sz_set_fields_f32", "sz_download_interactions_f32",
     "sz_get_boundary_rects", "sz_debug_match_vertices",
-    "sz_comm_available", "sz_comm_unique_id", "sz_comm_init", "sz_comm_init_host", "sz_comm_destroy", "sz_comm_selftest", "sz_comm_allreduce", "sz_tile_setup", "sz_tile_set_center", "sz_tile_run", "sz_tile_migrate", "sz_tile_owned_gidx", "sz_debug_migrate_path", "sz_download_subpoints",
+    "sz_comm_available", "sz_comm_unique_id", "sz_comm_init", "sz_comm_init_host", "sz_comm_destroy", "sz_comm_selftest", "sz_comm_allreduce", "sz_tile_setup", "sz_tile_set_center", "sz_tile_run", "sz_tile_migrate", "sz_tile_owned_gidx", "sz_debug_migrate_path", "sz_debug_find_key", "sz_debug_pairs_of_ids", "sz_download_subpoints",
 ]
 
 EUL_PARTIAL = 17      # SZ_EUL_PARTIAL: per-cell partial fields of sz_eulerian_partial
@@ -180,6 +180,8 @@ def load(build_if_missing=True):
     L.sz_download_subpoints.argtypes = [C.c_void_p, _ip, _dp, _dp]
     L.sz_tile_owned_gidx.argtypes = [C.c_void_p, _lp, C.c_int64]
     L.sz_debug_migrate_path.argtypes = [C.c_void_p]
+    L.sz_debug_find_key.argtypes = [C.c_void_p, C.c_int32, C.c_int64, _dp]
+    L.sz_debug_pairs_of_ids.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, _dp]
     L.sz_get_boundary_rects.argtypes = [C.c_void_p, _dp]
     L.sz_debug_match_vertices.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, C.c_int32, _dp, _dp, _ip, _ip]
     for n in EXPORTS:

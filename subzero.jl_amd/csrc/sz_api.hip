@@ -1837,6 +1837,34 @@ int sz_debug_crec_mismatches(sz_ctx* c, int64_t* n_bad) {
   *n_bad = (int64_t)v;
   return SZ_OK;
 }
+// diagnosis: the ghost / halo row that carried order key `key` in the last resident step that used ghost allocator `slot` (step s of a batch,
+// 0-based: s & 1), as the collision kernels saw it: out[0] = row (-1: none), cx, cy, u, v, xi, rmax, area, height, box, ring points, parent,
+// status, ring x (20) and y (20) -- 56 doubles
+int sz_debug_find_key(sz_ctx* c, int32_t slot, int64_t key, double* out56) {
+  if (!c || !c->have_floes || !out56 || slot < 0 || slot > 1) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  double* d = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d, 56 * sizeof(double)));
+  hipLaunchKernelGGL(sz_k_debug_find_key, dim3(1), dim3(64), 0, c->stream, c->S, slot, (long long)key, c->hostN, d);
+  HIPCHK(c, hipMemcpyAsync(out56, d, 56 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  return SZ_OK;
+}
+// diagnosis: the pair items of the last resident step (ghost allocator `slot`) between the instances of two floe ids: out[0] = entries (at most 12
+// returned), then {owner key, partner key, contact rows, owner row, partner row} each -- 61 doubles
+int sz_debug_pairs_of_ids(sz_ctx* c, int32_t slot, int64_t id_a, int64_t id_b, double* out61) {
+  if (!c || !c->have_floes || !out61 || slot < 0 || slot > 1) return SZ_E_ARG;
+  (void)hipSetDevice(c->device);
+  double* d = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d, 61 * sizeof(double)));
+  HIPCHK(c, hipMemsetAsync(d, 0, 61 * sizeof(double), c->stream));
+  hipLaunchKernelGGL(sz_k_debug_pairs_of_ids, dim3(1), dim3(64), 0, c->stream, c->S, slot, (long long)id_a, (long long)id_b, c->hostN, d, 12);
+  HIPCHK(c, hipMemcpyAsync(out61, d, 61 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  return SZ_OK;
+}
 int sz_debug_stamps(sz_ctx* c, long long* out16) {
   if (!c || !c->have_floes || !out16) return SZ_E_ARG;
   (void)hipSetDevice(c->device);
@@ -2950,7 +2978,8 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   // collision records of the owned floes (the halo floes get theirs from the unpack kernel, ghosts from their maker; see sz_step)
   S.crec = (!c->no_crec && c->crec_buf && nsteps > 0) ? c->crec_buf : nullptr; c->crec_was_live = S.crec != nullptr;
   if (S.crec) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, S, c->hostN);
-  if (periodic && nsteps > 0) hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0, c->hostN);
+  // (the periodic ghosts of the owned floes for the first step, and the swap of parents that lie outside the domain: in the loop, BEHIND the
+  //  first pack -- see there)
   auto fail = [&](int rc) { S.ginline = 0; S.famrec = 0; S.step = 0; S.crec = nullptr; S.retry_stop = 0; return rc; };
   // SZ_SYNC_DEBUG=1 (diagnosis of a faulting kernel): wait after every stage of every step and say so on stderr -- the last line names the stage
   const bool dbgsync = getenv("SZ_SYNC_DEBUG") != nullptr;
@@ -2973,22 +3002,26 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   bool lean = !c->retry_seen && !c->no_lean_narrow && !larger_rings(c) && !dbgsync;
   std::vector<int> callid_of((size_t)std::max(nsteps, 1), 0);
   int h[C_COUNT]; int rc = SZ_OK;
-  // The halo records of step s + 1 are written by the integrator of step s (the thread that has just placed the floe holds all a record
-  // carries; SZ_TILE_PACK_INLINE=0: by a pack launch at the start of every step, as the first step of a batch, the step after a box
-  // gather -- its boxes, slot counts and buffers are new -- and the step a batch is taken up again at always are).
-  static const bool pack_inline_on = !(getenv("SZ_TILE_PACK_INLINE") && atoi(getenv("SZ_TILE_PACK_INLINE")) == 0);
+  // The halo records of step s + 1 are written by the integrator of step s: the thread that has just placed the floe holds all a record
+  // carries, and it packs the floe as the update left it, BEFORE the swap of a parent that left the domain -- the receiving rank makes
+  // the ghosts with the routine the owner runs on the same values (see sz_k_integrate<true, true>).  A pack launch remains for the first
+  // step of a batch (and the step a paused batch is taken up again at): it runs BEFORE the launch that makes the owned floes' first
+  // ghosts and swaps the parents that lie outside, for the same reason.  New boxes for step s + 1 are therefore gathered before the
+  // integrator of step s (from the positions that step started with; the drift margin covers the step in between).
   for (int s_begin = 0;;) {
   S.retry_stop = lean ? 1 : 0;
-  bool packed = false;               // the records of the step about to run are in d_send already
   for (int s = s_begin; s < nsteps; s++) {
     const int tstep = tstep0 + s;
     S.step = s + 1; S.gslot = s & 1;
     c->tile_dt = dt;
-    if (c->tile_since_box < 0 || c->tile_since_box >= c->tile_rebox_cur) { int rc = tile_rebox(c); if (rc) return fail(rc); }
+    if (s == s_begin) {
+      if (c->tile_since_box < 0 || c->tile_since_box >= c->tile_rebox_cur) { int rc = tile_rebox(c); if (rc) return fail(rc); }
+      stage_done(s, "rebox");
+      tile_pack(c);
+      if (periodic) hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, s & 1, c->hostN);
+    }
     c->tile_since_box++;
     const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
-    stage_done(s, "rebox");
-    if (!packed) tile_pack(c);
     stage_done(s, "pack");
     // With peers the forcings of the owned floes (they need nothing from the halo) run BESIDE the exchange -- on the main stream while the
     // communication stream trades the regions, before the host's channel blocks -- and the narrow launch carries no forcing tail; without
@@ -3022,10 +3055,10 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
       stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, true, fmode == 2 ? (c->precision == 1 ? 2 : 1) : 0, 0); stage_done(s, "narrow phase");
       stage_reduce(c, 1, -1, dt, 0); stage_done(s, "reduce");
     } else collisions_step(c, -1, dt, false, true, fmode, lean, false);
-    // (the next step gathers the boxes anew when tile_since_box has reached the interval: see the top of the loop)
-    packed = pack_inline_on && !dbgsync && s + 1 < nsteps && c->tile_since_box < c->tile_rebox_cur && c->d_send != nullptr;
+    const bool pack_next = s + 1 < nsteps;
+    if (pack_next && c->tile_since_box >= c->tile_rebox_cur) { int rc = tile_rebox(c); if (rc) return fail(rc); }      // (synchronises: once per gather interval)
     const PackInl pk = tile_pack_args(c);
-    stage_integrate(c, dt, false, coupling, true, -1, periodic && s + 1 < nsteps ? 1 - (s & 1) : -1, packed ? &pk : nullptr);
+    stage_integrate(c, dt, false, coupling, true, -1, periodic && s + 1 < nsteps ? 1 - (s & 1) : -1, pack_next ? &pk : nullptr);
     stage_done(s, "integrate");
   }
   S.step = 0;
@@ -3070,8 +3103,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   c->grid_live = false; use_static_grid(c);
   HIPCHK(c, hipMemsetAsync(S.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
   if (S.crec) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, S, c->hostN);
-  if (periodic) hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, sp & 1, c->hostN);
-  s_begin = sp;
+  s_begin = sp;          // (the ghosts of that step: behind its pack, at the top of the loop)
   }
   S.step = 0; S.ginline = 0; S.famrec = 0; S.crec = nullptr; S.retry_stop = 0;
   {

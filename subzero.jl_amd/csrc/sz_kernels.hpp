@@ -720,9 +720,8 @@ __device__ __forceinline__ void ghost_row_load(const State& S, int i, int n, int
 __device__ __forceinline__ int ghost_count_of(int fl) { return fl == 5 ? 0 : ((fl & 3) != 1 && ((fl >> 2) & 3) != 1) ? 3 : 1; }
 // given: the caller has already drawn the rows and ring points of the ghosts from the allocator ({rows << 32 | points} before them) -- the halo
 // unpack of a tiled run allocates a received floe and its ghosts in one go
-// parent_shift (may be null): the translations a parent that swapped with its ghost was moved by (the caller goes on with the parent's new place)
 __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, const double* wall, int N, int NV0, int slot, int i, int fl, int n, int vo,
-                                                  const GhostRow& R, const unsigned long long* given = nullptr, Shift* parent_shift = nullptr) {
+                                                  const GhostRow& R, const unsigned long long* given = nullptr) {
   const int dir0 = (fl & 3) - 1, dir1 = ((fl >> 2) & 3) - 1;
   const int ng = dir0 != 0 && dir1 != 0 ? 3 : 1;
   const bool body = S.body_rings != 0;
@@ -835,7 +834,6 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
   if (ng == 3) { put(c1, 1, k1); put(c2, 2, k2); }
   GSTAMP(15);
   if (moved) {                                               // the parent swapped with its ghost(s)
-    if (parent_shift) *parent_shift = cp;
     double px = pcx, py = pcy, x0 = pb0, y0 = pb2, x1 = pb1, y1 = pb3;
     shift_apply(cp, px, py); shift_apply(cp, x0, y0); shift_apply(cp, x1, y1);
     S.cx[i] = px; S.cy[i] = py; S.bbx0[i] = x0; S.bbx1[i] = x1; S.bby0[i] = y0; S.bby1[i] = y1;
@@ -2806,7 +2804,6 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
         r[5] = make_double2(nu, nv); r[6] = make_double2(nxi, area); r[7].x = h;
       }
       ISTAMP(4);
-      Shift pshift = shift_none();          // a parent that swaps with its ghost below: where it goes
       if (gl_any) {
         const int gf = ghost_flag_of(wall, S.any_periodic_ew, S.any_periodic_ns, ncx, ncy, rmx, bx0, bx1, by0, by1, (frc_rm ? SZ_REMOVE : st0) == SZ_ACTIVE);
         if (ginl >= 0) {
@@ -2822,19 +2819,22 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
               R.rx[k] = xr + (cx + dx); R.ry[k] = yr + (cy + dy);
             }
             ISTAMP(5);
-            ghost_inline_make(S, geo, wall, N, nv0, ginl, i, gf, n, o, R, nullptr, PACK ? &pshift : nullptr);
+            ghost_inline_make(S, geo, wall, N, nv0, ginl, i, gf, n, o, R);
             ISTAMP(6);
           }
         }
         else ghost_candidate_wave(S, gl_fill, gf != 5, i, gf, n, o);
       }
       if (PACK) {
-        // ---- the floe's halo records for the next step, as sz_k_halo_pack writes them from the columns this thread has just stored: the drift
-        // test against the positions the boxes were gathered at, the ranks whose box holds the centroid (or an image of it), a slot in each
-        // of their regions -- ONE atomic per wavefront and destination (same-address atomics are worked off one at a time for the whole
-        // chip), handed on by the lanes' rank among the wavefront's hits -- and the record
-        double fx = ncx, fy = ncy;
-        shift_apply(pshift, fx, fy);
+        // ---- the floe's halo records for the next step: the drift test against the positions the boxes were gathered at, the ranks whose
+        // box holds the centroid (or an image of it), a slot in each of their regions -- ONE atomic per wavefront and destination
+        // (same-address atomics are worked off one at a time for the whole chip), handed on by the lanes' rank among the wavefront's
+        // hits -- and the record.  The record carries the floe as the update has left it, BEFORE a swap with its ghost (a parent that
+        // left the domain): the receiving rank makes the ghosts from the record with the very routine the owner has just run on the same
+        // values (ghost_inline_make, which also swaps the received parent), so the instances of a floe are the same bits -- and the same
+        // ghost numbers at the same places -- on every rank.  Ghosts made from a parent AFTER its swap are the same four places with two
+        // numbers exchanged and one coordinate rounded once more: the Dict rule then keeps another instance pair of the same contact.
+        const double fx = ncx, fy = ncy;
         if (PK.ref) {
           double ddx = fabs(fx - pk_rx), ddy = fabs(fy - pk_ry);
           if (PK.per_x && ddx > 0.5 * PK.Lx) ddx = fabs(ddx - PK.Lx);          // a parent the ghost pass wrapped around the domain
@@ -2861,13 +2861,11 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
               r[0] = (double)g_oki; r[1] = (double)(frc_rm ? SZ_REMOVE : st0); r[2] = (double)n; r[3] = fx; r[4] = fy; r[5] = rmx;
               r[6] = area; r[7] = h; r[8] = nu; r[9] = nv; r[10] = nxi; r[11] = (double)g_id;
 #pragma unroll
-              for (int k = 0; k < MV_RING; k++) {      // the moved ring once more (the expressions of the stores above, then the swap: the same bits)
+              for (int k = 0; k < MV_RING; k++) {      // the moved ring once more (the expressions of the stores above: the same bits)
                 if (k < n) {
                   const double x = px[k] + (-cx), y = py[k] + (-cy);
                   const double xr = cda * x - sda * y, yr = sda * x + cda * y;
-                  double mx = xr + (cx + dx), my = yr + (cy + dy);
-                  shift_apply(pshift, mx, my);
-                  r[12 + k] = mx; r[12 + HALO_RING + k] = my;
+                  r[12 + k] = xr + (cx + dx); r[12 + HALO_RING + k] = yr + (cy + dy);
                 }
               }
             }
@@ -3232,6 +3230,46 @@ __global__ void __launch_bounds__(UNPACK_TPB) sz_k_halo_unpack_inline(State S, c
     const unsigned long long given = ((unsigned long long)(og + 1) << 32) | (unsigned)(ov + nv);
     ghost_inline_make(S, geo, wall, nown, NV0, slot, g, gf, nv, vb, R, &given);
   }
+}
+// diagnosis (sz_debug_find_key): the row that held order key `key` in the last resident step that used allocator `slot` -- ghosts and halo floes stay
+// in memory behind the parents until the next step overwrites them.  out[0] = row (-1: not found), then cx, cy, u, v, xi, rmax, area, height,
+// box x0 x1 y0 y1, ring points, parent, status; the ring x.. at out[16], y.. at out[16 + MV_RING]
+__global__ void sz_k_debug_find_key(State S, int slot, long long key, int nown, double* out) {
+  if (blockIdx.x || threadIdx.x) return;
+  const int rows = (int)(S.galloc[slot * 16] >> 32);
+  out[0] = -1.0;
+  for (int og = 0; og < rows && og < S.capM - nown; og++) {
+    if (S.gkeys[(size_t)slot * S.capM + og] != key) continue;
+    const int g = nown + og, o = S.voff[g], n = S.voff[g + 1] - o;
+    out[0] = g; out[1] = S.cx[g]; out[2] = S.cy[g]; out[3] = S.u[g]; out[4] = S.v[g]; out[5] = S.xi[g]; out[6] = S.rmax[g]; out[7] = S.area[g]; out[8] = S.height[g];
+    out[9] = S.bbx0[g]; out[10] = S.bbx1[g]; out[11] = S.bby0[g]; out[12] = S.bby1[g]; out[13] = n; out[14] = S.parent[g]; out[15] = S.status[g];
+    for (int k = 0; k < MV_RING; k++) { const double2 p = k < n ? S.vxy[o + k] : make_double2(0.0, 0.0); out[16 + k] = p.x; out[16 + MV_RING + k] = p.y; }
+    return;
+  }
+}
+// diagnosis (sz_debug_pairs_of_ids): the pair items of the last resident step between instances (parent, ghosts) of two floe ids, by order key:
+// out[0] = entries, then per entry {key of the owner row, key of the partner row, contact rows of the item, owner row, partner row}
+__global__ void sz_k_debug_pairs_of_ids(State S, int slot, long long ida, long long idb, int nown, double* out, int cap) {
+  if (blockIdx.x || threadIdx.x) return;
+  const int rows = nown + (int)(S.galloc[slot * 16] >> 32);
+  int n = 0;
+  for (int k = 0; k < rows && k < S.capM; k++) {
+    const long long idk = S.id[k];
+    if (idk != ida && idk != idb) continue;
+    const int no = S.n_out[k];
+    for (int r = 0; r < no && r < S.maxnb; r++) {
+      const int p = S.nb_out[(size_t)k * S.maxnb + r];
+      if (p < 0 || p >= S.capM) continue;
+      const long long idp = S.id[p];
+      if (!((idk == ida && idp == idb) || (idk == idb && idp == ida))) continue;
+      if (n < cap) {
+        const int2 info = S.it_info[(size_t)k * S.maxnb + r];
+        out[1 + 5 * n] = (double)S.okey[k]; out[2 + 5 * n] = (double)S.okey[p]; out[3 + 5 * n] = (double)(info.x & 255); out[4 + 5 * n] = k; out[5 + 5 * n] = p;
+      }
+      n++;
+    }
+  }
+  out[0] = n;
 }
 // bounding box of the owned centroids and the largest rmax: out[0..4] = xmin, xmax, ymin, ymax, rmax; out[5] = the largest
 // displacement since the last box gather as the last pack kernel measured it (C_DRIFT); out[6] = the largest |u|, |v| now

@@ -265,6 +265,21 @@ class World:
         self._chk(self.L.sz_debug_crec_mismatches(self.h, C.byref(n)))
         return int(n.value)
 
+    def find_key(self, slot, key):
+        """diagnosis: the ghost / halo row with order key `key` of the last resident step that used ghost allocator `slot` (sz_debug_find_key)"""
+        out = np.zeros(56)
+        self._chk(self.L.sz_debug_find_key(self.h, int(slot), int(key), capi.ptr(out)))
+        n = int(out[13])
+        return None if out[0] < 0 else {"row": int(out[0]), "cx": out[1], "cy": out[2], "u": out[3], "v": out[4], "xi": out[5], "rmax": out[6], "area": out[7],
+                                        "height": out[8], "box": out[9:13].copy(), "parent": int(out[14]), "status": int(out[15]),
+                                        "x": out[16:16 + n].copy(), "y": out[36:36 + n].copy()}
+
+    def pairs_of_ids(self, slot, id_a, id_b):
+        """diagnosis: (owner key, partner key, contact rows, owner row, partner row) of the last resident step's pair items between instances of two ids"""
+        out = np.zeros(61)
+        self._chk(self.L.sz_debug_pairs_of_ids(self.h, int(slot), int(id_a), int(id_b), capi.ptr(out)))
+        return [tuple(int(v) for v in out[1 + 5 * k:6 + 5 * k]) for k in range(min(int(out[0]), 12))]
+
     def stats(self):
         s = capi.SzStats()
         self._chk(self.L.sz_get_stats(self.h, C.byref(s)))

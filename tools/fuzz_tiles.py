@@ -1,0 +1,31 @@
+"""Tiled runs with re-tiling against the single context, over random cases: 2 or 4 ranks sharing the GPU (library exchange over the host
+transport), fast floes crossing tile edges and periodic walls, a re-tile (sz_tile_migrate, device path) every few steps; every owned column
+must be bit-equal to the single context's.      python tools/fuzz_tiles.py [cases] [seed0]"""
+import os, sys, random, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    from tests import test_tiles_gpu as T
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    ok = 0
+    for c in range(cases):
+        rnd = random.Random(seed0 + c)
+        world = rnd.choice([2, 2, 4])
+        n = rnd.randrange(500, 1600) if world == 2 else rnd.randrange(1000, 2400)
+        every = rnd.randrange(4, 16)
+        steps = every * rnd.randrange(2, 5) + rnd.randrange(0, every)
+        t = time.time()
+        try:
+            moved = T.migration_case(world, n, seed0 + c, steps, every, verbose=False)
+            ok += 1
+            print(f"case {c}: world {world} n {n} steps {steps} re-tile every {every}: bit-equal, {moved} floes changed tile ({time.time() - t:.1f} s)", flush=True)
+        except AssertionError as e:
+            print(f"case {c}: world {world} n {n} steps {steps} re-tile every {every}: FAILED {str(e)[:400]}", flush=True)
+    print(f"{ok} / {cases} cases bit-equal")
+    sys.exit(0 if ok == cases else 1)
+
+
+if __name__ == "__main__":
+    main()
