@@ -589,7 +589,8 @@ void collisions_step(sz_ctx* c, int n_init, int dt, bool commit_ghosts, bool sta
   if (!resume) {
     // resident steps of a field between walls: the element items are made in the tail of the neighbour search's launch
     const bool ride = static_grid && fuse_forcing != 1 && c->S.any_domain_work && !c->S.any_periodic_ew && !c->S.any_periodic_ns &&
-                      c->S.maxnb <= MAXNB && !c->no_elems_ride;
+                      c->S.maxnb <= MAXNB && !c->no_elems_ride && !c->S.tiled;      // (a tile's neighbour launch commits the halo rows' count: the scan
+                                                                                        //  would read it while it changes)
     stage_broad(c, commit_ghosts, static_grid, fuse_forcing == 1, ride);
     if (!ride) stage_elems(c, true);
   }
@@ -3079,18 +3080,19 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   HIPCHK(c, hipMemsetAsync(S.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream));
   HIPCHK(c, hipMemsetAsync(S.cnt + C_PAUSED, 0, sizeof(int), c->stream));
   S.retry_stop = 0; c->retry_seen = true; lean = false;
+  {          // the forcing outputs as of step sp (the steps after it are run again).  BEFORE that step is finished: its integrator reads them, and
+             // the steps enqueued behind it have gone on alternating the sets on the host while their forcing kernels returned at once
+    int want = 0;
+    for (int s2 = 0; s2 < sp; s2++) if (fset[s2] >= 0) want = fset[s2];
+    if (want != cur_set) swap_frc();
+    for (int s2 = sp; s2 < nsteps; s2++) fset[s2] = -1;
+  }
   if (h[C_PAUSED] == sp) {          // this rank's step: the variant, then what the pause held back
     S.step = sp; S.gslot = (sp - 1) & 1; S.callid = callid_of[sp - 1];
     stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, true, 0, 2);
     stage_reduce(c, 1, -1, dt, 0);
     stage_integrate(c, dt, false, coupling_sp, true, -1, -1);
     S.step = 0;
-  }
-  {          // the forcing outputs as of step sp (the steps after it are run again)
-    int want = 0;
-    for (int s2 = 0; s2 < sp; s2++) if (fset[s2] >= 0) want = fset[s2];
-    if (want != cur_set) swap_frc();
-    for (int s2 = sp; s2 < nsteps; s2++) fset[s2] = -1;
   }
   c->tile_dirty = true;
   if (sp >= nsteps) {               // (the last step of the batch: no peer has heard of it, nothing is run again)

@@ -42,7 +42,12 @@ def _free_port():
 def _field(n, seed, fast=False, shape="star"):
     from subzero_jl_amd import fields
     from subzero_jl_amd import floe as floe_mod
-    cfg = fields.make_config(n_floes=n, seed=seed, shape=shape, **({"spacing": 1.0e4, "ocean": "shear"} if shape == "voronoi" else {}))
+    kw = {}
+    if shape == "voronoi":
+        kw = {"spacing": 1.0e4, "ocean": "shear"}
+    elif shape in ("walls", "walls-topo"):          # collision walls instead of periodic ones (configs[3]), with or without the island and the coast wedges
+        kw = {"walls": True, "topography": shape == "walls-topo", "ocean": "shear"}; shape = "star"
+    cfg = fields.make_config(n_floes=n, seed=seed, shape=shape, **kw)
     if fast:
         # fast floes on a field shifted so that parents straddle the walls: some start outside the domain, others leave it during the
         # run -- they swap with their ghosts (collisions.jl:942-950), and the forcings of a tiled step are evaluated BEFORE its ghost pass
@@ -496,6 +501,11 @@ def _worker_migrate(rank, world, port, n, seed, steps, every, q, shape="star", f
             ran += done
             if done < k:               # a floe was tagged: the batch ended on every rank (the host's simplify_floes! would run now)
                 break
+            if stop:                   # ... or it was tagged in the batch's last step: the host looks at the tags after every batch
+                tags = [None] * world
+                dist.all_gather_object(tags, bool(np.any(tw.owned("status") != 1)))
+                if any(tags):
+                    break
             if t0 + every < steps and not os.environ.get("SZ_PROBE_SKIP_MIGRATE"):          # (the switch: tools/probe/tiles_first_diff.py)
                 t = time.perf_counter(); moved += tw.migrate(); cost.append(time.perf_counter() - t)
                 assert tw.migrate_path == 1 or os.environ.get("SZ_PROBE_ANY_PATH"), tw.migrate_path          # floes that drifted over a tile edge: packed and placed on the device
@@ -530,6 +540,17 @@ def test_ghosts_of_a_halo_floe_in_the_step_it_swaps(world, n, seed, steps, every
     then keeps another instance pair of the same contact, and the rows differ in the last bits.  The halo record therefore carries the floe as the
     update left it, before the swap, and the receiving rank swaps it itself: bit-equal to the single context, rings included."""
     migration_case(world, n, seed, steps, every, verbose=False)
+
+
+@pytest.mark.parametrize("world,n,seed,steps,every,shape,fast", [(4, 2006, 30025, 40, 9, "walls-topo", True), (4, 1943, 30071, 25, 12, "walls", False),
+                                                                 (2, 977, 30003, 51, 11, "walls-topo", False)])
+def test_tiles_between_collision_walls(world, n, seed, steps, every, shape, fast):
+    """Fields between collision walls (configs[3]: no ghosts, floe - wall and floe - topography items) in tiles, cases of tools/fuzz_tiles.py ... walls.
+    The first one pauses for the largest narrow variant while the forcings of a spatially varying ocean run beside the exchange: the integrator that
+    finishes the paused step must read the forcing outputs of THAT step (the steps enqueued behind it go on alternating the two output sets on the
+    host).  The others ran into the element scan riding in the tail of a tile's neighbour launch, which commits the halo rows' count while the scan
+    reads it (spurious row-capacity errors and last-digit differences, from run to run): a tile's element items have a launch of their own."""
+    migration_case(world, n, seed, steps, every, verbose=False, shape=shape, fast=fast)
 
 
 def migration_case(world, n, seed, steps, every, verbose=True, shape="star", fast=True, stop=False):
@@ -568,7 +589,7 @@ def migration_case(world, n, seed, steps, every, verbose=True, shape="star", fas
         off, x, y = out["_rings"]; hoff, hx, hy = hw.rings()           # the rings too, point by point
         for k, g in enumerate(gidx):
             assert np.array_equal(x[off[k]:off[k + 1]], hx[hoff[g]:hoff[g + 1]]) and np.array_equal(y[off[k]:off[k + 1]], hy[hoff[g]:hoff[g + 1]]), (rank, "ring", int(g))
-    assert seen.all() and (moved > 0 or os.environ.get("SZ_PROBE_SKIP_MIGRATE") or not fast or ran < steps)
+    assert seen.all() and (moved > 0 or os.environ.get("SZ_PROBE_SKIP_MIGRATE") or not fast or ran < steps or shape != "star")
     return moved
 
 

@@ -1,15 +1,15 @@
 """first step at which a tiled run with re-tiling (a case of tools/fuzz_tiles.py) leaves the single context's trajectory, and the floes that do:
-    python tools/probe/tiles_first_diff.py <seed> [no-migrate | batches-only]"""
+    python tools/probe/tiles_first_diff.py <seed> [mixed | walls] [no-migrate | batches-only]"""
 import os, sys, random
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 
 
-def run(T_, world, n, seed, steps, every):
+def run(T_, world, n, seed, steps, every, shape="star", fast=True, stop=False):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue(); port = T_._free_port()
-    procs = [ctx.Process(target=T_._run_worker_migrate, args=(r, world, port, n, seed, steps, every, q)) for r in range(world)]
+    procs = [ctx.Process(target=T_._run_worker_migrate, args=(r, world, port, n, seed, steps, every, q, shape, fast, stop)) for r in range(world)]
     for p in procs:
         p.start()
     res = T_._collect(q, world)
@@ -24,23 +24,28 @@ def main():
     from tests import test_tiles_gpu as T
     os.environ["SZ_PROBE_ANY_PATH"] = "1"
     seed = int(sys.argv[1])
-    rnd = random.Random(seed)
-    world = rnd.choice([2, 2, 4])
-    n = rnd.randrange(500, 1600) if world == 2 else rnd.randrange(1000, 2400)
-    every = rnd.randrange(4, 16)
-    steps = every * rnd.randrange(2, 5) + rnd.randrange(0, every)
-    if len(sys.argv) > 2 and sys.argv[2] == "no-migrate":
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import fuzz_tiles
+    opts = sys.argv[2:]
+    world, n, steps, every, kind, shape, fast, stop = fuzz_tiles.case_params(seed, "mixed" in opts, "walls" in opts)
+    if "no-migrate" in opts:
         every = 10 ** 6               # one batch
-    if len(sys.argv) > 2 and sys.argv[2] == "batches-only":
+    if "batches-only" in opts:
         os.environ["SZ_PROBE_SKIP_MIGRATE"] = "1"          # the same batches, no re-tile between them
-    cfg = T._field(n, seed, fast=True)
+    cfg = T._field(n, seed, fast=fast, shape=shape)
 
     def diffs(Tn):
-        res = run(T, world, n, seed, Tn, every)
+        res = run(T, world, n, seed, Tn, every, shape, fast, stop)
         hw = fields.build_world(subzero_jl_amd.World(0), cfg)
-        hw.run(Tn, 0, cfg["dt"], coupling_dt=1, stop_on_tags=False)
+        hw.run(Tn, 0, cfg["dt"], coupling_dt=1, stop_on_tags=stop)
         bad = []
+        tagged = np.nonzero(hw.get("status")[:n] != 1)[0]
+        if len(tagged):
+            print(f"   after {Tn} steps the single context holds tagged floes {tagged.tolist()} (status {hw.get('status')[tagged].tolist()}), steps run there / here:",
+                  [r[2]["_ran"] for r in res])
         for rank, gidx, out, mv, cost in res:
+            if out["_ran"] != Tn:
+                bad.append((-1, rank, "steps run", float(out["_ran"]), float(Tn)))
             for f in T.FIELDS:
                 ref = hw.get(f)[gidx]
                 for k in np.nonzero(out[f] != ref)[0]:
@@ -62,7 +67,7 @@ def main():
         else: lo = mid
     bad, hw = diffs(hi)
     L = cfg["L"]
-    print(f"seed {seed}: world {world} n {n} steps {steps} re-tile every {every}: first difference after step {hi}")
+    print(f"seed {seed} [{kind}]: world {world} n {n} steps {steps} re-tile every {every}: first difference after step {hi}")
     floes = sorted(set(b[0] for b in bad))
     for g in floes[:8]:
         cx, cy, r = hw.get("cx")[g], hw.get("cy")[g], hw.get("rmax")[g]
