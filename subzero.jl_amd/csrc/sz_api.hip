@@ -137,6 +137,7 @@ struct sz_ctx {
   Pool tw_part_allocs; double* d_tw_partial = nullptr;
   Pool mig_allocs;                  // scratch of sz_tile_migrate (streams, directory, the gathered rows): kept between migrations
   Pool sub_allocs;                  // sub-floe points of a tile that outgrew State::capS in a migration (sz_tile_migrate): until the next upload
+  int upload_M = 0, upload_V = 0;   // floes and ring points of the last sz_upload_floes (what its capacities were carved for)
   int migrate_path = 0;             // how the last sz_tile_migrate ran: 1 packed on the device, 2 staged through the host (sz_debug_migrate_path)
   std::vector<long long> tile_gidx; // global index of every owned floe (sz_tile_enable): status.fuse_idx of a tiled context is reported in global numbers
   bool tile_inline_off = false;     // SZ_TILE_INLINE=0: the tiled steps of sz_tile_run keep the list-based ghost pass, their own forcing launch and the one-workgroup unpack (A/B)
@@ -1026,7 +1027,8 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   if (const char* e = getenv("SZ_MAXNB")) S.maxnb = atoi(e) > 64 ? 256 : atoi(e) > MAXNB ? 64 : MAXNB;
   S.rowcap = S.maxnb <= MAXNB ? ROWCAP : S.maxnb <= 64 ? 128 : 512;
   if (const char* e = getenv("SZ_ROWCAP")) S.rowcap = std::max(1, atoi(e));          // (tests of the growth path)
-  S.capM = 2 * M + 64; S.capV = 2 * V + 4096; S.capPairs = S.capM * (S.maxnb <= MAXNB ? 8 : 16); S.capElem = S.capM * 4;
+  S.capM = std::max(2 * M + 64, M + 2048);      // (rows for the floes, their ghosts and -- a tile -- its halo: small tiles of fast floes hold more halo floes than owned ones)
+  S.capV = std::max(2 * V + 4096, V + 32768); S.capPairs = S.capM * (S.maxnb <= MAXNB ? 8 : 16); S.capElem = S.capM * 4;
   S.capRows = S.capPairs * 3 + S.capElem * 2; S.capCells = 4 * S.capM + 64; S.capS = NS;
   int rc;
 #define DA(field, n) if ((rc = dalloc(c, &S.field, (size_t)(n), c->allocs))) return rc
@@ -1116,7 +1118,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   H2D(S.cnt, h, C_COUNT + 64 + 72, int);
   hipLaunchKernelGGL(sz_k_osign, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0);
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->hostM = M; c->hostN = N; c->have_floes = true; c->tile_dirty = false; c->mixed_pts_ok = false;
+  c->hostM = M; c->hostN = N; c->have_floes = true; c->tile_dirty = false; c->mixed_pts_ok = false; c->upload_M = M; c->upload_V = V;
   c->gl_valid = false; c->gl_est = 0;
   c->mixed_geom_ok = false; c->rings_stale = false; S.rec32 = nullptr; S.ring32 = nullptr; S.body_rings = 0;
   if (f->rmax) {          // parents near a periodic wall: how long the ghost-candidate list will be (a superset of it)
@@ -2589,10 +2591,9 @@ int tile_migrate_device(sz_ctx* c, int px, int py, const int32_t* owner_override
     hsrc[r] = s2; ngid[r] = src[r].g; nvoff[r + 1] = nvoff[r] + nv; nsoff[r + 1] = nsoff[r] + ns;
   }
   const int Vn = nvoff[Nn], NSn = nsoff[Nn];
-  // does it fit what the context was carved for (sz_upload_floes: capM = 2 M + 64 rows and capV = 2 V + 4096 ring points, for the owned floes, their
+  // does it fit what the context was carved for (sz_upload_floes: at least 2 M + 64 rows and 2 V + 4096 ring points, for the owned floes, their
   // ghosts and the halo)?  An eighth more than the upload held is let in.
-  const int M0 = (S.capM - 64) / 2, V0 = (S.capV - 4096) / 2;
-  const bool fits = Nn <= M0 + M0 / 8 && Vn <= V0 + V0 / 8 && !too_long;
+  const bool fits = Nn <= c->upload_M + c->upload_M / 8 && Vn <= c->upload_V + c->upload_V / 8 && !too_long;
   int bits = (nmove > 0 ? 1 : 0) | (fits ? 0 : 2) | (Nn == 0 ? 4 : 0) | (R < 0 ? 8 : 0), allb = 0;
   if ((rc = comm_agree_bits(c, bits, &allb))) return rc;
   if (allb & 8) { c->err = "sz_tile_migrate: a stream of movers arrived inconsistent"; return SZ_E_STATE; }

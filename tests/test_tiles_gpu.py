@@ -604,8 +604,9 @@ def _worker_overflow(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
-        cfg = _field(1000, 35)
-        # a drift margin as wide as the domain: every floe of every other rank is in this rank's halo -- three times what the tile's rows hold
+        cfg = _field(4000, 35)
+        # a drift margin as wide as the domain: every floe of every other rank is in this rank's halo -- 3 000 floes and their ghosts for a tile whose
+        # upload of 1 000 floes carved max(2 M + 64, M + 2048) = 3 048 rows
         tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True, backend="library-host", rebox_every=5, drift_margin=float(cfg["L"]))
         try:
             tw.run(4, 0, cfg["dt"], coupling_dt=1)
