@@ -495,6 +495,8 @@ def _worker_migrate(rank, world, port, n, seed, steps, every, q, shape="star", f
         cfg = _field(n, seed, fast=fast, shape=shape)
         backend = os.environ.get("SZ_FUZZ_BACKEND", "library-host")          # ("torch": the older path of one collective per step on buffers the library packs)
         tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True, backend=backend, rebox_every=5 if backend != "torch" else 50)
+        if os.environ.get("SZ_FUZZ_PRECISION") == "mixed":          # (tools/fuzz_tiles.py: fp32 forcings and broad-phase records, fp64 world rings)
+            tw.world.set_precision("mixed")
         moved, cost, ran = 0, [], 0
         for t0 in range(0, steps, every):
             k = min(every, steps - t0)
@@ -580,6 +582,8 @@ def migration_case(world, n, seed, steps, every, verbose=True, shape="star", fas
                 p.terminate()
     cfg = _field(n, seed, fast=fast, shape=shape)
     hw = fields.build_world(subzero_jl_amd.World(0), cfg)
+    if os.environ.get("SZ_FUZZ_PRECISION") == "mixed":
+        hw.set_precision("mixed")          # (with SZ_BODY_RINGS=0 in the environment: a tile keeps its rings in world coordinates, fp64)
     ran = hw.run(steps, 0, cfg["dt"], coupling_dt=1, stop_on_tags=stop)
     seen = np.zeros(n, bool); moved = 0
     for rank, gidx, out, mv, cost in res:
