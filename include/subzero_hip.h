@@ -299,9 +299,13 @@ int sz_set_stream(sz_ctx *ctx, void *hip_stream);
                          it measured and the largest velocity now (30 % of the margin), at most doubling it.  rebox_every < 0:
                          exactly every |rebox_every| steps, no adaptation (tests of the drift error)
      sz_tile_run         nsteps x timestep_sim! of the tiled run, collectively, same arguments on every rank.  Per step:
-                         pack kernel, grouped ncclSend / ncclRecv with the neighbouring tiles only (real counts in the header
-                         records, slots per pair sized at the last gather), forcings of the owned floes beside the exchange,
-                         unpack + step.  Two-way coupling partial sums are all-reduced.  A floe that moves further than half
+                         grouped ncclSend / ncclRecv (whole regions with the neighbouring tiles, real counts in the header
+                         records, slots per pair sized at the last gather; the header record with every rank), forcings of
+                         the owned floes beside the exchange, unpack + step; the halo records of the next step are written by
+                         the step's integrator (a pack launch starts a batch), each floe as the update left it, before a swap
+                         with its ghost -- the receiving rank swaps it with the owner's routine, so a floe's instances are the
+                         same bits with the same ghost numbers on every rank.  Two-way coupling partial sums are all-reduced
+                         (those batches run to their end: no tag stop).  A floe that moves further than half
                          the margin between two gathers is an error (halo-drift bit), never a silently missed contact.
                          As with sz_step the batch ends after the first step that leaves a floe tagged remove / fuse ON ANY RANK
                          (simplify_floes!, simulation.jl:205-214, runs after every step and is the host's): every rank's header

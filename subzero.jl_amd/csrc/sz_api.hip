@@ -2185,8 +2185,8 @@ int comm_agree_bits(sz_ctx* c, int local, int* all) {
   return SZ_OK;
 }
 // sync + sticky device errors of THIS rank + agreement: SZ_OK on every rank or the same error code on every rank
-int tile_sync_agree(sz_ctx* c) {
-  int rc = sync_and_check(c);
+int tile_sync_agree(sz_ctx* c, int* cnt_out = nullptr) {
+  int rc = sync_and_check(c, cnt_out);
   if (rc == SZ_E_HIP) return rc;              // (the runtime itself failed: nothing to agree on)
   int all = 0;
   const int rc2 = comm_agree_bits(c, rc ? (c->last_err_bits ? c->last_err_bits : 1) : 0, &all);
@@ -2933,18 +2933,27 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   const bool inl = coll && !c->tile_inline_off && c->ghost_inline && c->fused_move && c->grid_ok && !c->no_static_grid && !c->two_way &&
                    std::max(c->max_ring, c->max_ring_tiled) <= MV_RING && ((flags & SZ_COUPLING_ON) == 0 || c->have_fields);
   if (!inl) {
+    // The tag stop of these steps (one-way coupling): the pack kernel's header records carry every rank's stop word to EVERY rank, the unpack
+    // kernel of the next step reads them before that step has touched anything and ends the batch there (sz_k_halo_unpack), as in the inline
+    // steps.  The forcings then run behind the unpack instead of beside the exchange: a rank must not compute the forcings of a step its
+    // peers have already called off.  (Two-way coupling across tiles: no stop -- its per-cell sums are reduced over the ranks step by step.)
+    const bool stopping = !(flags & SZ_NO_STOP) && !c->two_way;
+    S.stop_on_tags = stopping ? 1 : 0; S.retry_stop = 0;
+    HIPCHK(c, hipMemsetAsync(S.cnt + C_STOP, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(S.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream));
     for (int s = 0; s < nsteps; s++) {
       const int tstep = tstep0 + s;
       c->tile_dt = dt;
-      if (c->tile_since_box < 0 || c->tile_since_box >= c->tile_rebox_cur) { int rc = tile_rebox(c); if (rc) return rc; }
+      S.step = stopping ? s + 1 : 0;
+      if (c->tile_since_box < 0 || c->tile_since_box >= c->tile_rebox_cur) { int rc = tile_rebox(c); if (rc) { S.step = 0; return rc; } }
       c->tile_since_box++;
       const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
       tile_pack(c);
       // (the host's channel blocks: the forcings go to the device first and run while the host trades the regions)
-      if (coupling && n > 1 && c->host_transport) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return rc; }
-      { int rc = tile_exchange(c, false); if (rc) return rc; }
+      if (coupling && !stopping && n > 1 && c->host_transport) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return rc; }
+      { int rc = tile_exchange(c, stopping); if (rc) { S.step = 0; return rc; } }
       // the forcings of the owned floes need nothing from the halo: they run beside the exchange
-      if (coupling && !(n > 1 && c->host_transport)) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return rc; }
+      if (coupling && !stopping && !(n > 1 && c->host_transport)) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return rc; }
       if (n > 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_recv, 0));
       int rc = sz_tile_step(c, c->d_recv, n, c->halo_cap, tstep, dt, coupling_dt, flags);
       if (rc) return rc;
@@ -2956,9 +2965,13 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
       }
     }
     // (the ranks agree on the error word: a rank with a device error and a clean one return the same code)
-    const int rce = tile_sync_agree(c);
+    S.step = 0;
+    int hl[C_COUNT] = { 0 };
+    const int rce = tile_sync_agree(c, hl);
     c->fuse_lists.resize(c->hostM);
-    if (steps_done) *steps_done = nsteps;
+    const int done = stopping && hl[C_STOP] > 0 ? std::min(hl[C_STOP], (int)nsteps) : nsteps;
+    if (done < nsteps) { c->grid_live = false; c->gl_valid = false; }          // stopped early: cells and ghost-candidate lists belong to steps that did not come
+    if (steps_done) *steps_done = done;
     return rce;
   }
   // ---------------- inline steps

@@ -3064,6 +3064,12 @@ __global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* 
   const GridGeo geo = grid_geo(S);
   __shared__ int before[65];
   __shared__ int tot, carry_s;
+  if (stopped(S)) return;
+  if (S.step > 0 && S.stop_on_tags) {          // sz_tile_run's list-based steps: a peer tagged a floe in the step before (its header's stop word; this rank's own region is zero)
+    int stop = 0;
+    for (int r = 0; r < nranks; r++) { const int f = (int)recv[(size_t)r * (cap + 1) * HALO_REC + 1]; if (f > 0) stop = f; }
+    if (stop > 0) { if (threadIdx.x == 0) S.cnt[C_STOP] = stop; return; }
+  }
   if (threadIdx.x == 0) {
     int acc = 0; bool bad = false;
     for (int r = 0; r < nranks; r++) { int cnt = (int)recv[(size_t)r * (cap + 1) * HALO_REC]; if (cnt > cap) { bad = true; cnt = cap; } before[r] = acc; acc += cnt; }
