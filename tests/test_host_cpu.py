@@ -195,3 +195,18 @@ def test_hot_kernels_keep_their_register_budgets():
         assert name in res, (name, sorted(k for k in res if k.startswith(name.split("<")[0])))
         assert res[name]["vgpr"] <= vg and res[name]["scratch"] <= scratch, (name, res[name])
     assert res["sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 1>"]["lds"] <= 16384
+
+
+def test_tile_fuzzer_seeds_keep_their_meaning():
+    """tools/fuzz_tiles.py: the cases recorded under profiles/r03_runs/r3_t_fuzz_tiles.txt and kept as GPU tests are named by seed -- the derivation of a
+    case from its seed must not drift"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_tiles", os.path.join(ROOT, "tools", "fuzz_tiles.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    assert m.case_params(5112) == (2, 573, 25, 10, "fast", "star", True, False)
+    assert m.case_params(5090) == (4, 2336, 27, 9, "fast", "star", True, False)
+    assert m.case_params(5056) == (2, 703, 54, 13, "fast", "star", True, False)
+    assert m.case_params(30025, walls=True)[:5] == (4, 2006, 40, 9, "walls-topo-fast")
+    assert m.case_params(30071, walls=True)[:5] == (4, 1943, 25, 12, "walls")
+    w, n, steps, every, kind, shape, fast, stop = m.case_params(9003, mixed=True)
+    assert kind == "voronoi-fast" and n == 3600 and w == 4 and shape == "voronoi" and fast and not stop
