@@ -5,7 +5,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "sz_api.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("sz_kernels.hpp", "sz_geom.hpp", "sz_state.hpp", "sz_twoway.hpp", "sz_output.hpp")] + \
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in sorted(f for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".hpp"))] + \
        [os.path.join(os.path.dirname(HERE), "include", "subzero_hip.h")]
 LIB = os.path.join(HERE, "libsubzero_hip.so")
 # -ffp-contract=off: fp64 expressions evaluate as written (no FMA), which is what makes the

@@ -7,6 +7,7 @@
 #include <signal.h>
 #include <unistd.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -144,6 +145,13 @@ struct sz_ctx {
   double tile_box_ctr[2] = { 0, 0 }; bool tile_box_valid = false;   // centre of this rank's owned box at the last gather (sz_k_owned_box: periodic images)
   int tile_forcing_tstep = -1;      // timestep whose forcings sz_tile_forcing has already enqueued
   bool tile_dirty = false;      // ghosts / halo floes of the last sz_tile_step still appended
+  // fixed-point totals (State::facc): resident batches only.  acc_mode: what the integrator is told (bit 0: totals / stress sums / tags from facc,
+  // bit 1: the batch's last step); reduce_mode: 0 sz_k_inter_fill does everything inside the step (process mode), 1 it only assembles rows inside
+  // the step, 2 it is left out of the steps and runs once behind the batch (the reduce-free steps)
+  long long* facc_buf = nullptr; int acc_mode = 0, reduce_mode = 0;
+  bool no_reduce_free = false;      // SZ_REDUCE_FREE=0: keep the (rows-only) reduce launch inside every step (A/B)
+  bool maybe_tagged = false;        // a parent may be non-active on the device (an upload said so, a batch ended on a tag, a process-mode call ran):
+                                    // the next batch then runs its first step on its own (see sz_step)
   int last_err_bits = 0;   // device error bits the last sync_and_check found (tiled runs agree on them between the ranks)
   int dbg = 0;   // SZ_DEBUG bits: timing experiments only (1 skip contact rows, 2 skip direction check, 4 skip clip)
 };
@@ -251,10 +259,10 @@ int sync_and_check(sz_ctx* c, int* cnt_out = nullptr) {
   if (cnt_out) memcpy(cnt_out, h, sizeof(h));
   c->last_err_bits = h[C_ERR];
   if (h[C_ERR]) {
-    char buf[360];
+    char buf[400];
     snprintf(buf, sizeof(buf),
              "device capacity/consistency error bits 0x%x (ring=1 crossings=2 regions=4 rows=8 trace=16 neighbours=32 "
-             "pairs=64 elems=128 inter=256 floes=512 verts=1024 cells=2048 ghosts/parent=4096 scan=8192 halo-drift=16384)", h[C_ERR]);
+             "pairs=64 elems=128 inter=256 floes=512 verts=1024 cells=2048 ghosts/parent=4096 scan=8192 halo-drift=16384 fixed-point-range=32768)", h[C_ERR]);
     c->err = buf;
     int z = 0;
     (void)hipMemcpy(c->S.cnt + C_ERR, &z, sizeof(int), hipMemcpyHostToDevice);
@@ -576,12 +584,15 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = 
 }
 
 // m_hint: see sz_k_inter_fill (resident steps: the parents + the ghosts the last look at the device showed, and some)
-void stage_reduce(sz_ctx* c, int mirror, int n_init, int dt, int m_hint = 0) {
+// the force scale of the fixed-point totals (sz_geom.hpp fx_force_exp): |row force| <= (1 + mu) E h sqrt(area)
+int force_scale_exp(const sz_ctx* c) { const double b = (1.0 + std::max(c->P.mu, 0.0)) * c->P.E; return (b > 0.0 && b < 1e300 ? std::ilogb(b) : 0) + 1; }
+// behind: the launch that assembles the rows of a reduce-free batch's last step (parents' centroids of that step from `mot`)
+void stage_reduce(sz_ctx* c, int mirror, int n_init, int dt, int m_hint = 0, bool behind = false) {
   State& S = c->S;
   Timed t(c, SZ_K_REDUCE);
-  int gM = grid_for(S.capM, 256);
-  hipLaunchKernelGGL(sz_k_inter_fill, dim3(grid_for(S.capM, 128 / IF_G, 16384)), dim3(128), 0, c->stream, S, mirror, n_init, m_hint);
-  if (mirror && c->any_moving) hipLaunchKernelGGL(sz_k_update_boundaries, dim3(1), dim3(64), 0, c->stream, S, dt);
+  if (behind || c->reduce_mode != 2)
+    hipLaunchKernelGGL(sz_k_inter_fill, dim3(grid_for(S.capM, 128 / IF_G, 16384)), dim3(128), 0, c->stream, S, mirror, n_init, m_hint, behind || c->reduce_mode == 1 ? 1 : 0, behind ? 1 : 0);
+  if (!behind && mirror && c->any_moving) hipLaunchKernelGGL(sz_k_update_boundaries, dim3(1), dim3(64), 0, c->stream, S, dt);
   t.end();
 }
 
@@ -714,10 +725,10 @@ void stage_integrate(sz_ctx* c, int dt, bool reset_guards, bool apply_frc, bool 
   // resident steps with small rings: one launch (thread per floe) integrates, moves the ring and bins the floe
   if (bin && c->max_ring <= MV_RING && c->fused_move) {
     // (tiled steps: the same thread also writes the floe's halo records for the next step -- sz_k_integrate<true, true>)
-    if (pack) hipLaunchKernelGGL((sz_k_integrate<true, true>), dim3(grid_for(c->S.capM, 128)), dim3(128), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 1, nh, gl_fill, ginl, *pack);
-    else hipLaunchKernelGGL(sz_k_integrate<true>, dim3(grid_for(c->S.capM, 128)), dim3(128), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 1, nh, gl_fill, ginl, PackInl{});
+    if (pack) hipLaunchKernelGGL((sz_k_integrate<true, true>), dim3(grid_for(c->S.capM, 128)), dim3(128), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 1, nh, gl_fill, ginl, *pack, c->acc_mode);
+    else hipLaunchKernelGGL(sz_k_integrate<true>, dim3(grid_for(c->S.capM, 128)), dim3(128), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 1, nh, gl_fill, ginl, PackInl{}, c->acc_mode);
   } else {
-    hipLaunchKernelGGL(sz_k_integrate<false>, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 0, nh, gl_fill, -1, PackInl{});
+    hipLaunchKernelGGL(sz_k_integrate<false>, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, c->P, dt, apply_frc ? 1 : 0, 0, nh, gl_fill, -1, PackInl{}, c->acc_mode);
     hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(c->S.capM, 16, 8192)), dim3(256), 0, c->stream, c->S, 0, bin ? 1 : 0, gl_fill);
   }
   if (!bin) c->grid_live = false;          // floes moved without re-binning: the resident steps' cell lists are stale
@@ -837,6 +848,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_TW_GENERAL_CLIP")) c->tw_general_clip = atoi(e) != 0;
   if (const char* e = getenv("SZ_LEAN_NARROW")) c->no_lean_narrow = atoi(e) == 0;
   if (const char* e = getenv("SZ_CREC")) c->no_crec = atoi(e) == 0;
+  if (const char* e = getenv("SZ_REDUCE_FREE")) c->no_reduce_free = atoi(e) == 0;
   if (const char* e = getenv("SZ_TILE_FORCING_TAIL")) c->tile_forcing_in_tail = atoi(e) != 0;
   if (const char* e = getenv("SZ_GHOST_INLINE")) c->ghost_inline = atoi(e) != 0;
   if (const char* e = getenv("SZ_TILE_INLINE")) c->tile_inline_off = atoi(e) == 0;
@@ -1048,6 +1060,8 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   if (f->stress_instant) H2D(S.si, f->stress_instant, 4 * M, double);
   if (f->strain) H2D(S.strain, f->strain, 4 * M, double);
   DA(id, S.capM); DA(ghost_id, S.capM); DA(okey, S.capM); DA(status, S.capM); DA(parent, S.capM); DA(gh, MAX_GHOSTS * S.capM); DA(ngh, S.capM);
+  DA(gh_save, MAX_GHOSTS * S.capM); DA(ngh_save, S.capM);
+  std::vector<int> tag0;          // (tagA starts as the status column: the integrator of a resident step only rewrites it where a tag was raised)
   DA(frc_remove, S.capM); DA(osign, S.capM); DA(bbx0, S.capM); DA(bbx1, S.capM); DA(bby0, S.capM); DA(bby1, S.capM);
   {
     std::vector<long long> id(M), gid(M, 0);
@@ -1063,6 +1077,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
     }
     { std::vector<long long> ok(S.capM); for (int i = 0; i < S.capM; i++) ok[i] = i; H2D(S.okey, ok.data(), S.capM, long long); HIPCHK(c, hipStreamSynchronize(c->stream)); }
     H2D(S.id, id.data(), M, long long); H2D(S.ghost_id, gid.data(), M, long long); H2D(S.status, st.data(), M, int);
+    tag0 = st;
     H2D(S.parent, parent.data(), M, int); H2D(S.gh, gh.data(), (size_t)MAX_GHOSTS * M, int); H2D(S.ngh, ngh.data(), M, int);
     HIPCHK(c, hipStreamSynchronize(c->stream));   // host vectors go out of scope
   }
@@ -1081,6 +1096,9 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(lb_agg, S.capM / 128 + 8); DA(lb_inc, S.capM / 128 + 8); DA(lb_flag, S.capM / 128 + 8); c->scan_epoch = 0;      // (tiles of 128 .. SCAN_B elements)
   DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2); DA(gcand, (size_t)2 * S.capM); DA(galloc, 32); DA(gkeys, (size_t)2 * S.capM); DA(fam, S.capM);
   DA(crec, (size_t)8 * S.capM); c->crec_buf = S.crec; S.crec = nullptr;
+  DA(facc, (size_t)FX_WORDS * S.capM); c->facc_buf = S.facc; S.facc = nullptr;
+  c->maybe_tagged = false;
+  if (f->status) for (int i = 0; i < N; i++) if (f->status[i] != SZ_ACTIVE) { c->maybe_tagged = true; break; }
   for (int k = 0; k < 4; k++) if ((rc = dalloc(c, &c->frc_alt[k], (size_t)S.capM, c->allocs))) return rc;
   DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1); DA(cell_ovf, S.capCells + 1); DA(cell_slots, (size_t)S.capCells * CELL_K + 8);
   DA(cell_items, S.capM);
@@ -1106,6 +1124,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   if ((rc = carve_interactions(c))) return rc;
   DA(blk, std::max(S.capCells, std::max(S.capM, 1024)) / SCAN_B + 1024);
   DA(tagA, S.capM + 1);
+  if (!tag0.empty()) { H2D(S.tagA, tag0.data(), M, int); HIPCHK(c, hipStreamSynchronize(c->stream)); }
   DA(stamps, 512 + 8 * 8000);
   trim_pool(c->allocs);
   int h[C_COUNT + 64 + 72] = { 0 };
@@ -1431,6 +1450,7 @@ int sz_remove_ghosts(sz_ctx* c) {
 
 int sz_timestep_collisions(sz_ctx* c, int64_t n_init, int32_t dt) {
   if (!c || !c->have_floes) return SZ_E_STATE;
+  c->maybe_tagged = true;
   (void)hipSetDevice(c->device);
   c->gi_valid = false;         // (what follows numbers its ghosts by storage position)
   leave_resident(c);            // a process-mode call: the resident steps' ghost-candidate list is stale, the world rings must be current
@@ -1455,6 +1475,7 @@ int sz_collide_pairs(sz_ctx* c, int64_t np, const int32_t* pi, const int32_t* pj
   leave_resident(c);
   State& S = c->S;
   if (np > S.capPairs) { c->err = "too many explicit pairs"; return SZ_E_CAPACITY; }
+  c->maybe_tagged = true;
   std::vector<std::pair<int, int>> ps(np);
   for (int64_t k = 0; k < np; k++) {
     if (pi[k] < 0 || pj[k] < 0 || pi[k] >= c->hostM || pj[k] >= c->hostM || pi[k] == pj[k]) { c->err = "pair index out of range"; return SZ_E_ARG; }
@@ -1479,6 +1500,7 @@ int sz_collide_pairs(sz_ctx* c, int64_t np, const int32_t* pi, const int32_t* pj
 
 int sz_collide_domain(sz_ctx* c, int32_t dt, double max_overlap) {
   if (!c || !c->have_floes) return SZ_E_STATE;
+  c->maybe_tagged = true;
   (void)hipSetDevice(c->device);
   c->gi_valid = false;         // (what follows numbers its ghosts by storage position)
   leave_resident(c);            // a process-mode call: the resident steps' ghost-candidate list is stale, the world rings must be current
@@ -1495,6 +1517,7 @@ int sz_collide_domain(sz_ctx* c, int32_t dt, double max_overlap) {
 int sz_timestep_coupling(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;
   if (!c->have_fields) { c->err = "sz_set_fields must be called before sz_timestep_coupling"; return SZ_E_STATE; }
+  c->maybe_tagged = true;
   (void)hipSetDevice(c->device);
   leave_resident(c);            // a process-mode call: the resident steps' ghost-candidate list is stale, the world rings must be current
   if (c->two_way) { if (c->S.tiled) { c->err = "tiled contexts couple through sz_tile_step + sz_two_way_partial / sz_two_way_finish"; return SZ_E_STATE; } int rc = ensure_two_way(c); if (rc) return rc; }
@@ -1658,11 +1681,27 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   // the largest narrow variant only takes items the small one hands on (none in most fields): it is left out of the steps until one
   // shows up -- the batch then pauses inside that step (stopped_late()) and is finished below
   bool lean = coll && !c->retry_seen && !c->no_lean_narrow && !c->S.tiled && !larger_rings(c);
+  // Fixed-point totals (State::facc; sz_geom.hpp): the narrow phase adds every row to both floes' totals, the integrator reads them -- no reduce
+  // launch inside the steps.  floe.interactions of the step that ended the batch is assembled once, behind the batch (stage_reduce(.., behind)):
+  // that needs the ghosts of that step still in their rows, i.e. the one-launch integrator with inline ghosts (or no periodic wall), which
+  // knows when it runs a batch's last step (sz_k_integrate: last_step).  The other paths keep the launch inside the step, rows only.
+  const bool facc_on = coll && c->facc_buf != nullptr;
+  const bool rfree = facc_on && !c->no_reduce_free && sg && (gi || !periodic) && c->fused_move && c->max_ring <= MV_RING && !c->any_moving;
+  c->S.facc = facc_on ? c->facc_buf : nullptr; c->S.kexp = force_scale_exp(c);
+  c->reduce_mode = !facc_on ? 0 : rfree ? 2 : 1;
+  if (facc_on) {
+    HIPCHK(c, hipMemsetAsync(c->facc_buf, 0, (size_t)FX_WORDS * c->S.capM * sizeof(long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->S.cnt + C_FRCSTOP, 0, sizeof(int), c->stream));
+  }
+  // a parent that is already tagged ends the batch after its first step, and the integrator only finds out while it runs (the tags of a
+  // step itself are raised by its narrow phase / forcings, a launch earlier): that first step is then enqueued on its own, as a last step
+  int s_end = rfree && c->maybe_tagged && c->S.stop_on_tags && nsteps > 1 ? 1 : nsteps;
+  auto leave = [&]() { c->S.retry_stop = 0; c->S.body_rings = 0; c->S.ginline = 0; c->S.famrec = 0; c->S.step = 0; c->S.crec = nullptr; c->S.facc = nullptr; c->acc_mode = 0; c->reduce_mode = 0; };
   int h[C_COUNT];
   const int callid0 = c->callid; c->callid += nsteps;          // (step s of this batch is collision call callid0 + s + 1, also when it is run again)
   for (int s0 = 0, mid = 0;;) {
     c->S.retry_stop = lean ? 1 : 0;
-    for (int s = s0; s < nsteps; s++) {
+    for (int s = s0; s < s_end; s++) {
       int tstep = tstep0 + s;
       c->S.step = s + 1; c->S.callid = callid0 + s + 1;
       const bool resume = mid && s == s0;
@@ -1690,20 +1729,43 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
       if (coll) collisions_step(c, c->hostN, dt, periodic && !sg, sg, resume ? 0 : fmode, lean, resume);
       if (overlap && !resume) stage_forcing_join(c);
       // (inline ghosts: the last step of the batch makes none -- there is no step to make them for, and the cell lists stay the parents')
-      stage_integrate(c, dt, !coll, coupling, sg, gl && !gi ? 1 - c->gl_cur : -1, gi && s + 1 < nsteps ? 1 - (s & 1) : -1);
+      c->acc_mode = !facc_on ? 0 : 1 | (rfree ? 4 | (s + 1 == s_end ? 2 : 0) : 0);
+      stage_integrate(c, dt, !coll, coupling, sg, gl && !gi ? 1 - c->gl_cur : -1, gi && s + 1 < s_end ? 1 - (s & 1) : -1);
       if (gl && !gi) c->gl_cur ^= 1;
     }
     c->S.step = 0;
+    // floe.interactions of the step that ended the batch (reduce-free steps): one launch for the whole batch
+    if (rfree) stage_reduce(c, 1, c->hostN, dt, c->hostN + 3 * c->gl_est + c->hostN / 64 + 32, true);
     if (coll && periodic) hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0);
     int rc = sync_and_check(c, h);
+    if (rfree && rc == SZ_E_CAPACITY && c->last_err_bits == ERR_CAP_INTER && h[C_RETRYSTOP] == 0) {
+      // a floe of that last step has more rows than the stride holds: only the rows' memory grows (collisions.jl:290-296), and the launch runs
+      // again on the parents with the ghost links sz_k_remove_ghosts has put aside
+      rc = SZ_OK;
+      for (int tries = 0; tries < 6; tries++) {
+        c->S.rowcap *= 4;
+        if (c->S.rowcap > 8192) { c->err = "a floe has more than 8192 interaction rows"; leave(); return SZ_E_CAPACITY; }
+        if ((rc = carve_interactions(c))) { leave(); return rc; }
+        c->inter_lost = false;
+        State S2 = c->S; S2.ngh = c->S.ngh_save; S2.gh = c->S.gh_save;
+        hipLaunchKernelGGL(sz_k_inter_fill, dim3(grid_for(S2.capM, 128 / IF_G, 16384)), dim3(128), 0, c->stream, S2, 1, c->hostN, 0, 1, 1);
+        int h2[C_COUNT];
+        rc = sync_and_check(c, h2);
+        if (!(rc == SZ_E_CAPACITY && c->last_err_bits == ERR_CAP_INTER)) break;
+      }
+    }
     if (rc == SZ_E_CAPACITY && growable(c->last_err_bits) && h[C_RETRYSTOP] > 0 && coll) {
       // A list outgrown inside step h[C_RETRYSTOP] (neighbours per floe, pair items, rows per floe): the batch paused there before anything
       // of the floes' state changed (capacity_stop()).  Larger lists, then that step and the rest of the batch again, from the parents as
       // they lie -- exactly as a batch that starts at that step would (cells, the step's ghosts): the reference's lists grow (collisions.jl:290-296).
-      if ((rc = grow_lists(c, c->last_err_bits))) { c->S.retry_stop = 0; c->S.body_rings = 0; c->S.ginline = 0; c->S.famrec = 0; c->S.step = 0; c->S.crec = nullptr; return rc; }
+      if ((rc = grow_lists(c, c->last_err_bits))) { leave(); return rc; }
       s0 = h[C_RETRYSTOP] - 1; mid = 0;
       (void)hipMemsetAsync(c->S.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream);
       (void)hipMemsetAsync(c->S.cnt + C_STOP, 0, sizeof(int), c->stream);
+      if (facc_on) {          // (the narrow phase of the step that is run again adds its rows again)
+        (void)hipMemsetAsync(c->facc_buf, 0, (size_t)FX_WORDS * c->S.capM * sizeof(long long), c->stream);
+        (void)hipMemsetAsync(c->S.cnt + C_FRCSTOP, 0, sizeof(int), c->stream);
+      }
       c->grid_live = false; use_static_grid(c);
       if (cr) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, c->S, c->hostN);
       if (gi) {
@@ -1713,7 +1775,18 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
       } else if (gl) { c->gl_valid = false; use_ghost_list(c); }
       continue;
     }
-    if (rc) { c->S.retry_stop = 0; c->S.body_rings = 0; c->S.ginline = 0; c->S.famrec = 0; c->S.crec = nullptr; return rc; }
+    if (rc) { leave(); return rc; }
+    if ((!lean || h[C_RETRYSTOP] == 0) && s_end < nsteps && h[C_STOP] == 0) {
+      // the first step ran on its own (a parent might have been tagged already) and nothing ended the batch: the rest of it, from the floes
+      // as they lie -- the cells hold the parents (the step made no ghosts), the ghosts of the next step are seeded as at a batch's start
+      s0 = s_end; s_end = nsteps; mid = 0;
+      if (gi) {
+        (void)hipMemsetAsync(c->S.galloc, 0, 32 * sizeof(unsigned long long), c->stream);
+        c->S.gslot = s0 & 1;
+        hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, s0 & 1, c->hostN);
+      }
+      continue;
+    }
     if (!lean || h[C_RETRYSTOP] == 0) break;
     // paused after the narrow launch of step h[C_RETRYSTOP]: that variant is in from now on
     c->retry_seen = true; lean = false;
@@ -1722,12 +1795,13 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
     (void)hipMemsetAsync(c->S.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream);
   }
   c->S.retry_stop = 0;
-  c->S.ginline = 0; c->S.famrec = 0; c->S.crec = nullptr;
+  c->S.ginline = 0; c->S.famrec = 0; c->S.crec = nullptr; c->S.facc = nullptr; c->acc_mode = 0; c->reduce_mode = 0;
+  if (coll && (h[C_STOP] > 0 || (flags & SZ_NO_STOP))) c->maybe_tagged = true;
   if (body && nsteps > 0) c->rings_stale = true;
   c->S.body_rings = 0;
   if (coll) { c->inter_any = true; c->inter_lost = false; }
   int rc = SZ_OK;
-  const int done = h[C_STOP] > 0 ? h[C_STOP] : nsteps;
+  const int done = h[C_STOP] > 0 ? std::min(h[C_STOP], (int)nsteps) : nsteps;
   if (steps_done) *steps_done = done;
   if (gl && !gi) {        // the list the last step that RAN has filled, and how long it is
     c->gl_cur = (gl0 + done) & 1;
@@ -1800,6 +1874,7 @@ int sz_tile_enable(sz_ctx* c, const int64_t* gidx, double halo_capacity_factor, 
   ok.assign(c->hostN, 0);
   for (int i = 0; i < c->hostN; i++) ok[i] = gidx[i];
   H2D(S.okey, ok.data(), c->hostN, long long);
+  if (c->facc_buf) HIPCHK(c, hipMemsetAsync(c->facc_buf, 0, (size_t)FX_WORDS * S.capM * sizeof(long long), c->stream));      // (rows change hands in a migration: no stale totals)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   S.tiled = 1;
   // largest ring among ALL ranks' floes (halo floes arrive unseen): decides which narrow variants can be needed
@@ -1935,9 +2010,14 @@ int sz_tile_step(sz_ctx* c, const void* d_recv, int32_t nranks, int32_t cap, int
   // floes of the LAST step are dropped when the host next looks at the state (tile_cleanup).
   // n_init = every local parent (owned + halo): totals of halo floes are computed and then ignored
   S.callid = ++c->callid;
+  // (fixed-point totals as in the resident steps of sz_step, so that a tile and the single context give the same bits; the reduce launch stays
+  //  inside the step here, assembling rows only)
+  const bool facc_on = coll && c->facc_buf != nullptr;
+  S.facc = facc_on ? c->facc_buf : nullptr; S.kexp = force_scale_exp(c); c->reduce_mode = facc_on ? 1 : 0; c->acc_mode = facc_on ? 1 : 0;
   if (coll) stage_ghosts(c, true, sg, gl);
   if (coll) collisions(c, -1, dt, periodic && !sg, sg);
   stage_integrate(c, dt, false, coupling, sg, gl ? 1 - c->gl_cur : -1);
+  S.facc = nullptr; c->reduce_mode = 0; c->acc_mode = 0;
   if (gl) { c->gl_cur ^= 1; c->gl_est = std::max(c->gl_est, 64); }
   c->tile_dirty = true;
   return SZ_OK;
@@ -2995,7 +3075,18 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   if (S.crec) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, S, c->hostN);
   // (the periodic ghosts of the owned floes for the first step, and the swap of parents that lie outside the domain: in the loop, BEHIND the
   //  first pack -- see there)
-  auto fail = [&](int rc) { S.ginline = 0; S.famrec = 0; S.step = 0; S.crec = nullptr; S.retry_stop = 0; return rc; };
+  // fixed-point totals and reduce-free steps as in sz_step.  With peers and the tag stop a rank learns that a step was the batch's last only
+  // in the unpack of the NEXT one -- after its integrator has made that step's ghosts over the rows of this one -- so the rows are then
+  // assembled inside every step (rows only); alone, or in batches that run through (SZ_NO_STOP), once behind the batch.
+  const bool facc_on = c->facc_buf != nullptr;
+  const int rmode = !facc_on ? 0 : (c->no_reduce_free || (n > 1 && S.stop_on_tags)) ? 1 : 2;
+  S.facc = facc_on ? c->facc_buf : nullptr; S.kexp = force_scale_exp(c); c->reduce_mode = rmode;
+  if (facc_on) {
+    HIPCHK(c, hipMemsetAsync(c->facc_buf, 0, (size_t)FX_WORDS * S.capM * sizeof(long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(S.cnt + C_FRCSTOP, 0, sizeof(int), c->stream));
+  }
+  auto accm = [&](bool last) { return !facc_on ? 0 : 1 | (rmode == 2 ? 4 | (last ? 2 : 0) : 0); };
+  auto fail = [&](int rc) { S.ginline = 0; S.famrec = 0; S.step = 0; S.crec = nullptr; S.retry_stop = 0; S.facc = nullptr; c->acc_mode = 0; c->reduce_mode = 0; return rc; };
   // SZ_SYNC_DEBUG=1 (diagnosis of a faulting kernel): wait after every stage of every step and say so on stderr -- the last line names the stage
   const bool dbgsync = getenv("SZ_SYNC_DEBUG") != nullptr;
   auto stage_done = [&](int s, const char* what) {
@@ -3073,10 +3164,12 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     const bool pack_next = s + 1 < nsteps;
     if (pack_next && c->tile_since_box >= c->tile_rebox_cur) { int rc = tile_rebox(c); if (rc) return fail(rc); }      // (synchronises: once per gather interval)
     const PackInl pk = tile_pack_args(c);
+    c->acc_mode = accm(s + 1 == nsteps);
     stage_integrate(c, dt, false, coupling, true, -1, periodic && s + 1 < nsteps ? 1 - (s & 1) : -1, pack_next ? &pk : nullptr);
     stage_done(s, "integrate");
   }
   S.step = 0;
+  if (rmode == 2 && nsteps > 0) stage_reduce(c, 1, -1, dt, 0, true);          // floe.interactions of the step that ended the batch
   c->tile_dirty = nsteps > 0;
   rc = sync_and_check(c, h);                     // (drops the halo floes and ghosts of the last step: tile_cleanup -- unless a step is paused)
   if (rc == SZ_E_HIP) return fail(rc);
@@ -3105,8 +3198,10 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     S.step = sp; S.gslot = (sp - 1) & 1; S.callid = callid_of[sp - 1];
     stage_narrow(c, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, true, 0, 2);
     stage_reduce(c, 1, -1, dt, 0);
+    c->acc_mode = accm(sp >= nsteps);
     stage_integrate(c, dt, false, coupling_sp, true, -1, -1);
     S.step = 0;
+    if (rmode == 2 && sp >= nsteps) stage_reduce(c, 1, -1, dt, 0, true);
   }
   c->tile_dirty = true;
   if (sp >= nsteps) {               // (the last step of the batch: no peer has heard of it, nothing is run again)
@@ -3121,7 +3216,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   if (S.crec) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, S, c->hostN);
   s_begin = sp;          // (the ghosts of that step: behind its pack, at the top of the loop)
   }
-  S.step = 0; S.ginline = 0; S.famrec = 0; S.crec = nullptr; S.retry_stop = 0;
+  S.step = 0; S.ginline = 0; S.famrec = 0; S.crec = nullptr; S.retry_stop = 0; S.facc = nullptr; c->acc_mode = 0; c->reduce_mode = 0;
   {
     int all = 0;
     const int rc2 = comm_agree_bits(c, rc ? (c->last_err_bits ? c->last_err_bits : 1) : 0, &all);

@@ -90,6 +90,7 @@ struct GroupMem {
   uint8_t rna, rnb; int8_t roa, rob;         // ring sizes and orientation signs of the item
   int8_t nchk, nkeep;
   uint8_t nsig;                              // crossings of the contact clip (entries of sga / sgb / sgf)
+  int8_t eri, erj;                           // fx_lever_exp(rmax) of the item's two floes (fixed-point totals: the scale of the torque / stress sums)
   uint8_t lists_ok, fullnow;                 // ea / eb / nea / neb are still the CONTACT clip's (no later clip in this memory has rebuilt them); this group
                                              // runs a clip that rebuilds them in the current pass -- see clip(.., reuse) and the narrow kernel's pass loop
 };
@@ -97,7 +98,61 @@ static_assert(sizeof(GroupMem<18, 8, 16, 4>) <= 2048, "eight groups of the first
 
 enum { ERR_CAP_RING = 1, ERR_CAP_XING = 2, ERR_CAP_REGION = 4, ERR_CAP_ROWS = 8, ERR_TRACE = 16,
        ERR_CAP_NEIGH = 32, ERR_CAP_PAIRS = 64, ERR_CAP_ELEM = 128, ERR_CAP_INTER = 256,
-       ERR_CAP_FLOES = 512, ERR_CAP_VERTS = 1024, ERR_CAP_CELLS = 2048, ERR_GHOSTS_PER_PARENT = 4096 };
+       ERR_CAP_FLOES = 512, ERR_CAP_VERTS = 1024, ERR_CAP_CELLS = 2048, ERR_GHOSTS_PER_PARENT = 4096,
+       ERR_FIXED_RANGE = 32768 };       // (8192: ERR_SCAN, 16384: ERR_HALO_DRIFT -- sz_kernels.hpp)
+
+// ---------------------------------------------------------------------------------------------
+// Fixed-point totals (round 4).  collision_force, collision_trq, overarea and the row sums of calc_stress! (collisions.jl:747-749,
+// 852-861; update_floe.jl:392-414) are sums over a floe's interaction rows.  The resident steps form them WITHOUT a reduce launch: the
+// lane group that finishes an item adds its rows to both floes' totals with integer atomics.  Integer addition is associative, so the
+// result does not depend on who adds when -- a tile, the single context and every repetition of a run give the same bits.
+//   * a row's force on floe k is bounded by (1 + mu) E h_k sqrt(area_k) (force_factor <= E h_k / sqrt(area_k) for either side, overlap
+//     <= min(area); friction <= mu |normal force|): with e_F = kexp + ilogb(h_k) + 1 + ceil((ilogb(area_k) + 1) / 2) every |f| < 2^e_F,
+//     and f 2^(52 - e_F) has 10 bits of headroom for the sum of up to 1024 rows in an int64.  The exponents are read off the doubles'
+//     exponent fields (area, height, rmax of the floe: the same bits in every instance of it, ghost or halo copy), so every
+//     contributor uses the same grid;
+//   * lever arms |x - cx_k| <= rmax_k (the contact point is the centroid of a region inside the floe): torque / stress products get
+//     e_T = e_F + ilogb(rmax_k) + 1;  overlap areas e_O = ilogb(area_k) + 1;
+//   * the words that drive the floe's motion -- force x / y and the two torque products -- are kept to 40 more bits in a second word
+//     (hi = rint(t), lo = rint((t - hi) 2^40), t - hi exact): the sum is then the EXACT sum of the rows' doubles down to 2^-92 of the
+//     bound, rounded once when it is read -- closer to the true sum than the serial double sum of the reference, and equal and
+//     opposite forces stay exactly so.  The stress products and the overlap area are outputs only: one word (2^-52 of the bound).
+// A value beyond its bound by more than the headroom raises ERR_FIXED_RANGE (never seen: the bounds are theorems about the formulas).
+constexpr int FX_WORDS = 16;        // int64 words per floe (one 128-byte line): 0 fx, 1 fy, 2 (x-cx)fx, 3 (y-cy)fx, 4 (x-cx)fy, 5 (y-cy)fy, 6 overlap, 7 tag bits,
+                                    // 8..11 the low words of 0, 1, 3, 4
+SZ_DEV int fx_lo_word(int w) { return w < 2 ? 8 + w : w == 3 ? 10 : w == 4 ? 11 : -1; }
+SZ_DEV int fx_ilogb(double x, int lo, int hi) {
+  int e = lo;
+  if (x > 0.0 && x < __builtin_inf()) { e = ilogb(x); e = e < lo ? lo : (e > hi ? hi : e); }
+  return e;
+}
+SZ_DEV int fx_force_exp(int kexp, double area, double h) { return kexp + fx_ilogb(h, -40, 40) + 1 + ((fx_ilogb(area, -80, 120) + 2) >> 1); }
+SZ_DEV int fx_lever_exp(double rmax) { return fx_ilogb(rmax, -40, 60) + 1; }
+SZ_DEV int fx_area_exp(double area) { return fx_ilogb(area, -80, 120) + 1; }
+SZ_DEV void fx_split(double v, int e, long long& hi, long long& lo, int& bad) {
+  const double t = ldexp(v, 52 - e);
+  if (!(fabs(t) < 0x1p62)) { bad = 1; hi = 0; lo = 0; return; }
+  const double r = rint(t);
+  hi = (long long)r; lo = __double2ll_rn(ldexp(t - r, 40));        // (|t| >= 2^52: t is an integer, the remainder 0)
+}
+SZ_DEV double fx_join(long long hi, long long lo, int e) {
+  const long long H = hi + (lo >> 40), L = lo & ((1ll << 40) - 1);      // (floor and a non-negative remainder: lo may be a negative sum)
+  return ldexp((double)H + ldexp((double)L, -40), e - 52);
+}
+// word w (0..6) of what one interaction row {fx, fy, px, py, overlap} adds to the totals of a floe with centroid (cx, cy) on the grid given by
+// the floe's area, height and lever exponent; sign: +1 for the pair's first floe, -1 for the second (the mirrored row, collisions.jl:820-828)
+SZ_DEV void fx_word(int w, const double* row, double sign, double cx, double cy, int kexp, double area, double h, int eL, long long& hi, long long& lo, int& bad) {
+  const int eF = fx_force_exp(kexp, area, h);
+  long long a = 0, b = 0;
+  if (w == 6) fx_split(row[4], fx_area_exp(area), a, b, bad);
+  else if (w < 2) fx_split(row[w] * sign, eF, a, b, bad);
+  else {
+    const bool lx = w == 2 || w == 4, ffx = w == 2 || w == 3;       // 2: (x - cx) fx   3: (y - cy) fx   4: (x - cx) fy   5: (y - cy) fy
+    fx_split(((lx ? row[2] : row[3]) - (lx ? cx : cy)) * ((ffx ? row[0] : row[1]) * sign), eF + eL, a, b, bad);
+  }
+  hi += a; lo += b;
+}
+
 
 SZ_DEV double orient(double ax, double ay, double bx, double by, double cx, double cy) {
   return (bx - ax) * (cy - ay) - (by - ay) * (cx - ax);
@@ -856,8 +911,9 @@ SZ_DEV void check_post(MEM& own, MEM& scr, int gl, int q, Stamps& st) {
   STAMP(st, 10);
 }
 
+// park (may be null; LDS): the rows are left there as well, for the lanes that add them to the floes' fixed-point totals (fx_word)
 template <int G, class MEM>
-SZ_DEV int finish_phase(MEM& m, int gl, const ItemCtx& cx_, double* out, int max_rows, Stamps& st) {
+SZ_DEV int finish_phase(MEM& m, int gl, const ItemCtx& cx_, double* out, int max_rows, Stamps& st, double* park = nullptr) {
   const int nkeep = m.nkeep;
   const double force_factor = m.ff;
   int nrows = 0;
@@ -897,7 +953,10 @@ SZ_DEV int finish_phase(MEM& m, int gl, const ItemCtx& cx_, double* out, int max
     double fx = fxn + xf, fy = fyn + yf;
     if (fx != 0 || fy != 0) {
       if (nrows < max_rows) {
-        if (gl == 0) { double* o = out + nrows * 5; o[0] = fx; o[1] = fy; o[2] = px; o[3] = py; o[4] = area; }
+        if (gl == 0) {
+          double* o = out + nrows * 5; o[0] = fx; o[1] = fy; o[2] = px; o[3] = py; o[4] = area;
+          if (park) { double* q = park + nrows * 5; q[0] = fx; q[1] = fy; q[2] = px; q[3] = py; q[4] = area; }
+        }
       } else if (gl == 0) m.ierr |= ERR_CAP_ROWS;
       nrows++;
     }

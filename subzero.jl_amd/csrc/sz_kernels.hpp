@@ -494,6 +494,7 @@ __device__ __forceinline__ void ghost_fill_parent(State& S, const GridGeo& geo, 
     if (bin && lane == 14) cell_insert(S, geo, g, gcx, gcy);
     if (lane == 16) { F->key[gid] = key; F->gid[gid] = (long long)gid; F->cx[gid] = gcx; F->cy[gid] = gcy; }
     if (lane < MAX_GHOSTS) S.gh[g * MAX_GHOSTS + lane] = -1;
+    if (S.facc && lane >= 20 && lane < 32) S.facc[(size_t)g * FX_WORDS + (lane - 20)] = 0;      // (fixed-point totals of the new row)
   };
   int s0 = 0, s1 = 0, s2 = 0;
   int ng = 0; bool moved = false;
@@ -817,6 +818,7 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
     if (S.rec32) rec32_store(S, g, gx, gy, c_rmax, x0, x1, y0, y1);
     if (S.crec) crec_store_all(S, g, gx, gy, c_rmax, idv, key, n, osv, body ? vo : vb, i, 0, x0, x1, y0, y1, c_u, c_v, c_xi, c_area, c_h, (long long)(w + 1));
     S.gkeys[(size_t)slot * S.capM + og + w] = key;
+    if (S.facc) { longlong4* a = (longlong4*)(S.facc + (size_t)g * FX_WORDS); a[0] = make_longlong4(0, 0, 0, 0); a[1] = make_longlong4(0, 0, 0, 0); a[2] = make_longlong4(0, 0, 0, 0); }      // (fixed-point totals of the new row)
   };
   GSTAMP(13);
   {
@@ -966,8 +968,8 @@ __global__ void sz_k_remove_ghosts(State S, int drop_halo) {
   if (S.retry_stop && S.cnt[C_RETRYSTOP] != 0) return;       // the batch is paused inside a step: its ghosts are still needed
   int N = drop_halo ? S.cnt[C_NOWN] : S.cnt[C_N];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-    S.ngh[i] = 0;
-    for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = -1;
+    S.ngh_save[i] = S.ngh[i]; S.ngh[i] = 0;
+    for (int q = 0; q < MAX_GHOSTS; q++) { S.gh_save[i * MAX_GHOSTS + q] = S.gh[i * MAX_GHOSTS + q]; S.gh[i * MAX_GHOSTS + q] = -1; }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     S.cnt[C_M] = N; S.cnt[C_N] = N; S.cnt[C_NV] = S.voff[N];        // C_NGHOSTS keeps the last step's count
@@ -1719,7 +1721,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
         const double2* ri = S.crec + (size_t)i * 8; const double2* rj = S.crec + (size_t)j * 8;
         const int qsel = (glv & 3) == 0 ? 0 : 4 + (glv & 3);
         const double2 qa = (glv < 4 ? ri : rj)[qsel];
-        const double2 qb = glv < 2 ? ri[3 + glv] : glv < 4 ? rj[1 + glv] : glv == 4 ? ri[2] : rj[2];
+        const double2 qb = glv < 2 ? ri[3 + glv] : glv < 4 ? rj[1 + glv] : glv == 4 ? ri[2] : glv == 5 ? rj[2] : glv == 6 ? ri[1] : rj[1];      // (6, 7: {rmax, id} -- the scale of the fixed-point torque / stress sums)
         kv[0] = qa.x; kv[NKI - 1] = qa.y; bv0 = qb.x; bv1 = qb.y;
       } else {
 #pragma unroll
@@ -1747,6 +1749,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
           }
         }
         if (glv < 2) osv = glv == 0 ? S.osign[i] : is_pair ? S.osign[j] : S.eosign[e];
+        if (S.facc && glv >= 2 && glv < 4) bv1 = glv == 2 ? S.rmax[i] : is_pair ? S.rmax[j] : 1.0;      // (the scale of the fixed-point torque / stress sums)
       }
       if (!is_pair) {
         ic.mode = ekind == 0 ? ITEM_OPEN : ITEM_SOLID; ic.max_overlap = fd_max_overlap;
@@ -1791,6 +1794,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
         if (w != 3) m.kin[at + 1] = kv[NKI - 1];
         if (gl < 4) { m.box[2 * gl] = bv0; m.box[2 * gl + 1] = bv1; }
         else if (gl < 6) (&m.roa)[gl - 4] = (__double_as_longlong(bv0) >> 56) & 1 ? -1 : 1;
+        else (&m.eri)[gl - 6] = (int8_t)fx_lever_exp(bv0);
       } else {
 #pragma unroll
         for (int r = 0; r < NKI; r++) {
@@ -1802,6 +1806,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
           for (int r = 0; r < NBV; r++) { const int qb = gl + r * G; if (qb < 8) m.box[qb] = bvx[r]; }
         } else if (gl < 8) m.box[gl] = bv0;
         if (gl < 2) (&m.roa)[gl] = (int8_t)osv;
+        if (S.facc && gl >= 2 && gl < 4) (&m.eri)[gl - 2] = (int8_t)fx_lever_exp(bv1);
       }
       gsync();
       const int oa = m.roa, ob = m.rob;
@@ -1891,12 +1896,50 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     // ================= phase C: friction and the rows of the own item, in region order
     if (have) {
       double* out = S.it_rows + (size_t)it.rows * ROWS_PER_ITEM * 5;
-      int nrows = finish_phase<G>(m, gl, ic, out, ROWS_PER_ITEM, st);
+      // fixed-point totals (sz_geom.hpp): the rows are parked in region buffer 1 as well (every direction check of the wavefront is done: it
+      // is free, and holds 2 RC >= 5 ROWS_PER_ITEM doubles in the variants whose items can have that many rows)
+      const bool fxon = S.facc != nullptr;
+      static_assert(2 * RC >= 5 * (RM < ROWS_PER_ITEM ? RM : ROWS_PER_ITEM), "the parked rows live in region buffer 1");
+      double* const park = &m.reg[1][0][0];
+      int nrows = finish_phase<G>(m, gl, ic, out, ROWS_PER_ITEM, st, fxon ? park : nullptr);
       gsync();
       if (CLS < 2 && (m.ierr & CAPBITS)) {                // working set too small: let the largest variant redo the item
         nrows = 0; flags = IT_RETRY;
         if (gl == 0) { atomicMax(&S.cnt[C_ITEMCLASS], 2); atomicAdd(&S.cnt[C_NRETRY], 1); if (S.retry_stop && S.step > 0) { S.cnt[C_RETRYSTOP] = S.step; S.cnt[C_PAUSED] = S.step; } }
       } else if (gl == 0 && m.ierr) m.err |= m.ierr;
+      if (fxon && ((nrows > 0 && !(flags & IT_RETRY)) || (flags & (IT_FUSE | IT_REMOVE)))) {
+        // the item's two rows come from the work list again (a hit in L2: the entry was read when the item started) rather than being
+        // held in two registers through the clips -- the kernel sits on its register budget, and nothing waits for these atomics
+        int ri, rj = -1;
+        if (is_pair) { const int4 wk = S.work[2 * (size_t)it.rows]; ri = wk.y; rj = wk.z; } else ri = S.el_floe[it.rows - S.capPairs];
+        int glw = gl; asm volatile("" : "+v"(glw));          // (opaque: nothing lane-dependent of this block is hoisted out of the item loop and spilled)
+        if (nrows > 0 && !(flags & IT_RETRY) && glw < 7) {          // lane w < 7: word w of what the item adds to floe i and to floe j
+          long long qi = 0, li = 0, qj = 0, lj = 0; int bad = 0;
+          for (int r = 0; r < nrows; r++) {
+            fx_word(glw, park + r * 5, 1.0, m.kin[KIN_I], m.kin[KIN_I + 1], S.kexp, m.kin[KIN_AREA_I], m.kin[KIN_H_I], m.eri, qi, li, bad);
+            if (rj >= 0) fx_word(glw, park + r * 5, -1.0, m.kin[KIN_J], m.kin[KIN_J + 1], S.kexp, m.kin[KIN_AREA_J], m.kin[KIN_H_J], m.erj, qj, lj, bad);
+          }
+          const int lw = fx_lo_word(glw);
+          unsigned long long* const ai = (unsigned long long*)(S.facc + (size_t)ri * FX_WORDS);
+          if (qi) atomicAdd(ai + glw, (unsigned long long)qi);
+          if (lw >= 0 && li) atomicAdd(ai + lw, (unsigned long long)li);
+          if (rj >= 0) {
+            unsigned long long* const aj = (unsigned long long*)(S.facc + (size_t)rj * FX_WORDS);
+            if (qj) atomicAdd(aj + glw, (unsigned long long)qj);
+            if (lw >= 0 && lj) atomicAdd(aj + lw, (unsigned long long)lj);
+          }
+          if (bad) atomicOr(&S.cnt[C_ERR], ERR_FIXED_RANGE);
+        }
+        // status tags (collisions.jl:367, 438, 525, 801-806) as bits beside the totals: 1 fuse as the pair's first floe, 2 remove (domain element),
+        // 4 fuse as its second floe -- the integrator resolves them in the reference's order.  A tag on a floe this context integrates ends the
+        // batch after this step (simplify_floes!, simulation.jl:205-214), and is raised HERE so that the step's integrator already knows
+        if ((flags & (IT_FUSE | IT_REMOVE)) && gl == 0) {
+          const int nown = S.cnt[C_NOWN];
+          if (flags & IT_FUSE) { atomicOr((int*)(S.facc + (size_t)ri * FX_WORDS + 7), 1); if (rj >= 0) atomicOr((int*)(S.facc + (size_t)rj * FX_WORDS + 7), 4); }
+          if (flags & IT_REMOVE) atomicOr((int*)(S.facc + (size_t)ri * FX_WORDS + 7), 2);
+          if (ri < nown || (rj >= 0 && rj < nown && (flags & IT_FUSE))) request_stop(S);
+        }
+      }
       if (gl == 0) {
         S.it_info[it.info] = make_int2(nrows | (flags << 8), it.rows);
         if (flags & IT_FUSE) atomicAdd(&S.cnt[C_NFUSE], 1);
@@ -2114,8 +2157,13 @@ __device__ __forceinline__ int emit_rows_fold(const State& S, int lane, int f, d
 // m_hint (resident steps; 0: none): about how many floes there are, from the host -- the floe a group starts with then does not
 // depend on the device's count, and its first loads go out together with the counter block (one round trip less in the launch's
 // chain).  Only the mapping uses the hint: floes beyond it are picked up afterwards, groups beyond the real count idle.
-__global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int n_init_arg, int m_hint) {
+// rows_only (resident batches, round 4): the floes' totals, the parents' status tags and floe.overarea are the integrator's, from the fixed-point
+// words of the narrow phase (State::facc); this launch then only assembles floe.interactions (rows, torque column, counts) and the
+// tags of the ghost rows -- once, BEHIND the batch, for the step that ended it (oldc: the parents have been moved since: their
+// centroids of that step are in `mot`), or inside every step on the paths that keep it there
+__global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int n_init_arg, int m_hint, int rows_only, int oldc) {
   const StopRegs stop = stop_load(S);
+  if (oldc && stop.r != 0) return;          // (behind a batch that is paused inside a step: that step is finished first)
   const int M = S.cnt[C_M];
   const int nparents = S.cnt[C_NOWN];
   const int n_init = n_init_arg >= 0 ? n_init_arg : S.cnt[C_N];   // < 0: every parent on the device
@@ -2125,8 +2173,10 @@ __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int 
   int k0 = -1;
   if (hinted) { const int vb = xcd_contiguous((int)blockIdx.x, (int)gridDim.x, nact_h); if (vb >= 0) k0 = vb * gpb + grp; }
   struct Pre { long long gid; double cx, cy; int st, par, ng; int4 cnts; } pre = { 0, 0.0, 0.0, 0, 0, 0, make_int4(0, 0, 0, 0) };
+  const int nmoved = oldc ? S.cnt[C_NOWN] : 0;        // rows [0, nmoved): their centroid of the step is in mot
+  auto cxy = [&](int k, double& x, double& y) { if (k < nmoved) { const double2 o = *(const double2*)(S.mot + (size_t)k * 4); x = o.x; y = o.y; } else { x = S.cx[k]; y = S.cy[k]; } };
   if (k0 >= 0) {
-    pre.gid = S.ghost_id[k0]; pre.cx = S.cx[k0]; pre.cy = S.cy[k0]; pre.st = S.status[k0]; pre.par = S.parent[k0]; pre.ng = S.ngh[k0];
+    pre.gid = S.ghost_id[k0]; cxy(k0, pre.cx, pre.cy); pre.st = S.status[k0]; pre.par = S.parent[k0]; pre.ng = S.ngh[k0];
     pre.cnts = make_int4(S.n_out[k0], S.el_off[k0], S.el_off[k0 + 1], S.n_in[k0]);
   }
   loads_issued();
@@ -2137,10 +2187,11 @@ __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int 
   auto reduce = [&](int k, const Pre* pr) {
     double* dst = S.inter_rows + (size_t)k * S.rowcap * 7;
     const bool is_ghost = (pr ? pr->gid : S.ghost_id[k]) != 0;
-    const double cx = pr ? pr->cx : S.cx[k], cy = pr ? pr->cy : S.cy[k];
+    double cx, cy;
+    if (pr) { cx = pr->cx; cy = pr->cy; } else cxy(k, cx, cy);
     double sx = 0.0, sy = 0.0;
     const int par = pr ? pr->par : S.parent[k];
-    if (mirror && is_ghost && par < n_init) { sx = cx - S.cx[par]; sy = cy - S.cy[par]; }
+    if (mirror && is_ghost && par < n_init) { double pcx, pcy; cxy(par, pcx, pcy); sx = cx - pcx; sy = cy - pcy; }
     bool ovf = false;
     int st = pr ? pr->st : S.status[k], tagA = st;
     const bool totals = mirror && k < n_init;
@@ -2172,7 +2223,16 @@ __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int 
         fx += __shfl(f1, l, IF_G); fy += __shfl(f2, l, IF_G); tq += __shfl(t, l, IF_G); over += __shfl(ov, l, IF_G);
       }
     }
-    if (lane == 0) {
+    if (lane == 0 && rows_only) {
+      S.inter_cnt[k] = c;
+      // (the tags of the parents are the integrator's, from the bits the narrow phase raised; a ghost's own tags are resolved here -- the fuse
+      //  replay walks them, collisions.jl:801-806 -- and so is every row's status before the mirror pass: for a parent it is re-derived from the
+      //  status the integrator has left, which differs from the original only where the replay does not look -- a floe fused as SECOND floe
+      //  of its pairs has no fuse list of its own to propagate, one removed by the coupling is not `fuse`)
+      S.tagA[k] = tagA;
+      if (k >= nparents) S.status[k] = st;
+    }
+    if (lane == 0 && !rows_only) {
       S.status[k] = st; S.tagA[k] = tagA;
       if (st != SZ_ACTIVE && k < nparents) request_stop(S);        // simplify_floes! has work after this step
       S.inter_cnt[k] = c;
@@ -2387,7 +2447,7 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
       // written by the integrate kernel: this kernel may run beside the collision kernels, which also
       // write status, and the reference applies the coupling result after them
       S.frc_remove[i] = npt == 0 ? 1 : 0;
-      if (npt == 0) { }
+      if (npt == 0) { if (S.step > 0 && S.stop_on_tags) S.cnt[C_FRCSTOP] = S.step; }      // (this step's integrator will tag the floe and end the batch: see C_FRCSTOP)
       else {
         double xcor = ma_ratio * P.fcor * v, ycor = ma_ratio * P.fcor * u;
         double totx = npt * xcor + tx, toty = -npt * ycor + ty;
@@ -2511,6 +2571,7 @@ __device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, in
     for (int d = FRC_PLAIN / 2; d >= 1; d >>= 1) npt += __shfl_xor(npt, d, FRC_PLAIN);
     if (lane == 0) {
       S.frc_remove[i] = npt == 0 ? 1 : 0;
+      if (npt == 0 && S.step > 0 && S.stop_on_tags) S.cnt[C_FRCSTOP] = S.step;
       if (npt != 0) {
         double xcor = ma_ratio * P.fcor * v, ycor = ma_ratio * P.fcor * u;
         double totx = npt * xcor + dtx, toty = -npt * ycor + dty;
@@ -2636,34 +2697,46 @@ template <bool MOVE, bool PACK = false>
 #else
 #define ISTAMP(k) do {} while (0)
 #endif
-__global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Params P, int dt, int apply_frc, int bin, int nh, int gl_fill, int ginl, PackInl PK) {
+// acc_mode (resident batches): bit 0: the collision totals, the stress sums and the status tags come from the fixed-point words the narrow
+// phase has accumulated (State::facc) -- no reduce launch ran in this step; bit 1: the host knows this is the batch's last step
+__global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Params P, int dt, int apply_frc, int bin, int nh, int gl_fill, int ginl, PackInl PK, int acc_mode) {
   const GridGeo geo = grid_geo(S);
   const StopRegs stop = stop_load(S);
+  const bool use_acc = (acc_mode & 1) != 0;
+  const int frcstop = use_acc ? S.cnt[C_FRCSTOP] : 0;
   const int N = nh >= 0 ? nh : S.cnt[C_NOWN];     // nh: see sz_k_ghost_flag_scan
   const int nv0 = MOVE && ginl >= 0 ? S.voff[N] : 0;       // ring points of the parents (inline ghosts are laid out behind them)
   int wh = 0, wf = 0, wv = 0, wx = 0;
   const double wall[4] = { S.eval[0], S.eval[1], S.eval[2], S.eval[3] };
   bool tested = false;
   double pk_drift = 0.0;
+  // the batch's last step -- the host says so, or a tag of this step has already asked for the stop (narrow phase: C_STOP; forcings: C_FRCSTOP):
+  // the step's ghosts stay attached and none are made for a next step, so that the rows of THIS step can still be assembled afterwards
+  // (sz_k_inter_fill runs once, behind the batch), and the parents' old centroids are kept for it in `mot`
+  const bool last_step = use_acc && ((acc_mode & 2) != 0 || (S.step > 0 && S.stop_on_tags && (stop.s == S.step || frcstop == S.step)));
+  if (last_step) { gl_fill = -1; ginl = -1; }
+  if (use_acc && blockIdx.x == 0 && threadIdx.x < 2 * NSEG && !stop_test_late(S, stop)) S.wq[(threadIdx.x >> 1) * 32 + (threadIdx.x & 1)] = 0;      // the narrow phase has consumed the work list (as sz_k_inter_fill does)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
     ISTAMP(0);
     const bool gl_any = gl_fill >= 0 || ginl >= 0;
-    const int st0 = gl_any || PACK ? S.status[i] : SZ_ACTIVE, ngh0 = gl_any ? S.ngh[i] : 0;
-    const double rmx = MOVE && (gl_any || S.rec32 || PACK) ? S.rmax[i] : 0.0;
+    const int st0 = gl_any || PACK || use_acc ? S.status[i] : SZ_ACTIVE, ngh0 = gl_any || use_acc ? S.ngh[i] : 0;
+    const double rmx = (MOVE && (gl_any || S.rec32 || PACK)) || use_acc ? S.rmax[i] : 0.0;
+    longlong4 fa0 = make_longlong4(0, 0, 0, 0), fa1 = fa0, fa2 = fa0;
+    if (use_acc) { const longlong4* a = (const longlong4*)(S.facc + (size_t)i * FX_WORDS); fa0 = a[0]; fa1 = a[1]; fa2 = a[2]; }
     const double pk_rx = PACK && PK.ref ? PK.ref[i] : 0.0, pk_ry = PACK && PK.ref ? PK.ref[S.capM + i] : 0.0;      // where the floe lay when the boxes were gathered
     // what a ghost copies of its parent beyond the update's own operands (inline ghosts): asked for HERE, with the first batch -- inside the
     // ghost branch these four loads were a dependent round trip behind the thread's ~60 stores (6.7 k cycles of the 21 k the ghost cost)
     const bool ghost_ops = MOVE && (ginl >= 0 || PACK);
     const long long g_id = ghost_ops ? S.id[i] : 0, g_oki = ghost_ops ? S.okey[i] : 0;
-    const double g_over = ghost_ops ? S.overarea[i] : 0.0;
+    double g_over = ghost_ops || use_acc ? S.overarea[i] : 0.0;
     const signed char g_os = ghost_ops ? S.osign[i] : (signed char)1;
     // Memory order is the whole cost of this kernel (a store in between keeps the compiler from hoisting the
     // loads behind it, and every batch of loads is one HBM round trip): everything is read first -- the
     // columns, then what their values address (contact rows, ring) -- then computed, then stored.
     const int frc_rm = apply_frc ? S.frc_remove[i] : 0;
-    double cfx = S.cfx[i], cfy = S.cfy[i], ctrq = S.ctrq[i];
+    double cfx = use_acc ? 0.0 : S.cfx[i], cfy = use_acc ? 0.0 : S.cfy[i], ctrq = use_acc ? 0.0 : S.ctrq[i];
     const double cx = S.cx[i], cy = S.cy[i];
-    const int rn = S.inter_cnt[i];
+    const int rn = use_acc ? 0 : S.inter_cnt[i];
     const double area = S.area[i], height0 = S.height[i], mass0 = S.mass[i], moment0 = S.moment[i], hflx = S.hflx[i];
     const double u = S.u[i], v = S.v[i], xi = S.xi[i], alpha0 = S.alpha[i];
     const double p_dxdt = S.p_dxdt[i], p_dydt = S.p_dydt[i], p_dalphadt = S.p_dalphadt[i];
@@ -2697,6 +2770,37 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
     if (MOVE && bin) { int ix, iy; cell_of(geo, cx + dx, cy + dy, ix, iy); cell_c = iy * geo.ncx + ix; cell_s = atomicAdd(&S.cell_cnt[cell_c], 1); }
     // calc_stress! (update_floe.jl:392-414): as floe_stress(), on the values read above
     double s11 = 0, s12 = 0, s21 = 0, s22 = 0;
+    int st_new = st0; bool st_dirty = false, over_dirty = false;
+    if (use_acc) {
+      // the totals of this floe's rows -- and of its ghosts' rows: the ghost fold of collisions.jl:830-850 is an integer addition here,
+      // a ghost's levers were taken about ITS centroid, which is the parent's shifted by the same vector as the contact points --
+      // as the narrow phase has accumulated them (fx_row): collision_force / collision_trq (:747-749, 852-861), overarea (:304), the
+      // stress sums, and the status tags in the reference's order (:367, 438, 525, then the mirror pass :801-806)
+      long long q[7] = { fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z }, ql[4] = { fa2.x, fa2.y, fa2.z, fa2.w };      // ql: low words of fx, fy, (y-cy)fx, (x-cx)fy
+      const int tagb = (int)(fa1.w & 0xffffffffll);
+      if (ngh0 != 0) {
+        for (int g3 = 0; g3 < MAX_GHOSTS; g3++) {
+          const int g = S.gh[i * MAX_GHOSTS + g3];
+          if (g >= 0) {
+            const longlong4* a = (const longlong4*)(S.facc + (size_t)g * FX_WORDS); const longlong4 b0 = a[0], b1 = a[1], b2 = a[2];
+            q[0] += b0.x; q[1] += b0.y; q[2] += b0.z; q[3] += b0.w; q[4] += b1.x; q[5] += b1.y; q[6] += b1.z;
+            ql[0] += b2.x; ql[1] += b2.y; ql[2] += b2.z; ql[3] += b2.w;
+          }
+        }
+      }
+      const int eF = fx_force_exp(S.kexp, area, height0), eT = eF + fx_lever_exp(rmx);
+      cfx = fx_join(q[0], ql[0], eF); cfy = fx_join(q[1], ql[1], eF); ctrq = fx_join(q[4] - q[3], ql[3] - ql[2], eT);
+      S.cfx[i] = cfx; S.cfy[i] = cfy; S.ctrq[i] = ctrq;          // (the totals as summed: the force guard below works on copies, as before)
+      if ((q[0] | q[1] | q[2] | q[3] | q[4] | q[5] | ql[0] | ql[1] | ql[2] | ql[3]) != 0) {
+        const double sc = 1 / (area * height0);
+        s11 = fx_join(q[2], 0, eT) * sc; s12 = fx_join(q[3] + q[4], ql[2] + ql[3], eT) * 0.5 * sc; s21 = s12; s22 = fx_join(q[5], 0, eT) * sc;
+      }
+      g_over = g_over + fx_join(q[6], 0, fx_area_exp(area)); over_dirty = q[6] != 0;
+      if (tagb & 1) st_new = SZ_FUSE;
+      if (tagb & 2) st_new = SZ_REMOVE;
+      if (tagb & 4) st_new = SZ_FUSE;
+      st_dirty = tagb != 0 || st0 != SZ_ACTIVE;
+    } else
     if (rn > 0) {
       for (int k = 0; k < rn; k++) {
         const double* r = S.inter_rows + ((size_t)i * S.rowcap + k) * 7;
@@ -2743,15 +2847,23 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
       if (cell_s < CELL_K) S.cell_slots[(size_t)cell_c * CELL_K + cell_s] = i;
       else S.cell_items[i] = atomicExch(&S.cell_ovf[cell_c], i + 1) - 1;
     }
-    if (frc_rm) {
-      S.status[i] = SZ_REMOVE;
+    if (use_acc) {
+      if (over_dirty) S.overarea[i] = g_over;
+      if ((fa0.x | fa0.y | fa0.z | fa0.w | fa1.x | fa1.y | fa1.z | fa1.w | fa2.x | fa2.y | fa2.z | fa2.w) != 0) {
+        longlong4* a = (longlong4*)(S.facc + (size_t)i * FX_WORDS); a[0] = make_longlong4(0, 0, 0, 0); a[1] = make_longlong4(0, 0, 0, 0); a[2] = make_longlong4(0, 0, 0, 0);
+      }
+      if (st_dirty) S.status[i] = st_new;          // (tagA -- the status before the mirror pass -- is written for every row by the launch that assembles the rows)
+      if (MOVE && last_step) *(double2*)(S.mot + (size_t)i * 4) = make_double2(cx, cy);      // (sz_k_inter_fill behind the batch: levers and ghost shifts of this step)
+    }
+    if (frc_rm || (use_acc && st_new != SZ_ACTIVE)) {
+      if (frc_rm) { S.status[i] = SZ_REMOVE; st_new = SZ_REMOVE; }
       if (PACK) {            // the workgroup that writes the halo headers at the end of THIS launch must see the request: performed at memory and waited for
         if (S.step > 0 && S.stop_on_tags) { const int was = atomicMax(&S.cnt[C_STOP], S.step); asm volatile("" :: "v"(was)); }
       } else request_stop(S);
     }
     // the ghosts of this step are detached here (nothing after the reduce looks at them): the next step's ghost pass
     // then only visits the parents that get new ones
-    if (ngh0 != 0) { S.ngh[i] = 0; for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = -1; }
+    if (ngh0 != 0 && !last_step) { S.ngh[i] = 0; for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = -1; }
     // (a wavefront holds at most 63 memory operations in flight, and this thread issues ~70 stores: the four-component columns go out
     //  as one 32-byte store each)
     *(double4*)(S.sa + (size_t)i * 4) = make_double4((1 - l) * sa0[0] + l * sv[0], (1 - l) * sa0[1] + l * sv[1], (1 - l) * sa0[2] + l * sv[2], (1 - l) * sa0[3] + l * sv[3]);
@@ -2805,7 +2917,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
       }
       ISTAMP(4);
       if (gl_any) {
-        const int gf = ghost_flag_of(wall, S.any_periodic_ew, S.any_periodic_ns, ncx, ncy, rmx, bx0, bx1, by0, by1, (frc_rm ? SZ_REMOVE : st0) == SZ_ACTIVE);
+        const int gf = ghost_flag_of(wall, S.any_periodic_ew, S.any_periodic_ns, ncx, ncy, rmx, bx0, bx1, by0, by1, st_new == SZ_ACTIVE);
         if (ginl >= 0) {
           if (gf != 5) {             // the next step's ghosts of this parent, from what has just been computed (a few per cent of the threads)
             GhostRow R;
@@ -2858,7 +2970,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
             if (slot >= (PK.dcap ? PK.dcap[d] : PK.cap) || n > HALO_RING) atomicOr(&S.cnt[C_ERR], n > HALO_RING ? ERR_CAP_RING : ERR_CAP_FLOES);
             else {
               double* r = PK.send + ((size_t)d * (PK.cap + 1) + 1 + slot) * HALO_REC;
-              r[0] = (double)g_oki; r[1] = (double)(frc_rm ? SZ_REMOVE : st0); r[2] = (double)n; r[3] = fx; r[4] = fy; r[5] = rmx;
+              r[0] = (double)g_oki; r[1] = (double)st_new; r[2] = (double)n; r[3] = fx; r[4] = fy; r[5] = rmx;
               r[6] = area; r[7] = h; r[8] = nu; r[9] = nv; r[10] = nxi; r[11] = (double)g_id;
 #pragma unroll
               for (int k = 0; k < MV_RING; k++) {      // the moved ring once more (the expressions of the stores above: the same bits)

@@ -42,6 +42,9 @@ enum {
   C_DRIFT,        // tiled runs: largest displacement of an owned floe since the last box gather, metres as float bits (pack kernel)
   C_PAUSED,       // the step C_RETRYSTOP names was paused by THIS context's narrow phase (tiled runs: a peer's pause arrives in the halo headers
                   // and sets C_RETRYSTOP alone)
+  C_FRCSTOP,      // resident batches: 0, or the batch-relative step whose forcing kernel found a floe without an in-bounds sub-floe point (it will be
+                  // tagged `remove` by that step's integrator, which ends the batch there): a HINT for that integrator -- "this step is the batch's
+                  // last: keep the ghost links, make no ghosts for a next step" -- raised a launch earlier than the tag itself
   C_COUNT = 32
 };
 
@@ -84,6 +87,7 @@ struct State {
   double *sa, *si, *strain;   // 4 per floe
   long long *id, *ghost_id, *okey;   // okey: position in the reference's serial order
   int *status, *parent, *gh, *ngh, *frc_remove;   // gh: MAX_GHOSTS per floe
+  int *gh_save, *ngh_save;                         // the ghost links sz_k_remove_ghosts has just cleared (the rows of a batch's last step may be assembled once more: sz_step)
   signed char* osign;                // ring orientation sign
   double *bbx0, *bbx1, *bby0, *bby1; // ring bounding boxes (kept current by every kernel that moves a ring)
   int* voff; double2* vxy;           // rings, CSR: point k of floe i at vxy[voff[i] + k] = {x, y} (closed: the first point repeated) -- interleaved,
@@ -169,6 +173,14 @@ struct State {
   double* mot;               // 4 per floe: dx, dy, cos, sin
   double* trig;              // 2 per floe: cos(alpha), sin(alpha), kept current by the upload and the integrator
   long long* stamps;         // diagnostic build (-DSZ_STAMPS) only
+  // ---- per-floe collision totals as order-independent fixed-point sums (round 4; sz_geom.hpp "fixed-point totals"): FX_WORDS = 16 int64 words per row
+  //   0 sum fx   1 sum fy   2 sum (x - cx) fx   3 sum (y - cy) fx   4 sum (x - cx) fy   5 sum (y - cy) fy   6 sum overlap area   7 tag bits (low word)
+  //   8 .. 11 the low words (40 more bits) of 0, 1, 3, 4
+  // accumulated by the narrow phase with one atomic per word and row side (no reduce launch in the resident steps: the integrator reads
+  // the eight words, forms collision_force / collision_trq / the stress sums of calc_stress! from them and clears them).  Integer sums do
+  // not depend on the order of the additions, so a tile and the single context -- and any two runs -- give the same bits.  Non-null only in
+  // the launches of resident batches; process-mode calls keep the serial double sums of sz_k_inter_fill.
+  long long* facc; int kexp;   // kexp: ilogb of (1 + mu) E, + 1 (host, sz_set_params): the force scale of a floe is 2^(kexp + ...), see fx_force_exp
   unsigned long long* acc;   // cumulative work counters of the narrow phase (ACC_SLOTS lines of 8 words: launches, pair items run,
                              // their ring points, pair rows, element items, element rows): what a launch averaged over a window of
                              // steps really did, for the roofline of bench.py (sz_get_stats acc_*, cleared by sz_profile_reset)
