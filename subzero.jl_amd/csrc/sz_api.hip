@@ -1726,6 +1726,9 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
         if (coupling) c->forcing_where = fmode;
       }
       c->S.gslot = s & 1;
+      // (the totals of the rows the inline makers allocated for this step are cleared by its neighbour search when it runs on collision records;
+      //  without them -- SZ_CREC=0 -- here)
+      if (facc_on && gi && !(cr && c->S.maxnb <= MAXNB) && !resume) (void)hipMemsetAsync(c->facc_buf + (size_t)FX_WORDS * c->hostN, 0, (size_t)FX_WORDS * (c->S.capM - c->hostN) * sizeof(long long), c->stream);
       if (coll) collisions_step(c, c->hostN, dt, periodic && !sg, sg, resume ? 0 : fmode, lean, resume);
       if (overlap && !resume) stage_forcing_join(c);
       // (inline ghosts: the last step of the batch makes none -- there is no step to make them for, and the cell lists stay the parents')
@@ -3155,6 +3158,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     if (coupling && !fuse && !beside) stage_forcing(c, dt);
     if (coupling) c->forcing_where = fmode;
     S.callid = ++c->callid; callid_of[s] = S.callid;
+    if (facc_on && !(S.crec && S.maxnb <= MAXNB)) (void)hipMemsetAsync(c->facc_buf + (size_t)FX_WORDS * c->hostN, 0, (size_t)FX_WORDS * (S.capM - c->hostN) * sizeof(long long), c->stream);      // (see sz_step)
     if (dbgsync) {          // (the stages of collisions_step one by one)
       stage_broad(c, false, true, fmode == 1, false); stage_done(s, "neighbour search");
       stage_elems(c, true); stage_done(s, "element items");

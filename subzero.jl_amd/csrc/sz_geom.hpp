@@ -113,14 +113,13 @@ enum { ERR_CAP_RING = 1, ERR_CAP_XING = 2, ERR_CAP_REGION = 4, ERR_CAP_ROWS = 8,
 //     contributor uses the same grid;
 //   * lever arms |x - cx_k| <= rmax_k (the contact point is the centroid of a region inside the floe): torque / stress products get
 //     e_T = e_F + ilogb(rmax_k) + 1;  overlap areas e_O = ilogb(area_k) + 1;
-//   * the words that drive the floe's motion -- force x / y and the two torque products -- are kept to 40 more bits in a second word
-//     (hi = rint(t), lo = rint((t - hi) 2^40), t - hi exact): the sum is then the EXACT sum of the rows' doubles down to 2^-92 of the
-//     bound, rounded once when it is read -- closer to the true sum than the serial double sum of the reference, and equal and
-//     opposite forces stay exactly so.  The stress products and the overlap area are outputs only: one word (2^-52 of the bound).
+//   * every word is kept to 40 more bits in a second word (hi = rint(t), lo = rint((t - hi) 2^40), t - hi exact): the sum is then the
+//     EXACT sum of the rows' doubles down to 2^-92 of the bound, rounded once when it is read -- closer to the true sum than the serial
+//     double sum of the reference (one word alone, 2^-52 of the BOUND, was measurably coarser than the reference's own round-off: the
+//     suite's 10-step trajectories left the oracle's by 1e-8), and equal and opposite forces stay exactly so.
 // A value beyond its bound by more than the headroom raises ERR_FIXED_RANGE (never seen: the bounds are theorems about the formulas).
 constexpr int FX_WORDS = 16;        // int64 words per floe (one 128-byte line): 0 fx, 1 fy, 2 (x-cx)fx, 3 (y-cy)fx, 4 (x-cx)fy, 5 (y-cy)fy, 6 overlap, 7 tag bits,
-                                    // 8..11 the low words of 0, 1, 3, 4
-SZ_DEV int fx_lo_word(int w) { return w < 2 ? 8 + w : w == 3 ? 10 : w == 4 ? 11 : -1; }
+                                    // 8..14 the low words of 0..6
 SZ_DEV int fx_ilogb(double x, int lo, int hi) {
   int e = lo;
   if (x > 0.0 && x < __builtin_inf()) { e = ilogb(x); e = e < lo ? lo : (e > hi ? hi : e); }

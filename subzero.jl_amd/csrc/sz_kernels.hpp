@@ -494,7 +494,7 @@ __device__ __forceinline__ void ghost_fill_parent(State& S, const GridGeo& geo, 
     if (bin && lane == 14) cell_insert(S, geo, g, gcx, gcy);
     if (lane == 16) { F->key[gid] = key; F->gid[gid] = (long long)gid; F->cx[gid] = gcx; F->cy[gid] = gcy; }
     if (lane < MAX_GHOSTS) S.gh[g * MAX_GHOSTS + lane] = -1;
-    if (S.facc && lane >= 20 && lane < 32) S.facc[(size_t)g * FX_WORDS + (lane - 20)] = 0;      // (fixed-point totals of the new row)
+    if (S.facc && lane >= 20 && lane < 36) S.facc[(size_t)g * FX_WORDS + (lane - 20)] = 0;      // (fixed-point totals of the new row)
   };
   int s0 = 0, s1 = 0, s2 = 0;
   int ng = 0; bool moved = false;
@@ -818,7 +818,9 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
     if (S.rec32) rec32_store(S, g, gx, gy, c_rmax, x0, x1, y0, y1);
     if (S.crec) crec_store_all(S, g, gx, gy, c_rmax, idv, key, n, osv, body ? vo : vb, i, 0, x0, x1, y0, y1, c_u, c_v, c_xi, c_area, c_h, (long long)(w + 1));
     S.gkeys[(size_t)slot * S.capM + og + w] = key;
-    if (S.facc) { longlong4* a = (longlong4*)(S.facc + (size_t)g * FX_WORDS); a[0] = make_longlong4(0, 0, 0, 0); a[1] = make_longlong4(0, 0, 0, 0); a[2] = make_longlong4(0, 0, 0, 0); }      // (fixed-point totals of the new row)
+    // (the fixed-point totals of the new row are cleared by the neighbour search of its step, not here: the rows of step t + 1 are the rows
+    //  of step t again, and while this thread makes a ghost another thread of the same launch may still be reading the totals of ITS
+    //  step-t ghost in that row)
   };
   GSTAMP(13);
   {
@@ -1188,6 +1190,7 @@ __device__ __forceinline__ Item item_of(const State& S, const Seg& g, int t) {
 // owned pairs whose ring boxes overlap are appended to the narrow phase's work list here (one tail atomic per workgroup);
 // the others get their (empty) result at once.
 constexpr int NB_G = 16, NB_TPB = 128;
+static_assert(NB_G == FX_WORDS, "the neighbour search clears a new row's fixed-point totals with one store per lane");
 // FAM: the Dict rule may read family records (inline ghosts; State::Fam) -- its arrays cost ~50 registers, a wavefront per SIMD that a
 // large field (throughput-bound search) misses: the host picks the instantiation by size
 // NBC: neighbours a floe may have in either direction (= State::maxnb, the stride of the neighbour lists): 24 for fields of like-sized
@@ -1215,9 +1218,11 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   const int gl = threadIdx.x % NB_G, gi = threadIdx.x / NB_G;
   const StopRegs stop = stop_load(S);
   int M = S.cnt[C_M];
+  int nfix = 0x7fffffff;        // rows from here on get their fixed-point totals cleared by this launch (the rows the step's inline makers allocated)
   if (S.ginline) {            // inline ghosts: the step's ghosts were made by the kernel that placed their parents; the counts are committed here
     const unsigned long long a = S.galloc[S.gslot * 16], poisoned = S.galloc[S.gslot * 16 + 1];
     const int N = S.cnt[C_N]; int G = (int)(a >> 32), V = (int)(a & 0xffffffffull);
+    if (REC && S.facc) nfix = N;          // (the instantiations on collision records -- what the resident steps run; without records the host clears the rows, sz_step)
     if (poisoned || N + G > S.capM) { G = 0; V = 0; }          // a poisoned allocator (see ghost_inline_make): the parents alone, the error bit is up
     M = N + G;
     if (bid == 0 && threadIdx.x == 0 && !stop_test(S, stop)) { S.cnt[C_M] = M; S.cnt[C_NV] = S.voff[N] + V; S.cnt[C_NGHOSTS] = G; }
@@ -1256,6 +1261,7 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
     if (stop_test(S, stop) || kb >= M) break;
     if (bid == 0 && threadIdx.x == 0 && kb == vb0 * GPB) { S.cnt[C_ITEMCLASS] = 0; S.cnt[C_NFUSE] = 0; }     // per-step counters the narrow phase raises
     const bool act = k < M;
+    if constexpr (REC) { if (act && k >= nfix) S.facc[(size_t)k * FX_WORDS + gl] = 0; }         // (NB_G = FX_WORDS lanes: one line)
     __syncthreads();
     if (gl == 0) { cnts[gi][0] = 0; cnts[gi][1] = 0; npool[gi] = 0; if constexpr (MW == 1) wmask[gi] = (mask_t)0; }
     if constexpr (MW > 1) { if (gl < MW) wmaskw[gi][gl] = 0ull; }
@@ -1919,14 +1925,13 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
             fx_word(glw, park + r * 5, 1.0, m.kin[KIN_I], m.kin[KIN_I + 1], S.kexp, m.kin[KIN_AREA_I], m.kin[KIN_H_I], m.eri, qi, li, bad);
             if (rj >= 0) fx_word(glw, park + r * 5, -1.0, m.kin[KIN_J], m.kin[KIN_J + 1], S.kexp, m.kin[KIN_AREA_J], m.kin[KIN_H_J], m.erj, qj, lj, bad);
           }
-          const int lw = fx_lo_word(glw);
           unsigned long long* const ai = (unsigned long long*)(S.facc + (size_t)ri * FX_WORDS);
           if (qi) atomicAdd(ai + glw, (unsigned long long)qi);
-          if (lw >= 0 && li) atomicAdd(ai + lw, (unsigned long long)li);
+          if (li) atomicAdd(ai + 8 + glw, (unsigned long long)li);
           if (rj >= 0) {
             unsigned long long* const aj = (unsigned long long*)(S.facc + (size_t)rj * FX_WORDS);
             if (qj) atomicAdd(aj + glw, (unsigned long long)qj);
-            if (lw >= 0 && lj) atomicAdd(aj + lw, (unsigned long long)lj);
+            if (lj) atomicAdd(aj + 8 + glw, (unsigned long long)lj);
           }
           if (bad) atomicOr(&S.cnt[C_ERR], ERR_FIXED_RANGE);
         }
@@ -2721,8 +2726,8 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
     const bool gl_any = gl_fill >= 0 || ginl >= 0;
     const int st0 = gl_any || PACK || use_acc ? S.status[i] : SZ_ACTIVE, ngh0 = gl_any || use_acc ? S.ngh[i] : 0;
     const double rmx = (MOVE && (gl_any || S.rec32 || PACK)) || use_acc ? S.rmax[i] : 0.0;
-    longlong4 fa0 = make_longlong4(0, 0, 0, 0), fa1 = fa0, fa2 = fa0;
-    if (use_acc) { const longlong4* a = (const longlong4*)(S.facc + (size_t)i * FX_WORDS); fa0 = a[0]; fa1 = a[1]; fa2 = a[2]; }
+    longlong4 fa0 = make_longlong4(0, 0, 0, 0), fa1 = fa0, fa2 = fa0, fa3 = fa0;
+    if (use_acc) { const longlong4* a = (const longlong4*)(S.facc + (size_t)i * FX_WORDS); fa0 = a[0]; fa1 = a[1]; fa2 = a[2]; fa3 = a[3]; }
     const double pk_rx = PACK && PK.ref ? PK.ref[i] : 0.0, pk_ry = PACK && PK.ref ? PK.ref[S.capM + i] : 0.0;      // where the floe lay when the boxes were gathered
     // what a ghost copies of its parent beyond the update's own operands (inline ghosts): asked for HERE, with the first batch -- inside the
     // ghost branch these four loads were a dependent round trip behind the thread's ~60 stores (6.7 k cycles of the 21 k the ghost cost)
@@ -2776,26 +2781,26 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
       // a ghost's levers were taken about ITS centroid, which is the parent's shifted by the same vector as the contact points --
       // as the narrow phase has accumulated them (fx_row): collision_force / collision_trq (:747-749, 852-861), overarea (:304), the
       // stress sums, and the status tags in the reference's order (:367, 438, 525, then the mirror pass :801-806)
-      long long q[7] = { fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z }, ql[4] = { fa2.x, fa2.y, fa2.z, fa2.w };      // ql: low words of fx, fy, (y-cy)fx, (x-cx)fy
+      long long q[7] = { fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z }, ql[7] = { fa2.x, fa2.y, fa2.z, fa2.w, fa3.x, fa3.y, fa3.z };      // ql: the low words
       const int tagb = (int)(fa1.w & 0xffffffffll);
       if (ngh0 != 0) {
         for (int g3 = 0; g3 < MAX_GHOSTS; g3++) {
           const int g = S.gh[i * MAX_GHOSTS + g3];
           if (g >= 0) {
-            const longlong4* a = (const longlong4*)(S.facc + (size_t)g * FX_WORDS); const longlong4 b0 = a[0], b1 = a[1], b2 = a[2];
+            const longlong4* a = (const longlong4*)(S.facc + (size_t)g * FX_WORDS); const longlong4 b0 = a[0], b1 = a[1], b2 = a[2], b3 = a[3];
             q[0] += b0.x; q[1] += b0.y; q[2] += b0.z; q[3] += b0.w; q[4] += b1.x; q[5] += b1.y; q[6] += b1.z;
-            ql[0] += b2.x; ql[1] += b2.y; ql[2] += b2.z; ql[3] += b2.w;
+            ql[0] += b2.x; ql[1] += b2.y; ql[2] += b2.z; ql[3] += b2.w; ql[4] += b3.x; ql[5] += b3.y; ql[6] += b3.z;
           }
         }
       }
       const int eF = fx_force_exp(S.kexp, area, height0), eT = eF + fx_lever_exp(rmx);
-      cfx = fx_join(q[0], ql[0], eF); cfy = fx_join(q[1], ql[1], eF); ctrq = fx_join(q[4] - q[3], ql[3] - ql[2], eT);
+      cfx = fx_join(q[0], ql[0], eF); cfy = fx_join(q[1], ql[1], eF); ctrq = fx_join(q[4] - q[3], ql[4] - ql[3], eT);
       S.cfx[i] = cfx; S.cfy[i] = cfy; S.ctrq[i] = ctrq;          // (the totals as summed: the force guard below works on copies, as before)
-      if ((q[0] | q[1] | q[2] | q[3] | q[4] | q[5] | ql[0] | ql[1] | ql[2] | ql[3]) != 0) {
+      if ((q[0] | q[1] | q[2] | q[3] | q[4] | q[5] | ql[0] | ql[1] | ql[2] | ql[3] | ql[4] | ql[5]) != 0) {
         const double sc = 1 / (area * height0);
-        s11 = fx_join(q[2], 0, eT) * sc; s12 = fx_join(q[3] + q[4], ql[2] + ql[3], eT) * 0.5 * sc; s21 = s12; s22 = fx_join(q[5], 0, eT) * sc;
+        s11 = fx_join(q[2], ql[2], eT) * sc; s12 = fx_join(q[3] + q[4], ql[3] + ql[4], eT) * 0.5 * sc; s21 = s12; s22 = fx_join(q[5], ql[5], eT) * sc;
       }
-      g_over = g_over + fx_join(q[6], 0, fx_area_exp(area)); over_dirty = q[6] != 0;
+      g_over = g_over + fx_join(q[6], ql[6], fx_area_exp(area)); over_dirty = (q[6] | ql[6]) != 0;
       if (tagb & 1) st_new = SZ_FUSE;
       if (tagb & 2) st_new = SZ_REMOVE;
       if (tagb & 4) st_new = SZ_FUSE;
@@ -2849,8 +2854,8 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
     }
     if (use_acc) {
       if (over_dirty) S.overarea[i] = g_over;
-      if ((fa0.x | fa0.y | fa0.z | fa0.w | fa1.x | fa1.y | fa1.z | fa1.w | fa2.x | fa2.y | fa2.z | fa2.w) != 0) {
-        longlong4* a = (longlong4*)(S.facc + (size_t)i * FX_WORDS); a[0] = make_longlong4(0, 0, 0, 0); a[1] = make_longlong4(0, 0, 0, 0); a[2] = make_longlong4(0, 0, 0, 0);
+      if ((fa0.x | fa0.y | fa0.z | fa0.w | fa1.x | fa1.y | fa1.z | fa1.w | fa2.x | fa2.y | fa2.z | fa2.w | fa3.x | fa3.y | fa3.z) != 0) {
+        longlong4* a = (longlong4*)(S.facc + (size_t)i * FX_WORDS); a[0] = make_longlong4(0, 0, 0, 0); a[1] = make_longlong4(0, 0, 0, 0); a[2] = make_longlong4(0, 0, 0, 0); a[3] = make_longlong4(0, 0, 0, 0);
       }
       if (st_dirty) S.status[i] = st_new;          // (tagA -- the status before the mirror pass -- is written for every row by the launch that assembles the rows)
       if (MOVE && last_step) *(double2*)(S.mot + (size_t)i * 4) = make_double2(cx, cy);      // (sz_k_inter_fill behind the batch: levers and ghost shifts of this step)
