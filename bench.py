@@ -196,7 +196,35 @@ def reference_cpu(cfg, cores, budget_s=60.0):
         return None
 
 
-def cpu_baseline(cfg, budget_s=20.0, relax_steps=0):
+def parity_after_relaxation(cfg, ow, steps, device):
+    """The HIP engine against the oracle at the END of the relaxation -- the state the timed window starts from, not the unrelaxed field:
+    a fresh context runs the same `steps` timesteps the oracle has just walked through (cpu_baseline); pair list of the last step,
+    guard counters, and the state columns on their own scale.  Stated tolerance 1e-6: fifty steps of a stiff contact network amplify
+    the last-bit differences of a step (1e-15 .. 1e-12: libm trig, the exactly summed totals against the reference's serial sums) by about
+    one decade per ten steps; the suite holds 3 .. 10 steps to 1e-9."""
+    import numpy as np
+    import subzero_jl_amd
+    from subzero_jl_amd import fields
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity
+    out = {"steps": steps, "tolerance": 1e-6}
+    try:
+        hw = fields.build_world(subzero_jl_amd.World(device), cfg)
+        done = hw.run(steps, 0, cfg["dt"], coupling_dt=1)
+        out["steps_run"] = int(done)
+        hi, hj = hw.pairs(); oi, oj = ow.pairs()
+        out["n_pairs"] = int(len(oi))
+        out["pairs_equal"] = bool(len(hi) == len(oi) and np.array_equal(hi, oi) and np.array_equal(hj, oj))
+        errs = {f: parity.relerr(hw.get(f), ow.get(f)) for f in ("cx", "cy", "alpha", "u", "v", "xi", "coll_fx", "coll_fy", "coll_trq", "fxOA", "fyOA", "trqOA", "overarea")}
+        out["max_rel_state_err"] = max(errs.values()); out["worst_column"] = max(errs, key=errs.get)
+        out["guards_equal"] = bool(np.array_equal(hw.warn_counts(), ow.warn_counts()))
+        out["ok"] = bool(done == steps and out["pairs_equal"] and out["max_rel_state_err"] <= out["tolerance"])
+    except Exception as e:      # noqa: BLE001
+        out["ok"] = False; out["error"] = str(e)[:300]
+    return out
+
+
+def cpu_baseline(cfg, budget_s=20.0, relax_steps=0, device=None):
     """The oracle (kind: port) on a bounded sample of the same workload: the same 10k-floe field,
     as many whole timesteps as fit the budget (at least 2), all host cores of this process."""
     from oracle import orc
@@ -219,6 +247,7 @@ def cpu_baseline(cfg, budget_s=20.0, relax_steps=0):
         w.timestep_sim(k, cfg["dt"], coupling_dt=1)
     tr = time.perf_counter() - tr
     base = max(relax_steps, 1)
+    relaxed_parity = parity_after_relaxation(cfg, w, base, device) if device is not None else None
     w.phase_times()
     t0 = time.perf_counter(); steps = 0
     while steps < 2 or (time.perf_counter() - t0 < 0.75 * budget_s and steps < 300):
@@ -236,6 +265,7 @@ def cpu_baseline(cfg, budget_s=20.0, relax_steps=0):
             "sample": f"{steps} timesteps of the same {cfg['n_floes']}-floe field ({el:.1f} s) after {base} untimed relaxation steps ({tr:.1f} s), "
                       f"OpenMP over floes like the reference's Threads.@threads loops; then {s1} steps on one core ({el1:.1f} s)",
             "value_1core": cfg["n_floes"] * s1 / el1,
+            "hip_against_this_oracle_after_the_relaxation": relaxed_parity,
             # where the port spends its time (ms per step): the phases the reference runs serially (Dict pass, mirror / ghost fold,
             # the forcing loop: collisions.jl:799-862, coupling.jl:1498) are why more cores buy little
             "ms_per_step_by_phase": {k: 1e3 * v / steps for k, v in ph.items()},
@@ -713,7 +743,7 @@ def main():
                 out["strong_scaling_workload_on_one_gpu"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline ...")
-            out["cpu_baseline"] = cpu_baseline(cfg, relax_steps=args.relax_steps)
+            out["cpu_baseline"] = cpu_baseline(cfg, relax_steps=args.relax_steps, device=local)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()

@@ -405,6 +405,12 @@ int sz_simplify_check(sz_ctx *ctx, int32_t max_vertices, double min_floe_area, d
    given points (<= 64) and a given closed region ring; idx = sorted 0-based vertex indices */
 int sz_debug_match_vertices(sz_ctx *ctx, int32_t npts, const double *px, const double *py, int32_t nr, const double *rx,
                             const double *ry, int32_t *idx, int32_t *n_out);
+
+/* test hook: the in-bounds test of calc_subfloe_values! (in_bounds, coupling.jl:494-597) and the lattice sample of mc_interpolation
+   (find_interp_knots + linear_interpolation, coupling.jl:702-902) as the forcing kernels evaluate them, at n given points.
+   out12[12 k ..] = in_bounds (0 / 1), uocn, vocn, hflx, uatm, vatm, the 1-based grid lines west, east, south, north the bilinear
+   blend reads, its weights tx, ty.  Needs sz_set_domain and sz_set_fields. */
+int sz_debug_sample_fields(sz_ctx *ctx, int32_t n, const double *x, const double *y, double *out12);
 /* diagnostic build (-DSZ_STAMPS) only: stamp log of one lane group of the narrow phase
    (out512[0] = entries, then (stage << 48) | cycles since the wave started) */
 int sz_debug_stamps(sz_ctx *ctx, long long *out512);

@@ -147,6 +147,11 @@ void orc_floe_floe_interaction(orc_world *w, int i, int j, int dt, double max_ov
 void orc_floe_domain_interaction(orc_world *w, int i, int dt, double max_overlap);      /* :594 */
 void orc_calc_torque(orc_world *w, int i);                           /* collisions.jl:673-686 */
 void orc_timestep_coupling(orc_world *w);                            /* coupling.jl:1705-1738 */
+int  orc_in_bounds(const orc_world *w, double x, double y, int per_x, int per_y);      /* coupling.jl:494-597 */
+int  orc_find_interp_knots(int npts, const int *point_idx, int ncells, double g0, double dg, double L, int dd, int periodic,
+                           int cap, double *knots, int *knot_idx);                      /* coupling.jl:702-797 */
+void orc_sample_lines(const orc_world *w, double x, double y, int per_x, int per_y, int *lines4, double *t2);
+void orc_sample_fields(const orc_world *w, double x, double y, int per_x, int per_y, double *out5);   /* coupling.jl:845-902 */
 /* two-way coupling (off by default): ice-on-ocean stress per centre cell, coupling.jl:1617-1680 */
 void orc_set_two_way(orc_world *w, int on, double Cd_ao, double k, double L, int dt);
 void orc_set_temps(orc_world *w, const double *t_ocn, const double *t_atm);       /* (Nx+1) x (Ny+1), [ix][iy] */

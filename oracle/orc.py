@@ -56,7 +56,8 @@ def lib():
         L.orc_add_floe.restype = C.c_int
         for name in ("orc_num_floes", "orc_total_ring_points", "orc_total_interactions",
                      "orc_total_ghost_links", "orc_total_fuse", "orc_num_pairs",
-                     "orc_clip_flat", "orc_ipoints_flat", "orc_cell_count", "orc_shift_cell_idx", "orc_which_vertices_match_points"):
+                     "orc_clip_flat", "orc_ipoints_flat", "orc_cell_count", "orc_shift_cell_idx", "orc_which_vertices_match_points",
+                     "orc_in_bounds", "orc_find_interp_knots"):
             getattr(L, name).restype = C.c_int
     return _LIB
 
@@ -87,6 +88,17 @@ def which_vertices_match_points(points, region):
     idx = np.zeros(max(len(px), 1), np.int32)
     n = lib().orc_which_vertices_match_points(len(px), _p(px), _p(py), len(rx), _p(rx), _p(ry), _p(idx, _ip))
     return [int(v) + 1 for v in idx[:n]]
+
+
+def find_interp_knots(point_idx, ncells, g0, dg, L, dd, periodic):
+    """find_interp_knots (coupling.jl:702-797): (knots, 1-based knot_idx)"""
+    pts = np.ascontiguousarray(point_idx, dtype=np.int32)
+    cap = 4 * (ncells + 2 * dd + 8)
+    knots = np.zeros(cap); idx = np.zeros(cap, np.int32)
+    n = lib().orc_find_interp_knots(len(pts), _p(pts, _ip), int(ncells), C.c_double(g0), C.c_double(dg), C.c_double(L), int(dd), int(periodic),
+                                    cap, _p(knots), _p(idx, _ip))
+    assert 0 <= n <= cap
+    return knots[:n].tolist(), idx[:n].tolist()
 
 
 def intersection_points(a, b, max_pts=1024):
@@ -167,6 +179,21 @@ class World:
         out = np.zeros((n, 6))
         for k in range(n):
             row = np.zeros(6); self.L.orc_cell_entry(self.h, int(xidx), int(yidx), k, _p(row)); out[k] = row
+        return out
+
+    def in_bounds(self, x, y, per_x, per_y):
+        """in_bounds (coupling.jl:494-597) as the coupling evaluates it per sub-floe point; per_x: the east/west pair is periodic"""
+        return bool(self.L.orc_in_bounds(self.h, C.c_double(x), C.c_double(y), int(per_x), int(per_y)))
+
+    def sample_lines(self, x, y, per_x, per_y):
+        """the 1-based grid lines (west, east, south, north) and the weights (tx, ty) the lattice sample blends at (x, y)"""
+        lines = np.zeros(4, np.int32); t = np.zeros(2)
+        self.L.orc_sample_lines(self.h, C.c_double(x), C.c_double(y), int(per_x), int(per_y), _p(lines, _ip), _p(t))
+        return lines.tolist(), t.tolist()
+
+    def sample_fields(self, x, y, per_x, per_y):
+        out = np.zeros(5)
+        self.L.orc_sample_fields(self.h, C.c_double(x), C.c_double(y), int(per_x), int(per_y), _p(out))
         return out
 
     def center_cell_coords(self, xidx, yidx, ns_periodic, ew_periodic):

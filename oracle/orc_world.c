@@ -864,6 +864,58 @@ static double sample(const orc_world *w, const double *A, double x, double y, in
   return (1.0 - tx) * c0 + tx * c1;
 }
 
+/* in_bounds, coupling.jl:494-597: four methods dispatched on the (north/south, east/west) boundary kinds -- a direction with a
+   periodic pair admits every coordinate.  The expression orc_timestep_coupling evaluates per sub-floe point. */
+int orc_in_bounds(const orc_world *w, double x, double y, int per_x, int per_y) {
+  return (per_x || (w->gx0 <= x && x <= w->gxf)) && (per_y || (w->gy0 <= y && y <= w->gyf));
+}
+/* find_interp_knots, coupling.jl:702-744 (periodic) and :776-797 (non-periodic): the grid lines (1-based numbers in knot_idx, values in
+   knots) around the points nearest to lines point_idx[0..npts), with a buffer of dd + 1 lines either side.  Periodic: line ncells + 1 IS
+   line 1 and is not repeated; lines beyond an edge are the far side's, their values shifted by the grid length L.  Returns the number of
+   knots (at most cap). */
+int orc_find_interp_knots(int npts, const int *point_idx, int ncells, double g0, double dg, double L, int dd, int periodic,
+                          int cap, double *knots, int *knot_idx) {
+  int min_line = point_idx[0], max_line = point_idx[0], n = 0;
+  for (int k = 1; k < npts; k++) { if (point_idx[k] < min_line) min_line = point_idx[k]; if (point_idx[k] > max_line) max_line = point_idx[k]; }
+  min_line -= dd + 1; max_line += dd + 1;
+#define ORC_KNOT(line, shift) do { if (n < cap) { knot_idx[n] = (line); knots[n] = g0 + ((line) - 1) * dg + (shift); } n++; } while (0)
+  if (!periodic) {
+    const int nlines = ncells + 1;
+    if (min_line < 1) min_line = 1;
+    if (max_line > nlines) max_line = nlines;
+    for (int l = min_line; l <= max_line; l++) ORC_KNOT(l, 0.0);
+    return n;
+  }
+  int lo0 = 1, lo1 = 0, hi0 = 1, hi1 = 0, in0, in1;          /* empty ranges */
+  if (min_line < 1 && max_line > ncells) { lo0 = min_line + ncells; lo1 = ncells; hi0 = 1; hi1 = max_line - ncells; in0 = 1; in1 = ncells; }
+  else if (min_line < 1) { lo0 = min_line + ncells; lo1 = ncells; in0 = 1; in1 = max_line; }
+  else if (max_line > ncells) { hi0 = 1; hi1 = max_line - ncells; in0 = min_line; in1 = ncells; }
+  else { in0 = min_line; in1 = max_line; }
+  for (int l = lo0; l <= lo1; l++) ORC_KNOT(l, -L);
+  for (int l = in0; l <= in1; l++) ORC_KNOT(l, 0.0);
+  for (int l = hi0; l <= hi1; l++) ORC_KNOT(l, L);
+#undef ORC_KNOT
+  return n;
+}
+/* the grid lines sample() blends at (x, y) -- 1-based numbers west, east, south, north -- and its weights: what ties sample()'s wrap to
+   find_interp_knots' knot_idx (tests/test_oracle_golden.py) */
+void orc_sample_lines(const orc_world *w, double x, double y, int per_x, int per_y, int *lines4, double *t2) {
+  int Nx = w->Nx, Ny = w->Ny;
+  long ix = (long)floor((x - w->gx0) / w->gdx), iy = (long)floor((y - w->gy0) / w->gdy);
+  if (!per_x) { if (ix < 0) ix = 0; if (ix > Nx - 1) ix = Nx - 1; }
+  if (!per_y) { if (iy < 0) iy = 0; if (iy > Ny - 1) iy = Ny - 1; }
+  t2[0] = (x - (w->gx0 + (double)ix * w->gdx)) / w->gdx; t2[1] = (y - (w->gy0 + (double)iy * w->gdy)) / w->gdy;
+  long i0, i1, j0, j1;
+  if (per_x) { i0 = ((ix % Nx) + Nx) % Nx; i1 = (((ix + 1) % Nx) + Nx) % Nx; } else { i0 = ix; i1 = ix + 1; }
+  if (per_y) { j0 = ((iy % Ny) + Ny) % Ny; j1 = (((iy + 1) % Ny) + Ny) % Ny; } else { j0 = iy; j1 = iy + 1; }
+  lines4[0] = (int)i0 + 1; lines4[1] = (int)i1 + 1; lines4[2] = (int)j0 + 1; lines4[3] = (int)j1 + 1;
+}
+/* the five lattices at (x, y) as the coupling samples them: uocn, vocn, hflx, uatm, vatm */
+void orc_sample_fields(const orc_world *w, double x, double y, int per_x, int per_y, double *out5) {
+  out5[0] = sample(w, w->uo, x, y, per_x, per_y); out5[1] = sample(w, w->vo, x, y, per_x, per_y); out5[2] = sample(w, w->hf, x, y, per_x, per_y);
+  out5[3] = sample(w, w->ua, x, y, per_x, per_y); out5[4] = sample(w, w->va, x, y, per_x, per_y);
+}
+
 /* ------------------------------------------------------------------ two-way coupling */
 void orc_set_two_way(orc_world *w, int on, double Cd_ao, double k, double L, int dt) {
   w->two_way = on; w->Cd_ao = Cd_ao; w->k_ice = k; w->L_ice = L; w->dt_couple = dt;
@@ -1079,7 +1131,7 @@ void orc_timestep_coupling(orc_world *w) {
     for (int k = 0; k < f->nsub; k++) {
       double x = (ca * f->sx[k] - sa * f->sy[k]) + f->cx;
       double y = (sa * f->sx[k] + ca * f->sy[k]) + f->cy;
-      int inb = (per_x || (w->gx0 <= x && x <= w->gxf)) && (per_y || (w->gy0 <= y && y <= w->gyf));
+      int inb = orc_in_bounds(w, x, y, per_x, per_y);
       if (inb) npoints++;
     }
     if (npoints == 0) { f->status = ORC_REMOVE; continue; }
@@ -1087,7 +1139,7 @@ void orc_timestep_coupling(orc_world *w) {
     for (int k = 0; k < f->nsub; k++) {
       double x = (ca * f->sx[k] - sa * f->sy[k]) + f->cx;
       double y = (sa * f->sx[k] + ca * f->sy[k]) + f->cy;
-      int inb = (per_x || (w->gx0 <= x && x <= w->gxf)) && (per_y || (w->gy0 <= y && y <= w->gyf));
+      int inb = orc_in_bounds(w, x, y, per_x, per_y);
       if (!inb) continue;
       double xc = x - f->cx, yc = y - f->cy;
       double th = atan2(yc, xc), rad = sqrt(xc * xc + yc * yc);

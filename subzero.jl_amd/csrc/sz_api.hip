@@ -1417,6 +1417,23 @@ int sz_debug_match_vertices(sz_ctx* c, int32_t npts, const double* px, const dou
   return SZ_OK;
 }
 
+// the forcing kernels' in-bounds test and lattice sample at given points (the reference's vectors for in_bounds / find_interp_knots)
+int sz_debug_sample_fields(sz_ctx* c, int32_t n, const double* x, const double* y, double* out12) {
+  if (!c || n < 0 || (n > 0 && (!x || !y || !out12))) return SZ_E_ARG;
+  if (!c->have_fields || !c->have_domain) { c->err = "sz_debug_sample_fields needs sz_set_domain and sz_set_fields"; return SZ_E_STATE; }
+  if (n == 0) return SZ_OK;
+  (void)hipSetDevice(c->device);
+  PoolGuard pool;
+  double *dx, *dy, *dout;
+  int rc;
+  if ((rc = dalloc(c, &dx, n, pool.v)) || (rc = dalloc(c, &dy, n, pool.v)) || (rc = dalloc(c, &dout, (size_t)12 * n, pool.v))) return rc;
+  H2D(dx, x, n, double); H2D(dy, y, n, double);
+  hipLaunchKernelGGL(sz_k_debug_sample, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->S, n, dx, dy, dout);
+  HIPCHK(c, hipMemcpyAsync(out12, dout, (size_t)12 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SZ_OK;
+}
+
 // ---------------------------------------------------------------- processes
 int sz_add_ghosts(sz_ctx* c) {
   if (!c || !c->have_floes) return SZ_E_STATE;

@@ -2308,10 +2308,27 @@ __device__ __forceinline__ LatticeCell lattice_cell(const State& S, double x, do
 }
 // The five lattices are interleaved per node (8 doubles = one 64-byte line: uo, vo, hf, ua, va, pad):
 // a point touches 4 lines instead of 10.  Field f of the four corner nodes -> bilinear value.
+// in_bounds, coupling.jl:494-597 (four methods dispatched on the boundary kinds): a direction with a periodic pair admits every coordinate
+__device__ __forceinline__ bool point_in_bounds(const State& S, double x, double y, int per_x, int per_y) {
+  return (per_x || (S.gx0 <= x && x <= S.gxf)) && (per_y || (S.gy0 <= y && y <= S.gyf));
+}
 __device__ __forceinline__ double sample_field(const double* nodes, int f, const LatticeCell& c) {
   double c0 = (1.0 - c.ty) * nodes[(size_t)c.o00 * 8 + f] + c.ty * nodes[(size_t)c.o01 * 8 + f];
   double c1 = (1.0 - c.ty) * nodes[(size_t)c.o10 * 8 + f] + c.ty * nodes[(size_t)c.o11 * 8 + f];
   return (1.0 - c.tx) * c0 + c.tx * c1;
+}
+// test hook (sz_debug_sample_fields): the in-bounds test and the lattice sample of the forcing kernels at given points -- out[12 k ..] = in_bounds,
+// uocn, vocn, hflx, uatm, vatm, the 1-based grid lines west / east / south / north the blend reads, its weights tx, ty
+__global__ void sz_k_debug_sample(State S, int n, const double* x, const double* y, double* out) {
+  const int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1, s = S.Ny + 1;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    double* o = out + (size_t)k * 12;
+    o[0] = point_in_bounds(S, x[k], y[k], per_x, per_y) ? 1.0 : 0.0;
+    const LatticeCell c = lattice_cell(S, x[k], y[k], per_x, per_y);
+    for (int f = 0; f < 5; f++) o[1 + f] = sample_field(S.nodes, f, c);
+    o[6] = (double)(c.o00 / s + 1); o[7] = (double)(c.o10 / s + 1); o[8] = (double)(c.o00 % s + 1); o[9] = (double)(c.o01 % s + 1);
+    o[10] = c.tx; o[11] = c.ty;
+  }
 }
 __global__ void sz_k_interleave_fields(State S) {
   int n = (S.Nx + 1) * (S.Ny + 1);
@@ -2388,7 +2405,7 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
       double sxk = S.sx[o + k], syk = S.sy[o + k];
       double x = (ca * sxk - sa * syk) + cxf;
       double y = (sa * sxk + ca * syk) + cyf;
-      bool inb = (per_x || (S.gx0 <= x && x <= S.gxf)) && (per_y || (S.gy0 <= y && y <= S.gyf));
+      bool inb = point_in_bounds(S, x, y, per_x, per_y);
       if (!inb) continue;
       np++;
       double xc = x - cxf, yc = y - cyf;
@@ -2549,7 +2566,7 @@ __device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, in
       const float2 sp = S.s32[o + k];
       const float px = ca * sp.x - sa * sp.y, py = sa * sp.x + ca * sp.y;      // offset from the centroid
       const double x = cxf + (double)px, y = cyf + (double)py;
-      bool inb = (per_x || (S.gx0 <= x && x <= S.gxf)) && (per_y || (S.gy0 <= y && y <= S.gyf));
+      bool inb = point_in_bounds(S, x, y, per_x, per_y);
       if (!inb) continue;
       np++;
       const float up = uf - xif * py, vp = vf + xif * px;            // (rad * sin / cos of the point's angle are py and px: see the fp64 kernel)

@@ -418,6 +418,14 @@ class World:
                                                  capi.ptr(idx, capi._ip), C.byref(n)))
         return [int(v) + 1 for v in idx[:n.value]]
 
+    def sample_fields(self, x, y):
+        """the forcing kernels' in-bounds test and lattice sample at points (x, y): rows [in_bounds, uocn, vocn, hflx, uatm, vatm, line west, east,
+        south, north (1-based), tx, ty]"""
+        x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+        out = np.zeros((len(x), 12))
+        self._chk(self.L.sz_debug_sample_fields(self.h, len(x), capi.ptr(x), capi.ptr(y), capi.ptr(out)))
+        return out
+
     def warn_counts(self):
         s = self.stats()
         return np.array([s["warn_height"], s["warn_force"], s["warn_vel"], s["warn_xi"]], _I64)

@@ -495,11 +495,11 @@ def update_floe():
 
 
 def coupling_grid():
-    """Grid bookkeeping of the coupling: test_coupling.jl:165-180 (find_center_cell_index), :276-289
-    (center_cell_coords) and :291-460 (floe_to_grid_info!), literal inputs and expected values."""
+    """Grid bookkeeping of the coupling: test_coupling.jl:165-180 (find_center_cell_index), :181-197 (in_bounds), :199-282
+    (find_interp_knots), :276-289 (center_cell_coords) and :291-460 (floe_to_grid_info!), literal inputs and expected values."""
     P, O = "periodic", "open"
     return {
-        "_source": "test/test_physical_processes/test_coupling.jl:165-180,276-460",
+        "_source": "test/test_physical_processes/test_coupling.jl:165-460",
         "grid": {"x0": -10.0, "xf": 10.0, "y0": -8.0, "yf": 8.0, "dx": 2.0, "dy": 4.0},
         "find_center_cell_index": {"x": [-10.5, -10, -10, -6.5, -6, -4, 10, 10.5, 12], "y": [0.0, 6.0, -8.0, 4.5, 0.0, 5.0, -8.0, 0.0, 0.0],
                                    "xidx": [1, 1, 1, 3, 3, 4, 11, 11, 12], "yidx": [3, 5, 1, 4, 3, 4, 1, 3, 3]},
@@ -512,6 +512,27 @@ def coupling_grid():
             {"idx": [11, 6], "ns": O, "ew": P, "rect": [9, 11, 8, 8]},
             {"idx": [11, 6], "ns": P, "ew": O, "rect": [9, 10, 10, 14]},
         ],
+        # in_bounds(x, y, grid, north-south boundary, east-west boundary): test_coupling.jl:181-197 (source coupling.jl:494-597).  Keys name the
+        # (north/south, east/west) kinds of the argument order of the reference's call.
+        "in_bounds": {"x": [-12, -10, -8, -6, 0, 4, 4, 10, 12, 12], "y": [5, -6, 4, 10, -10, 8, -8, -6, 4, 10],
+                      "open_open": [False, True, True, False, False, True, True, True, False, False],
+                      "periodic_open": [False, True, True, True, True, True, True, True, False, False],
+                      "open_periodic": [True, True, True, False, False, True, True, True, True, False],
+                      "periodic_periodic": [True] * 10},
+        # find_interp_knots(point_idx, ncells, glines, L, dd, boundary) -> (knots, knot_idx): test_coupling.jl:199-282 (source coupling.jl:702-797);
+        # glines 0:10:80 (8 cells, L = 80); knot_idx 1-based grid-line numbers -- periodic: line ncells + 1 IS line 1 and is not repeated
+        "find_interp_knots": [
+            {"points": [4], "dd": 2, "periodic": False, "knots": list(range(0, 70, 10)), "idx": list(range(1, 8))},
+            {"points": [4], "dd": 2, "periodic": True, "knots": list(range(0, 70, 10)), "idx": list(range(1, 8))},
+            {"points": [0, 1], "dd": 2, "periodic": False, "knots": list(range(0, 40, 10)), "idx": list(range(1, 5))},
+            {"points": [0, 1], "dd": 2, "periodic": True, "knots": list(range(-40, 40, 10)), "idx": [5, 6, 7, 8, 1, 2, 3, 4]},
+            {"points": [8, 9], "dd": 1, "periodic": False, "knots": list(range(50, 90, 10)), "idx": list(range(6, 10))},
+            {"points": [8, 9], "dd": 1, "periodic": True, "knots": list(range(50, 110, 10)), "idx": [6, 7, 8, 1, 2, 3]},
+            {"points": list(range(1, 9)), "dd": 2, "periodic": False, "knots": list(range(0, 90, 10)), "idx": list(range(1, 10))},
+            {"points": list(range(1, 9)), "dd": 2, "periodic": True, "knots": list(range(-30, 110, 10)), "idx": [6, 7, 8] + list(range(1, 9)) + [1, 2, 3]},
+            {"points": list(range(0, 10)), "dd": 2, "periodic": False, "knots": list(range(0, 90, 10)), "idx": list(range(1, 10))},
+        ],
+        "knots_grid": {"g0": 0.0, "dg": 10.0, "ncells": 8, "L": 80.0},
         # floe_to_grid_info!(floeidx, xidx[i], yidx[i], tx[i], ty[i], grid, ns, ew, scells, two_way_coupling_on)
         "floe_to_grid": [
             {"floeidx": 1, "xidx": [7, 7, 6, 6, 7, 7], "yidx": [4, 4, 3, 3, 4, 4], "tx": 1.0, "ty": 2.0, "ns": O, "ew": O,

@@ -125,6 +125,75 @@ def test_forcings(golden, k):
     cases.check_forcing(cases.run_forcing(mk, F, case), case)
 
 
+@pytest.mark.parametrize("ns,ew", [("open", "open"), ("periodic", "open"), ("open", "periodic"), ("periodic", "periodic")])
+def test_in_bounds_and_lattice_sample(golden, ns, ew):
+    """The forcing kernels' own in-bounds test and lattice sample (sz_debug_sample_fields) against the reference's vectors: the four in_bounds
+    truth tables (test_coupling.jl:181-197; coupling.jl:494-597), and find_interp_knots (test_coupling.jl:199-282; coupling.jl:702-797) -- which
+    grid lines a bilinear blend reads at a point, beyond each edge too: in a periodic direction line ncells + 1 is line 1 and the window wraps;
+    in a non-periodic one it ends at the grid's edge.  A lattice with a distinct value per line makes the lines visible in the sampled value
+    (held to the oracle's sample, 1e-12)."""
+    from oracle import orc as O
+    G = golden["coupling_grid"]; g = G["grid"]; B = G["in_bounds"]
+    kind = {"open": 0, "periodic": 1}
+    kinds = [kind[ns], kind[ns], kind[ew], kind[ew]]
+    Nx = int(round((g["xf"] - g["x0"]) / g["dx"])); Ny = int(round((g["yf"] - g["y0"]) / g["dy"]))
+    ix, iy = np.meshgrid(np.arange(Nx + 1, dtype=float), np.arange(Ny + 1, dtype=float), indexing="ij")
+    uo, vo = ix.copy(), iy.copy()                      # uocn: the x line's number - 1, vocn: the y line's
+    if ew == "periodic":
+        uo[Nx, :] = uo[0, :]                            # (a periodic ocean: the last line is the first)
+    if ns == "periodic":
+        vo[:, Ny] = vo[:, 0]
+    hf = 100.0 * uo + vo; ua = -uo; va = 0.5 * vo
+    hw, ow = mk(), omk()
+    for w in (hw, ow):
+        w.set_domain(kinds, g["x0"], g["xf"], g["y0"], g["yf"])
+        w.set_grid_fields(Nx, Ny, g["x0"], g["xf"], g["y0"], g["yf"], uo, vo, hf, ua, va)
+    per_x, per_y = ew == "periodic", ns == "periodic"
+    # in_bounds: the reference's table for this pair of kinds
+    got = hw.sample_fields(B["x"], B["y"])
+    assert [bool(v) for v in got[:, 0]] == B[f"{ns}_{ew}"]
+    # find_interp_knots through the sample: points beyond each edge (they are only sampled where in_bounds admits them), on lines, inside cells
+    xs = np.array([-13.0, -10.5, -10.0, -9.5, -7.0, 0.0, 3.25, 9.5, 10.0, 10.5, 13.0]); ys = np.array([-11.0, -8.0, -7.0, -1.0, 3.0, 7.5, 8.0, 9.0, 13.0])
+    X, Y = [a.ravel() for a in np.meshgrid(xs, ys, indexing="ij")]
+    got = hw.sample_fields(X, Y)
+    n_checked = 0
+    for k, (x, y) in enumerate(zip(X, Y)):
+        assert bool(got[k, 0]) == ow.in_bounds(x, y, per_x, per_y)
+        if not got[k, 0]:
+            continue
+        lines, (tx, ty) = ow.sample_lines(x, y, per_x, per_y)
+        want = ow.sample_fields(x, y, per_x, per_y)
+        assert np.allclose(got[k, 1:6], want, rtol=0, atol=1e-12 * 1e3), (x, y, got[k], want)
+        # the lines, up to the one freedom of a point ON a grid line (either neighbouring cell gives the same value)
+        on_x, on_y = abs((x - g["x0"]) / g["dx"] - round((x - g["x0"]) / g["dx"])) < 1e-12, abs((y - g["y0"]) / g["dy"] - round((y - g["y0"]) / g["dy"])) < 1e-12
+        if not on_x:
+            assert [int(got[k, 6]), int(got[k, 7])] == lines[:2] and abs(got[k, 10] - tx) < 1e-12, (x, y, got[k], lines)
+        if not on_y:
+            assert [int(got[k, 8]), int(got[k, 9])] == lines[2:] and abs(got[k, 11] - ty) < 1e-12, (x, y, got[k], lines)
+        n_checked += 1
+    assert n_checked >= (len(X) if per_x and per_y else 20)
+    # and the reference's own knot windows (glines 0:10:80): the two lines read inside each knot interval are its knot_idx
+    K = G["knots_grid"]
+    for c in G["find_interp_knots"]:
+        if c["periodic"] != per_x:
+            continue
+        w = mk()
+        w.set_domain(kinds, K["g0"], K["g0"] + K["L"], 0.0, 40.0)
+        n = K["ncells"]
+        line = np.arange(n + 1, dtype=float)[:, None] * np.ones((1, 5))
+        if per_x:
+            line[n] = line[0]
+        w.set_grid_fields(n, 4, K["g0"], K["g0"] + K["L"], 0.0, 40.0, line, 0.0, 0.0, 0.0, 0.0)
+        px = [a + t * (b - a) for a, b in zip(c["knots"][:-1], c["knots"][1:]) for t in (0.25, 0.5, 0.875)]
+        r = w.sample_fields(px, [15.0] * len(px))
+        q = 0
+        for (a, b, ia, ib) in zip(c["knots"][:-1], c["knots"][1:], c["idx"][:-1], c["idx"][1:]):
+            for t in (0.25, 0.5, 0.875):
+                assert r[q, 0] == 1.0 and (int(r[q, 6]), int(r[q, 7])) == (ia, ib) and abs(r[q, 10] - t) < 1e-12, (c, px[q], r[q])
+                assert abs(r[q, 1] - ((1 - t) * (ia - 1) + t * (ib - 1 if ib != 1 or not per_x else 0))) < 1e-12
+                q += 1
+
+
 # ---------------------------------------------------------------- seeded random fields vs the oracle
 def _pair(cfg):
     from subzero_jl_amd import fields
@@ -456,6 +525,37 @@ def test_collision_call_100k_pairs_bit_exact():
     hw.timestep_collisions(n, cfg["dt"]); ow.timestep_collisions(n, cfg["dt"])
     res = parity.compare_worlds(hw, ow, rtol=1e-10, fields=["coll_fx", "coll_fy", "coll_trq", "overarea"])
     assert res["n_pairs"] > n
+
+
+def test_resident_step_100k_against_the_oracle():
+    """BASELINE configs[2] at full size through the RESIDENT path: two whole timesteps (ghosts, collisions, forcings of the converge / diverge
+    ocean, update) of 100 000 floes in one sz_step batch against the oracle -- pair list of the last step equal, interaction rows and totals
+    1e-10 per element, state 1e-9, guard counters equal.  (The collision call alone at this size: the test above.)"""
+    cfg = _bench_cfg("configs2")
+    hw, ow = _pair(cfg); ow.set_threads(_cores())
+    steps = 2
+    assert hw.run(steps, 0, cfg["dt"], coupling_dt=1) == steps
+    for t in range(steps):
+        ow.timestep_sim(t, cfg["dt"], coupling_dt=1)
+    res = parity.compare_worlds(hw, ow, rtol=1e-9)
+    assert res["n_pairs"] > cfg["n_floes"]
+    assert np.array_equal(hw.warn_counts(), ow.warn_counts())
+    assert np.max(np.abs(ow.get("fxOA"))) > 0                      # the forcings really acted
+
+
+def test_collision_call_configs4_sparse_100k_fp64():
+    """BASELINE configs[4]'s field -- 100 000 floes at 25 % concentration, the broad-phase compaction stress -- in fp64: add_ghosts! +
+    timestep_collisions! against the oracle's O(M^2) pair loop: ghosts equal, overlap-pair indices bit-exact, rows and totals 1e-10.  (The
+    mixed-precision run of this field is held to this fp64 path: test_mixed_precision_configs4_sparse_100k.)"""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=100000, seed=12347, concentration=0.25)
+    n = cfg["n_floes"]
+    hw, ow = _pair(cfg); ow.set_threads(_cores())
+    hw.add_ghosts(); ow.add_ghosts()
+    assert hw.M == ow.M and hw.ghosts() == ow.ghosts()
+    hw.timestep_collisions(n, cfg["dt"]); ow.timestep_collisions(n, cfg["dt"])
+    res = parity.compare_worlds(hw, ow, rtol=1e-10, fields=["coll_fx", "coll_fy", "coll_trq", "overarea"])
+    assert res["n_pairs"] > 1000
 
 
 def test_reupload_into_the_same_context():

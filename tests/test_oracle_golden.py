@@ -131,6 +131,54 @@ def test_find_center_cell_index(golden):
     assert O.lib().orc_shift_cell_idx(11, 11, 0) == 11
 
 
+_KIND = {"open": 0, "periodic": 1}
+
+
+def _kinds(ns, ew):
+    # boundary kinds in the engine's order north, south, east, west (0 open, 1 periodic)
+    return [_KIND[ns], _KIND[ns], _KIND[ew], _KIND[ew]]
+
+
+def test_in_bounds(golden):
+    """in_bounds (coupling.jl:494-597), the reference's four truth tables (test_coupling.jl:181-197): the predicate the oracle's coupling
+    evaluates per sub-floe point"""
+    G = golden["coupling_grid"]; B = G["in_bounds"]
+    for key in ("open_open", "periodic_open", "open_periodic", "periodic_periodic"):
+        ns, ew = key.split("_")
+        w, _, _ = _grid_world(G, ns, ew)
+        got = [w.in_bounds(x, y, ew == "periodic", ns == "periodic") for x, y in zip(B["x"], B["y"])]
+        assert got == B[key], (key, got)
+
+
+def test_find_interp_knots(golden):
+    """find_interp_knots (coupling.jl:702-797), the reference's nine cases (test_coupling.jl:199-282), and the tie to the lattice sample the
+    oracle's coupling really uses: inside a knot window the two grid lines sample() blends at a point are the knot_idx of the two knots
+    that bracket it -- line ncells + 1 IS line 1 in a periodic direction"""
+    from oracle import orc as O
+    G = golden["coupling_grid"]; K = G["knots_grid"]
+    for c in G["find_interp_knots"]:
+        knots, idx = O.find_interp_knots(c["points"], K["ncells"], K["g0"], K["dg"], K["L"], c["dd"], c["periodic"])
+        assert knots == [float(v) for v in c["knots"]] and idx == c["idx"], (c, knots, idx)
+    # sample(): a lattice over the knots' grid (8 cells of 10 m in x, one direction at a time); every point strictly inside a knot interval
+    for c in G["find_interp_knots"]:
+        w = O.World()
+        per = c["periodic"]
+        w.set_domain([0, 0, 1 if per else 0, 1 if per else 0], K["g0"], K["g0"] + K["L"], 0.0, 40.0)
+        Nx = K["ncells"]
+        line = np.arange(Nx + 1, dtype=float)[:, None] * np.ones((1, 5))            # uocn = the x grid line's number - 1
+        if per:
+            line[Nx] = line[0]                                                        # a periodic ocean: the last line is the first
+        w.set_grid_fields(Nx, 4, K["g0"], K["g0"] + K["L"], 0.0, 40.0, line, 0.0, 0.0, 0.0, 0.0)
+        for a, b, ia, ib in zip(c["knots"][:-1], c["knots"][1:], c["idx"][:-1], c["idx"][1:]):
+            for t in (0.25, 0.5, 0.875):
+                x = a + t * (b - a)
+                lines, (tx, ty) = w.sample_lines(x, 15.0, per, False)
+                want = (ia, ib if not (per and ib == Nx + 1) else 1)
+                assert (lines[0], lines[1]) == want and abs(tx - t) < 1e-12, (c, x, lines, tx)
+                v = w.sample_fields(x, 15.0, per, False)[0]
+                assert abs(v - ((1 - t) * (ia - 1) + t * (ib - 1))) < 1e-12 or (per and ib == 1 and abs(v - (1 - t) * (ia - 1)) < 1e-12), (c, x, v)
+
+
 def test_two_way_coupling_analytic():
     cases.check_two_way_analytic(*cases.run_two_way_analytic(mk))
 

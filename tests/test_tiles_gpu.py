@@ -106,6 +106,68 @@ def _run_worker_two_way(*a):
     _guard(_worker_two_way)(*a)
 
 
+def _cfg2():
+    from subzero_jl_amd import fields
+    return fields.make_config(n_floes=100000, seed=12346, ocean="converge_diverge")          # bench.py's configs[2] field
+
+
+def _worker_cfg2(rank, world, port, steps, q):
+    import torch.distributed as dist
+    from subzero_jl_amd import tiles
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    try:
+        cfg = _cfg2()
+        tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True, backend="library-host", rebox_every=50)
+        tw.run(steps, 0, cfg["dt"], coupling_dt=1)
+        q.put((rank, tw.gidx, {f: tw.owned(f) for f in FIELDS}, tw.n_halo_last, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_worker_cfg2(*a):
+    _guard(_worker_cfg2)(*a)
+
+
+def test_configs2_100k_in_four_tiles_equals_the_single_context():
+    """BASELINE configs[2] at the size the multi-GPU metric is quoted on: 100 000 floes, converge / diverge ocean, cut into 2 x 2 tiles (four
+    ranks sharing the box's GPU, the library's exchange over the host channel), three coupled timesteps -- every owned column of every
+    rank bit-equal to the single context's run of the same field."""
+    import torch.multiprocessing as mp
+    import subzero_jl_amd
+    from subzero_jl_amd import fields
+    world, steps = 4, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_run_worker_cfg2, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = []
+        for _ in range(world):
+            r = q.get(timeout=600)
+            assert r[0] != "error", f"rank {r[1]} failed:\n{r[2]}"
+            res.append(r)
+        for p in procs:
+            p.join(120)
+        assert all(p.exitcode == 0 for p in procs)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    cfg = _cfg2()
+    hw = fields.build_world(subzero_jl_amd.World(0), cfg)
+    hw.run(steps, 0, cfg["dt"], coupling_dt=1, stop_on_tags=False)
+    seen = np.zeros(cfg["n_floes"], bool)
+    for rank, gidx, out, nhalo, _ in res:
+        assert nhalo > 0 and 15000 < len(gidx) < 35000
+        seen[gidx] = True
+        for f in FIELDS:
+            ref = hw.get(f)[gidx]
+            assert np.array_equal(out[f], ref), (rank, f, np.max(np.abs(out[f] - ref)))
+    assert seen.all()
+
+
 @pytest.mark.parametrize("world,n,seed,steps,repartition,fast,backend", [
     (2, 600, 31, 4, False, False, "torch"), (2, 600, 33, 6, True, False, "torch"), (4, 1000, 35, 4, False, False, "torch"),
     (2, 500, 77, 30, False, True, "torch"),
