@@ -15,6 +15,7 @@
 
 #include "../../include/subzero_hip.h"
 #include "sz_kernels.hpp"
+#include "sz_pipeline.hpp"
 #include "sz_twoway.hpp"
 #include "sz_output.hpp"
 #include "sz_migrate.hpp"
@@ -149,6 +150,14 @@ struct sz_ctx {
   // bit 1: the batch's last step); reduce_mode: 0 sz_k_inter_fill does everything inside the step (process mode), 1 it only assembles rows inside
   // the step, 2 it is left out of the steps and runs once behind the batch (the reduce-free steps)
   long long* facc_buf = nullptr; int acc_mode = 0, reduce_mode = 0;
+  // pipelined resident steps (sz_pipeline.hpp): the second set of what is double-buffered by step parity.  pb[0] is what the upload carved
+  // (State::vxy, crec_buf, the cell lists, the work list, the ghost links), pb[1] its twin; gpar: the set that holds the context's state.
+  struct PipeBuf { double2 *vxy = nullptr, *crec = nullptr; int *cell_cnt = nullptr, *cell_slots = nullptr, *cell_ovf = nullptr, *cell_items = nullptr;
+                   int4* work = nullptr; int* wq = nullptr; int *gh = nullptr, *ngh = nullptr; } pb[2];
+  int gpar = 0;
+  bool no_pipeline = false;         // SZ_PIPELINE=0: the three-launch steps (A/B)
+  int pipe_min_steps = 4;           // batches shorter than this take the three-launch steps (a pipelined batch has a prologue and an epilogue)
+  int last_pipelined = 0;           // the last sz_step batch ran pipelined (sz_debug_pipelined)
   bool no_reduce_free = false;      // SZ_REDUCE_FREE=0: keep the (rows-only) reduce launch inside every step (A/B)
   bool maybe_tagged = false;        // a parent may be non-active on the device (an upload said so, a batch ended on a tag, a process-mode call ran):
                                     // the next batch then runs its first step on its own (see sz_step)
@@ -293,10 +302,13 @@ int carve_lists(sz_ctx* c) {
 #define DL(field, n) if ((rc = dalloc(c, &S.field, (size_t)(n), c->list_allocs))) return rc
   DL(nb_out, (size_t)S.capM * S.maxnb); DL(nb_in, (size_t)S.capM * S.maxnb);
   DL(work, 2 * ((size_t)S.capPairs + NSEG)); DL(wq, NSEG * 32); DL(pair_i, S.capPairs); DL(pair_j, S.capPairs);
+  if ((rc = dalloc(c, &c->pb[1].work, 2 * ((size_t)S.capPairs + NSEG), c->list_allocs)) || (rc = dalloc(c, &c->pb[1].wq, (size_t)NSEG * 32, c->list_allocs))) return rc;
+  c->pb[0].work = S.work; c->pb[0].wq = S.wq;
   DL(it_rows, ((size_t)S.capPairs + S.capElem) * ROWS_PER_ITEM * 5); DL(it_info, (size_t)S.capM * S.maxnb + S.capElem + 1);
 #undef DL
   trim_pool(c->list_allocs);
   HIPCHK(c, hipMemsetAsync(S.wq, 0, NSEG * 32 * sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->pb[1].wq, 0, NSEG * 32 * sizeof(int), c->stream));
   return SZ_OK;
 }
 // The reference's lists grow as needed (collisions.jl:290-296: vcat; the Dict of the pair loop).  A call / step that outgrew a list has
@@ -562,11 +574,11 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = 
     }
     const int nbn = grid_for(capItems, TPB / G, grid);
     const int nbf = frc ? grid_for(S.capM, TPB / FRC_PLAIN, 32768) : 0;
-    if (frc == 1) hipLaunchKernelGGL((sz_k_narrow<G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 1>), dim3(nbn + nbf), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, nbf);
-    else if (frc == 2) hipLaunchKernelGGL((sz_k_narrow<G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 2>), dim3(nbn + nbf), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, nbf);
-    else hipLaunchKernelGGL(kern, dim3(nbn), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0);
+    if (frc == 1) hipLaunchKernelGGL((sz_k_narrow<G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 1>), dim3(nbn + nbf), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, nbf, PipeAlt{}, 0, 0);
+    else if (frc == 2) hipLaunchKernelGGL((sz_k_narrow<G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 2>), dim3(nbn + nbf), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, nbf, PipeAlt{}, 0, 0);
+    else hipLaunchKernelGGL(kern, dim3(nbn), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0, PipeAlt{}, 0, 0);
     if (c->dbg & 8)       // timing experiment: the same launch again (same results) -- how much of a launch is a cold instruction cache?
-      hipLaunchKernelGGL(kern, dim3(nbn), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0);
+      hipLaunchKernelGGL(kern, dim3(nbn), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0, PipeAlt{}, 0, 0);
     t.end();
   }
   {
@@ -576,9 +588,9 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = 
     if (parts == 1 && !larger) { t.end(); return; }
     if (larger)
       hipLaunchKernelGGL((sz_k_narrow<16, NARROW_CAP1, 16, 80, 6, 64, NARROW_CAP0, 1>), dim3(grid_for(capItems, 4, 2048)), dim3(64), 0,
-                         c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0);
+                         c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0, PipeAlt{}, 0, 0);
     hipLaunchKernelGGL((sz_k_narrow<64, NARROW_CAP2, NARROW_KC2, NARROW_RC2, 16, 64, NARROW_CAP1, 2>), dim3(grid_for(capItems, 1, larger ? 2048 : 256)), dim3(64), 0,
-                       c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0);
+                       c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0, PipeAlt{}, 0, 0);
     t.end();
   }
 }
@@ -625,12 +637,13 @@ void collisions(sz_ctx* c, int n_init, int dt, bool commit_ghosts = false, bool 
 // hflx_factor, which nothing but the integrator reads: inside a step they run on a second stream
 // BESIDE the ghost / broad / narrow / reduce kernels (all of them latency-bound, the chip is far
 // from full) and join before the integrator.
-void stage_forcing_fork(sz_ctx* c) {
+void stage_forcing_fork(sz_ctx* c, const State* Sp = nullptr) {
+  const State& S = Sp ? *Sp : c->S;
   (void)hipEventRecord(c->ev_fork, c->stream);
   (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
   Timed t(c, SZ_K_FORCING, c->stream2);
-  if (c->precision == 1) hipLaunchKernelGGL(sz_k_forcing_mixed, dim3(grid_for(c->S.capM, 256 / FRC_PLAIN, 8192)), dim3(256), 0, c->stream2, c->S, c->P);
-  else hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_PLAIN, 8192)), dim3(256), 0, c->stream2, c->S, c->P, 0);
+  if (c->precision == 1) hipLaunchKernelGGL(sz_k_forcing_mixed, dim3(grid_for(c->S.capM, 256 / FRC_PLAIN, 8192)), dim3(256), 0, c->stream2, S, c->P);
+  else hipLaunchKernelGGL(sz_k_forcing<false>, dim3(grid_for(c->S.capM, 256 / FRC_PLAIN, 8192)), dim3(256), 0, c->stream2, S, c->P, 0);
   t.end();
   (void)hipEventRecord(c->ev_join, c->stream2);
 }
@@ -849,6 +862,8 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_LEAN_NARROW")) c->no_lean_narrow = atoi(e) == 0;
   if (const char* e = getenv("SZ_CREC")) c->no_crec = atoi(e) == 0;
   if (const char* e = getenv("SZ_REDUCE_FREE")) c->no_reduce_free = atoi(e) == 0;
+  if (const char* e = getenv("SZ_PIPELINE")) c->no_pipeline = atoi(e) == 0;
+  if (const char* e = getenv("SZ_PIPE_MIN_STEPS")) c->pipe_min_steps = std::max(2, atoi(e));
   if (const char* e = getenv("SZ_TILE_FORCING_TAIL")) c->tile_forcing_in_tail = atoi(e) != 0;
   if (const char* e = getenv("SZ_GHOST_INLINE")) c->ghost_inline = atoi(e) != 0;
   if (const char* e = getenv("SZ_TILE_INLINE")) c->tile_inline_off = atoi(e) == 0;
@@ -1055,7 +1070,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
     if ((rc = dalloc(c, dcols[k], S.capM, c->allocs))) return rc;
     if (hcols[k]) H2D(*dcols[k], hcols[k], M, double);
   }
-  DA(sa, 4 * S.capM); DA(si, 4 * S.capM); DA(strain, 4 * S.capM); DA(mot, 4 * S.capM); DA(trig, 2 * S.capM);
+  DA(sa, 4 * S.capM); DA(si, 4 * S.capM); DA(strain, 4 * S.capM); DA(mot, 4 * S.capM); DA(mot2, 2 * S.capM); DA(trig, 2 * S.capM);
   if (f->stress_accum) H2D(S.sa, f->stress_accum, 4 * M, double);
   if (f->stress_instant) H2D(S.si, f->stress_instant, 4 * M, double);
   if (f->strain) H2D(S.strain, f->strain, 4 * M, double);
@@ -1096,12 +1111,24 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   DA(lb_agg, S.capM / 128 + 8); DA(lb_inc, S.capM / 128 + 8); DA(lb_flag, S.capM / 128 + 8); c->scan_epoch = 0;      // (tiles of 128 .. SCAN_B elements)
   DA(gflag, S.capM + 1); DA(gvscan, S.capM + 2); DA(gcand, (size_t)2 * S.capM); DA(galloc, 32); DA(gkeys, (size_t)2 * S.capM); DA(fam, S.capM);
   DA(crec, (size_t)8 * S.capM); c->crec_buf = S.crec; S.crec = nullptr;
+  {          // the twin set of the pipelined steps' double buffers (sz_pipeline.hpp)
+    sz_ctx::PipeBuf& B = c->pb[1];
+    if ((rc = dalloc(c, &B.vxy, (size_t)S.capV, c->allocs)) || (rc = dalloc(c, &B.crec, (size_t)8 * S.capM, c->allocs)) ||
+        (rc = dalloc(c, &B.gh, (size_t)MAX_GHOSTS * S.capM, c->allocs)) || (rc = dalloc(c, &B.ngh, (size_t)S.capM, c->allocs))) return rc;
+    HIPCHK(c, hipMemsetAsync(B.gh, 0xff, (size_t)MAX_GHOSTS * S.capM * sizeof(int), c->stream));
+    c->gpar = 0;
+  }
   DA(facc, (size_t)FX_WORDS * S.capM); c->facc_buf = S.facc; S.facc = nullptr;
   c->maybe_tagged = false;
   if (f->status) for (int i = 0; i < N; i++) if (f->status[i] != SZ_ACTIVE) { c->maybe_tagged = true; break; }
   for (int k = 0; k < 4; k++) if ((rc = dalloc(c, &c->frc_alt[k], (size_t)S.capM, c->allocs))) return rc;
   DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1); DA(cell_ovf, S.capCells + 1); DA(cell_slots, (size_t)S.capCells * CELL_K + 8);
   DA(cell_items, S.capM);
+  {
+    sz_ctx::PipeBuf& B = c->pb[1];
+    if ((rc = dalloc(c, &B.cell_cnt, (size_t)S.capCells + 1, c->allocs)) || (rc = dalloc(c, &B.cell_ovf, (size_t)S.capCells + 1, c->allocs)) ||
+        (rc = dalloc(c, &B.cell_slots, (size_t)S.capCells * CELL_K + 8, c->allocs)) || (rc = dalloc(c, &B.cell_items, (size_t)S.capM, c->allocs))) return rc;
+  }
   DA(n_out, S.capM + 1); DA(n_in, S.capM + 1); DA(over_stamp, S.capM + 1); DA(over_base, S.capM + 1);
   DA(out_off, S.capM + 2);
   DA(el_off, S.capM + 2); DA(el_floe, S.capElem); DA(el_elem, S.capElem);
@@ -1123,6 +1150,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   // sz_upload_interactions or a collision call provides them again
   if ((rc = carve_interactions(c))) return rc;
   DA(blk, std::max(S.capCells, std::max(S.capM, 1024)) / SCAN_B + 1024);
+  { sz_ctx::PipeBuf& B = c->pb[0]; B.vxy = S.vxy; B.crec = c->crec_buf; B.cell_cnt = S.cell_cnt; B.cell_slots = S.cell_slots; B.cell_ovf = S.cell_ovf; B.cell_items = S.cell_items; B.gh = S.gh; B.ngh = S.ngh; }
   DA(tagA, S.capM + 1);
   if (!tag0.empty()) { H2D(S.tagA, tag0.data(), M, int); HIPCHK(c, hipStreamSynchronize(c->stream)); }
   DA(stamps, 512 + 8 * 8000);
@@ -1645,6 +1673,260 @@ int sz_calc_strain(sz_ctx* c) {
   return sync_and_check(c);
 }
 
+namespace {
+// ---------------------------------------------------------------- pipelined batches (sz_pipeline.hpp)
+// the State of step parity q: everything that is double-buffered points at set q; rows of the step's makers at region q
+State pipe_state(sz_ctx* c, int q) {
+  State S = c->S;
+  const sz_ctx::PipeBuf& B = c->pb[q];
+  S.vxy = B.vxy; S.crec = B.crec; S.cell_cnt = B.cell_cnt; S.cell_slots = B.cell_slots; S.cell_ovf = B.cell_ovf; S.cell_items = B.cell_items;
+  S.work = B.work; S.wq = B.wq; S.gh = B.gh; S.ngh = B.ngh;
+  // rows of a step's makers: set 0 straight behind the parents (as everywhere else), set 1 from a multiple of 16 half way through the spare rows
+  const int nr1 = (c->hostN + (S.capM - c->hostN) / 2 + 15) & ~15;
+  S.goff = q ? nr1 - c->hostN : 0; S.gcap = q ? S.capM - nr1 : nr1 - c->hostN; S.gslot = q;
+  return S;
+}
+PipeAlt pipe_alt(sz_ctx* c, int q, int make_ghosts) {
+  const State T = pipe_state(c, q);
+  PipeAlt A;
+  A.crec = T.crec; A.vxy = T.vxy; A.cell_cnt = T.cell_cnt; A.cell_slots = T.cell_slots; A.cell_ovf = T.cell_ovf; A.cell_items = T.cell_items;
+  A.work = T.work; A.wq = T.wq; A.gh = T.gh; A.ngh = T.ngh; A.goff = T.goff; A.gslot = T.gslot; A.make_ghosts = make_ghosts;
+  return A;
+}
+// make set q the context's own (c->S, crec_buf): where the state lies after a pipelined batch
+void pipe_adopt(sz_ctx* c, int q) {
+  const State T = pipe_state(c, q);
+  State& S = c->S;
+  S.vxy = T.vxy; S.cell_cnt = T.cell_cnt; S.cell_slots = T.cell_slots; S.cell_ovf = T.cell_ovf; S.cell_items = T.cell_items;
+  S.work = T.work; S.wq = T.wq; S.gh = T.gh; S.ngh = T.ngh;
+  c->crec_buf = T.crec; c->gpar = q;
+}
+bool pipeline_eligible(const sz_ctx* c, int nsteps, bool coll, bool sg, bool gi, bool periodic, bool cr, bool rfree, int flags) {
+  return rfree && !c->no_pipeline && coll && sg && (gi || !periodic) && cr && nsteps >= c->pipe_min_steps && c->precision == 0 && !c->two_way &&
+         !c->S.any_domain_work && c->S.maxnb <= MAXNB && !larger_rings(c) && c->pb[1].vxy && c->pb[1].work && !c->pmask &&
+         (c->S.capM - c->hostN) / 2 > 64 && !(c->dbg & 8) && (flags & SZ_COLLISIONS_ON);
+}
+
+// A batch of pipelined steps: L1(s) = narrow(s) | GEO(s) | forcings(s), L2(s) = VEL(s) | search(s + 1).  Same contract as the loop of sz_step
+// it replaces: h = the counter block after the batch, *done = the steps that ran; the context's state is complete when it returns (rows of
+// the last step assembled, strain evaluated, ghosts detached).
+int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling_dt, int flags, bool periodic, bool gi, int* h, int* done_out) {
+  State& S0 = c->S;
+  const int N = c->hostN;
+  const bool user_stop = !(flags & SZ_NO_STOP);
+  const bool fam = N <= 40000 && periodic;
+  const int q0 = c->gpar;
+  auto par = [&](int s) { return (q0 + s) & 1; };
+  S0.stop_on_tags = user_stop ? 1 : 0; S0.restart_on_tags = user_stop ? 0 : 1;
+  S0.ginline = gi ? 1 : 0; S0.famrec = gi ? 1 : 0; S0.pipe = 0;
+  S0.facc = c->facc_buf; S0.kexp = force_scale_exp(c);
+  bool lean = !c->retry_seen && !c->no_lean_narrow;
+  auto leave = [&](int rc) { S0.retry_stop = 0; S0.ginline = 0; S0.famrec = 0; S0.step = 0; S0.crec = nullptr; S0.facc = nullptr; S0.goff = 0; S0.gcap = 0; S0.pipe = 0; S0.restart_on_tags = 0; c->acc_mode = 0; c->reduce_mode = 0; return rc; };
+  HIPCHK(c, hipMemsetAsync(c->facc_buf, 0, (size_t)FX_WORDS * S0.capM * sizeof(long long), c->stream));
+  HIPCHK(c, hipMemsetAsync(S0.cnt + C_FRCSTOP, 0, sizeof(int), c->stream));
+  const int callid0 = c->callid; c->callid += nsteps;
+  // ---- the prologue of a (sub-)batch that starts at step s: cells, records, ghosts and the neighbour search of that step, from the floes as they lie
+  auto prologue = [&](int s) -> int {
+    const int q = par(s);
+    pipe_adopt(c, q);                                   // (the geometry of step s is in set q: the context's own from here on)
+    S0.step = 0; S0.goff = 0; S0.gcap = 0;
+    c->grid_live = false; use_static_grid(c);           // cells[q] <- the parents
+    const sz_ctx::PipeBuf& O = c->pb[1 - q];
+    HIPCHK(c, hipMemsetAsync(O.cell_cnt, 0, ((size_t)S0.capCells + 1) * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(O.cell_ovf, 0, ((size_t)S0.capCells + 1) * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pb[0].wq, 0, NSEG * 32 * sizeof(int), c->stream)); HIPCHK(c, hipMemsetAsync(c->pb[1].wq, 0, NSEG * 32 * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(O.ngh, 0, (size_t)S0.capM * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(S0.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
+    // the records of both sets from the columns (the static quads of the twin; its geometry quads are GEO's)
+    for (int b = 0; b < 2; b++) { State T = pipe_state(c, b); T.step = 0; hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(N, 256)), dim3(256), 0, c->stream, T, N); }
+    State T = pipe_state(c, q); T.step = s + 1; T.callid = callid0 + s + 1; T.retry_stop = lean ? 1 : 0;
+    if (gi) hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(S0.capM, 256)), dim3(256), 0, c->stream, T, q, N);
+    const dim3 gr(grid_for(S0.capM, NB_TPB / NB_G, 8192)), bl(NB_TPB);
+    if (fam) hipLaunchKernelGGL((sz_k_neighbors<true, MAXNB, true>), gr, bl, 0, c->stream, T);
+    else hipLaunchKernelGGL((sz_k_neighbors<false, MAXNB, true>), gr, bl, 0, c->stream, T);
+    return SZ_OK;
+  };
+  auto coupling_at = [&](int s) { return (flags & SZ_COUPLING_ON) && coupling_dt > 0 && ((tstep0 + s) % coupling_dt) == 0; };
+  // grid of the narrow launch (as stage_narrow)
+  constexpr int TPB = 64;
+  if (c->narrow_grid0 == 0) {
+    int per_cu = 0, cus = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sz_k_narrow<NARROW_G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 0>, TPB, 0);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    c->narrow_grid0 = per_cu > 0 && cus > 0 ? per_cu * cus : 2048;
+    if (const char* e = getenv("SZ_NARROW_GRID")) { int v = atoi(e); if (v > 0) c->narrow_grid0 = v; }
+  }
+  const long long capItems = (long long)S0.capPairs + S0.capElem;
+  const int nbn = grid_for(capItems, TPB / NARROW_G, c->narrow_grid0), nbg = grid_for(N, TPB, 1 << 20);
+  const int queue = c->no_queue ? 0 : 1;
+  auto launch_L1 = [&](int s, bool make_ghosts) {
+    State T = pipe_state(c, par(s)); T.step = s + 1; T.callid = callid0 + s + 1; T.retry_stop = lean ? 1 : 0;
+    const PipeAlt A = pipe_alt(c, par(s + 1), make_ghosts ? 1 : 0);
+    const bool coupling = coupling_at(s);
+    const bool overlap = coupling && (c->overlap_forcing >= 0 ? c->overlap_forcing != 0 : N > 65536);
+    if (overlap) stage_forcing_fork(c, &T);
+    const int nbf = coupling && !overlap ? grid_for(S0.capM, TPB / FRC_PLAIN, 32768) : 0;
+    if (coupling) c->forcing_where = overlap ? 0 : 2;
+    if (nbf) hipLaunchKernelGGL((sz_k_narrow<NARROW_G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 1, 1>), dim3(nbn + nbg + nbf), dim3(TPB), 0, c->stream,
+                                T, c->P, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, c->dbg, queue, nbf, A, nbg, N);
+    else hipLaunchKernelGGL((sz_k_narrow<NARROW_G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 0, 1>), dim3(nbn + nbg), dim3(TPB), 0, c->stream,
+                            T, c->P, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, c->dbg, queue, 0, A, nbg, N);
+    if (!lean) {          // the largest variant takes what the small one hands on (see stage_narrow)
+      hipLaunchKernelGGL((sz_k_narrow<64, NARROW_CAP2, NARROW_KC2, NARROW_RC2, 16, 64, NARROW_CAP1, 2>), dim3(grid_for(capItems, 1, 256)), dim3(64), 0,
+                         c->stream, T, c->P, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, c->dbg, queue, 0, PipeAlt{}, 0, 0);
+    }
+    return overlap;
+  };
+  auto launch_L2 = [&](int s, bool with_search, bool host_last, bool joined) {
+    if (joined) stage_forcing_join(c);
+    State T = pipe_state(c, par(s + 1)); T.step = s + 2; T.callid = callid0 + s + 2; T.retry_stop = lean ? 1 : 0;
+    const PipeAlt A = pipe_alt(c, par(s), 0);
+    const int nbv = grid_for(N, NB_TPB, 1 << 20), nbs = with_search ? grid_for(S0.capM, NB_TPB / NB_G, 8192) : 0;
+    const int am = 1 | 4 | (host_last ? 2 : 0);
+    if (fam) hipLaunchKernelGGL((sz_k_vel_search<true>), dim3(nbv + nbs), dim3(NB_TPB), 0, c->stream, T, c->P, A, dt, coupling_at(s) ? 1 : 0, nbv, N, am);
+    else hipLaunchKernelGGL((sz_k_vel_search<false>), dim3(nbv + nbs), dim3(NB_TPB), 0, c->stream, T, c->P, A, dt, coupling_at(s) ? 1 : 0, nbv, N, am);
+  };
+  // what lies behind the last step `last` (0-based) of the batch: parents un-swapped after a tag stop, strain, the step's rows, rows home, ghosts off
+  auto epilogue = [&](int last, bool after_device_stop) -> int {
+    const int q = par(last + 1);                          // the geometry of the state that is handed back
+    pipe_adopt(c, q);
+    if (after_device_stop) {
+      State T = pipe_state(c, q); T.step = 0;
+      hipLaunchKernelGGL(sz_k_unswap, dim3(grid_for(N, 128)), dim3(128), 0, c->stream, T, pipe_alt(c, 1 - q, 0), N);
+      c->grid_live = false;
+    }
+    State T = pipe_state(c, q); T.step = 0; T.goff = 0;
+    hipLaunchKernelGGL(sz_k_move_strain, dim3(grid_for(S0.capM, 16, 8192)), dim3(256), 0, c->stream, T, 1, 0, -1);      // calc_strain! of the state handed back
+    // the rows of step `last`: its links and row region are parity par(last)'s; the parents' centroids of that step are in mot
+    State R = pipe_state(c, par(last)); R.step = 0; R.vxy = T.vxy;
+    hipLaunchKernelGGL(sz_k_inter_fill, dim3(grid_for(S0.capM, 128 / IF_G, 16384)), dim3(128), 0, c->stream, R, 1, N, 0, 1, 2 + last);      // (2 + last: behind, for 1-based step last + 1)
+    return SZ_OK;
+  };
+  int s_end = c->maybe_tagged && user_stop && nsteps > 1 ? 1 : nsteps;
+  int s0 = 0, done = 0; bool need_prologue = true;
+  for (;;) {
+    S0.retry_stop = lean ? 1 : 0;
+    if (need_prologue) { int rc = prologue(s0); if (rc) return leave(rc); need_prologue = false; }
+    for (int s = s0; s < s_end; s++) {
+      const bool host_last = s + 1 == s_end;
+      const bool joined = launch_L1(s, !host_last);
+      launch_L2(s, !host_last, host_last, joined);
+    }
+    // the epilogue of the case "all steps ran" goes out with the steps: its launches look at the counters and return when the batch ended early
+    // (sz_k_inter_fill: behind-mode guard; the strain launch is harmless either way and is repeated below)
+    S0.step = 0;
+    { int rc = epilogue(s_end - 1, false); if (rc) return leave(rc); }
+    HIPCHK(c, hipMemcpyAsync(h, S0.cnt, C_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (h[C_ERR] & ~ERR_CAP_INTER) {          // (the rows' stride, ERR_CAP_INTER, is dealt with behind the loop: the bit stays up until then)
+      const int bits = h[C_ERR] & ~ERR_CAP_INTER;
+      if (growable(bits) && h[C_RETRYSTOP] > 0) {
+        // a list of step sr outgrown (neighbours, pair items): the batch paused there before the step changed anything -- larger lists, then that
+        // step and the rest again (as sz_step)
+        int z = 0; (void)hipMemcpy(S0.cnt + C_ERR, &z, sizeof(int), hipMemcpyHostToDevice);
+        const int sr = h[C_RETRYSTOP] - 1;
+        pipe_adopt(c, par(sr));
+        int rc = grow_lists(c, bits & (ERR_CAP_NEIGH | ERR_CAP_PAIRS)); if (rc) return leave(rc);
+        (void)hipMemsetAsync(S0.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream); (void)hipMemsetAsync(S0.cnt + C_STOP, 0, sizeof(int), c->stream);
+        (void)hipMemsetAsync(S0.cnt + C_FRCSTOP, 0, sizeof(int), c->stream);
+        (void)hipMemsetAsync(c->facc_buf, 0, (size_t)FX_WORDS * S0.capM * sizeof(long long), c->stream);
+        s0 = sr; need_prologue = true;
+        continue;
+      }
+      (void)sync_and_check(c, h);          // (sets the error text, clears the word)
+      return leave(SZ_E_CAPACITY);
+    }
+    if (lean && h[C_RETRYSTOP] > 0) {
+      // paused inside step sr: an item for the largest narrow variant.  That variant on the step's own State, the step's second launch again, on
+      // with the steps behind it (the variant stays in from now on)
+      const int sr = h[C_RETRYSTOP] - 1;
+      c->retry_seen = true; lean = false;
+      (void)hipMemsetAsync(S0.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream); (void)hipMemsetAsync(S0.cnt + C_PAUSED, 0, sizeof(int), c->stream);
+      State T = pipe_state(c, par(sr)); T.step = sr + 1; T.callid = callid0 + sr + 1; T.retry_stop = 0;
+      hipLaunchKernelGGL((sz_k_narrow<64, NARROW_CAP2, NARROW_KC2, NARROW_RC2, 16, 64, NARROW_CAP1, 2>), dim3(grid_for(capItems, 1, 256)), dim3(64), 0,
+                         c->stream, T, c->P, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, c->dbg, queue, 0, PipeAlt{}, 0, 0);
+      const bool host_last = sr + 1 == s_end;
+      S0.retry_stop = 0;
+      launch_L2(sr, !host_last, host_last, false);
+      s0 = sr + 1;
+      if (s0 >= s_end) {          // it was the last step: only the epilogue is left
+        S0.step = 0;
+        { int rc = epilogue(s_end - 1, false); if (rc) return leave(rc); }
+        HIPCHK(c, hipMemcpyAsync(h, S0.cnt, C_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (h[C_ERR] & ~ERR_CAP_INTER) { (void)sync_and_check(c, h); return leave(SZ_E_CAPACITY); }
+        done = s_end;
+        break;
+      }
+      continue;
+    }
+    if (h[C_STOP] > 0 && h[C_STOP] < s_end) {
+      // a tag ended the enqueued steps after step k: the state behind it (GEO(k) has run ahead: parents un-swapped), then either the end of
+      // the batch (the caller's stop) or -- a batch that runs through -- the rest of it, started like a batch (the ghosts know the tag now)
+      const int k = h[C_STOP] - 1;
+      if (user_stop) { int rc = epilogue(k, true); if (rc) return leave(rc); done = k + 1; HIPCHK(c, hipMemcpyAsync(h, S0.cnt, C_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); break; }
+      pipe_adopt(c, par(k + 1));
+      { State T = pipe_state(c, par(k + 1)); T.step = 0; hipLaunchKernelGGL(sz_k_unswap, dim3(grid_for(N, 128)), dim3(128), 0, c->stream, T, pipe_alt(c, par(k), 0), N); }
+      (void)hipMemsetAsync(S0.cnt + C_STOP, 0, sizeof(int), c->stream); (void)hipMemsetAsync(S0.cnt + C_FRCSTOP, 0, sizeof(int), c->stream);
+      s0 = k + 1; need_prologue = true;
+      continue;
+    }
+    if (s_end < nsteps && h[C_STOP] == 0) {          // the first step ran on its own (a parent might have been tagged before the batch): the rest
+      s0 = s_end; s_end = nsteps; need_prologue = true;
+      continue;
+    }
+    done = h[C_STOP] > 0 ? std::min(h[C_STOP], nsteps) : s_end;
+    break;
+  }
+  // ---- the batch is over: state in set par(done); rows of step done - 1 assembled (region par(done - 1))
+  const int qlast = par(done - 1);
+  if (h[C_ERR] & ERR_CAP_INTER) {          // a floe of the last step has more rows than the stride holds: more room, the launch again (sz_step does the same)
+    int z = 0; (void)hipMemcpy(S0.cnt + C_ERR, &z, sizeof(int), hipMemcpyHostToDevice);
+    for (int tries = 0; tries < 6; tries++) {
+      S0.rowcap *= 4;
+      if (S0.rowcap > 8192) { c->err = "a floe has more than 8192 interaction rows"; return leave(SZ_E_CAPACITY); }
+      int rc = carve_interactions(c); if (rc) return leave(rc);
+      c->inter_lost = false;
+      State R = pipe_state(c, qlast); R.step = 0; R.vxy = S0.vxy;
+      hipLaunchKernelGGL(sz_k_inter_fill, dim3(grid_for(S0.capM, 128 / IF_G, 16384)), dim3(128), 0, c->stream, R, 1, N, 0, 1, 1);
+      HIPCHK(c, hipMemcpyAsync(h, S0.cnt, C_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (!(h[C_ERR] & ERR_CAP_INTER)) break;
+      (void)hipMemcpy(S0.cnt + C_ERR, &z, sizeof(int), hipMemcpyHostToDevice);
+    }
+    if (h[C_ERR]) { (void)sync_and_check(c, h); return leave(SZ_E_CAPACITY); }
+  }
+  {          // the per-row results of the last step to the rows straight behind the parents; its links become the context's; ghosts off
+    const State R = pipe_state(c, qlast);
+    const int G = h[C_NGHOSTS];
+    if (R.goff != 0 && G > 0) {
+      State T = c->S; T.gh = R.gh; T.ngh = R.ngh; T.step = 0;
+      hipLaunchKernelGGL(sz_k_rows_home, dim3(grid_for((long long)G * S0.maxnb, 256)), dim3(256), 0, c->stream, T, N, G, R.goff);
+      hipLaunchKernelGGL(sz_k_rows_rename, dim3(grid_for((long long)(N + G) * S0.maxnb, 256, 8192)), dim3(256), 0, c->stream, T, N, G, R.goff);
+    }
+    // (the links of the last step are set qlast's; the context's own set is par(done)'s: sz_k_remove_ghosts saves and clears what it is given)
+    State T = c->S; T.gh = R.gh; T.ngh = R.ngh; T.step = 0; T.retry_stop = 0;
+    hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(S0.capM, 256)), dim3(256), 0, c->stream, T, 0);
+    HIPCHK(c, hipMemsetAsync(c->pb[1 - qlast].ngh, 0, (size_t)S0.capM * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pb[1 - qlast].gh, 0xff, (size_t)MAX_GHOSTS * S0.capM * sizeof(int), c->stream));
+  }
+  {
+    const int keepG = h[C_NGHOSTS];
+    int rc = sync_and_check(c, h);
+    h[C_NGHOSTS] = keepG;
+    if (rc) return leave(rc);
+  }
+  if (done < nsteps) c->grid_live = false;
+  *done_out = done;
+  c->last_pipelined = 1; c->gi_pending_slot = qlast;
+  // (h[C_STOP]: the caller's view -- a batch that ran through ended at nsteps)
+  if (!user_stop) h[C_STOP] = 0;
+  return leave(SZ_OK);
+}
+}  // namespace
+
+int sz_debug_pipelined(sz_ctx* c) { return c ? c->last_pipelined : 0; }
+
 int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupling_dt, int32_t flags, int32_t* steps_done) {
   if (steps_done) *steps_done = 0;
   if (!c || !c->have_floes) return SZ_E_STATE;
@@ -1690,8 +1972,12 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   // inline ghost maker; seeded here from the columns (before the ghost seed: the maker updates the records of the parents it visits)
   const bool cr = coll && sg && !c->no_crec && c->crec_buf && c->fused_move && c->max_ring <= MV_RING && (gi || !periodic) && nsteps > 0;
   c->S.crec = cr ? c->crec_buf : nullptr; c->crec_was_live = cr;
-  if (cr) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, c->S, c->hostN);
-  if (gi) {               // the ghosts of the first step, from the parents as they lie (after the rings are in the batch's form)
+  // pipelined batches (sz_pipeline.hpp: two launches per step) run their own prologue -- records, first ghosts, first neighbour search
+  c->last_pipelined = 0;
+  const bool pipe = pipeline_eligible(c, nsteps, coll, sg, gi, periodic, cr,
+                                      coll && c->facc_buf != nullptr && !c->no_reduce_free && sg && (gi || !periodic) && c->fused_move && c->max_ring <= MV_RING && !c->any_moving, flags);
+  if (cr && !pipe) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, c->S, c->hostN);
+  if (gi && !pipe) {               // the ghosts of the first step, from the parents as they lie (after the rings are in the batch's form)
     HIPCHK(c, hipMemsetAsync(c->S.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S, 0, c->hostN);
   }
@@ -1715,8 +2001,15 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   int s_end = rfree && c->maybe_tagged && c->S.stop_on_tags && nsteps > 1 ? 1 : nsteps;
   auto leave = [&]() { c->S.retry_stop = 0; c->S.body_rings = 0; c->S.ginline = 0; c->S.famrec = 0; c->S.step = 0; c->S.crec = nullptr; c->S.facc = nullptr; c->acc_mode = 0; c->reduce_mode = 0; };
   int h[C_COUNT];
-  const int callid0 = c->callid; c->callid += nsteps;          // (step s of this batch is collision call callid0 + s + 1, also when it is run again)
-  for (int s0 = 0, mid = 0;;) {
+  int pipe_done = -1;
+  if (pipe) {
+    c->S.stop_on_tags = (flags & SZ_NO_STOP) ? 0 : 1;
+    int rcp = step_batch_pipelined(c, nsteps, tstep0, dt, coupling_dt, flags, periodic, gi, h, &pipe_done);
+    c->S.stop_on_tags = (flags & SZ_NO_STOP) ? 0 : 1;
+    if (rcp) { leave(); return rcp; }
+  }
+  const int callid0 = c->callid; if (!pipe) c->callid += nsteps;          // (step s of this batch is collision call callid0 + s + 1, also when it is run again)
+  for (int s0 = 0, mid = 0; !pipe;) {
     c->S.retry_stop = lean ? 1 : 0;
     for (int s = s0; s < s_end; s++) {
       int tstep = tstep0 + s;
@@ -1821,7 +2114,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   c->S.body_rings = 0;
   if (coll) { c->inter_any = true; c->inter_lost = false; }
   int rc = SZ_OK;
-  const int done = h[C_STOP] > 0 ? std::min(h[C_STOP], (int)nsteps) : nsteps;
+  const int done = pipe ? pipe_done : h[C_STOP] > 0 ? std::min(h[C_STOP], (int)nsteps) : nsteps;
   if (steps_done) *steps_done = done;
   if (gl && !gi) {        // the list the last step that RAN has filled, and how long it is
     c->gl_cur = (gl0 + done) & 1;
@@ -1829,7 +2122,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   }
   if (gi) {               // the order keys of the last step's ghosts are what the host needs to number them as the reference does:
     // they are fetched when somebody asks for numbers (gi_fetch: downloads, the fuse replay) -- most batches end without
-    c->gi_pending_n = done > 0 ? h[C_NGHOSTS] : 0; c->gi_pending_slot = (done - 1) & 1; c->gi_pending = true;
+    c->gi_pending_n = done > 0 ? h[C_NGHOSTS] : 0; if (!pipe) c->gi_pending_slot = (done - 1) & 1; c->gi_pending = true;
     if (coll) c->gi_valid = done > 0;
     if (done < nsteps) c->grid_live = false;       // stopped early: the step that ended the batch has binned ghosts for a step that did not come
     c->gl_est = std::max(c->gl_est, c->gi_pending_n);        // (sizes the list pass should the next batch use it)
@@ -1858,7 +2151,7 @@ int sz_profile_enable(sz_ctx* c, int32_t on) {
 int sz_narrow_kernel_name(sz_ctx* c, char* buf, int32_t n) {
   if (!c || !buf || n < 8) return SZ_E_ARG;
   const int frc = c->forcing_where == 2 ? (c->precision == 1 ? 2 : 1) : 0;
-  snprintf(buf, (size_t)n, "sz_k_narrow<%d,%d,%d,%d,4,64,0,0,3,%d>", NARROW_G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, frc);
+  snprintf(buf, (size_t)n, "sz_k_narrow<%d,%d,%d,%d,4,64,0,0,3,%d,%d>", NARROW_G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, frc, c->last_pipelined ? 1 : 0);
   return SZ_OK;
 }
 int sz_forcing_launch(sz_ctx* c, int32_t* where) {

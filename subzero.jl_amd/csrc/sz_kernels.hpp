@@ -53,6 +53,11 @@ __device__ __forceinline__ void loads_issued() { asm volatile("" ::: "memory"); 
 __device__ __forceinline__ void request_stop(const State& S) {
   if (S.step > 0 && S.stop_on_tags) S.cnt[C_STOP] = S.step;      // every requester of a step writes the same value
 }
+// a NEW tag (raised by the narrow phase or the forcings of the step): also ends the enqueued steps of a pipelined batch that runs through
+// (State::restart_on_tags)
+__device__ __forceinline__ void request_stop_new_tag(const State& S) {
+  if (S.step > 0 && (S.stop_on_tags || S.restart_on_tags)) S.cnt[C_STOP] = S.step;
+}
 // A list of this step has outgrown its capacity (neighbours per floe, pair items, interaction rows per floe): the reference's lists
 // grow as needed (collisions.jl:290-296), the engine's are carved per upload.  Besides the sticky error bit the step is paused like
 // the step that needs the largest narrow variant (C_RETRYSTOP): the kernels that follow in it and all later steps return at once,
@@ -721,8 +726,12 @@ __device__ __forceinline__ void ghost_row_load(const State& S, int i, int n, int
 __device__ __forceinline__ int ghost_count_of(int fl) { return fl == 5 ? 0 : ((fl & 3) != 1 && ((fl >> 2) & 3) != 1) ? 3 : 1; }
 // given: the caller has already drawn the rows and ring points of the ghosts from the allocator ({rows << 32 | points} before them) -- the halo
 // unpack of a tiled run allocates a received floe and its ghosts in one go
+// RING: where the parent's (moved) ring comes from, `void get(int k, double& x, double& y)` -- the row's registers (RingRegs), or the old ring in
+// memory put through the step's motion again (sz_pipeline.hpp RingMoved: the same expressions, the same bits)
+struct RingRegs { const GhostRow& R; __device__ __forceinline__ void get(int k, double& x, double& y) const { x = R.rx[k]; y = R.ry[k]; } };
+template <class ROW, class RING>
 __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, const double* wall, int N, int NV0, int slot, int i, int fl, int n, int vo,
-                                                  const GhostRow& R, const unsigned long long* given = nullptr) {
+                                                  const ROW& R, const RING& ring, const unsigned long long* given = nullptr) {
   const int dir0 = (fl & 3) - 1, dir1 = ((fl >> 2) & 3) - 1;
   const int ng = dir0 != 0 && dir1 != 0 ? 3 : 1;
   const bool body = S.body_rings != 0;
@@ -792,11 +801,12 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
   // (out of rows or ring points: the error bit, and the allocator is marked POISONED in the word beside it -- its count then says nothing
   //  about how many rows were really written, and the neighbour search that commits it runs the step on the parents alone instead of
   //  walking rows nobody made.  The count itself is left alone: later allocations must keep seeing a plain, ever larger offset.)
-  if (N + og + ng > S.capM) { atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); atomicOr(&S.galloc[slot * 16 + 1], 1ull); return; }
+  if (og + ng > (S.gcap > 0 ? S.gcap : S.capM - N - S.goff)) { atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); atomicOr(&S.galloc[slot * 16 + 1], 1ull); return; }
+  const int NR = N + S.goff;          // first row of the step's allocated rows (pipelined steps: one of two regions)
   if (NV0 + ov + npts > S.capV) { atomicOr(&S.cnt[C_ERR], ERR_CAP_VERTS); atomicOr(&S.galloc[slot * 16 + 1], 1ull); return; }
   // ---- stores
   auto put = [&](const Shift& c, int w, long long key) {
-    const int g = N + og + w, vb = NV0 + ov + w * n;
+    const int g = NR + og + w, vb = NV0 + ov + w * n;
     double gx = pcx, gy = pcy, x0 = pb0, y0 = pb2, x1 = pb1, y1 = pb3;
     shift_apply(c, gx, gy); shift_apply(c, x0, y0); shift_apply(c, x1, y1);
     // (only what the collision kernels read of a ghost: these rows live for one resident step and are never handed to the host -- mass,
@@ -812,7 +822,7 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
     else {
       S.voff[g] = vb; S.voff[g + 1] = vb + n;                // (the next allocation writes the same value: rings are packed back to back)
 #pragma unroll
-      for (int k = 0; k < MV_RING; k++) if (k < n) { double x = R.rx[k], y = R.ry[k]; shift_apply(c, x, y); S.vxy[vb + k] = make_double2(x, y); }
+      for (int k = 0; k < MV_RING; k++) if (k < n) { double x, y; ring.get(k, x, y); shift_apply(c, x, y); S.vxy[vb + k] = make_double2(x, y); }
     }
     GSTAMP(17);
     if (S.rec32) rec32_store(S, g, gx, gy, c_rmax, x0, x1, y0, y1);
@@ -830,8 +840,8 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
       if (sl < CELL_K) S.cell_slots[(size_t)cl * CELL_K + sl] = g;
       else S.cell_items[g] = atomicExch(&S.cell_ovf[cl], g + 1) - 1;
     };
-    place(cl0, s0, N + og);
-    if (cl1 >= 0) { place(cl1, s1, N + og + 1); place(cl2, s2, N + og + 2); }
+    place(cl0, s0, NR + og);
+    if (cl1 >= 0) { place(cl1, s1, NR + og + 1); place(cl2, s2, NR + og + 2); }
   }
   GSTAMP(14);
   put(c0, 0, k0);
@@ -840,16 +850,18 @@ __device__ __forceinline__ void ghost_inline_make(State& S, const GridGeo& geo, 
   if (moved) {                                               // the parent swapped with its ghost(s)
     double px = pcx, py = pcy, x0 = pb0, y0 = pb2, x1 = pb1, y1 = pb3;
     shift_apply(cp, px, py); shift_apply(cp, x0, y0); shift_apply(cp, x1, y1);
-    S.cx[i] = px; S.cy[i] = py; S.bbx0[i] = x0; S.bbx1[i] = x1; S.bby0[i] = y0; S.bby1[i] = y1;
+    // (pipelined steps: this runs beside the narrow phase and the forcings of the step BEFORE, which read the parent's columns -- they are
+    //  brought up to date from the record by that step's update, sz_pipeline.hpp)
+    if (!S.pipe) { S.cx[i] = px; S.cy[i] = py; S.bbx0[i] = x0; S.bbx1[i] = x1; S.bby0[i] = y0; S.bby1[i] = y1; }
     if (!body) {
 #pragma unroll
-      for (int k = 0; k < MV_RING; k++) if (k < n) { double x = R.rx[k], y = R.ry[k]; shift_apply(cp, x, y); S.vxy[vo + k] = make_double2(x, y); }
+      for (int k = 0; k < MV_RING; k++) if (k < n) { double x, y; ring.get(k, x, y); shift_apply(cp, x, y); S.vxy[vo + k] = make_double2(x, y); }
     }
     if (S.rec32) rec32_store(S, i, px, py, c_rmax, x0, x1, y0, y1);
     if (S.crec) crec_store_place(S, i, px, py, x0, x1, y0, y1);
   }
-  for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = q < ng ? N + og + q : -1;
-  S.ngh[i] = ng;
+  for (int q = 0; q < MAX_GHOSTS; q++) S.gh[i * MAX_GHOSTS + q] = q < ng ? NR + og + q : -1;
+  S.ngh[i] = ng | (S.pipe && moved ? 0x100 : 0);          // (0x100: the parent swapped with its ghost -- only pipelined steps look at it)
   if (S.crec) S.crec[(size_t)i * 8 + 2].y = crec_vp(vo, i, ng);
   {
     // the family record of this id for the Dict rule (pair_allowed_fam): the parent as it now lies, then its ghosts -- the values of the rows
@@ -877,7 +889,7 @@ __global__ void __launch_bounds__(256) sz_k_ghost_inline_seed(State S, int slot,
       const int n = ring_n(S, i), vo = ring_off(S, i);
       if (n > MV_RING) { atomicOr(&S.cnt[C_ERR], ERR_CAP_RING); continue; }
       GhostRow R; ghost_row_load(S, i, n, vo, R);
-      ghost_inline_make(S, geo, wall, N, NV0, slot, i, fl, n, vo, R);
+      ghost_inline_make(S, geo, wall, N, NV0, slot, i, fl, n, vo, R, RingRegs{ R });
     }
   }
 }
@@ -1219,13 +1231,19 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   const StopRegs stop = stop_load(S);
   int M = S.cnt[C_M];
   int nfix = 0x7fffffff;        // rows from here on get their fixed-point totals cleared by this launch (the rows the step's inline makers allocated)
+  // Pipelined steps (State::goff != 0): the rows the step's makers allocated lie at [N + goff, ..), a multiple of 16 (the host's choice), not
+  // straight behind the parents.  The launch walks blocks of GPB rows; the blocks that hold parents end at nsplit = N rounded up to 16, the
+  // blocks from there on are the allocated rows, kshift further on -- a SCALAR decision per block (the search sits on its register budget:
+  // a per-lane mapping cost it a wavefront per SIMD), rows [N, nsplit) do not exist.  Without goff: nsplit is never reached.
+  int nsplit = 0x7fffffff, kshift = 0, lim0 = M, lim1 = M;      // rows below nsplit exist while < lim0, the others while < lim1 (physical numbers)
   if (S.ginline) {            // inline ghosts: the step's ghosts were made by the kernel that placed their parents; the counts are committed here
     const unsigned long long a = S.galloc[S.gslot * 16], poisoned = S.galloc[S.gslot * 16 + 1];
     const int N = S.cnt[C_N]; int G = (int)(a >> 32), V = (int)(a & 0xffffffffull);
     if (REC && S.facc) nfix = N;          // (the instantiations on collision records -- what the resident steps run; without records the host clears the rows, sz_step)
-    if (poisoned || N + G > S.capM) { G = 0; V = 0; }          // a poisoned allocator (see ghost_inline_make): the parents alone, the error bit is up
-    M = N + G;
+    if (poisoned || N + S.goff + G > S.capM || (S.gcap > 0 && G > S.gcap)) { G = 0; V = 0; }          // a poisoned allocator (see ghost_inline_make): the parents alone, the error bit is up
+    M = N + G; lim0 = M; lim1 = M;
     if (bid == 0 && threadIdx.x == 0 && !stop_test(S, stop)) { S.cnt[C_M] = M; S.cnt[C_NV] = S.voff[N] + V; S.cnt[C_NGHOSTS] = G; }
+    if (REC && S.goff != 0) { nsplit = (N + 15) & ~15; kshift = N + S.goff - nsplit; lim0 = N; lim1 = N + S.goff + G; M = nsplit + G; }      // (M: the walk's end, in block numbers)
   }
   const GridGeo g = grid_geo(S);
   const int ncx = g.ncx, ncy = g.ncy;
@@ -1236,8 +1254,11 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
   const int vb0 = S.xcd_neigh ? xcd_contiguous(bid, nblk, (M + GPB - 1) / GPB) : bid;
   // (the floe's own row is asked for before the count of floes is looked at -- rows up to capM exist, one past the end is read and
   //  ignored: the launch's first two round trips, counter block and row, become one)
+  static_assert(16 % GPB == 0 || GPB % 16 == 0, "blocks of rows must not straddle nsplit");
   for (int kb = vb0 < 0 ? S.capM : vb0 * GPB; kb < S.capM; kb += nblk * GPB) {
-    const int k = kb + gi;
+    const bool hi = REC && kb >= nsplit;                        // (uniform)
+    const int k = (hi ? kb + kshift : kb) + gi;
+    const bool act = k < (hi ? lim1 : lim0);
     double ckx = 0, cky = 0, rk = 0, kx0 = 0, kx1 = 0, ky0 = 0, ky1 = 0;
     long long idk = 0, okk = 0, kgid = 0; bool kplain = true; int ix = 0, iy = 0, vok = 0, nvk = 0, kpar = 0;
     if (k < S.capM) {
@@ -1260,7 +1281,6 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
     loads_issued();
     if (stop_test(S, stop) || kb >= M) break;
     if (bid == 0 && threadIdx.x == 0 && kb == vb0 * GPB) { S.cnt[C_ITEMCLASS] = 0; S.cnt[C_NFUSE] = 0; }     // per-step counters the narrow phase raises
-    const bool act = k < M;
     if constexpr (REC) { if (act && k >= nfix) S.facc[(size_t)k * FX_WORDS + gl] = 0; }         // (NB_G = FX_WORDS lanes: one line)
     __syncthreads();
     if (gl == 0) { cnts[gi][0] = 0; cnts[gi][1] = 0; npool[gi] = 0; if constexpr (MW == 1) wmask[gi] = (mask_t)0; }
@@ -1590,13 +1610,19 @@ __global__ void __launch_bounds__(NB_TPB) sz_k_neighbors_elem(State S, unsigned 
 template <bool TW>
 __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid, int nblk, int pmax, int first);
 __device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, int bid, int nblk, int first);
-template <int G, int CAP, int KC, int RC, int RM, int TPB, int LO, int CLS, int WPE = 1, int FRC = 0>
-__global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int dt, double ff_max_overlap, double fd_max_overlap, int dbg, int queue, int nbf) {
+// GEO / PA / nbg / nn (pipelined steps, sz_pipeline.hpp): nbg more workgroups, straight behind the narrow ones, make the geometry of the NEXT step
+// (thread per parent, nn parents) into the other parity's buffers
+__device__ __forceinline__ void geo_body(State S, const PipeAlt& A, int dt, int bid, int nblk, int N);
+template <int G, int CAP, int KC, int RC, int RM, int TPB, int LO, int CLS, int WPE = 1, int FRC = 0, int GEO = 0>
+__global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int dt, double ff_max_overlap, double fd_max_overlap, int dbg, int queue, int nbf,
+                                                       PipeAlt PA, int nbg, int nn) {
   constexpr int GPB = TPB / G;
-  const int nblk = (int)gridDim.x - (FRC != 0 ? nbf : 0);       // the narrow workgroups
+  const int nblk = (int)gridDim.x - (FRC != 0 ? nbf : 0) - (GEO != 0 ? nbg : 0);       // the narrow workgroups
+  if (GEO != 0 && (int)blockIdx.x >= nblk && (int)blockIdx.x < nblk + nbg) { geo_body(S, PA, dt, (int)blockIdx.x - nblk, nbg, nn); return; }
   if (FRC != 0 && (int)blockIdx.x >= nblk) {
-    if (FRC == 1) forcing_body<false>(S, P, (int)blockIdx.x - nblk, nbf, 0, nblk);
-    else forcing_mixed_body(S, P, (int)blockIdx.x - nblk, nbf, nblk);
+    const int first = nblk + (GEO != 0 ? nbg : 0);
+    if (FRC == 1) forcing_body<false>(S, P, (int)blockIdx.x - first, nbf, 0, first);
+    else forcing_mixed_body(S, P, (int)blockIdx.x - first, nbf, first);
     return;
   }
   static_assert(4 * KC <= 2 * RC, "raw crossing slots alias reg[1]");
@@ -1636,7 +1662,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     const int ncells = (int)S.bounds[4] * (int)S.bounds[5];
     for (int q = blockIdx.x * TPB + threadIdx.x; q <= ncells; q += nblk * TPB) { S.cell_cnt[q] = 0; S.cell_ovf[q] = 0; }
     if (blockIdx.x == 0) for (int q = threadIdx.x; q < WARN_SLOTS * 4; q += TPB) S.warn[(q >> 2) * 32 + (q & 3)] = 0;
-    if (S.ginline && blockIdx.x == 0 && threadIdx.x == 0) { S.galloc[(1 - S.gslot) * 16] = 0ull; S.galloc[(1 - S.gslot) * 16 + 1] = 0ull; }      // the allocator (and its poison mark) this step's integrator makes the next ghosts in
+    if (S.ginline && !GEO && blockIdx.x == 0 && threadIdx.x == 0) { S.galloc[(1 - S.gslot) * 16] = 0ull; S.galloc[(1 - S.gslot) * 16 + 1] = 0ull; }      // the allocator (and its poison mark) this step's integrator makes the next ghosts in (pipelined steps: cleared by the update of the step before -- GEO draws from it in this very launch)
     // a list the neighbour search outgrew (its error bits): the batch pauses in this step -- raised here, where the counter block is
     // at hand anyway, rather than in the search (which sits exactly on its register budget)
     if (blockIdx.x == 0 && threadIdx.x == 0 && (S.cnt[C_ERR] & (ERR_CAP_NEIGH | ERR_CAP_PAIRS))) capacity_stop(S);
@@ -1942,7 +1968,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
           const int nown = S.cnt[C_NOWN];
           if (flags & IT_FUSE) { atomicOr((int*)(S.facc + (size_t)ri * FX_WORDS + 7), 1); if (rj >= 0) atomicOr((int*)(S.facc + (size_t)rj * FX_WORDS + 7), 4); }
           if (flags & IT_REMOVE) atomicOr((int*)(S.facc + (size_t)ri * FX_WORDS + 7), 2);
-          if (ri < nown || (rj >= 0 && rj < nown && (flags & IT_FUSE))) request_stop(S);
+          if (ri < nown || (rj >= 0 && rj < nown && (flags & IT_FUSE))) request_stop_new_tag(S);
         }
       }
       if (gl == 0) {
@@ -2168,7 +2194,9 @@ __device__ __forceinline__ int emit_rows_fold(const State& S, int lane, int f, d
 // centroids of that step are in `mot`), or inside every step on the paths that keep it there
 __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int n_init_arg, int m_hint, int rows_only, int oldc) {
   const StopRegs stop = stop_load(S);
-  if (oldc && stop.r != 0) return;          // (behind a batch that is paused inside a step: that step is finished first)
+  // (behind a batch that is paused inside a step: that step is finished first; oldc - 1 = the 1-based step the launch was enqueued for: a
+  //  batch that a tag ended BEFORE it has this launch again, for the step that did end it)
+  if (oldc && (stop.r != 0 || (stop.s != 0 && stop.s < oldc - 1))) return;
   const int M = S.cnt[C_M];
   const int nparents = S.cnt[C_NOWN];
   const int n_init = n_init_arg >= 0 ? n_init_arg : S.cnt[C_N];   // < 0: every parent on the device
@@ -2176,12 +2204,17 @@ __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int 
   const int mh = m_hint < S.capM ? m_hint : S.capM, nact_h = (mh + gpb - 1) / gpb;
   const bool hinted = mh > 0 && nact_h <= (int)gridDim.x;
   int k0 = -1;
+  // (pipelined steps: the rows behind the parents lie goff further on -- the launch walks VIRTUAL rows [0, M) and maps them)
+  const int nsplit = S.goff != 0 ? S.cnt[C_N] : 0x7fffffff;
+  auto phys = [&](int kv) { return kv >= nsplit ? kv + S.goff : kv; };
   if (hinted) { const int vb = xcd_contiguous((int)blockIdx.x, (int)gridDim.x, nact_h); if (vb >= 0) k0 = vb * gpb + grp; }
+  const int k0v = k0;
+  if (k0 >= 0) k0 = phys(k0) < S.capM ? phys(k0) : -1;
   struct Pre { long long gid; double cx, cy; int st, par, ng; int4 cnts; } pre = { 0, 0.0, 0.0, 0, 0, 0, make_int4(0, 0, 0, 0) };
   const int nmoved = oldc ? S.cnt[C_NOWN] : 0;        // rows [0, nmoved): their centroid of the step is in mot
   auto cxy = [&](int k, double& x, double& y) { if (k < nmoved) { const double2 o = *(const double2*)(S.mot + (size_t)k * 4); x = o.x; y = o.y; } else { x = S.cx[k]; y = S.cy[k]; } };
   if (k0 >= 0) {
-    pre.gid = S.ghost_id[k0]; cxy(k0, pre.cx, pre.cy); pre.st = S.status[k0]; pre.par = S.parent[k0]; pre.ng = S.ngh[k0];
+    pre.gid = S.ghost_id[k0]; cxy(k0, pre.cx, pre.cy); pre.st = S.status[k0]; pre.par = S.parent[k0]; pre.ng = S.ngh[k0] & 0xff;
     pre.cnts = make_int4(S.n_out[k0], S.el_off[k0], S.el_off[k0 + 1], S.n_in[k0]);
   }
   loads_issued();
@@ -2202,7 +2235,7 @@ __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int 
     const bool totals = mirror && k < n_init;
     int c;
     if (totals) {                      // own rows + ghost fold (collisions.jl:830-850), one pass
-      const int ng = pr ? pr->ng : S.ngh[k];
+      const int ng = pr ? pr->ng : (S.ngh[k] & 0xff);
       int gf[MAX_GHOSTS];
 #pragma unroll
       for (int g = 0; g < MAX_GHOSTS; g++) gf[g] = S.gh[k * MAX_GHOSTS + g];
@@ -2250,11 +2283,11 @@ __global__ void __launch_bounds__(128) sz_k_inter_fill(State S, int mirror, int 
     }
   };
   if (hinted) {
-    if (k0 >= 0 && k0 < M) reduce(k0, &pre);
-    for (int k = nact_h * gpb + (int)blockIdx.x * gpb + grp; k < M; k += gridDim.x * gpb) reduce(k, nullptr);      // beyond the hint
+    if (k0 >= 0 && k0v < M) reduce(k0, &pre);
+    for (int k = nact_h * gpb + (int)blockIdx.x * gpb + grp; k < M; k += gridDim.x * gpb) reduce(phys(k), nullptr);      // beyond the hint
   } else {
     const int vb0 = xcd_contiguous((int)blockIdx.x, (int)gridDim.x, (M + gpb - 1) / gpb);
-    for (int k = vb0 < 0 ? M : vb0 * gpb + grp; k < M; k += gridDim.x * gpb) reduce(k, nullptr);
+    for (int k = vb0 < 0 ? M : vb0 * gpb + grp; k < M; k += gridDim.x * gpb) reduce(phys(k), nullptr);
   }
 }
 // CSR compaction of the fixed-stride rows (sz_download_interactions only)
@@ -2469,7 +2502,7 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
       // written by the integrate kernel: this kernel may run beside the collision kernels, which also
       // write status, and the reference applies the coupling result after them
       S.frc_remove[i] = npt == 0 ? 1 : 0;
-      if (npt == 0) { if (S.step > 0 && S.stop_on_tags) S.cnt[C_FRCSTOP] = S.step; }      // (this step's integrator will tag the floe and end the batch: see C_FRCSTOP)
+      if (npt == 0) { if (S.step > 0 && (S.stop_on_tags || S.restart_on_tags)) S.cnt[C_FRCSTOP] = S.step; }      // (this step's integrator will tag the floe and end the batch: see C_FRCSTOP)
       else {
         double xcor = ma_ratio * P.fcor * v, ycor = ma_ratio * P.fcor * u;
         double totx = npt * xcor + tx, toty = -npt * ycor + ty;
@@ -2593,7 +2626,7 @@ __device__ __forceinline__ void forcing_mixed_body(State& S, const Params& P, in
     for (int d = FRC_PLAIN / 2; d >= 1; d >>= 1) npt += __shfl_xor(npt, d, FRC_PLAIN);
     if (lane == 0) {
       S.frc_remove[i] = npt == 0 ? 1 : 0;
-      if (npt == 0 && S.step > 0 && S.stop_on_tags) S.cnt[C_FRCSTOP] = S.step;
+      if (npt == 0 && S.step > 0 && (S.stop_on_tags || S.restart_on_tags)) S.cnt[C_FRCSTOP] = S.step;
       if (npt != 0) {
         double xcor = ma_ratio * P.fcor * v, ycor = ma_ratio * P.fcor * u;
         double totx = npt * xcor + dtx, toty = -npt * ycor + dty;
@@ -2953,7 +2986,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
               R.rx[k] = xr + (cx + dx); R.ry[k] = yr + (cy + dy);
             }
             ISTAMP(5);
-            ghost_inline_make(S, geo, wall, N, nv0, ginl, i, gf, n, o, R);
+            ghost_inline_make(S, geo, wall, N, nv0, ginl, i, gf, n, o, R, RingRegs{ R });
             ISTAMP(6);
           }
         }
@@ -3368,7 +3401,7 @@ __global__ void __launch_bounds__(UNPACK_TPB) sz_k_halo_unpack_inline(State S, c
   S.gkeys[(size_t)slot * S.capM + og] = R.oki;
   if (gf != 5) {
     const unsigned long long given = ((unsigned long long)(og + 1) << 32) | (unsigned)(ov + nv);
-    ghost_inline_make(S, geo, wall, nown, NV0, slot, g, gf, nv, vb, R, &given);
+    ghost_inline_make(S, geo, wall, nown, NV0, slot, g, gf, nv, vb, R, RingRegs{ R }, &given);
   }
 }
 // diagnosis (sz_debug_find_key): the row that held order key `key` in the last resident step that used allocator `slot` -- ghosts and halo floes stay

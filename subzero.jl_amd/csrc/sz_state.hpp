@@ -74,6 +74,12 @@ struct State {
                              // steps after a stop request return at once (stopped(), sz_kernels.hpp)
   int retry_stop;            // sz_step: the largest narrow variant is not enqueued; an item that needs it raises C_RETRYSTOP
   int stop_on_tags;          // sz_step: raise C_STOP when a parent is tagged (off with SZ_NO_STOP)
+  int goff;                  // pipelined resident steps (sz_pipeline.hpp): the rows a step's inline makers allocate lie at [N + goff, ..) -- two regions, used
+                             // alternately step by step, so that the ghosts of step t + 1 can be made while those of step t are still read; 0 elsewhere
+  int gcap;                  // rows the step's inline makers may allocate (pipelined steps: the size of the step's region; 0: all rows behind the parents)
+  int pipe;                  // this launch belongs to a pipelined step (the ghost maker leaves the parent's COLUMNS alone and marks a swapped parent)
+  int restart_on_tags;       // pipelined batches that run through (SZ_NO_STOP): a NEW tag still ends the enqueued steps -- the host starts the rest again,
+                             // so that the next step's ghosts are made knowing the tag (the steps' ghosts are made one launch ahead of the tags)
   int xcd_forcing;           // SZ_XCD_FORCING=1: XCD-contiguous floe ranges in the forcing kernels (A/B switch; default off: slower at 100 k)
   int xcd_neigh;             // SZ_XCD=1: XCD-contiguous floe ranges in the neighbour search too (A/B switch; default off)
   // ---- counters
@@ -171,6 +177,7 @@ struct State {
   int* blk;
   // ---- motion scratch (integrator)
   double* mot;               // 4 per floe: dx, dy, cos, sin
+  double* mot2;              // 2 per floe: cos / sin of the step's rotation (pipelined batches: what the un-swap behind a batch needs beside mot = {old cx, cy, dx, dy})
   double* trig;              // 2 per floe: cos(alpha), sin(alpha), kept current by the upload and the integrator
   long long* stamps;         // diagnostic build (-DSZ_STAMPS) only
   // ---- per-floe collision totals as order-independent fixed-point sums (round 4; sz_geom.hpp "fixed-point totals"): FX_WORDS = 16 int64 words per row
@@ -184,6 +191,16 @@ struct State {
   unsigned long long* acc;   // cumulative work counters of the narrow phase (ACC_SLOTS lines of 8 words: launches, pair items run,
                              // their ring points, pair rows, element items, element rows): what a launch averaged over a window of
                              // steps really did, for the roofline of bench.py (sz_get_stats acc_*, cleared by sz_profile_reset)
+};
+
+// what a launch of a pipelined step (sz_pipeline.hpp) needs of the OTHER step parity -- the State it is given holds one parity's pointers
+struct PipeAlt {
+  double2 *crec, *vxy;
+  int *cell_cnt, *cell_slots, *cell_ovf, *cell_items;
+  int4* work; int* wq;
+  int *gh, *ngh;
+  int goff, gslot;
+  int make_ghosts;        // GEO: 0 in a step the host knows to be the batch's last (no ghosts, no swap: there is no step to make them for)
 };
 
 using szg_flags_note = int;   // IT_FUSE / IT_REMOVE are defined in sz_geom.hpp

@@ -189,12 +189,15 @@ def test_hot_kernels_keep_their_register_budgets():
               "sz_k_neighbors<true, 24, true>": (168, 0), "sz_k_neighbors<false, 24, true>": (128, 0),
               # (the narrow phase parks the prefetched first work item -- four loop-invariant words -- in scratch once per launch: 16 bytes + one
               #  word, stored before the first round and read back by the round that uses it)
-              "sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 0>": (168, 20), "sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 1>": (168, 20),
+              "sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 0, 0>": (168, 20), "sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 1, 0>": (168, 20),
+              # (pipelined steps: the same launch with GEO workgroups behind the narrow ones, and the update beside the neighbour search -- both at
+              #  the three-wavefront budget; their rare paths (a parent that gets ghosts) may spill)
+              "sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 1, 1>": (168, 400), "sz_k_vel_search<true>": (168, 400),
               "sz_k_inter_fill": (128, 0), "sz_k_forcing<false>": (128, 0), "sz_k_forcing_mixed": (80, 16), "sz_k_halo_pack": (128, 0)}
     for name, (vg, scratch) in budget.items():
         assert name in res, (name, sorted(k for k in res if k.startswith(name.split("<")[0])))
         assert res[name]["vgpr"] <= vg and res[name]["scratch"] <= scratch, (name, res[name])
-    assert res["sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 1>"]["lds"] <= 16384
+    assert res["sz_k_narrow<8, 18, 8, 16, 4, 64, 0, 0, 3, 1, 0>"]["lds"] <= 16384
 
 
 def test_tile_fuzzer_seeds_keep_their_meaning():

@@ -1,4 +1,4 @@
-"""Reduce-free resident steps against the same steps with the (rows-only) reduce launch inside every step, and against the oracle:
+"""Pipelined resident steps (default) against the three-launch steps (SZ_PIPELINE=0; SZ_REDUCE_FREE=0 in the environment adds the in-step reduce), bit for bit:
 state columns, interaction rows, ghost statistics.  Run on the GPU box:  python tools/probe/rfree_ab.py [n] [fast]"""
 import os, sys, subprocess, json
 import numpy as np
@@ -18,7 +18,7 @@ def child(n, fast, batches):
         done = hw.run(k, t, cfg["dt"], coupling_dt=1, stop_on_tags=False); t += done
     out["stats"] = {k: int(v) for k, v in hw.stats().items() if k in ("n_ghosts", "n_status_fuse", "n_inter_rows", "M", "N")}
     off, rows = hw.interactions()
-    np.savez(os.environ["RF_OUT"], off=off, rows=rows, **{f: hw.get(f) for f in ("cx", "cy", "u", "v", "xi", "coll_fx", "coll_trq", "overarea", "si11", "si12")})
+    np.savez(os.environ["RF_OUT"], off=off, rows=rows, **{f: hw.get(f) for f in ("cx", "cy", "u", "v", "xi", "alpha", "coll_fx", "coll_trq", "overarea", "si11", "si12", "e11", "e22", "fxOA", "height")}, vx=hw.rings()[1], vy=hw.rings()[2])
     print(json.dumps(out))
 
 if __name__ == "__main__":
@@ -29,7 +29,7 @@ if __name__ == "__main__":
     fast = "1" if len(sys.argv) > 2 and sys.argv[2] == "fast" else "0"
     batches = sys.argv[3] if len(sys.argv) > 3 else "1,7,3,1,12"
     res = {}
-    for tag, env in (("rfree", {}), ("instep", {"SZ_REDUCE_FREE": "0"})):
+    for tag, env in (("rfree", {}), ("instep", {"SZ_PIPELINE": "0"})):
         e = dict(os.environ, RF_CHILD="1", RF_OUT=f"/tmp/rf_{tag}.npz", **env)
         p = subprocess.run([sys.executable, os.path.abspath(__file__), str(n), fast, batches], env=e, capture_output=True, text=True)
         print(tag, p.stdout.strip()[-300:], p.stderr.strip()[-500:])
