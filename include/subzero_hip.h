@@ -411,6 +411,9 @@ int sz_debug_match_vertices(sz_ctx *ctx, int32_t npts, const double *px, const d
    out12[12 k ..] = in_bounds (0 / 1), uocn, vocn, hflx, uatm, vatm, the 1-based grid lines west, east, south, north the bilinear
    blend reads, its weights tx, ty.  Needs sz_set_domain and sz_set_fields. */
 int sz_debug_sample_fields(sz_ctx *ctx, int32_t n, const double *x, const double *y, double *out12);
+
+/* test hook: 1 when the last sz_step batch ran as pipelined steps (two launches per timestep: csrc/sz_pipeline.hpp), 0 otherwise */
+int sz_debug_pipelined(sz_ctx *ctx);
 /* diagnostic build (-DSZ_STAMPS) only: stamp log of one lane group of the narrow phase
    (out512[0] = entries, then (stage << 48) | cycles since the wave started) */
 int sz_debug_stamps(sz_ctx *ctx, long long *out512);

@@ -80,7 +80,7 @@ EXPORTS = [
     "sz_eulerian_data", "sz_eulerian_partial", "sz_eulerian_finish", "sz_simplify_check",
     "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms", "sz_forcing_launch", "sz_narrow_kernel_name",
     "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_forcing", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps", "sz_debug_crec_mismatches", "sz_upload_floes_f32", "sz_download_floes_f32", "sz_set_fields_f32", "sz_download_interactions_f32",
-    "sz_get_boundary_rects", "sz_debug_match_vertices", "sz_debug_sample_fields",
+    "sz_get_boundary_rects", "sz_debug_match_vertices", "sz_debug_sample_fields", "sz_debug_pipelined",
     "sz_comm_available", "sz_comm_unique_id", "sz_comm_init", "sz_comm_init_host", "sz_comm_destroy", "sz_comm_selftest", "sz_comm_allreduce", "sz_tile_setup", "sz_tile_set_center", "sz_tile_run", "sz_tile_migrate", "sz_tile_owned_gidx", "sz_debug_migrate_path", "sz_debug_find_key", "sz_debug_pairs_of_ids", "sz_download_subpoints",
 ]
 
@@ -185,6 +185,7 @@ def load(build_if_missing=True):
     L.sz_get_boundary_rects.argtypes = [C.c_void_p, _dp]
     L.sz_debug_match_vertices.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, C.c_int32, _dp, _dp, _ip, _ip]
     L.sz_debug_sample_fields.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp]
+    L.sz_debug_pipelined.argtypes = [C.c_void_p]
     for n in EXPORTS:
         if n not in ("sz_create", "sz_destroy", "sz_last_error", "sz_version"):
             getattr(L, n).restype = C.c_int

@@ -1735,7 +1735,8 @@ int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling
     HIPCHK(c, hipMemsetAsync(O.cell_cnt, 0, ((size_t)S0.capCells + 1) * sizeof(int), c->stream));
     HIPCHK(c, hipMemsetAsync(O.cell_ovf, 0, ((size_t)S0.capCells + 1) * sizeof(int), c->stream));
     HIPCHK(c, hipMemsetAsync(c->pb[0].wq, 0, NSEG * 32 * sizeof(int), c->stream)); HIPCHK(c, hipMemsetAsync(c->pb[1].wq, 0, NSEG * 32 * sizeof(int), c->stream));
-    HIPCHK(c, hipMemsetAsync(O.ngh, 0, (size_t)S0.capM * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pb[0].ngh, 0, (size_t)S0.capM * sizeof(int), c->stream));          // (no links: a restart after a tag comes with those GEO made for a step that is now started afresh)
+    HIPCHK(c, hipMemsetAsync(c->pb[1].ngh, 0, (size_t)S0.capM * sizeof(int), c->stream));
     HIPCHK(c, hipMemsetAsync(S0.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
     // the records of both sets from the columns (the static quads of the twin; its geometry quads are GEO's)
     for (int b = 0; b < 2; b++) { State T = pipe_state(c, b); T.step = 0; hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(N, 256)), dim3(256), 0, c->stream, T, N); }

@@ -426,6 +426,10 @@ class World:
         self._chk(self.L.sz_debug_sample_fields(self.h, len(x), capi.ptr(x), capi.ptr(y), capi.ptr(out)))
         return out
 
+    def pipelined(self):
+        """the last run() batch ran as pipelined steps (two launches per timestep)"""
+        return bool(self.L.sz_debug_pipelined(self.h))
+
     def warn_counts(self):
         s = self.stats()
         return np.array([s["warn_height"], s["warn_force"], s["warn_vel"], s["warn_xi"]], _I64)

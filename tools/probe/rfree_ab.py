@@ -16,6 +16,7 @@ def child(n, fast, batches):
     t = 0; out = {}
     for k in batches:
         done = hw.run(k, t, cfg["dt"], coupling_dt=1, stop_on_tags=False); t += done
+        out.setdefault("pipelined", []).append(int(hw.pipelined()))
     out["stats"] = {k: int(v) for k, v in hw.stats().items() if k in ("n_ghosts", "n_status_fuse", "n_inter_rows", "M", "N")}
     off, rows = hw.interactions()
     np.savez(os.environ["RF_OUT"], off=off, rows=rows, **{f: hw.get(f) for f in ("cx", "cy", "u", "v", "xi", "alpha", "coll_fx", "coll_trq", "overarea", "si11", "si12", "e11", "e22", "fxOA", "height")}, vx=hw.rings()[1], vy=hw.rings()[2])
