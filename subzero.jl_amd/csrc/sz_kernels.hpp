@@ -1069,7 +1069,7 @@ __device__ __forceinline__ bool circles_touch(const State& S, int a, int b) {
 // all instances (parent + ghosts) of the two ids that pass the circle test.
 __device__ bool pair_allowed(const State& S, int i, int j) {   // i < j, ids differ, circles touch
   int pi = S.parent[i], pj = S.parent[j];
-  int ni = S.ngh[pi], nj = S.ngh[pj];
+  int ni = S.ngh[pi] & 0xff, nj = S.ngh[pj] & 0xff;
   if (ni == 0 && nj == 0) return true;
   int ba = 0x7fffffff, bb = 0x7fffffff;
   for (int x = -1; x < ni; x++) {
@@ -1089,6 +1089,42 @@ __device__ bool pair_allowed(const State& S, int i, int j) {   // i < j, ids dif
   if (S.id[ba] > S.id[bb]) { g1 = S.ghost_id[ba]; g2 = S.ghost_id[bb]; } else { g1 = S.ghost_id[bb]; g2 = S.ghost_id[ba]; }
   if (S.id[i] > S.id[j]) { c1 = S.ghost_id[i]; c2 = S.ghost_id[j]; } else { c1 = S.ghost_id[j]; c2 = S.ghost_id[i]; }
   bool A = c1 == g1, B = c2 == g2;
+  return (A && B) || (A != B);
+}
+
+// ... and on collision records (the lean search of large fields, where the family records cost a wavefront per SIMD): every value of an
+// instance comes from its record -- in a pipelined step the parents' COLUMNS are being brought up to date beside this search -- and the
+// ghost count is the links' low byte (pipelined steps keep a flag above it)
+__device__ bool pair_allowed_rec(const State& S, int i, int j) {   // i before j in the serial order, ids differ, circles touch
+  auto key_of = [&](int f) { return __double_as_longlong(S.crec[(size_t)f * 8 + 2].x) & CREC_KEYMASK; };
+  auto touch = [&](int a, int b) {
+    const double2 pa = S.crec[(size_t)a * 8], pb = S.crec[(size_t)b * 8];
+    const double dx = pa.x - pb.x, dy = pa.y - pb.y, rr = S.crec[(size_t)a * 8 + 1].x + S.crec[(size_t)b * 8 + 1].x;
+    return (dx * dx + dy * dy) < rr * rr;
+  };
+  const int pi = (int)(__double_as_longlong(S.crec[(size_t)i * 8 + 2].y) >> 32) & 0x0fffffff, pj = (int)(__double_as_longlong(S.crec[(size_t)j * 8 + 2].y) >> 32) & 0x0fffffff;
+  const int ni = S.ngh[pi] & 0xff, nj = S.ngh[pj] & 0xff;
+  if (ni == 0 && nj == 0) return true;
+  int ba = 0x7fffffff, bb = 0x7fffffff;
+  for (int x = -1; x < ni; x++) {
+    const int fx = x < 0 ? pi : S.gh[pi * MAX_GHOSTS + x];
+    for (int y = -1; y < nj; y++) {
+      const int fy = y < 0 ? pj : S.gh[pj * MAX_GHOSTS + y];
+      const bool lt = key_of(fx) < key_of(fy);
+      const int a = lt ? fx : fy, b = lt ? fy : fx;
+      if (ba != 0x7fffffff) {
+        const long long ka = key_of(a), kb = key_of(b), kba = key_of(ba), kbb = key_of(bb);
+        if (ka > kba || (ka == kba && kb >= kbb)) continue;
+      }
+      if (touch(a, b)) { ba = a; bb = b; }
+    }
+  }
+  auto id_of = [&](int f) { return __double_as_longlong(S.crec[(size_t)f * 8 + 1].y); };
+  auto gid_of = [&](int f) { return __double_as_longlong(S.crec[(size_t)f * 8 + 7].y); };
+  long long g1, g2, c1, c2;
+  if (id_of(ba) > id_of(bb)) { g1 = gid_of(ba); g2 = gid_of(bb); } else { g1 = gid_of(bb); g2 = gid_of(ba); }
+  if (id_of(i) > id_of(j)) { c1 = gid_of(i); c2 = gid_of(j); } else { c1 = gid_of(j); c2 = gid_of(i); }
+  const bool A = c1 == g1, B = c2 == g2;
   return (A && B) || (A != B);
 }
 
@@ -1335,7 +1371,8 @@ __device__ __forceinline__ void neighbors_body(State& S, int bid, int nblk) {
             const long long gk = REC ? __double_as_longlong(S.crec[(size_t)k * 8 + 7].y) : kgid, go = REC ? __double_as_longlong(S.crec[(size_t)o * 8 + 7].y) : S.ghost_id[o];
             ok = after ? pair_allowed_fam(S, kp, op, !kplain, !oplain, okk, gk, ckx, cky, rk, ko, go, ocx, ocy, orm)
                        : pair_allowed_fam(S, op, kp, !oplain, !kplain, ko, go, ocx, ocy, orm, okk, gk, ckx, cky, rk);
-          } else ok = pair_allowed(S, after ? k : o, after ? o : k);
+          } else if constexpr (REC) ok = pair_allowed_rec(S, after ? k : o, after ? o : k);
+          else ok = pair_allowed(S, after ? k : o, after ? o : k);
           if (!ok) continue;
         }
         int w = after ? 0 : 1;

@@ -528,13 +528,15 @@ def test_collision_call_100k_pairs_bit_exact():
 
 
 def test_resident_step_100k_against_the_oracle():
-    """BASELINE configs[2] at full size through the RESIDENT path: two whole timesteps (ghosts, collisions, forcings of the converge / diverge
-    ocean, update) of 100 000 floes in one sz_step batch against the oracle -- pair list of the last step equal, interaction rows and totals
-    1e-10 per element, state 1e-9, guard counters equal.  (The collision call alone at this size: the test above.)"""
+    """BASELINE configs[2] at full size through the RESIDENT path: four whole timesteps (ghosts, collisions, forcings of the converge / diverge
+    ocean, update) of 100 000 floes in one sz_step batch -- pipelined steps, the forcings on their second stream -- against the oracle: pair
+    list of the last step equal, interaction rows and totals 1e-10 per element, state 1e-9, guard counters equal.  (The collision call alone
+    at this size: the test above.)"""
     cfg = _bench_cfg("configs2")
     hw, ow = _pair(cfg); ow.set_threads(_cores())
-    steps = 2
+    steps = 4
     assert hw.run(steps, 0, cfg["dt"], coupling_dt=1) == steps
+    assert hw.pipelined()
     for t in range(steps):
         ow.timestep_sim(t, cfg["dt"], coupling_dt=1)
     res = parity.compare_worlds(hw, ow, rtol=1e-9)
