@@ -157,6 +157,7 @@ struct sz_ctx {
   int gpar = 0;
   bool no_pipeline = false;         // SZ_PIPELINE=0: the three-launch steps (A/B)
   int pipe_min_steps = 4;           // batches shorter than this take the three-launch steps (a pipelined batch has a prologue and an epilogue)
+  int pipe_max_floes = 60000;       // larger fields keep the three-launch steps: they are throughput-bound, nothing idles beside the narrow phase (measured at 100 k: 0.486 against 0.476 ms; SZ_PIPE_MAX_FLOES)
   int last_pipelined = 0;           // the last sz_step batch ran pipelined (sz_debug_pipelined)
   bool no_reduce_free = false;      // SZ_REDUCE_FREE=0: keep the (rows-only) reduce launch inside every step (A/B)
   bool maybe_tagged = false;        // a parent may be non-active on the device (an upload said so, a batch ended on a tag, a process-mode call ran):
@@ -864,6 +865,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_REDUCE_FREE")) c->no_reduce_free = atoi(e) == 0;
   if (const char* e = getenv("SZ_PIPELINE")) c->no_pipeline = atoi(e) == 0;
   if (const char* e = getenv("SZ_PIPE_MIN_STEPS")) c->pipe_min_steps = std::max(2, atoi(e));
+  if (const char* e = getenv("SZ_PIPE_MAX_FLOES")) c->pipe_max_floes = atoi(e);
   if (const char* e = getenv("SZ_TILE_FORCING_TAIL")) c->tile_forcing_in_tail = atoi(e) != 0;
   if (const char* e = getenv("SZ_GHOST_INLINE")) c->ghost_inline = atoi(e) != 0;
   if (const char* e = getenv("SZ_TILE_INLINE")) c->tile_inline_off = atoi(e) == 0;
@@ -1702,7 +1704,7 @@ void pipe_adopt(sz_ctx* c, int q) {
   c->crec_buf = T.crec; c->gpar = q;
 }
 bool pipeline_eligible(const sz_ctx* c, int nsteps, bool coll, bool sg, bool gi, bool periodic, bool cr, bool rfree, int flags) {
-  return rfree && !c->no_pipeline && coll && sg && (gi || !periodic) && cr && nsteps >= c->pipe_min_steps && c->precision == 0 && !c->two_way &&
+  return rfree && !c->no_pipeline && coll && sg && (gi || !periodic) && cr && nsteps >= c->pipe_min_steps && c->hostN <= c->pipe_max_floes && c->precision == 0 && !c->two_way &&
          !c->S.any_domain_work && c->S.maxnb <= MAXNB && !larger_rings(c) && c->pb[1].vxy && c->pb[1].work && !c->pmask &&
          (c->S.capM - c->hostN) / 2 > 64 && !(c->dbg & 8) && (flags & SZ_COLLISIONS_ON);
 }

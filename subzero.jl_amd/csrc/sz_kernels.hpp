@@ -1655,22 +1655,25 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
                                                        PipeAlt PA, int nbg, int nn) {
   constexpr int GPB = TPB / G;
   const int nblk = (int)gridDim.x - (FRC != 0 ? nbf : 0) - (GEO != 0 ? nbg : 0);       // the narrow workgroups
-  if (GEO != 0 && (int)blockIdx.x >= nblk && (int)blockIdx.x < nblk + nbg) { geo_body(S, PA, dt, (int)blockIdx.x - nblk, nbg, nn); return; }
-  if (FRC != 0 && (int)blockIdx.x >= nblk) {
+  // (the GEO workgroups come FIRST: a few wavefronts per CU that fit beside the narrow ones -- those fill the LDS, not the wave slots -- and
+  //  are done long before the narrow round is; behind the narrow workgroups they would only start when those finish)
+  if (GEO != 0 && (int)blockIdx.x < nbg) { geo_body(S, PA, dt, (int)blockIdx.x, nbg, nn); return; }
+  const int bidx = (int)blockIdx.x - (GEO != 0 ? nbg : 0);        // this workgroup's number among the narrow (and, behind them, the forcing) ones
+  if (FRC != 0 && bidx >= nblk) {
     const int first = nblk + (GEO != 0 ? nbg : 0);
-    if (FRC == 1) forcing_body<false>(S, P, (int)blockIdx.x - first, nbf, 0, first);
-    else forcing_mixed_body(S, P, (int)blockIdx.x - first, nbf, first);
+    if (FRC == 1) forcing_body<false>(S, P, bidx - nblk, nbf, 0, first);
+    else forcing_mixed_body(S, P, bidx - nblk, nbf, first);
     return;
   }
   static_assert(4 * KC <= 2 * RC, "raw crossing slots alias reg[1]");
   Stamps st; STAMP_INIT(st);
 #ifdef SZ_STAMPS
-  st.on = (CLS == 0 && blockIdx.x == (unsigned)(dbg >> 8) && threadIdx.x == 0); st.log = S.stamps + 1;
+  st.on = (CLS == 0 && bidx == (dbg >> 8) && threadIdx.x == 0); st.log = S.stamps + 1;
 #endif
-  const int qk = (int)(blockIdx.x % NSEG);
+  const int qk = bidx % NSEG;
   // the first round's item of this lane group is known without the segment's length: its work-list entry is asked for
   // together with the length (one dependent round trip less in the launch's chain; an entry past the end is read and ignored)
-  const int t_first = (int)(blockIdx.x / NSEG) * (TPB / G) + (int)(threadIdx.x / G);
+  const int t_first = (bidx / NSEG) * (TPB / G) + (int)(threadIdx.x / G);
   const bool pre_ok = !(G == 64 && TPB == 64) && t_first < seg_cap(S);
   int4 pre0 = make_int4(0, 0, 0, 0), pre1 = make_int4(0, 0, 0, 0);
   if (pre_ok) { const size_t w2 = 2 * ((size_t)qk * seg_cap(S) + t_first); pre0 = S.work[w2]; pre1 = S.work[w2 + 1]; }
@@ -1697,12 +1700,12 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     // housekeeping of the step (the neighbour search has consumed the cells; the integrator fills them again): cell counts
     // and overflow heads cleared, the guard counters of the coming update reset
     const int ncells = (int)S.bounds[4] * (int)S.bounds[5];
-    for (int q = blockIdx.x * TPB + threadIdx.x; q <= ncells; q += nblk * TPB) { S.cell_cnt[q] = 0; S.cell_ovf[q] = 0; }
-    if (blockIdx.x == 0) for (int q = threadIdx.x; q < WARN_SLOTS * 4; q += TPB) S.warn[(q >> 2) * 32 + (q & 3)] = 0;
-    if (S.ginline && !GEO && blockIdx.x == 0 && threadIdx.x == 0) { S.galloc[(1 - S.gslot) * 16] = 0ull; S.galloc[(1 - S.gslot) * 16 + 1] = 0ull; }      // the allocator (and its poison mark) this step's integrator makes the next ghosts in (pipelined steps: cleared by the update of the step before -- GEO draws from it in this very launch)
+    for (int q = bidx * TPB + threadIdx.x; q <= ncells; q += nblk * TPB) { S.cell_cnt[q] = 0; S.cell_ovf[q] = 0; }
+    if (bidx == 0) for (int q = threadIdx.x; q < WARN_SLOTS * 4; q += TPB) S.warn[(q >> 2) * 32 + (q & 3)] = 0;
+    if (S.ginline && !GEO && bidx == 0 && threadIdx.x == 0) { S.galloc[(1 - S.gslot) * 16] = 0ull; S.galloc[(1 - S.gslot) * 16 + 1] = 0ull; }      // the allocator (and its poison mark) this step's integrator makes the next ghosts in (pipelined steps: cleared by the update of the step before -- GEO draws from it in this very launch)
     // a list the neighbour search outgrew (its error bits): the batch pauses in this step -- raised here, where the counter block is
     // at hand anyway, rather than in the search (which sits exactly on its register budget)
-    if (blockIdx.x == 0 && threadIdx.x == 0 && (S.cnt[C_ERR] & (ERR_CAP_NEIGH | ERR_CAP_PAIRS))) capacity_stop(S);
+    if (bidx == 0 && threadIdx.x == 0 && (S.cnt[C_ERR] & (ERR_CAP_NEIGH | ERR_CAP_PAIRS))) capacity_stop(S);
   }
   STAMP(st, 21);
   // The one-item-per-wavefront variant mostly looks for the few items meant for it: its lanes test 64
@@ -1710,7 +1713,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
   constexpr bool SCAN = (G == 64 && TPB == 64);
   constexpr int STRIDE = SCAN ? 64 : GPB;
   const bool useq = CLS == 0 && !SCAN && queue != 0;       // (the larger variants look at every item of their segment: static rounds)
-  const int rb = (int)(blockIdx.x / NSEG), nbq = (nblk + NSEG - 1 - qk) / NSEG;    // this workgroup's rank in its segment, workgroups per segment
+  const int rb = bidx / NSEG, nbq = (nblk + NSEG - 1 - qk) / NSEG;    // this workgroup's rank in its segment, workgroups per segment
   const int limit = nitems;
   // (measured and dropped: spreading the only round of a small field over ALL resident workgroups -- 6 to 7 items per wavefront
   //  instead of 8 -- made the launch 18 % SLOWER, 47 -> 56 us at 10 k floes: a SIMD issues the instruction streams of its
@@ -2040,9 +2043,9 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     unsigned v[7];
     for (int k = 0; k < 7; k++) { v[k] = gl != 0 ? 0u : k == 0 ? m.acc16[0] : k == 1 ? m.acc[0] : k == 2 ? m.acc[1] : k == 3 ? m.acc16[1] : k == 4 ? m.acc16[2] : k == 5 ? m.acc16[3] : m.acc16[4]; for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d); }
     if ((threadIdx.x & 63) == 0) {
-      unsigned long long* a = S.acc + (size_t)((blockIdx.x * (TPB / 64) + (threadIdx.x >> 6)) % ACC_SLOTS) * 8;
+      unsigned long long* a = S.acc + (size_t)((bidx * (TPB / 64) + (threadIdx.x >> 6)) % ACC_SLOTS) * 8;
       for (int k = 0; k < 7; k++) if (v[k]) atomicAdd(a + 1 + k, (unsigned long long)v[k]);
-      if (CLS == 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a, 1ull);
+      if (CLS == 0 && bidx == 0 && threadIdx.x == 0) atomicAdd(a, 1ull);
     }
   }
 #ifdef SZ_STAMPS

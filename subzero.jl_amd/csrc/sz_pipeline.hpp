@@ -126,34 +126,28 @@ __device__ __forceinline__ void vel_body(State S, const Params& P, const PipeAlt
   }
   int wh = 0, wf = 0, wv = 0, wx = 0;
   bool tested = false;
+  // Three batches of loads instead of one: the launch is compiled for the search's register budget (three wavefronts per SIMD), and the
+  // update is not what the launch waits for -- the search beside it takes longer.  (The stores of a phase keep the compiler from
+  // hoisting the next phase's loads above them.)
   for (int i = bid * (int)blockDim.x + (int)threadIdx.x; i < N; i += nblk * (int)blockDim.x) {
-    const int st0 = S.status[i], ngh0 = A.ngh[i] & 0xff, ngh1 = S.ngh[i];
-    const double rmx = S.rmax[i];
+    // ---- phase 1: the step's totals (fixed-point words of the floe and of its ghosts), tags
+    const int st0 = S.status[i], ngh0 = A.ngh[i] & 0xff;
+    const double rmx = S.rmax[i], area = S.area[i], height0 = S.height[i];
     longlong4 fa0, fa1, fa2, fa3;
     { const longlong4* a = (const longlong4*)(S.facc + (size_t)i * FX_WORDS); fa0 = a[0]; fa1 = a[1]; fa2 = a[2]; fa3 = a[3]; }
     double g_over = S.overarea[i];
     const int frc_rm = apply_frc ? S.frc_remove[i] : 0;
-    const double cx = S.cx[i], cy = S.cy[i];
-    const double area = S.area[i], height0 = S.height[i], mass0 = S.mass[i], moment0 = S.moment[i], hflx = S.hflx[i];
-    const double u = S.u[i], v = S.v[i], xi = S.xi[i], alpha0 = S.alpha[i];
-    const double p_dxdt = S.p_dxdt[i], p_dydt = S.p_dydt[i], p_dalphadt = S.p_dalphadt[i];
-    const double p_dudt = S.p_dudt[i], p_dvdt = S.p_dvdt[i], p_dxidt = S.p_dxidt[i];
-    const double fxOA = S.fxOA[i], fyOA = S.fyOA[i], trqOA = S.trqOA[i];
-    const double4 sa4 = *(const double4*)(S.sa + (size_t)i * 4);
-    const double sa0[4] = { sa4.x, sa4.y, sa4.z, sa4.w };
-    const double2* rn = S.crec + (size_t)i * 8;
-    const double2 g0 = rn[0], g3 = rn[3], g4 = rn[4];          // the geometry GEO(t) has left for step t + 1
     if (!tested) {
       loads_issued();
       if (halted) break;
       tested = true;
     }
-    // ---- totals, stress sums, tags: as sz_k_integrate (use_acc)
     double cfx, cfy, ctrq, s11 = 0, s12 = 0, s21 = 0, s22 = 0;
-    int st_new = st0; bool st_dirty = false, over_dirty = false;
+    int st_new = st0; bool st_dirty = false;
     {
       long long q[7] = { fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z }, ql[7] = { fa2.x, fa2.y, fa2.z, fa2.w, fa3.x, fa3.y, fa3.z };
       const int tagb = (int)(fa1.w & 0xffffffffll);
+      const bool dirty = (fa0.x | fa0.y | fa0.z | fa0.w | fa1.x | fa1.y | fa1.z | fa1.w | fa2.x | fa2.y | fa2.z | fa2.w | fa3.x | fa3.y | fa3.z) != 0;
       if (ngh0 != 0) {
         for (int g3i = 0; g3i < MAX_GHOSTS; g3i++) {
           const int g = A.gh[i * MAX_GHOSTS + g3i];
@@ -166,18 +160,35 @@ __device__ __forceinline__ void vel_body(State S, const Params& P, const PipeAlt
       }
       const int eF = fx_force_exp(S.kexp, area, height0), eT = eF + fx_lever_exp(rmx);
       cfx = fx_join(q[0], ql[0], eF); cfy = fx_join(q[1], ql[1], eF); ctrq = fx_join(q[4] - q[3], ql[4] - ql[3], eT);
-      S.cfx[i] = cfx; S.cfy[i] = cfy; S.ctrq[i] = ctrq;
       if ((q[0] | q[1] | q[2] | q[3] | q[4] | q[5] | ql[0] | ql[1] | ql[2] | ql[3] | ql[4] | ql[5]) != 0) {
         const double sc = 1 / (area * height0);
         s11 = fx_join(q[2], ql[2], eT) * sc; s12 = fx_join(q[3] + q[4], ql[3] + ql[4], eT) * 0.5 * sc; s21 = s12; s22 = fx_join(q[5], ql[5], eT) * sc;
       }
-      g_over = g_over + fx_join(q[6], ql[6], fx_area_exp(area)); over_dirty = (q[6] | ql[6]) != 0;
+      if ((q[6] | ql[6]) != 0) { g_over = g_over + fx_join(q[6], ql[6], fx_area_exp(area)); S.overarea[i] = g_over; }
       if (tagb & 1) st_new = SZ_FUSE;
       if (tagb & 2) st_new = SZ_REMOVE;
       if (tagb & 4) st_new = SZ_FUSE;
       st_dirty = tagb != 0 || st0 != SZ_ACTIVE;
+      S.cfx[i] = cfx; S.cfy[i] = cfy; S.ctrq[i] = ctrq;
+      if (dirty) { longlong4* a = (longlong4*)(S.facc + (size_t)i * FX_WORDS); a[0] = make_longlong4(0, 0, 0, 0); a[1] = make_longlong4(0, 0, 0, 0); a[2] = make_longlong4(0, 0, 0, 0); a[3] = make_longlong4(0, 0, 0, 0); }
     }
-    const double l = P.lambda, sv[4] = { s11, s12, s21, s22 };
+    if (st_dirty) S.status[i] = st_new;
+    if (frc_rm || st_new != SZ_ACTIVE) {
+      if (frc_rm) { S.status[i] = SZ_REMOVE; st_new = SZ_REMOVE; }
+      if (step > 0 && S.stop_on_tags) S.cnt[C_STOP] = step;          // (request_stop for THIS step: the State carries the search's number)
+    }
+    {          // calc_stress! / _update_stress_accum! (update_floe.jl:392-414, stress_calculators.jl:118-122)
+      const double l = P.lambda;
+      const double4 sa4 = *(const double4*)(S.sa + (size_t)i * 4);
+      *(double4*)(S.sa + (size_t)i * 4) = make_double4((1 - l) * sa4.x + l * s11, (1 - l) * sa4.y + l * s12, (1 - l) * sa4.z + l * s21, (1 - l) * sa4.w + l * s22);
+      *(double4*)(S.si + (size_t)i * 4) = make_double4(s11, s12, s21, s22);
+    }
+    // ---- phase 2: the update proper (update_floe.jl:482-545), sz_k_integrate's expressions
+    const double mass0 = S.mass[i], moment0 = S.moment[i], hflx = S.hflx[i];
+    const double u = S.u[i], v = S.v[i], xi = S.xi[i], alpha0 = S.alpha[i];
+    const double p_dxdt = S.p_dxdt[i], p_dydt = S.p_dydt[i], p_dalphadt = S.p_dalphadt[i];
+    const double p_dudt = S.p_dudt[i], p_dvdt = S.p_dvdt[i], p_dxidt = S.p_dxidt[i];
+    const double fxOA = S.fxOA[i], fyOA = S.fyOA[i], trqOA = S.trqOA[i];
     double hh = height0;
     if (hh > P.max_h) { hh = P.max_h; wh++; }
     double mass = mass0;
@@ -186,12 +197,10 @@ __device__ __forceinline__ void vel_body(State S, const Params& P, const PipeAlt
     double dh = hflx / h;
     double hfrac = (h + dh) / h;
     mass *= hfrac; double moment = moment0 * hfrac; h -= dh;
-    const double dx = 1.5 * dt * u - 0.5 * dt * p_dxdt;
-    const double dy = 1.5 * dt * v - 0.5 * dt * p_dydt;
     double da = 1.5 * dt * xi - 0.5 * dt * p_dalphadt;
     const double al = alpha0 + da;
-    double cal, sal, cda, sda;
-    sincos(al, &sal, &cal); sincos(da, &sda, &cda);
+    double cal, sal;
+    sincos(al, &sal, &cal);
     double dudt = (fxOA + cfx) / mass, dvdt = (fyOA + cfy) / mass;
     double frac = 1.0, au = fabs(dt * dudt), av = fabs(dt * dvdt), h2 = h / 2;
     if (au > h2 && av > h2) {
@@ -206,18 +215,6 @@ __device__ __forceinline__ void vel_body(State S, const Params& P, const PipeAlt
     dxidt = frac * dxidt;
     double nxi = xi + 1.5 * dt * dxidt - 0.5 * dt * p_dxidt;
     if (fabs(nxi) > P.max_xi) { nxi = sgn(nxi) * P.max_xi; wx++; }
-    // ---- stores
-    if (over_dirty) S.overarea[i] = g_over;
-    if ((fa0.x | fa0.y | fa0.z | fa0.w | fa1.x | fa1.y | fa1.z | fa1.w | fa2.x | fa2.y | fa2.z | fa2.w | fa3.x | fa3.y | fa3.z) != 0) {
-      longlong4* a = (longlong4*)(S.facc + (size_t)i * FX_WORDS); a[0] = make_longlong4(0, 0, 0, 0); a[1] = make_longlong4(0, 0, 0, 0); a[2] = make_longlong4(0, 0, 0, 0); a[3] = make_longlong4(0, 0, 0, 0);
-    }
-    if (st_dirty) S.status[i] = st_new;
-    if (frc_rm || st_new != SZ_ACTIVE) {
-      if (frc_rm) { S.status[i] = SZ_REMOVE; st_new = SZ_REMOVE; }
-      if (step > 0 && S.stop_on_tags) S.cnt[C_STOP] = step;          // (request_stop for THIS step: the State carries the search's number)
-    }
-    *(double4*)(S.sa + (size_t)i * 4) = make_double4((1 - l) * sa0[0] + l * sv[0], (1 - l) * sa0[1] + l * sv[1], (1 - l) * sa0[2] + l * sv[2], (1 - l) * sa0[3] + l * sv[3]);
-    *(double4*)(S.si + (size_t)i * 4) = make_double4(sv[0], sv[1], sv[2], sv[3]);
     S.mass[i] = mass; S.moment[i] = moment; S.height[i] = h;
     S.alpha[i] = al;
     *(double2*)(S.trig + (size_t)i * 2) = make_double2(cal, sal);
@@ -225,23 +222,26 @@ __device__ __forceinline__ void vel_body(State S, const Params& P, const PipeAlt
     S.u[i] = nu; S.v[i] = nv;
     S.p_dudt[i] = dudt; S.p_dvdt[i] = dvdt;
     S.xi[i] = nxi; S.p_dxidt[i] = dxidt;
-    // the columns follow the record GEO(t) wrote (for a parent that swapped with its ghost: the swapped place)
-    S.cx[i] = g0.x; S.cy[i] = g0.y; S.bbx0[i] = g3.x; S.bbx1[i] = g3.y; S.bby0[i] = g4.x; S.bby1[i] = g4.y;
-    {
-      double2* r = S.crec + (size_t)i * 8;
-      r[5] = make_double2(nu, nv); r[6] = make_double2(nxi, area); r[7].x = h;
+    // ---- phase 3: the columns follow the record GEO(t) wrote (for a parent that swapped with its ghost: the swapped place); the record
+    // and the ghosts GEO(t) made of this parent take the new kinematic columns (deepcopy of the parent, collisions.jl:893)
+    const int ngh1 = S.ngh[i];
+    const double cx = S.cx[i], cy = S.cy[i];
+    double2* r = S.crec + (size_t)i * 8;
+    const double2 g0 = r[0], g3 = r[3], g4 = r[4];
+    if (last_step) {          // behind the batch: the rows of this step (levers about the old centroid) and, after a stop, the un-swap of the parents
+      double cda, sda;
+      sincos(da, &sda, &cda);
+      *(double4*)(S.mot + (size_t)i * 4) = make_double4(cx, cy, 1.5 * dt * u - 0.5 * dt * p_dxdt, 1.5 * dt * v - 0.5 * dt * p_dydt);
+      *(double2*)(S.mot2 + (size_t)i * 2) = make_double2(cda, sda);
     }
-    // the ghosts GEO(t) made of this parent carry the parent's kinematic columns of step t + 1 (deepcopy of the parent, collisions.jl:893)
+    S.cx[i] = g0.x; S.cy[i] = g0.y; S.bbx0[i] = g3.x; S.bbx1[i] = g3.y; S.bby0[i] = g4.x; S.bby1[i] = g4.y;
+    r[5] = make_double2(nu, nv); r[6] = make_double2(nxi, area); r[7].x = h;
     for (int q = 0; q < (ngh1 & 0xff); q++) {
       const int g = S.gh[i * MAX_GHOSTS + q];
       if (g < 0) continue;
-      double2* r = S.crec + (size_t)g * 8;
-      r[5] = make_double2(nu, nv); r[6] = make_double2(nxi, area); r[7].x = h;
+      double2* rg = S.crec + (size_t)g * 8;
+      rg[5] = make_double2(nu, nv); rg[6] = make_double2(nxi, area); rg[7].x = h;
       S.u[g] = nu; S.v[g] = nv; S.xi[g] = nxi; S.height[g] = h; S.overarea[g] = g_over;
-    }
-    if (last_step) {          // behind the batch: the rows of this step (levers about the old centroid) and, after a stop, the un-swap of the parents
-      *(double4*)(S.mot + (size_t)i * 4) = make_double4(cx, cy, dx, dy);
-      *(double2*)(S.mot2 + (size_t)i * 2) = make_double2(cda, sda);
     }
   }
   for (int d = 32; d >= 1; d >>= 1) { wh += __shfl_xor(wh, d); wf += __shfl_xor(wf, d); wv += __shfl_xor(wv, d); wx += __shfl_xor(wx, d); }

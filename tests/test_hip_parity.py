@@ -532,8 +532,14 @@ def test_resident_step_100k_against_the_oracle():
     ocean, update) of 100 000 floes in one sz_step batch -- pipelined steps, the forcings on their second stream -- against the oracle: pair
     list of the last step equal, interaction rows and totals 1e-10 per element, state 1e-9, guard counters equal.  (The collision call alone
     at this size: the test above.)"""
+    import os
     cfg = _bench_cfg("configs2")
-    hw, ow = _pair(cfg); ow.set_threads(_cores())
+    os.environ["SZ_PIPE_MAX_FLOES"] = "1000000"          # (fields of this size take the three-launch steps by default: the pipelined ones are held to the oracle here)
+    try:
+        hw, ow = _pair(cfg)
+    finally:
+        del os.environ["SZ_PIPE_MAX_FLOES"]
+    ow.set_threads(_cores())
     steps = 4
     assert hw.run(steps, 0, cfg["dt"], coupling_dt=1) == steps
     assert hw.pipelined()
