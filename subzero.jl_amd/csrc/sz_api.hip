@@ -157,6 +157,7 @@ struct sz_ctx {
   int gpar = 0;
   bool no_pipeline = false;         // SZ_PIPELINE=0: the three-launch steps (A/B)
   int pipe_min_steps = 4;           // batches shorter than this take the three-launch steps (a pipelined batch has a prologue and an epilogue)
+  int frc_first = 0;                // SZ_FRC_FIRST=n: the forcing tail of the narrow launch as n persistent workgroups in FRONT of the narrow ones (0: behind them)
   int pipe_max_floes = 60000;       // larger fields keep the three-launch steps: they are throughput-bound, nothing idles beside the narrow phase (measured at 100 k: 0.486 against 0.476 ms; SZ_PIPE_MAX_FLOES)
   int last_pipelined = 0;           // the last sz_step batch ran pipelined (sz_debug_pipelined)
   bool no_reduce_free = false;      // SZ_REDUCE_FREE=0: keep the (rows-only) reduce launch inside every step (A/B)
@@ -574,9 +575,11 @@ void stage_narrow(sz_ctx* c, int dt, double ffmo, double fdmo, bool housekept = 
       if (getenv("SZ_VERBOSE")) fprintf(stderr, "[subzero-hip] narrow: %d workgroups per CU x %d CUs\n", per_cu, cus);
     }
     const int nbn = grid_for(capItems, TPB / G, grid);
-    const int nbf = frc ? grid_for(S.capM, TPB / FRC_PLAIN, 32768) : 0;
-    if (frc == 1) hipLaunchKernelGGL((sz_k_narrow<G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 1>), dim3(nbn + nbf), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, nbf, PipeAlt{}, 0, 0);
-    else if (frc == 2) hipLaunchKernelGGL((sz_k_narrow<G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 2>), dim3(nbn + nbf), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, nbf, PipeAlt{}, 0, 0);
+    int nbf = frc ? grid_for(S.capM, TPB / FRC_PLAIN, 32768) : 0;
+    const int nbfg = c->frc_first > 0 && nbf > 0 ? std::min(c->frc_first, nbf) : nbf;      // (workgroups in the grid)
+    if (c->frc_first > 0 && nbf > 0) nbf = -nbfg;
+    if (frc == 1) hipLaunchKernelGGL((sz_k_narrow<G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 1>), dim3(nbn + nbfg), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, nbf, PipeAlt{}, 0, 0);
+    else if (frc == 2) hipLaunchKernelGGL((sz_k_narrow<G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 2>), dim3(nbn + nbfg), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, nbf, PipeAlt{}, 0, 0);
     else hipLaunchKernelGGL(kern, dim3(nbn), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0, PipeAlt{}, 0, 0);
     if (c->dbg & 8)       // timing experiment: the same launch again (same results) -- how much of a launch is a cold instruction cache?
       hipLaunchKernelGGL(kern, dim3(nbn), dim3(TPB), 0, c->stream, S, c->P, dt, ffmo, fdmo, c->dbg, queue, 0, PipeAlt{}, 0, 0);
@@ -866,6 +869,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_PIPELINE")) c->no_pipeline = atoi(e) == 0;
   if (const char* e = getenv("SZ_PIPE_MIN_STEPS")) c->pipe_min_steps = std::max(2, atoi(e));
   if (const char* e = getenv("SZ_PIPE_MAX_FLOES")) c->pipe_max_floes = atoi(e);
+  if (const char* e = getenv("SZ_FRC_FIRST")) c->frc_first = std::max(0, atoi(e));
   if (const char* e = getenv("SZ_TILE_FORCING_TAIL")) c->tile_forcing_in_tail = atoi(e) != 0;
   if (const char* e = getenv("SZ_GHOST_INLINE")) c->ghost_inline = atoi(e) != 0;
   if (const char* e = getenv("SZ_TILE_INLINE")) c->tile_inline_off = atoi(e) == 0;
@@ -1768,9 +1772,11 @@ int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling
     const bool coupling = coupling_at(s);
     const bool overlap = coupling && (c->overlap_forcing >= 0 ? c->overlap_forcing != 0 : N > 65536);
     if (overlap) stage_forcing_fork(c, &T);
-    const int nbf = coupling && !overlap ? grid_for(S0.capM, TPB / FRC_PLAIN, 32768) : 0;
+    int nbf = coupling && !overlap ? grid_for(S0.capM, TPB / FRC_PLAIN, 32768) : 0;
+    const int nbfg = c->frc_first > 0 && nbf > 0 ? std::min(c->frc_first, nbf) : nbf;
+    if (c->frc_first > 0 && nbf > 0) nbf = -nbfg;
     if (coupling) c->forcing_where = overlap ? 0 : 2;
-    if (nbf) hipLaunchKernelGGL((sz_k_narrow<NARROW_G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 1, 1>), dim3(nbn + nbg + nbf), dim3(TPB), 0, c->stream,
+    if (nbf) hipLaunchKernelGGL((sz_k_narrow<NARROW_G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 1, 1>), dim3(nbn + nbg + nbfg), dim3(TPB), 0, c->stream,
                                 T, c->P, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, c->dbg, queue, nbf, A, nbg, N);
     else hipLaunchKernelGGL((sz_k_narrow<NARROW_G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 0, 1>), dim3(nbn + nbg), dim3(TPB), 0, c->stream,
                             T, c->P, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, c->dbg, queue, 0, A, nbg, N);
@@ -2581,6 +2587,33 @@ int comm_agree_bits(sz_ctx* c, int local, int* all) {
   return SZ_OK;
 }
 // sync + sticky device errors of THIS rank + agreement: SZ_OK on every rank or the same error code on every rank
+// one int of every rank (n <= 64), on every rank
+int comm_gather_int(sz_ctx* c, int local, int* all64) {
+  const int n = c->comm_n;
+  all64[0] = local;
+  if (n == 1) return SZ_OK;
+  int* d = (int*)(c->d_gather + 8 + 8 * 64 + 64 * 64 / 2);
+  HIPCHK(c, hipMemcpyAsync(d, &local, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  int rc = comm_allgather(c, d, d + 32, 1, NCCL_INT32, sizeof(int));
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(all64, d + 32, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SZ_OK;
+}
+// The two words that decide how a tiled batch goes on -- the step a tag ended it at (C_STOP) and the step that paused for the largest narrow
+// variant or a list that outgrew its capacity (C_RETRYSTOP) -- as ALL ranks must see them before anyone branches: the smallest non-zero
+// value of each.  A rank's own counters are not enough: a pause on one rank and a tag on another in the SAME step are not heard by either
+// (the unpack kernels of the next step return at their stop test before they read the peers' headers), and ranks that then take
+// different branches wait for each other in different collectives.
+int comm_agree_steps(sz_ctx* c, int stop_local, int pause_local, int* stop_all, int* pause_all) {
+  int a[64], b[64];
+  int rc = comm_gather_int(c, stop_local, a); if (rc) return rc;
+  rc = comm_gather_int(c, pause_local, b); if (rc) return rc;
+  int s = 0, p = 0;
+  for (int r = 0; r < c->comm_n; r++) { if (a[r] > 0 && (s == 0 || a[r] < s)) s = a[r]; if (b[r] > 0 && (p == 0 || b[r] < p)) p = b[r]; }
+  *stop_all = s; *pause_all = p;
+  return SZ_OK;
+}
 int tile_sync_agree(sz_ctx* c, int* cnt_out = nullptr) {
   int rc = sync_and_check(c, cnt_out);
   if (rc == SZ_E_HIP) return rc;              // (the runtime itself failed: nothing to agree on)
@@ -3496,8 +3529,11 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     if (rc2) return fail(rc2);
     if (all) return fail(SZ_E_CAPACITY);
   }
-  const int sp = h[C_RETRYSTOP];                 // 1-based step that was paused, here or on a peer (0: none)
-  if (!lean || sp <= 0 || (h[C_STOP] > 0 && h[C_STOP] < sp)) break;
+  // the step that was paused (here or on a peer) and the step a tag ended the batch at, as every rank sees them (comm_agree_steps)
+  int sp = h[C_RETRYSTOP], st_all = h[C_STOP];
+  { const int rc3 = comm_agree_steps(c, h[C_STOP], h[C_RETRYSTOP], &st_all, &sp); if (rc3) return fail(rc3); }
+  if (st_all > 0) h[C_STOP] = st_all;
+  if (!lean || sp <= 0 || (st_all > 0 && st_all < sp)) break;
   // ---- a pause for the largest narrow variant in step sp
   const int tsp = tstep0 + sp - 1;
   const bool coupling_sp = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tsp % coupling_dt) == 0;
@@ -3521,9 +3557,10 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     if (rmode == 2 && sp >= nsteps) stage_reduce(c, 1, -1, dt, 0, true);
   }
   c->tile_dirty = true;
-  if (sp >= nsteps) {               // (the last step of the batch: no peer has heard of it, nothing is run again)
+  if (sp >= nsteps || (st_all > 0 && st_all <= sp)) {               // (the last step of the batch -- or a peer tagged a floe in this very step: the batch ends with it -- nothing is run again)
     rc = sync_and_check(c, h);
     if (rc == SZ_E_HIP) return fail(rc);
+    if (st_all > 0) h[C_STOP] = h[C_STOP] > 0 ? std::min(h[C_STOP], st_all) : st_all;
     break;
   }
   // the rest of the batch again, from the floes as they lie after step sp (sz_step's capacity restart does the same)

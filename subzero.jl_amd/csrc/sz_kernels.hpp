@@ -1654,16 +1654,23 @@ template <int G, int CAP, int KC, int RC, int RM, int TPB, int LO, int CLS, int 
 __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int dt, double ff_max_overlap, double fd_max_overlap, int dbg, int queue, int nbf,
                                                        PipeAlt PA, int nbg, int nn) {
   constexpr int GPB = TPB / G;
-  const int nblk = (int)gridDim.x - (FRC != 0 ? nbf : 0) - (GEO != 0 ? nbg : 0);       // the narrow workgroups
+  // nbf < 0: -nbf forcing workgroups IN FRONT of the narrow ones (a few persistent wavefronts per CU that walk all floes, in the wave slots the
+  // narrow workgroups -- which fill the LDS -- leave free) instead of behind them
+  const int nf = nbf < 0 ? -nbf : nbf;
+  const int nblk = (int)gridDim.x - (FRC != 0 ? nf : 0) - (GEO != 0 ? nbg : 0);       // the narrow workgroups
   // (the GEO workgroups come FIRST: a few wavefronts per CU that fit beside the narrow ones -- those fill the LDS, not the wave slots -- and
   //  are done long before the narrow round is; behind the narrow workgroups they would only start when those finish)
   if (GEO != 0 && (int)blockIdx.x < nbg) { geo_body(S, PA, dt, (int)blockIdx.x, nbg, nn); return; }
-  const int bidx = (int)blockIdx.x - (GEO != 0 ? nbg : 0);        // this workgroup's number among the narrow (and, behind them, the forcing) ones
-  if (FRC != 0 && bidx >= nblk) {
-    const int first = nblk + (GEO != 0 ? nbg : 0);
-    if (FRC == 1) forcing_body<false>(S, P, bidx - nblk, nbf, 0, first);
-    else forcing_mixed_body(S, P, bidx - nblk, nbf, first);
-    return;
+  int bidx = (int)blockIdx.x - (GEO != 0 ? nbg : 0);        // this workgroup's number among the narrow ones
+  if (FRC != 0) {
+    int fb = -1, first = 0;
+    if (nbf < 0) { if (bidx < nf) { fb = bidx; first = GEO != 0 ? nbg : 0; } else bidx -= nf; }
+    else if (bidx >= nblk) { fb = bidx - nblk; first = nblk + (GEO != 0 ? nbg : 0); }
+    if (fb >= 0) {
+      if (FRC == 1) forcing_body<false>(S, P, fb, nf, 0, first);
+      else forcing_mixed_body(S, P, fb, nf, first);
+      return;
+    }
   }
   static_assert(4 * KC <= 2 * RC, "raw crossing slots alias reg[1]");
   Stamps st; STAMP_INIT(st);

@@ -639,6 +639,77 @@ def _tag_scenario(w, kind):
     return w
 
 
+def _ab_worlds(build, env_off):
+    """two contexts on the same input: the default engine and the one with the switches of env_off in the environment (read at sz_create)"""
+    import os
+    a = build(mk())
+    for k, v in env_off.items():
+        os.environ[k] = v
+    try:
+        b = build(mk())
+    finally:
+        for k in env_off:
+            del os.environ[k]
+    return a, b
+
+
+def _assert_worlds_bit_equal(a, b, fields=None):
+    for f in fields or parity.SCALARS:
+        assert np.array_equal(a.get(f), b.get(f)), f
+    assert np.array_equal(a.rings()[1], b.rings()[1]) and np.array_equal(a.rings()[2], b.rings()[2])
+    ia, ib = a.interactions(), b.interactions()
+    assert np.array_equal(ia[0], ib[0]) and np.array_equal(ia[1], ib[1])
+    assert np.array_equal(a.ids()[2], b.ids()[2]) and a.fuse() == b.fuse()
+    pa, pb = a.pairs(), b.pairs()
+    assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1])
+
+
+@pytest.mark.parametrize("scenario", ["dense", "fast-through", "fast-stops", "fuse-stop", "retry-pause", "tagged-before"])
+def test_pipelined_steps_equal_the_three_launch_steps(scenario):
+    """Pipelined resident steps (csrc/sz_pipeline.hpp: narrow phase | next geometry, then update | next neighbour search -- two launches per
+    timestep) against the three-launch steps (SZ_PIPELINE=0), bit for bit: every column, the rings, floe.interactions, the pair list, the status
+    tags and status.fuse_idx.  dense: a plain periodic field; fast-through: fast floes that cross the periodic walls (parents swap with their
+    ghosts) and fuse, in batches that run through -- a new tag restarts the enqueued steps so that the next ghosts know it; fast-stops: the same
+    with the tag stop (the state handed back has the parents un-swapped again); fuse-stop: the reference's stop on a fuse in the middle of a
+    batch; retry-pause: the pause for the largest narrow variant inside a pipelined step; tagged-before: a parent already tagged when the batch
+    starts (its first step runs on its own)."""
+    from subzero_jl_amd import fields
+    if scenario in ("dense", "fast-through", "fast-stops", "tagged-before"):
+        cfg = fields.make_config(n_floes=1500, seed=77, concentration=0.8)
+        def build(w):
+            fields.build_world(w, cfg)
+            if scenario.startswith("fast"):
+                rng = np.random.default_rng(3)
+                w.set("u", rng.uniform(-40.0, 40.0, cfg["n_floes"])); w.set("v", rng.uniform(-40.0, 40.0, cfg["n_floes"]))
+            if scenario == "tagged-before":
+                st = np.ones(cfg["n_floes"], np.int32); st[17] = cases.FUSE
+                w.set_status(st)
+            return w
+        dt = cfg["dt"]
+        plan = {"dense": [(25, True), (6, True)], "fast-through": [(9, False), (14, False)], "fast-stops": [(12, True)] * 6, "tagged-before": [(8, True)]}[scenario]
+    elif scenario == "fuse-stop":
+        build = lambda w: _tag_scenario(w, "fuse"); dt = 10; plan = [(12, True)]
+    else:
+        build = _retry_scenario; dt = 10; plan = [(8, False), (5, False)]
+    a, b = _ab_worlds(build, {"SZ_PIPELINE": "0"})
+    t = 0; ran_pipelined = False
+    for n, stop in plan:
+        coupling = scenario not in ("fuse-stop", "retry-pause")
+        da = a.run(n, t, dt, coupling_dt=1 if coupling else 10, coupling_on=coupling, stop_on_tags=stop)
+        db = b.run(n, t, dt, coupling_dt=1 if coupling else 10, coupling_on=coupling, stop_on_tags=stop)
+        assert da == db and not b.pipelined()
+        ran_pipelined |= a.pipelined()
+        _assert_worlds_bit_equal(a, b)
+        t += da
+    assert ran_pipelined, scenario
+    if scenario == "fast-stops":
+        assert t < 72                                             # batches really ended on tags
+    if scenario == "fuse-stop":
+        assert 2 <= t < 12
+    if scenario == "retry-pause":
+        assert a.stats()["n_retry"] >= 1
+
+
 @pytest.mark.parametrize("kind", ["fuse", "open"])
 def test_resident_batch_stops_when_a_floe_is_tagged(kind):
     """The reference runs simplify_floes! after EVERY step (simulation.jl:205-214).  A resident batch therefore ends

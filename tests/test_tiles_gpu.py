@@ -546,6 +546,98 @@ def test_tiled_batch_pauses_for_the_largest_narrow_variant(x0):
     assert paused == ({0} if x0 < 4.5e4 else {0, 1}), paused
 
 
+def _pause_and_tag_cfg(w0):
+    """the two stars of _retry_cfg on the left tile (their pair needs the largest narrow variant a few steps in) and, on the right tile, two
+    squares closing in on each other from an initial overlap of w0 metres until they fuse (collisions.jl:366)"""
+    from subzero_jl_amd import floe as floe_mod
+    cfg = _retry_cfg(4.0e4)
+    sq = lambda x0_, y0, s=1e4: np.array([[x0_, y0], [x0_, y0 + s], [x0_ + s, y0 + s], [x0_ + s, y0], [x0_, y0]])
+    off = cfg["vert_off"]
+    rings = [np.stack([cfg["vx"][off[k]:off[k + 1]], cfg["vy"][off[k]:off[k + 1]]], 1) for k in range(2)]
+    rings += [sq(6.0e4, 1.5e4), sq(7.0e4 - w0, 1.6e4)]
+    n = len(rings)
+    off = np.zeros(n + 1, np.int32); off[1:] = np.cumsum([len(r) for r in rings])
+    vx = np.concatenate([r[:, 0] for r in rings]); vy = np.concatenate([r[:, 1] for r in rings])
+    cfg.update(n_floes=n, vert_off=off, vx=vx, vy=vy, height=np.full(n, 0.5), u=np.array([0.0, -30.0, 3.0, -3.0]), v=np.zeros(n), xi=np.zeros(n),
+               derived=floe_mod.derive(off, vx, vy, np.full(n, 0.5)), sub_off=np.zeros(n + 1, np.int32))
+    return cfg
+
+
+def _worker_pause_and_tag(rank, world, port, w0, q):
+    import torch.distributed as dist
+    from subzero_jl_amd import tiles
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        cfg = _pause_and_tag_cfg(w0)
+        tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True, backend="library-host", rebox_every=3, drift_margin=3000.0)
+        done = tw.run(10, 0, 10, coupling_dt=10, coupling_on=False, stop_on_tags=True)
+        q.put((rank, tw.gidx, {f: tw.owned(f) for f in FIELDS + ["status"]}, done, int(tw.world.stats()["n_retry"])))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_worker_pause_and_tag(*a):
+    _guard(_worker_pause_and_tag)(*a)
+
+
+def test_a_pause_on_one_rank_and_a_tag_on_another_in_the_same_step():
+    """Rank 0's narrow phase meets an item for the largest variant in step k (it pauses inside that step) while rank 1 tags a floe `fuse` in the
+    very same step (the batch ends after it).  Neither rank hears of the other's word through the halo headers -- the unpack kernels of step
+    k + 1 return at their own stop test first -- so the ranks agree on both words before anyone branches (comm_agree_steps): rank 0 finishes
+    its step, both return after step k with the single context's state.  The overlap of the fusing pair is tuned (with the single context) so
+    that the two events fall into one step."""
+    import torch.multiprocessing as mp
+    import subzero_jl_amd
+    from subzero_jl_amd import fields
+
+    def events(w0):
+        hw = fields.build_world(subzero_jl_amd.World(0), _pause_and_tag_cfg(w0))
+        pause = fuse = None
+        for k in range(12):
+            d = hw.run(1, k, 10, coupling_dt=10, coupling_on=False, stop_on_tags=True)
+            if pause is None and hw.stats()["n_retry"] >= 1:
+                pause = k + 1
+            if np.any(hw.get("status")[2:] != 1):
+                fuse = k + 1
+                break
+        return pause, fuse
+    w0 = None
+    for cand in range(5900, 6110, 15):
+        p_, f_ = events(float(cand))
+        if p_ is not None and f_ == p_:
+            w0 = float(cand); k = p_
+            break
+    assert w0 is not None, "no overlap puts the fuse into the pause's step"
+    assert 2 <= k <= 9
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_run_worker_pause_and_tag, args=(r, 2, port, w0, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = _collect(q, 2)
+        for p in procs:
+            p.join(60)
+        assert all(p.exitcode == 0 for p in procs)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    hw = fields.build_world(subzero_jl_amd.World(0), _pause_and_tag_cfg(w0))
+    assert hw.run(10, 0, 10, coupling_dt=10, coupling_on=False, stop_on_tags=True) == k
+    paused = set(); tagged = set()
+    for rank, gidx, out, done, nretry in res:
+        assert done == k, (rank, done, k)
+        if nretry:
+            paused.add(rank)
+        if np.any(out["status"] != 1):
+            tagged.add(rank)
+        for f in FIELDS + ["status"]:
+            assert np.array_equal(out[f], hw.get(f)[gidx]), (rank, f)
+    assert paused == {0} and tagged == {1}, (paused, tagged)
+
+
 # ---------------------------------------------------------------- migration inside the library
 def _worker_migrate(rank, world, port, n, seed, steps, every, q, shape="star", fast=True, stop=False):
     import time
