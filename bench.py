@@ -323,7 +323,7 @@ def step_traffic(workload, n_floes, narrow_kernel):
     for k, v in ent.items():
         if k == "_meta":
             continue
-        if k == narrow_kernel or k.startswith(("sz_k_neighbors", "sz_k_inter_fill", "sz_k_integrate<true", "sz_k_elem_scan_fill", "sz_k_ghost_list")):
+        if k == narrow_kernel or k.startswith(("sz_k_neighbors", "sz_k_inter_fill", "sz_k_integrate<true", "sz_k_vel_search", "sz_k_elem_scan_fill", "sz_k_ghost_list")):
             pick[k] = float(v["hbm_bytes_per_launch"])
     return {"per_launch_bytes": pick, "bytes": sum(pick.values())} if pick else None
 
@@ -678,7 +678,12 @@ def main():
         b_narrow = narrow_algorithmic_bytes(win)
         # small fields: the step's forcings ride in the narrow launch (its tail) -- the launch the events bracket then does both
         rides = forcing_where == 2 and coupling_dt == 1
-        b_launch = b_narrow + (forcing_algorithmic_bytes(st) if rides else 0)
+        # pipelined steps (two launches per timestep, csrc/sz_pipeline.hpp): the launch also moves the rings for the NEXT step (GEO) -- its share
+        # of B_integ of SURVEY.md section 8(d): every ring point read and written (4 w per point), 8 columns read and the 6 geometry words of
+        # the floe's collision record written per floe
+        pipelined = bool(hw.pipelined()) if hasattr(hw, "pipelined") else False
+        b_geo = (4 * W * st["n_ring_points"] + st["N"] * 14 * W) if pipelined else 0
+        b_launch = b_narrow + (forcing_algorithmic_bytes(st) if rides else 0) + b_geo
         achieved = b_launch / (narrow_ms * 1e-3) / 1e9 if narrow_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic(workload, cfg["n_floes"], kernel_name) if not tiled else (None, "tiled run")
         step_bytes = step_algorithmic_bytes({**st, **win})
@@ -702,12 +707,15 @@ def main():
                        "n_floes": cfg["n_floes"], "seed": cfg["seed"], "coupling_dt": coupling_dt, "two_way_coupling": bool(args.two_way),
                        "tiles": world if tiled else 1, "timed_step_window": [t_relaxed + args.warmup, tstep]},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
-                         "kernel_note": ("narrow phase + the step's forcings in one launch (the forcings run in the tail of the narrow phase's single round): "
-                                         "algorithmic bytes = B_narrow + B_force") if rides else "narrow phase",
+                         "kernel_note": (("narrow phase + the step's forcings in one launch (the forcings run in the tail of the narrow phase's single round): "
+                                          "algorithmic bytes = B_narrow + B_force") if rides else "narrow phase") +
+                                        (" + the ring move, boxes, records, cells and periodic ghosts of the NEXT step (GEO, pipelined steps: + B_geo = 4w per ring point + 14w per floe)" if pipelined else ""),
+                         "pipelined_steps": pipelined,
+                         "launches_per_step": 2 if pipelined else 3,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "measured_copy_ceiling": ceiling, "frac_of_measured_ceiling": achieved / ceiling if ceiling > 0 else None,
                          "kernel_ms": narrow_ms, "kernel_launches_timed": n_launch, "algorithmic_bytes_per_launch": b_launch,
-                         "algorithmic_bytes_narrow_only": b_narrow,
+                         "algorithmic_bytes_narrow_only": b_narrow, "algorithmic_bytes_geo": b_geo,
                          "counts_per_launch": win, "direction_checks": dirchk, "counts_note": "device counters accumulated over the launches the event time averages (the middle timed block)",
                          "step_algorithmic_bytes": step_bytes,
                          "step_frac": step_bytes / (el / args.steps) / 1e9 / HBM_PEAK_GBS,

@@ -1709,7 +1709,7 @@ void pipe_adopt(sz_ctx* c, int q) {
 }
 bool pipeline_eligible(const sz_ctx* c, int nsteps, bool coll, bool sg, bool gi, bool periodic, bool cr, bool rfree, int flags) {
   return rfree && !c->no_pipeline && coll && sg && (gi || !periodic) && cr && nsteps >= c->pipe_min_steps && c->hostN <= c->pipe_max_floes && c->precision == 0 && !c->two_way &&
-         !c->S.any_domain_work && c->S.maxnb <= MAXNB && !larger_rings(c) && c->pb[1].vxy && c->pb[1].work && !c->pmask &&
+         !c->S.any_domain_work && c->S.maxnb <= MAXNB && !larger_rings(c) && c->pb[1].vxy && c->pb[1].work &&
          (c->S.capM - c->hostN) / 2 > 64 && !(c->dbg & 8) && (flags & SZ_COLLISIONS_ON);
 }
 
@@ -1776,10 +1776,12 @@ int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling
     const int nbfg = c->frc_first > 0 && nbf > 0 ? std::min(c->frc_first, nbf) : nbf;
     if (c->frc_first > 0 && nbf > 0) nbf = -nbfg;
     if (coupling) c->forcing_where = overlap ? 0 : 2;
+    Timed tm(c, SZ_K_NARROW);          // (event-timed classes of a pipelined step: "narrow" = L1, "integrate" = L2)
     if (nbf) hipLaunchKernelGGL((sz_k_narrow<NARROW_G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 1, 1>), dim3(nbn + nbg + nbfg), dim3(TPB), 0, c->stream,
                                 T, c->P, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, c->dbg, queue, nbf, A, nbg, N);
     else hipLaunchKernelGGL((sz_k_narrow<NARROW_G, NARROW_CAP0, NARROW_KC0, NARROW_RC0, 4, TPB, 0, 0, 3, 0, 1>), dim3(nbn + nbg), dim3(TPB), 0, c->stream,
                             T, c->P, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, c->dbg, queue, 0, A, nbg, N);
+    tm.end();
     if (!lean) {          // the largest variant takes what the small one hands on (see stage_narrow)
       hipLaunchKernelGGL((sz_k_narrow<64, NARROW_CAP2, NARROW_KC2, NARROW_RC2, 16, 64, NARROW_CAP1, 2>), dim3(grid_for(capItems, 1, 256)), dim3(64), 0,
                          c->stream, T, c->P, dt, c->P.ff_max_overlap, c->P.fd_max_overlap, c->dbg, queue, 0, PipeAlt{}, 0, 0);
@@ -1792,8 +1794,10 @@ int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling
     const PipeAlt A = pipe_alt(c, par(s), 0);
     const int nbv = grid_for(N, NB_TPB, 1 << 20), nbs = with_search ? grid_for(S0.capM, NB_TPB / NB_G, 8192) : 0;
     const int am = 1 | 4 | (host_last ? 2 : 0);
+    Timed tm(c, SZ_K_INTEGRATE);
     if (fam) hipLaunchKernelGGL((sz_k_vel_search<true>), dim3(nbv + nbs), dim3(NB_TPB), 0, c->stream, T, c->P, A, dt, coupling_at(s) ? 1 : 0, nbv, N, am);
     else hipLaunchKernelGGL((sz_k_vel_search<false>), dim3(nbv + nbs), dim3(NB_TPB), 0, c->stream, T, c->P, A, dt, coupling_at(s) ? 1 : 0, nbv, N, am);
+    tm.end();
   };
   // what lies behind the last step `last` (0-based) of the batch: parents un-swapped after a tag stop, strain, the step's rows, rows home, ghosts off
   auto epilogue = [&](int last, bool after_device_stop) -> int {
