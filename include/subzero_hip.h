@@ -277,6 +277,9 @@ int sz_narrow_kernel_name(sz_ctx *ctx, char *buf, int32_t n);
 int sz_tile_enable(sz_ctx *ctx, const int64_t *gidx, double max_ring, double max_rmax);
 int sz_owned_box(sz_ctx *ctx, double *out5);
 int sz_halo_record_doubles(void);
+/* ... of THIS context after sz_tile_enable: the records have room for the largest ring of all ranks' floes (12 + 2 x ring capacity, at
+   least the value above; rings of up to 255 points, as in a single context -- Floe rings are unbounded, floe.jl:24-77) */
+int sz_halo_record_doubles_ctx(sz_ctx *ctx);
 int sz_halo_set_boxes(sz_ctx *ctx, int32_t nranks, const double *boxes);
 int sz_halo_pack(sz_ctx *ctx, int32_t nranks, int32_t my_rank, double Lx, double Ly, int32_t periodic_x,
                  int32_t periodic_y, void *d_send, int32_t cap);

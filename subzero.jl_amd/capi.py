@@ -79,7 +79,7 @@ EXPORTS = [
     "sz_set_two_way", "sz_set_temps", "sz_download_ocean_stress", "sz_two_way_partial", "sz_two_way_finish", "sz_set_precision",
     "sz_eulerian_data", "sz_eulerian_partial", "sz_eulerian_finish", "sz_simplify_check",
     "sz_profile_enable", "sz_profile_reset", "sz_kernel_time_ms", "sz_forcing_launch", "sz_narrow_kernel_name",
-    "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_forcing", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps", "sz_debug_crec_mismatches", "sz_upload_floes_f32", "sz_download_floes_f32", "sz_set_fields_f32", "sz_download_interactions_f32",
+    "sz_tile_enable", "sz_owned_box", "sz_halo_record_doubles", "sz_halo_record_doubles_ctx", "sz_halo_set_boxes", "sz_halo_pack", "sz_halo_counts", "sz_tile_forcing", "sz_tile_step", "sz_sync", "sz_set_stream", "sz_debug_stamps", "sz_debug_crec_mismatches", "sz_upload_floes_f32", "sz_download_floes_f32", "sz_set_fields_f32", "sz_download_interactions_f32",
     "sz_get_boundary_rects", "sz_debug_match_vertices", "sz_debug_sample_fields", "sz_debug_pipelined",
     "sz_comm_available", "sz_comm_unique_id", "sz_comm_init", "sz_comm_init_host", "sz_comm_destroy", "sz_comm_selftest", "sz_comm_allreduce", "sz_tile_setup", "sz_tile_set_center", "sz_tile_run", "sz_tile_migrate", "sz_tile_owned_gidx", "sz_debug_migrate_path", "sz_debug_find_key", "sz_debug_pairs_of_ids", "sz_download_subpoints",
 ]
@@ -155,6 +155,7 @@ def load(build_if_missing=True):
     L.sz_tile_enable.argtypes = [C.c_void_p, _lp, C.c_double, C.c_double]
     L.sz_owned_box.argtypes = [C.c_void_p, _dp]
     L.sz_halo_record_doubles.argtypes = []
+    L.sz_halo_record_doubles_ctx.argtypes = [C.c_void_p]
     L.sz_halo_set_boxes.argtypes = [C.c_void_p, C.c_int32, _dp]
     L.sz_halo_pack.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32,
                                C.c_void_p, C.c_int32]

@@ -2205,6 +2205,10 @@ int sz_tile_enable(sz_ctx* c, const int64_t* gidx, double halo_capacity_factor, 
   S.tiled = 1;
   // largest ring among ALL ranks' floes (halo floes arrive unseen): decides which narrow variants can be needed
   c->max_ring_tiled = halo_capacity_factor > 0 ? (int)halo_capacity_factor : HALO_RING;
+  // the halo records have room for the largest ring of ANY rank's floes (Floe rings are unbounded, floe.jl:24-77; the engine's narrow phase
+  // takes 255 points, and so do the tiles): 12 + 2 * halo_ring doubles per record
+  if (c->max_ring_tiled > NARROW_CAP2) { c->err = "a ring has more than 255 points: beyond the narrow phase's largest variant"; return SZ_E_CAPACITY; }
+  S.halo_ring = std::max(HALO_RING, (std::max(c->max_ring_tiled, c->max_ring) + 3) & ~3);
   // largest rmax among ALL ranks' floes: the static broad-phase grid must hold for halo floes too (0: unknown ->
   // the grid is fitted to the centroids every step instead)
   c->rmax_hint = max_rmax; c->rmax_max = max_rmax > 0 ? c->rmax_max : 0.0;
@@ -2222,6 +2226,7 @@ int sz_owned_box(sz_ctx* c, double* out5) {
 }
 
 int sz_halo_record_doubles(void) { return HALO_REC; }
+int sz_halo_record_doubles_ctx(sz_ctx* c) { return c ? halo_rec(c->S) : HALO_REC; }
 
 // diagnostic build only: cycles per narrow-phase stage, summed over groups (zeros otherwise)
 // test hook: quads of the collision records (State::crec) of the owned parents that differ from the columns they cache; *n_bad = -1 when the last
@@ -2699,13 +2704,13 @@ int tile_rebox(sz_ctx* c) {
   if (cap > c->halo_cap || !c->d_send) {
     reset_pool(c->comm_allocs);          // (chunks that are large enough are carved again: a set-up after a migration allocates nothing)
     c->halo_cap = cap;
-    const size_t nd = (size_t)n * (cap + 1) * HALO_REC;
+    const size_t nd = (size_t)n * (cap + 1) * halo_rec(c->S);
     if ((rc = dalloc(c, &c->d_send, nd, c->comm_allocs)) || (rc = dalloc(c, &c->d_recv, nd, c->comm_allocs)) ||
         (rc = dalloc(c, &c->d_ref, (size_t)2 * S.capM, c->comm_allocs)) || (rc = dalloc(c, &c->d_dcap, 64, c->comm_allocs))) return rc;
     trim_pool(c->comm_allocs);
   }
   // regions of ranks that send nothing keep a zero count in their header record
-  HIPCHK(c, hipMemsetAsync(c->d_recv, 0, (size_t)n * (c->halo_cap + 1) * HALO_REC * sizeof(double), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_recv, 0, (size_t)n * (c->halo_cap + 1) * halo_rec(c->S) * sizeof(double), c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_dcap, c->cap_send.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_ref, S.cx, (size_t)c->hostN * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_ref + S.capM, S.cy, (size_t)c->hostN * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -3277,7 +3282,8 @@ namespace {
 int tile_exchange(sz_ctx* c, bool all_ranks) {
   const int n = c->comm_n, me = c->comm_rank;
   if (n <= 1) return SZ_OK;
-  const size_t stride = (size_t)(c->halo_cap + 1) * HALO_REC;
+  const int HREC = halo_rec(c->S);
+  const size_t stride = (size_t)(c->halo_cap + 1) * HREC;
   HIPCHK(c, hipEventRecord(c->ev_packed, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
   if (c->host_transport) {
@@ -3285,8 +3291,8 @@ int tile_exchange(sz_ctx* c, bool all_ranks) {
     std::vector<int32_t> peer; std::vector<const void*> sp; std::vector<void*> rp; std::vector<int64_t> sb, rb;
     for (int d = 0; d < n; d++) {
       if (d == me || (!all_ranks && c->cap_send[d] <= 0 && c->cap_recv[d] <= 0)) continue;
-      const size_t ns = (all_ranks || c->cap_send[d] > 0) ? (size_t)(c->cap_send[d] + 1) * HALO_REC : 0;
-      const size_t nr = (all_ranks || c->cap_recv[d] > 0) ? (size_t)(c->cap_recv[d] + 1) * HALO_REC : 0;
+      const size_t ns = (all_ranks || c->cap_send[d] > 0) ? (size_t)(c->cap_send[d] + 1) * HREC : 0;
+      const size_t nr = (all_ranks || c->cap_recv[d] > 0) ? (size_t)(c->cap_recv[d] + 1) * HREC : 0;
       if (ns) HIPCHK(c, hipMemcpyAsync(c->h_send.data() + d * stride, c->d_send + d * stride, ns * sizeof(double), hipMemcpyDeviceToHost, c->comm_stream));
       peer.push_back(d); sp.push_back(c->h_send.data() + d * stride); sb.push_back((int64_t)(ns * sizeof(double)));
       rp.push_back(c->h_recv.data() + d * stride); rb.push_back((int64_t)(nr * sizeof(double)));
@@ -3300,8 +3306,8 @@ int tile_exchange(sz_ctx* c, bool all_ranks) {
     NCCLCHK(c, g_rccl.GroupStart());
     for (int d = 0; d < n; d++) {
       if (d == me) continue;
-      if (all_ranks || c->cap_send[d] > 0) NCCLCHK(c, g_rccl.Send(c->d_send + d * stride, (size_t)(c->cap_send[d] + 1) * HALO_REC, NCCL_FLOAT64, d, c->comm, c->comm_stream));
-      if (all_ranks || c->cap_recv[d] > 0) NCCLCHK(c, g_rccl.Recv(c->d_recv + d * stride, (size_t)(c->cap_recv[d] + 1) * HALO_REC, NCCL_FLOAT64, d, c->comm, c->comm_stream));
+      if (all_ranks || c->cap_send[d] > 0) NCCLCHK(c, g_rccl.Send(c->d_send + d * stride, (size_t)(c->cap_send[d] + 1) * HREC, NCCL_FLOAT64, d, c->comm, c->comm_stream));
+      if (all_ranks || c->cap_recv[d] > 0) NCCLCHK(c, g_rccl.Recv(c->d_recv + d * stride, (size_t)(c->cap_recv[d] + 1) * HREC, NCCL_FLOAT64, d, c->comm, c->comm_stream));
     }
     NCCLCHK(c, g_rccl.GroupEnd());
   }

@@ -2727,8 +2727,10 @@ __global__ void sz_k_calc_stress(State S, Params P) {
 
 // ---- halo records of tiled runs (multi-GPU; the exchange itself: "halo exchange" below).  One record per floe sent to another
 // rank: the columns the collision path reads + the ring.
-constexpr int HALO_RING = 32;
-constexpr int HALO_REC = 12 + 2 * HALO_RING;   // doubles
+constexpr int HALO_RING = 32;                  // the smallest ring capacity of a record (State::halo_ring: what this context's records have room for)
+constexpr int HALO_REC = 12 + 2 * HALO_RING;   // doubles, at that smallest capacity
+__device__ __host__ __forceinline__ int halo_ring_of(const State& S) { return S.halo_ring > HALO_RING ? S.halo_ring : HALO_RING; }
+__device__ __host__ __forceinline__ int halo_rec(const State& S) { return 12 + 2 * halo_ring_of(S); }
 constexpr int ERR_HALO_DRIFT = 16384;
 // the ranks whose (already expanded) box holds the centroid or one of its periodic images, as a bit set
 __device__ __forceinline__ unsigned long long halo_hits(const double* boxes, int nranks, int me, double Lx, double Ly, int per_x, int per_y, double cx, double cy) {
@@ -2761,7 +2763,7 @@ __device__ __forceinline__ void halo_headers(const State& S, int nranks, double*
       // on EVERY rank: sz_k_halo_unpack_inline reads the flags of all ranks before the next step does anything)
       // (the stop word may have been raised inside the launch that packs -- the integrator, on another XCD: read where it was written, past
       //  this XCD's L2)
-      double* hdr = send + (size_t)d * (cap + 1) * HALO_REC;
+      double* hdr = send + (size_t)d * (cap + 1) * halo_rec(S);
       hdr[0] = (double)(tot < room ? tot : room); hdr[1] = (double)__hip_atomic_load(&S.cnt[C_STOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       hdr[2] = (double)S.cnt[C_RETRYSTOP];      // ... and its pause (the step whose narrow phase met an item for the variant that was left out, or outgrew a list)
     }
@@ -3069,9 +3071,9 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
           base = __shfl(base, leader);
           if (mine) {
             const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (slot >= (PK.dcap ? PK.dcap[d] : PK.cap) || n > HALO_RING) atomicOr(&S.cnt[C_ERR], n > HALO_RING ? ERR_CAP_RING : ERR_CAP_FLOES);
+            if (slot >= (PK.dcap ? PK.dcap[d] : PK.cap) || n > halo_ring_of(S)) atomicOr(&S.cnt[C_ERR], n > halo_ring_of(S) ? ERR_CAP_RING : ERR_CAP_FLOES);
             else {
-              double* r = PK.send + ((size_t)d * (PK.cap + 1) + 1 + slot) * HALO_REC;
+              double* r = PK.send + ((size_t)d * (PK.cap + 1) + 1 + slot) * halo_rec(S);
               r[0] = (double)g_oki; r[1] = (double)st_new; r[2] = (double)n; r[3] = fx; r[4] = fy; r[5] = rmx;
               r[6] = area; r[7] = h; r[8] = nu; r[9] = nv; r[10] = nxi; r[11] = (double)g_id;
 #pragma unroll
@@ -3079,7 +3081,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
                 if (k < n) {
                   const double x = px[k] + (-cx), y = py[k] + (-cy);
                   const double xr = cda * x - sda * y, yr = sda * x + cda * y;
-                  r[12 + k] = xr + (cx + dx); r[12 + HALO_RING + k] = yr + (cy + dy);
+                  r[12 + k] = xr + (cx + dx); r[12 + halo_ring_of(S) + k] = yr + (cy + dy);
                 }
               }
             }
@@ -3101,7 +3103,7 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
       // nothing was integrated and nothing packed: the records of the last pack stay, but the peers must hear of the stop / the pause in the
       // header words of the next exchange (the pack launch this replaces ran regardless)
       if (blockIdx.x == 0 && (int)threadIdx.x < PK.nranks) {
-        double* hdr = PK.send + (size_t)threadIdx.x * (PK.cap + 1) * HALO_REC;
+        double* hdr = PK.send + (size_t)threadIdx.x * (PK.cap + 1) * halo_rec(S);
         hdr[1] = (double)S.cnt[C_STOP]; hdr[2] = (double)S.cnt[C_RETRYSTOP];
       }
     } else {
@@ -3253,11 +3255,11 @@ __global__ void __launch_bounds__(PACK_TPB) sz_k_halo_pack(State S, int nranks, 
       while (hits) {
         int d = __ffsll((long long)hits) - 1; hits &= hits - 1;
         int slot = base[d] + atomicAdd(&lc2[d], 1);
-        if (slot >= (dcap ? dcap[d] : cap) || nv > HALO_RING) { atomicOr(&S.cnt[C_ERR], nv > HALO_RING ? ERR_CAP_RING : ERR_CAP_FLOES); continue; }
-        double* r = send + ((size_t)d * (cap + 1) + 1 + slot) * HALO_REC;
+        if (slot >= (dcap ? dcap[d] : cap) || nv > halo_ring_of(S)) { atomicOr(&S.cnt[C_ERR], nv > halo_ring_of(S) ? ERR_CAP_RING : ERR_CAP_FLOES); continue; }
+        double* r = send + ((size_t)d * (cap + 1) + 1 + slot) * halo_rec(S);
         r[0] = (double)S.okey[q]; r[1] = (double)S.status[q]; r[2] = (double)nv; r[3] = cx; r[4] = cy; r[5] = S.rmax[q];
         r[6] = S.area[q]; r[7] = S.height[q]; r[8] = S.u[q]; r[9] = S.v[q]; r[10] = S.xi[q]; r[11] = (double)S.id[q];
-        for (int k = 0; k < nv; k++) { const double2 p = S.vxy[o + k]; r[12 + k] = p.x; r[12 + HALO_RING + k] = p.y; }
+        for (int k = 0; k < nv; k++) { const double2 p = S.vxy[o + k]; r[12 + k] = p.x; r[12 + halo_ring_of(S) + k] = p.y; }
       }
     }
   __syncthreads();
@@ -3281,12 +3283,12 @@ __global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* 
   if (stopped(S)) return;
   if (S.step > 0 && S.stop_on_tags) {          // sz_tile_run's list-based steps: a peer tagged a floe in the step before (its header's stop word; this rank's own region is zero)
     int stop = 0;
-    for (int r = 0; r < nranks; r++) { const int f = (int)recv[(size_t)r * (cap + 1) * HALO_REC + 1]; if (f > 0) stop = f; }
+    for (int r = 0; r < nranks; r++) { const int f = (int)recv[(size_t)r * (cap + 1) * halo_rec(S) + 1]; if (f > 0) stop = f; }
     if (stop > 0) { if (threadIdx.x == 0) S.cnt[C_STOP] = stop; return; }
   }
   if (threadIdx.x == 0) {
     int acc = 0; bool bad = false;
-    for (int r = 0; r < nranks; r++) { int cnt = (int)recv[(size_t)r * (cap + 1) * HALO_REC]; if (cnt > cap) { bad = true; cnt = cap; } before[r] = acc; acc += cnt; }
+    for (int r = 0; r < nranks; r++) { int cnt = (int)recv[(size_t)r * (cap + 1) * halo_rec(S)]; if (cnt > cap) { bad = true; cnt = cap; } before[r] = acc; acc += cnt; }
     before[nranks] = acc;
     if (bad) atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES);
     carry_s = 0;
@@ -3301,7 +3303,7 @@ __global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* 
     int q = base + threadIdx.x, nv = 0;
     if (q < nrec) {
       int src = 0; while (q >= before[src + 1]) src++;
-      nv = (int)recv[((size_t)src * (cap + 1) + 1 + (q - before[src])) * HALO_REC + 2];
+      nv = (int)recv[((size_t)src * (cap + 1) + 1 + (q - before[src])) * halo_rec(S) + 2];
     }
     int ex = block_exclusive_scan(nv, &tot);
     if (q < nrec) S.gvscan[q] = carry_s + ex;
@@ -3314,7 +3316,7 @@ __global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* 
   // pass 2: copy
   for (int q = threadIdx.x; q < nrec; q += blockDim.x) {
     int src = 0; while (q >= before[src + 1]) src++;
-    const double* r = recv + ((size_t)src * (cap + 1) + 1 + (q - before[src])) * HALO_REC;
+    const double* r = recv + ((size_t)src * (cap + 1) + 1 + (q - before[src])) * halo_rec(S);
     int g = nown + q, nv = (int)r[2], vb = vbase + S.gvscan[q];
     S.okey[g] = (long long)r[0]; S.status[g] = (int)r[1]; S.cx[g] = r[3]; S.cy[g] = r[4]; S.rmax[g] = r[5];
     S.area[g] = r[6]; S.height[g] = r[7]; S.u[g] = r[8]; S.v[g] = r[9]; S.xi[g] = r[10]; S.id[g] = (long long)r[11];
@@ -3324,11 +3326,11 @@ __global__ void __launch_bounds__(1024) sz_k_halo_unpack(State S, const double* 
     S.voff[g] = vb; S.voff[g + 1] = vb + nv;
     double x0 = __builtin_inf(), x1 = -__builtin_inf(), y0 = __builtin_inf(), y1 = -__builtin_inf();
     for (int k = 0; k < nv; k++) {
-      double x = r[12 + k], y = r[12 + HALO_RING + k];
+      double x = r[12 + k], y = r[12 + halo_ring_of(S) + k];
       S.vxy[vb + k] = make_double2(x, y);
       x0 = fmin(x0, x); x1 = fmax(x1, x); y0 = fmin(y0, y); y1 = fmax(y1, y);
     }
-    S.osign[g] = ring_signed_area(r + 12, r + 12 + HALO_RING, nv) >= 0.0 ? 1 : -1;
+    S.osign[g] = ring_signed_area(r + 12, r + 12 + halo_ring_of(S), nv) >= 0.0 ? 1 : -1;
     S.bbx0[g] = x0; S.bbx1[g] = x1; S.bby0[g] = y0; S.bby1[g] = y1;
     if (S.rec32) rec32_store(S, g, r[3], r[4], r[5], x0, x1, y0, y1);
     if (bin) cell_insert(S, geo, g, r[3], r[4]);
@@ -3360,7 +3362,7 @@ __global__ void __launch_bounds__(UNPACK_TPB) sz_k_halo_unpack_inline(State S, c
     int stop = 0, pause = 0;
     for (int r = 0; r < nranks; r++) {
       if (r == me) continue;
-      const double* hdr = recv + (size_t)r * (cap + 1) * HALO_REC;
+      const double* hdr = recv + (size_t)r * (cap + 1) * halo_rec(S);
       const int f = (int)hdr[1], pz = (int)hdr[2];
       if (f > 0) stop = f;
       if (pz > 0) pause = pz;
@@ -3378,17 +3380,17 @@ __global__ void __launch_bounds__(UNPACK_TPB) sz_k_halo_unpack_inline(State S, c
   const int r = (int)(t / cap), q = (int)(t % cap);
   bool act = r < nranks && r != me;
   if (act) {
-    int cnt_r = (int)recv[(size_t)r * (cap + 1) * HALO_REC];
+    int cnt_r = (int)recv[(size_t)r * (cap + 1) * halo_rec(S)];
     if (cnt_r > cap) { if (q == 0) atomicOr(&S.cnt[C_ERR], ERR_CAP_FLOES); cnt_r = cap; }
     act = q < cnt_r;
   }
   if (t == 0) {          // (statistics only)
     int tot = 0;
-    for (int rr = 0; rr < nranks; rr++) if (rr != me) { const int c0 = (int)recv[(size_t)rr * (cap + 1) * HALO_REC]; tot += c0 < cap ? c0 : cap; }
+    for (int rr = 0; rr < nranks; rr++) if (rr != me) { const int c0 = (int)recv[(size_t)rr * (cap + 1) * halo_rec(S)]; tot += c0 < cap ? c0 : cap; }
     S.cnt[C_NHALO] = tot;
   }
   // ---- the record, all of it before the first store
-  const double* rec = recv + ((size_t)(act ? r : 0) * (cap + 1) + 1 + (act ? q : 0)) * HALO_REC;
+  const double* rec = recv + ((size_t)(act ? r : 0) * (cap + 1) + 1 + (act ? q : 0)) * halo_rec(S);
   GhostRow R;
   int nv = 0;
   if (act) {
@@ -3399,7 +3401,7 @@ __global__ void __launch_bounds__(UNPACK_TPB) sz_k_halo_unpack_inline(State S, c
   R.rmax = act ? rec[5] : 0.0; R.area = act ? rec[6] : 0.0; R.h = act ? rec[7] : 0.0; R.u = act ? rec[8] : 0.0; R.v = act ? rec[9] : 0.0;
   R.xi = act ? rec[10] : 0.0; R.id = act ? (long long)rec[11] : 0; R.mass = 0.0; R.mom = 0.0; R.al = 0.0; R.over = 0.0; R.tc = 1.0; R.ts = 0.0;
 #pragma unroll
-  for (int k = 0; k < MV_RING; k++) { R.rx[k] = k < nv ? rec[12 + k] : 0.0; R.ry[k] = k < nv ? rec[12 + HALO_RING + k] : 0.0; }
+  for (int k = 0; k < MV_RING; k++) { R.rx[k] = k < nv ? rec[12 + k] : 0.0; R.ry[k] = k < nv ? rec[12 + halo_ring_of(S) + k] : 0.0; }
   double x0 = __builtin_inf(), x1 = -__builtin_inf(), y0 = __builtin_inf(), y1 = -__builtin_inf();
 #pragma unroll
   for (int k = 0; k < MV_RING; k++) if (k < nv) { x0 = fmin(x0, R.rx[k]); x1 = fmax(x1, R.rx[k]); y0 = fmin(y0, R.ry[k]); y1 = fmax(y1, R.ry[k]); }

@@ -76,6 +76,8 @@ struct State {
   int stop_on_tags;          // sz_step: raise C_STOP when a parent is tagged (off with SZ_NO_STOP)
   int goff;                  // pipelined resident steps (sz_pipeline.hpp): the rows a step's inline makers allocate lie at [N + goff, ..) -- two regions, used
                              // alternately step by step, so that the ghosts of step t + 1 can be made while those of step t are still read; 0 elsewhere
+  int halo_ring;             // tiled runs: ring points a halo record has room for (>= 32; sz_tile_enable sizes it from the largest ring of ALL ranks, <= 255);
+                             // a record is 12 + 2 * halo_ring doubles (sz_kernels.hpp halo_rec)
   int gcap;                  // rows the step's inline makers may allocate (pipelined steps: the size of the step's region; 0: all rows behind the parents)
   int pipe;                  // this launch belongs to a pipelined step (the ghost maker leaves the parent's COLUMNS alone and marks a swapped parent)
   int restart_on_tags;       // pipelined batches that run through (SZ_NO_STOP): a NEW tag still ends the enqueued steps -- the host starts the rest again,

@@ -169,7 +169,7 @@ class TiledWorld:
             drift_margin = max(2000.0, 0.5 * max_rmax)
         w._chk(w.L.sz_tile_enable(w.h, capi.ptr(g, capi._lp), max_ring, max_rmax))
         self.world = w
-        self.REC = w.L.sz_halo_record_doubles()
+        self.REC = w.L.sz_halo_record_doubles_ctx(w.h)          # (follows the largest ring of all ranks: 12 + 2 x ring capacity)
         self.dev = torch.device("cuda", device)
         self.cap = 0                                          # record slots per peer, sized from a counting pass
         self.send = self.recv = None

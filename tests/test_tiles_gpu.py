@@ -638,6 +638,86 @@ def test_a_pause_on_one_rank_and_a_tag_on_another_in_the_same_step():
     assert paused == {0} and tagged == {1}, (paused, tagged)
 
 
+def _many_vertex_cfg(seed=5, n_side=12):
+    """a periodic field of star polygons with 34 .. 60 vertices each (rings far above the 32 points a halo record used to hold; the reference's
+    own fixture outlines have 35 .. 203 points, Floe rings are unbounded: floe.jl:24-77), overlapping their neighbours, with some drift"""
+    from subzero_jl_amd import floe as floe_mod
+    rng = np.random.default_rng(seed)
+    L = 1.2e5; sp = L / n_side
+    rings = []
+    for gy in range(n_side):
+        for gx in range(n_side):
+            nv = int(rng.integers(34, 61))
+            th = ((2 * np.pi / nv) * (np.arange(nv) + rng.uniform(-0.3, 0.3, nv)))[::-1]
+            rad = 0.62 * sp * rng.uniform(0.7, 1.0, nv)
+            cx = (gx + 0.5) * sp + rng.uniform(-0.1, 0.1) * sp; cy = (gy + 0.5) * sp + rng.uniform(-0.1, 0.1) * sp
+            r = np.stack([cx + rad * np.cos(th), cy + rad * np.sin(th)], 1)
+            rings.append(np.vstack([r, r[:1]]))
+    n = len(rings)
+    off = np.zeros(n + 1, np.int32); off[1:] = np.cumsum([len(r) for r in rings])
+    vx = np.concatenate([r[:, 0] for r in rings]); vy = np.concatenate([r[:, 1] for r in rings])
+    h = np.full(n, 0.3); z = np.zeros((11, 11))
+    return dict(n_floes=n, L=L, kinds=["periodic"] * 4, vert_off=off, vx=vx, vy=vy, height=h, u=rng.uniform(-0.3, 0.3, n), v=rng.uniform(-0.3, 0.3, n),
+                xi=rng.uniform(-1e-5, 1e-5, n), dt=10, Nx=10, Ny=10, uo=z, vo=z, hf=z, ua=z, va=z, topography=[], E=6e6, derived=floe_mod.derive(off, vx, vy, h),
+                sub_off=np.zeros(n + 1, np.int32), sx=np.zeros(0), sy=np.zeros(0), seed=seed)
+
+
+def _worker_many_vertex(rank, world, port, steps, q):
+    import torch.distributed as dist
+    from subzero_jl_amd import tiles
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        cfg = _many_vertex_cfg()
+        tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True, backend="library-host", rebox_every=3)
+        assert tw.REC >= 12 + 2 * 60                      # the records follow the largest ring of all ranks
+        done = tw.run(steps, 0, cfg["dt"], coupling_dt=10, coupling_on=False)
+        q.put((rank, tw.gidx, {f: tw.owned(f) for f in FIELDS}, done, tw.n_halo_last))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_worker_many_vertex(*a):
+    _guard(_worker_many_vertex)(*a)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tiles_take_rings_above_32_points(world):
+    """A tiled run used to refuse rings above the 32 points its halo records held (ERR_CAP_RING) while the single context takes 255.  The
+    records now have room for the largest ring of any rank's floes (sz_tile_enable): a field of 34 .. 60-vertex floes in 2 and 2 x 2 tiles,
+    six steps, owned columns bit-equal to the single context."""
+    import torch.multiprocessing as mp
+    import subzero_jl_amd
+    from subzero_jl_amd import fields
+    steps = 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_run_worker_many_vertex, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = _collect(q, world)
+        for p in procs:
+            p.join(60)
+        assert all(p.exitcode == 0 for p in procs)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    cfg = _many_vertex_cfg()
+    assert np.diff(cfg["vert_off"]).min() > 32
+    hw = fields.build_world(subzero_jl_amd.World(0), cfg)
+    assert hw.run(steps, 0, cfg["dt"], coupling_dt=10, coupling_on=False, stop_on_tags=False) == steps
+    assert hw.stats()["n_pairs"] > cfg["n_floes"]
+    seen = np.zeros(cfg["n_floes"], bool)
+    for rank, gidx, out, done, nhalo in res:
+        assert done == steps and nhalo > 0
+        seen[gidx] = True
+        for f in FIELDS:
+            assert np.array_equal(out[f], hw.get(f)[gidx]), (rank, f, np.max(np.abs(out[f] - hw.get(f)[gidx])))
+    assert seen.all()
+
+
 # ---------------------------------------------------------------- migration inside the library
 def _worker_migrate(rank, world, port, n, seed, steps, every, q, shape="star", fast=True, stop=False):
     import time
