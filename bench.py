@@ -29,6 +29,9 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH
 W = 8                        # fp64 bytes
 
 
+WATCHDOG_AFTER_SETUP_S = 120.0
+
+
 def log(msg):
     """progress line on stderr: what the self-launching parent's watchdog (and a human) sees of a running rank"""
     sys.stderr.write(f"[bench rank {os.environ.get('RANK', '0')}] {msg}\n"); sys.stderr.flush()
@@ -50,6 +53,7 @@ def launch_ranks(n, child_cmd, watchdog_s=900.0, shared_gpu=False, extra_env=Non
     procs, tails, threads = [], [], []
     last = [time.monotonic()]
     lines0 = []
+    set_up = set()          # ranks that have said "tile set up": from then on every phase of every rank writes a line, and the watchdog is short
 
     def pump(stream, rank, is_out):
         for raw in iter(stream.readline, b""):
@@ -59,6 +63,8 @@ def launch_ranks(n, child_cmd, watchdog_s=900.0, shared_gpu=False, extra_env=Non
                 lines0.append(line)
             else:
                 tails[rank].append(line)
+                if "tile set up" in line:
+                    set_up.add(rank)
                 err.write(f"[rank {rank}] {line}"); err.flush()
         stream.close()
 
@@ -94,8 +100,12 @@ def launch_ranks(n, child_cmd, watchdog_s=900.0, shared_gpu=False, extra_env=Non
             break
         if all(c == 0 for c in codes):
             break
-        if time.monotonic() - last[0] > watchdog_s:
-            rc, why = 3, f"no rank wrote anything for {watchdog_s:.0f} s"
+        # (building the 100 k-floe field and the first RCCL communicator are silent for tens of seconds; once every rank has its tile, a rank
+        #  reports each phase and a step takes a fraction of a millisecond: silence then means a hung exchange, and a second attempt on
+        #  the torch exchange must still fit the driver's time limit)
+        wd = min(watchdog_s, WATCHDOG_AFTER_SETUP_S) if len(set_up) == n else watchdog_s
+        if time.monotonic() - last[0] > wd:
+            rc, why = 3, f"no rank wrote anything for {wd:.0f} s" + (" after the tiles were set up" if len(set_up) == n else "")
             break
         time.sleep(poll_s)
     if rc:
@@ -107,6 +117,14 @@ def launch_ranks(n, child_cmd, watchdog_s=900.0, shared_gpu=False, extra_env=Non
         for r, tl in enumerate(tails):
             err.write(f"--- rank {r} ---\n" + "".join(tl))
         err.flush()
+        try:          # the evidence of a failed attempt is kept as a file as well (the line of a second attempt names it)
+            d = os.path.join(ROOT, "gpurun_out"); os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "bench_failed_attempt_stderr.txt"), "w") as f:
+                f.write(f"{why}\n")
+                for r, tl in enumerate(tails):
+                    f.write(f"--- rank {r} ---\n" + "".join(tl))
+        except OSError:
+            pass
         return rc
     js = [l for l in lines0 if l.lstrip().startswith("{")]
     if len(js) != 1:
@@ -447,7 +465,7 @@ def main():
             # (all_to_all_single on the buffers the library packs); the line then says so.
             sys.stderr.write(f"[bench launcher] first attempt ended with code {rc}; one more with SZ_TILES_BACKEND=torch\n"); sys.stderr.flush()
             rc = launch_ranks(args.gpus, child, watchdog_s=args.watchdog, shared_gpu=False,
-                              extra_env={"SZ_TILES_BACKEND": "torch", "SZ_BENCH_NOTE": f"the run with the library's RCCL exchange ended with launcher code {rc}; "
+                              extra_env={"SZ_TILES_BACKEND": "torch", "SZ_BENCH_PRIMARY_RC": str(rc), "SZ_BENCH_NOTE": f"the run with the library's RCCL exchange ended with launcher code {rc}; "
                                                                                         "this line is the second attempt (torch.distributed all_to_all_single)"})
         sys.exit(rc)
 
@@ -741,6 +759,15 @@ def main():
                 out["config"]["halo_exchange_note"] = backend_note
         if os.environ.get("SZ_BENCH_NOTE"):
             out["note"] = os.environ["SZ_BENCH_NOTE"]
+        if os.environ.get("SZ_BENCH_PRIMARY_RC"):
+            # a degraded line must say so to tools, not only to readers: the library's own RCCL exchange -- the default multi-GPU path -- failed
+            # or hung (launcher code: 1 a rank failed, 3 watchdog), and this line was measured on the torch.distributed exchange instead
+            out["primary_exchange_failed"] = int(os.environ["SZ_BENCH_PRIMARY_RC"])
+            out["primary_exchange_stderr"] = "gpurun_out/bench_failed_attempt_stderr.txt"
+        if tiled:
+            out["exchange"] = {"backend": backend, "headers": "neighbouring tiles only (SZ_TILE_HEADERS=neighbours: measurement arm, no tag stop)" if os.environ.get("SZ_TILE_HEADERS") == "neighbours" else "every ordered pair of ranks (stop / pause words)",
+                               "ms_per_step_event_timed": (kt_all.get("exchange", (0.0, 0))[0] / nb) if "exchange" in kt_all else None,
+                               "note": "HIP events around the grouped send / receive on the library's communication stream, in the separate pass that event-times every class"}
         if args.rehearse_shared_gpu:
             out["data"] = "REHEARSAL: all ranks share GPU 0, transfers over gloo through the host -- not a measurement"
         if world == 1 and not tiled and workload == "configs1" and args.floes == 0 and args.total_floes == 0 and not args.no_strong_reference:

@@ -19,7 +19,7 @@ NORTH, SOUTH, EAST, WEST = 0, 1, 2, 3
 ACTIVE, REMOVE, FUSE = 1, 2, 3
 COLLISIONS_ON, COUPLING_ON, NO_STOP = 1, 2, 4
 K_GHOSTS, K_BROAD, K_NARROW, K_REDUCE, K_FORCING, K_INTEGRATE, K_NARROW_LARGE = range(7)
-KERNEL_CLASS_NAMES = ["ghosts", "broad", "narrow", "reduce", "forcing", "integrate", "narrow_large"]
+KERNEL_CLASS_NAMES = ["ghosts", "broad", "narrow", "reduce", "forcing", "integrate", "narrow_large", "exchange"]
 
 DCOLS = ["cx", "cy", "rmax", "area", "height", "mass", "moment", "alpha", "u", "v", "xi",
          "p_dxdt", "p_dydt", "p_dalphadt", "p_dudt", "p_dvdt", "p_dxidt",

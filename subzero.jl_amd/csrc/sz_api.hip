@@ -25,8 +25,8 @@ using namespace sz;
 
 namespace {
 
-constexpr int NK = SZ_K_COUNT + 1;   // + large narrow variant
-constexpr int K_NARROW_LARGE = SZ_K_COUNT;
+constexpr int NK = SZ_K_COUNT + 2;   // + large narrow variant, + the halo exchange of a tiled step (events on the communication stream)
+constexpr int K_NARROW_LARGE = SZ_K_COUNT, K_EXCHANGE = SZ_K_COUNT + 1;
 #ifndef NARROW_G
 #define NARROW_G 8
 #endif
@@ -142,6 +142,8 @@ struct sz_ctx {
   int upload_M = 0, upload_V = 0;   // floes and ring points of the last sz_upload_floes (what its capacities were carved for)
   int migrate_path = 0;             // how the last sz_tile_migrate ran: 1 packed on the device, 2 staged through the host (sz_debug_migrate_path)
   std::vector<long long> tile_gidx; // global index of every owned floe (sz_tile_enable): status.fuse_idx of a tiled context is reported in global numbers
+  bool tile_hdr_neighbours = false; // SZ_TILE_HEADERS=neighbours (measurement only, batches that run through): the inline steps trade with the neighbouring tiles only --
+                                    // no header record to the others, hence no tag stop and no pause agreement in that arm (the largest narrow variant stays in)
   bool tile_inline_off = false;     // SZ_TILE_INLINE=0: the tiled steps of sz_tile_run keep the list-based ghost pass, their own forcing launch and the one-workgroup unpack (A/B)
   double tile_box_ctr[2] = { 0, 0 }; bool tile_box_valid = false;   // centre of this rank's owned box at the last gather (sz_k_owned_box: periodic images)
   int tile_forcing_tstep = -1;      // timestep whose forcings sz_tile_forcing has already enqueued
@@ -867,6 +869,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_CREC")) c->no_crec = atoi(e) == 0;
   if (const char* e = getenv("SZ_REDUCE_FREE")) c->no_reduce_free = atoi(e) == 0;
   if (const char* e = getenv("SZ_PIPELINE")) c->no_pipeline = atoi(e) == 0;
+  if (const char* e = getenv("SZ_TILE_HEADERS")) c->tile_hdr_neighbours = strcmp(e, "neighbours") == 0;
   if (const char* e = getenv("SZ_PIPE_MIN_STEPS")) c->pipe_min_steps = std::max(2, atoi(e));
   if (const char* e = getenv("SZ_PIPE_MAX_FLOES")) c->pipe_max_floes = atoi(e);
   if (const char* e = getenv("SZ_FRC_FIRST")) c->frc_first = std::max(0, atoi(e));
@@ -3287,6 +3290,7 @@ int tile_exchange(sz_ctx* c, bool all_ranks) {
   HIPCHK(c, hipEventRecord(c->ev_packed, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
   if (c->host_transport) {
+    Timed tx(c, K_EXCHANGE, c->comm_stream);
     c->h_send.resize((size_t)n * stride); c->h_recv.resize((size_t)n * stride);
     std::vector<int32_t> peer; std::vector<const void*> sp; std::vector<void*> rp; std::vector<int64_t> sb, rb;
     for (int d = 0; d < n; d++) {
@@ -3302,7 +3306,9 @@ int tile_exchange(sz_ctx* c, bool all_ranks) {
     for (size_t k = 0; k < peer.size(); k++)
       if (rb[k]) HIPCHK(c, hipMemcpyAsync(c->d_recv + peer[k] * stride, rp[k], (size_t)rb[k], hipMemcpyHostToDevice, c->comm_stream));
     HIPCHK(c, hipStreamSynchronize(c->comm_stream));       // (h_recv is reused by the next step)
+    tx.end();
   } else {
+    Timed tx(c, K_EXCHANGE, c->comm_stream);          // (class "exchange" of sz_kernel_time_ms: the grouped send / receive on the communication stream)
     NCCLCHK(c, g_rccl.GroupStart());
     for (int d = 0; d < n; d++) {
       if (d == me) continue;
@@ -3310,6 +3316,7 @@ int tile_exchange(sz_ctx* c, bool all_ranks) {
       if (all_ranks || c->cap_recv[d] > 0) NCCLCHK(c, g_rccl.Recv(c->d_recv + d * stride, (size_t)(c->cap_recv[d] + 1) * HREC, NCCL_FLOAT64, d, c->comm, c->comm_stream));
     }
     NCCLCHK(c, g_rccl.GroupEnd());
+    tx.end();
   }
   HIPCHK(c, hipEventRecord(c->ev_recv, c->comm_stream));
   return SZ_OK;
@@ -3464,7 +3471,8 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   // exchange (sz_k_halo_pack hdr[2]), whose unpack kernel stops every other rank before that step has touched anything.  After the sync
   // all ranks know the step: the rank that paused finishes it (the variant, the reduce, the integrator), and everybody runs the rest of
   // the batch again from the step after it, as a batch that starts there (cells, ghosts, records seeded anew) with the variant in.
-  bool lean = !c->retry_seen && !c->no_lean_narrow && !larger_rings(c) && !dbgsync;
+  const bool hdr_all = !(c->tile_hdr_neighbours && (flags & SZ_NO_STOP));      // (the A/B arm without the all-pairs headers: see tile_hdr_neighbours)
+  bool lean = !c->retry_seen && !c->no_lean_narrow && !larger_rings(c) && !dbgsync && hdr_all;
   std::vector<int> callid_of((size_t)std::max(nsteps, 1), 0);
   int h[C_COUNT]; int rc = SZ_OK;
   // The halo records of step s + 1 are written by the integrator of step s: the thread that has just placed the floe holds all a record
@@ -3498,7 +3506,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     //  step it ended with, as sz_step does.)
     if (beside) { swap_frc(); fset[s] = (signed char)cur_set; }
     if (beside && c->host_transport) stage_forcing(c, dt);
-    { int rc = tile_exchange(c, true); if (rc) return fail(rc); }
+    { int rc = tile_exchange(c, hdr_all); if (rc) return fail(rc); }
     if (beside && !c->host_transport) stage_forcing(c, dt);
     if (n > 1) {
       HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_recv, 0));
