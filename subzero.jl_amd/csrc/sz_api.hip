@@ -1309,7 +1309,9 @@ int sz_download_floes_f32(sz_ctx* c, sz_floe_columns_f32* f) {
   SZ_F32_TENSORS(X)
 #undef X
   d.id = f->id; d.ghost_id = f->ghost_id; d.status = f->status; d.vert_off = f->vert_off; d.sub_off = f->sub_off; d.ghost_off = f->ghost_off; d.ghost_idx = f->ghost_idx;
-  d.vx = room(f->vx, V); d.vy = room(f->vy, V); d.sx = room(f->sx, NS); d.sy = room(f->sy, NS);
+  // (sx / sy are not written by a download -- sz_download_subpoints is their way back --, so the caller's buffers are left alone: staging them
+  //  here used to hand zeros back)
+  d.vx = room(f->vx, V); d.vy = room(f->vy, V); d.sx = nullptr; d.sy = nullptr; (void)NS;
   rc = sz_download_floes(c, &d); if (rc) return rc;
   for (const Back& b : back) for (size_t k = 0; k < b.n; k++) b.dst[k] = (float)b.src[k];
   return SZ_OK;
@@ -3382,32 +3384,37 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     // The tag stop of these steps (one-way coupling): the pack kernel's header records carry every rank's stop word to EVERY rank, the unpack
     // kernel of the next step reads them before that step has touched anything and ends the batch there (sz_k_halo_unpack), as in the inline
     // steps.  The forcings then run behind the unpack instead of beside the exchange: a rank must not compute the forcings of a step its
-    // peers have already called off.  (Two-way coupling across tiles: no stop -- its per-cell sums are reduced over the ranks step by step.)
-    const bool stopping = !(flags & SZ_NO_STOP) && !c->two_way;
+    // peers have already called off.  Two-way coupling across tiles (round 4): the same stop -- the steps behind it are enqueued and return at
+    // once; their all-reduces of the per-cell sums still run on every rank (collectives must), on the sums of the step that ended the
+    // batch, and sz_two_way_finish writes the ocean fields of that step once more: the same values.
+    const bool stopping = !(flags & SZ_NO_STOP);
     S.stop_on_tags = stopping ? 1 : 0; S.retry_stop = 0;
     HIPCHK(c, hipMemsetAsync(S.cnt + C_STOP, 0, sizeof(int), c->stream));
     HIPCHK(c, hipMemsetAsync(S.cnt + C_RETRYSTOP, 0, sizeof(int), c->stream));
+    // (every way out of the loop leaves the context as a batch that has ended: no step number in the State, or the next process-mode call's
+    //  kernels would take themselves for launches behind a stop)
+    auto out = [&](int rc) { S.step = 0; S.stop_on_tags = 0; return rc; };
     for (int s = 0; s < nsteps; s++) {
       const int tstep = tstep0 + s;
       c->tile_dt = dt;
       S.step = stopping ? s + 1 : 0;
-      if (c->tile_since_box < 0 || c->tile_since_box >= c->tile_rebox_cur) { int rc = tile_rebox(c); if (rc) { S.step = 0; return rc; } }
+      if (c->tile_since_box < 0 || c->tile_since_box >= c->tile_rebox_cur) { int rc = tile_rebox(c); if (rc) return out(rc); }
       c->tile_since_box++;
       const bool coupling = (flags & SZ_COUPLING_ON) && coupling_dt > 0 && (tstep % coupling_dt) == 0;
       tile_pack(c);
       // (the host's channel blocks: the forcings go to the device first and run while the host trades the regions)
-      if (coupling && !stopping && n > 1 && c->host_transport) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return rc; }
-      { int rc = tile_exchange(c, stopping); if (rc) { S.step = 0; return rc; } }
+      if (coupling && !stopping && n > 1 && c->host_transport) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return out(rc); }
+      { int rc = tile_exchange(c, stopping); if (rc) return out(rc); }
       // the forcings of the owned floes need nothing from the halo: they run beside the exchange
-      if (coupling && !stopping && !(n > 1 && c->host_transport)) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return rc; }
-      if (n > 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_recv, 0));
+      if (coupling && !stopping && !(n > 1 && c->host_transport)) { int rc = sz_tile_forcing(c, tstep, coupling_dt, flags); if (rc) return out(rc); }
+      if (n > 1 && hipStreamWaitEvent(c->stream, c->ev_recv, 0) != hipSuccess) { c->err = "hipStreamWaitEvent (halo exchange)"; return out(SZ_E_HIP); }
       int rc = sz_tile_step(c, c->d_recv, n, c->halo_cap, tstep, dt, coupling_dt, flags);
-      if (rc) return rc;
+      if (rc) return out(rc);
       if (c->two_way && coupling) {       // ice-on-ocean stress: per-cell partial sums, summed over the ranks, finished on every rank
         const size_t nc = 3 * c->tw_ncell;
         if (!c->d_tw_partial) { int r2 = dalloc(c, &c->d_tw_partial, nc, c->tw_part_allocs); if (r2) return r2; }
         if ((rc = sz_two_way_partial(c, c->d_tw_partial)) || (rc = sz_comm_allreduce(c, c->d_tw_partial, (int64_t)nc)) ||
-            (rc = sz_two_way_finish(c, c->d_tw_partial, dt))) return rc;
+            (rc = sz_two_way_finish(c, c->d_tw_partial, dt))) return out(rc);
       }
     }
     // (the ranks agree on the error word: a rank with a device error and a clean one return the same code)
@@ -3452,7 +3459,9 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     HIPCHK(c, hipMemsetAsync(S.cnt + C_FRCSTOP, 0, sizeof(int), c->stream));
   }
   auto accm = [&](bool last) { return !facc_on ? 0 : 1 | (rmode == 2 ? 4 | (last ? 2 : 0) : 0); };
-  auto fail = [&](int rc) { S.ginline = 0; S.famrec = 0; S.step = 0; S.crec = nullptr; S.retry_stop = 0; S.facc = nullptr; c->acc_mode = 0; c->reduce_mode = 0; return rc; };
+  int cur_set = 0;          // (the forcing output set in use: see `beside` below)
+  auto swap_frc = [&]() { std::swap(S.fxOA, c->frc_alt[0]); std::swap(S.fyOA, c->frc_alt[1]); std::swap(S.trqOA, c->frc_alt[2]); std::swap(S.hflx, c->frc_alt[3]); cur_set ^= 1; };
+  auto fail = [&](int rc) { if (cur_set) swap_frc(); S.ginline = 0; S.famrec = 0; S.step = 0; S.crec = nullptr; S.retry_stop = 0; S.facc = nullptr; c->acc_mode = 0; c->reduce_mode = 0; return rc; };
   // SZ_SYNC_DEBUG=1 (diagnosis of a faulting kernel): wait after every stage of every step and say so on stderr -- the last line names the stage
   const bool dbgsync = getenv("SZ_SYNC_DEBUG") != nullptr;
   auto stage_done = [&](int s, const char* what) {
@@ -3464,8 +3473,6 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   };
   stage_done(-1, "seed");
   std::vector<signed char> fset((size_t)std::max(nsteps, 1), (signed char)-1);      // the output set the forcings of step s wrote (-1: none of this kind)
-  int cur_set = 0;
-  auto swap_frc = [&]() { std::swap(S.fxOA, c->frc_alt[0]); std::swap(S.fyOA, c->frc_alt[1]); std::swap(S.trqOA, c->frc_alt[2]); std::swap(S.hflx, c->frc_alt[3]); cur_set ^= 1; };
   // The largest narrow variant is left out of the steps until an item needs it, as in sz_step (-4 us and a launch boundary per step).  A
   // rank whose narrow phase meets such an item pauses inside that step (C_RETRYSTOP); its pause rides in the header records of the next
   // exchange (sz_k_halo_pack hdr[2]), whose unpack kernel stops every other rank before that step has touched anything.  After the sync
@@ -3481,15 +3488,22 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   // step of a batch (and the step a paused batch is taken up again at): it runs BEFORE the launch that makes the owned floes' first
   // ghosts and swaps the parents that lie outside, for the same reason.  New boxes for step s + 1 are therefore gathered before the
   // integrator of step s (from the positions that step started with; the drift margin covers the step in between).
+  // fresh: this rank starts the (sub-)batch from its parents as they lie -- boxes, the first pack, the first ghosts.  After a pause only the
+  // rank that paused does: it finished its step without making anything for the next one.  The others have that step behind them as any other
+  // -- their integrator has made the next step's ghosts (from the parents BEFORE their swap, like the single context and the reference:
+  // collisions.jl:942-950) and packed the halo records -- and simply take up the steps where the pause stopped them.
+  bool fresh = true;
   for (int s_begin = 0;;) {
   S.retry_stop = lean ? 1 : 0;
   for (int s = s_begin; s < nsteps; s++) {
     const int tstep = tstep0 + s;
     S.step = s + 1; S.gslot = s & 1;
     c->tile_dt = dt;
-    if (s == s_begin) {
+    if (s == s_begin && s_begin == 0) {
       if (c->tile_since_box < 0 || c->tile_since_box >= c->tile_rebox_cur) { int rc = tile_rebox(c); if (rc) return fail(rc); }
       stage_done(s, "rebox");
+    }
+    if (s == s_begin && fresh) {
       tile_pack(c);
       if (periodic) hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, s & 1, c->hostN);
     }
@@ -3509,7 +3523,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     { int rc = tile_exchange(c, hdr_all); if (rc) return fail(rc); }
     if (beside && !c->host_transport) stage_forcing(c, dt);
     if (n > 1) {
-      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_recv, 0));
+      if (hipStreamWaitEvent(c->stream, c->ev_recv, 0) != hipSuccess) { c->err = "hipStreamWaitEvent (halo exchange)"; return fail(SZ_E_HIP); }
       const long long slots = (long long)n * c->halo_cap;
       hipLaunchKernelGGL(sz_k_halo_unpack_inline, dim3(grid_for(slots, UNPACK_TPB, 1 << 20)), dim3(UNPACK_TPB), 0, c->stream, S, (const double*)c->d_recv, n, me, c->halo_cap,
                          S.gslot, c->hostN);
@@ -3581,11 +3595,20 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
     if (st_all > 0) h[C_STOP] = h[C_STOP] > 0 ? std::min(h[C_STOP], st_all) : st_all;
     break;
   }
-  // the rest of the batch again, from the floes as they lie after step sp (sz_step's capacity restart does the same)
-  tile_cleanup(c);
-  c->grid_live = false; use_static_grid(c);
-  HIPCHK(c, hipMemsetAsync(S.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
-  if (S.crec) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, S, c->hostN);
+  // the rest of the batch again.  The rank that paused: from its floes as they lie after step sp (sz_step's capacity restart does the same);
+  // the others: on from where the pause stopped them (see `fresh`)
+  fresh = h[C_PAUSED] == sp;
+  if (fresh) {
+    tile_cleanup(c);
+    c->grid_live = false; use_static_grid(c);
+    HIPCHK(c, hipMemsetAsync(S.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
+    if (S.crec) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, S, c->hostN);
+  } else {
+    c->tile_dirty = false;          // (nothing to drop: the rows behind the owned floes are the NEXT step's ghosts)
+    // the header records this rank's last pack left say "paused" (the launches enqueued behind the pause wrote the word there): not any more
+    const size_t hstride = (size_t)(c->halo_cap + 1) * halo_rec(S);
+    for (int d = 0; d < n; d++) HIPCHK(c, hipMemsetAsync(c->d_send + (size_t)d * hstride + 2, 0, sizeof(double), c->stream));
+  }
   s_begin = sp;          // (the ghosts of that step: behind its pack, at the top of the loop)
   }
   S.step = 0; S.ginline = 0; S.famrec = 0; S.crec = nullptr; S.retry_stop = 0; S.facc = nullptr; c->acc_mode = 0; c->reduce_mode = 0;

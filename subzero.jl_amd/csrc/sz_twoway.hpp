@@ -11,6 +11,7 @@
 namespace sz {
 
 __global__ void sz_k_tw_count(State S) {
+  if (stopped(S)) return;          // (a step behind the one that ended the batch: its launches are enqueued and return at once, like the forcing kernel's)
   if (stopped(S)) return;
   int N = S.cnt[C_NOWN];
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < (long long)N * FC_CAP; t += (long long)gridDim.x * blockDim.x) {
@@ -19,6 +20,7 @@ __global__ void sz_k_tw_count(State S) {
   }
 }
 __global__ void sz_k_tw_fill(State S) {
+  if (stopped(S)) return;          // (a step behind the one that ended the batch: its launches are enqueued and return at once, like the forcing kernel's)
   if (stopped(S)) return;
   int N = S.cnt[C_NOWN];
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < (long long)N * FC_CAP; t += (long long)gridDim.x * blockDim.x) {
@@ -29,6 +31,7 @@ __global__ void sz_k_tw_fill(State S) {
 // every cell's entries in the order the serial reference meets them: floe index ascending, then slot
 // (= first appearance among the floe's points); the lists are a handful of entries long
 __global__ void sz_k_tw_sort(State S, int ncell) {
+  if (stopped(S)) return;          // (a step behind the one that ended the batch: its launches are enqueued and return at once, like the forcing kernel's)
   if (stopped(S)) return;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < ncell; q += gridDim.x * blockDim.x) {
     int lo = S.cl_off[q], hi = S.cl_off[q + 1];
@@ -57,6 +60,7 @@ __device__ __forceinline__ void center_cell(const State& S, int ix0, int iy0, in
 // floe_area_in_cell of every (floe, cell) entry: G lanes per entry
 constexpr int TW_G = 8, TW_CAP = 32, TW_KC = 16, TW_RC = 64, TW_RM = 6;
 __global__ void __launch_bounds__(64) sz_k_tw_area(State S) {
+  if (stopped(S)) return;          // (a step behind the one that ended the batch: its launches are enqueued and return at once, like the forcing kernel's)
   if (stopped(S)) return;
   constexpr int GPB = 64 / TW_G;
   __shared__ GroupMem<TW_CAP, TW_KC, TW_RC, TW_RM> mem[GPB];
@@ -149,6 +153,7 @@ struct RectClip {
   }
 };
 __global__ void __launch_bounds__(256) sz_k_tw_area_rect(State S) {
+  if (stopped(S)) return;          // (a step behind the one that ended the batch: its launches are enqueued and return at once, like the forcing kernel's)
   if (stopped(S)) return;
   const int nent = S.cnt[C_NENT];
   const int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
@@ -207,6 +212,7 @@ __device__ __forceinline__ void tw_cell_finish(State& S, const Params& P, int q,
   S.hf[q] = hf; S.nodes[(size_t)q * 8 + 2] = hf;
 }
 __global__ void sz_k_tw_reduce(State S, Params P, int ncell, int dt) {
+  if (stopped(S)) return;          // (a step behind the one that ended the batch: its launches are enqueued and return at once, like the forcing kernel's)
   if (stopped(S)) return;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < ncell; q += gridDim.x * blockDim.x) {
     double tx, ty, si;
@@ -217,6 +223,7 @@ __global__ void sz_k_tw_reduce(State S, Params P, int ncell, int dt) {
 // tiled runs: every rank sums over the floes it owns (partial[q], [ncell + q], [2 ncell + q]), the host adds the
 // partial fields up across the ranks (all-reduce), then every rank finishes the cells
 __global__ void sz_k_tw_partial(State S, int ncell, double* partial) {
+  if (stopped(S)) return;          // (a step behind the one that ended the batch: its launches are enqueued and return at once, like the forcing kernel's)
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < ncell; q += gridDim.x * blockDim.x) {
     double tx, ty, si;
     tw_cell_sums(S, q, tx, ty, si);
@@ -224,6 +231,7 @@ __global__ void sz_k_tw_partial(State S, int ncell, double* partial) {
   }
 }
 __global__ void sz_k_tw_finish(State S, Params P, int ncell, int dt, const double* partial) {
+  if (stopped(S)) return;          // (a step behind the one that ended the batch: its launches are enqueued and return at once, like the forcing kernel's)
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < ncell; q += gridDim.x * blockDim.x)
     tw_cell_finish(S, P, q, partial[q], partial[ncell + q], partial[2 * (size_t)ncell + q], dt);
 }

@@ -271,6 +271,72 @@ def _worker_two_way(rank, world, port, n, seed, steps, q, backend="torch"):
         dist.destroy_process_group()
 
 
+def _two_way_stop_cfg(n, seed):
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=n, seed=seed, concentration=0.8, ocean="shear")
+    rng = np.random.default_rng(3)          # floes fast enough to run deep into one another within a few steps (a fuse: collisions.jl:366)
+    cfg["u"] = rng.uniform(-40.0, 40.0, n); cfg["v"] = rng.uniform(-40.0, 40.0, n)
+    return cfg
+
+
+def _worker_two_way_stop(rank, world, port, n, seed, steps, q):
+    import torch.distributed as dist
+    from subzero_jl_amd import tiles
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        cfg = _two_way_stop_cfg(n, seed)
+        tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True, backend="library-host", rebox_every=3)
+        tw.set_two_way(0.5, -8.0, cfg["dt"])
+        done = tw.run(steps, 0, cfg["dt"], coupling_dt=2, stop_on_tags=True)
+        tw.sync()
+        q.put((rank, tw.gidx, {f: tw.owned(f) for f in ("cx", "cy", "u", "v", "xi", "height", "status")}, [a.copy() for a in tw.world.ocean_stress()], done))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_worker_two_way_stop(*a):
+    _guard(_worker_two_way_stop)(*a)
+
+
+def test_two_way_coupling_across_tiles_ends_the_batch_on_a_tag():
+    """simplify_floes! runs after every step in the reference (simulation.jl:205-214): a tiled batch with two-way coupling on ends, on every
+    rank, after the step that tagged a floe -- it used to run to its end.  Fast floes that fuse a few steps in; two ranks against the
+    single context: the same number of steps, the same tags, columns and ocean fields to the round-off of the cross-rank sums."""
+    import torch.multiprocessing as mp
+    import subzero_jl_amd
+    from subzero_jl_amd import fields
+    n, seed, steps, world = 500, 77, 30, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_run_worker_two_way_stop, args=(r, world, port, n, seed, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = _collect(q, world)
+        for p in procs:
+            p.join(60)
+        assert all(p.exitcode == 0 for p in procs)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    cfg = _two_way_stop_cfg(n, seed)
+    hw = fields.build_world(subzero_jl_amd.World(0), cfg)
+    hw.set_two_way(True, dt=cfg["dt"]); hw.set_temps(0.5, -8.0)
+    k = hw.run(steps, 0, cfg["dt"], coupling_dt=2, stop_on_tags=True)
+    assert 1 <= k < steps and np.any(hw.get("status") != 1)          # a tag ended the batch in its middle
+    ref = hw.ocean_stress()
+    for rank, gidx, out, fields_, done in res:
+        assert done == k, (rank, done, k)
+        assert np.array_equal(out["status"], hw.get("status")[gidx]), rank
+        for name, g, r in zip(("tau_x", "tau_y", "si_frac", "hflx"), fields_, ref):
+            assert np.max(np.abs(g - r)) <= 1e-12 * max(np.max(np.abs(r)), 1e-300), (rank, name)
+        for f, v in out.items():
+            if f != "status":
+                assert np.max(np.abs(v - hw.get(f)[gidx])) <= 1e-12 * np.max(np.abs(hw.get(f))), (rank, f)
+
+
 @pytest.mark.parametrize("backend", ["torch", "library-host"])
 def test_two_way_coupling_across_tiles(backend):
     """Two ranks, two-way coupling on: the per-cell sums of both ranks added up give the single-context ocean
@@ -636,6 +702,94 @@ def test_a_pause_on_one_rank_and_a_tag_on_another_in_the_same_step():
         for f in FIELDS + ["status"]:
             assert np.array_equal(out[f], hw.get(f)[gidx]), (rank, f)
     assert paused == {0} and tagged == {1}, (paused, tagged)
+
+
+def _pause_in_a_fast_field_cfg(seed):
+    """fast floes that cross the periodic walls all the time (parents swap with their ghosts: collisions.jl:942-950) around the two stars whose
+    pair needs the largest narrow variant a few steps in (the pause), which sit in the middle of the left tile"""
+    from subzero_jl_amd import floe as floe_mod
+    base = _field(700, seed, fast=True)
+    L = base["L"]; off = base["vert_off"]
+    th = np.arange(16) * (2 * np.pi / 16)
+    rad = np.where(np.arange(16) % 2 == 0, 1.0e4, 0.55e4) * (L / 4.0e5)          # (the stars of _retry_cfg, scaled to this box)
+    c0 = np.array([0.25 * L, 0.5 * L])
+    def star(rot, cx):
+        r = np.stack([cx + rad * np.cos(-th + rot), c0[1] + rad * np.sin(-th + rot)], 1)
+        return np.concatenate([r, r[:1]])
+    stars = [star(0.0, c0[0]), star(np.pi / 8, c0[0] + 0.5 * rad.max())]
+    keep = [k for k in range(base["n_floes"]) if np.hypot(base["derived"]["cx"][k] - c0[0] - 0.25 * rad.max(), base["derived"]["cy"][k] - c0[1]) > 3.2 * rad.max()]
+    rings = stars + [np.stack([base["vx"][off[k]:off[k + 1]], base["vy"][off[k]:off[k + 1]]], 1) for k in keep]
+    n = len(rings)
+    o2 = np.zeros(n + 1, np.int32); o2[1:] = np.cumsum([len(r) for r in rings])
+    vx = np.concatenate([r[:, 0] for r in rings]); vy = np.concatenate([r[:, 1] for r in rings])
+    h = np.concatenate([[0.5, 0.5], base["height"][keep]])
+    cfg = dict(base)
+    cfg.update(n_floes=n, vert_off=o2, vx=vx, vy=vy, height=h, u=np.concatenate([[0.0, -0.75 * rad.max() / (6 * base["dt"])], base["u"][keep]]),
+               v=np.concatenate([[0.0, 0.0], base["v"][keep]]), xi=np.concatenate([[0.0, 0.0], base["xi"][keep]]),
+               derived=floe_mod.derive(o2, vx, vy, h), sub_off=np.zeros(n + 1, np.int32), sx=np.zeros(0), sy=np.zeros(0))
+    return cfg
+
+
+def _worker_pause_fast(rank, world, port, seed, steps, q):
+    import torch.distributed as dist
+    from subzero_jl_amd import tiles
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        cfg = _pause_in_a_fast_field_cfg(seed)
+        tw = tiles.TiledWorld(cfg, rank, world, 0, dist, host_staging=True, backend="library-host", rebox_every=3)
+        done = tw.run(steps, 0, cfg["dt"], coupling_dt=10, coupling_on=False)
+        off, x, y = tw.world.rings()
+        q.put((rank, tw.gidx, {f: tw.owned(f) for f in FIELDS}, done, int(tw.world.stats()["n_retry"]), x[:off[len(tw.gidx)]].copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_worker_pause_fast(*a):
+    _guard(_worker_pause_fast)(*a)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_a_pause_among_parents_that_swap_with_their_ghosts(seed):
+    """The pause for the largest narrow variant (rank 0's star pair) in a field whose parents cross the periodic walls all the time.  The ranks
+    that did NOT pause have the paused step behind them like any other -- their integrator has made the next ghosts from the parents
+    BEFORE their swap (collisions.jl:942-950) -- and take the steps up where they stopped; they used to start again from parents already
+    swapped, which re-numbers the ghosts of a corner parent and rounds a coordinate once more.  Two ranks, owned columns and ring points
+    bit-equal to the single context."""
+    import torch.multiprocessing as mp
+    import subzero_jl_amd
+    from subzero_jl_amd import fields
+    steps = 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_run_worker_pause_fast, args=(r, 2, port, seed, steps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = _collect(q, 2)
+        for p in procs:
+            p.join(60)
+        assert all(p.exitcode == 0 for p in procs)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    cfg = _pause_in_a_fast_field_cfg(seed)
+    hw = fields.build_world(subzero_jl_amd.World(0), cfg)
+    assert hw.run(steps, 0, cfg["dt"], coupling_dt=10, coupling_on=False, stop_on_tags=False) == steps
+    assert hw.stats()["n_retry"] >= 1
+    wrapped = np.abs(hw.get("cx") - cfg["derived"]["cx"]) > 0.5 * cfg["L"]
+    assert wrapped.sum() >= 3
+    hoff, hx, _ = hw.rings()
+    paused = set()
+    for rank, gidx, out, done, nretry, vx in res:
+        assert done == steps
+        if nretry:
+            paused.add(rank)
+        for f in FIELDS:
+            assert np.array_equal(out[f], hw.get(f)[gidx]), (rank, f, np.max(np.abs(out[f] - hw.get(f)[gidx])))
+        assert np.array_equal(vx, np.concatenate([hx[hoff[g]:hoff[g + 1]] for g in gidx])), rank
+    assert 0 in paused
 
 
 def _many_vertex_cfg(seed=5, n_side=12):
