@@ -1714,7 +1714,7 @@ void pipe_adopt(sz_ctx* c, int q) {
 }
 bool pipeline_eligible(const sz_ctx* c, int nsteps, bool coll, bool sg, bool gi, bool periodic, bool cr, bool rfree, int flags) {
   return rfree && !c->no_pipeline && coll && sg && (gi || !periodic) && cr && nsteps >= c->pipe_min_steps && c->hostN <= c->pipe_max_floes && c->precision == 0 && !c->two_way &&
-         !c->S.any_domain_work && c->S.maxnb <= MAXNB && !larger_rings(c) && c->pb[1].vxy && c->pb[1].work &&
+         (!c->S.any_domain_work || (!periodic && !c->any_moving)) && c->S.maxnb <= MAXNB && !larger_rings(c) && c->pb[1].vxy && c->pb[1].work &&
          (c->S.capM - c->hostN) / 2 > 64 && !(c->dbg & 8) && (flags & SZ_COLLISIONS_ON);
 }
 
@@ -1726,6 +1726,7 @@ int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling
   const int N = c->hostN;
   const bool user_stop = !(flags & SZ_NO_STOP);
   const bool fam = N <= 40000 && periodic;
+  const bool elems = S0.any_domain_work != 0;          // (eligible only without a periodic pair: no ghosts, the floe count is the host's)
   const int q0 = c->gpar;
   auto par = [&](int s) { return (q0 + s) & 1; };
   S0.stop_on_tags = user_stop ? 1 : 0; S0.restart_on_tags = user_stop ? 0 : 1;
@@ -1754,7 +1755,10 @@ int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling
     State T = pipe_state(c, q); T.step = s + 1; T.callid = callid0 + s + 1; T.retry_stop = lean ? 1 : 0;
     if (gi) hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(S0.capM, 256)), dim3(256), 0, c->stream, T, q, N);
     const dim3 gr(grid_for(S0.capM, NB_TPB / NB_G, 8192)), bl(NB_TPB);
-    if (fam) hipLaunchKernelGGL((sz_k_neighbors<true, MAXNB, true>), gr, bl, 0, c->stream, T);
+    if (elems) {          // (between walls: the element items of the step in the tail of its search, as the three-launch steps do)
+      const int nbe0 = grid_for(S0.capM, NB_TPB, 1 << 20);
+      hipLaunchKernelGGL((sz_k_neighbors_elem<false, true>), dim3(gr.x + nbe0), bl, 0, c->stream, T, next_epoch(c), (int)gr.x);
+    } else if (fam) hipLaunchKernelGGL((sz_k_neighbors<true, MAXNB, true>), gr, bl, 0, c->stream, T);
     else hipLaunchKernelGGL((sz_k_neighbors<false, MAXNB, true>), gr, bl, 0, c->stream, T);
     return SZ_OK;
   };
@@ -1798,10 +1802,12 @@ int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling
     State T = pipe_state(c, par(s + 1)); T.step = s + 2; T.callid = callid0 + s + 2; T.retry_stop = lean ? 1 : 0;
     const PipeAlt A = pipe_alt(c, par(s), 0);
     const int nbv = grid_for(N, NB_TPB, 1 << 20), nbs = with_search ? grid_for(S0.capM, NB_TPB / NB_G, 8192) : 0;
+    const int nbe = with_search && elems ? grid_for(N, NB_TPB, 1 << 20) : 0;
+    const unsigned ep = nbe ? next_epoch(c) : 0u;
     const int am = 1 | 4 | (host_last ? 2 : 0);
     Timed tm(c, SZ_K_INTEGRATE);
-    if (fam) hipLaunchKernelGGL((sz_k_vel_search<true>), dim3(nbv + nbs), dim3(NB_TPB), 0, c->stream, T, c->P, A, dt, coupling_at(s) ? 1 : 0, nbv, N, am);
-    else hipLaunchKernelGGL((sz_k_vel_search<false>), dim3(nbv + nbs), dim3(NB_TPB), 0, c->stream, T, c->P, A, dt, coupling_at(s) ? 1 : 0, nbv, N, am);
+    if (fam) hipLaunchKernelGGL((sz_k_vel_search<true>), dim3(nbv + nbs + nbe), dim3(NB_TPB), 0, c->stream, T, c->P, A, dt, coupling_at(s) ? 1 : 0, nbv, N, am, nbe, ep);
+    else hipLaunchKernelGGL((sz_k_vel_search<false>), dim3(nbv + nbs + nbe), dim3(NB_TPB), 0, c->stream, T, c->P, A, dt, coupling_at(s) ? 1 : 0, nbv, N, am, nbe, ep);
     tm.end();
   };
   // what lies behind the last step `last` (0-based) of the batch: parents un-swapped after a tag stop, strain, the step's rows, rows home, ghosts off

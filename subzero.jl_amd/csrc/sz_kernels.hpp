@@ -1590,9 +1590,12 @@ __global__ void sz_k_pairs_explicit(State S, int np) {
   if (blockIdx.x == 0 && threadIdx.x == 0) { S.cnt[C_ITEMCLASS] = 0; S.cnt[C_NFUSE] = 0; }
 }
 // ============================================================================ domain element items (A10 prefilter)
-template <typename F>
+// REC: centroid and rmax from the floe's collision record (pipelined steps: the columns are being brought up to date beside this scan)
+template <bool REC = false, typename F>
 __device__ __forceinline__ void elem_candidates(const State& S, int k, F&& emit) {
-  double cx = S.cx[k], cy = S.cy[k], r = S.rmax[k];
+  double cx, cy, r;
+  if constexpr (REC) { const double2 q0 = S.crec[(size_t)k * 8], q1 = S.crec[(size_t)k * 8 + 1]; cx = q0.x; cy = q0.y; r = q1.x; }
+  else { cx = S.cx[k]; cy = S.cy[k]; r = S.rmax[k]; }
   if (cy + r > S.eval[0] && S.ekind[0] != 1) emit(0);
   if (cy - r < S.eval[1] && S.ekind[1] != 1) emit(1);
   if (cx + r > S.eval[2] && S.ekind[2] != 1) emit(2);
@@ -1603,15 +1606,17 @@ __device__ __forceinline__ void elem_candidates(const State& S, int k, F&& emit)
   }
 }
 // count, scan (look-back) and fill of the floe-element items in one launch; tile: this workgroup's number among the scan's workgroups
-__device__ __forceinline__ void elem_scan_fill_body(State& S, unsigned epoch, int tile) {
+// mh >= 0 (pipelined steps of fields between walls: no ghosts, the host knows the count): the number of floes
+template <bool REC = false>
+__device__ __forceinline__ void elem_scan_fill_body(State& S, unsigned epoch, int tile, int mh = -1) {
   __shared__ int4 tot;
   if (stopped(S)) return;
-  const int M = S.cnt[C_M];
+  const int M = mh >= 0 ? mh : S.cnt[C_M];
   const int base = tile * (int)blockDim.x;
   if (base >= M && tile != 0) return;
   const int k = base + threadIdx.x;
   int c = 0;
-  if (k < M) elem_candidates(S, k, [&](int) { c++; });
+  if (k < M) elem_candidates<REC>(S, k, [&](int) { c++; });
   const int4 ex = block_exclusive_scan4(make_int4(c, 0, 0, 0), &tot);
   const int4 before = lookback_prefix4(S, tot, epoch, tile);
   if (M == 0) { if (k == 0) { S.el_off[0] = 0; S.cnt[C_NELEM] = 0; } return; }
@@ -1624,7 +1629,7 @@ __device__ __forceinline__ void elem_scan_fill_body(State& S, unsigned epoch, in
     S.cnt[C_NELEM] = t;
   }
   if (o + c > S.capElem) return;
-  elem_candidates(S, k, [&](int e) { S.el_floe[o] = k; S.el_elem[o] = e; o++; });
+  elem_candidates<REC>(S, k, [&](int e) { S.el_floe[o] = k; S.el_elem[o] = e; o++; });
 }
 __global__ void __launch_bounds__(SCAN_B) sz_k_elem_scan_fill(State S, unsigned epoch) { elem_scan_fill_body(S, epoch, (int)blockIdx.x); }
 // The element items ride in the tail of the neighbour search's launch (fields between walls: nothing in that launch changes the floe

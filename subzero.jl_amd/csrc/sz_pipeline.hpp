@@ -255,12 +255,16 @@ __device__ __forceinline__ void vel_body(State S, const Params& P, const PipeAlt
 }
 
 // L2(t): workgroups [0, nbv) update the parents, the others search the neighbours of step t + 1 (the search's REC instantiations)
+// nbe / epoch (fields between walls: no periodic pair, no ghosts): nbe more workgroups behind the search's count, scan and fill the floe-wall /
+// floe-topography items of step t + 1 (sz_k_elem_scan_fill, from the collision records)
 template <bool FAM>
-__global__ void __launch_bounds__(NB_TPB, 3) sz_k_vel_search(State S, Params P, PipeAlt A, int dt, int apply_frc, int nbv, int N, int acc_mode) {
+__global__ void __launch_bounds__(NB_TPB, 3) sz_k_vel_search(State S, Params P, PipeAlt A, int dt, int apply_frc, int nbv, int N, int acc_mode, int nbe, unsigned epoch) {
   if ((int)blockIdx.x < nbv) { vel_body(S, P, A, dt, apply_frc, (int)blockIdx.x, nbv, N, acc_mode); return; }
   // (a floe the forcings of step t leave without an in-bounds point is tagged by VEL(t), in this very launch: the hint says so a launch earlier)
   if ((S.stop_on_tags || S.restart_on_tags) && S.cnt[C_FRCSTOP] == S.step - 1 && S.step > 1) return;
-  neighbors_body<NB_TPB, FAM, MAXNB, true>(S, (int)blockIdx.x - nbv, (int)gridDim.x - nbv);
+  const int nbs = (int)gridDim.x - nbv - nbe;
+  if ((int)blockIdx.x < nbv + nbs) neighbors_body<NB_TPB, FAM, MAXNB, true>(S, (int)blockIdx.x - nbv, nbs);
+  else elem_scan_fill_body<true>(S, epoch, (int)blockIdx.x - nbv - nbs, N);
 }
 
 // ---------------------------------------------------------------- behind a pipelined batch

@@ -664,7 +664,7 @@ def _assert_worlds_bit_equal(a, b, fields=None):
     assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1])
 
 
-@pytest.mark.parametrize("scenario", ["dense", "fast-through", "fast-stops", "fuse-stop", "retry-pause", "tagged-before"])
+@pytest.mark.parametrize("scenario", ["dense", "fast-through", "fast-stops", "fuse-stop", "retry-pause", "tagged-before", "walls", "open-stop"])
 def test_pipelined_steps_equal_the_three_launch_steps(scenario):
     """Pipelined resident steps (csrc/sz_pipeline.hpp: narrow phase | next geometry, then update | next neighbour search -- two launches per
     timestep) against the three-launch steps (SZ_PIPELINE=0), bit for bit: every column, the rings, floe.interactions, the pair list, the status
@@ -672,7 +672,8 @@ def test_pipelined_steps_equal_the_three_launch_steps(scenario):
     ghosts) and fuse, in batches that run through -- a new tag restarts the enqueued steps so that the next ghosts know it; fast-stops: the same
     with the tag stop (the state handed back has the parents un-swapped again); fuse-stop: the reference's stop on a fuse in the middle of a
     batch; retry-pause: the pause for the largest narrow variant inside a pipelined step; tagged-before: a parent already tagged when the batch
-    starts (its first step runs on its own)."""
+    starts (its first step runs on its own); walls: configs[3]'s kind of field -- four collision walls and the strait's topography, the element
+    items of the next step made beside the update; open-stop: a floe drifting through an open boundary (tagged remove, collisions.jl:438)."""
     from subzero_jl_amd import fields
     if scenario in ("dense", "fast-through", "fast-stops", "tagged-before"):
         cfg = fields.make_config(n_floes=1500, seed=77, concentration=0.8)
@@ -687,6 +688,11 @@ def test_pipelined_steps_equal_the_three_launch_steps(scenario):
             return w
         dt = cfg["dt"]
         plan = {"dense": [(25, True), (6, True)], "fast-through": [(9, False), (14, False)], "fast-stops": [(12, True)] * 6, "tagged-before": [(8, True)]}[scenario]
+    elif scenario == "walls":
+        cfg = fields.make_config(n_floes=900, seed=5, walls=True, topography=True, ocean="strait")
+        build = lambda w: fields.build_world(w, cfg); dt = cfg["dt"]; plan = [(20, True), (7, False)]
+    elif scenario == "open-stop":
+        build = lambda w: _tag_scenario(w, "open"); dt = 10; plan = [(12, True)]
     elif scenario == "fuse-stop":
         build = lambda w: _tag_scenario(w, "fuse"); dt = 10; plan = [(12, True)]
     else:
@@ -694,7 +700,7 @@ def test_pipelined_steps_equal_the_three_launch_steps(scenario):
     a, b = _ab_worlds(build, {"SZ_PIPELINE": "0"})
     t = 0; ran_pipelined = False
     for n, stop in plan:
-        coupling = scenario not in ("fuse-stop", "retry-pause")
+        coupling = scenario not in ("fuse-stop", "retry-pause", "open-stop")
         da = a.run(n, t, dt, coupling_dt=1 if coupling else 10, coupling_on=coupling, stop_on_tags=stop)
         db = b.run(n, t, dt, coupling_dt=1 if coupling else 10, coupling_on=coupling, stop_on_tags=stop)
         assert da == db and not b.pipelined()
@@ -704,7 +710,7 @@ def test_pipelined_steps_equal_the_three_launch_steps(scenario):
     assert ran_pipelined, scenario
     if scenario == "fast-stops":
         assert t < 72                                             # batches really ended on tags
-    if scenario == "fuse-stop":
+    if scenario in ("fuse-stop", "open-stop"):
         assert 2 <= t < 12
     if scenario == "retry-pause":
         assert a.stats()["n_retry"] >= 1
