@@ -162,6 +162,8 @@ struct sz_ctx {
   int frc_first = 0;                // SZ_FRC_FIRST=n: the forcing tail of the narrow launch as n persistent workgroups in FRONT of the narrow ones (0: behind them)
   int pipe_max_floes = 60000;       // larger fields keep the three-launch steps: they are throughput-bound, nothing idles beside the narrow phase (measured at 100 k: 0.486 against 0.476 ms; SZ_PIPE_MAX_FLOES)
   int last_pipelined = 0;           // the last sz_step batch ran pipelined (sz_debug_pipelined)
+  bool crec_current = false;        // the collision records of set gpar hold the parents as they lie (a pipelined batch left them so; any call that moves or
+                                    // re-uploads floes outside such a batch clears it) and the twin set has the static quads: the next batch seeds neither
   bool no_reduce_free = false;      // SZ_REDUCE_FREE=0: keep the (rows-only) reduce launch inside every step (A/B)
   bool maybe_tagged = false;        // a parent may be non-active on the device (an upload said so, a batch ended on a tag, a process-mode call ran):
                                     // the next batch then runs its first step on its own (see sz_step)
@@ -449,7 +451,7 @@ void world_rings(sz_ctx* c) {
   c->rings_stale = false;
 }
 // every call outside the resident steps: the candidate list they keep goes stale, the world rings must be current
-void leave_resident(sz_ctx* c) { c->gl_valid = false; c->S.famrec = 0; world_rings(c); }
+void leave_resident(sz_ctx* c) { c->gl_valid = false; c->S.famrec = 0; c->crec_current = false; world_rings(c); }
 
 // the candidate list of the coming step, seeded from the parents as they lie
 void use_ghost_list(sz_ctx* c) {
@@ -1128,7 +1130,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
     c->gpar = 0;
   }
   DA(facc, (size_t)FX_WORDS * S.capM); c->facc_buf = S.facc; S.facc = nullptr;
-  c->maybe_tagged = false;
+  c->maybe_tagged = false; c->crec_current = false;
   if (f->status) for (int i = 0; i < N; i++) if (f->status[i] != SZ_ACTIVE) { c->maybe_tagged = true; break; }
   for (int k = 0; k < 4; k++) if ((rc = dalloc(c, &c->frc_alt[k], (size_t)S.capM, c->allocs))) return rc;
   DA(bounds, 16 + 64 * 4); DA(cell_cnt, S.capCells + 1); DA(cell_ovf, S.capCells + 1); DA(cell_slots, (size_t)S.capCells * CELL_K + 8);
@@ -1738,11 +1740,13 @@ int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling
   HIPCHK(c, hipMemsetAsync(S0.cnt + C_FRCSTOP, 0, sizeof(int), c->stream));
   const int callid0 = c->callid; c->callid += nsteps;
   // ---- the prologue of a (sub-)batch that starts at step s: cells, records, ghosts and the neighbour search of that step, from the floes as they lie
+  bool first_start = true;
   auto prologue = [&](int s) -> int {
     const int q = par(s);
     pipe_adopt(c, q);                                   // (the geometry of step s is in set q: the context's own from here on)
     S0.step = 0; S0.goff = 0; S0.gcap = 0;
-    c->grid_live = false; use_static_grid(c);           // cells[q] <- the parents
+    if (!first_start) c->grid_live = false;             // (a restart: the cells hold ghosts of a step that is started afresh)
+    use_static_grid(c);                                 // cells[q] <- the parents (unless they are: the last batch's update binned them)
     const sz_ctx::PipeBuf& O = c->pb[1 - q];
     HIPCHK(c, hipMemsetAsync(O.cell_cnt, 0, ((size_t)S0.capCells + 1) * sizeof(int), c->stream));
     HIPCHK(c, hipMemsetAsync(O.cell_ovf, 0, ((size_t)S0.capCells + 1) * sizeof(int), c->stream));
@@ -1750,8 +1754,10 @@ int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling
     HIPCHK(c, hipMemsetAsync(c->pb[0].ngh, 0, (size_t)S0.capM * sizeof(int), c->stream));          // (no links: a restart after a tag comes with those GEO made for a step that is now started afresh)
     HIPCHK(c, hipMemsetAsync(c->pb[1].ngh, 0, (size_t)S0.capM * sizeof(int), c->stream));
     HIPCHK(c, hipMemsetAsync(S0.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
-    // the records of both sets from the columns (the static quads of the twin; its geometry quads are GEO's)
-    for (int b = 0; b < 2; b++) { State T = pipe_state(c, b); T.step = 0; hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(N, 256)), dim3(256), 0, c->stream, T, N); }
+    // the records of both sets from the columns (the static quads of the twin; its geometry quads are GEO's) -- unless the last batch left them current
+    if (!(first_start && c->crec_current))
+      for (int b = 0; b < 2; b++) { State T = pipe_state(c, b); T.step = 0; hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(N, 256)), dim3(256), 0, c->stream, T, N); }
+    first_start = false;
     State T = pipe_state(c, q); T.step = s + 1; T.callid = callid0 + s + 1; T.retry_stop = lean ? 1 : 0;
     if (gi) hipLaunchKernelGGL(sz_k_ghost_inline_seed, dim3(grid_for(S0.capM, 256)), dim3(256), 0, c->stream, T, q, N);
     const dim3 gr(grid_for(S0.capM, NB_TPB / NB_G, 8192)), bl(NB_TPB);
@@ -1943,6 +1949,7 @@ int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling
   if (done < nsteps) c->grid_live = false;
   *done_out = done;
   c->last_pipelined = 1; c->gi_pending_slot = qlast;
+  c->crec_current = done == nsteps;          // (the records of the adopted set follow the columns; after a tag stop the un-swap rewrote a few: seeded again next time)
   // (h[C_STOP]: the caller's view -- a batch that ran through ended at nsteps)
   if (!user_stop) h[C_STOP] = 0;
   return leave(SZ_OK);
@@ -2000,6 +2007,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   c->last_pipelined = 0;
   const bool pipe = pipeline_eligible(c, nsteps, coll, sg, gi, periodic, cr,
                                       coll && c->facc_buf != nullptr && !c->no_reduce_free && sg && (gi || !periodic) && c->fused_move && c->max_ring <= MV_RING && !c->any_moving, flags);
+  if (!pipe) c->crec_current = false;          // (the three-launch steps seed the records they use; they may not keep the twin set's)
   if (cr && !pipe) hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(c->hostN, 256)), dim3(256), 0, c->stream, c->S, c->hostN);
   if (gi && !pipe) {               // the ghosts of the first step, from the parents as they lie (after the rings are in the batch's form)
     HIPCHK(c, hipMemsetAsync(c->S.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
