@@ -11,6 +11,8 @@ LIB = os.path.join(HERE, "libsubzero_hip.so")
 # -ffp-contract=off: fp64 expressions evaluate as written (no FMA), which is what makes the
 # discrete decisions of the narrow phase agree with the CPU reference path.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# experiments (tools/probe/*): extra -D switches for an A/B build, e.g. SZ_EXTRA_FLAGS="-DFRC_PLAIN_LANES=16"
+FLAGS += os.environ.get("SZ_EXTRA_FLAGS", "").split()
 
 
 def hipcc():

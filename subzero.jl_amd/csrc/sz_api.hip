@@ -91,6 +91,7 @@ struct sz_ctx {
   int narrow_grid0 = 0;
   // mixed precision (sz_set_precision): fp32 copies for the forcing kernel, rebuilt when their sources change
   int precision = 0; bool mixed_pts_ok = false, mixed_nodes_ok = false; Pool mixed_pt_allocs, mixed_node_allocs;
+  bool blk_pts_ok = false, no_block_points = false; Pool blk_pt_allocs; int pts_N = 0;      // State::sxy (ensure_block_points); pts_N: floes whose soff entries are set (upload, migration)
   // mixed precision, geometry: fp32 broad-phase records and body-frame rings (sz_state.hpp); rings_stale: resident steps ran on the
   // body rings, the world rings vx / vy are behind (rebuilt by world_rings() before anything else looks at them)
   bool mixed_geom_ok = false, rings_stale = false, no_body_rings = false; Pool mixed_geom_allocs;
@@ -656,6 +657,20 @@ void stage_forcing_fork(sz_ctx* c, const State* Sp = nullptr) {
   (void)hipEventRecord(c->ev_join, c->stream2);
 }
 void stage_forcing_join(sz_ctx* c) { (void)hipStreamWaitEvent(c->stream, c->ev_join, 0); }
+// the blocked copy of the sub-floe points the one-way fp64 forcing loop reads (State::sxy): made when the points or the lattice spacing changed
+// (SZ_BLOCK_POINTS=0: never -- the loop then reads sx / sy in the caller's order, A/B switch)
+int ensure_block_points(sz_ctx* c) {
+  State& S = c->S;
+  if (c->blk_pts_ok || c->no_block_points || !c->have_fields) return SZ_OK;
+  int rc;
+  free_pool(c->blk_pt_allocs);
+  S.sxy = nullptr;
+  if ((rc = dalloc(c, &S.sxy, (size_t)std::max(S.capS, 1), c->blk_pt_allocs))) return rc;
+  const double q = std::min(S.gdx, S.gdy) / 4.0;
+  if (c->pts_N > 0) hipLaunchKernelGGL(sz_k_block_points, dim3(grid_for(c->pts_N, 1, 1 << 16)), dim3(64), 0, c->stream, S, c->pts_N, q > 0 ? 1.0 / q : 1.0);
+  c->blk_pts_ok = true;
+  return SZ_OK;
+}
 // fp32 copies of the sub-floe points and of the lattice for the mixed-precision forcing kernel
 int ensure_mixed(sz_ctx* c) {
   State& S = c->S;
@@ -875,6 +890,7 @@ sz_ctx* sz_create(int device_id) {
   if (const char* e = getenv("SZ_PIPE_MIN_STEPS")) c->pipe_min_steps = std::max(2, atoi(e));
   if (const char* e = getenv("SZ_PIPE_MAX_FLOES")) c->pipe_max_floes = atoi(e);
   if (const char* e = getenv("SZ_FRC_FIRST")) c->frc_first = std::max(0, atoi(e));
+  if (const char* e = getenv("SZ_BLOCK_POINTS")) c->no_block_points = atoi(e) == 0;
   if (const char* e = getenv("SZ_TILE_FORCING_TAIL")) c->tile_forcing_in_tail = atoi(e) != 0;
   if (const char* e = getenv("SZ_GHOST_INLINE")) c->ghost_inline = atoi(e) != 0;
   if (const char* e = getenv("SZ_TILE_INLINE")) c->tile_inline_off = atoi(e) == 0;
@@ -908,7 +924,7 @@ void sz_destroy(sz_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   free_pool(c->allocs); free_pool(c->list_allocs); free_pool(c->inter_allocs); free_pool(c->static_allocs); free_pool(c->field_allocs); free_pool(c->tw_allocs); free_pool(c->tw_field_allocs);
-  free_pool(c->mixed_pt_allocs); free_pool(c->mixed_node_allocs); free_pool(c->mixed_geom_allocs); free_pool(c->comm_allocs); free_pool(c->tw_part_allocs); free_pool(c->sub_allocs); free_pool(c->mig_allocs);
+  free_pool(c->blk_pt_allocs); free_pool(c->mixed_pt_allocs); free_pool(c->mixed_node_allocs); free_pool(c->mixed_geom_allocs); free_pool(c->comm_allocs); free_pool(c->tw_part_allocs); free_pool(c->sub_allocs); free_pool(c->mig_allocs);
   (void)sz_comm_destroy(c);
   for (auto& e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   (void)hipFree(c->d_stats); (void)hipFree(c->S.acc);
@@ -981,7 +997,7 @@ int sz_set_fields(sz_ctx* c, int32_t Nx, int32_t Ny, double x0, double xf, doubl
   S.Nx = Nx; S.Ny = Ny; S.gx0 = x0; S.gxf = xf; S.gy0 = y0; S.gyf = yf; S.gdx = (xf - x0) / Nx; S.gdy = (yf - y0) / Ny; S.rdx = 1.0 / S.gdx; S.rdy = 1.0 / S.gdy;
   hipLaunchKernelGGL(sz_k_interleave_fields, dim3(grid_for((long long)n, 256)), dim3(256), 0, c->stream, S);
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->have_fields = true; c->mixed_nodes_ok = false;
+  c->have_fields = true; c->mixed_nodes_ok = false; c->blk_pts_ok = false; c->S.sxy = nullptr;
   return SZ_OK;
 }
 
@@ -1176,7 +1192,7 @@ int sz_upload_floes(sz_ctx* c, int64_t M64, int64_t N64, const sz_floe_columns* 
   H2D(S.cnt, h, C_COUNT + 64 + 72, int);
   hipLaunchKernelGGL(sz_k_osign, dim3(grid_for(S.capM, 256)), dim3(256), 0, c->stream, S, 0);
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->hostM = M; c->hostN = N; c->have_floes = true; c->tile_dirty = false; c->mixed_pts_ok = false; c->upload_M = M; c->upload_V = V;
+  c->hostM = M; c->hostN = N; c->have_floes = true; c->tile_dirty = false; c->mixed_pts_ok = false; c->blk_pts_ok = false; S.sxy = nullptr; c->pts_N = f->sub_off ? N : 0; c->upload_M = M; c->upload_V = V;
   c->gl_valid = false; c->gl_est = 0;
   c->mixed_geom_ok = false; c->rings_stale = false; S.rec32 = nullptr; S.ring32 = nullptr; S.body_rings = 0;
   if (f->rmax) {          // parents near a periodic wall: how long the ghost-candidate list will be (a superset of it)
@@ -1580,6 +1596,7 @@ int sz_timestep_coupling(sz_ctx* c) {
   leave_resident(c);            // a process-mode call: the resident steps' ghost-candidate list is stale, the world rings must be current
   if (c->two_way) { if (c->S.tiled) { c->err = "tiled contexts couple through sz_tile_step + sz_two_way_partial / sz_two_way_finish"; return SZ_E_STATE; } int rc = ensure_two_way(c); if (rc) return rc; }
   if (c->precision == 1 && !c->two_way) { int rc = ensure_mixed(c); if (rc) return rc; }
+  if (c->precision == 0 && !c->two_way) { int rc = ensure_block_points(c); if (rc) return rc; }
   stage_forcing(c);
   hipLaunchKernelGGL(sz_k_apply_frc, dim3(grid_for(c->S.capM, 256)), dim3(256), 0, c->stream, c->S);
   return sync_and_check(c);
@@ -1994,6 +2011,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   if (coll) c->gi_valid = false;    // (this batch's rows replace the old ones; set again below if they carry order keys of inline ghosts)
   const bool mixed = c->precision == 1 && !c->two_way;
   if (mixed) { int rc = ensure_mixed(c); if (rc) return rc; }
+  if (c->precision == 0 && !c->two_way && c->have_fields) { int rc = ensure_block_points(c); if (rc) return rc; }
   // mixed precision: the steps run on body-frame rings (the integrator moves poses, not rings) when nothing else in the batch
   // needs world rings -- single context, the list path for the ghosts, rings small enough for the fused integrator
   const bool body = mixed && coll && sg && (gl || !periodic) && !c->S.tiled && c->fused_move && c->max_ring <= MV_RING && !c->no_body_rings;
@@ -2329,6 +2347,7 @@ int tile_forcing(sz_ctx* c) {
   if (!c->have_fields) { c->err = "sz_set_fields must be called before coupling"; return SZ_E_STATE; }
   if (c->two_way) { int rc = ensure_two_way(c); if (rc) return rc; }
   else if (c->precision == 1) { int rc = ensure_mixed(c); if (rc) return rc; }
+  else { int rc = ensure_block_points(c); if (rc) return rc; }
   stage_forcing(c);
   return SZ_OK;
 }
@@ -3105,7 +3124,7 @@ int tile_migrate_device(sz_ctx* c, int px, int py, const int32_t* owner_override
   const int prec = c->precision;
   S.tiled = 0; S.famrec = 0;
   c->tile_margin = 0.0; c->tile_since_box = -1; c->halo_cap = 0; c->d_send = c->d_recv = c->d_ref = nullptr; c->d_dcap = nullptr;
-  c->hostM = Nn; c->hostN = Nn; c->tile_dirty = false; c->mixed_pts_ok = false;
+  c->hostM = Nn; c->hostN = Nn; c->tile_dirty = false; c->mixed_pts_ok = false; c->blk_pts_ok = false; S.sxy = nullptr; c->pts_N = Nn;
   c->gl_valid = false; c->gl_est = std::min(Nn, c->gl_est + R);          // (the ghost-candidate estimate is an upper bound)
   c->mixed_geom_ok = false; c->rings_stale = false; S.rec32 = nullptr; S.ring32 = nullptr; S.body_rings = 0;
   c->max_ring = std::max(c->max_ring, ring_in); c->max_sub = std::max(c->max_sub, sub_in); c->rmax_max = std::max(c->rmax_max, rmax_in);
@@ -3454,6 +3473,7 @@ int sz_tile_run(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t c
   HIPCHK(c, hipMemsetAsync(S.cnt + C_PAUSED, 0, sizeof(int), c->stream));
   use_static_grid(c);
   if (c->precision == 1) { int rc = ensure_mixed(c); if (rc) return rc; }
+  else if (!c->two_way && c->have_fields) { int rc = ensure_block_points(c); if (rc) return rc; }
   S.ginline = 1; S.famrec = 1; S.retry_stop = 0; S.body_rings = 0;
   HIPCHK(c, hipMemsetAsync(S.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
   // the periodic ghosts of the owned floes for the first step (and the swap of parents that lie outside the domain), BEFORE the first pack

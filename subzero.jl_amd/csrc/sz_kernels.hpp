@@ -2439,10 +2439,11 @@ __device__ __forceinline__ void forcing_wrap(const State& S, int i, double& cx, 
 }
 constexpr int FRC_G = 32;      // lanes per floe of the two-way variant
 #ifndef FRC_PLAIN_LANES
-#define FRC_PLAIN_LANES 32
+#define FRC_PLAIN_LANES 16
 #endif
-constexpr int FRC_PLAIN = FRC_PLAIN_LANES;   // lanes per floe of the one-way kernels (measured at 10 k floes: 64 lanes -- half as many trips over a floe's
-                                             // ~100 points -- is SLOWER, 24.4 against 21.4 us: the kernel is bound by the scattered lattice reads, not the chain)
+constexpr int FRC_PLAIN = FRC_PLAIN_LANES;   // lanes per floe of the one-way kernels.  Round 4, lean loop (tools/probe/r4_frc_lanes.sh; ms/step at 10 k | 100 k floes):
+                                             // 64 lanes 0.0846 | 0.5173, 32 lanes 0.0772 | 0.4894, 16 lanes 0.0765 | 0.4773, 8 lanes 0.0774 | 0.5038 -- a floe's ~100 points
+                                             // fill 7 trips of 16 lanes to 90 %, 4 trips of 32 to 78 %; with 8 lanes the floes' scalar loads take over
 // Two-way coupling (TW): the kernel also fills the floe's part of grid.floe_locations / ocean.scells
 // (floe_to_grid_info!, coupling.jl:1417-1454): per distinct centre cell its sub-floe points fall into, the
 // periodic shift of the first such point, the sum of minus the ocean stress over the points IN POINT ORDER, and
@@ -2456,8 +2457,34 @@ constexpr int TW_FPB = 4;       // floes per workgroup of the two-way variant (1
 // bid / nblk: rank and number of the forcing workgroups; first: physical id of the first of them in the launch.  The floes of one
 // XCD's workgroups are a contiguous index range (= a region in space): a lattice node is then fetched by one or two XCDs' L2
 // instead of all eight
+// ---- the one-way forcings with lean per-point arithmetic (round 4; SZ_FRC_LEAN=0 compiles the plain loop back in for A/B).
+// The contract on fxOA / fyOA / trqOA / hflx is a tolerance against the reference (1e-10 relative; the reference's own tests hold them to
+// 1e-3), not bit-equality with the straightforward evaluation -- and the kernel is bound by the fp64 instructions it issues (L1 launch at
+// 10 k floes: 63 % of all issue cycles busy, a third of its vector instructions are this loop).  What stays EXACTLY as before: the
+// point's world coordinates, the in-bounds test and the lattice cell (the discrete decisions).  What changes, a few ulps per point:
+//   * the bilinear blend as four weights (one product + three fused multiply-adds per field instead of six operations),
+//   * square roots from the hardware reciprocal-square-root estimate + two coupled Newton steps (~1 ulp; the arguments are squared
+//     relative speeds: zero or far above the denormal range),
+//   * the stress sums contracted into fused multiply-adds,
+//   * the next point's body coordinates are asked for before the current point is worked on.
+#ifndef SZ_FRC_LEAN
+#define SZ_FRC_LEAN 1
+#endif
+__device__ __forceinline__ double sqrt_fast(double s) {
+  const double y = __builtin_amdgcn_rsq(s);
+  double g = s * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  const double d = fma(-g, g, s);
+  g = fma(d, h, g);
+  return s > 0.0 ? g : 0.0;
+}
+template <int FG>
+__device__ __forceinline__ void forcing_lean_body(State& S, const Params& P, int bid, int nblk, int first);
+
 template <bool TW>
 __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid, int nblk, int pmax, int first) {
+  if constexpr (!TW && SZ_FRC_LEAN != 0) { forcing_lean_body<FRC_PLAIN>(S, P, bid, nblk, first); return; }
   extern __shared__ double tw_lds[];
   constexpr int FG = TW ? FRC_G : FRC_PLAIN;      // lanes per floe
   int lane = threadIdx.x % FG, wpb = blockDim.x / FG, wid = threadIdx.x / FG;
@@ -2604,6 +2631,77 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
   }
 }
 
+template <int FG>
+__device__ __forceinline__ void forcing_lean_body(State& S, const Params& P, int bid, int nblk, int first) {
+  const int lane = threadIdx.x % FG, wpb = blockDim.x / FG, wid = threadIdx.x / FG;
+  if (stopped(S)) return;
+  const int N = S.cnt[C_NOWN];
+  const int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
+  const double cturn = cos(P.turn), sturn = sin(P.turn);
+  const double ka = P.rho_a * P.Cd_ia, ko = P.rho_o * P.Cd_io;
+  const int vb0 = S.xcd_forcing ? xcd_contiguous_from(first + bid, first, nblk, (N + wpb - 1) / wpb) : bid;
+  for (int i = vb0 < 0 ? N : vb0 * wpb + wid; i < N; i += nblk * wpb) {
+    double cxf = S.cx[i], cyf = S.cy[i]; const double u = S.u[i], v = S.v[i], xi = S.xi[i];
+    forcing_wrap(S, i, cxf, cyf);
+    const double ca = S.trig[2 * i], sa = S.trig[2 * i + 1];   // cos(alpha), sin(alpha)
+    const double ma_ratio = S.mass[i] / S.area[i];
+    const double mf = ma_ratio * P.fcor;
+    const int o = S.soff[i], ns = S.soff[i + 1] - o;
+    double tx = 0, ty = 0, ttrq = 0, th = 0; int np = 0;
+    const bool blocked = S.sxy != nullptr;      // (the blocked copy when it has been made: State::sxy)
+    auto point = [&](int k) { return k >= ns ? make_double2(0.0, 0.0) : blocked ? S.sxy[o + k] : make_double2(S.sx[o + k], S.sy[o + k]); };
+    double2 nxt = point(lane);
+    for (int k = lane; k < ns; k += FG) {
+      const double sxk = nxt.x, syk = nxt.y;
+      nxt = point(k + FG);
+      // (the point's coordinates, the in-bounds test and the cell: the expressions of the plain loop, bit for bit)
+      const double x = (ca * sxk - sa * syk) + cxf;
+      const double y = (sa * sxk + ca * syk) + cyf;
+      if (!point_in_bounds(S, x, y, per_x, per_y)) continue;
+      np++;
+      const double xc = x - cxf, yc = y - cyf;      // (rad sin / rad cos of coupling.jl:1530-1537: see the plain loop)
+      const double up = fma(-xi, yc, u), vp = fma(xi, xc, v);
+      const LatticeCell lc = lattice_cell(S, x, y, per_x, per_y);
+      double n4[4][5];
+      {
+        const int oo[4] = { lc.o00, lc.o01, lc.o10, lc.o11 };
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const double4 a = *(const double4*)(S.nodes + (size_t)oo[q] * 8);
+          n4[q][0] = a.x; n4[q][1] = a.y; n4[q][2] = a.z; n4[q][3] = a.w; n4[q][4] = S.nodes[(size_t)oo[q] * 8 + 4];
+        }
+      }
+      const double omty = 1.0 - lc.ty, omtx = 1.0 - lc.tx;
+      const double w00 = omtx * omty, w01 = omtx * lc.ty, w10 = lc.tx * omty, w11 = lc.tx * lc.ty;
+      auto sample = [&](int f) { return fma(w11, n4[3][f], fma(w10, n4[2][f], fma(w01, n4[1][f], w00 * n4[0][f]))); };
+      const double uatm = sample(3), vatm = sample(4), uocn = sample(0), vocn = sample(1), hfl = sample(2);
+      const double du = uatm - up, dv = vatm - vp, duo = uocn - up, dvo = vocn - vp;
+      const double qa = ka * sqrt_fast(fma(du, du, dv * dv)), qo = ko * sqrt_fast(fma(duo, duo, dvo * dvo));
+      const double fx = fma(qa, du, fma(qo, fma(cturn, duo, -(sturn * dvo)), -(mf * vocn)));
+      const double fy = fma(qa, dv, fma(qo, fma(sturn, duo, cturn * dvo), mf * uocn));
+      tx += fx; ty += fy; th += hfl;
+      ttrq += fma(fy, xc, -(fx * yc));
+    }
+    for (int d = FG / 2; d >= 1; d >>= 1) {
+      tx += __shfl_xor(tx, d, FG); ty += __shfl_xor(ty, d, FG); ttrq += __shfl_xor(ttrq, d, FG); th += __shfl_xor(th, d, FG);
+    }
+    int npt = np;
+    for (int d = FG / 2; d >= 1; d >>= 1) npt += __shfl_xor(npt, d, FG);
+    if (lane == 0) {
+      // (no in-bounds point: marked for removal, coupling.jl:1507-1508 -- see the plain loop)
+      S.frc_remove[i] = npt == 0 ? 1 : 0;
+      if (npt == 0) { if (S.step > 0 && (S.stop_on_tags || S.restart_on_tags)) S.cnt[C_FRCSTOP] = S.step; }
+      else {
+        const double xcor = ma_ratio * P.fcor * v, ycor = ma_ratio * P.fcor * u;
+        const double totx = npt * xcor + tx, toty = -npt * ycor + ty;
+        const double area = S.area[i];
+        S.fxOA[i] = totx / npt * area; S.fyOA[i] = toty / npt * area;
+        S.trqOA[i] = ttrq / npt * area; S.hflx[i] = th / npt;
+      }
+    }
+  }
+}
+
 template <bool TW>
 __global__ void __launch_bounds__(256) sz_k_forcing(State S, Params P, int pmax) { forcing_body<TW>(S, P, blockIdx.x, gridDim.x, pmax, 0); }
 
@@ -2618,6 +2716,36 @@ inline size_t tw_forcing_lds(int pmax) { return (size_t)TW_FPB * ((size_t)2 * pm
 // -- and the per-floe totals stay fp64.  Everything else (contacts, integrator) is unchanged fp64.  The
 // reference has no Float32 answers to match (documentation.md:25: only Float64 is tested and supported): the
 // mixed path is held to the fp64 path with a stated tolerance (tests/test_hip_parity.py::test_mixed_precision).
+// blocked copy of the sub-floe points (State::sxy): one wavefront per floe ranks the floe's points by the Morton key of their body-frame
+// coordinates (quantum q: a quarter of the lattice spacing) -- a counting rank, ties by index: a permutation whatever the keys are
+constexpr int BLK_CAP = 2048;
+__device__ __forceinline__ unsigned morton16(unsigned x, unsigned y) {
+  auto spread = [](unsigned v) { v &= 0xffffu; v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u; return v; };
+  return spread(x) | (spread(y) << 1);
+}
+__global__ void __launch_bounds__(64) sz_k_block_points(State S, int N, double rq) {
+  __shared__ unsigned key[BLK_CAP];
+  for (int i = blockIdx.x; i < N; i += gridDim.x) {
+    const int o = S.soff[i], ns = S.soff[i + 1] - o;
+    if (ns > BLK_CAP) {          // (a floe with more points than the sort holds keeps its order)
+      for (int k = threadIdx.x; k < ns; k += 64) S.sxy[o + k] = make_double2(S.sx[o + k], S.sy[o + k]);
+      continue;
+    }
+    for (int k = threadIdx.x; k < ns; k += 64) {
+      const double fx = floor(S.sx[o + k] * rq) + 32768.0, fy = floor(S.sy[o + k] * rq) + 32768.0;
+      const unsigned qx = (unsigned)fmin(fmax(fx, 0.0), 65535.0), qy = (unsigned)fmin(fmax(fy, 0.0), 65535.0);
+      key[k] = morton16(qx, qy);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < ns; k += 64) {
+      const unsigned mine = key[k];
+      int r = 0;
+      for (int j = 0; j < ns; j++) { const unsigned kj = key[j]; r += (kj < mine || (kj == mine && j < k)) ? 1 : 0; }
+      S.sxy[o + r] = make_double2(S.sx[o + k], S.sy[o + k]);
+    }
+    __syncthreads();
+  }
+}
 __global__ void sz_k_to_f32_points(State S, int n) {
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) S.s32[q] = make_float2((float)S.sx[q], (float)S.sy[q]);
 }

@@ -101,6 +101,13 @@ struct State {
   int* voff; double2* vxy;           // rings, CSR: point k of floe i at vxy[voff[i] + k] = {x, y} (closed: the first point repeated) -- interleaved,
                                      // so that whoever moves, copies or stages a ring issues one 16-byte access per point instead of two 8-byte ones
   int* soff; double *sx, *sy;
+  // the sub-floe points once more, {x, y} interleaved and every floe's points in BLOCKED order (Morton order of the body-frame coordinates on a quarter
+  // of the lattice spacing: sz_k_block_points).  The one-way forcing loop reads these: 16 consecutive points then lie in one or two lattice cells
+  // instead of along a row of the floe's sub-grid, and the lattice loads of a wavefront touch a third as many cache lines -- the loop was bound by
+  // the lines its loads touch (round 4: 79.6 M line accesses per launch at 100 k floes = 311 k cycles per CU of a 327 k-cycle kernel).  A derived
+  // copy like s32 (null until made; made again after an upload, a migration or new fields); the per-floe sums of the one-way path are held to a
+  // tolerance, not to the point order -- the two-way kernel, whose per-cell sums ARE ordered, keeps reading sx / sy.
+  double2* sxy;
   // ---- domain elements: 0..3 = N,S,E,W boundaries, 4.. = topography
   int* eoff; double *ex, *ey;
   int *ekind, *edir; double *eval, *eu, *ev, *ecx, *ecy, *ermax, *erect;  // erect: 4 per boundary

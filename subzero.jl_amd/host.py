@@ -217,6 +217,16 @@ class World:
                 a = np.ascontiguousarray(a, _I32); keep.append(a); setattr(f, n, capi.ptr(a, capi._ip))
         return f
 
+    def subpoints(self):
+        """(offsets, sx, sy) of the sub-floe points as the library holds them (sz_download_subpoints): the caller's points in the caller's order"""
+        self._push()
+        n = self.N
+        off = np.zeros(n + 1, _I32)
+        self._chk(self.L.sz_download_subpoints(self.h, capi.ptr(off, capi._ip), None, None))
+        sx = np.zeros(max(int(off[n]), 1)); sy = np.zeros(max(int(off[n]), 1))
+        self._chk(self.L.sz_download_subpoints(self.h, capi.ptr(off, capi._ip), capi.ptr(sx), capi.ptr(sy)))
+        return off, sx[:off[n]], sy[:off[n]]
+
     def _fetch_subpoints(self):
         """after a migration of a tiled run (tiles.TiledWorld.migrate) the sub-floe points of the tile are the library's: fetched when needed"""
         if not getattr(self, "_sub_on_device", False):

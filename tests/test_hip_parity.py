@@ -278,6 +278,33 @@ def test_forcing_and_integrator_random():
     parity.compare_worlds(hw, ow, rtol=1e-11, check_pairs=False, check_inter=False)
 
 
+def test_blocked_subfloe_points_are_a_reordering(monkeypatch):
+    """The one-way forcing loop reads a blocked copy of the sub-floe points (State::sxy, Morton order per floe): the same points, another
+    order of the per-floe sums -- forcings within 1e-12 of the loop on the caller's order (SZ_BLOCK_POINTS=0), both within 1e-11 of the oracle
+    (coupling.jl:1486-1589), and the points handed back to the host are the caller's, in the caller's order."""
+    from subzero_jl_amd import fields
+    cfg = fields.make_config(n_floes=700, seed=14, ocean="converge_diverge")
+    ow = fields.build_world(omk(), cfg)
+    ow.timestep_coupling()
+    got = {}
+    for env in ("1", "0"):
+        monkeypatch.setenv("SZ_BLOCK_POINTS", env)
+        hw = fields.build_world(mk(), cfg)
+        off0, sx0, sy0 = hw.subpoints()
+        hw.timestep_coupling()
+        hw.run(2, 0, cfg["dt"], coupling_dt=1)          # (resident steps: the forcings in the tail of the narrow launch read the same copy)
+        off1, sx1, sy1 = hw.subpoints()
+        assert np.array_equal(off0, off1) and np.array_equal(sx0, sx1) and np.array_equal(sy0, sy1)
+        hw2 = fields.build_world(mk(), cfg)
+        hw2.timestep_coupling()
+        got[env] = {f: hw2.get(f).copy() for f in ("fxOA", "fyOA", "trqOA", "hflx_factor")}
+        for f in got[env]:
+            assert parity.relerr(got[env][f], ow.get(f)) <= 1e-11, (env, f)
+    for f in got["1"]:
+        assert parity.relerr(got["1"][f], got["0"][f]) <= 1e-12, f
+    assert not np.array_equal(got["1"]["fxOA"], got["0"]["fxOA"])          # (it really is another order)
+
+
 @pytest.mark.parametrize("n,seed,steps", [(400, 5, 10), (2500, 6, 4)])
 def test_trajectories(n, seed, steps):
     """timestep_sim! for several steps, state resident on the device: trajectories within 1e-9."""

@@ -1,0 +1,7 @@
+# lanes per floe of the one-way forcing loop (lean arithmetic): A/B builds on the GPU box
+P='import sys,json; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],4), round(d["ms_per_step_min"],4), {k: round(v,4) for k,v in d["kernel_ms_per_step"].items() if v})'
+for f in "-DFRC_PLAIN_LANES=16" "-DFRC_PLAIN_LANES=64" "-DSZ_FRC_LEAN=0" "-DFRC_PLAIN_LANES=32"; do
+  echo "build $f"; SZ_EXTRA_FLAGS="$f" python subzero.jl_amd/build.py > /dev/null 2>&1 || { echo build failed; continue; }
+  echo " 10k:"; python bench.py --no-cpu-baseline --no-strong-reference --repeats 5 2>/dev/null | python -c "$P"
+  echo " 100k:"; python bench.py --no-cpu-baseline --no-strong-reference --floes 100000 --workload configs2 --steps 50 --repeats 5 2>/dev/null | python -c "$P"
+done

@@ -1,0 +1,3 @@
+# forcings on the second stream BEHIND the narrow launch, one-wavefront workgroups (SZ_OVERLAP=2), 10 k floes
+P='import sys,json; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],4), round(d["ms_per_step_min"],4), d["roofline"].get("pipelined_steps"), {k: round(v,4) for k,v in d["kernel_ms_per_step"].items() if v})'
+for v in "SZ_X=0" "SZ_OVERLAP=2" "SZ_OVERLAP=2 SZ_NARROW_GRID=2048" "SZ_OVERLAP=2 SZ_NARROW_GRID=2304" "SZ_OVERLAP=1"; do echo $v; env $v python bench.py --no-cpu-baseline --no-strong-reference --repeats 5 2>/dev/null | python -c "$P"; done
