@@ -2631,73 +2631,86 @@ __device__ __forceinline__ void forcing_body(State& S, const Params& P, int bid,
   }
 }
 
+// the constants of the loop (hoisted out of the floe loop by whoever runs it)
+struct FrcConsts { int per_x, per_y; double cturn, sturn, ka, ko; };
+__device__ __forceinline__ FrcConsts frc_consts(const State& S, const Params& P) {
+  FrcConsts C; C.per_x = S.ekind[2] == 1; C.per_y = S.ekind[0] == 1; C.cturn = cos(P.turn); C.sturn = sin(P.turn);
+  C.ka = P.rho_a * P.Cd_ia; C.ko = P.rho_o * P.Cd_io;
+  return C;
+}
+// the forcings of ONE floe by the FG lanes of a group (calc_one_way_coupling!, coupling.jl:1486-1589): on return every lane holds npt, the number of
+// in-bounds points, and -- if npt > 0 -- the floe's fxOA, fyOA, trqOA and hflx_factor.  Nothing is stored.
+template <int FG>
+__device__ __forceinline__ void forcing_lean_floe(const State& S, const Params& P, const FrcConsts& C, int i, int lane, int& npt, double& o_fx, double& o_fy, double& o_trq, double& o_hflx) {
+  double cxf = S.cx[i], cyf = S.cy[i]; const double u = S.u[i], v = S.v[i], xi = S.xi[i];
+  forcing_wrap(S, i, cxf, cyf);
+  const double ca = S.trig[2 * i], sa = S.trig[2 * i + 1];   // cos(alpha), sin(alpha)
+  const double area = S.area[i];
+  const double ma_ratio = S.mass[i] / area;
+  const double mf = ma_ratio * P.fcor;
+  const int o = S.soff[i], ns = S.soff[i + 1] - o;
+  double tx = 0, ty = 0, ttrq = 0, th = 0; int np = 0;
+  const bool blocked = S.sxy != nullptr;      // (the blocked copy when it has been made: State::sxy)
+  auto point = [&](int k) { return k >= ns ? make_double2(0.0, 0.0) : blocked ? S.sxy[o + k] : make_double2(S.sx[o + k], S.sy[o + k]); };
+  double2 nxt = point(lane);
+  for (int k = lane; k < ns; k += FG) {
+    const double sxk = nxt.x, syk = nxt.y;
+    nxt = point(k + FG);
+    // (the point's coordinates, the in-bounds test and the cell: the expressions of the plain loop, bit for bit)
+    const double x = (ca * sxk - sa * syk) + cxf;
+    const double y = (sa * sxk + ca * syk) + cyf;
+    if (!point_in_bounds(S, x, y, C.per_x, C.per_y)) continue;
+    np++;
+    const double xc = x - cxf, yc = y - cyf;      // (rad sin / rad cos of coupling.jl:1530-1537: see the plain loop)
+    const double up = fma(-xi, yc, u), vp = fma(xi, xc, v);
+    const LatticeCell lc = lattice_cell(S, x, y, C.per_x, C.per_y);
+    double n4[4][5];
+    {
+      const int oo[4] = { lc.o00, lc.o01, lc.o10, lc.o11 };
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double4 a = *(const double4*)(S.nodes + (size_t)oo[q] * 8);
+        n4[q][0] = a.x; n4[q][1] = a.y; n4[q][2] = a.z; n4[q][3] = a.w; n4[q][4] = S.nodes[(size_t)oo[q] * 8 + 4];
+      }
+    }
+    const double omty = 1.0 - lc.ty, omtx = 1.0 - lc.tx;
+    const double w00 = omtx * omty, w01 = omtx * lc.ty, w10 = lc.tx * omty, w11 = lc.tx * lc.ty;
+    auto sample = [&](int f) { return fma(w11, n4[3][f], fma(w10, n4[2][f], fma(w01, n4[1][f], w00 * n4[0][f]))); };
+    const double uatm = sample(3), vatm = sample(4), uocn = sample(0), vocn = sample(1), hfl = sample(2);
+    const double du = uatm - up, dv = vatm - vp, duo = uocn - up, dvo = vocn - vp;
+    const double qa = C.ka * sqrt_fast(fma(du, du, dv * dv)), qo = C.ko * sqrt_fast(fma(duo, duo, dvo * dvo));
+    const double fx = fma(qa, du, fma(qo, fma(C.cturn, duo, -(C.sturn * dvo)), -(mf * vocn)));
+    const double fy = fma(qa, dv, fma(qo, fma(C.sturn, duo, C.cturn * dvo), mf * uocn));
+    tx += fx; ty += fy; th += hfl;
+    ttrq += fma(fy, xc, -(fx * yc));
+  }
+  for (int d = FG / 2; d >= 1; d >>= 1) {
+    tx += __shfl_xor(tx, d, FG); ty += __shfl_xor(ty, d, FG); ttrq += __shfl_xor(ttrq, d, FG); th += __shfl_xor(th, d, FG);
+  }
+  npt = np;
+  for (int d = FG / 2; d >= 1; d >>= 1) npt += __shfl_xor(npt, d, FG);
+  o_fx = o_fy = o_trq = o_hflx = 0.0;
+  if (npt != 0) {
+    const double xcor = ma_ratio * P.fcor * v, ycor = ma_ratio * P.fcor * u;
+    const double totx = npt * xcor + tx, toty = -npt * ycor + ty;
+    o_fx = totx / npt * area; o_fy = toty / npt * area; o_trq = ttrq / npt * area; o_hflx = th / npt;
+  }
+}
 template <int FG>
 __device__ __forceinline__ void forcing_lean_body(State& S, const Params& P, int bid, int nblk, int first) {
   const int lane = threadIdx.x % FG, wpb = blockDim.x / FG, wid = threadIdx.x / FG;
   if (stopped(S)) return;
   const int N = S.cnt[C_NOWN];
-  const int per_x = S.ekind[2] == 1, per_y = S.ekind[0] == 1;
-  const double cturn = cos(P.turn), sturn = sin(P.turn);
-  const double ka = P.rho_a * P.Cd_ia, ko = P.rho_o * P.Cd_io;
+  const FrcConsts C = frc_consts(S, P);
   const int vb0 = S.xcd_forcing ? xcd_contiguous_from(first + bid, first, nblk, (N + wpb - 1) / wpb) : bid;
   for (int i = vb0 < 0 ? N : vb0 * wpb + wid; i < N; i += nblk * wpb) {
-    double cxf = S.cx[i], cyf = S.cy[i]; const double u = S.u[i], v = S.v[i], xi = S.xi[i];
-    forcing_wrap(S, i, cxf, cyf);
-    const double ca = S.trig[2 * i], sa = S.trig[2 * i + 1];   // cos(alpha), sin(alpha)
-    const double ma_ratio = S.mass[i] / S.area[i];
-    const double mf = ma_ratio * P.fcor;
-    const int o = S.soff[i], ns = S.soff[i + 1] - o;
-    double tx = 0, ty = 0, ttrq = 0, th = 0; int np = 0;
-    const bool blocked = S.sxy != nullptr;      // (the blocked copy when it has been made: State::sxy)
-    auto point = [&](int k) { return k >= ns ? make_double2(0.0, 0.0) : blocked ? S.sxy[o + k] : make_double2(S.sx[o + k], S.sy[o + k]); };
-    double2 nxt = point(lane);
-    for (int k = lane; k < ns; k += FG) {
-      const double sxk = nxt.x, syk = nxt.y;
-      nxt = point(k + FG);
-      // (the point's coordinates, the in-bounds test and the cell: the expressions of the plain loop, bit for bit)
-      const double x = (ca * sxk - sa * syk) + cxf;
-      const double y = (sa * sxk + ca * syk) + cyf;
-      if (!point_in_bounds(S, x, y, per_x, per_y)) continue;
-      np++;
-      const double xc = x - cxf, yc = y - cyf;      // (rad sin / rad cos of coupling.jl:1530-1537: see the plain loop)
-      const double up = fma(-xi, yc, u), vp = fma(xi, xc, v);
-      const LatticeCell lc = lattice_cell(S, x, y, per_x, per_y);
-      double n4[4][5];
-      {
-        const int oo[4] = { lc.o00, lc.o01, lc.o10, lc.o11 };
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const double4 a = *(const double4*)(S.nodes + (size_t)oo[q] * 8);
-          n4[q][0] = a.x; n4[q][1] = a.y; n4[q][2] = a.z; n4[q][3] = a.w; n4[q][4] = S.nodes[(size_t)oo[q] * 8 + 4];
-        }
-      }
-      const double omty = 1.0 - lc.ty, omtx = 1.0 - lc.tx;
-      const double w00 = omtx * omty, w01 = omtx * lc.ty, w10 = lc.tx * omty, w11 = lc.tx * lc.ty;
-      auto sample = [&](int f) { return fma(w11, n4[3][f], fma(w10, n4[2][f], fma(w01, n4[1][f], w00 * n4[0][f]))); };
-      const double uatm = sample(3), vatm = sample(4), uocn = sample(0), vocn = sample(1), hfl = sample(2);
-      const double du = uatm - up, dv = vatm - vp, duo = uocn - up, dvo = vocn - vp;
-      const double qa = ka * sqrt_fast(fma(du, du, dv * dv)), qo = ko * sqrt_fast(fma(duo, duo, dvo * dvo));
-      const double fx = fma(qa, du, fma(qo, fma(cturn, duo, -(sturn * dvo)), -(mf * vocn)));
-      const double fy = fma(qa, dv, fma(qo, fma(sturn, duo, cturn * dvo), mf * uocn));
-      tx += fx; ty += fy; th += hfl;
-      ttrq += fma(fy, xc, -(fx * yc));
-    }
-    for (int d = FG / 2; d >= 1; d >>= 1) {
-      tx += __shfl_xor(tx, d, FG); ty += __shfl_xor(ty, d, FG); ttrq += __shfl_xor(ttrq, d, FG); th += __shfl_xor(th, d, FG);
-    }
-    int npt = np;
-    for (int d = FG / 2; d >= 1; d >>= 1) npt += __shfl_xor(npt, d, FG);
+    int npt; double fx, fy, trq, hf;
+    forcing_lean_floe<FG>(S, P, C, i, lane, npt, fx, fy, trq, hf);
     if (lane == 0) {
       // (no in-bounds point: marked for removal, coupling.jl:1507-1508 -- see the plain loop)
       S.frc_remove[i] = npt == 0 ? 1 : 0;
       if (npt == 0) { if (S.step > 0 && (S.stop_on_tags || S.restart_on_tags)) S.cnt[C_FRCSTOP] = S.step; }
-      else {
-        const double xcor = ma_ratio * P.fcor * v, ycor = ma_ratio * P.fcor * u;
-        const double totx = npt * xcor + tx, toty = -npt * ycor + ty;
-        const double area = S.area[i];
-        S.fxOA[i] = totx / npt * area; S.fyOA[i] = toty / npt * area;
-        S.trqOA[i] = ttrq / npt * area; S.hflx[i] = th / npt;
-      }
+      else { S.fxOA[i] = fx; S.fyOA[i] = fy; S.trqOA[i] = trq; S.hflx[i] = hf; }
     }
   }
 }
