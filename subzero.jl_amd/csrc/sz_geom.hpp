@@ -138,17 +138,18 @@ SZ_DEV double fx_join(long long hi, long long lo, int e) {
   const long long H = hi + (lo >> 40), L = lo & ((1ll << 40) - 1);      // (floor and a non-negative remainder: lo may be a negative sum)
   return ldexp((double)H + ldexp((double)L, -40), e - 52);
 }
-// word w (0..6) of what one interaction row {fx, fy, px, py, overlap} adds to the totals of a floe with centroid (cx, cy) on the grid given by
-// the floe's area, height and lever exponent; sign: +1 for the pair's first floe, -1 for the second (the mirrored row, collisions.jl:820-828)
-SZ_DEV void fx_word(int w, const double* row, double sign, double cx, double cy, int kexp, double area, double h, int eL, long long& hi, long long& lo, int& bad) {
-  const int eF = fx_force_exp(kexp, area, h);
+// word w (0..6) of what one interaction row {fx, fy, px, py, overlap} adds to the totals of a floe with centroid (cx, cy); sign: +1 for the pair's
+// first floe, -1 for the second (the mirrored row, collisions.jl:820-828).  eF, eA, eL: the floe's force, area and lever exponents (fx_force_exp,
+// fx_area_exp, fx_lever_exp -- formed once per item and side, not per row).  The seven words take ONE path: value and exponent are selected, the
+// split is evaluated once (the lanes of a group hold a word each; three branches here were three passes for every row and side).
+SZ_DEV void fx_word(int w, const double* row, double sign, double cx, double cy, int eF, int eA, int eL, long long& hi, long long& lo, int& bad) {
+  const bool lx = w == 2 || w == 4, ffx = w == 0 || w == 2 || w == 3;       // 2: (x - cx) fx   3: (y - cy) fx   4: (x - cx) fy   5: (y - cy) fy
+  const double f = (ffx ? row[0] : row[1]) * sign;
+  const double lever = (lx ? row[2] : row[3]) - (lx ? cx : cy);
+  const double v = w == 6 ? row[4] : w < 2 ? f : lever * f;
+  const int e = w == 6 ? eA : w < 2 ? eF : eF + eL;
   long long a = 0, b = 0;
-  if (w == 6) fx_split(row[4], fx_area_exp(area), a, b, bad);
-  else if (w < 2) fx_split(row[w] * sign, eF, a, b, bad);
-  else {
-    const bool lx = w == 2 || w == 4, ffx = w == 2 || w == 3;       // 2: (x - cx) fx   3: (y - cy) fx   4: (x - cx) fy   5: (y - cy) fy
-    fx_split(((lx ? row[2] : row[3]) - (lx ? cx : cy)) * ((ffx ? row[0] : row[1]) * sign), eF + eL, a, b, bad);
-  }
+  fx_split(v, e, a, b, bad);
   hi += a; lo += b;
 }
 

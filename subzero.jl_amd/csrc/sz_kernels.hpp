@@ -1761,6 +1761,14 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     STAMP(st, 22);
     const bool is_pair = it.is_pair;
     const int i = it.i, j = it.j, e = it.e;
+    // What phase C needs of the item -- its it_info index and the rows of its two floes (fixed-point totals) -- rides through the clips in ONE
+    // register, a different word in each of the group's first three lanes (every lane of a group holds the same item, so the lanes can share the
+    // work of remembering it).  Round 4, second half: phase C used to ask the work list for the two rows again (a hit in L2 -- but a vector LOAD
+    // late in a wavefront's life, behind the forcing wavefronts that have moved into the CU by then and keep its texture path busy with scattered
+    // lattice reads: the slowest wavefronts of a launch -- which set its length -- spent 52 k of their 180 k cycles in phase C, 4 k before the
+    // fixed-point totals: profiles/r04_wave_records*.txt).  Lane shuffles do not go through the texture path.
+    int carry = (gl == 0 ? it.info : gl == 1 ? i : j);
+    asm volatile("" : "+v"(carry));          // (opaque: the three words are not kept alive on their own beside it)
     const int na = it.na, nb = it.nb, ao = it.ao, bo = it.bo;
     if (have) {
       const int big = na > nb ? na : nb;
@@ -1978,6 +1986,8 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
 #endif
     }
     // ================= phase C: friction and the rows of the own item, in region order
+    const int gbase = (int)(threadIdx.x & 63) - gl;          // first lane of this group within its wavefront
+    const int c_info = __shfl(carry, gbase), c_i = __shfl(carry, gbase + 1), c_j = __shfl(carry, gbase + 2);
     if (have) {
       double* out = S.it_rows + (size_t)it.rows * ROWS_PER_ITEM * 5;
       // fixed-point totals (sz_geom.hpp): the rows are parked in region buffer 1 as well (every direction check of the wavefront is done: it
@@ -1994,14 +2004,15 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       if (fxon && ((nrows > 0 && !(flags & IT_RETRY)) || (flags & (IT_FUSE | IT_REMOVE)))) {
         // the item's two rows come from the work list again (a hit in L2: the entry was read when the item started) rather than being
         // held in two registers through the clips -- the kernel sits on its register budget, and nothing waits for these atomics
-        int ri, rj = -1;
-        if (is_pair) { const int4 wk = S.work[2 * (size_t)it.rows]; ri = wk.y; rj = wk.z; } else ri = S.el_floe[it.rows - S.capPairs];
+        const int ri = c_i, rj = is_pair ? c_j : -1;
         int glw = gl; asm volatile("" : "+v"(glw));          // (opaque: nothing lane-dependent of this block is hoisted out of the item loop and spilled)
         if (nrows > 0 && !(flags & IT_RETRY) && glw < 7) {          // lane w < 7: word w of what the item adds to floe i and to floe j
           long long qi = 0, li = 0, qj = 0, lj = 0; int bad = 0;
+          const int eFi = fx_force_exp(S.kexp, m.kin[KIN_AREA_I], m.kin[KIN_H_I]), eAi = fx_area_exp(m.kin[KIN_AREA_I]);
+          const int eFj = rj >= 0 ? fx_force_exp(S.kexp, m.kin[KIN_AREA_J], m.kin[KIN_H_J]) : 0, eAj = rj >= 0 ? fx_area_exp(m.kin[KIN_AREA_J]) : 0;
           for (int r = 0; r < nrows; r++) {
-            fx_word(glw, park + r * 5, 1.0, m.kin[KIN_I], m.kin[KIN_I + 1], S.kexp, m.kin[KIN_AREA_I], m.kin[KIN_H_I], m.eri, qi, li, bad);
-            if (rj >= 0) fx_word(glw, park + r * 5, -1.0, m.kin[KIN_J], m.kin[KIN_J + 1], S.kexp, m.kin[KIN_AREA_J], m.kin[KIN_H_J], m.erj, qj, lj, bad);
+            fx_word(glw, park + r * 5, 1.0, m.kin[KIN_I], m.kin[KIN_I + 1], eFi, eAi, m.eri, qi, li, bad);
+            if (rj >= 0) fx_word(glw, park + r * 5, -1.0, m.kin[KIN_J], m.kin[KIN_J + 1], eFj, eAj, m.erj, qj, lj, bad);
           }
           unsigned long long* const ai = (unsigned long long*)(S.facc + (size_t)ri * FX_WORDS);
           if (qi) atomicAdd(ai + glw, (unsigned long long)qi);
@@ -2024,7 +2035,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
         }
       }
       if (gl == 0) {
-        S.it_info[it.info] = make_int2(nrows | (flags << 8), it.rows);
+        S.it_info[c_info] = make_int2(nrows | (flags << 8), it.rows);
         if (flags & IT_FUSE) atomicAdd(&S.cnt[C_NFUSE], 1);
         if (!(flags & IT_RETRY)) {                           // counted by the variant that finishes the item
           if (is_pair) { m.acc16[0]++; m.acc[0] += (unsigned)(na + nb); m.acc[1] += (unsigned)nrows; } else { m.acc16[1]++; m.acc16[2] += (uint16_t)nrows; }
@@ -2041,6 +2052,10 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
    { long long now = clock64(); st.cC += now - st.tmark; st.tmark = now; }
    if ((dbg & 16) && !st.pass) { st.pass = 1; continue; }      // timing experiment: the same round again, now with a warm instruction cache
 #endif
+   // (a segment the first -- static -- round has covered hands out nothing more: no ticket.  The ticket is a RETURNING atomic, and it comes back
+   //  in order, behind the round's stores and the atomics of its fixed-point totals, through a texture path the forcing wavefronts of the launch's
+   //  tail keep busy: the slowest wavefronts of a one-round launch -- which set its length -- waited ~50 k cycles for a ticket that said "nothing")
+   if (useq && nbq * GPB >= limit) break;
    if (useq) {
      int tk = 0;
      if (threadIdx.x == 0) tk = atomicAdd(&S.wq[qk * 32], GPB);

@@ -39,3 +39,19 @@ print("phase A by live items:")
 for l in sorted(set(r[:, 3])):
     q = r[r[:, 3] == l]
     print(f"  live {l}: {len(q):5d} wavefronts  A mean {q[:,4].mean()/1e3:5.1f} k  max {q[:,4].max()/1e3:5.1f} k")
+# round 4: where the slowest wavefronts spend their time -- the launch lasts as long as its slowest wavefront
+order = np.argsort(-r[:, 0])
+rest = r[:, 4] - a1 - a2
+def row(name, sel):
+    q = r[sel]
+    print(f"  {name:28s} n={len(q):5d}  lifetime {q[:,0].mean()/1e3:6.1f} k | staging {a1[sel].mean()/1e3:5.1f}  contact clip {a2[sel].mean()/1e3:5.1f}  after the clip {rest[sel].mean()/1e3:5.1f}  checks (B) {q[:,5].mean()/1e3:5.1f}  rows (C) {q[:,6].mean()/1e3:4.1f}  | passes {q[:,1].mean():.2f} tasks {q[:,2].mean():.1f} live {q[:,3].mean():.1f}")
+print("phase split by lifetime rank (mean k cycles):")
+n = len(r)
+row("slowest 1 %", order[:max(1, n // 100)])
+row("slowest 5 %", order[:max(1, n // 20)])
+row("slowest 25 %", order[:max(1, n // 4)])
+row("middle half", order[n // 4:3 * n // 4])
+row("fastest 25 %", order[3 * n // 4:])
+print("percentiles (k cycles)   50%    90%    99%    max")
+for name, v in (("staging", a1), ("contact clip", a2), ("after the clip", rest), ("checks (B)", r[:, 5]), ("lifetime", r[:, 0])):
+    print(f"  {name:20s} {np.percentile(v,50)/1e3:6.1f} {np.percentile(v,90)/1e3:6.1f} {np.percentile(v,99)/1e3:6.1f} {v.max()/1e3:6.1f}")
