@@ -1732,6 +1732,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
   //  wavefronts one after the other, and a wavefront's stream is as long with 6 items as with 8)
   for (int t0 = rb * STRIDE; t0 < limit;) {
    unsigned long long todo = 1;
+   int tk_next = 0;
    if (SCAN) {
      const int tt = t0 + (int)threadIdx.x;
      bool want = false;
@@ -1986,6 +1987,10 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
 #endif
     }
     // ================= phase C: friction and the rows of the own item, in region order
+    // The ticket for the wavefront's NEXT round is drawn here, in front of phase C: every load of the round has long returned, so the answer is back
+    // while the rows are formed -- behind phase C it waits, in order, for the round's row stores and the atomics of its fixed-point totals (and a
+    // ticket drawn before the round's own loads makes THEM wait: measured in round 1).  SCAN rounds work several items off: the last one draws.
+    if (useq && !todo && nbq * GPB < limit && threadIdx.x == 0) tk_next = atomicAdd(&S.wq[qk * 32], GPB);
     const int gbase = (int)(threadIdx.x & 63) - gl;          // first lane of this group within its wavefront
     const int c_info = __shfl(carry, gbase), c_i = __shfl(carry, gbase + 1), c_j = __shfl(carry, gbase + 2);
     if (have) {
@@ -2056,11 +2061,8 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
    //  in order, behind the round's stores and the atomics of its fixed-point totals, through a texture path the forcing wavefronts of the launch's
    //  tail keep busy: the slowest wavefronts of a one-round launch -- which set its length -- waited ~50 k cycles for a ticket that said "nothing")
    if (useq && nbq * GPB >= limit) break;
-   if (useq) {
-     int tk = 0;
-     if (threadIdx.x == 0) tk = atomicAdd(&S.wq[qk * 32], GPB);
-     t0 = nbq * GPB + __shfl(tk, 0);
-   } else t0 += nbq * STRIDE;
+   if (useq) t0 = nbq * GPB + __shfl(tk_next, 0);
+   else t0 += nbq * STRIDE;
   }
   gsync();
   if (gl == 0 && m.err) atomicOr(&S.cnt[C_ERR], m.err);
