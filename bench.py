@@ -770,6 +770,29 @@ def main():
                                "note": "HIP events around the grouped send / receive on the library's communication stream, in the separate pass that event-times every class"}
         if args.rehearse_shared_gpu:
             out["data"] = "REHEARSAL: all ranks share GPU 0, transfers over gloo through the host -- not a measurement"
+        if world == 1 and not tiled and workload == "configs1" and coupling_dt == 1 and not args.two_way and not args.no_strong_reference:
+            # The line's `value` couples the floes to ocean and atmosphere in EVERY step (coupling_dt 1: the heaviest setting, and what rounds 1-3
+            # timed).  The reference's own default is CouplingSettings(Δt = 10) (process_settings.jl:134-135): the same field, the same steps, with
+            # the forcings evaluated every tenth step -- what a user who switches over with default settings would see.  Reported beside `value`,
+            # never instead of it.
+            try:
+                log("secondary leg: the reference's default coupling interval (every 10th step) ...")
+                w10 = fields.build_world(subzero_jl_amd.World(local), cfg); w10.set_precision(args.precision)
+                r10 = lambda n, t0: w10.run(n, t0, cfg["dt"], coupling_dt=10, stop_on_tags=False)
+                r10(args.relax_steps, 0); r10(args.warmup, args.relax_steps)
+                b10 = []; ts = args.relax_steps + args.warmup
+                for rep in range(nrep):
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    r10(args.steps, ts)
+                    torch.cuda.synchronize(); b10.append(time.perf_counter() - t1); ts += args.steps
+                m10 = float(np.median(b10))
+                out["reference_default_coupling_interval"] = {
+                    "coupling_dt": 10, "value": cfg["n_floes"] * args.steps / m10, "unit": "floe-steps/s", "ms_per_step": 1e3 * m10 / args.steps,
+                    "ms_per_step_min": 1e3 * min(b10) / args.steps, "steps": args.steps, "repeats": nrep,
+                    "note": "same field and steps as `value`, forcings every 10th step (the reference's CouplingSettings default, process_settings.jl:134-135); `value` couples every step"}
+                del w10
+            except Exception as e:      # noqa: BLE001
+                out["reference_default_coupling_interval"] = {"error": str(e)[:200]}
         if world == 1 and not tiled and workload == "configs1" and args.floes == 0 and args.total_floes == 0 and not args.no_strong_reference:
             # the N > 1 lines of this script time configs[2] (100 000 floes, strong scaling): the same field in ONE context on this GPU, through
             # the same regime, is the N = 1 point of THAT curve (this line's `value` is the metric's one-GPU configuration, configs[1])

@@ -33,8 +33,8 @@ namespace szg {
 // In-kernel phase stamps for the diagnostic build only (-DSZ_STAMPS): cycles per phase summed
 // over all groups.  The production build compiles them out.
 #ifdef SZ_STAMPS
-struct Stamps { long long t0, t0w, tmark, cA, cB, cC, cA1, cA2; long long* log; int n; bool on; int maxrows; int pass; int npass, ntask, nlive; };
-#define STAMP_INIT(st) do { (st).t0 = clock64(); (st).t0w = (st).t0; (st).maxrows = 0; (st).pass = 0; (st).npass = 0; (st).ntask = 0; (st).nlive = 0; (st).cA = (st).cB = (st).cC = (st).cA1 = (st).cA2 = 0; (st).tmark = (st).t0; (st).n = 0; (st).on = false; (st).log = nullptr; } while (0)
+struct Stamps { long long t0, t0w, tmark, cA, cB, cC, cA1, cA2, cP; long long* log; int n; bool on; int maxrows; int pass; int npass, ntask, nlive; };
+#define STAMP_INIT(st) do { (st).t0 = clock64(); (st).t0w = (st).t0; (st).maxrows = 0; (st).pass = 0; (st).npass = 0; (st).ntask = 0; (st).nlive = 0; (st).cA = (st).cB = (st).cC = (st).cA1 = (st).cA2 = 0; (st).cP = -1; (st).tmark = (st).t0; (st).n = 0; (st).on = false; (st).log = nullptr; } while (0)
 #define STAMP(st, k) do { if ((st).on && (st).n < 500) { (st).log[(st).n++] = ((long long)(k) << 48) | (clock64() - (st).t0); } } while (0)
 #else
 struct Stamps {};

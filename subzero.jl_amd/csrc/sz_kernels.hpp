@@ -1747,6 +1747,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     // ================= phase A: every lane group stages its own item and runs the contact clip
 #ifdef SZ_STAMPS
     st.tmark = clock64();
+    if (st.cP < 0) st.cP = st.tmark - st.t0w;          // (the wavefront's prologue: launch to its first item)
 #endif
     int t;
     if (SCAN) { t = t0 + __ffsll((long long)todo) - 1; todo &= todo - 1; }
@@ -2071,7 +2072,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
     // one set of atomics per wavefront, spread over ACC_SLOTS lines (same-address atomics serialise chip-wide)
     unsigned v[7];
     for (int k = 0; k < 7; k++) { v[k] = gl != 0 ? 0u : k == 0 ? m.acc16[0] : k == 1 ? m.acc[0] : k == 2 ? m.acc[1] : k == 3 ? m.acc16[1] : k == 4 ? m.acc16[2] : k == 5 ? m.acc16[3] : m.acc16[4]; for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d); }
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0 && !(dbg & 32)) {          // (SZ_DEBUG=32: without the work counters -- a timing experiment)
       unsigned long long* a = S.acc + (size_t)((bidx * (TPB / 64) + (threadIdx.x >> 6)) % ACC_SLOTS) * 8;
       for (int k = 0; k < 7; k++) if (v[k]) atomicAdd(a + 1 + k, (unsigned long long)v[k]);
       if (CLS == 0 && bidx == 0 && threadIdx.x == 0) atomicAdd(a, 1ull);
@@ -2093,7 +2094,7 @@ __global__ void __launch_bounds__(TPB, WPE) sz_k_narrow(State S, Params P, int d
       const unsigned long long slot = atomicAdd((unsigned long long*)&S.stamps[511], 1ull);
       if (slot < 8000) {
         long long* r = S.stamps + 512 + slot * 8;
-        r[0] = el; r[1] = st.npass; r[2] = st.ntask; r[3] = st.nlive; r[4] = st.cA; r[5] = st.cB; r[6] = st.cC; r[7] = mr | ((st.cA1 >> 8) << 8) | ((st.cA2 >> 8) << 36);
+        r[0] = el; r[1] = st.npass | ((st.cP > 0 ? st.cP >> 8 : 0) << 8); r[2] = st.ntask; r[3] = st.nlive; r[4] = st.cA; r[5] = st.cB; r[6] = st.cC; r[7] = mr | ((st.cA1 >> 8) << 8) | ((st.cA2 >> 8) << 36);
       }
     }
   }

@@ -23,6 +23,7 @@ nrec = int(min(out[511], 8000))
 r = out[512:512 + 8 * nrec].reshape(nrec, 8)
 r = r[(r[:, 4] + r[:, 5] > 0) & (r[:, 1] > 0) & (r[:, 4] < (1 << 40))]      # wavefronts that ran a round (a record of a wavefront without items holds no phase times)
 a1 = ((r[:, 7] >> 8) & ((1 << 28) - 1)) << 8; a2 = (r[:, 7] >> 36) << 8; r[:, 7] &= 255
+pro = (r[:, 1] >> 8) << 8; r[:, 1] &= 255          # cycles from the wavefront's start to its first item (prologue)
 print("phase A split, mean k cycles: staging %.1f  contact clip %.1f  after the clip (overlap tests, vertex matching, directions) %.1f" % (a1.mean() / 1e3, a2.mean() / 1e3, (r[:, 4] - a1 - a2).mean() / 1e3))
 heavy = r[:, 7] >= 2
 print("   ... of the wavefronts with a 2-row item: staging %.1f  clip %.1f  after %.1f ; the others: %.1f  %.1f  %.1f" % (a1[heavy].mean() / 1e3, a2[heavy].mean() / 1e3, (r[heavy, 4] - a1[heavy] - a2[heavy]).mean() / 1e3, a1[~heavy].mean() / 1e3, a2[~heavy].mean() / 1e3, (r[~heavy, 4] - a1[~heavy] - a2[~heavy]).mean() / 1e3))
@@ -44,7 +45,7 @@ order = np.argsort(-r[:, 0])
 rest = r[:, 4] - a1 - a2
 def row(name, sel):
     q = r[sel]
-    print(f"  {name:28s} n={len(q):5d}  lifetime {q[:,0].mean()/1e3:6.1f} k | staging {a1[sel].mean()/1e3:5.1f}  contact clip {a2[sel].mean()/1e3:5.1f}  after the clip {rest[sel].mean()/1e3:5.1f}  checks (B) {q[:,5].mean()/1e3:5.1f}  rows (C) {q[:,6].mean()/1e3:4.1f}  | passes {q[:,1].mean():.2f} tasks {q[:,2].mean():.1f} live {q[:,3].mean():.1f}")
+    print(f"  {name:28s} n={len(q):5d}  lifetime {q[:,0].mean()/1e3:6.1f} k | prologue {pro[sel].mean()/1e3:5.1f}  epilogue {(q[:,0]-pro[sel]-q[:,4]-q[:,5]-q[:,6]).mean()/1e3:5.1f} | staging {a1[sel].mean()/1e3:5.1f}  contact clip {a2[sel].mean()/1e3:5.1f}  after the clip {rest[sel].mean()/1e3:5.1f}  checks (B) {q[:,5].mean()/1e3:5.1f}  rows (C) {q[:,6].mean()/1e3:4.1f}  | passes {q[:,1].mean():.2f} tasks {q[:,2].mean():.1f} live {q[:,3].mean():.1f}")
 print("phase split by lifetime rank (mean k cycles):")
 n = len(r)
 row("slowest 1 %", order[:max(1, n // 100)])
