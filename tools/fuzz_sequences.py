@@ -16,10 +16,10 @@ from oracle import orc
 
 
 
-def run(nseeds=8, nops=10, rtol=1e-9, device=0, verbose=True, walls=False):
-  """returns the number of sequences that disagree"""
+def run(nseeds=8, nops=10, rtol=1e-9, device=0, verbose=True, walls=False, seed0=0):
+  """returns the number of sequences that disagree (seeds seed0 .. seed0 + nseeds - 1)"""
   bad = 0; t00 = time.time()
-  for seed in range(nseeds):
+  for seed in range(seed0, seed0 + nseeds):
       rng = np.random.default_rng(9000 + seed)
       n = int(rng.integers(150, 500))
       walled = walls and seed % 2 == 1          # every other field between collision walls with the strait's topography
@@ -84,4 +84,4 @@ def run(nseeds=8, nops=10, rtol=1e-9, device=0, verbose=True, walls=False):
 
 
 if __name__ == "__main__":
-    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 8, int(sys.argv[2]) if len(sys.argv) > 2 else 10, walls=len(sys.argv) > 3 and sys.argv[3] == "walls") else 0)
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 8, int(sys.argv[2]) if len(sys.argv) > 2 else 10, walls=len(sys.argv) > 3 and sys.argv[3] == "walls", seed0=int(sys.argv[4]) if len(sys.argv) > 4 else 0) else 0)
