@@ -1704,6 +1704,20 @@ int sz_calc_strain(sz_ctx* c) {
 }
 
 namespace {
+// a list of buffers to fill with one launch (sz_k_clear_many); bytes must be a multiple of 4, the value is a byte value as for memset
+struct Clears {
+  ClearList L{}; unsigned long long maxw = 0;
+  void add(void* p, size_t bytes, int byte_val = 0) {
+    const unsigned b = (unsigned)(byte_val & 0xff);
+    L.p[L.n] = (unsigned*)p; L.words[L.n] = bytes / 4; L.val[L.n] = b | (b << 8) | (b << 16) | (b << 24);
+    maxw = std::max(maxw, L.words[L.n]); L.n++;
+  }
+  void launch(sz_ctx* c) {
+    if (!L.n) return;
+    hipLaunchKernelGGL(sz_k_clear_many, dim3(grid_for((long long)maxw, 256, 2048)), dim3(256), 0, c->stream, L);
+    L.n = 0; maxw = 0;
+  }
+};
 // ---------------------------------------------------------------- pipelined batches (sz_pipeline.hpp)
 // the State of step parity q: everything that is double-buffered points at set q; rows of the step's makers at region q
 State pipe_state(sz_ctx* c, int q) {
@@ -1753,8 +1767,9 @@ int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling
   S0.facc = c->facc_buf; S0.kexp = force_scale_exp(c);
   bool lean = !c->retry_seen && !c->no_lean_narrow;
   auto leave = [&](int rc) { S0.retry_stop = 0; S0.ginline = 0; S0.famrec = 0; S0.step = 0; S0.crec = nullptr; S0.facc = nullptr; S0.goff = 0; S0.gcap = 0; S0.pipe = 0; S0.restart_on_tags = 0; c->acc_mode = 0; c->reduce_mode = 0; return rc; };
-  HIPCHK(c, hipMemsetAsync(c->facc_buf, 0, (size_t)FX_WORDS * S0.capM * sizeof(long long), c->stream));
-  HIPCHK(c, hipMemsetAsync(S0.cnt + C_FRCSTOP, 0, sizeof(int), c->stream));
+  Clears clr;          // (the batch's clears go out with the first prologue's, in one launch)
+  clr.add(c->facc_buf, (size_t)FX_WORDS * S0.capM * sizeof(long long));
+  clr.add(S0.cnt + C_FRCSTOP, sizeof(int));
   const int callid0 = c->callid; c->callid += nsteps;
   // ---- the prologue of a (sub-)batch that starts at step s: cells, records, ghosts and the neighbour search of that step, from the floes as they lie
   bool first_start = true;
@@ -1765,12 +1780,13 @@ int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling
     if (!first_start) c->grid_live = false;             // (a restart: the cells hold ghosts of a step that is started afresh)
     use_static_grid(c);                                 // cells[q] <- the parents (unless they are: the last batch's update binned them)
     const sz_ctx::PipeBuf& O = c->pb[1 - q];
-    HIPCHK(c, hipMemsetAsync(O.cell_cnt, 0, ((size_t)S0.capCells + 1) * sizeof(int), c->stream));
-    HIPCHK(c, hipMemsetAsync(O.cell_ovf, 0, ((size_t)S0.capCells + 1) * sizeof(int), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->pb[0].wq, 0, NSEG * 32 * sizeof(int), c->stream)); HIPCHK(c, hipMemsetAsync(c->pb[1].wq, 0, NSEG * 32 * sizeof(int), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->pb[0].ngh, 0, (size_t)S0.capM * sizeof(int), c->stream));          // (no links: a restart after a tag comes with those GEO made for a step that is now started afresh)
-    HIPCHK(c, hipMemsetAsync(c->pb[1].ngh, 0, (size_t)S0.capM * sizeof(int), c->stream));
-    HIPCHK(c, hipMemsetAsync(S0.galloc, 0, 32 * sizeof(unsigned long long), c->stream));
+    clr.add(O.cell_cnt, ((size_t)S0.capCells + 1) * sizeof(int));
+    clr.add(O.cell_ovf, ((size_t)S0.capCells + 1) * sizeof(int));
+    clr.add(c->pb[0].wq, NSEG * 32 * sizeof(int)); clr.add(c->pb[1].wq, NSEG * 32 * sizeof(int));
+    clr.add(c->pb[0].ngh, (size_t)S0.capM * sizeof(int));          // (no links: a restart after a tag comes with those GEO made for a step that is now started afresh)
+    clr.add(c->pb[1].ngh, (size_t)S0.capM * sizeof(int));
+    clr.add(S0.galloc, 32 * sizeof(unsigned long long));
+    clr.launch(c);
     // the records of both sets from the columns (the static quads of the twin; its geometry quads are GEO's) -- unless the last batch left them current
     if (!(first_start && c->crec_current))
       for (int b = 0; b < 2; b++) { State T = pipe_state(c, b); T.step = 0; hipLaunchKernelGGL(sz_k_crec_seed, dim3(grid_for(N, 256)), dim3(256), 0, c->stream, T, N); }
@@ -1954,8 +1970,10 @@ int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling
     // (the links of the last step are set qlast's; the context's own set is par(done)'s: sz_k_remove_ghosts saves and clears what it is given)
     State T = c->S; T.gh = R.gh; T.ngh = R.ngh; T.step = 0; T.retry_stop = 0;
     hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(S0.capM, 256)), dim3(256), 0, c->stream, T, 0);
-    HIPCHK(c, hipMemsetAsync(c->pb[1 - qlast].ngh, 0, (size_t)S0.capM * sizeof(int), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->pb[1 - qlast].gh, 0xff, (size_t)MAX_GHOSTS * S0.capM * sizeof(int), c->stream));
+    Clears tail;
+    tail.add(c->pb[1 - qlast].ngh, (size_t)S0.capM * sizeof(int));
+    tail.add(c->pb[1 - qlast].gh, (size_t)MAX_GHOSTS * S0.capM * sizeof(int), 0xff);
+    tail.launch(c);
   }
   {
     const int keepG = h[C_NGHOSTS];
@@ -2042,7 +2060,7 @@ int sz_step(sz_ctx* c, int32_t nsteps, int32_t tstep0, int32_t dt, int32_t coupl
   const bool rfree = facc_on && !c->no_reduce_free && sg && (gi || !periodic) && c->fused_move && c->max_ring <= MV_RING && !c->any_moving;
   c->S.facc = facc_on ? c->facc_buf : nullptr; c->S.kexp = force_scale_exp(c);
   c->reduce_mode = !facc_on ? 0 : rfree ? 2 : 1;
-  if (facc_on) {
+  if (facc_on && !pipe) {          // (a pipelined batch clears them with the rest of its prologue: one launch)
     HIPCHK(c, hipMemsetAsync(c->facc_buf, 0, (size_t)FX_WORDS * c->S.capM * sizeof(long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->S.cnt + C_FRCSTOP, 0, sizeof(int), c->stream));
   }

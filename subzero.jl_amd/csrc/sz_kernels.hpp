@@ -178,6 +178,17 @@ __global__ void __launch_bounds__(SCAN_B) sz_k_scan_one(const int* in, int* out,
 }
 
 // ============================================================================ small utilities
+// several buffers filled in ONE launch (words of 4 bytes, a value each): a batch of resident steps starts and ends with a dozen small clears --
+// counters, queue heads, cell counts, ghost links, the fixed-point totals -- and a hipMemsetAsync apiece is a launch apiece (~16 of them, 7 us
+// apart, in front of every batch: a tenth of a 20-step batch)
+constexpr int CLEAR_MAX = 12;
+struct ClearList { unsigned* p[CLEAR_MAX]; unsigned long long words[CLEAR_MAX]; unsigned val[CLEAR_MAX]; int n; };
+__global__ void __launch_bounds__(256) sz_k_clear_many(ClearList L) {
+  for (int e = 0; e < L.n; e++) {
+    unsigned* const p = L.p[e]; const unsigned long long n = L.words[e]; const unsigned v = L.val[e];
+    for (unsigned long long q = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; q < n; q += (unsigned long long)gridDim.x * blockDim.x) p[q] = v;
+  }
+}
 __global__ void sz_k_zero_int(int* p, const int* cnt, int ci, int add) {
   int n = (ci >= 0 ? cnt[ci] : 0) + add;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
