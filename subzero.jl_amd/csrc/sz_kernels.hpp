@@ -3236,14 +3236,29 @@ __global__ void __launch_bounds__(MOVE ? 128 : 256) sz_k_integrate(State S, Para
         const unsigned long long hits = halo_hits(PK.boxes, PK.nranks, PK.me, PK.Lx, PK.Ly, PK.per_x, PK.per_y, fx, fy);
         const int lane = threadIdx.x & 63;
         int* run = PK.counts + 64;
+        // Lane d draws the wavefront's slots of destination d: ALL destinations with ONE atomic instruction and one wait (nranks <= 64 lanes) --
+        // a loop of returning atomics, one per destination the wavefront's floes reach, was as many dependent round trips (a corner tile's
+        // wavefronts reach three to eight ranks).  Which lane asks changes nothing about the slots: they are handed out by the running totals.
+        // (a wavefront with idle lanes -- the last one of the launch -- asks destination by destination, through its first lane that has a hit)
+        const bool full = __ballot(true) == ~0ull;
+        int mybase = 0;
+        if (full) {
+          int mycount = 0;
+          for (int d = 0; d < PK.nranks; d++) { const int cnt_d = __popcll(__ballot((hits >> d) & 1ull)); if (lane == d) mycount = cnt_d; }
+          if (mycount > 0) mybase = atomicAdd(&run[lane], mycount);
+        }
         for (int d = 0; d < PK.nranks; d++) {
           const bool mine = (hits >> d) & 1ull;
           const unsigned long long m = __ballot(mine);
           if (!m) continue;
-          const int leader = __ffsll((long long)m) - 1;
-          int base = 0;
-          if (lane == leader) base = atomicAdd(&run[d], __popcll(m));
-          base = __shfl(base, leader);
+          int base;
+          if (full) base = __shfl(mybase, d);
+          else {
+            const int leader = __ffsll((long long)m) - 1;
+            base = 0;
+            if (lane == leader) base = atomicAdd(&run[d], __popcll(m));
+            base = __shfl(base, leader);
+          }
           if (mine) {
             const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
             if (slot >= (PK.dcap ? PK.dcap[d] : PK.cap) || n > halo_ring_of(S)) atomicOr(&S.cnt[C_ERR], n > halo_ring_of(S) ? ERR_CAP_RING : ERR_CAP_FLOES);
