@@ -1706,8 +1706,10 @@ int sz_calc_strain(sz_ctx* c) {
 namespace {
 // a list of buffers to fill with one launch (sz_k_clear_many); bytes must be a multiple of 4, the value is a byte value as for memset
 struct Clears {
-  ClearList L{}; unsigned long long maxw = 0;
+  ClearList L{}; unsigned long long maxw = 0; sz_ctx* ctx;
+  explicit Clears(sz_ctx* c) : ctx(c) {}
   void add(void* p, size_t bytes, int byte_val = 0) {
+    if (L.n == CLEAR_MAX) launch(ctx);          // (a full list goes out; the order of the clears among themselves does not matter)
     const unsigned b = (unsigned)(byte_val & 0xff);
     L.p[L.n] = (unsigned*)p; L.words[L.n] = bytes / 4; L.val[L.n] = b | (b << 8) | (b << 16) | (b << 24);
     maxw = std::max(maxw, L.words[L.n]); L.n++;
@@ -1767,7 +1769,7 @@ int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling
   S0.facc = c->facc_buf; S0.kexp = force_scale_exp(c);
   bool lean = !c->retry_seen && !c->no_lean_narrow;
   auto leave = [&](int rc) { S0.retry_stop = 0; S0.ginline = 0; S0.famrec = 0; S0.step = 0; S0.crec = nullptr; S0.facc = nullptr; S0.goff = 0; S0.gcap = 0; S0.pipe = 0; S0.restart_on_tags = 0; c->acc_mode = 0; c->reduce_mode = 0; return rc; };
-  Clears clr;          // (the batch's clears go out with the first prologue's, in one launch)
+  Clears clr(c);          // (the batch's clears go out with the first prologue's, in one launch)
   clr.add(c->facc_buf, (size_t)FX_WORDS * S0.capM * sizeof(long long));
   clr.add(S0.cnt + C_FRCSTOP, sizeof(int));
   const int callid0 = c->callid; c->callid += nsteps;
@@ -1970,7 +1972,7 @@ int step_batch_pipelined(sz_ctx* c, int nsteps, int tstep0, int dt, int coupling
     // (the links of the last step are set qlast's; the context's own set is par(done)'s: sz_k_remove_ghosts saves and clears what it is given)
     State T = c->S; T.gh = R.gh; T.ngh = R.ngh; T.step = 0; T.retry_stop = 0;
     hipLaunchKernelGGL(sz_k_remove_ghosts, dim3(grid_for(S0.capM, 256)), dim3(256), 0, c->stream, T, 0);
-    Clears tail;
+    Clears tail(c);
     tail.add(c->pb[1 - qlast].ngh, (size_t)S0.capM * sizeof(int));
     tail.add(c->pb[1 - qlast].gh, (size_t)MAX_GHOSTS * S0.capM * sizeof(int), 0xff);
     tail.launch(c);
